@@ -1,0 +1,125 @@
+"""ctypes binding of libbotlab_hip.so (include/botlab_hip.h).  Loading fails loudly when the HIP library has not
+been built: there is no CPU fallback anywhere in this package."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libbotlab_hip.so")
+
+
+class Pose(C.Structure):
+    """lcmtypes/pose_xyt_t.lcm (24 bytes)."""
+    _fields_ = [("utime", C.c_int64), ("x", C.c_float), ("y", C.c_float), ("theta", C.c_float)]
+
+    def __repr__(self):
+        return f"Pose(utime={self.utime}, x={self.x!r}, y={self.y!r}, theta={self.theta!r})"
+
+
+class Particle(C.Structure):
+    """lcmtypes/particle_t.lcm (56 bytes)."""
+    _fields_ = [("pose", Pose), ("parent_pose", Pose), ("weight", C.c_double)]
+
+
+class Lidar(C.Structure):
+    """lcmtypes/lidar_t.lcm, arrays as host pointers."""
+    _fields_ = [("utime", C.c_int64), ("num_ranges", C.c_int32), ("ranges", C.POINTER(C.c_float)),
+                ("thetas", C.POINTER(C.c_float)), ("times", C.POINTER(C.c_int64)),
+                ("intensities", C.POINTER(C.c_float))]
+
+
+class SearchParams(C.Structure):
+    """src/planning/astar.hpp:15-27."""
+    _fields_ = [("minDistanceToObstacle", C.c_double), ("maxDistanceWithCost", C.c_double),
+                ("distanceCostExponent", C.c_double)]
+
+
+assert C.sizeof(Pose) == 24 and C.sizeof(Particle) == 56
+
+BL_K_MCL_MAIN, BL_K_MCL_SCAN, BL_K_MAP, BL_K_DIST, BL_K_ASTAR = range(5)
+BL_OK, BL_ERR_HIP, BL_ERR_ARG, BL_ERR_CAPACITY, BL_ERR_STATE = range(5)
+
+_vp = C.c_void_p
+_P = C.POINTER
+
+# name -> (restype, argtypes); every symbol include/botlab_hip.h declares
+SIGNATURES = {
+    "bl_last_error": (C.c_char_p, []),
+    "bl_version": (C.c_char_p, []),
+    "bl_ctx_create": (C.c_int, [C.c_int, _vp, _P(_vp)]),
+    "bl_ctx_destroy": (None, [_vp]),
+    "bl_ctx_sync": (C.c_int, [_vp]),
+    "bl_ctx_timing_enable": (C.c_int, [_vp, C.c_int]),
+    "bl_ctx_timing_get": (C.c_int, [_vp, C.c_int, _P(C.c_double), _P(C.c_int64)]),
+    "bl_ctx_timing_reset": (C.c_int, [_vp]),
+    "bl_grid_create": (C.c_int, [_vp, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, _P(_vp)]),
+    "bl_grid_destroy": (None, [_vp]),
+    "bl_grid_upload": (C.c_int, [_vp, _vp]),
+    "bl_grid_download": (C.c_int, [_vp, _vp]),
+    "bl_grid_reset": (C.c_int, [_vp]),
+    "bl_grid_set_frame": (C.c_int, [_vp, C.c_float, C.c_float, C.c_float, C.c_float]),
+    "bl_grid_copy": (C.c_int, [_vp, _vp]),
+    "bl_grid_device_ptr": (_vp, [_vp]),
+    "bl_grid_shape": (C.c_int, [_vp, _P(C.c_int), _P(C.c_int)]),
+    "bl_mapping_create": (C.c_int, [_vp, C.c_float, C.c_int8, C.c_int8, _P(_vp)]),
+    "bl_mapping_destroy": (None, [_vp]),
+    "bl_mapping_update": (C.c_int, [_vp, _P(Lidar), _P(Pose), _vp]),
+    "bl_mapping_update_dev_pose": (C.c_int, [_vp, _P(Lidar), _vp, C.c_int64, _vp]),
+    "bl_pf_create": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _P(_vp)]),
+    "bl_pf_destroy": (None, [_vp]),
+    "bl_pf_set_exchange_buffers": (C.c_int, [_vp, _vp, _vp, _vp]),
+    "bl_pf_exchange_rec_ptr": (_vp, [_vp]),
+    "bl_pf_exchange_sums_ptr": (_vp, [_vp]),
+    "bl_pf_init_at_pose": (C.c_int, [_vp, _P(Pose), C.c_uint64]),
+    "bl_pf_set_particles": (C.c_int, [_vp, _vp, _vp]),
+    "bl_pf_get_particles": (C.c_int, [_vp, _vp]),
+    "bl_pf_set_noise_seed": (C.c_int, [_vp, C.c_uint64]),
+    "bl_pf_update": (C.c_int, [_vp, _P(Pose), _P(Lidar), _vp, C.c_int, _vp, _P(Pose)]),
+    "bl_pf_update_begin": (C.c_int, [_vp, _P(Pose), _P(Lidar), _vp, C.c_int, _vp, _P(C.c_int)]),
+    "bl_pf_update_end": (C.c_int, [_vp, _P(Pose)]),
+    "bl_pf_update_action_only": (C.c_int, [_vp, _P(Pose), _vp, _P(Pose)]),
+    "bl_pf_pose_estimate": (C.c_int, [_vp, _P(Pose)]),
+    "bl_pf_pose_device_ptr": (_vp, [_vp]),
+    "bl_pf_debug_last": (C.c_int, [_vp, _vp, _vp]),
+    "bl_dist_create": (C.c_int, [_vp, _P(_vp)]),
+    "bl_dist_destroy": (None, [_vp]),
+    "bl_dist_set_distances": (C.c_int, [_vp, _vp]),
+    "bl_dist_download": (C.c_int, [_vp, _vp]),
+    "bl_dist_shape": (C.c_int, [_vp, _P(C.c_int), _P(C.c_int)]),
+    "bl_dist_frame": (C.c_int, [_vp, _P(C.c_float), _P(C.c_float), _P(C.c_float), _P(C.c_float)]),
+    "bl_dist_device_ptr": (_vp, [_vp]),
+    "bl_astar_search": (C.c_int, [_vp, _vp, _P(Pose), _P(Pose), _P(SearchParams), _vp, C.c_int, _P(C.c_int),
+                                  _P(C.c_int64)]),
+    "bl_astar_set_open_capacity": (C.c_int, [_vp, C.c_int64]),
+    "bl_astar_search_async": (C.c_int, [_vp, _vp, _P(Pose), _P(Pose), _P(SearchParams)]),
+    "bl_astar_search_result": (C.c_int, [_vp, _vp, C.c_int, _P(C.c_int), _P(C.c_int64)]),
+}
+
+_lib = None
+
+
+class BotlabHipError(RuntimeError):
+    pass
+
+
+def load():
+    """Returns the loaded library with argtypes set; raises if the extension is missing (no fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise BotlabHipError(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950). botlab_amd has no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError here = header/library mismatch
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc):
+    if rc != 0:
+        msg = load().bl_last_error()
+        raise BotlabHipError(f"botlab_hip call failed (status {rc}): {msg.decode() if msg else ''}")

@@ -1,0 +1,306 @@
+// bl_ctx.hip -- context, error reporting, kernel timers, scan staging and the device OccupancyGrid.
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "bl_internal.h"
+
+static thread_local char g_err[512] = "";
+
+void bl_set_error(const char* fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+extern "C" const char* bl_last_error(void) { return g_err; }
+extern "C" const char* bl_version(void) { return "botlab_hip 0.1 (gfx950)"; }
+
+void bl_astar_free(bl_ctx* ctx);   // bl_planning.hip
+
+extern "C" int bl_ctx_create(int device, void* stream, bl_ctx** out)
+{
+    BL_CHECK_ARG(out != nullptr);
+    int ndev = 0;
+    BL_HIP(hipGetDeviceCount(&ndev));
+    if (device < 0 || device >= ndev) {
+        bl_set_error("device %d out of range (%d visible)", device, ndev);
+        return BL_ERR_ARG;
+    }
+    BL_HIP(hipSetDevice(device));
+    bl_ctx* c = new bl_ctx();
+    c->device = device;
+    if (stream) {
+        c->stream = (hipStream_t)stream;
+        c->own_stream = false;
+    } else {
+        hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+        if (e != hipSuccess) {
+            bl_set_error("hipStreamCreate failed: %s", hipGetErrorString(e));
+            delete c;
+            return BL_ERR_HIP;
+        }
+        c->own_stream = true;
+    }
+    *out = c;
+    return BL_OK;
+}
+
+extern "C" void bl_ctx_destroy(bl_ctx* ctx)
+{
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    bl_astar_free(ctx);
+    for (int i = 0; i < BL_K_COUNT; ++i) {
+        for (auto& p : ctx->timers[i].pending) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
+        for (auto& p : ctx->timers[i].pool) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
+    }
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+extern "C" int bl_ctx_sync(bl_ctx* ctx)
+{
+    BL_CHECK_ARG(ctx != nullptr);
+    BL_HIP(hipStreamSynchronize(ctx->stream));
+    return BL_OK;
+}
+
+// ---------------------------------------------------------------- timers
+extern "C" int bl_ctx_timing_enable(bl_ctx* ctx, int on)
+{
+    BL_CHECK_ARG(ctx != nullptr);
+    ctx->timing = on != 0;
+    return BL_OK;
+}
+
+int bl_timer_begin(bl_ctx* ctx, int id, hipEvent_t* a, hipEvent_t* b)
+{
+    *a = nullptr; *b = nullptr;
+    if (!ctx->timing) return BL_OK;
+    bl_timer& t = ctx->timers[id];
+    if (!t.pool.empty()) {
+        *a = t.pool.back().first; *b = t.pool.back().second;
+        t.pool.pop_back();
+    } else {
+        BL_HIP(hipEventCreate(a));
+        BL_HIP(hipEventCreate(b));
+    }
+    BL_HIP(hipEventRecord(*a, ctx->stream));
+    return BL_OK;
+}
+
+int bl_timer_end(bl_ctx* ctx, int id, hipEvent_t a, hipEvent_t b)
+{
+    if (!ctx->timing || !a) return BL_OK;
+    BL_HIP(hipEventRecord(b, ctx->stream));
+    ctx->timers[id].pending.emplace_back(a, b);
+    return BL_OK;
+}
+
+static int timer_drain(bl_ctx* ctx, int id)
+{
+    bl_timer& t = ctx->timers[id];
+    for (auto& p : t.pending) {
+        BL_HIP(hipEventSynchronize(p.second));
+        float ms = 0;
+        BL_HIP(hipEventElapsedTime(&ms, p.first, p.second));
+        t.total_ms += ms;
+        t.launches += 1;
+        t.pool.push_back(p);
+    }
+    t.pending.clear();
+    return BL_OK;
+}
+
+extern "C" int bl_ctx_timing_get(bl_ctx* ctx, int kernel_id, double* total_ms, int64_t* launches)
+{
+    BL_CHECK_ARG(ctx != nullptr && kernel_id >= 0 && kernel_id < BL_K_COUNT);
+    int rc = timer_drain(ctx, kernel_id);
+    if (rc) return rc;
+    if (total_ms) *total_ms = ctx->timers[kernel_id].total_ms;
+    if (launches) *launches = ctx->timers[kernel_id].launches;
+    return BL_OK;
+}
+
+extern "C" int bl_ctx_timing_reset(bl_ctx* ctx)
+{
+    BL_CHECK_ARG(ctx != nullptr);
+    for (int i = 0; i < BL_K_COUNT; ++i) {
+        int rc = timer_drain(ctx, i);
+        if (rc) return rc;
+        ctx->timers[i].total_ms = 0;
+        ctx->timers[i].launches = 0;
+    }
+    return BL_OK;
+}
+
+// ---------------------------------------------------------------- scan staging
+// One lidar_t (lcmtypes/lidar_t.lcm) is packed [ranges | thetas | ratio] into a pinned slot and copied with one
+// async H2D.  ratio[n] = (double)(times[n] - begin) / (double)(end - begin) is the interpolateRatio of
+// interpolate_pose_by_time (src/common/interpolation.hpp:35) for the (begin, end) pose pair of this call; it is the
+// same for every particle / every ray origin, so it is formed once on the host.
+static const int kScanSlots = 16;
+
+struct bl_scan_slots {
+    void* host[kScanSlots];
+    hipEvent_t done[kScanSlots];
+    bool used[kScanSlots];
+    int next;
+};
+
+int bl_scan_upload(bl_ctx* ctx, bl_scan_dev* sd, const bl_lidar_t* scan, int64_t begin_utime, int64_t end_utime,
+                   int* num_rays)
+{
+    BL_CHECK_ARG(scan != nullptr && scan->num_ranges >= 0);
+    int R = scan->num_ranges;
+    *num_rays = R;
+    if (R == 0) return BL_OK;
+    BL_CHECK_ARG(scan->ranges && scan->thetas && scan->times);
+    size_t per = (size_t)R * (4 + 4 + 8);
+    if (R > sd->capacity) {
+        int cap = R < 512 ? 512 : R;
+        bl_scan_free(sd);
+        size_t bytes = (size_t)cap * (4 + 4 + 8);
+        char* d = nullptr;
+        BL_HIP(hipMalloc((void**)&d, bytes));
+        sd->capacity = cap;
+        sd->ratio = (double*)d;                                  // 8-byte aligned part first
+        sd->ranges = (float*)(d + (size_t)cap * 8);
+        sd->thetas = (float*)(d + (size_t)cap * 12);
+        bl_scan_slots* sl = new bl_scan_slots();
+        memset(sl, 0, sizeof(*sl));
+        sd->staging_bytes = bytes;
+        for (int i = 0; i < kScanSlots; ++i) {
+            BL_HIP(hipHostMalloc(&sl->host[i], bytes, hipHostMallocDefault));
+            BL_HIP(hipEventCreateWithFlags(&sl->done[i], hipEventDisableTiming));
+        }
+        sd->staging = sl;
+    }
+    bl_scan_slots* sl = (bl_scan_slots*)sd->staging;
+    int s = sl->next;
+    sl->next = (s + 1) % kScanSlots;
+    if (sl->used[s]) BL_HIP(hipEventSynchronize(sl->done[s]));
+    char* h = (char*)sl->host[s];
+    size_t cap = (size_t)sd->capacity;
+    double* hr = (double*)h;
+    float* hrange = (float*)(h + cap * 8);
+    float* htheta = (float*)(h + cap * 12);
+    memcpy(hrange, scan->ranges, (size_t)R * 4);
+    memcpy(htheta, scan->thetas, (size_t)R * 4);
+    if (begin_utime != end_utime) {
+        double den = (double)(end_utime - begin_utime);
+        for (int n = 0; n < R; ++n) hr[n] = (double)(scan->times[n] - begin_utime) / den;
+    } else {
+        for (int n = 0; n < R; ++n) hr[n] = 0.0;
+    }
+    (void)per;
+    // host slot and device block share one layout, so the whole block goes over in a single copy (8 KB at 512 rays)
+    BL_HIP(hipMemcpyAsync(sd->ratio, h, sd->staging_bytes, hipMemcpyHostToDevice, ctx->stream));
+    BL_HIP(hipEventRecord(sl->done[s], ctx->stream));
+    sl->used[s] = true;
+    return BL_OK;
+}
+
+void bl_scan_free(bl_scan_dev* sd)
+{
+    if (sd->ratio) (void)hipFree(sd->ratio);
+    if (sd->staging) {
+        bl_scan_slots* sl = (bl_scan_slots*)sd->staging;
+        for (int i = 0; i < kScanSlots; ++i) {
+            if (sl->used[i]) (void)hipEventSynchronize(sl->done[i]);
+            if (sl->host[i]) (void)hipHostFree(sl->host[i]);
+            if (sl->done[i]) (void)hipEventDestroy(sl->done[i]);
+        }
+        delete sl;
+    }
+    sd->capacity = 0;
+    sd->ratio = nullptr; sd->ranges = nullptr; sd->thetas = nullptr; sd->staging = nullptr;
+}
+
+// ---------------------------------------------------------------- OccupancyGrid (src/slam/occupancy_grid.cpp)
+extern "C" int bl_grid_create(bl_ctx* ctx, int width, int height, float meters_per_cell, float cells_per_meter,
+                              float origin_x, float origin_y, bl_grid** out)
+{
+    BL_CHECK_ARG(ctx != nullptr && out != nullptr);
+    BL_CHECK_ARG(width > 0 && height > 0 && (int64_t)width * height < (1ll << 31));
+    BL_HIP(hipSetDevice(ctx->device));
+    bl_grid* g = new bl_grid();
+    g->ctx = ctx;
+    g->frame.width = width; g->frame.height = height;
+    g->frame.mpc = meters_per_cell; g->frame.cpm = cells_per_meter;
+    g->frame.ox = origin_x; g->frame.oy = origin_y;
+    hipError_t e = hipMalloc((void**)&g->cells, (size_t)width * height);
+    if (e != hipSuccess) {
+        bl_set_error("hipMalloc(grid %dx%d) failed: %s", width, height, hipGetErrorString(e));
+        delete g;
+        return BL_ERR_HIP;
+    }
+    BL_HIP(hipMemsetAsync(g->cells, 0, (size_t)width * height, ctx->stream));
+    *out = g;
+    return BL_OK;
+}
+
+extern "C" void bl_grid_destroy(bl_grid* g)
+{
+    if (!g) return;
+    (void)hipStreamSynchronize(g->ctx->stream);
+    (void)hipFree(g->cells);
+    delete g;
+}
+
+extern "C" int bl_grid_upload(bl_grid* g, const int8_t* cells)
+{
+    BL_CHECK_ARG(g != nullptr && cells != nullptr);
+    size_t n = (size_t)g->frame.width * g->frame.height;
+    BL_HIP(hipMemcpyAsync(g->cells, cells, n, hipMemcpyHostToDevice, g->ctx->stream));
+    BL_HIP(hipStreamSynchronize(g->ctx->stream));    // the host buffer is caller-owned and may be reused at once
+    return BL_OK;
+}
+
+extern "C" int bl_grid_download(bl_grid* g, int8_t* cells)
+{
+    BL_CHECK_ARG(g != nullptr && cells != nullptr);
+    size_t n = (size_t)g->frame.width * g->frame.height;
+    BL_HIP(hipMemcpyAsync(cells, g->cells, n, hipMemcpyDeviceToHost, g->ctx->stream));
+    BL_HIP(hipStreamSynchronize(g->ctx->stream));
+    return BL_OK;
+}
+
+extern "C" int bl_grid_reset(bl_grid* g)
+{
+    BL_CHECK_ARG(g != nullptr);
+    BL_HIP(hipMemsetAsync(g->cells, 0, (size_t)g->frame.width * g->frame.height, g->ctx->stream));
+    return BL_OK;
+}
+
+extern "C" int bl_grid_set_frame(bl_grid* g, float meters_per_cell, float cells_per_meter, float origin_x, float origin_y)
+{
+    BL_CHECK_ARG(g != nullptr);
+    g->frame.mpc = meters_per_cell; g->frame.cpm = cells_per_meter;
+    g->frame.ox = origin_x; g->frame.oy = origin_y;
+    return BL_OK;
+}
+
+extern "C" int bl_grid_copy(bl_grid* dst, const bl_grid* src)
+{
+    BL_CHECK_ARG(dst != nullptr && src != nullptr);
+    BL_CHECK_ARG(dst->frame.width == src->frame.width && dst->frame.height == src->frame.height);
+    dst->frame = src->frame;
+    BL_HIP(hipMemcpyAsync(dst->cells, src->cells, (size_t)src->frame.width * src->frame.height,
+                          hipMemcpyDeviceToDevice, dst->ctx->stream));
+    return BL_OK;
+}
+
+extern "C" void* bl_grid_device_ptr(bl_grid* g) { return g ? (void*)g->cells : nullptr; }
+
+extern "C" int bl_grid_shape(const bl_grid* g, int* width, int* height)
+{
+    BL_CHECK_ARG(g != nullptr);
+    if (width) *width = g->frame.width;
+    if (height) *height = g->frame.height;
+    return BL_OK;
+}

@@ -1,0 +1,273 @@
+// bl_mapping.hip -- Mapping::updateMap (src/slam/mapping.cpp:17-127) as one gfx950 workgroup.
+//
+// Reference semantics: pass 1 adds hitOdds (saturating at 127) at the end cell of every ray with range <= max laser
+// distance; pass 2 walks the reference's Bresenham variant from the truncated start cell to the end cell (end cell
+// excluded) subtracting missOdds (saturating at -128).  Because every pass-1 update precedes every pass-2 update and
+// both saturate monotonically, a cell that is the end of H rays and is crossed by M rays ends at
+//     v' = max(-128, min(127, v + hit*H) - miss*M)
+// which is order-independent.  The kernel counts H per end cell (rays are few: a leader thread per distinct end
+// cell) and M per crossed cell in an LDS window (uint16 counters), then applies the closed form with one owner
+// thread per cell -- no global atomics, bit-exact int8 results.
+//
+// Launch shape: ONE workgroup of 1024 threads.  The whole update touches ~20 KB (290 rays x <=142 cells @5 cm / 5 m);
+// it is latency-bound, not bandwidth-bound, and a single workgroup keeps every phase boundary a __syncthreads().
+// The LDS window is the bounding box of all ray cells clipped to the grid; if it exceeds the LDS budget it is
+// processed in horizontal strips (each strip re-walks the rays), so any resolution / laser range is handled.
+#include "bl_internal.h"
+
+#define MAP_THREADS 1024
+#define MAP_LDS_COUNTERS (72 * 1024)         // uint16 counters -> 144 KB of the 160 KB LDS
+#define MAP_MAX_RAYS 8192
+#define MAP_CELL_LIMIT (1 << 24)             // |cell coordinate| bound for a ray to be traced (rejects NaN/inf geometry)
+
+struct bl_mapping {
+    bl_ctx* ctx;
+    float max_laser;
+    int hit, miss;
+    bool initialized;
+    int64_t prev_utime;
+    bl_pose_xyt_t* d_prev;      // previousPose_ (device)
+    int4* d_rays;               // scratch: (x0, y0, x1, y1) per ray
+    int ray_capacity;
+    bl_scan_dev scan;
+};
+
+struct map_args {
+    int8_t* cells;
+    bl_frame frame;
+    const float* ranges;
+    const float* thetas;
+    const double* ratio;
+    int R;
+    bl_pose_xyt_t* prev;            // device previousPose_
+    const bl_pose_xyt_t* cur_dev;   // device pose of this update, or null
+    bl_pose_xyt_t cur_host;         // pose of this update when cur_dev is null
+    int64_t cur_utime;              // utime to record with the pose
+    int interp;                     // prev.utime != cur.utime
+    int apply;                      // initialized_
+    float max_laser;
+    int hit, miss;
+    int4* rays;
+};
+
+__device__ __forceinline__ bool cell_in_grid(const bl_frame& f, int x, int y)
+{
+    return x >= 0 && x < f.width && y >= 0 && y < f.height;
+}
+
+__global__ __launch_bounds__(MAP_THREADS) void k_map_update(map_args a)
+{
+    extern __shared__ __align__(16) unsigned int s_cnt[];     // MAP_LDS_COUNTERS/2 dwords, two uint16 counters each
+    __shared__ int s_box[4];                                   // xmin, ymin, xmax, ymax over all traced cells
+    __shared__ float s_pose[6];                                // prev x,y,theta ; cur x,y,theta
+
+    const int tid = threadIdx.x;
+    if (tid == 0) {
+        bl_pose_xyt_t cur = a.cur_dev ? *a.cur_dev : a.cur_host;
+        bl_pose_xyt_t prev = a.apply ? *a.prev : cur;          // mapping.cpp:19-21: first call uses pose for both
+        s_pose[0] = prev.x; s_pose[1] = prev.y; s_pose[2] = prev.theta;
+        s_pose[3] = cur.x; s_pose[4] = cur.y; s_pose[5] = cur.theta;
+        s_box[0] = 0x7fffffff; s_box[1] = 0x7fffffff; s_box[2] = -0x7fffffff; s_box[3] = -0x7fffffff;
+        // previousPose_ = pose (mapping.cpp:38)
+        bl_pose_xyt_t rec = cur;
+        rec.utime = a.cur_utime;
+        *a.prev = rec;
+    }
+    __syncthreads();
+    if (!a.apply) return;                                       // increase/decreaseCellOdds do nothing (mapping.cpp:74,88)
+
+    const bl_pose3 pb = {s_pose[0], s_pose[1], s_pose[2]};
+    const bl_pose3 pe = {s_pose[3], s_pose[4], s_pose[5]};
+
+    // ---- phase A: ray geometry (moving_laser_scan.cpp:22-37, mapping.cpp:45-49)
+    for (int r = tid; r < a.R; r += MAP_THREADS) {
+        int4 ray = make_int4(0, 0, 0, 0);
+        int valid = 0;
+        float range = a.ranges[r];
+        if (range > 0.15f && range <= a.max_laser) {
+            bl_pose3 rp = a.interp ? bl_interpolate_pose(pb, pe, a.ratio[r]) : pe;
+            float theta = bl_wrap_to_pi(rp.theta - a.thetas[r]);
+            float sn, cs, sx, sy;
+            bl_sincosf(theta, &sn, &cs);
+            bl_global_to_grid(rp.x, rp.y, a.frame, &sx, &sy);
+            float fx = (range * cs * a.frame.cpm) + sx;
+            float fy = (range * sn * a.frame.cpm) + sy;
+            const float lim = (float)MAP_CELL_LIMIT;
+            if (fx > -lim && fx < lim && fy > -lim && fy < lim && sx > -lim && sx < lim && sy > -lim && sy < lim) {
+                ray.x = (int)sx; ray.y = (int)sy;               // float -> int truncation at the bresenham() call
+                ray.z = (int)fx; ray.w = (int)fy;
+                valid = 1;
+                atomicMin(&s_box[0], min(ray.x, ray.z)); atomicMin(&s_box[1], min(ray.y, ray.w));
+                atomicMax(&s_box[2], max(ray.x, ray.z)); atomicMax(&s_box[3], max(ray.y, ray.w));
+            }
+        }
+        if (!valid) ray.x = 0x7fffffff;
+        a.rays[r] = ray;
+    }
+    __syncthreads();
+
+    // ---- phase B: endpoint pass (mapping.cpp:42-57).  One leader per distinct end cell applies min(127, v + hit*H).
+    for (int r = tid; r < a.R; r += MAP_THREADS) {
+        int4 me = a.rays[r];
+        if (me.x == 0x7fffffff || !cell_in_grid(a.frame, me.z, me.w)) continue;
+        int H = 0;
+        bool leader = true;
+        for (int q = 0; q < a.R; ++q) {
+            int4 o = a.rays[q];
+            if (o.x != 0x7fffffff && o.z == me.z && o.w == me.w) {
+                H++;
+                if (q < r) leader = false;
+            }
+        }
+        if (leader) {
+            size_t idx = (size_t)me.w * a.frame.width + me.z;
+            int v = a.cells[idx];
+            v = min(127, v + a.hit * H);
+            a.cells[idx] = (int8_t)v;
+        }
+    }
+    __syncthreads();
+
+    // ---- phase C: free-space pass (mapping.cpp:59-71, 101-127) through an LDS window of miss counters
+    int bx0 = max(s_box[0], 0), by0 = max(s_box[1], 0);
+    int bx1 = min(s_box[2], a.frame.width - 1), by1 = min(s_box[3], a.frame.height - 1);
+    if (bx1 < bx0 || by1 < by0) return;                         // nothing inside the grid
+    const int ww = bx1 - bx0 + 1;
+    const int wh = by1 - by0 + 1;
+    int rows_per_strip = MAP_LDS_COUNTERS / ww;
+    if (rows_per_strip < 1) rows_per_strip = 1;                 // ww > 73728 cannot happen for int32 grids < 2^31 cells with sane width
+    if (rows_per_strip > wh) rows_per_strip = wh;
+    const int strip_cells_max = rows_per_strip * ww;
+    if (strip_cells_max > MAP_LDS_COUNTERS) return;             // defensive: never index past the LDS window
+
+    for (int sy0 = by0; sy0 <= by1; sy0 += rows_per_strip) {
+        const int sy1 = min(sy0 + rows_per_strip - 1, by1);
+        const int ncell = (sy1 - sy0 + 1) * ww;
+        for (int i = tid; i < (ncell + 1) / 2; i += MAP_THREADS) s_cnt[i] = 0;
+        __syncthreads();
+        for (int r = tid; r < a.R; r += MAP_THREADS) {
+            int4 ray = a.rays[r];
+            if (ray.x == 0x7fffffff) continue;
+            int x = ray.x, y = ray.y;
+            const int x2 = ray.z, y2 = ray.w;
+            const int dx = abs(x2 - x), dy = abs(y2 - y);
+            const int sx = x < x2 ? 1 : -1, sy = y < y2 ? 1 : -1;
+            int err = dx - dy;
+            int guard = dx + dy + 2;                             // the walk needs max(dx,dy) steps; bound it regardless
+            while ((x != x2 || y != y2) && guard-- > 0) {
+                if (x >= bx0 && x <= bx1 && y >= sy0 && y <= sy1) {   // window is already clipped to the grid
+                    int ci = (y - sy0) * ww + (x - bx0);
+                    atomicAdd(&s_cnt[ci >> 1], (ci & 1) ? 0x10000u : 1u);
+                }
+                int e2 = 2 * err;                                // float e2 in the reference; exact for these magnitudes
+                if (e2 >= -dy) { err -= dy; x += sx; }
+                if (e2 <= dx) { err += dx; y += sy; }
+            }
+        }
+        __syncthreads();
+        for (int ci = tid; ci < ncell; ci += MAP_THREADS) {
+            unsigned int pair = s_cnt[ci >> 1];
+            int M = (ci & 1) ? (int)(pair >> 16) : (int)(pair & 0xffffu);
+            if (M > 0) {
+                int cy = sy0 + ci / ww, cx = bx0 + ci % ww;
+                size_t idx = (size_t)cy * a.frame.width + cx;
+                int v = a.cells[idx];
+                v = max(-128, v - a.miss * M);
+                a.cells[idx] = (int8_t)v;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------- host side
+extern "C" int bl_mapping_create(bl_ctx* ctx, float max_laser_distance, int8_t hit_odds, int8_t miss_odds, bl_mapping** out)
+{
+    BL_CHECK_ARG(ctx != nullptr && out != nullptr);
+    BL_CHECK_ARG(hit_odds >= 0 && miss_odds >= 0);
+    BL_HIP(hipSetDevice(ctx->device));
+    bl_mapping* m = new bl_mapping();
+    m->ctx = ctx;
+    m->max_laser = max_laser_distance;
+    m->hit = hit_odds; m->miss = miss_odds;
+    m->initialized = false;
+    m->prev_utime = 0;
+    m->d_prev = nullptr; m->d_rays = nullptr; m->ray_capacity = 0;
+    hipError_t e = hipMalloc((void**)&m->d_prev, sizeof(bl_pose_xyt_t));
+    if (e != hipSuccess) { bl_set_error("hipMalloc failed: %s", hipGetErrorString(e)); delete m; return BL_ERR_HIP; }
+    BL_HIP(hipMemsetAsync(m->d_prev, 0, sizeof(bl_pose_xyt_t), ctx->stream));
+    static bool attr_set = false;
+    if (!attr_set) {
+        BL_HIP(hipFuncSetAttribute((const void*)k_map_update, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   MAP_LDS_COUNTERS * 2));
+        attr_set = true;
+    }
+    *out = m;
+    return BL_OK;
+}
+
+extern "C" void bl_mapping_destroy(bl_mapping* m)
+{
+    if (!m) return;
+    (void)hipStreamSynchronize(m->ctx->stream);
+    bl_scan_free(&m->scan);
+    (void)hipFree(m->d_prev);
+    if (m->d_rays) (void)hipFree(m->d_rays);
+    delete m;
+}
+
+static int mapping_update_impl(bl_mapping* m, const bl_lidar_t* scan, const bl_pose_xyt_t* h_pose, const void* d_pose,
+                               int64_t pose_utime, bl_grid* map)
+{
+    BL_CHECK_ARG(m != nullptr && scan != nullptr && map != nullptr);
+    BL_CHECK_ARG(scan->num_ranges >= 0 && scan->num_ranges <= MAP_MAX_RAYS);
+    bl_ctx* ctx = m->ctx;
+    BL_HIP(hipSetDevice(ctx->device));
+    int64_t begin = m->initialized ? m->prev_utime : pose_utime;
+    int R = 0;
+    int rc = bl_scan_upload(ctx, &m->scan, scan, begin, pose_utime, &R);
+    if (rc) return rc;
+    if (R > m->ray_capacity) {
+        if (m->d_rays) { BL_HIP(hipStreamSynchronize(ctx->stream)); BL_HIP(hipFree(m->d_rays)); }
+        int cap = R < 1024 ? 1024 : R;
+        BL_HIP(hipMalloc((void**)&m->d_rays, (size_t)cap * sizeof(int4)));
+        m->ray_capacity = cap;
+    }
+    map_args a;
+    a.cells = map->cells;
+    a.frame = map->frame;
+    a.ranges = m->scan.ranges; a.thetas = m->scan.thetas; a.ratio = m->scan.ratio;
+    a.R = R;
+    a.prev = m->d_prev;
+    a.cur_dev = (const bl_pose_xyt_t*)d_pose;
+    if (h_pose) a.cur_host = *h_pose; else { a.cur_host.utime = 0; a.cur_host.x = a.cur_host.y = a.cur_host.theta = 0; }
+    a.cur_utime = pose_utime;
+    a.interp = (begin != pose_utime) ? 1 : 0;
+    a.apply = m->initialized ? 1 : 0;
+    a.max_laser = m->max_laser;
+    a.hit = m->hit; a.miss = m->miss;
+    a.rays = m->d_rays;
+    hipEvent_t e0, e1;
+    rc = bl_timer_begin(ctx, BL_K_MAP, &e0, &e1);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_map_update, dim3(1), dim3(MAP_THREADS), MAP_LDS_COUNTERS * 2, ctx->stream, a);
+    BL_HIP(hipGetLastError());
+    rc = bl_timer_end(ctx, BL_K_MAP, e0, e1);
+    if (rc) return rc;
+    m->initialized = true;
+    m->prev_utime = pose_utime;
+    return BL_OK;
+}
+
+extern "C" int bl_mapping_update(bl_mapping* m, const bl_lidar_t* scan, const bl_pose_xyt_t* pose, bl_grid* map)
+{
+    BL_CHECK_ARG(pose != nullptr);
+    return mapping_update_impl(m, scan, pose, nullptr, pose->utime, map);
+}
+
+extern "C" int bl_mapping_update_dev_pose(bl_mapping* m, const bl_lidar_t* scan, const void* d_pose, int64_t pose_utime,
+                                          bl_grid* map)
+{
+    BL_CHECK_ARG(d_pose != nullptr);
+    return mapping_update_impl(m, scan, nullptr, d_pose, pose_utime, map);
+}

@@ -1,0 +1,694 @@
+// bl_mcl.hip -- ParticleFilter (src/slam/particle_filter.cpp) with ActionModel (src/slam/action_model.cpp) and
+// SensorModel (src/slam/sensor_model.cpp) as gfx950 kernels.
+//
+// Data layout in HBM (per filter):
+//   rec[2]   float4[N]   exchange record of ALL N particles, double-buffered: (x, y, theta, weight-units as uint32 bits).
+//                        rec[cur] is the posterior of the previous update; k_mcl_main writes rec[cur^1].
+//   prefix   uint64[N]   inclusive prefix sum of the weight-units of rec[cur] (exact integers)
+//   parent   float4[n]   parent pose of the local shard (x, y, theta, -)
+//   state    pf_state    S (sum of units), pose estimate
+//
+// Weights as exact integers.  A raw particle weight in the reference is max(likelihood, 0.001) with likelihood a sum
+// of terms k or k/2, k an int8 log-odds (sensor_model.cpp:40-57, particle_filter.cpp:125-133).  In units of 0.0005
+// every raw weight is an integer: 1000 * (2*likelihood) or 2.  Sums and prefix sums of units are exact in uint64, so
+// the normalisation, the resampling cumulative and the result are independent of launch shape and GPU count.
+//
+// Resampling rule (particle_filter.cpp:84-103): output particle m takes the first source i whose cumulative normalised
+// weight c_i satisfies U_m <= c_i, U_m = r + m/N.  Here: first i with U_m * S <= prefix[i] (double product against an
+// exact integer), i clamped to N-1.  The reference accumulates c_i sequentially in double; the two rules can differ
+// only when U_m lies within rounding distance of a partial sum (DESIGN.md "Resampling").
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#include <new>
+
+#include "bl_internal.h"
+
+#define MCL_THREADS 256
+#define SCAN_THREADS 256
+#define SCAN_ITEMS 8
+#define SCAN_TILE (SCAN_THREADS * SCAN_ITEMS)
+
+struct pf_state {
+    double S;                 // total weight units of rec[cur]
+    bl_pose_xyt_t pose;       // posteriorPose_
+    double sums_used[5];      // the (all-reduced) sums the estimate was formed from (diagnostic)
+};
+
+struct bl_pf {
+    bl_ctx* ctx;
+    int N, lo, hi, n_local;
+    float4* rec[2];
+    bool rec_external;
+    int cur;
+    double* sums;             // 8 doubles
+    bool sums_external;
+    unsigned long long* prefix;
+    float4* parent;
+    pf_state* state;
+    double* partials;         // [blocks][5]
+    unsigned long long* block_sums;   // scan scratch
+    int scan_blocks;
+    int32_t* dbg_idx;
+    int32_t* dbg_like;
+    float* d_noise;           // 3 * n_local (parity mode)
+    bl_particle_t* d_export;  // n_local
+    bl_scan_dev scan;
+    // uniform utimes of the particle set (every particle carries the same pair; DESIGN.md "Particle utimes")
+    int64_t pose_utime, parent_utime;
+    // ActionModel state (action_model.hpp:60-78)
+    bl_pose_xyt_t prev_odom;
+    bool action_initialized, moved;
+    double rot1, trans, rot2, rot1Std, transStd, rot2Std;
+    uint64_t noise_seed;
+    uint32_t step;
+    bool initialized;
+    bool pending_end;         // update_begin issued, update_end not yet
+    int64_t pending_utime;
+};
+
+// ---------------------------------------------------------------- device helpers
+__device__ __forceinline__ double wave_sum(double v)
+{
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;
+}
+
+__device__ __forceinline__ int grid_odds(const int8_t* __restrict__ cells, const bl_frame& f, int x, int y)
+{
+    // OccupancyGrid::logOdds (occupancy_grid.cpp:63-71): 0 outside the grid
+    if (x >= 0 && x < f.width && y >= 0 && y < f.height) return cells[(size_t)y * f.width + x];
+    return 0;
+}
+
+// SensorModel::scoreRay (sensor_model.cpp:28-59) in half-units: returns 2*odds, o1 or o2 (score = that / 2)
+__device__ __forceinline__ int score_ray_half_units(const int8_t* __restrict__ cells, const bl_frame& f, float sx, float sy,
+                                                     float range, float cs, float sn)
+{
+    int ex = (int)((range * cs * f.cpm) + sx);
+    int ey = (int)((range * sn * f.cpm) + sy);
+    int odds = grid_odds(cells, f, ex, ey);
+    if (odds > 0) return 2 * odds;
+    int xx = (int)((2 * range * cs * f.cpm) + sx);
+    int xy = (int)((2 * range * sn * f.cpm) + sy);
+    int ax, ay;
+    bl_bresenham_first_step(ex, ey, (int)sx, (int)sy, &ax, &ay);
+    int o1 = grid_odds(cells, f, ax, ay);
+    if (o1 > 0) return o1;
+    bl_bresenham_first_step(ex, ey, xx, xy, &ax, &ay);
+    int o2 = grid_odds(cells, f, ax, ay);
+    return o2 > 0 ? o2 : 0;
+}
+
+struct mcl_args {
+    const float4* src;            // rec[cur]     (all N)
+    float4* dst;                  // rec[cur ^ 1] (all N; this shard writes [lo, hi))
+    const unsigned long long* prefix;
+    const pf_state* state;
+    float4* parent;               // local
+    double* partials;             // [gridDim.x][5]
+    int32_t* dbg_idx;
+    int32_t* dbg_like;
+    const int8_t* cells;
+    bl_frame frame;
+    const float* ranges;
+    const float* thetas;
+    const double* ratio;
+    int R;
+    int N, lo, n_local;
+    double r;                     // (rand/RAND_MAX) * (1/N)
+    double M_inv;                 // 1/N
+    double rot1, trans, rot2, rot1Std, transStd, rot2Std;
+    const float* noise;           // 3 * n_local or null
+    uint32_t seed_lo, seed_hi, step;
+    int interp;                   // parent utime != pose utime (first moved update)
+    int resample;                 // 0: action-only (source = own index)
+};
+
+__device__ __forceinline__ void philox_normals3(uint32_t m, uint32_t step, uint32_t k0, uint32_t k1, float z[3])
+{
+    uint32_t o[4];
+    bl_philox4x32(m, step, 0x6d636c31u, 0, k0, k1, o);
+    // (0,1] uniforms; Box-Muller
+    float u1 = ((float)(o[0] >> 8) + 1.0f) * (1.0f / 16777216.0f);
+    float u2 = ((float)(o[1] >> 8) + 0.5f) * (1.0f / 16777216.0f);
+    float u3 = ((float)(o[2] >> 8) + 1.0f) * (1.0f / 16777216.0f);
+    float u4 = ((float)(o[3] >> 8) + 0.5f) * (1.0f / 16777216.0f);
+    float ra = sqrtf(-2.0f * logf(u1)), rb = sqrtf(-2.0f * logf(u3));
+    float s2, c2, c4;
+    sincosf(6.2831853071795864769f * u2, &s2, &c2);
+    c4 = cosf(6.2831853071795864769f * u4);
+    z[0] = ra * c2; z[1] = ra * s2; z[2] = rb * c4;
+}
+
+// One thread per output particle m of the shard: low-variance resample (gather), ActionModel::applyAction,
+// SensorModel::likelihood, weight units, and the block's partial sums for normalisation + pose estimate.
+template <int INTERP>
+__global__ __launch_bounds__(MCL_THREADS) void k_mcl_main(mcl_args a)
+{
+    __shared__ double s_part[MCL_THREADS / 64][5];
+    const int j = blockIdx.x * MCL_THREADS + threadIdx.x;
+    const bool active = j < a.n_local;
+    double t_units = 0, t_x = 0, t_y = 0, t_s = 0, t_c = 0;
+
+    if (active) {
+        const int m = a.lo + j;
+        // ---- resamplePosteriorDistribution (particle_filter.cpp:84-103)
+        int i = m;
+        if (a.resample) {
+            const double U = a.r + m * a.M_inv;
+            const double T = U * a.state->S;
+            int lo = 0, hi = a.N - 1;                       // first index with T <= prefix[i], clamped to N-1
+            while (lo < hi) {
+                int mid = (lo + hi) >> 1;
+                if (T <= (double)a.prefix[mid]) hi = mid; else lo = mid + 1;
+            }
+            i = lo;
+        }
+        const float4 s = a.src[i];
+        // ---- ActionModel::applyAction (action_model.cpp:78-103)
+        float n1, n2, n3;
+        if (a.noise) {
+            n1 = a.noise[3 * j]; n2 = a.noise[3 * j + 1]; n3 = a.noise[3 * j + 2];
+        } else {
+            float z[3];
+            philox_normals3((uint32_t)m, a.step, a.seed_lo, a.seed_hi, z);
+            n1 = (float)(a.rot1 + a.rot1Std * (double)z[0]);
+            n2 = (float)(a.trans + a.transStd * (double)z[1]);
+            n3 = (float)(a.rot2 + a.rot2Std * (double)z[2]);
+        }
+        const float head = s.z + n1;                        // float sum, then double libm cos/sin of it
+        const float px = (float)((double)s.x + (double)n2 * cos((double)head));
+        const float py = (float)((double)s.y + (double)n2 * sin((double)head));
+        const float pth = bl_wrap_to_pi(s.z + n1 + n3);
+
+        // ---- SensorModel::likelihood (sensor_model.cpp:14-25) over MovingLaserScan(scan, parent_pose, pose)
+        int acc = 0;                                        // half-units: likelihood = acc / 2 exactly
+        if (a.cells) {
+            const bl_pose3 pb = {s.x, s.y, s.z};
+            const bl_pose3 pe = {px, py, pth};
+            float sx0, sy0;
+            bl_global_to_grid(px, py, a.frame, &sx0, &sy0);
+            for (int n = 0; n < a.R; ++n) {
+                const float range = a.ranges[n];
+                if (!(range > 0.15f)) continue;             // moving_laser_scan.cpp:24
+                float theta, sx, sy;
+                if (INTERP) {
+                    bl_pose3 rp = bl_interpolate_pose(pb, pe, a.ratio[n]);
+                    theta = bl_wrap_to_pi(rp.theta - a.thetas[n]);
+                    bl_global_to_grid(rp.x, rp.y, a.frame, &sx, &sy);
+                } else {
+                    theta = bl_wrap_to_pi(pth - a.thetas[n]);
+                    sx = sx0; sy = sy0;
+                }
+                float sn, cs;
+                bl_sincosf(theta, &sn, &cs);
+                acc += score_ray_half_units(a.cells, a.frame, sx, sy, range, cs, sn);
+            }
+        }
+        // ---- computeNormalizedPosterior (particle_filter.cpp:116-141): w = max(likelihood, 0.001) in units of 0.0005
+        const uint32_t units = a.cells ? (acc > 0 ? (uint32_t)acc * 1000u : 2u) : __float_as_uint(s.w);
+        a.dst[m] = make_float4(px, py, pth, __uint_as_float(units));
+        a.parent[j] = make_float4(s.x, s.y, s.z, 0.0f);
+        if (a.dbg_idx) { a.dbg_idx[j] = i; a.dbg_like[j] = acc; }
+        // ---- estimatePosteriorPose (particle_filter.cpp:144-160) partial sums
+        float sth, cth;
+        bl_sincosf(pth, &sth, &cth);
+        t_units = (double)units;
+        t_x = t_units * (double)px;
+        t_y = t_units * (double)py;
+        t_s = t_units * (double)sth;
+        t_c = t_units * (double)cth;
+    }
+    t_units = wave_sum(t_units); t_x = wave_sum(t_x); t_y = wave_sum(t_y); t_s = wave_sum(t_s); t_c = wave_sum(t_c);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (lane == 0) { s_part[wave][0] = t_units; s_part[wave][1] = t_x; s_part[wave][2] = t_y; s_part[wave][3] = t_s; s_part[wave][4] = t_c; }
+    __syncthreads();
+    if (threadIdx.x < 5) {
+        double v = 0;
+        for (int w = 0; w < MCL_THREADS / 64; ++w) v += s_part[w][threadIdx.x];
+        a.partials[(size_t)blockIdx.x * 5 + threadIdx.x] = v;
+    }
+}
+
+// fixed-order reduction of the block partials -> sums[0..4] (sums[5..7] = 0)
+__global__ __launch_bounds__(256) void k_mcl_reduce(const double* __restrict__ partials, int nblocks, double* __restrict__ sums)
+{
+    __shared__ double s[256][5];
+    double v[5] = {0, 0, 0, 0, 0};
+    for (int b = threadIdx.x; b < nblocks; b += 256)
+        for (int k = 0; k < 5; ++k) v[k] += partials[(size_t)b * 5 + k];
+    for (int k = 0; k < 5; ++k) s[threadIdx.x][k] = v[k];
+    __syncthreads();
+    for (int stride = 128; stride > 0; stride >>= 1) {
+        if (threadIdx.x < stride)
+            for (int k = 0; k < 5; ++k) s[threadIdx.x][k] += s[threadIdx.x + stride][k];
+        __syncthreads();
+    }
+    if (threadIdx.x < 8) sums[threadIdx.x] = threadIdx.x < 5 ? s[0][threadIdx.x] : 0.0;
+}
+
+// ---------------------------------------------------------------- weight-unit prefix scan over all N (3 launches)
+__global__ __launch_bounds__(SCAN_THREADS) void k_scan_tile_sums(const float4* __restrict__ rec, int N,
+                                                                 unsigned long long* __restrict__ tile_sums)
+{
+    __shared__ unsigned long long s[SCAN_THREADS / 64];
+    const int base = blockIdx.x * SCAN_TILE + threadIdx.x * SCAN_ITEMS;
+    unsigned long long v = 0;
+    for (int k = 0; k < SCAN_ITEMS; ++k)
+        if (base + k < N) v += __float_as_uint(rec[base + k].w);
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long t = 0;
+        for (int w = 0; w < SCAN_THREADS / 64; ++w) t += s[w];
+        tile_sums[blockIdx.x] = t;
+    }
+}
+
+// single workgroup: exclusive scan of the tile sums (in place), total -> state.S, and the pose estimate
+// (estimatePosteriorPose, particle_filter.cpp:144-160) from the five (all-reduced) sums.
+__global__ __launch_bounds__(1024) void k_scan_tiles_and_estimate(unsigned long long* __restrict__ tile_sums, int ntiles,
+                                                                  const double* __restrict__ sums, pf_state* state,
+                                                                  int64_t utime, int write_pose)
+{
+    __shared__ unsigned long long s_wave[16];
+    __shared__ unsigned long long s_carry;
+    if (threadIdx.x == 0) s_carry = 0;
+    __syncthreads();
+    for (int base = 0; base < ntiles; base += 1024) {
+        int idx = base + threadIdx.x;
+        unsigned long long v = idx < ntiles ? tile_sums[idx] : 0ull;
+        unsigned long long incl = v;
+        for (int off = 1; off < 64; off <<= 1) {
+            unsigned long long t = __shfl_up(incl, off, 64);
+            if ((threadIdx.x & 63) >= off) incl += t;
+        }
+        if ((threadIdx.x & 63) == 63) s_wave[threadIdx.x >> 6] = incl;
+        __syncthreads();
+        unsigned long long wave_off = 0;
+        for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) wave_off += s_wave[w];
+        unsigned long long carry = s_carry;
+        if (idx < ntiles) tile_sums[idx] = carry + wave_off + incl - v;      // exclusive
+        __syncthreads();
+        if (threadIdx.x == 1023) s_carry = carry + wave_off + incl;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        state->S = (double)s_carry;
+        if (write_pose) {
+            double su = sums[0];
+            bl_pose_xyt_t p;
+            p.utime = utime;
+            p.x = (float)(sums[1] / su);
+            p.y = (float)(sums[2] / su);
+            p.theta = (float)atan2(sums[3], sums[4]);
+            state->pose = p;
+            for (int k = 0; k < 5; ++k) state->sums_used[k] = sums[k];
+        }
+    }
+}
+
+__global__ __launch_bounds__(SCAN_THREADS) void k_scan_write_prefix(const float4* __restrict__ rec, int N,
+                                                                    const unsigned long long* __restrict__ tile_offsets,
+                                                                    unsigned long long* __restrict__ prefix)
+{
+    __shared__ unsigned long long s_wave[SCAN_THREADS / 64];
+    const int base = blockIdx.x * SCAN_TILE + threadIdx.x * SCAN_ITEMS;
+    unsigned long long loc[SCAN_ITEMS];
+    unsigned long long run = 0;
+    for (int k = 0; k < SCAN_ITEMS; ++k) {
+        if (base + k < N) run += __float_as_uint(rec[base + k].w);
+        loc[k] = run;
+    }
+    unsigned long long incl = run;
+    for (int off = 1; off < 64; off <<= 1) {
+        unsigned long long t = __shfl_up(incl, off, 64);
+        if ((threadIdx.x & 63) >= off) incl += t;
+    }
+    if ((threadIdx.x & 63) == 63) s_wave[threadIdx.x >> 6] = incl;
+    __syncthreads();
+    unsigned long long off0 = tile_offsets[blockIdx.x] + incl - run;
+    for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) off0 += s_wave[w];
+    for (int k = 0; k < SCAN_ITEMS; ++k)
+        if (base + k < N) prefix[base + k] = off0 + loc[k];
+}
+
+// ---------------------------------------------------------------- init / export / small state kernels
+__global__ void k_pf_init(float4* rec, float4* parent, int N, int lo, int n_local, bl_pose_xyt_t pose, uint32_t k0, uint32_t k1)
+{
+    // initializeFilterAtPose (particle_filter.cpp:16-34): every rank fills the WHOLE record (it is replicated)
+    int m = blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= N) return;
+    float z[3];
+    philox_normals3((uint32_t)m, 0xffffffffu, k0, k1, z);
+    float x = (float)((double)pose.x + 0.01 * (double)z[0]);
+    float y = (float)((double)pose.y + 0.01 * (double)z[1]);
+    float th = bl_wrap_to_pi((float)((double)pose.theta + 0.01 * (double)z[2]));
+    if (m == N - 1) { x = pose.x; y = pose.y; th = pose.theta; }     // posterior_.back().pose = pose
+    rec[m] = make_float4(x, y, th, __uint_as_float(1u));
+    int j = m - lo;
+    if (j >= 0 && j < n_local) parent[j] = make_float4(x, y, th, 0.0f);
+}
+
+__global__ void k_pf_export(const float4* rec, const float4* parent, const pf_state* state, int lo, int n_local,
+                            int64_t pose_utime, int64_t parent_utime, bl_particle_t* out)
+{
+    int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n_local) return;
+    float4 r = rec[lo + j];
+    float4 p = parent[j];
+    bl_particle_t o;
+    o.pose.utime = pose_utime; o.pose.x = r.x; o.pose.y = r.y; o.pose.theta = r.z;
+    o.parent_pose.utime = parent_utime; o.parent_pose.x = p.x; o.parent_pose.y = p.y; o.parent_pose.theta = p.z;
+    o.weight = (double)__float_as_uint(r.w) / state->S;
+    out[j] = o;
+}
+
+__global__ void k_pf_set_pose(pf_state* state, bl_pose_xyt_t pose, int only_utime)
+{
+    if (only_utime) state->pose.utime = pose.utime;
+    else state->pose = pose;
+}
+
+// ---------------------------------------------------------------- host side
+static int pf_alloc(bl_pf* pf)
+{
+    size_t N = pf->N, n = pf->n_local;
+    if (!pf->rec[0]) {
+        BL_HIP(hipMalloc((void**)&pf->rec[0], N * sizeof(float4)));
+        BL_HIP(hipMalloc((void**)&pf->rec[1], N * sizeof(float4)));
+    }
+    if (!pf->sums) BL_HIP(hipMalloc((void**)&pf->sums, 8 * sizeof(double)));
+    BL_HIP(hipMalloc((void**)&pf->prefix, N * sizeof(unsigned long long)));
+    BL_HIP(hipMalloc((void**)&pf->parent, n * sizeof(float4)));
+    BL_HIP(hipMalloc((void**)&pf->state, sizeof(pf_state)));
+    int blocks = (int)((n + MCL_THREADS - 1) / MCL_THREADS);
+    BL_HIP(hipMalloc((void**)&pf->partials, (size_t)blocks * 5 * sizeof(double)));
+    pf->scan_blocks = (int)((N + SCAN_TILE - 1) / SCAN_TILE);
+    BL_HIP(hipMalloc((void**)&pf->block_sums, (size_t)pf->scan_blocks * sizeof(unsigned long long)));
+    BL_HIP(hipMalloc((void**)&pf->dbg_idx, n * sizeof(int32_t)));
+    BL_HIP(hipMalloc((void**)&pf->dbg_like, n * sizeof(int32_t)));
+    BL_HIP(hipMemsetAsync(pf->state, 0, sizeof(pf_state), pf->ctx->stream));
+    BL_HIP(hipMemsetAsync(pf->sums, 0, 8 * sizeof(double), pf->ctx->stream));
+    return BL_OK;
+}
+
+extern "C" int bl_pf_create(bl_ctx* ctx, int num_particles, int shard_lo, int shard_hi, bl_pf** out)
+{
+    BL_CHECK_ARG(ctx != nullptr && out != nullptr);
+    BL_CHECK_ARG(num_particles > 1);                         // particle_filter.cpp:11
+    BL_CHECK_ARG(shard_lo >= 0 && shard_lo < shard_hi && shard_hi <= num_particles);
+    BL_HIP(hipSetDevice(ctx->device));
+    bl_pf* pf = new bl_pf();
+    memset((void*)pf, 0, sizeof(*pf));
+    new (&pf->scan) bl_scan_dev();
+    pf->ctx = ctx;
+    pf->N = num_particles; pf->lo = shard_lo; pf->hi = shard_hi; pf->n_local = shard_hi - shard_lo;
+    pf->noise_seed = 0x243F6A8885A308D3ull;
+    *out = pf;
+    return BL_OK;
+}
+
+extern "C" void bl_pf_destroy(bl_pf* pf)
+{
+    if (!pf) return;
+    (void)hipStreamSynchronize(pf->ctx->stream);
+    if (!pf->rec_external) { if (pf->rec[0]) (void)hipFree(pf->rec[0]); if (pf->rec[1]) (void)hipFree(pf->rec[1]); }
+    if (!pf->sums_external && pf->sums) (void)hipFree(pf->sums);
+    void* ptrs[] = {pf->prefix, pf->parent, pf->state, pf->partials, pf->block_sums, pf->dbg_idx, pf->dbg_like,
+                    pf->d_noise, pf->d_export};
+    for (void* p : ptrs) if (p) (void)hipFree(p);
+    bl_scan_free(&pf->scan);
+    delete pf;
+}
+
+extern "C" int bl_pf_set_exchange_buffers(bl_pf* pf, void* d_rec0, void* d_rec1, void* d_sums)
+{
+    BL_CHECK_ARG(pf != nullptr && d_rec0 && d_rec1 && d_sums);
+    if (pf->prefix) { bl_set_error("exchange buffers must be set before the filter is initialised"); return BL_ERR_STATE; }
+    pf->rec[0] = (float4*)d_rec0; pf->rec[1] = (float4*)d_rec1; pf->rec_external = true;
+    pf->sums = (double*)d_sums; pf->sums_external = true;
+    return BL_OK;
+}
+
+extern "C" void* bl_pf_exchange_rec_ptr(bl_pf* pf) { return pf && pf->prefix ? (void*)pf->rec[pf->pending_end ? pf->cur ^ 1 : pf->cur] : nullptr; }
+extern "C" void* bl_pf_exchange_sums_ptr(bl_pf* pf) { return pf ? (void*)pf->sums : nullptr; }
+extern "C" const void* bl_pf_pose_device_ptr(bl_pf* pf) { return pf && pf->state ? (const void*)&pf->state->pose : nullptr; }
+
+// prefix scan of rec[which] + (optionally) the pose estimate; timed as BL_K_MCL_SCAN
+static int pf_scan(bl_pf* pf, int which, int write_pose, int64_t utime)
+{
+    bl_ctx* ctx = pf->ctx;
+    hipEvent_t e0, e1;
+    int rc = bl_timer_begin(ctx, BL_K_MCL_SCAN, &e0, &e1);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_scan_tile_sums, dim3(pf->scan_blocks), dim3(SCAN_THREADS), 0, ctx->stream, pf->rec[which], pf->N,
+                       pf->block_sums);
+    hipLaunchKernelGGL(k_scan_tiles_and_estimate, dim3(1), dim3(1024), 0, ctx->stream, pf->block_sums, pf->scan_blocks,
+                       pf->sums, pf->state, utime, write_pose);
+    hipLaunchKernelGGL(k_scan_write_prefix, dim3(pf->scan_blocks), dim3(SCAN_THREADS), 0, ctx->stream, pf->rec[which], pf->N,
+                       pf->block_sums, pf->prefix);
+    BL_HIP(hipGetLastError());
+    return bl_timer_end(ctx, BL_K_MCL_SCAN, e0, e1);
+}
+
+static void pf_reset_action(bl_pf* pf)
+{
+    pf->action_initialized = false; pf->moved = false;
+    pf->rot1 = pf->trans = pf->rot2 = 0;
+    pf->step = 0;
+    pf->pending_end = false;
+}
+
+extern "C" int bl_pf_init_at_pose(bl_pf* pf, const bl_pose_xyt_t* pose, uint64_t seed)
+{
+    BL_CHECK_ARG(pf != nullptr && pose != nullptr);
+    BL_HIP(hipSetDevice(pf->ctx->device));
+    if (!pf->prefix) { int rc = pf_alloc(pf); if (rc) return rc; }
+    pf->cur = 0;
+    hipLaunchKernelGGL(k_pf_init, dim3((pf->N + 255) / 256), dim3(256), 0, pf->ctx->stream, pf->rec[0], pf->parent, pf->N,
+                       pf->lo, pf->n_local, *pose, (uint32_t)seed, (uint32_t)(seed >> 32));
+    hipLaunchKernelGGL(k_pf_set_pose, dim3(1), dim3(1), 0, pf->ctx->stream, pf->state, *pose, 0);
+    BL_HIP(hipGetLastError());
+    pf->pose_utime = pose->utime; pf->parent_utime = pose->utime;
+    pf->initialized = true;
+    // the reference does not reset its ActionModel here; a filter is initialised once (slam.cpp:232-250)
+    return pf_scan(pf, 0, 0, 0);
+}
+
+extern "C" int bl_pf_set_particles(bl_pf* pf, const bl_particle_t* particles, const uint32_t* units)
+{
+    BL_CHECK_ARG(pf != nullptr && particles != nullptr);
+    BL_HIP(hipSetDevice(pf->ctx->device));
+    if (!pf->prefix) { int rc = pf_alloc(pf); if (rc) return rc; }
+    std::vector<float4> rec(pf->N), par(pf->n_local);
+    for (int m = 0; m < pf->N; ++m) {
+        uint32_t u = units ? units[m] : 1u;
+        float w; memcpy(&w, &u, 4);
+        rec[m] = make_float4(particles[m].pose.x, particles[m].pose.y, particles[m].pose.theta, w);
+    }
+    for (int j = 0; j < pf->n_local; ++j) {
+        const bl_pose_xyt_t& pp = particles[pf->lo + j].parent_pose;
+        par[j] = make_float4(pp.x, pp.y, pp.theta, 0.0f);
+    }
+    pf->cur = 0;
+    BL_HIP(hipMemcpyAsync(pf->rec[0], rec.data(), rec.size() * sizeof(float4), hipMemcpyHostToDevice, pf->ctx->stream));
+    BL_HIP(hipMemcpyAsync(pf->parent, par.data(), par.size() * sizeof(float4), hipMemcpyHostToDevice, pf->ctx->stream));
+    BL_HIP(hipStreamSynchronize(pf->ctx->stream));
+    pf->pose_utime = particles[0].pose.utime;
+    pf->parent_utime = particles[0].parent_pose.utime;
+    pf->initialized = true;
+    pf->pending_end = false;
+    return pf_scan(pf, 0, 0, 0);
+}
+
+extern "C" int bl_pf_get_particles(bl_pf* pf, bl_particle_t* out_local)
+{
+    BL_CHECK_ARG(pf != nullptr && out_local != nullptr);
+    if (!pf->initialized || pf->pending_end) { bl_set_error("filter not initialised or update pending"); return BL_ERR_STATE; }
+    BL_HIP(hipSetDevice(pf->ctx->device));
+    if (!pf->d_export) BL_HIP(hipMalloc((void**)&pf->d_export, (size_t)pf->n_local * sizeof(bl_particle_t)));
+    hipLaunchKernelGGL(k_pf_export, dim3((pf->n_local + 255) / 256), dim3(256), 0, pf->ctx->stream, pf->rec[pf->cur],
+                       pf->parent, pf->state, pf->lo, pf->n_local, pf->pose_utime, pf->parent_utime, pf->d_export);
+    BL_HIP(hipGetLastError());
+    BL_HIP(hipMemcpyAsync(out_local, pf->d_export, (size_t)pf->n_local * sizeof(bl_particle_t), hipMemcpyDeviceToHost,
+                          pf->ctx->stream));
+    BL_HIP(hipStreamSynchronize(pf->ctx->stream));
+    return BL_OK;
+}
+
+extern "C" int bl_pf_set_noise_seed(bl_pf* pf, uint64_t seed)
+{
+    BL_CHECK_ARG(pf != nullptr);
+    pf->noise_seed = seed;
+    return BL_OK;
+}
+
+// ActionModel::updateAction (action_model.cpp:22-75) -- host scalars, same libm calls as the reference
+static bool action_update(bl_pf* pf, const bl_pose_xyt_t& odometry)
+{
+    if (!pf->action_initialized) { pf->prev_odom = odometry; pf->action_initialized = true; }
+    float deltaX = odometry.x - pf->prev_odom.x;
+    float deltaY = odometry.y - pf->prev_odom.y;
+    float deltaTheta = (float)bl_angle_diff(odometry.theta, pf->prev_odom.theta);
+    float dir = 1.0;
+    pf->rot1 = bl_angle_diff(atan2f(deltaY, deltaX), pf->prev_odom.theta);
+    pf->trans = sqrtf(deltaX * deltaX + deltaY * deltaY);
+    if (fabs(pf->trans) < 0.0001) { pf->rot1 = 0.0f; }
+    else if (fabs(pf->rot1) > BL_PI / 2.0) { pf->rot1 = -bl_angle_diff(BL_PI, pf->rot1); dir = -1.0; }
+    // (the reference's third branch, |rot1| < -pi/2, can never be taken: action_model.cpp:44-47)
+    pf->trans *= dir;
+    pf->rot2 = bl_angle_diff(deltaTheta, pf->rot1);
+    pf->moved = !((fabs(pf->trans) + fabs(pf->rot2)) < 0.00001f);
+    pf->rot1Std = 0.05; pf->transStd = 0.005; pf->rot2Std = 0.05;
+    pf->prev_odom = odometry;
+    return pf->moved;
+}
+
+static int pf_upload_noise(bl_pf* pf, const float* noise)
+{
+    if (!pf->d_noise) BL_HIP(hipMalloc((void**)&pf->d_noise, (size_t)pf->n_local * 3 * sizeof(float)));
+    BL_HIP(hipMemcpyAsync(pf->d_noise, noise + (size_t)pf->lo * 3, (size_t)pf->n_local * 3 * sizeof(float),
+                          hipMemcpyHostToDevice, pf->ctx->stream));
+    BL_HIP(hipStreamSynchronize(pf->ctx->stream));          // caller-owned pageable buffer
+    return BL_OK;
+}
+
+static int pf_launch_main(bl_pf* pf, const bl_grid* map, int R, int rand_value, const float* noise, int resample)
+{
+    bl_ctx* ctx = pf->ctx;
+    mcl_args a;
+    a.src = pf->rec[pf->cur];
+    a.dst = pf->rec[pf->cur ^ 1];
+    a.prefix = pf->prefix;
+    a.state = pf->state;
+    a.parent = pf->parent;
+    a.partials = pf->partials;
+    a.dbg_idx = pf->dbg_idx; a.dbg_like = pf->dbg_like;
+    a.cells = map ? map->cells : nullptr;
+    if (map) a.frame = map->frame; else memset(&a.frame, 0, sizeof(a.frame));
+    a.ranges = pf->scan.ranges; a.thetas = pf->scan.thetas; a.ratio = pf->scan.ratio;
+    a.R = R;
+    a.N = pf->N; a.lo = pf->lo; a.n_local = pf->n_local;
+    a.M_inv = 1.0 / pf->N;                                           // particle_filter.cpp:89
+    a.r = (((double)rand_value) / (double)RAND_MAX) * a.M_inv;       // particle_filter.cpp:92
+    a.rot1 = pf->rot1; a.trans = pf->trans; a.rot2 = pf->rot2;
+    a.rot1Std = pf->rot1Std; a.transStd = pf->transStd; a.rot2Std = pf->rot2Std;
+    a.noise = noise ? pf->d_noise : nullptr;
+    a.seed_lo = (uint32_t)pf->noise_seed; a.seed_hi = (uint32_t)(pf->noise_seed >> 32);
+    a.step = pf->step;
+    a.resample = resample;
+    // MovingLaserScan(scan, parent_pose, pose): parent_pose.utime is the particle's previous pose utime, pose.utime is
+    // ActionModel::utime_ == 0 (D3); they differ only on the first moved update after initialisation.
+    a.interp = (map && pf->pose_utime != 0) ? 1 : 0;
+    int blocks = (pf->n_local + MCL_THREADS - 1) / MCL_THREADS;
+    hipEvent_t e0, e1;
+    int rc = bl_timer_begin(ctx, BL_K_MCL_MAIN, &e0, &e1);
+    if (rc) return rc;
+    if (a.interp) hipLaunchKernelGGL(k_mcl_main<1>, dim3(blocks), dim3(MCL_THREADS), 0, ctx->stream, a);
+    else hipLaunchKernelGGL(k_mcl_main<0>, dim3(blocks), dim3(MCL_THREADS), 0, ctx->stream, a);
+    BL_HIP(hipGetLastError());
+    rc = bl_timer_end(ctx, BL_K_MCL_MAIN, e0, e1);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_mcl_reduce, dim3(1), dim3(256), 0, ctx->stream, pf->partials, blocks, pf->sums);
+    BL_HIP(hipGetLastError());
+    return BL_OK;
+}
+
+extern "C" int bl_pf_update_begin(bl_pf* pf, const bl_pose_xyt_t* odometry, const bl_lidar_t* scan, const bl_grid* map,
+                                  int rand_value, const float* noise, int* moved)
+{
+    BL_CHECK_ARG(pf != nullptr && odometry != nullptr && scan != nullptr && map != nullptr);
+    if (!pf->initialized) { bl_set_error("bl_pf_update before bl_pf_init_at_pose / bl_pf_set_particles"); return BL_ERR_STATE; }
+    if (pf->pending_end) { bl_set_error("bl_pf_update_begin called twice without bl_pf_update_end"); return BL_ERR_STATE; }
+    BL_HIP(hipSetDevice(pf->ctx->device));
+    bool mv = action_update(pf, *odometry);
+    if (moved) *moved = mv ? 1 : 0;
+    pf->pending_utime = odometry->utime;
+    if (!mv) {
+        // posteriorPose_.utime = odometry.utime (particle_filter.cpp:50)
+        bl_pose_xyt_t p; p.utime = odometry->utime; p.x = p.y = p.theta = 0;
+        hipLaunchKernelGGL(k_pf_set_pose, dim3(1), dim3(1), 0, pf->ctx->stream, pf->state, p, 1);
+        BL_HIP(hipGetLastError());
+        return BL_OK;
+    }
+    int R = 0;
+    int rc = bl_scan_upload(pf->ctx, &pf->scan, scan, pf->pose_utime, 0 /* ActionModel::utime_ (D3) */, &R);
+    if (rc) return rc;
+    if (noise) { rc = pf_upload_noise(pf, noise); if (rc) return rc; }
+    rc = pf_launch_main(pf, map, R, rand_value, noise, 1);
+    if (rc) return rc;
+    pf->pending_end = true;
+    return BL_OK;
+}
+
+extern "C" int bl_pf_update_end(bl_pf* pf, bl_pose_xyt_t* out_pose)
+{
+    BL_CHECK_ARG(pf != nullptr);
+    BL_HIP(hipSetDevice(pf->ctx->device));
+    if (pf->pending_end) {
+        int rc = pf_scan(pf, pf->cur ^ 1, 1, pf->pending_utime);
+        if (rc) return rc;
+        pf->cur ^= 1;
+        pf->parent_utime = pf->pose_utime;       // parent_pose = sample.pose (action_model.cpp:92)
+        pf->pose_utime = 0;                      // pose.utime = utime_ (D3)
+        pf->step += 1;
+        pf->pending_end = false;
+    }
+    if (out_pose) return bl_pf_pose_estimate(pf, out_pose);
+    return BL_OK;
+}
+
+extern "C" int bl_pf_update(bl_pf* pf, const bl_pose_xyt_t* odometry, const bl_lidar_t* scan, const bl_grid* map,
+                            int rand_value, const float* noise, bl_pose_xyt_t* out_pose)
+{
+    int moved = 0;
+    int rc = bl_pf_update_begin(pf, odometry, scan, map, rand_value, noise, &moved);
+    if (rc) return rc;
+    return bl_pf_update_end(pf, out_pose);
+}
+
+extern "C" int bl_pf_update_action_only(bl_pf* pf, const bl_pose_xyt_t* odometry, const float* noise, bl_pose_xyt_t* out_pose)
+{
+    BL_CHECK_ARG(pf != nullptr && odometry != nullptr);
+    if (!pf->initialized || pf->pending_end) { bl_set_error("filter not initialised or update pending"); return BL_ERR_STATE; }
+    if (pf->n_local != pf->N) { bl_set_error("updateFilterActionOnly needs the whole particle set on one device"); return BL_ERR_ARG; }
+    BL_HIP(hipSetDevice(pf->ctx->device));
+    bool mv = action_update(pf, *odometry);
+    if (mv) {
+        if (noise) { int rc = pf_upload_noise(pf, noise); if (rc) return rc; }
+        int rc = pf_launch_main(pf, nullptr, 0, 0, noise, 0);     // proposal = applyAction(posterior_) (particle_filter.cpp:60-61)
+        if (rc) return rc;
+        rc = pf_scan(pf, pf->cur ^ 1, 0, 0);
+        if (rc) return rc;
+        pf->cur ^= 1;
+        pf->parent_utime = pf->pose_utime;
+        pf->pose_utime = 0;
+        pf->step += 1;
+    }
+    hipLaunchKernelGGL(k_pf_set_pose, dim3(1), dim3(1), 0, pf->ctx->stream, pf->state, *odometry, 0);   // posteriorPose_ = odometry
+    BL_HIP(hipGetLastError());
+    if (out_pose) *out_pose = *odometry;
+    return BL_OK;
+}
+
+extern "C" int bl_pf_pose_estimate(bl_pf* pf, bl_pose_xyt_t* out_pose)
+{
+    BL_CHECK_ARG(pf != nullptr && out_pose != nullptr && pf->state != nullptr);
+    BL_HIP(hipMemcpyAsync(out_pose, &pf->state->pose, sizeof(bl_pose_xyt_t), hipMemcpyDeviceToHost, pf->ctx->stream));
+    BL_HIP(hipStreamSynchronize(pf->ctx->stream));
+    return BL_OK;
+}
+
+extern "C" int bl_pf_debug_last(bl_pf* pf, int32_t* resample_idx, int32_t* likelihood_half_units)
+{
+    BL_CHECK_ARG(pf != nullptr && pf->dbg_idx != nullptr);
+    if (resample_idx)
+        BL_HIP(hipMemcpyAsync(resample_idx, pf->dbg_idx, (size_t)pf->n_local * 4, hipMemcpyDeviceToHost, pf->ctx->stream));
+    if (likelihood_half_units)
+        BL_HIP(hipMemcpyAsync(likelihood_half_units, pf->dbg_like, (size_t)pf->n_local * 4, hipMemcpyDeviceToHost, pf->ctx->stream));
+    BL_HIP(hipStreamSynchronize(pf->ctx->stream));
+    return BL_OK;
+}

@@ -1,0 +1,411 @@
+"""Host-side mirror of the reference's C++ surfaces for the hot path, over the C ABI of libbotlab_hip.so.
+
+Same names, argument meaning and error behaviour as the reference classes (the C++ drop-in with identical signatures
+lives in include/botlab/; this module is what the parity tests and bench.py drive):
+
+  OccupancyGrid          src/slam/occupancy_grid.hpp:51-209
+  Mapping                src/slam/mapping.hpp:25-34
+  ParticleFilter         src/slam/particle_filter.hpp:38-77
+  ObstacleDistanceGrid   src/planning/obstacle_distance_grid.hpp:28-96
+  search_for_path        src/planning/astar.hpp:58-61
+  MotionPlanner          src/planning/motion_planner.hpp:89-130 (setMap / planPath / isValidGoal / setParams)
+
+All arithmetic runs in the HIP library; nothing here computes a result on the CPU.
+"""
+import ctypes as C
+import math
+
+import numpy as np
+
+from . import _capi
+from ._capi import Lidar, Particle, Pose, SearchParams, check
+
+_libc = C.CDLL(None)
+_libc.rand.restype = C.c_int
+
+PARTICLE_DTYPE = np.dtype([("utime", "<i8"), ("x", "<f4"), ("y", "<f4"), ("theta", "<f4"), ("_pad0", "<f4"),
+                           ("p_utime", "<i8"), ("p_x", "<f4"), ("p_y", "<f4"), ("p_theta", "<f4"), ("_pad1", "<f4"),
+                           ("weight", "<f8")])
+POSE_DTYPE = np.dtype([("utime", "<i8"), ("x", "<f4"), ("y", "<f4"), ("theta", "<f4"), ("_pad", "<f4")])
+assert PARTICLE_DTYPE.itemsize == 56 and POSE_DTYPE.itemsize == 24
+
+
+def make_pose(x=0.0, y=0.0, theta=0.0, utime=0):
+    return Pose(int(utime), float(np.float32(x)), float(np.float32(y)), float(np.float32(theta)))
+
+
+class LidarScan:
+    """lidar_t (lcmtypes/lidar_t.lcm): utime, ranges[], thetas[], times[]."""
+
+    def __init__(self, ranges, thetas, times, utime=0):
+        self.ranges = np.ascontiguousarray(ranges, dtype=np.float32)
+        self.thetas = np.ascontiguousarray(thetas, dtype=np.float32)
+        self.times = np.ascontiguousarray(times, dtype=np.int64)
+        assert self.ranges.shape == self.thetas.shape == self.times.shape and self.ranges.ndim == 1
+        self.utime = int(utime)
+        self.num_ranges = int(self.ranges.size)
+
+    def as_c(self):
+        return Lidar(self.utime, self.num_ranges, self.ranges.ctypes.data_as(C.POINTER(C.c_float)),
+                     self.thetas.ctypes.data_as(C.POINTER(C.c_float)), self.times.ctypes.data_as(C.POINTER(C.c_int64)),
+                     None)
+
+
+class Context:
+    """One HIP stream's worth of state on one device (bl_ctx)."""
+
+    def __init__(self, device=0, stream=None):
+        self.lib = _capi.load()
+        h = C.c_void_p()
+        check(self.lib.bl_ctx_create(int(device), C.c_void_p(stream) if stream else None, C.byref(h)))
+        self.h = h
+        self.device = device
+
+    def sync(self):
+        check(self.lib.bl_ctx_sync(self.h))
+
+    def timing_enable(self, on=True):
+        check(self.lib.bl_ctx_timing_enable(self.h, 1 if on else 0))
+
+    def timing_reset(self):
+        check(self.lib.bl_ctx_timing_reset(self.h))
+
+    def timing_get(self, kernel_id):
+        ms, n = C.c_double(), C.c_int64()
+        check(self.lib.bl_ctx_timing_get(self.h, kernel_id, C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
+    def close(self):
+        if self.h:
+            self.lib.bl_ctx_destroy(self.h)
+            self.h = None
+
+
+_default_ctx = None
+
+
+def default_context():
+    global _default_ctx
+    if _default_ctx is None:
+        _default_ctx = Context(0)
+    return _default_ctx
+
+
+class OccupancyGrid:
+    """Device-resident int8 log-odds grid (occupancy_grid.hpp).  Float members follow the reference's float32
+    arithmetic (occupancy_grid.cpp:19-36)."""
+
+    def __init__(self, widthInMeters=None, heightInMeters=None, metersPerCell=0.05, ctx=None, _raw=None):
+        self.ctx = ctx or default_context()
+        lib = self.ctx.lib
+        if _raw is not None:
+            width, height, mpc, cpm, ox, oy = _raw
+        else:
+            assert widthInMeters > 0 and heightInMeters > 0            # occupancy_grid.cpp:25-28
+            mpc = np.float32(metersPerCell)
+            assert mpc <= np.float32(widthInMeters) and mpc <= np.float32(heightInMeters)
+            cpm = np.float32(1.0) / mpc
+            width = int(np.float32(widthInMeters) * cpm)
+            height = int(np.float32(heightInMeters) * cpm)
+            ox = -np.float32(widthInMeters) / np.float32(2.0)
+            oy = -np.float32(heightInMeters) / np.float32(2.0)
+        self.width, self.height = int(width), int(height)
+        self.mpc, self.cpm = np.float32(mpc), np.float32(cpm)
+        self.origin = (np.float32(ox), np.float32(oy))
+        h = C.c_void_p()
+        check(lib.bl_grid_create(self.ctx.h, self.width, self.height, self.mpc, self.cpm, self.origin[0], self.origin[1],
+                                 C.byref(h)))
+        self.h = h
+
+    @classmethod
+    def from_cells(cls, cells, origin, metersPerCell, cellsPerMeter=None, ctx=None):
+        """loadFromFile / fromLCM equivalent: cells is an (H, W) int8 array.  loadFromFile keeps the cellsPerMeter_ of
+        the default constructor (20.0f, occupancy_grid.cpp:9-16,138-175); fromLCM sets 1.0f/mpc (:99-108)."""
+        cells = np.ascontiguousarray(cells, dtype=np.int8)
+        hgt, wid = cells.shape
+        mpc = np.float32(metersPerCell)
+        cpm = np.float32(cellsPerMeter) if cellsPerMeter is not None else np.float32(1.0) / mpc
+        g = cls(ctx=ctx, _raw=(wid, hgt, mpc, cpm, np.float32(origin[0]), np.float32(origin[1])))
+        g.upload(cells)
+        return g
+
+    # accessors (occupancy_grid.hpp:80-91)
+    def widthInCells(self): return self.width
+    def heightInCells(self): return self.height
+    def metersPerCell(self): return self.mpc
+    def cellsPerMeter(self): return self.cpm
+    def originInGlobalFrame(self): return self.origin
+    def isCellInGrid(self, x, y): return 0 <= x < self.width and 0 <= y < self.height
+
+    def upload(self, cells):
+        cells = np.ascontiguousarray(cells, dtype=np.int8)
+        assert cells.shape == (self.height, self.width)
+        check(self.ctx.lib.bl_grid_upload(self.h, cells.ctypes.data))
+
+    def cells(self):
+        out = np.empty((self.height, self.width), dtype=np.int8)
+        check(self.ctx.lib.bl_grid_download(self.h, out.ctypes.data))
+        return out
+
+    def reset(self):
+        check(self.ctx.lib.bl_grid_reset(self.h))
+
+    def logOdds(self, x, y):
+        """Host read of one cell (downloads the grid; test convenience only)."""
+        return int(self.cells()[y, x]) if self.isCellInGrid(x, y) else 0
+
+    def saveToFile(self, filename):
+        """ASCII .map format (occupancy_grid.cpp:111-136)."""
+        c = self.cells()
+        with open(filename, "w") as f:
+            f.write(f"{_fmt(self.origin[0])} {_fmt(self.origin[1])} {self.width} {self.height} {_fmt(self.mpc)}\n")
+            for y in range(self.height):
+                f.write(" ".join(str(int(v)) for v in c[y]) + " \n")
+        return True
+
+    @classmethod
+    def loadFromFile(cls, filename, ctx=None):
+        with open(filename) as f:
+            tok = f.read().split()
+        ox, oy, w, h, mpc = np.float32(tok[0]), np.float32(tok[1]), int(tok[2]), int(tok[3]), np.float32(tok[4])
+        cells = np.array(tok[5:5 + w * h], dtype=np.int64).astype(np.int8).reshape(h, w)
+        return cls.from_cells(cells, (ox, oy), mpc, cellsPerMeter=np.float32(1.0 / np.float64(np.float32(0.05))), ctx=ctx)
+
+    def close(self):
+        if self.h:
+            self.ctx.lib.bl_grid_destroy(self.h)
+            self.h = None
+
+
+def _fmt(v):
+    return np.format_float_positional(np.float32(v), precision=6, unique=True, trim="-")
+
+
+class Mapping:
+    """Mapping(maxLaserDistance, hitOdds, missOdds).updateMap(scan, pose, map) (mapping.hpp:25-34)."""
+
+    def __init__(self, maxLaserDistance, hitOdds, missOdds, ctx=None):
+        self.ctx = ctx or default_context()
+        h = C.c_void_p()
+        check(self.ctx.lib.bl_mapping_create(self.ctx.h, np.float32(maxLaserDistance), int(hitOdds), int(missOdds), C.byref(h)))
+        self.h = h
+
+    def updateMap(self, scan, pose, grid):
+        ls = scan.as_c()
+        check(self.ctx.lib.bl_mapping_update(self.h, C.byref(ls), C.byref(pose), grid.h))
+
+    def updateMapDevicePose(self, scan, d_pose_ptr, pose_utime, grid):
+        ls = scan.as_c()
+        check(self.ctx.lib.bl_mapping_update_dev_pose(self.h, C.byref(ls), d_pose_ptr, int(pose_utime), grid.h))
+
+    def close(self):
+        if self.h:
+            self.ctx.lib.bl_mapping_destroy(self.h)
+            self.h = None
+
+
+class ParticleFilter:
+    """ParticleFilter(numParticles) (particle_filter.hpp:38-77).  shard=(lo, hi) keeps only those particles' private
+    state on this device (botlab_amd.sharded drives the exchange)."""
+
+    def __init__(self, numParticles, ctx=None, shard=None):
+        assert numParticles > 1                                         # particle_filter.cpp:11
+        self.ctx = ctx or default_context()
+        self.N = int(numParticles)
+        self.lo, self.hi = shard if shard else (0, self.N)
+        h = C.c_void_p()
+        check(self.ctx.lib.bl_pf_create(self.ctx.h, self.N, self.lo, self.hi, C.byref(h)))
+        self.h = h
+
+    def initializeFilterAtPose(self, pose, seed=None):
+        if seed is None:                                                # reference: std::random_device
+            seed = int.from_bytes(np.random.bytes(8), "little")
+        check(self.ctx.lib.bl_pf_init_at_pose(self.h, C.byref(pose), C.c_uint64(seed)))
+
+    def setParticles(self, particles, units=None):
+        """particles: structured array (PARTICLE_DTYPE) of all N particles."""
+        p = np.ascontiguousarray(particles)
+        assert p.dtype.itemsize == 56 and p.size == self.N
+        u = None
+        if units is not None:
+            u = np.ascontiguousarray(units, dtype=np.uint32)
+            assert u.size == self.N
+        check(self.ctx.lib.bl_pf_set_particles(self.h, p.ctypes.data, u.ctypes.data if u is not None else None))
+
+    def setNoiseSeed(self, seed):
+        check(self.ctx.lib.bl_pf_set_noise_seed(self.h, C.c_uint64(seed)))
+
+    def updateFilter(self, odometry, laser, grid, rand_value=None, noise=None, want_pose=True):
+        """pose_xyt_t updateFilter(odometry, laser, map).  rand_value defaults to libc rand(), as the reference's
+        resampler calls it (particle_filter.cpp:92); noise (3*N float32) replaces the Philox action noise."""
+        if rand_value is None:
+            rand_value = _libc.rand()
+        ls = laser.as_c()
+        nz = None
+        if noise is not None:
+            nz = np.ascontiguousarray(noise, dtype=np.float32)
+            assert nz.size == 3 * self.N
+        out = Pose()
+        check(self.ctx.lib.bl_pf_update(self.h, C.byref(odometry), C.byref(ls), grid.h, int(rand_value),
+                                        nz.ctypes.data if nz is not None else None, C.byref(out) if want_pose else None))
+        return out if want_pose else None
+
+    def updateBegin(self, odometry, laser, grid, rand_value, noise=None):
+        ls = laser.as_c()
+        nz = None
+        if noise is not None:
+            nz = np.ascontiguousarray(noise, dtype=np.float32)
+        moved = C.c_int()
+        check(self.ctx.lib.bl_pf_update_begin(self.h, C.byref(odometry), C.byref(ls), grid.h, int(rand_value),
+                                              nz.ctypes.data if nz is not None else None, C.byref(moved)))
+        return bool(moved.value)
+
+    def updateEnd(self, want_pose=True):
+        out = Pose()
+        check(self.ctx.lib.bl_pf_update_end(self.h, C.byref(out) if want_pose else None))
+        return out if want_pose else None
+
+    def updateFilterActionOnly(self, odometry, noise=None):
+        nz = None
+        if noise is not None:
+            nz = np.ascontiguousarray(noise, dtype=np.float32)
+        out = Pose()
+        check(self.ctx.lib.bl_pf_update_action_only(self.h, C.byref(odometry), nz.ctypes.data if nz is not None else None,
+                                                    C.byref(out)))
+        return out
+
+    def poseEstimate(self):
+        out = Pose()
+        check(self.ctx.lib.bl_pf_pose_estimate(self.h, C.byref(out)))
+        return out
+
+    def poseDevicePtr(self):
+        return self.ctx.lib.bl_pf_pose_device_ptr(self.h)
+
+    def particles(self):
+        """particles_t.particles of the local shard as a structured array."""
+        out = np.zeros(self.hi - self.lo, dtype=PARTICLE_DTYPE)
+        check(self.ctx.lib.bl_pf_get_particles(self.h, out.ctypes.data))
+        return out
+
+    def debugLast(self):
+        n = self.hi - self.lo
+        idx = np.empty(n, np.int32)
+        like = np.empty(n, np.int32)
+        check(self.ctx.lib.bl_pf_debug_last(self.h, idx.ctypes.data, like.ctypes.data))
+        return idx, like
+
+    def close(self):
+        if self.h:
+            self.ctx.lib.bl_pf_destroy(self.h)
+            self.h = None
+
+
+class ObstacleDistanceGrid:
+    """ObstacleDistanceGrid().setDistances(map); operator()(x, y) (obstacle_distance_grid.hpp:28-96)."""
+
+    def __init__(self, ctx=None):
+        self.ctx = ctx or default_context()
+        h = C.c_void_p()
+        check(self.ctx.lib.bl_dist_create(self.ctx.h, C.byref(h)))
+        self.h = h
+        self._host = None
+
+    def setDistances(self, grid):
+        check(self.ctx.lib.bl_dist_set_distances(self.h, grid.h))
+        self._host = None
+
+    def shape(self):
+        w, h = C.c_int(), C.c_int()
+        check(self.ctx.lib.bl_dist_shape(self.h, C.byref(w), C.byref(h)))
+        return w.value, h.value
+
+    def widthInCells(self): return self.shape()[0]
+    def heightInCells(self): return self.shape()[1]
+
+    def frame(self):
+        v = [C.c_float() for _ in range(4)]
+        check(self.ctx.lib.bl_dist_frame(self.h, *[C.byref(x) for x in v]))
+        return tuple(np.float32(x.value) for x in v)      # mpc, cpm, ox, oy
+
+    def cells(self):
+        if self._host is None:
+            w, h = self.shape()
+            out = np.empty((h, w), dtype=np.float32)
+            check(self.ctx.lib.bl_dist_download(self.h, out.ctypes.data))
+            self._host = out
+        return self._host
+
+    def isCellInGrid(self, x, y):
+        w, h = self.shape()
+        return 0 <= x < w and 0 <= y < h
+
+    def __call__(self, x, y):
+        return self.cells()[y, x]
+
+    def close(self):
+        if self.h:
+            self.ctx.lib.bl_dist_destroy(self.h)
+            self.h = None
+
+
+def search_for_path(start, goal, distances, params, return_stats=False, cap=1 << 20):
+    """robot_path_t search_for_path(start, goal, distances, params) (astar.hpp:58-61).  Returns the list of poses
+    (path_length == len(result); length 1 == no path)."""
+    ctx = distances.ctx
+    buf = (Pose * cap)()
+    n = C.c_int()
+    stats = (C.c_int64 * 2)()
+    check(ctx.lib.bl_astar_search(ctx.h, distances.h, C.byref(start), C.byref(goal), C.byref(params), buf, cap, C.byref(n), stats))
+    path = [Pose(p.utime, p.x, p.y, p.theta) for p in buf[:min(n.value, cap)]]
+    if return_stats:
+        return path, (stats[0], stats[1])
+    return path
+
+
+class MotionPlannerParams:
+    def __init__(self, robotRadius=0.2):                                 # motion_planner.hpp:27-35
+        self.robotRadius = float(robotRadius)
+
+
+class MotionPlanner:
+    """MotionPlanner (motion_planner.cpp:9-110): setMap, planPath, isValidGoal, setParams quirks included."""
+
+    def __init__(self, params=None, ctx=None):
+        self.params_ = params or MotionPlannerParams()
+        self.distances_ = ObstacleDistanceGrid(ctx=ctx)
+        self.searchParams_ = SearchParams()
+        self.num_frontiers = 1           # uninitialised in the reference (motion_planner.hpp:164); callers set it
+        self.prev_goal = make_pose(1e9, 1e9, 0.0)
+        self.setParams(self.params_)
+
+    def setParams(self, params):
+        # motion_planner.cpp:105-110 reads params_ (the constructor's copy), not the argument
+        self.searchParams_.minDistanceToObstacle = self.params_.robotRadius
+        self.searchParams_.maxDistanceWithCost = 10.0 * self.searchParams_.minDistanceToObstacle
+        self.searchParams_.distanceCostExponent = 1.0
+
+    def setMap(self, grid):
+        self.distances_.setDistances(grid)
+
+    def setPrevGoal(self, goal): self.prev_goal = goal
+    def setNumFrontiers(self, n): self.num_frontiers = int(n)
+
+    def isValidGoal(self, goal):
+        # motion_planner.cpp:52-74
+        dx = np.float32(goal.x) - np.float32(self.prev_goal.x)
+        dy = np.float32(goal.y) - np.float32(self.prev_goal.y)
+        dist_prev = np.sqrt(np.float32(dx * dx + dy * dy), dtype=np.float32)
+        if self.num_frontiers != 1 and float(dist_prev) < 2 * self.searchParams_.minDistanceToObstacle:
+            return False
+        mpc, cpm, ox, oy = self.distances_.frame()
+        gx = int((float(np.float32(goal.x)) - float(ox)) * float(cpm))
+        gy = int((float(np.float32(goal.y)) - float(oy)) * float(cpm))
+        if self.distances_.isCellInGrid(gx, gy):
+            return float(self.distances_(gx, gy)) > self.params_.robotRadius
+        return False
+
+    def planPath(self, start, goal, searchParams=None):
+        if not self.isValidGoal(goal):
+            return [Pose(start.utime, start.x, start.y, start.theta)]   # failedPath (motion_planner.cpp:28-40)
+        return search_for_path(start, goal, self.distances_, searchParams or self.searchParams_)

@@ -1,0 +1,174 @@
+/* botlab_hip.h -- C ABI of libbotlab_hip.so: the MI355X (gfx950) implementation of botLab's SLAM / MCL / planning
+ * hot path.  Plain C, POD arguments, caller-owned buffers, int status returns (0 = ok), no exceptions, no torch types.
+ *
+ * Each entry point names the reference interface it stands in for (paths relative to the botLab checkout).  The C++
+ * classes in include/botlab/ (OccupancyGrid, Mapping, ParticleFilter, ObstacleDistanceGrid, search_for_path) keep the
+ * reference's signatures and forward to these calls; INTEGRATION.md shows the binding.
+ *
+ * Threading: one bl_ctx per host thread (the reference touches Mapping / ParticleFilter / map_ only from the runSLAM
+ * thread, src/slam/slam_main.cpp:56-58).  All work of a ctx is stream-ordered on ONE HIP stream (its own, or a
+ * caller-supplied one); calls return after enqueueing unless they hand a result back to host memory, in which case
+ * they synchronise that stream first.
+ */
+#ifndef BOTLAB_HIP_H
+#define BOTLAB_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ------------------------------------------------------------------ status */
+#define BL_OK 0
+#define BL_ERR_HIP 1        /* a HIP runtime call failed; text in bl_last_error() */
+#define BL_ERR_ARG 2        /* bad argument (null handle, shape mismatch, out-of-range parameter) */
+#define BL_ERR_CAPACITY 3   /* a device-side work list (A* open list) ran out of its configured capacity */
+#define BL_ERR_STATE 4      /* call order violated (e.g. update before init) */
+
+const char* bl_last_error(void);          /* thread-local message of the last failing call */
+const char* bl_version(void);
+
+/* ------------------------------------------------------------------ message records (in-memory layout of the
+ * lcm-gen structs the reference passes around; field order from the lcmtypes .lcm files) */
+typedef struct bl_pose_xyt_t {            /* lcmtypes/pose_xyt_t.lcm:1-8 ; 24 bytes */
+    int64_t utime;
+    float x, y, theta;
+} bl_pose_xyt_t;
+
+typedef struct bl_particle_t {            /* lcmtypes/particle_t.lcm:4-9 ; 56 bytes */
+    bl_pose_xyt_t pose;
+    bl_pose_xyt_t parent_pose;
+    double weight;
+} bl_particle_t;
+
+typedef struct bl_lidar_t {               /* lcmtypes/lidar_t.lcm:1-14 ; arrays are HOST pointers, num_ranges long */
+    int64_t utime;
+    int32_t num_ranges;
+    const float* ranges;
+    const float* thetas;
+    const int64_t* times;
+    const float* intensities;             /* may be NULL (unused on the hot path) */
+} bl_lidar_t;
+
+typedef struct bl_search_params_t {       /* src/planning/astar.hpp:15-27 */
+    double minDistanceToObstacle;
+    double maxDistanceWithCost;
+    double distanceCostExponent;
+} bl_search_params_t;
+
+/* ------------------------------------------------------------------ context */
+typedef struct bl_ctx bl_ctx;
+
+/* device: HIP device ordinal.  stream: NULL -> the ctx creates its own non-blocking stream; otherwise a hipStream_t
+ * owned by the caller (e.g. torch's current stream, so collectives issued by the caller order with this ctx). */
+int bl_ctx_create(int device, void* stream, bl_ctx** out);
+void bl_ctx_destroy(bl_ctx* ctx);
+int bl_ctx_sync(bl_ctx* ctx);
+/* Per-kernel HIP-event timing on the ctx stream (bench.py's roofline leg).  kernel ids: BL_K_* below. */
+int bl_ctx_timing_enable(bl_ctx* ctx, int on);
+int bl_ctx_timing_get(bl_ctx* ctx, int kernel_id, double* total_ms, int64_t* launches);
+int bl_ctx_timing_reset(bl_ctx* ctx);
+#define BL_K_MCL_MAIN 0      /* resample-gather + action + sensor model, one thread per particle */
+#define BL_K_MCL_SCAN 1      /* weight prefix scan + pose estimate (3 small launches, timed together) */
+#define BL_K_MAP 2           /* Mapping::updateMap */
+#define BL_K_DIST 3          /* ObstacleDistanceGrid::setDistances (2 launches, timed together) */
+#define BL_K_ASTAR 4         /* search_for_path */
+#define BL_K_COUNT 5
+
+/* ------------------------------------------------------------------ OccupancyGrid  (src/slam/occupancy_grid.hpp:51-209)
+ * Device-resident int8 log-odds cells, row-major y*width+x.  meters_per_cell and cells_per_meter are both carried
+ * because the reference carries both (occupancy_grid.cpp:19-36 computes cpm = 1.0f/mpc; loadFromFile :138-175 does
+ * not touch cpm). */
+typedef struct bl_grid bl_grid;
+int bl_grid_create(bl_ctx* ctx, int width, int height, float meters_per_cell, float cells_per_meter,
+                   float origin_x, float origin_y, bl_grid** out);       /* cells zeroed (reset(), :48-52) */
+void bl_grid_destroy(bl_grid* g);
+int bl_grid_upload(bl_grid* g, const int8_t* cells);                     /* host -> device, width*height bytes */
+int bl_grid_download(bl_grid* g, int8_t* cells);                         /* device -> host (synchronises) */
+int bl_grid_reset(bl_grid* g);                                           /* OccupancyGrid::reset */
+int bl_grid_set_frame(bl_grid* g, float meters_per_cell, float cells_per_meter, float origin_x, float origin_y);
+int bl_grid_copy(bl_grid* dst, const bl_grid* src);                      /* device -> device, same shape */
+void* bl_grid_device_ptr(bl_grid* g);                                    /* int8_t* in HBM */
+int bl_grid_shape(const bl_grid* g, int* width, int* height);
+
+/* ------------------------------------------------------------------ Mapping  (src/slam/mapping.hpp:25-34, mapping.cpp:8-127) */
+typedef struct bl_mapping bl_mapping;
+/* 0 <= hit_odds, miss_odds <= 127 */
+int bl_mapping_create(bl_ctx* ctx, float max_laser_distance, int8_t hit_odds, int8_t miss_odds, bl_mapping** out);
+void bl_mapping_destroy(bl_mapping* m);
+/* Mapping::updateMap(scan, pose, map): first call ever latches the pose and changes no cell (initialized_). */
+int bl_mapping_update(bl_mapping* m, const bl_lidar_t* scan, const bl_pose_xyt_t* pose, bl_grid* map);
+/* Same, the pose read from device memory (the particle filter's estimate of this step) -- no host round trip. */
+int bl_mapping_update_dev_pose(bl_mapping* m, const bl_lidar_t* scan, const void* d_pose /* bl_pose_xyt_t* */,
+                               int64_t pose_utime, bl_grid* map);
+
+/* ------------------------------------------------------------------ ParticleFilter  (src/slam/particle_filter.hpp:38-77)
+ * Particles [shard_lo, shard_hi) of num_particles live on this device; the exchange record of all num_particles
+ * (x, y, theta, weight-units: 16 bytes each) is replicated.  Single GPU: shard = [0, N). */
+typedef struct bl_pf bl_pf;
+int bl_pf_create(bl_ctx* ctx, int num_particles, int shard_lo, int shard_hi, bl_pf** out);
+void bl_pf_destroy(bl_pf* pf);
+/* Optional, before init: use caller-allocated device buffers for the two exchange records (each num_particles*16 B)
+ * and the partial sums (8 doubles) so a caller can run collectives on them without copies. */
+int bl_pf_set_exchange_buffers(bl_pf* pf, void* d_rec0, void* d_rec1, void* d_sums);
+void* bl_pf_exchange_rec_ptr(bl_pf* pf);     /* the record written by the last update_begin (all N; own slice filled) */
+void* bl_pf_exchange_sums_ptr(bl_pf* pf);    /* 8 doubles: units, units*x, units*y, units*sin, units*cos, 0,0,0 */
+/* initializeFilterAtPose (particle_filter.cpp:16-34): N(pose, 0.01) per coordinate from a counter-based Philox stream
+ * keyed by seed (reference: std::random_device), last particle = pose, weights 1/N. */
+int bl_pf_init_at_pose(bl_pf* pf, const bl_pose_xyt_t* pose, uint64_t seed);
+/* Replace the whole posterior from a host AoS array of num_particles records (weights must be uniform or the
+ * weight-unit integers in `units` given; units == NULL -> uniform). */
+int bl_pf_set_particles(bl_pf* pf, const bl_particle_t* particles, const uint32_t* units);
+/* particles(): the local shard as lcm particle_t records (synchronises). */
+int bl_pf_get_particles(bl_pf* pf, bl_particle_t* out_local);
+/* noise source of the action model: seed for the Philox stream used when update() gets noise == NULL */
+int bl_pf_set_noise_seed(bl_pf* pf, uint64_t seed);
+
+/* updateFilter (particle_filter.cpp:37-52), single GPU or replicated-call form.
+ *   rand_value: the value the reference takes from rand() for the low-variance sampler (particle_filter.cpp:92).
+ *   noise: NULL -> Philox; else HOST array of 3*num_particles floats (sampledRot1, sampledTrans, sampledRot2 per
+ *          output particle, global index order) -- the parity mode.
+ *   out_pose may be NULL (pose stays on device, see bl_pf_pose_device_ptr). */
+int bl_pf_update(bl_pf* pf, const bl_pose_xyt_t* odometry, const bl_lidar_t* scan, const bl_grid* map, int rand_value,
+                 const float* noise, bl_pose_xyt_t* out_pose);
+/* Sharded form: begin enqueues action + sensor model for the shard and fills its slice of the exchange record and
+ * its partial sums; the caller then all-gathers the record and all-reduces the sums; end scans the weights of all
+ * N particles and forms the pose estimate.  *moved == 0 -> nothing was enqueued (robot did not move). */
+int bl_pf_update_begin(bl_pf* pf, const bl_pose_xyt_t* odometry, const bl_lidar_t* scan, const bl_grid* map,
+                       int rand_value, const float* noise, int* moved);
+int bl_pf_update_end(bl_pf* pf, bl_pose_xyt_t* out_pose);
+/* updateFilterActionOnly (particle_filter.cpp:54-65) */
+int bl_pf_update_action_only(bl_pf* pf, const bl_pose_xyt_t* odometry, const float* noise, bl_pose_xyt_t* out_pose);
+int bl_pf_pose_estimate(bl_pf* pf, bl_pose_xyt_t* out_pose);              /* poseEstimate() (synchronises) */
+const void* bl_pf_pose_device_ptr(bl_pf* pf);                             /* bl_pose_xyt_t in HBM */
+/* diagnostics for the parity tests: resample source index and raw likelihood (half-units) of the local shard */
+int bl_pf_debug_last(bl_pf* pf, int32_t* resample_idx, int32_t* likelihood_half_units);
+
+/* ------------------------------------------------------------------ ObstacleDistanceGrid  (src/planning/obstacle_distance_grid.hpp:28-96) */
+typedef struct bl_dist bl_dist;
+int bl_dist_create(bl_ctx* ctx, bl_dist** out);
+void bl_dist_destroy(bl_dist* d);
+int bl_dist_set_distances(bl_dist* d, const bl_grid* map);                /* setDistances(map), obstacle_distance_grid.cpp:73-91 */
+int bl_dist_download(bl_dist* d, float* cells);                           /* width*height floats (synchronises) */
+int bl_dist_shape(const bl_dist* d, int* width, int* height);
+int bl_dist_frame(const bl_dist* d, float* meters_per_cell, float* cells_per_meter, float* origin_x, float* origin_y);
+void* bl_dist_device_ptr(bl_dist* d);                                     /* float* in HBM */
+
+/* ------------------------------------------------------------------ search_for_path  (src/planning/astar.hpp:58-61, astar.cpp:9-274)
+ * out_path[0] is always the start pose; *out_len == 1 means "no path" (lcmtypes/robot_path_t.lcm:7).  If the path is
+ * longer than cap, *out_len is the full length and only cap poses are written.  stats (optional, 2 x int64): pops,
+ * pushes.  open_capacity (nodes) bounds the device open list; 0 -> default. */
+int bl_astar_search(bl_ctx* ctx, const bl_dist* distances, const bl_pose_xyt_t* start, const bl_pose_xyt_t* goal,
+                    const bl_search_params_t* params, bl_pose_xyt_t* out_path, int cap, int* out_len, int64_t* stats);
+int bl_astar_set_open_capacity(bl_ctx* ctx, int64_t nodes);
+/* Asynchronous form for step pipelines: enqueue the search, fetch the result later. */
+int bl_astar_search_async(bl_ctx* ctx, const bl_dist* distances, const bl_pose_xyt_t* start, const bl_pose_xyt_t* goal,
+                          const bl_search_params_t* params);
+int bl_astar_search_result(bl_ctx* ctx, bl_pose_xyt_t* out_path, int cap, int* out_len, int64_t* stats);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BOTLAB_HIP_H */

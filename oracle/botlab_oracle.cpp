@@ -1,0 +1,693 @@
+// botlab_oracle.cpp -- CPU ORACLE (TEST INFRASTRUCTURE, NOT PRODUCT CODE).
+//
+// A plain, serial C++ restatement of the botLab SLAM / MCL / planning hot path, written from a reading of the
+// reference sources; every function cites the reference file:line it follows (paths relative to /root/reference).
+// Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library.  The product
+// (botlab_amd/csrc, include/) never includes, links or calls anything in oracle/.
+//
+// PARITY PIN STATUS (see DESIGN.md "Oracle"):
+//   * The reference hot path is UNBUILDABLE in this image: every .cpp on the path includes lcm-gen generated
+//     headers (lcmtypes/*.hpp) and LCM is not installed; writing stand-ins for generated code is not allowed.
+//   * Pinned by the reference's own tests/fixtures: ObstacleDistanceGrid (src/planning/obstacle_distance_grid_test.cpp
+//     :58-196, three assertions) and search_for_path/MotionPlanner (src/planning/astar_test.cpp fixtures
+//     data/astar/*.map + *_poses.txt: shouldExist + is_valid_path clearance).  Pinned by compiling the reference's
+//     self-contained header templates (oracle/_ref): wrap_to_pi, angle_diff, angle_sum, interpolate_pose_by_time.
+//   * PARITY UNPINNED: Mapping, MovingLaserScan assembly, ActionModel, SensorModel, ParticleFilter -- the reference
+//     holds no test, golden vector or fixture for them (its .log inputs are missing from the checkout), so these
+//     restatements are pinned only by line-by-line reading.
+//
+// Definitions adopted where the reference has undefined behaviour (each is part of the parity contract):
+//   D1  pose_xyt_t locals are zero-initialised (estimatePosteriorPose accumulates from 0; particle_filter.cpp:146).
+//   D2  initial particle weights are 1.0/N (reference: integer division 1/N == 0 -> resampler walks off the end;
+//       particle_filter.cpp:18,94-99).
+//   D3  ActionModel::utime_ (never initialised, action_model.hpp:72) is 0.
+//   D4  the resampler index is clamped to N-1 (particle_filter.cpp:96-99 has no bound).
+//   D5  search_for_path with an exhausted open list (falls off the end, astar.cpp:136-137) returns the 1-pose path;
+//       isValid() of an off-grid cell (reads before its bounds check, astar.cpp:140-149) is false.
+//   D6  poses appended by makePath carry utime 0 (uninitialised in astar.cpp:250).
+//   D7  MotionPlanner::num_frontiers / prev_goal (uninitialised, motion_planner.hpp:164-165) are passed explicitly.
+
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+#include <limits>
+#include <queue>
+#include <random>
+#include <stack>
+#include <vector>
+
+extern "C" {
+
+// lcmtypes/pose_xyt_t.lcm:1-8 (int64 utime; float x, y, theta) -> 24 bytes with tail padding
+struct orc_pose_t { int64_t utime; float x, y, theta; };
+// lcmtypes/particle_t.lcm:4-9 -> 56 bytes
+struct orc_particle_t { orc_pose_t pose; orc_pose_t parent_pose; double weight; };
+// occupancy grid view: src/slam/occupancy_grid.hpp:196-208 (row-major y*width+x, int8 cells)
+struct orc_grid_t { int32_t width, height; float meters_per_cell, cells_per_meter, origin_x, origin_y; int8_t* cells; };
+// distance grid view: src/planning/obstacle_distance_grid.hpp:72-84
+struct orc_dist_t { int32_t width, height; float meters_per_cell, cells_per_meter, origin_x, origin_y; float* cells; };
+// lcmtypes/lidar_t.lcm:1-14 (SoA view)
+struct orc_lidar_t { int64_t utime; int32_t num_ranges; const float* ranges; const float* thetas; const int64_t* times; };
+// src/slam/moving_laser_scan.hpp:15-20
+struct orc_ray_t { float ox, oy, range, theta; };
+// src/planning/astar.hpp:15-27
+struct orc_search_params_t { double minDistanceToObstacle, maxDistanceWithCost, distanceCostExponent; };
+
+}  // extern "C"
+
+namespace {
+
+// ---------------------------------------------------------------- src/common/angle_functions.hpp
+// :12-24
+inline float wrap_to_pi(float angle)
+{
+    if (angle < -M_PI) { for (; angle < -M_PI; angle += 2.0 * M_PI); }
+    else if (angle > M_PI) { for (; angle > M_PI; angle -= 2.0 * M_PI); }
+    return angle;
+}
+// :78-87
+inline double angle_diff(double l, double r)
+{
+    double diff = l - r;
+    if (fabs(diff) > M_PI) diff -= (diff > 0) ? M_PI * 2 : M_PI * -2;
+    return diff;
+}
+// :128-138
+inline double angle_sum(double a, double b)
+{
+    double sum = a + b;
+    if (fabs(sum) > M_PI) sum -= (sum > 0) ? M_PI * 2 : M_PI * -2;
+    return sum;
+}
+
+// ---------------------------------------------------------------- src/common/interpolation.hpp:23-50
+inline orc_pose_t interpolate_pose_by_time(int64_t time, const orc_pose_t& before, const orc_pose_t& after)
+{
+    if (before.utime == after.utime) {
+        orc_pose_t p = after;
+        p.utime = time;
+        return p;
+    }
+    double ratio = static_cast<double>(time - before.utime) / static_cast<double>(after.utime - before.utime);
+    double xStep = (after.x - before.x) * ratio;   // float subtraction, then double product
+    double yStep = (after.y - before.y) * ratio;
+    double thetaStep = angle_diff(after.theta, before.theta) * ratio;
+    orc_pose_t out;
+    out.utime = time;
+    out.x = before.x + xStep;       // double sum narrowed to float
+    out.y = before.y + yStep;
+    out.theta = angle_sum(before.theta, thetaStep);
+    return out;
+}
+
+// ---------------------------------------------------------------- src/slam/occupancy_grid.cpp
+inline bool in_grid(const orc_grid_t& g, int x, int y)   // :56-61
+{
+    return (x >= 0) && (x < g.width) && (y >= 0) && (y < g.height);
+}
+inline int8_t log_odds(const orc_grid_t& g, int x, int y)   // :63-71
+{
+    return in_grid(g, x, y) ? g.cells[y * g.width + x] : 0;
+}
+
+// src/common/grid_utils.hpp:49-55 -- double arithmetic on float members, caller narrows to Point<float>
+inline void global_to_grid_position(float gx, float gy, const orc_grid_t& g, float* px, float* py)
+{
+    double x = (static_cast<double>(gx) - static_cast<double>(g.origin_x)) * static_cast<double>(g.cells_per_meter);
+    double y = (static_cast<double>(gy) - static_cast<double>(g.origin_y)) * static_cast<double>(g.cells_per_meter);
+    *px = static_cast<float>(x);
+    *py = static_cast<float>(y);
+}
+
+// ---------------------------------------------------------------- src/slam/moving_laser_scan.cpp:8-39
+std::vector<orc_ray_t> moving_laser_scan(const orc_lidar_t& scan, const orc_pose_t& begin, const orc_pose_t& end)
+{
+    std::vector<orc_ray_t> rays;
+    if (scan.num_ranges > 0) {
+        for (int n = 0; n < scan.num_ranges; ++n) {           // rayStride == 1 at every call site
+            if (scan.ranges[n] > 0.15f) {
+                orc_pose_t rayPose = interpolate_pose_by_time(scan.times[n], begin, end);
+                orc_ray_t ray;
+                ray.ox = rayPose.x;
+                ray.oy = rayPose.y;
+                ray.range = scan.ranges[n];
+                ray.theta = wrap_to_pi(rayPose.theta - scan.thetas[n]);
+                rays.push_back(ray);
+            }
+        }
+    }
+    return rays;
+}
+
+// ---------------------------------------------------------------- src/slam/mapping.cpp
+struct Mapping {
+    float maxLaser; int8_t hit, miss; bool initialized; orc_pose_t prev;
+
+    void increase(orc_grid_t& m, int x, int y)     // :73-85
+    {
+        int8_t& c = m.cells[y * m.width + x];
+        if (!initialized) {}
+        else if (std::numeric_limits<int8_t>::max() - c > hit) c += hit;
+        else c = std::numeric_limits<int8_t>::max();
+    }
+    void decrease(orc_grid_t& m, int x, int y)     // :87-99
+    {
+        int8_t& c = m.cells[y * m.width + x];
+        if (!initialized) {}
+        else if (c - miss > std::numeric_limits<int8_t>::min()) c -= miss;
+        else c = std::numeric_limits<int8_t>::min();
+    }
+    static void ray_cell(const orc_ray_t& ray, const orc_grid_t& m, float* sx, float* sy, int* cx, int* cy)   // :45-49
+    {
+        global_to_grid_position(ray.ox, ray.oy, m, sx, sy);
+        *cx = static_cast<int>((ray.range * std::cos(ray.theta) * m.cells_per_meter) + *sx);   // float cosf
+        *cy = static_cast<int>((ray.range * std::sin(ray.theta) * m.cells_per_meter) + *sy);
+    }
+    void bresenham(int x1, int y1, int x2, int y2, orc_grid_t& m)   // :101-127
+    {
+        int dx, dy, sx, sy, err, x, y;
+        float e2;
+        dx = std::abs(x2 - x1);
+        dy = std::abs(y2 - y1);
+        sx = x1 < x2 ? 1 : -1;
+        sy = y1 < y2 ? 1 : -1;
+        err = dx - dy;
+        x = x1; y = y1;
+        while (x != x2 || y != y2) {
+            if (in_grid(m, x, y)) decrease(m, x, y);
+            e2 = 2 * err;
+            if (e2 >= -dy) { err -= dy; x += sx; }
+            if (e2 <= dx) { err += dx; y += sy; }
+        }
+    }
+    void update(const orc_lidar_t& scan, const orc_pose_t& pose, orc_grid_t& m)   // :17-40
+    {
+        if (!initialized) prev = pose;
+        std::vector<orc_ray_t> rays = moving_laser_scan(scan, prev, pose);
+        for (auto& ray : rays) {                       // endpoint pass :42-57
+            if (ray.range <= maxLaser) {
+                float sx, sy; int cx, cy;
+                ray_cell(ray, m, &sx, &sy, &cx, &cy);
+                if (in_grid(m, cx, cy)) increase(m, cx, cy);
+            }
+        }
+        for (auto& ray : rays) {                       // free-space pass :59-71
+            if (ray.range <= maxLaser) {
+                float sx, sy; int cx, cy;
+                ray_cell(ray, m, &sx, &sy, &cx, &cy);
+                bresenham(static_cast<int>(sx), static_cast<int>(sy), cx, cy, m);   // float -> int truncation
+            }
+        }
+        initialized = true;
+        prev = pose;
+    }
+};
+
+// ---------------------------------------------------------------- src/slam/action_model.cpp
+struct ActionModel {
+    orc_pose_t prevOdom; double rot1, trans, rot2; bool moved, initialized; int64_t utime;
+    double rot1Std, transStd, rot2Std;
+    std::mt19937 gen;                                   // default seed 5489 (action_model.hpp:78, never seeded)
+
+    ActionModel() : rot1(0), trans(0), rot2(0), moved(false), initialized(false), utime(0) /* D3 */,
+                    rot1Std(0), transStd(0), rot2Std(0) { std::memset(&prevOdom, 0, sizeof(prevOdom)); }
+
+    bool update(const orc_pose_t& odometry)             // :22-75
+    {
+        if (!initialized) { prevOdom = odometry; initialized = true; }
+        float deltaX = odometry.x - prevOdom.x;
+        float deltaY = odometry.y - prevOdom.y;
+        float deltaTheta = angle_diff(odometry.theta, prevOdom.theta);
+        float dir = 1.0;
+        rot1 = angle_diff(std::atan2(deltaY, deltaX), prevOdom.theta);    // atan2f
+        trans = std::sqrt(deltaX * deltaX + deltaY * deltaY);             // sqrtf
+        if (std::abs(trans) < 0.0001) { rot1 = 0.0f; }
+        else if (std::abs(rot1) > M_PI / 2.0) { rot1 = -angle_diff(M_PI, rot1); dir = -1.0; }
+        else if (std::abs(rot1) < -M_PI / 2.0) { rot1 = -angle_diff(-M_PI, rot1); dir = -1.0; }   // dead branch
+        trans *= dir;
+        rot2 = angle_diff(deltaTheta, rot1);
+        moved = !((fabs(trans) + fabs(rot2)) < 0.00001f);
+        rot1Std = 0.05; transStd = 0.005; rot2Std = 0.05;
+        prevOdom = odometry;
+        return moved;
+    }
+    // :78-103.  noise3 (optional) receives the three float samples actually drawn.
+    orc_particle_t apply(const orc_particle_t& sample, float* noise3)
+    {
+        orc_particle_t ns = sample;
+        if (moved) {
+            float sampledRot1 = std::normal_distribution<>(rot1, rot1Std)(gen);
+            float sampledTrans = std::normal_distribution<>(trans, transStd)(gen);
+            float sampledRot2 = std::normal_distribution<>(rot2, rot2Std)(gen);
+            if (noise3) { noise3[0] = sampledRot1; noise3[1] = sampledTrans; noise3[2] = sampledRot2; }
+            // unqualified cos/sin of a float sum: ::cos(double) from <cmath> -> double libm
+            ns.pose.x += sampledTrans * ::cos(static_cast<double>(sample.pose.theta + sampledRot1));
+            ns.pose.y += sampledTrans * ::sin(static_cast<double>(sample.pose.theta + sampledRot1));
+            ns.pose.theta = wrap_to_pi(sample.pose.theta + sampledRot1 + sampledRot2);
+        }
+        ns.pose.utime = utime;
+        ns.parent_pose = sample.pose;
+        return ns;
+    }
+    // same arithmetic with externally supplied samples (used to drive the GPU parity mode from recorded noise)
+    orc_particle_t apply_with_noise(const orc_particle_t& sample, const float* n3)
+    {
+        orc_particle_t ns = sample;
+        if (moved) {
+            ns.pose.x += n3[1] * ::cos(static_cast<double>(sample.pose.theta + n3[0]));
+            ns.pose.y += n3[1] * ::sin(static_cast<double>(sample.pose.theta + n3[0]));
+            ns.pose.theta = wrap_to_pi(sample.pose.theta + n3[0] + n3[2]);
+        }
+        ns.pose.utime = utime;
+        ns.parent_pose = sample.pose;
+        return ns;
+    }
+};
+
+// ---------------------------------------------------------------- src/slam/sensor_model.cpp
+int get_cell_odds(int x1, int y1, int x2, int y2, const orc_grid_t& m)   // :61-86
+{
+    int dx, dy, sx, sy, err, x, y;
+    double e2;
+    dx = std::abs(x2 - x1);
+    dy = std::abs(y2 - y1);
+    sx = x1 < x2 ? 1 : -1;
+    sy = y1 < y2 ? 1 : -1;
+    err = dx - dy;
+    x = x1; y = y1;
+    e2 = 2 * err;
+    if (e2 >= -dy) { err -= dy; x += sx; }
+    if (e2 <= dx) { err += dx; y += sy; }
+    return log_odds(m, x, y);
+}
+double score_ray(const orc_ray_t& ray, const orc_grid_t& m)   // :28-59
+{
+    float sx, sy;
+    global_to_grid_position(ray.ox, ray.oy, m, &sx, &sy);
+    double fraction = 0.5;
+    int ex = (ray.range * std::cos(ray.theta) * m.cells_per_meter) + sx;        // float -> int truncation
+    int ey = (ray.range * std::sin(ray.theta) * m.cells_per_meter) + sy;
+    int xx = (2 * ray.range * std::cos(ray.theta) * m.cells_per_meter) + sx;
+    int xy = (2 * ray.range * std::sin(ray.theta) * m.cells_per_meter) + sy;
+    double odds = log_odds(m, ex, ey);
+    if (odds > 0) {}
+    else {
+        odds = 0;
+        int o1 = get_cell_odds(ex, ey, sx, sy, m);      // float start -> int truncation at the call
+        int o2 = get_cell_odds(ex, ey, xx, xy, m);
+        if (o1 > 0) odds += fraction * o1;
+        else if (o2 > 0) odds += fraction * o2;
+    }
+    return odds;
+}
+double likelihood(const orc_particle_t& p, const orc_lidar_t& scan, const orc_grid_t& m)   // :14-25
+{
+    double scanScore = 0.0;
+    std::vector<orc_ray_t> rays = moving_laser_scan(scan, p.parent_pose, p.pose);
+    for (auto& ray : rays) scanScore += score_ray(ray, m);
+    return scanScore;
+}
+
+// ---------------------------------------------------------------- src/slam/particle_filter.cpp
+struct ParticleFilter {
+    int N;
+    std::vector<orc_particle_t> posterior;
+    orc_pose_t posteriorPose;
+    ActionModel action;
+
+    explicit ParticleFilter(int n) : N(n), posterior(n) { std::memset(&posteriorPose, 0, sizeof(posteriorPose)); }
+
+    // :84-103 with D4; idx (optional) receives the chosen source index per output particle
+    std::vector<orc_particle_t> resample(int rand_value, int32_t* idx)
+    {
+        std::vector<orc_particle_t> prior;
+        int i = 0;
+        double M_inv = 1.0 / N;
+        double c, r;
+        r = (((double)rand_value) / (double)RAND_MAX) * M_inv;
+        c = posterior[0].weight;
+        for (int m = 0; m < N; m++) {
+            double U = r + m * M_inv;
+            while (U > c && i < N - 1) { i++; c += posterior[i].weight; }
+            if (idx) idx[m] = i;
+            prior.push_back(posterior[i]);
+        }
+        return prior;
+    }
+    // :116-141
+    std::vector<orc_particle_t> normalized_posterior(const std::vector<orc_particle_t>& proposal,
+                                                     const orc_lidar_t& laser, const orc_grid_t& map, double* raw)
+    {
+        double wSum = 0.0, tolerance = 0.001, w;
+        std::vector<orc_particle_t> post;
+        for (size_t k = 0; k < proposal.size(); ++k) {
+            orc_particle_t t = proposal[k];
+            w = likelihood(proposal[k], laser, map);
+            if (raw) raw[k] = w;
+            if (w < tolerance) w = tolerance;
+            t.weight = w;
+            post.push_back(t);
+            wSum += t.weight;
+        }
+        for (auto& p : post) p.weight /= wSum;
+        return post;
+    }
+    // :144-160 with D1
+    static orc_pose_t estimate(const std::vector<orc_particle_t>& post)
+    {
+        orc_pose_t pose; std::memset(&pose, 0, sizeof(pose));
+        double weightedSin = 0.0, weightedCos = 0.0;
+        for (auto& p : post) {
+            pose.x += p.weight * p.pose.x;                       // float accumulator, double product
+            pose.y += p.weight * p.pose.y;
+            weightedSin += p.weight * std::sin(p.pose.theta);    // sinf
+            weightedCos += p.weight * std::cos(p.pose.theta);
+        }
+        pose.theta = std::atan2(weightedSin, weightedCos);
+        return pose;
+    }
+    // :37-52.  noise: 3*N floats in or out (mode 0: draw from mt19937 and record; mode 1: consume)
+    orc_pose_t update(const orc_pose_t& odom, const orc_lidar_t& laser, const orc_grid_t& map, int rand_value,
+                      int noise_mode, float* noise, int32_t* idx, double* raw)
+    {
+        bool moved = action.update(odom);
+        if (moved) {
+            std::vector<orc_particle_t> prior = resample(rand_value, idx);
+            std::vector<orc_particle_t> proposal;                 // :106-113
+            for (size_t k = 0; k < prior.size(); ++k) {
+                float* n3 = noise ? noise + 3 * k : nullptr;
+                proposal.push_back(noise_mode == 1 ? action.apply_with_noise(prior[k], n3) : action.apply(prior[k], n3));
+            }
+            posterior = normalized_posterior(proposal, laser, map, raw);
+            posteriorPose = estimate(posterior);
+        }
+        posteriorPose.utime = odom.utime;
+        return posteriorPose;
+    }
+    // :54-65
+    orc_pose_t update_action_only(const orc_pose_t& odom, int noise_mode, float* noise)
+    {
+        bool moved = action.update(odom);
+        if (moved) {
+            std::vector<orc_particle_t> proposal;
+            for (size_t k = 0; k < posterior.size(); ++k) {
+                float* n3 = noise ? noise + 3 * k : nullptr;
+                proposal.push_back(noise_mode == 1 ? action.apply_with_noise(posterior[k], n3)
+                                                   : action.apply(posterior[k], n3));
+            }
+            posterior = proposal;
+        }
+        posteriorPose = odom;
+        return posteriorPose;
+    }
+};
+
+// ---------------------------------------------------------------- src/planning/obstacle_distance_grid.cpp
+struct DistanceNode {                                   // :8-17
+    int x, y; float distance;
+    bool operator<(const DistanceNode& rhs) const { return rhs.distance < distance; }
+};
+void dist_expand(const DistanceNode& node, orc_dist_t& g, std::priority_queue<DistanceNode>& q)   // :154-181
+{
+    const int xDeltas[4] = {1, -1, 0, 0};
+    const int yDeltas[4] = {0, 0, 1, -1};
+    for (int n = 0; n < 4; ++n) {
+        int ax = node.x + xDeltas[n], ay = node.y + yDeltas[n];
+        if (ax >= 0 && ax < g.width && ay >= 0 && ay < g.height) {
+            if (g.cells[ay * g.width + ax] == -1) {
+                DistanceNode a; a.x = ax; a.y = ay;
+                a.distance = node.distance + 0.1f;
+                g.cells[ay * g.width + ax] = a.distance;
+                q.push(a);
+            }
+        }
+    }
+}
+void set_distances(const orc_grid_t& map, orc_dist_t& g)   // :73-91 (+ :39-71, :130-152)
+{
+    for (int y = 0; y < map.height; ++y)
+        for (int x = 0; x < map.width; ++x)
+            g.cells[y * g.width + x] = (log_odds(map, x, y) < 0) ? -1.0f : 0.0f;
+    std::priority_queue<DistanceNode> q;
+    for (int y = 0; y < map.height; ++y)
+        for (int x = 0; x < map.width; ++x)
+            if (log_odds(map, x, y) >= 0) {
+                DistanceNode n; n.x = x; n.y = y; n.distance = g.cells[y * g.width + x];
+                dist_expand(n, g, q);
+            }
+    while (!q.empty()) {
+        DistanceNode n = q.top();
+        q.pop();
+        dist_expand(n, g, q);
+    }
+}
+
+// ---------------------------------------------------------------- src/planning/astar.cpp
+struct Node {                                           // astar.hpp:31-45
+    int cx, cy, px, py, gCost, hCost, fCost;
+    bool operator>(const Node& rhs) const { return fCost > rhs.fCost; }
+};
+inline bool dist_in_grid(const orc_dist_t& d, int x, int y) { return x >= 0 && x < d.width && y >= 0 && y < d.height; }
+inline bool is_valid(int x, int y, const orc_dist_t& d, double minDist)   // :140-149 with D5
+{
+    if (!dist_in_grid(d, x, y)) return false;
+    return d.cells[y * d.width + x] > minDist * 1.000001;
+}
+inline int h_cost(int gx, int gy, int x, int y)         // :170-179
+{
+    int ax = std::abs((double)gx - x), ay = std::abs((double)gy - y);
+    return (ax >= ay) ? 14 * ay + 10 * (ax - ay) : 14 * ax + 10 * (ay - ax);
+}
+inline int o_cost(int x, int y, const orc_search_params_t& p, const orc_dist_t& d)   // :181-186
+{
+    int c = 0;
+    float dist = d.cells[y * d.width + x];
+    if (dist > p.minDistanceToObstacle && dist < p.maxDistanceWithCost)
+        c = static_cast<int>(pow(p.maxDistanceWithCost - dist * 2000, p.distanceCostExponent));   // float product
+    return c;
+}
+inline void cell_to_global(int cx, int cy, const orc_dist_t& d, float* gx, float* gy)   // grid_utils.hpp:14-19
+{
+    *gx = static_cast<double>(d.origin_x) + static_cast<double>(cx) * static_cast<double>(d.meters_per_cell);
+    *gy = static_cast<double>(d.origin_y) + static_cast<double>(cy) * static_cast<double>(d.meters_per_cell);
+}
+
+struct SearchStats { int64_t pops, pushes; };
+
+// :9-137 + makePath :235-274.  literal != 0 keeps the reference's linear closed-list scans (astar.cpp:188-203);
+// literal == 0 answers the same two queries ("is the cell closed", "first closed entry of the cell") from an index
+// grid in O(1).  Both forms produce the same pops in the same order.
+std::vector<orc_pose_t> search_for_path(orc_pose_t start, orc_pose_t goal, const orc_dist_t& d,
+                                        const orc_search_params_t& params, int literal, SearchStats* st)
+{
+    std::priority_queue<Node, std::vector<Node>, std::greater<Node>> open;
+    std::vector<Node> closed;
+    std::vector<int32_t> firstClosed;                    // cell -> first index in closed, -1 if none
+    if (!literal) firstClosed.assign(static_cast<size_t>(d.width) * d.height, -1);
+    std::vector<orc_pose_t> path;
+    path.push_back(start);
+    if (st) { st->pops = 0; st->pushes = 0; }
+
+    int ex = static_cast<int>((static_cast<double>(goal.x) - d.origin_x) * d.cells_per_meter);    // grid_utils.hpp:33-38
+    int ey = static_cast<int>((static_cast<double>(goal.y) - d.origin_y) * d.cells_per_meter);
+    int sx = static_cast<int>((static_cast<double>(start.x) - d.origin_x) * d.cells_per_meter);
+    int sy = static_cast<int>((static_cast<double>(start.y) - d.origin_y) * d.cells_per_meter);
+    double initialtheta = start.theta;
+
+    if (!is_valid(ex, ey, d, params.minDistanceToObstacle)) return path;      // :40-44
+    if (!is_valid(sx, sy, d, params.minDistanceToObstacle)) return path;      // :46-50
+    if (sx == ex && sy == ey) return path;                                    // :52-56
+    // :58-62 is implied by is_valid under D5
+
+    auto find_closed = [&](int x, int y) -> int {
+        if (!literal) return firstClosed[static_cast<size_t>(y) * d.width + x];
+        for (size_t k = 0; k < closed.size(); ++k)
+            if (closed[k].cx == x && closed[k].cy == y) return static_cast<int>(k);
+        return -1;
+    };
+
+    Node first; first.cx = sx; first.cy = sy; first.px = 0; first.py = 0; first.gCost = 0; first.hCost = 0; first.fCost = 0;
+    open.push(first);
+    const int xDeltas[4] = {1, -1, 0, 0};
+    const int yDeltas[4] = {0, 0, 1, -1};
+
+    while (!open.empty()) {
+        Node n = open.top();
+        closed.push_back(n);
+        if (!literal) {
+            int32_t& fc = firstClosed[static_cast<size_t>(n.cy) * d.width + n.cx];
+            if (fc < 0) fc = static_cast<int32_t>(closed.size() - 1);
+        }
+        open.pop();
+        if (st) st->pops++;
+        for (int k = 0; k < 4; ++k) {                                          // expand_node :213-233
+            int kx = n.cx + xDeltas[k], ky = n.cy + yDeltas[k];
+            if (!dist_in_grid(d, kx, ky)) continue;
+            int member = find_closed(kx, ky);
+            Node ngbr;
+            if (member >= 0) ngbr = closed[member];
+            else { ngbr.cx = kx; ngbr.cy = ky; ngbr.px = n.cx; ngbr.py = n.cy; ngbr.gCost = 0; ngbr.hCost = 0; ngbr.fCost = INT16_MAX; }
+            if (is_valid(ngbr.cx, ngbr.cy, d, params.minDistanceToObstacle)) {
+                if (ngbr.cx == ex && ngbr.cy == ey) {                          // :107-114 -> makePath
+                    std::stack<orc_pose_t> init;
+                    int c = 0;
+                    float prevX = 0, prevY = 0;
+                    Node t = ngbr;
+                    while (!(t.cx == sx && t.cy == sy)) {
+                        orc_pose_t np; np.utime = 0;                           // D6
+                        cell_to_global(t.cx, t.cy, d, &np.x, &np.y);
+                        if (c == 0) { np.theta = initialtheta; c++; }
+                        else np.theta = atan2(prevY - (double)t.cy, prevX - (double)t.cx);
+                        init.push(np);
+                        prevX = t.cx; prevY = t.cy;
+                        int pi = find_closed(t.px, t.py);
+                        t = closed[pi];
+                    }
+                    while (!init.empty()) { path.push_back(init.top()); init.pop(); }
+                    return path;
+                }
+                int gNew = n.gCost + 10;                                       // :161-168 (4-connected: never 14)
+                int hNew = h_cost(ex, ey, ngbr.cx, ngbr.cy);
+                int fNew = gNew + hNew + o_cost(ngbr.cx, ngbr.cy, params, d);
+                if (member < 0) {
+                    if (ngbr.fCost > fNew) {
+                        ngbr.gCost = gNew; ngbr.hCost = hNew; ngbr.fCost = fNew;
+                        ngbr.px = n.cx; ngbr.py = n.cy;
+                        open.push(ngbr);
+                        if (st) st->pushes++;
+                    }
+                }
+            }
+        }
+    }
+    return path;   // D5
+}
+
+}  // namespace
+
+// =============================================================================================== C API
+extern "C" {
+
+float orc_wrap_to_pi(float a) { return wrap_to_pi(a); }
+double orc_angle_diff(double l, double r) { return angle_diff(l, r); }
+double orc_angle_sum(double a, double b) { return angle_sum(a, b); }
+void orc_interpolate_pose(int64_t t, const orc_pose_t* b, const orc_pose_t* e, orc_pose_t* out)
+{
+    *out = interpolate_pose_by_time(t, *b, *e);
+}
+float orc_cosf(float x) { return std::cos(x); }
+float orc_sinf(float x) { return std::sin(x); }
+
+int orc_moving_scan(const orc_lidar_t* scan, const orc_pose_t* begin, const orc_pose_t* end, orc_ray_t* out, int cap)
+{
+    std::vector<orc_ray_t> r = moving_laser_scan(*scan, *begin, *end);
+    int n = std::min<int>(cap, r.size());
+    std::memcpy(out, r.data(), n * sizeof(orc_ray_t));
+    return static_cast<int>(r.size());
+}
+
+// ---- Mapping
+void* orc_mapping_create(float maxLaser, int8_t hit, int8_t miss)
+{
+    Mapping* m = new Mapping();
+    m->maxLaser = maxLaser; m->hit = hit; m->miss = miss; m->initialized = false;
+    std::memset(&m->prev, 0, sizeof(m->prev));
+    return m;
+}
+void orc_mapping_destroy(void* m) { delete static_cast<Mapping*>(m); }
+void orc_mapping_update(void* m, const orc_lidar_t* scan, const orc_pose_t* pose, orc_grid_t* map)
+{
+    static_cast<Mapping*>(m)->update(*scan, *pose, *map);
+}
+
+// ---- ParticleFilter
+void* orc_pf_create(int n) { return new ParticleFilter(n); }
+void orc_pf_destroy(void* pf) { delete static_cast<ParticleFilter*>(pf); }
+void orc_pf_set_particles(void* pf, const orc_particle_t* p)
+{
+    ParticleFilter* f = static_cast<ParticleFilter*>(pf);
+    std::memcpy(f->posterior.data(), p, sizeof(orc_particle_t) * f->N);
+}
+void orc_pf_get_particles(void* pf, orc_particle_t* p)
+{
+    ParticleFilter* f = static_cast<ParticleFilter*>(pf);
+    std::memcpy(p, f->posterior.data(), sizeof(orc_particle_t) * f->N);
+}
+// initializeFilterAtPose (particle_filter.cpp:16-34) with a caller-seeded generator (reference: random_device) and D2
+void orc_pf_init_at_pose(void* pf, const orc_pose_t* pose, uint32_t seed)
+{
+    ParticleFilter* f = static_cast<ParticleFilter*>(pf);
+    double sampleWeight = 1.0 / f->N;
+    f->posteriorPose = *pose;
+    std::mt19937 generator(seed);
+    std::normal_distribution<> dist(0.0, 0.01);
+    for (auto& p : f->posterior) {
+        p.pose.x = f->posteriorPose.x + dist(generator);
+        p.pose.y = f->posteriorPose.y + dist(generator);
+        p.pose.theta = wrap_to_pi(f->posteriorPose.theta + dist(generator));
+        p.pose.utime = pose->utime;
+        p.parent_pose = p.pose;
+        p.weight = sampleWeight;
+    }
+    f->posterior.back().pose = *pose;
+}
+void orc_pf_update(void* pf, const orc_pose_t* odom, const orc_lidar_t* laser, const orc_grid_t* map, int rand_value,
+                   int noise_mode, float* noise, int32_t* idx, double* raw, orc_pose_t* out_pose, int* moved)
+{
+    ParticleFilter* f = static_cast<ParticleFilter*>(pf);
+    *out_pose = f->update(*odom, *laser, *map, rand_value, noise_mode, noise, idx, raw);
+    if (moved) *moved = f->action.moved ? 1 : 0;
+}
+void orc_pf_update_action_only(void* pf, const orc_pose_t* odom, int noise_mode, float* noise, orc_pose_t* out_pose)
+{
+    *out_pose = static_cast<ParticleFilter*>(pf)->update_action_only(*odom, noise_mode, noise);
+}
+void orc_pf_action_state(void* pf, double* rot1_trans_rot2, int* moved)
+{
+    ParticleFilter* f = static_cast<ParticleFilter*>(pf);
+    rot1_trans_rot2[0] = f->action.rot1; rot1_trans_rot2[1] = f->action.trans; rot1_trans_rot2[2] = f->action.rot2;
+    *moved = f->action.moved ? 1 : 0;
+}
+// stand-alone pieces for unit tests
+void orc_likelihood(const orc_particle_t* p, int n, const orc_lidar_t* scan, const orc_grid_t* map, double* out)
+{
+    for (int i = 0; i < n; ++i) out[i] = likelihood(p[i], *scan, *map);
+}
+void orc_estimate_pose(const orc_particle_t* p, int n, orc_pose_t* out)
+{
+    std::vector<orc_particle_t> v(p, p + n);
+    *out = ParticleFilter::estimate(v);
+}
+
+// ---- ObstacleDistanceGrid
+void orc_set_distances(const orc_grid_t* map, orc_dist_t* dist) { set_distances(*map, *dist); }
+
+// ---- A*
+int orc_search_for_path(const orc_pose_t* start, const orc_pose_t* goal, const orc_dist_t* d,
+                        const orc_search_params_t* params, int literal, orc_pose_t* out, int cap, int64_t* pops_pushes)
+{
+    SearchStats st;
+    std::vector<orc_pose_t> p = search_for_path(*start, *goal, *d, *params, literal, &st);
+    int n = std::min<int>(cap, p.size());
+    std::memcpy(out, p.data(), n * sizeof(orc_pose_t));
+    if (pops_pushes) { pops_pushes[0] = st.pops; pops_pushes[1] = st.pushes; }
+    return static_cast<int>(p.size());
+}
+// MotionPlanner::isValidGoal (motion_planner.cpp:52-74) with D7
+int orc_is_valid_goal(const orc_pose_t* goal, const orc_dist_t* d, double robotRadius, double minDist,
+                      int num_frontiers, const orc_pose_t* prev_goal)
+{
+    float dx = goal->x - prev_goal->x, dy = goal->y - prev_goal->y;
+    float distanceFromPrev = std::sqrt(dx * dx + dy * dy);
+    if (num_frontiers != 1 && distanceFromPrev < 2 * minDist) return 0;
+    int gx = static_cast<int>((static_cast<double>(goal->x) - d->origin_x) * d->cells_per_meter);
+    int gy = static_cast<int>((static_cast<double>(goal->y) - d->origin_y) * d->cells_per_meter);
+    if (dist_in_grid(*d, gx, gy)) return d->cells[gy * d->width + gx] > robotRadius;
+    return 0;
+}
+
+}  // extern "C"

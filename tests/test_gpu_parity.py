@@ -1,0 +1,276 @@
+"""Parity tests proper: the HIP path (through the C ABI) against the CPU oracle on the same inputs.  Bit-exact for
+int8 grids, distance floats, resample indices, likelihoods and A* paths; particle poses / weights / pose estimate
+within the tolerances north_star states (1e-5 relative), written next to each assertion."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import helpers
+import oracle_lib
+import botlab_amd as bl
+from botlab_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+REL = 1e-5      # north_star: particle poses/weights within 1e-5 relative
+
+
+def _grid_from_map(m, ctx):
+    return bl.OccupancyGrid.from_cells(m["cells"], m["origin"], m["mpc"], cellsPerMeter=helpers.CPM_DEFAULT, ctx=ctx)
+
+
+# ------------------------------------------------------------------ ObstacleDistanceGrid
+@pytest.mark.parametrize("name", helpers.ALL_MAPS)
+def test_distance_grid_bit_exact_on_shipped_maps(oracle, maps, gpu_ctx, name):
+    m = maps[name]
+    g = _grid_from_map(m, gpu_ctx)
+    d = bl.ObstacleDistanceGrid(ctx=gpu_ctx)
+    d.setDistances(g)
+    exp = oracle.set_distances(m["cells"], m["mpc"], helpers.CPM_DEFAULT, m["origin"])
+    assert np.array_equal(d.cells().view(np.uint32), exp.view(np.uint32))
+    d.close(); g.close()
+
+
+def test_distance_grid_reference_test_grid(oracle, gpu_ctx):
+    # generate_grid of obstacle_distance_grid_test.cpp:172-196
+    from test_oracle_pins import _generate_grid
+    cells, lo, hi = _generate_grid()
+    g = bl.OccupancyGrid(2.5, 2.5, 0.1, ctx=gpu_ctx)
+    assert (g.width, g.height) == (25, 25)
+    g.upload(cells)
+    d = bl.ObstacleDistanceGrid(ctx=gpu_ctx)
+    d.setDistances(g)
+    got = d.cells()
+    exp = oracle.set_distances(cells, g.mpc, g.cpm, g.origin)
+    assert np.array_equal(got.view(np.uint32), exp.view(np.uint32))
+    assert np.all(got[cells == 0] == 0.0) and np.all(got[cells > 0] == 0.0)
+
+
+@pytest.mark.parametrize("shape", [(1, 1), (1, 37), (53, 1), (64, 64), (257, 129), (300, 1000)])
+def test_distance_grid_ragged_shapes(oracle, gpu_ctx, shape):
+    rng = np.random.default_rng(shape[0] * 1000 + shape[1])
+    h, w = shape
+    cells = np.where(rng.random(shape) < 0.02, rng.integers(0, 100, shape), -rng.integers(1, 100, shape)).astype(np.int8)
+    for variant in (cells, np.full(shape, -5, np.int8), np.zeros(shape, np.int8)):
+        g = bl.OccupancyGrid.from_cells(variant, (-1.0, -2.0), 0.05, ctx=gpu_ctx)
+        d = bl.ObstacleDistanceGrid(ctx=gpu_ctx)
+        d.setDistances(g)
+        exp = oracle.set_distances(variant, g.mpc, g.cpm, g.origin)
+        assert np.array_equal(d.cells().view(np.uint32), exp.view(np.uint32))
+        d.close(); g.close()
+
+
+def test_distance_grid_2000x2000_tiled_maze(oracle, maps, gpu_ctx):
+    world = synth.tile_world(maps["astar_maze"]["cells"], 2000)
+    g = bl.OccupancyGrid.from_cells(world, (-50.0, -50.0), 0.05, ctx=gpu_ctx)
+    d = bl.ObstacleDistanceGrid(ctx=gpu_ctx)
+    d.setDistances(g)
+    exp = oracle.set_distances(world, g.mpc, g.cpm, g.origin)
+    assert np.array_equal(d.cells().view(np.uint32), exp.view(np.uint32))
+
+
+# ------------------------------------------------------------------ Mapping
+def _drive(maps, name, steps, seed):
+    m = maps[name]
+    truth = np.where(m["cells"] > 0, 127, -127).astype(np.int8)
+    rng = np.random.default_rng(seed)
+    poses = synth.square_trajectory((0.0, 0.0, 0.0), steps, step_len=0.04, turn=0.1, side=0.4)
+    scans = []
+    for k in range(1, len(poses)):
+        t = 1_000_000 + k * 100_000
+        scans.append(synth.raycast_scan(truth, m["origin"], float(m["mpc"]), poses[k - 1], poses[k], t, noise_sigma=0.005, rng=rng))
+    return m, truth, poses, scans
+
+
+@pytest.mark.parametrize("name,hit,miss", [("obstacle_slam_10mx10m_5cm", 4, 1), ("astar_maze", 3, 2), ("convex_10mx10m_5cm", 60, 45)])
+def test_mapping_bit_exact(oracle, maps, gpu_ctx, name, hit, miss):
+    m, truth, poses, scans = _drive(maps, name, 25, 11)
+    g = bl.OccupancyGrid(10.0, 10.0, 0.05, ctx=gpu_ctx)                   # slam.cpp:23
+    mapper = bl.Mapping(5.0, hit, miss, ctx=gpu_ctx)                        # slam.cpp:24
+    om = oracle_lib.OracleMapping(oracle, 5.0, hit, miss)
+    ref = np.zeros((g.height, g.width), np.int8)
+    for k, scan in enumerate(scans):
+        p = poses[k + 1]
+        # a ranges array with invalid (<= 0.15) and beyond-max entries exercises both cuts
+        if k == 3:
+            scan.ranges[::7] = 0.1
+            scan.ranges[5::11] = 7.5
+        mapper.updateMap(scan, bl.make_pose(p[0], p[1], p[2], utime=scan.times[-1]), g)
+        om.update(scan, oracle.pose(p[0], p[1], p[2], utime=scan.times[-1]), ref, g.mpc, g.cpm, g.origin)
+        assert np.array_equal(g.cells(), ref), f"step {k}"
+    assert (ref != 0).sum() > 1000
+
+
+def test_mapping_off_grid_and_empty_scan(oracle, gpu_ctx, maps):
+    m, truth, poses, scans = _drive(maps, "obstacle_slam_10mx10m_5cm", 4, 5)
+    g = bl.OccupancyGrid(10.0, 10.0, 0.05, ctx=gpu_ctx)
+    mapper = bl.Mapping(5.0, 4, 1, ctx=gpu_ctx)
+    om = oracle_lib.OracleMapping(oracle, 5.0, 4, 1)
+    ref = np.zeros((g.height, g.width), np.int8)
+    far = [(4.9, 4.9, 0.3), (4.95, 4.8, 0.5), (6.0, 6.0, 1.0), (-4.99, -4.99, 2.0)]     # rays leave the grid / robot outside it
+    for k, (scan, p) in enumerate(zip(scans, far)):
+        mapper.updateMap(scan, bl.make_pose(*p, utime=scan.times[-1]), g)
+        om.update(scan, oracle.pose(*p, utime=scan.times[-1]), ref, g.mpc, g.cpm, g.origin)
+        assert np.array_equal(g.cells(), ref), k
+    empty = bl.LidarScan(np.zeros(0, np.float32), np.zeros(0, np.float32), np.zeros(0, np.int64), utime=5)
+    mapper.updateMap(empty, bl.make_pose(0, 0, 0, utime=5), g)
+    assert np.array_equal(g.cells(), ref)
+
+
+# ------------------------------------------------------------------ ParticleFilter
+def _mcl_sequence(oracle, maps, gpu_ctx, N, steps, name="obstacle_slam_10mx10m_5cm", seed=1):
+    m, truth, poses, scans = _drive(maps, name, steps, seed)
+    rng = np.random.default_rng(seed + 100)
+    odo = synth.odometry_from_truth(poses, rng)
+    cells = m["cells"]
+    g = _grid_from_map(m, gpu_ctx)
+    opf = oracle_lib.OraclePF(oracle, N)
+    t0 = int(scans[0].times[0])
+    opf.init_at_pose(oracle.pose(0.0, 0.0, 0.0, utime=t0), 1234)
+    pf = bl.ParticleFilter(N, ctx=gpu_ctx)
+    pf.setParticles(opf.particles())
+    rands = [1804289383, 846930886, 1681692777, 1714636915, 1957747793, 424238335, 719885386, 1649760492, 596516649,
+             1189641421, 1025202362, 1350490027, 783368690, 1102520059, 2044897763, 1967513926]     # glibc rand(), unseeded
+    return m, g, opf, pf, odo, scans, rands, cells
+
+
+@pytest.mark.parametrize("N", [200, 4096])
+def test_mcl_parity_with_oracle_noise(oracle, maps, gpu_ctx, N):
+    m, g, opf, pf, odo, scans, rands, cells = _mcl_sequence(oracle, maps, gpu_ctx, N, 10)
+    moved_updates = 0
+    for k, scan in enumerate(scans):
+        o = odo[k + 1] if k != 4 else odo[k]              # step 4 repeats the odometry: "robot did not move" branch
+        if k == 5:
+            o = odo[k + 1]
+        t = int(scan.times[-1])
+        res = opf.update(oracle.pose(o[0], o[1], o[2], utime=t), scan, cells, m["mpc"], helpers.CPM_DEFAULT, m["origin"], rands[k])
+        pose = pf.updateFilter(bl.make_pose(o[0], o[1], o[2], utime=t), scan, g, rand_value=rands[k], noise=res["noise"])
+        assert pose.utime == res["pose"].utime == t
+        if not res["moved"]:
+            continue
+        moved_updates += 1
+        idx, like = pf.debugLast()
+        assert np.array_equal(idx, res["idx"]), f"resample indices differ at step {k}"            # index work: exact
+        assert np.array_equal(like.astype(np.float64) * 0.5, res["raw"]), f"likelihoods differ at step {k}"   # exact half-integers
+        got, exp = pf.particles(), opf.particles()
+        for f in ("x", "y", "theta", "p_x", "p_y", "p_theta"):
+            assert np.allclose(got[f], exp[f], rtol=REL, atol=1e-7), (k, f)
+            assert np.array_equal(got[f], exp[f]), (k, f)      # in practice bit-equal; a failure here is informational
+        assert np.array_equal(got["utime"], exp["utime"]) and np.array_equal(got["p_utime"], exp["p_utime"])
+        assert np.allclose(got["weight"], exp["weight"], rtol=REL, atol=0)
+        # pose estimate: the reference accumulates x, y in a float (order-dependent rounding up to ~N * 2^-24 relative);
+        # the kernel reduces in double.  Tolerance 1e-5 relative + float epsilon absolute.
+        for f in ("x", "y", "theta"):
+            a, b = getattr(pose, f), getattr(res["pose"], f)
+            assert abs(a - b) <= REL * abs(b) + 2e-6, (k, f, a, b)
+    assert moved_updates >= 7
+
+
+def test_mcl_action_only(oracle, maps, gpu_ctx):
+    N = 512
+    m, g, opf, pf, odo, scans, rands, cells = _mcl_sequence(oracle, maps, gpu_ctx, N, 5)
+    for k in range(4):
+        o = odo[k + 1]
+        t = int(scans[k].times[-1])
+        exp_pose, noise = opf.update_action_only(oracle.pose(o[0], o[1], o[2], utime=t))
+        got_pose = pf.updateFilterActionOnly(bl.make_pose(o[0], o[1], o[2], utime=t), noise=noise)
+        assert (got_pose.x, got_pose.y, got_pose.theta, got_pose.utime) == (exp_pose.x, exp_pose.y, exp_pose.theta, exp_pose.utime)
+        got, exp = pf.particles(), opf.particles()
+        for f in ("x", "y", "theta", "p_x", "p_y", "p_theta"):
+            assert np.allclose(got[f], exp[f], rtol=REL, atol=1e-7), (k, f)
+        assert np.allclose(got["weight"], exp["weight"], rtol=REL)
+
+
+def test_mcl_philox_mode_statistics(maps, gpu_ctx):
+    """Perf mode (device Philox noise) has no serial-RNG counterpart in the reference: check the proposal moments and
+    that the filter tracks the truth."""
+    N = 20000
+    m = maps["obstacle_slam_10mx10m_5cm"]
+    truth = np.where(m["cells"] > 0, 127, -127).astype(np.int8)
+    g = _grid_from_map(m, gpu_ctx)
+    pf = bl.ParticleFilter(N, ctx=gpu_ctx)
+    pf.initializeFilterAtPose(bl.make_pose(0, 0, 0, utime=1000), seed=42)
+    p0 = pf.particles()
+    assert abs(p0["x"].mean()) < 5e-4 and abs(p0["x"].std() - 0.01) < 5e-4 and abs(p0["theta"].std() - 0.01) < 5e-4
+    assert p0["x"][-1] == 0 and p0["theta"][-1] == 0 and np.allclose(p0["weight"], 1.0 / N)
+    poses = synth.square_trajectory((0.0, 0.0, 0.0), 12, step_len=0.04, turn=0.1, side=0.4)
+    pf.updateFilter(bl.make_pose(0, 0, 0, utime=1000), synth.raycast_scan(truth, m["origin"], 0.05, poses[0], poses[0], 1000), g)
+    for k in range(1, len(poses)):
+        scan = synth.raycast_scan(truth, m["origin"], 0.05, poses[k - 1], poses[k], 1000 + k * 100000)
+        est = pf.updateFilter(bl.make_pose(*poses[k], utime=scan.utime), scan, g)
+    assert abs(est.x - poses[-1][0]) < 0.05 and abs(est.y - poses[-1][1]) < 0.05
+    w = pf.particles()["weight"]
+    assert abs(w.sum() - 1.0) < 1e-9 and (w > 0).all()
+
+
+# ------------------------------------------------------------------ search_for_path
+ASTAR_GPU_SKIP = {("narrow", 2): "2.6e8 pops", ("convex", 2): "1.8e6 pops (covered by test_astar_long_case)"}
+
+
+@pytest.mark.parametrize("name", ["empty", "filled", "narrow", "wide", "convex", "maze"])
+def test_astar_paths_bit_exact_on_reference_fixtures(oracle, maps, gpu_ctx, name):
+    m = maps["astar_" + name]
+    cpm = helpers.CPM_DEFAULT
+    g = _grid_from_map(m, gpu_ctx)
+    params = bl.MotionPlannerParams(0.1)                                    # astar_test.cpp:227-228
+    planner = bl.MotionPlanner(params, ctx=gpu_ctx)
+    planner.setMap(g)
+    dist = oracle.set_distances(m["cells"], m["mpc"], cpm, m["origin"])
+    assert np.array_equal(planner.distances_.cells().view(np.uint32), dist.view(np.uint32))
+    for i, row in enumerate(helpers.load_astar_cases()[name]):
+        if (name, i) in ASTAR_GPU_SKIP:
+            continue
+        if name == "wide" and i == 2:
+            continue        # 526k pops: covered once in test_astar_long_case
+        s = bl.make_pose(row["start"][0], row["start"][1], 0.0)
+        gl = bl.make_pose(row["goal"][0], row["goal"][1], 0.0)
+        os_, og = oracle.pose(*row["start"], 0.0), oracle.pose(*row["goal"], 0.0)
+        assert planner.isValidGoal(gl) == oracle.is_valid_goal(og, dist, m["mpc"], cpm, m["origin"], 0.1, 0.1)
+        path, stats = bl.search_for_path(s, gl, planner.distances_, planner.searchParams_, return_stats=True)
+        exp, est = oracle.search(os_, og, dist, m["mpc"], cpm, m["origin"], 0.1, 1.0)
+        assert len(path) == len(exp), (name, i)
+        assert stats == est, (name, i, stats, est)
+        got = np.array([(p.utime, p.x, p.y, p.theta) for p in path], dtype=exp.dtype)
+        assert got.tobytes() == exp.tobytes(), (name, i)
+
+
+def test_astar_long_case(oracle, maps, gpu_ctx):
+    m = maps["astar_wide"]
+    row = helpers.load_astar_cases()["wide"][2]
+    g = _grid_from_map(m, gpu_ctx)
+    planner = bl.MotionPlanner(bl.MotionPlannerParams(0.1), ctx=gpu_ctx)
+    planner.setMap(g)
+    dist = oracle.set_distances(m["cells"], m["mpc"], helpers.CPM_DEFAULT, m["origin"])
+    path, stats = bl.search_for_path(bl.make_pose(*row["start"], 0.0), bl.make_pose(*row["goal"], 0.0), planner.distances_,
+                                     planner.searchParams_, return_stats=True)
+    exp, est = oracle.search(oracle.pose(*row["start"], 0.0), oracle.pose(*row["goal"], 0.0), dist, m["mpc"],
+                             helpers.CPM_DEFAULT, m["origin"], 0.1, 1.0)
+    assert stats == est == (526431, 763405)
+    got = np.array([(p.utime, p.x, p.y, p.theta) for p in path], dtype=exp.dtype)
+    assert got.tobytes() == exp.tobytes()
+
+
+def test_astar_on_slam_map_with_default_radius(oracle, maps, gpu_ctx):
+    """MotionPlanner() default robotRadius 0.2 (motion_planner.hpp:31) on a SLAM-built map, several goals."""
+    m = maps["obstacle_slam_10mx10m_5cm"]
+    g = _grid_from_map(m, gpu_ctx)
+    planner = bl.MotionPlanner(ctx=gpu_ctx)
+    planner.setMap(g)
+    dist = oracle.set_distances(m["cells"], m["mpc"], helpers.CPM_DEFAULT, m["origin"])
+    free = np.argwhere(dist > 0.25)
+    rng = np.random.default_rng(2)
+    n_found = 0
+    for _ in range(12):
+        (sy, sx), (gy, gx) = free[rng.integers(len(free))], free[rng.integers(len(free))]
+        sp = (m["origin"][0] + (sx + 0.5) * 0.05, m["origin"][1] + (sy + 0.5) * 0.05)
+        gp = (m["origin"][0] + (gx + 0.5) * 0.05, m["origin"][1] + (gy + 0.5) * 0.05)
+        path, stats = bl.search_for_path(bl.make_pose(*sp, 0.3), bl.make_pose(*gp, 0.0), planner.distances_,
+                                         planner.searchParams_, return_stats=True)
+        exp, est = oracle.search(oracle.pose(*sp, 0.3), oracle.pose(*gp, 0.0), dist, m["mpc"], helpers.CPM_DEFAULT,
+                                 m["origin"], 0.2, 2.0)
+        assert stats == est
+        got = np.array([(p.utime, p.x, p.y, p.theta) for p in path], dtype=exp.dtype)
+        assert got.tobytes() == exp.tobytes()
+        n_found += len(path) > 1
+    assert n_found >= 3
