@@ -1,0 +1,244 @@
+#!/usr/bin/env python3
+"""bench.py -- SLAM steps/sec (map + MCL + A* replan) on MI355X.
+
+Workload (BASELINE.json configs[1], the configuration the metric is quoted on): full SLAM on the 200x200 @5 cm
+obstacle_slam map with 100k particles.  The reference's .log inputs are absent from its checkout, so scans and
+odometry are synthesised over the shipped .map (botlab_amd/synth.py) -- "data": "synthetic".
+
+One step = OccupancyGridSLAM::runSLAMIteration (src/slam/slam.cpp:191-207) + the planner's per-map work
+(src/planning/exploration.cpp:300-317):
+    ParticleFilter::updateFilter(odometry, scan, map)      pre-update map, pose returned to the host
+    Mapping::updateMap(scan, pose, map)
+    ObstacleDistanceGrid::setDistances(map)  +  search_for_path(pose, goal)
+Multi-GPU (--gpus N under torch.distributed.run): the particles are block-sharded over the ranks (RCCL all-gather of
+the 16-byte exchange record + all-reduce of the weight/pose sums); the map update and the replan are replicated.
+Total work is fixed as N grows ("scaling": "strong").
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8 TB/s
+
+
+def load_map(name):
+    z = np.load(os.path.join(ROOT, "tests", "golden", "reference_maps.npz"))
+    return dict(cells=z[name + "__cells"], origin=tuple(z[name + "__origin"]), mpc=z[name + "__mpc"][0])
+
+
+def build_inputs(args, total_steps):
+    from botlab_amd import synth
+    m = load_map("obstacle_slam_10mx10m_5cm")
+    if args.grid != 200:
+        cells = synth.tile_world(load_map("astar_maze")["cells"], args.grid)
+        half = args.grid * 0.05 / 2.0
+        m = dict(cells=np.where(cells > 0, 127, -100).astype(np.int8), origin=(np.float32(-half), np.float32(-half)),
+                 mpc=np.float32(0.05))
+        start = (0.3, 0.3, 0.0)
+    else:
+        start = (0.0, 0.0, 0.0)
+    truth = np.where(m["cells"] > 0, 127, -127).astype(np.int8)
+    rng = np.random.default_rng(1234)
+    poses = synth.square_trajectory(start, total_steps, step_len=0.02, turn=0.05, side=1.0)
+    odo = synth.odometry_from_truth(poses, rng)
+    scans = []
+    for k in range(1, len(poses)):
+        scans.append(synth.raycast_scan(truth, m["origin"], float(m["mpc"]), poses[k - 1], poses[k], 1_000_000 + k * 100_000,
+                                        noise_sigma=0.005, rng=rng))
+    rands = np.random.default_rng(99).integers(0, 2**31 - 1, size=total_steps + 4)
+    return m, truth, poses, odo, scans, rands
+
+
+def pick_goal(dist_cells, origin, start_xy, radius, max_l1_cells):
+    """A reachable-looking replan goal: the free cell with clearance > radius + 1 cell that is farthest (L1) from the
+    start but no farther than max_l1_cells (SURVEY.md section 8d picks the farthest such cell)."""
+    h, w = dist_cells.shape
+    sx = int((start_xy[0] - origin[0]) * 20.0)
+    sy = int((start_xy[1] - origin[1]) * 20.0)
+    ys, xs = np.nonzero(dist_cells > radius + 0.05)
+    l1 = np.abs(xs - sx) + np.abs(ys - sy)
+    ok = l1 <= max_l1_cells
+    if not ok.any():
+        return None
+    k = np.argmax(np.where(ok, l1, -1))
+    return (float(origin[0]) + (xs[k] + 0.5) * 0.05, float(origin[1]) + (ys[k] + 0.5) * 0.05)
+
+
+def cpu_baseline(args, m, odo, scans, rands, goal, n_steps):
+    """The CPU oracle (a serial restatement of the reference path, oracle/botlab_oracle.cpp) timed on ONE host core on
+    a bounded sample of the same workload."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import helpers
+    import oracle_lib
+    orc = oracle_lib.load_oracle()
+    cpm = helpers.CPM_DEFAULT
+    cells = m["cells"].copy()
+    N = args.particles
+    pf = oracle_lib.OraclePF(orc, N)
+    pf.init_at_pose(orc.pose(*odo[0], utime=int(scans[0].times[0])), 42)
+    om = oracle_lib.OracleMapping(orc, 5.0, 4, 1)
+    # one untimed step latches odometry / previous pose (first calls are no-ops in the reference)
+    o = odo[1]
+    res = pf.update(orc.pose(*o, utime=scans[0].utime), scans[0], cells, m["mpc"], cpm, m["origin"], int(rands[0]))
+    om.update(scans[0], res["pose"], cells, m["mpc"], cpm, m["origin"])
+    t0 = time.perf_counter()
+    pops = 0
+    for k in range(1, 1 + n_steps):
+        o = odo[k + 1]
+        res = pf.update(orc.pose(*o, utime=scans[k].utime), scans[k], cells, m["mpc"], cpm, m["origin"], int(rands[k]))
+        om.update(scans[k], res["pose"], cells, m["mpc"], cpm, m["origin"])
+        if goal is not None:
+            d = orc.set_distances(cells, m["mpc"], cpm, m["origin"])
+            _, st = orc.search(res["pose"], orc.pose(goal[0], goal[1], 0.0), d, m["mpc"], cpm, m["origin"], 0.2, 2.0)
+            pops += st[0]
+    dt = time.perf_counter() - t0
+    return dict(value=n_steps / dt, unit="steps/s", cores=1, kind="port",
+                sample=f"{n_steps} full steps of the same workload ({N} particles, {scans[0].num_ranges} rays, "
+                       f"{cells.shape[1]}x{cells.shape[0]} grid, A* {pops // max(n_steps, 1)} pops/step), oracle on 1 thread, "
+                       f"{os.cpu_count()} host cores visible")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--particles", type=int, default=100_000)
+    ap.add_argument("--grid", type=int, default=200, help="grid side in cells (200 = shipped obstacle_slam map)")
+    ap.add_argument("--no-astar", action="store_true", help="skip the replan (distance grid + A*) in the step")
+    ap.add_argument("--goal-l1", type=int, default=40, help="max L1 distance (cells) of the replan goal from the start")
+    ap.add_argument("--cpu-steps", type=int, default=10, help="steps of the CPU baseline sample (0 = skip)")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+
+    import torch
+    import torch.distributed as dist
+    import botlab_amd as bl
+    from botlab_amd import _capi, sharded
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: botlab_amd has no CPU path")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    total = args.steps + args.warmup + 2
+    m, truth, poses, odo, scans, rands = build_inputs(args, total)
+    cpm = np.float32(1.0 / np.float64(np.float32(0.05)))
+
+    engine = sharded.HipShardEngine(args.particles, rank, world, local_rank)
+    ctx = engine.ctx
+    spf = sharded.ShardedParticleFilter(engine)
+    grid = bl.OccupancyGrid.from_cells(m["cells"], m["origin"], m["mpc"], cellsPerMeter=cpm, ctx=ctx)
+    mapper = bl.Mapping(5.0, 4, 1, ctx=ctx)                 # slam.cpp:24, slam_main.cpp:22-23
+    planner = bl.MotionPlanner(ctx=ctx)                       # robotRadius 0.2 (motion_planner.hpp:31)
+    planner.setMap(grid)
+    goal = None
+    if not args.no_astar:
+        goal = pick_goal(planner.distances_.cells(), m["origin"], poses[0][:2], 0.2, args.goal_l1)
+    goal_pose = bl.make_pose(goal[0], goal[1], 0.0) if goal else None
+
+    spf.initializeFilterAtPose(bl.make_pose(*odo[0], utime=int(scans[0].times[0])), seed=42)
+
+    pops_total = [0]
+
+    def step(k):
+        o = odo[k + 1]
+        sc = scans[k]
+        pose = spf.updateFilter(bl.make_pose(o[0], o[1], o[2], utime=sc.utime), sc, grid, int(rands[k]))
+        mapper.updateMap(sc, pose, grid)
+        if goal_pose is not None:
+            planner.setMap(grid)
+            path, st = bl.search_for_path(pose, goal_pose, planner.distances_, planner.searchParams_, return_stats=True)
+            pops_total[0] += st[0]
+        return pose
+
+    k = 0
+    for _ in range(args.warmup):
+        step(k)
+        k += 1
+    ctx.timing_reset()
+    ctx.timing_enable(True)
+    pops_total[0] = 0
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        pose = step(k)
+        k += 1
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    ctx.timing_enable(False)
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    stage_ms = {}
+    for name, kid in (("mcl_main", _capi.BL_K_MCL_MAIN), ("mcl_scan", _capi.BL_K_MCL_SCAN), ("map", _capi.BL_K_MAP),
+                      ("dist", _capi.BL_K_DIST), ("astar", _capi.BL_K_ASTAR)):
+        ms, n = ctx.timing_get(kid)
+        stage_ms[name] = (ms / n if n else 0.0, n)
+
+    if rank == 0:
+        N, R = args.particles, scans[0].num_ranges
+        W, H = m["cells"].shape[1], m["cells"].shape[0]
+        n_local = engine.hi - engine.lo
+        # algorithmic bytes of one k_mcl_main launch: 128 B per particle of this shard
+        # + the grid once + 20 B per ray
+        alg_bytes = 128.0 * n_local + W * H + 20.0 * R
+        main_ms = stage_ms["mcl_main"][0]
+        achieved = alg_bytes / (main_ms * 1e-3) / 1e9 if main_ms > 0 else 0.0
+        out = {
+            "metric": "SLAM steps/sec (map+MCL+A*)",
+            "value": args.steps / elapsed,
+            "unit": "steps/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "int8 grid / f32 poses with f64 intermediates / int64 weights",
+            "data": "synthetic",
+            "config": {"workload": f"full SLAM step on {W}x{H} @5cm grid (shipped obstacle_slam map), {N} particles, "
+                                   f"{R} rays, A* replan {'off' if goal is None else 'on'}",
+                       "particles": N, "grid": [W, H], "rays": R,
+                       "parallelism": f"particle-shard x{world}" if world > 1 else "single GPU"},
+            "roofline": {"bound": "hbm", "kernel": "k_mcl_main", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": main_ms,
+                         "particle_rays_per_s": (n_local * R) / (main_ms * 1e-3) if main_ms > 0 else 0.0},
+            "stage_ms": {k_: round(v[0], 5) for k_, v in stage_ms.items()},
+            "astar_pops_per_step": pops_total[0] / args.steps,
+            "final_pose": [pose.x, pose.y, pose.theta],
+            "truth_pose": [float(v) for v in poses[k]],
+        }
+        if args.cpu_steps > 0 and world == 1:
+            out["cpu_baseline"] = cpu_baseline(args, m, odo, scans, rands, goal, args.cpu_steps)
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,106 @@
+"""Particle sharding across the GPUs of one node: one process per GPU, torch.distributed (backend "nccl" = RCCL over
+xGMI; "gloo" in the CPU tests).
+
+Exchange per moved update:
+  1. every rank runs resample-gather + action + sensor model for its block of output particles [lo, hi) and writes its
+     slice of the 16-byte exchange record (x, y, theta, weight-units);
+  2. ONE all-gather of the record (in place: each rank's slice already sits at its offset) and ONE all-reduce of the
+     8-double partial sums;
+  3. every rank scans the integer weight units of all N particles (exact, so every rank derives the same cumulative
+     and the same total) and forms the pose estimate from the reduced sums.
+The map update, distance grid and A* are replicated (every rank applies the identical integer update; no traffic).
+
+The engine behind a shard is pluggable so the orchestration is testable without a GPU: the product engine is
+HipShardEngine (libbotlab_hip.so); tests/ supply a CPU stand-in to exercise the collectives under gloo.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from . import host
+from ._capi import check
+
+
+def shard_bounds(num_particles, rank, world):
+    """Block partition with equal padded block size S = ceil(N / world); shard = [rank*S, min(N, (rank+1)*S))."""
+    S = (num_particles + world - 1) // world
+    lo = rank * S
+    hi = min(num_particles, lo + S)
+    if lo >= hi:
+        raise ValueError(f"rank {rank} of {world} would own no particle of {num_particles}")
+    return lo, hi, S
+
+
+class HipShardEngine:
+    """One shard on one MI355X.  The exchange buffers are torch tensors (device memory + stream plumbing) handed to
+    the library, so collectives run on them in place."""
+
+    def __init__(self, num_particles, rank, world, device):
+        self.N, self.rank, self.world = num_particles, rank, world
+        self.lo, self.hi, self.S = shard_bounds(num_particles, rank, world)
+        self.device = torch.device("cuda", device)
+        torch.cuda.set_device(self.device)
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        self.ctx = host.Context(device, stream=stream)
+        padded = self.S * world
+        self.rec = [torch.zeros(padded, 4, dtype=torch.float32, device=self.device) for _ in range(2)]
+        self.sums = torch.zeros(8, dtype=torch.float64, device=self.device)
+        self.pf = host.ParticleFilter(num_particles, ctx=self.ctx, shard=(self.lo, self.hi))
+        check(self.ctx.lib.bl_pf_set_exchange_buffers(self.pf.h, self.rec[0].data_ptr(), self.rec[1].data_ptr(),
+                                                      self.sums.data_ptr()))
+
+    def init_at_pose(self, pose, seed):
+        self.pf.initializeFilterAtPose(pose, seed=seed)
+
+    def set_particles(self, particles, units=None):
+        self.pf.setParticles(particles, units)
+
+    def begin(self, odometry, scan, grid, rand_value, noise=None):
+        return self.pf.updateBegin(odometry, scan, grid, rand_value, noise)
+
+    def exchange_record(self):
+        ptr = self.ctx.lib.bl_pf_exchange_rec_ptr(self.pf.h)
+        for t in self.rec:
+            if t.data_ptr() == ptr:
+                return t
+        raise RuntimeError("exchange record pointer does not match a bound buffer")
+
+    def exchange_sums(self):
+        return self.sums
+
+    def end(self, want_pose=True):
+        return self.pf.updateEnd(want_pose)
+
+    def particles(self):
+        return self.pf.particles()
+
+
+class ShardedParticleFilter:
+    """ParticleFilter whose particles are block-partitioned over the ranks of a process group."""
+
+    def __init__(self, engine, group=None):
+        self.engine = engine
+        self.group = group
+        self.world = engine.world
+        self.rank = engine.rank
+
+    def initializeFilterAtPose(self, pose, seed=1):
+        self.engine.init_at_pose(pose, seed)          # counter-based: every rank generates the identical full record
+
+    def setParticles(self, particles, units=None):
+        self.engine.set_particles(particles, units)
+
+    def updateFilter(self, odometry, scan, grid, rand_value, noise=None, want_pose=True):
+        moved = self.engine.begin(odometry, scan, grid, rand_value, noise)
+        if moved and self.world > 1:
+            rec = self.engine.exchange_record()
+            S = self.engine.S
+            mine = rec[self.rank * S:(self.rank + 1) * S]
+            dist.all_gather_into_tensor(rec, mine, group=self.group)
+            dist.all_reduce(self.engine.exchange_sums(), op=dist.ReduceOp.SUM, group=self.group)
+        return self.engine.end(want_pose)
+
+    def particles(self):
+        return self.engine.particles()
