@@ -10,10 +10,11 @@
 //
 // A*.  The reference's result depends on the pop order of libstdc++'s binary heap among equal fCost and on its
 // re-expansion of duplicate open-list entries, so the search is executed with exactly those heap index operations
-// (std::push_heap / std::pop_heap semantics, stl_heap.h) by one wavefront; the closed list is an int32 parent grid
+// (std::push_heap / std::pop_heap semantics, stl_heap.h) by one wavefront; the closed list is an int32 grid of parent moves
 // (first closing of a cell wins, which is all is_member/get_member ever observe).  Single-search latency is bound by
 // dependent memory accesses, not bandwidth (DESIGN.md "A*").
 #include <math.h>
+#include <stdio.h>
 #include <string.h>
 
 #include "bl_internal.h"
@@ -253,17 +254,33 @@ extern "C" void* bl_dist_device_ptr(bl_dist* d) { return d ? (void*)d->cells : n
 #define ASTAR_ST_CAPACITY 2
 #define ASTAR_ST_LIMIT 3
 
-struct astar_result { int status; int path_len; long long pops; long long pushes; };
+struct astar_result { int status; int path_len; long long pops; long long pushes; long long stamps[6]; };
+
+// Diagnostic build only (-DBL_ASTAR_STAMPS): s_memtime shares of the search loop, written to the result record's
+// stamps[] (never to an output the search computes from).
+#ifdef BL_ASTAR_STAMPS
+#define STAMP(var) do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var) :: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define STAMP(var) do { } while (0)
+#endif
+
+// Open-list entry: x = fCost, y = (cy << 17) | (cx << 2) | k where the cell (cx, cy) was generated from its parent by
+// move k (cell = parent + delta[k]).  gCost is not stored: fCost = gCost + hCost(cell) + oCost(cell) and the last two
+// are functions of the cell alone, so gCost is recovered when the entry is popped.
+#define AH_LDS 16383                 // heap levels 0..13 live in LDS; deeper levels in HBM/L2
+#define AH_COST_LDS 8000             // per-L1-distance cost table in LDS when it fits (W + H + 1 <= 8000)
+#define AH_LDS_BYTES ((AH_LDS + 1) * 8 + AH_COST_LDS * 4)
+#define AH_MAX_DIM 32767
+#define AH_MAX_CAP (1 << 25)
 
 struct bl_astar_state {
-    int4* heap; int64_t heap_cap;
-    int32_t* closed; size_t closed_cap;
+    int2* heap; int64_t heap_cap;
+    int32_t* closed; size_t closed_cap;    // -1: not closed; 0..3: move that produced the FIRST closed entry; 4: start
     int32_t* path; size_t path_cap;
     int32_t* cost_lut; int cost_lut_cap;
     astar_result* d_result;
     astar_result* h_result;            // pinned
     int32_t* h_cost;                   // pinned staging for the cost table
-    // pending search (async form)
     bool pending;
     bl_pose_xyt_t start;
     bl_frame frame;
@@ -271,8 +288,8 @@ struct bl_astar_state {
 
 struct astar_args {
     const uint16_t* l1; int W, H;
-    const int32_t* cost_lut;           // per L1 distance: obstacle cost, or ASTAR_INVALID_COST if the cell is not valid
-    int4* heap; long long heap_cap;
+    const int32_t* cost_lut; int cost_n;   // per L1 distance: obstacle cost, or ASTAR_INVALID_COST if the cell is not valid
+    int2* heap; int heap_cap;
     int32_t* closed;
     int32_t* path; long long path_cap;
     astar_result* result;
@@ -280,105 +297,253 @@ struct astar_args {
     long long max_pops;
 };
 
-__device__ __forceinline__ int astar_cell_cost(const astar_args& a, int x, int y)
+// The LDS part of the heap is addressed through an address_space(3) pointer: a two-way select between an LDS and a
+// global pointer makes hipcc emit FLAT accesses, which reach LDS through the aperture check at several times the
+// ds_read latency.  The slow (mixed) accessors are only used for rounds that touch entries beyond AH_LDS.
+extern __shared__ int2 s_heap[];                    // [AH_LDS entries][1 dummy][cost table]
+typedef __attribute__((address_space(3))) long long lds_ll_t;
+typedef __attribute__((address_space(3))) int lds_int_t;
+
+__device__ __forceinline__ int2 lds_entry(int i)
 {
-    // isValid (astar.cpp:140-149, D5) folded with get_oCost (astar.cpp:181-186): both depend only on the cell's
-    // distance value, i.e. on its integer L1 distance
-    if (x < 0 || y < 0 || x >= a.W || y >= a.H) return ASTAR_INVALID_COST;
-    int n = a.l1[(size_t)y * a.W + x];
-    if (n == 0xFFFF) return ASTAR_INVALID_COST;          // distance -1: never > minDist
-    return a.cost_lut[n];
+    long long raw = ((volatile lds_ll_t*)s_heap)[i];
+    return make_int2((int)(raw & 0xffffffffll), (int)(raw >> 32));
+}
+__device__ __forceinline__ void lds_entry_store(int i, int2 v)
+{
+    ((volatile lds_ll_t*)s_heap)[i] = ((long long)(unsigned int)v.x) | ((long long)v.y << 32);
+}
+__device__ __forceinline__ int2 heap_read(const int2* g_heap, int i)
+{
+    int2 v = lds_entry(i < AH_LDS ? i : AH_LDS);
+    if (i >= AH_LDS) v = g_heap[i];
+    return v;
+}
+__device__ __forceinline__ void heap_write(int2* g_heap, int i, int2 v)
+{
+    lds_entry_store(i < AH_LDS ? i : AH_LDS, v);
+    if (i >= AH_LDS) g_heap[i] = v;
 }
 
-// node layout: x = fCost, y = gCost, z = cell index, w = parent cell index
+// std::__push_heap(first, hole, 0, value, greater-by-fCost) (stl_heap.h:128-146) by one wavefront: lane a holds the
+// (a+1)-th ancestor of the hole; the value rises past the leading run of ancestors with a larger fCost, each of which
+// drops one level.  IN_LDS: the hole (and therefore its whole ancestor chain) is below AH_LDS -- that instantiation
+// contains no vector-memory instruction, so the loads the caller left in flight are not waited for here.
+template <bool IN_LDS>
+__device__ __forceinline__ void heap_sift_up(int2* g_heap, int hole, int2 value, int lane)
+{
+    const unsigned int hp = (unsigned int)hole + 1u;
+    const int D = 31 - __clz(hp);                       // ancestors of the hole
+    const bool v = lane < D;
+    const int anc = (int)(hp >> (lane + 1)) - 1;
+    const int below = (int)(hp >> lane) - 1;            // where this ancestor lands if it drops one level
+    int2 e = make_int2(0, 0);
+    if (v) e = IN_LDS ? lds_entry(anc) : heap_read(g_heap, anc);
+    const unsigned long long m = __ballot(v && (e.x > value.x));
+    const int t = __ffsll((long long)~m) - 1;           // length of the leading run
+    if (IN_LDS) {
+        if (lane < t) lds_entry_store(below, e);
+        if (lane == 0) lds_entry_store((int)(hp >> t) - 1, value);
+    } else {
+        if (lane < t) heap_write(g_heap, below, e);
+        if (lane == 0) heap_write(g_heap, (int)(hp >> t) - 1, value);
+        __threadfence_block();                          // drain the wave's HBM stores before dependent loads
+    }
+    __builtin_amdgcn_wave_barrier();
+}
+
+// std::__adjust_heap(first, 0, len, value) (stl_heap.h:214-250): the hole walks to a leaf always taking the child for
+// which comp(right, left) is false, then value is pushed up from there.
+// A round handles the 6-level subtree under the hole with 63 lanes: lane l (level k, index j in its level) loads its
+// own entry and, if internal, the fCost of its two children; bit l of M = ballot("prefers right child").  Lane l is on
+// the walk iff it is a valid node and every ancestor inside the subtree prefers the branch toward it -- a compare of M
+// against two per-lane constant masks (amask: its ancestors' lanes, areq: the branch bit required at each).  Each
+// on-path lane moves its entry to its parent; the deepest on-path lane is the new hole.
+// IN_LDS: len <= AH_LDS, the whole heap is in LDS (no vector-memory instruction in that instantiation).
+template <bool IN_LDS>
+__device__ __forceinline__ void heap_adjust(int2* g_heap, int len, int2 value, int lane, int lk, int ljm1,
+                                            unsigned long long amask, unsigned long long areq)
+{
+    int hole = 0;
+    while (true) {
+        const int hp = hole + 1;
+        const int node = (hp << lk) + ljm1;
+        const bool valid = lane < 63 && node < len;
+        const int cl = 2 * node + 1;
+        const bool two = lane < 31 && cl + 1 < len;     // both children exist
+        int2 e = make_int2(0, 0);
+        int fl = 0, fr = 0;
+        if (valid) {
+            if (IN_LDS) {
+                e = lds_entry(node);
+                if (two) { fl = lds_entry(cl).x; fr = lds_entry(cl + 1).x; }
+            } else {
+                e = heap_read(g_heap, node);
+                if (two) { fl = heap_read(g_heap, cl).x; fr = heap_read(g_heap, cl + 1).x; }
+            }
+        }
+        // right child preferred unless comp(right, left), i.e. right.fCost > left.fCost; a lone left child -> left
+        const unsigned long long M = __ballot(valid && two && !(fr > fl));
+        const bool on_path = valid && (((M ^ areq) & amask) == 0ull);
+        const unsigned long long P = __ballot(on_path);
+        const int cur = 63 - __clzll((long long)P);     // deepest on-path lane
+        if (on_path && lane > 0) {
+            if (IN_LDS) lds_entry_store((node - 1) >> 1, e);
+            else heap_write(g_heap, (node - 1) >> 1, e);
+        }
+        hole = __builtin_amdgcn_readlane(node, cur);
+        if (!(cur >= 31 && 2 * hole + 1 < len)) break;
+    }
+    if (!IN_LDS) __threadfence_block();
+    __builtin_amdgcn_wave_barrier();
+    heap_sift_up<IN_LDS>(g_heap, hole, value, lane);
+}
+
+// One wavefront runs the reference's search loop (astar.cpp:75-135) with libstdc++'s heap operations executed
+// cooperatively; lanes 0..3 evaluate the four neighbours of the popped node, lane 4 re-derives its gCost.
+// Closed cells: closed[] is written with a no-return atomic compare-and-swap (first closing wins) and read with
+// L1-bypassing loads, so no lane ever waits on the closing store of the popped cell.
 __global__ __launch_bounds__(64) void k_astar(astar_args a)
 {
-    if (threadIdx.x != 0) return;                        // v1: the heap is walked by one lane (see DESIGN.md "A*")
+    int2* g_heap = a.heap;
+    const int lane = threadIdx.x;
     astar_result res; res.status = ASTAR_ST_NOPATH; res.path_len = 0; res.pops = 0; res.pushes = 0;
-    const int start = a.sy * a.W + a.sx, goal = a.gy * a.W + a.gx;
-    bool ok = astar_cell_cost(a, a.gx, a.gy) != ASTAR_INVALID_COST       // astar.cpp:40-44
-              && astar_cell_cost(a, a.sx, a.sy) != ASTAR_INVALID_COST    // :46-50
-              && !(a.sx == a.gx && a.sy == a.gy);                        // :52-56
-    if (!ok) { *a.result = res; return; }
-    int4* h = a.heap;
-    long long len = 1;
-    h[0] = make_int4(0, 0, start, 0);                    // firstNode: costs 0, parent Point() == (0,0)
-    const int xD[4] = {1, -1, 0, 0};
-    const int yD[4] = {0, 0, 1, -1};
-    while (len > 0) {
+    for (int q = 0; q < 6; ++q) res.stamps[q] = 0;
+    const bool cost_in_lds = a.cost_n <= AH_COST_LDS;
+    lds_int_t* s_cost = (lds_int_t*)s_heap + 2 * (AH_LDS + 1);
+    if (cost_in_lds) for (int i = lane; i < a.cost_n; i += 64) s_cost[i] = a.cost_lut[i];
+    __syncthreads();
+    // isValid (astar.cpp:140-149, D5) folded with get_oCost (astar.cpp:181-186): both depend only on the cell's distance
+    // value, i.e. on its integer L1 distance
+    auto cell_cost = [&](int x, int y) -> int {
+        if (x < 0 || y < 0 || x >= a.W || y >= a.H) return ASTAR_INVALID_COST;
+        int n = a.l1[(size_t)y * a.W + x];
+        if (n == 0xFFFF) return ASTAR_INVALID_COST;                 // distance -1: never > minDist
+        return a.cost_lut[n];
+    };
+    const bool ok = cell_cost(a.gx, a.gy) != ASTAR_INVALID_COST       // astar.cpp:40-44
+                    && cell_cost(a.sx, a.sy) != ASTAR_INVALID_COST    // :46-50
+                    && !(a.sx == a.gx && a.sy == a.gy);               // :52-56
+    if (!ok) { if (lane == 0) *a.result = res; return; }
+
+    // ---- per-lane constants of the sift-down rounds
+    const int lk = 31 - __clz(lane + 1);                // level of this lane in a 6-level subtree (lane 63 unused)
+    const int lj = (lane + 1) - (1 << lk);
+    unsigned long long amask = 0, areq = 0;
+    for (int t = 0; t < lk; ++t) {
+        const int anc_lane = ((1 << t) - 1) + (lj >> (lk - t));
+        amask |= 1ull << anc_lane;
+        areq |= (unsigned long long)((lj >> (lk - t - 1)) & 1) << anc_lane;
+    }
+    // lane-constant neighbour offsets: xDeltas {1,-1,0,0}, yDeltas {0,0,1,-1} (astar.cpp:215-216); lane 4: the cell itself
+    const int ddx = lane == 0 ? 1 : (lane == 1 ? -1 : 0);
+    const int ddy = lane == 2 ? 1 : (lane == 3 ? -1 : 0);
+
+    int len = 1;
+    if (lane == 0) lds_entry_store(0, make_int2(0, (a.sy << 17) | (a.sx << 2)));      // firstNode: all costs 0
+    __builtin_amdgcn_wave_barrier();
+    bool done = false;
+    unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0, tr0 = 0, tr1 = 0, acc_adj = 0, acc_nb = 0, acc_all = 0;
+    (void)t0; (void)t1; (void)t2; (void)t3; (void)tr0; (void)tr1; (void)acc_adj; (void)acc_nb; (void)acc_all;
+#ifdef BL_ASTAR_STAMPS
+    tr0 = __builtin_amdgcn_s_memrealtime();
+#endif
+    while (len > 0 && !done) {
         if (res.pops >= a.max_pops) { res.status = ASTAR_ST_LIMIT; break; }
-        const int4 top = h[0];
-        if (a.closed[top.z] < 0) a.closed[top.z] = top.w;             // closedList.push_back: first entry per cell wins
-        // ---- std::pop_heap + pop_back (stl_heap.h __pop_heap/__adjust_heap/__push_heap, comp = fCost greater)
+        STAMP(t0);
+        __threadfence_block();                           // the previous closing CAS has landed before closed[] is re-read
+        const int2 top = lds_entry(0);
+        const int cx = (top.y >> 2) & 0x7fff, cy = (int)((unsigned)top.y >> 17), tdir = top.y & 3;
+        // ---- issue the per-lane loads of this expansion first; they stay in flight across the heap work below.  The two
+        // loads are inline asm so that hipcc does not wait for them at the next join (it would: both results are
+        // "atomic"/L1-bypassing reads); the matching s_waitcnt is the asm statement after the pop.
+        const int nx = cx + ddx, ny = cy + ddy;
+        const bool inb = lane < 5 && nx >= 0 && ny >= 0 && nx < a.W && ny < a.H;
+        const int ncell = inb ? ny * a.W + nx : 0;                             // lanes without a neighbour read cell 0, unused
+        const uint16_t* l1_addr = a.l1 + ncell;
+        const int32_t* cl_addr = a.closed + ncell;
+        int my_l1, my_closed;
+        asm volatile("global_load_ushort %0, %2, off\n\tglobal_load_dword %1, %3, off sc1"
+                     : "=&v"(my_l1), "=&v"(my_closed) : "v"(l1_addr), "v"(cl_addr) : "memory");
+        // closedList.push_back(nNode): only the first entry per cell is ever observed (is_member / get_member)
+        if (lane == 0) atomicCAS(&a.closed[cy * a.W + cx], -1, res.pops == 0 ? 4 : tdir);
+        // ---- openList.pop(): std::pop_heap + pop_back
+        STAMP(t1);
         len -= 1;
         if (len > 0) {
-            const int4 value = h[len];
-            long long hole = 0, child = 0;
-            while (child < (len - 1) / 2) {
-                child = 2 * (child + 1);
-                if (h[child].x > h[child - 1].x) child--;
-                h[hole] = h[child];
-                hole = child;
+            if (len <= AH_LDS) {
+                const int2 value = lds_entry(len);
+                heap_adjust<true>(g_heap, len, value, lane, lk, lj - 1, amask, areq);
+            } else {
+                const int2 value = heap_read(g_heap, len);
+                heap_adjust<false>(g_heap, len, value, lane, lk, lj - 1, amask, areq);
             }
-            if ((len & 1) == 0 && child == (len - 2) / 2) {
-                child = 2 * (child + 1);
-                h[hole] = h[child - 1];
-                hole = child - 1;
-            }
-            long long parent = (hole - 1) / 2;
-            while (hole > 0 && h[parent].x > value.x) {
-                h[hole] = h[parent];
-                hole = parent;
-                parent = (hole - 1) / 2;
-            }
-            h[hole] = value;
         }
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(my_l1), "+v"(my_closed) :: "memory");
+        if (!inb) { my_l1 = 0xFFFF; my_closed = -1; }
+        if (lane >= 4) my_closed = -1;
+        STAMP(t2);
         res.pops += 1;
-        const int cx = top.z % a.W, cy = top.z / a.W;
-        bool done = false;
-        for (int k = 0; k < 4; ++k) {                                  // expand_node (astar.cpp:213-233)
-            const int kx = cx + xD[k], ky = cy + yD[k];
-            const int cost = astar_cell_cost(a, kx, ky);
-            if (cost == ASTAR_INVALID_COST) continue;                  // off grid or !isValid
-            const int kc = ky * a.W + kx;
-            if (kc == goal) {                                          // :107-114 -> makePath (:235-274)
+        // ---- the four neighbours, one per lane (expand_node order is the lane order, astar.cpp:213-233)
+        int my_cost = ASTAR_INVALID_COST;
+        if (inb && my_l1 != 0xFFFF) {
+            if (cost_in_lds) my_cost = s_cost[my_l1]; else my_cost = a.cost_lut[my_l1];
+        }
+        // gCost of the popped node: fCost - hCost - oCost of its cell (the start node carries zeros, astar.cpp:66-69)
+        const int ax = abs(a.gx - nx), ay = abs(a.gy - ny);                     // get_hCost (:170-179); lane 4: the cell itself
+        const int hc = (ax >= ay) ? 14 * ay + 10 * (ax - ay) : 14 * ax + 10 * (ay - ax);
+        const int c_cost = __builtin_amdgcn_readlane(my_cost, 4);
+        const int c_h = __builtin_amdgcn_readlane(hc, 4);
+        const int tg = (res.pops == 1) ? 0 : top.x - c_h - c_cost;
+        const bool nvalid = lane < 4 && my_cost != ASTAR_INVALID_COST;          // in grid and isValid
+        const int f = tg + 10 + hc + (nvalid ? my_cost : 0);                    // get_gCost: 4-connected step
+        const unsigned int goal_m = (unsigned int)__ballot(nvalid && nx == a.gx && ny == a.gy);
+        // a valid neighbour is pushed unless it is closed (:123) or fNew >= INT16_MAX (:103,124)
+        unsigned int push_m = (unsigned int)__ballot(nvalid && my_closed < 0 && 32767 > f);
+        const int ey = (ny << 17) | (nx << 2) | lane;
+        if (goal_m) push_m &= (goal_m & (0u - goal_m)) - 1u;                    // neighbours before the goal neighbour only
+        while (push_m) {
+            const int kk = __ffs((int)push_m) - 1;
+            push_m &= push_m - 1u;
+            if (len >= a.heap_cap) { res.status = ASTAR_ST_CAPACITY; done = true; break; }
+            const int fk = __builtin_amdgcn_readlane(f, kk);
+            const int yk = __builtin_amdgcn_readlane(ey, kk);
+            if (len < AH_LDS) heap_sift_up<true>(g_heap, len, make_int2(fk, yk), lane);      // push_back + std::push_heap
+            else heap_sift_up<false>(g_heap, len, make_int2(fk, yk), lane);
+            len += 1;
+            res.pushes += 1;
+        }
+        if (goal_m && !done) {                                                  // :107-114 -> makePath (:235-274)
+            const int kk = __ffs((int)goal_m) - 1;
+            if (lane == 0) {
+                const int start = a.sy * a.W + a.sx;
+                const int gnx = cx + (kk == 0 ? 1 : (kk == 1 ? -1 : 0)), gny = cy + (kk == 2 ? 1 : (kk == 3 ? -1 : 0));
                 long long n = 0;
-                int cell = kc, parent = top.z;
+                int cell = gny * a.W + gnx, parent = cy * a.W + cx;
                 while (cell != start) {
                     if (n < a.path_cap) a.path[n] = cell;
                     n += 1;
                     cell = parent;
-                    parent = a.closed[cell];
+                    int d = __hip_atomic_load(&a.closed[cell], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (d < 0 || d >= 4) break;                                 // reached the start entry
+                    parent = cell - (d == 0 ? 1 : (d == 1 ? -1 : (d == 2 ? a.W : -a.W)));
                 }
-                res.status = ASTAR_ST_FOUND;
                 res.path_len = (int)n;
-                done = true;
-                break;
             }
-            if (a.closed[kc] >= 0) continue;                           // member of closedList: never pushed (:123)
-            const int g = top.y + 10;                                  // get_gCost: 4-connected step
-            const int ax = abs(a.gx - kx), ay = abs(a.gy - ky);        // get_hCost (:170-179)
-            const int hc = (ax >= ay) ? 14 * ay + 10 * (ax - ay) : 14 * ax + 10 * (ay - ax);
-            const int f = g + hc + cost;
-            if (32767 > f) {                                           // ngbr.fCost = INT16_MAX > fNew (:103,124)
-                if (len >= a.heap_cap) { res.status = ASTAR_ST_CAPACITY; done = true; break; }
-                // std::push_heap
-                const int4 value = make_int4(f, g, kc, top.z);
-                long long hole = len;
-                len += 1;
-                long long parent = (hole - 1) / 2;
-                while (hole > 0 && h[parent].x > value.x) {
-                    h[hole] = h[parent];
-                    hole = parent;
-                    parent = (hole - 1) / 2;
-                }
-                h[hole] = value;
-                res.pushes += 1;
-            }
+            res.status = ASTAR_ST_FOUND;
+            done = true;
         }
-        if (done) break;
+        STAMP(t3);
+#ifdef BL_ASTAR_STAMPS
+        acc_adj += t2 - t1; acc_nb += t3 - t2; acc_all += t3 - t0;
+#endif
     }
-    *a.result = res;
+#ifdef BL_ASTAR_STAMPS
+    tr1 = __builtin_amdgcn_s_memrealtime();
+    res.stamps[0] = (long long)acc_all; res.stamps[1] = (long long)acc_adj; res.stamps[2] = (long long)acc_nb;
+    res.stamps[3] = (long long)(tr1 - tr0); res.stamps[4] = len; res.stamps[5] = 0;
+#endif
+    if (lane == 0) *a.result = res;
 }
 
 void bl_astar_free(bl_ctx* ctx)
@@ -412,13 +577,16 @@ static int astar_prepare(bl_ctx* ctx, const bl_dist* d)
         BL_HIP(hipHostMalloc((void**)&ctx->astar->h_result, sizeof(astar_result), hipHostMallocDefault));
     }
     bl_astar_state* s = ctx->astar;
-    int64_t want = ctx->astar_capacity > 0 ? ctx->astar_capacity : (int64_t)1 << 24;     // 16M nodes = 256 MB
+    int64_t want = ctx->astar_capacity > 0 ? ctx->astar_capacity : (int64_t)1 << 24;     // 16M entries = 128 MB
+    if (want > AH_MAX_CAP) want = AH_MAX_CAP;
+    if (want < AH_LDS + 1) want = AH_LDS + 1;
     if (s->heap_cap != want) {
         BL_HIP(hipStreamSynchronize(ctx->stream));
         if (s->heap) BL_HIP(hipFree(s->heap));
         s->heap = nullptr;
-        BL_HIP(hipMalloc((void**)&s->heap, (size_t)want * sizeof(int4)));
+        BL_HIP(hipMalloc((void**)&s->heap, (size_t)want * sizeof(int2)));
         s->heap_cap = want;
+        BL_HIP(hipFuncSetAttribute((const void*)k_astar, hipFuncAttributeMaxDynamicSharedMemorySize, AH_LDS_BYTES));
     }
     size_t n = (size_t)d->frame.width * d->frame.height;
     if (n > s->closed_cap) {
@@ -448,6 +616,7 @@ extern "C" int bl_astar_search_async(bl_ctx* ctx, const bl_dist* d, const bl_pos
 {
     BL_CHECK_ARG(ctx != nullptr && d != nullptr && start != nullptr && goal != nullptr && params != nullptr);
     BL_CHECK_ARG(d->valid && d->ctx == ctx);
+    BL_CHECK_ARG(d->frame.width <= AH_MAX_DIM && d->frame.height <= AH_MAX_DIM);
     BL_HIP(hipSetDevice(ctx->device));
     int rc = astar_prepare(ctx, d);
     if (rc) return rc;
@@ -475,8 +644,8 @@ extern "C" int bl_astar_search_async(bl_ctx* ctx, const bl_dist* d, const bl_pos
     BL_HIP(hipMemcpyAsync(s->cost_lut, s->h_cost, (size_t)ln * 4, hipMemcpyHostToDevice, ctx->stream));
     astar_args a;
     a.l1 = d->l1; a.W = d->frame.width; a.H = d->frame.height;
-    a.cost_lut = s->cost_lut;
-    a.heap = s->heap; a.heap_cap = s->heap_cap;
+    a.cost_lut = s->cost_lut; a.cost_n = ln;
+    a.heap = s->heap; a.heap_cap = (int)s->heap_cap;
     a.closed = s->closed;
     a.path = s->path; a.path_cap = (long long)s->path_cap;
     a.result = s->d_result;
@@ -487,7 +656,7 @@ extern "C" int bl_astar_search_async(bl_ctx* ctx, const bl_dist* d, const bl_pos
     rc = bl_timer_begin(ctx, BL_K_ASTAR, &e0, &e1);
     if (rc) return rc;
     BL_HIP(hipMemsetAsync(s->closed, 0xFF, (size_t)a.W * a.H * 4, ctx->stream));
-    hipLaunchKernelGGL(k_astar, dim3(1), dim3(64), 0, ctx->stream, a);
+    hipLaunchKernelGGL(k_astar, dim3(1), dim3(64), AH_LDS_BYTES, ctx->stream, a);
     BL_HIP(hipGetLastError());
     rc = bl_timer_end(ctx, BL_K_ASTAR, e0, e1);
     if (rc) return rc;
@@ -507,6 +676,12 @@ extern "C" int bl_astar_search_result(bl_ctx* ctx, bl_pose_xyt_t* out_path, int 
     s->pending = false;
     astar_result r = *s->h_result;
     if (stats) { stats[0] = r.pops; stats[1] = r.pushes; }
+#ifdef BL_ASTAR_STAMPS
+    fprintf(stderr, "[astar stamps] pops %lld cycles/pop all %.0f adjust %.0f expand+push %.0f | realtime ticks(100MHz) %lld -> clock %.2f GHz, final len %lld\n",
+            r.pops, (double)r.stamps[0] / (double)(r.pops ? r.pops : 1), (double)r.stamps[1] / (double)(r.pops ? r.pops : 1),
+            (double)r.stamps[2] / (double)(r.pops ? r.pops : 1), r.stamps[3],
+            r.stamps[3] ? (double)r.stamps[0] / ((double)r.stamps[3] * 10.0) / 1.0 : 0.0, r.stamps[4]);
+#endif
     out_path[0] = s->start;                                            // path.path.push_back(start) (astar.cpp:21)
     *out_len = 1;
     if (r.status == ASTAR_ST_CAPACITY) { bl_set_error("A* open list exceeded its capacity (%lld pops)", r.pops); return BL_ERR_CAPACITY; }
