@@ -43,12 +43,13 @@ def build_inputs(args, total_steps):
         half = args.grid * 0.05 / 2.0
         m = dict(cells=np.where(cells > 0, 127, -100).astype(np.int8), origin=(np.float32(-half), np.float32(-half)),
                  mpc=np.float32(0.05))
-        start = (0.3, 0.3, 0.0)
+        start, side = (0.3, 0.3, 0.0), 0.5
     else:
-        start = (0.0, 0.0, 0.0)
+        # a 0.8 m square loop that keeps >= 0.2 m clearance inside the mapped arena of obstacle_slam (searched offline)
+        start, side = (-0.75, 0.2, 0.0), 0.8
     truth = np.where(m["cells"] > 0, 127, -127).astype(np.int8)
     rng = np.random.default_rng(1234)
-    poses = synth.square_trajectory(start, total_steps, step_len=0.02, turn=0.05, side=1.0)
+    poses = synth.square_trajectory(start, total_steps, step_len=0.02, turn=0.05, side=side)
     odo = synth.odometry_from_truth(poses, rng)
     scans = []
     for k in range(1, len(poses)):
@@ -115,7 +116,10 @@ def main():
     ap.add_argument("--particles", type=int, default=100_000)
     ap.add_argument("--grid", type=int, default=200, help="grid side in cells (200 = shipped obstacle_slam map)")
     ap.add_argument("--no-astar", action="store_true", help="skip the replan (distance grid + A*) in the step")
-    ap.add_argument("--goal-l1", type=int, default=40, help="max L1 distance (cells) of the replan goal from the start")
+    ap.add_argument("--goal", type=float, nargs=2, default=None, metavar=("X", "Y"),
+                    help="replan goal in metres (default: a point on the driven loop, see build_inputs)")
+    ap.add_argument("--goal-l1", type=int, default=40, help="without --goal on a non-default grid: max L1 distance (cells) "
+                    "of the replan goal from the start")
     ap.add_argument("--cpu-steps", type=int, default=10, help="steps of the CPU baseline sample (0 = skip)")
     args = ap.parse_args()
 
@@ -149,7 +153,15 @@ def main():
     planner.setMap(grid)
     goal = None
     if not args.no_astar:
-        goal = pick_goal(planner.distances_.cells(), m["origin"], poses[0][:2], 0.2, args.goal_l1)
+        if args.goal is not None:
+            goal = tuple(args.goal)
+        elif args.grid == 200:
+            # Replan target: a fixed point on the driven loop, 0-0.9 m from the robot (0-450 pops per search).  The
+            # reference's cost function (negative obstacle cost, duplicate re-expansion) makes most farther goals on this
+            # map take 1e5-2e6 pops, which the reference itself cannot finish; see DESIGN.md "A*".
+            goal = (-0.35, 0.2)
+        else:
+            goal = pick_goal(planner.distances_.cells(), m["origin"], poses[0][:2], 0.2, args.goal_l1)
     goal_pose = bl.make_pose(goal[0], goal[1], 0.0) if goal else None
 
     spf.initializeFilterAtPose(bl.make_pose(*odo[0], utime=int(scans[0].times[0])), seed=42)

@@ -25,6 +25,8 @@
 #include "bl_internal.h"
 
 #define MCL_THREADS 256
+#define MCL_WIN_SMALL_BYTES (40 * 1024)       // whole-grid staging budget per 256-thread workgroup (200x200 int8 = 40 KB)
+#define MCL_WIN_BIG 384                       // window side for larger grids: 384^2 = 144 KB, one 1024-thread workgroup per CU
 #define SCAN_THREADS 256
 #define SCAN_ITEMS 8
 #define SCAN_TILE (SCAN_THREADS * SCAN_ITEMS)
@@ -47,6 +49,8 @@ struct bl_pf {
     float4* parent;
     pf_state* state;
     double* partials;         // [blocks][5]
+    int partials_cap;
+    bool use_lds;
     unsigned long long* block_sums;   // scan scratch
     int scan_blocks;
     int32_t* dbg_idx;
@@ -74,29 +78,45 @@ __device__ __forceinline__ double wave_sum(double v)
     return v;
 }
 
-__device__ __forceinline__ int grid_odds(const int8_t* __restrict__ cells, const bl_frame& f, int x, int y)
+// Map window staged in LDS (hard part 5): every gather of one update falls inside the bounding box
+// of the particle cloud dilated by the laser range.  win = (x0, y0, w, h) in cells, already clipped to the grid; stride
+// is the LDS row pitch in bytes.  A cell outside the window (cloud wider than expected) is read from HBM/L2 instead,
+// so the window is a cache, never a correctness condition.
+struct map_window { int x0, y0, w, h, stride; };
+
+typedef __attribute__((address_space(3))) signed char lds_i8_t;
+
+template <bool USE_LDS>
+__device__ __forceinline__ int grid_odds(const int8_t* __restrict__ cells, const lds_i8_t* s_map, const map_window& win,
+                                         const bl_frame& f, int x, int y)
 {
     // OccupancyGrid::logOdds (occupancy_grid.cpp:63-71): 0 outside the grid
-    if (x >= 0 && x < f.width && y >= 0 && y < f.height) return cells[(size_t)y * f.width + x];
-    return 0;
+    if (x < 0 || x >= f.width || y < 0 || y >= f.height) return 0;
+    if (USE_LDS) {
+        const unsigned int wx = (unsigned int)(x - win.x0), wy = (unsigned int)(y - win.y0);
+        if (wx < (unsigned int)win.w && wy < (unsigned int)win.h) return s_map[wy * win.stride + wx];
+    }
+    return cells[(size_t)y * f.width + x];
 }
 
 // SensorModel::scoreRay (sensor_model.cpp:28-59) in half-units: returns 2*odds, o1 or o2 (score = that / 2)
-__device__ __forceinline__ int score_ray_half_units(const int8_t* __restrict__ cells, const bl_frame& f, float sx, float sy,
+template <bool USE_LDS>
+__device__ __forceinline__ int score_ray_half_units(const int8_t* __restrict__ cells, const lds_i8_t* s_map,
+                                                     const map_window& win, const bl_frame& f, float sx, float sy,
                                                      float range, float cs, float sn)
 {
     int ex = (int)((range * cs * f.cpm) + sx);
     int ey = (int)((range * sn * f.cpm) + sy);
-    int odds = grid_odds(cells, f, ex, ey);
+    int odds = grid_odds<USE_LDS>(cells, s_map, win, f, ex, ey);
     if (odds > 0) return 2 * odds;
     int xx = (int)((2 * range * cs * f.cpm) + sx);
     int xy = (int)((2 * range * sn * f.cpm) + sy);
     int ax, ay;
     bl_bresenham_first_step(ex, ey, (int)sx, (int)sy, &ax, &ay);
-    int o1 = grid_odds(cells, f, ax, ay);
+    int o1 = grid_odds<USE_LDS>(cells, s_map, win, f, ax, ay);
     if (o1 > 0) return o1;
     bl_bresenham_first_step(ex, ey, xx, xy, &ax, &ay);
-    int o2 = grid_odds(cells, f, ax, ay);
+    int o2 = grid_odds<USE_LDS>(cells, s_map, win, f, ax, ay);
     return o2 > 0 ? o2 : 0;
 }
 
@@ -123,6 +143,7 @@ struct mcl_args {
     uint32_t seed_lo, seed_hi, step;
     int interp;                   // parent utime != pose utime (first moved update)
     int resample;                 // 0: action-only (source = own index)
+    int win_w, win_h;             // LDS map window size in cells (0: no staging); >= grid size means the whole grid
 };
 
 __device__ __forceinline__ void philox_normals3(uint32_t m, uint32_t step, uint32_t k0, uint32_t k1, float z[3])
@@ -143,11 +164,60 @@ __device__ __forceinline__ void philox_normals3(uint32_t m, uint32_t step, uint3
 
 // One thread per output particle m of the shard: low-variance resample (gather), ActionModel::applyAction,
 // SensorModel::likelihood, weight units, and the block's partial sums for normalisation + pose estimate.
-template <int INTERP>
-__global__ __launch_bounds__(MCL_THREADS) void k_mcl_main(mcl_args a)
+template <int INTERP, int BLOCK, bool USE_LDS>
+__global__ __launch_bounds__(BLOCK) void k_mcl_main(mcl_args a)
 {
-    __shared__ double s_part[MCL_THREADS / 64][5];
-    const int j = blockIdx.x * MCL_THREADS + threadIdx.x;
+    extern __shared__ __align__(16) signed char s_dyn[];
+    __shared__ double s_part[BLOCK / 64][5];
+    __shared__ map_window s_win;
+    const lds_i8_t* s_map = (const lds_i8_t*)s_dyn;
+    map_window win = {0, 0, 0, 0, 0};
+
+    if (USE_LDS) {
+        // ---- stage the map window: centred on the cell the previous pose estimate moves to under the odometry action
+        if (threadIdx.x == 0) {
+            map_window w;
+            if (a.win_w >= a.frame.width && a.win_h >= a.frame.height) {
+                w.x0 = 0; w.y0 = 0; w.w = a.frame.width; w.h = a.frame.height;
+            } else {
+                const bl_pose_xyt_t p = a.state->pose;
+                const float ex = (float)((double)p.x + a.trans * cos((double)p.theta + a.rot1));
+                const float ey = (float)((double)p.y + a.trans * sin((double)p.theta + a.rot1));
+                float gx, gy;
+                bl_global_to_grid(ex, ey, a.frame, &gx, &gy);
+                int cx = (gx > -1.0e9f && gx < 1.0e9f) ? (int)gx : 0, cy = (gy > -1.0e9f && gy < 1.0e9f) ? (int)gy : 0;
+                int x0 = max(0, min(cx - a.win_w / 2, a.frame.width - a.win_w));
+                int y0 = max(0, min(cy - a.win_h / 2, a.frame.height - a.win_h));
+                x0 &= ~3;                                     // dword-aligned window columns
+                w.x0 = x0; w.y0 = y0;
+                w.w = min(a.win_w, a.frame.width - x0);
+                w.h = min(a.win_h, a.frame.height - y0);
+            }
+            w.stride = (w.w + 3) & ~3;
+            s_win = w;
+        }
+        __syncthreads();
+        win = s_win;
+        const int wq = win.stride >> 2;                       // dwords per staged row
+        int* s_map32 = (int*)s_dyn;
+        const bool aligned = ((a.frame.width & 3) == 0) && ((win.x0 & 3) == 0);
+        for (int i = threadIdx.x; i < wq * win.h; i += BLOCK) {
+            const int ry = i / wq, q = i - ry * wq;
+            const size_t g = (size_t)(win.y0 + ry) * a.frame.width + win.x0 + 4 * q;
+            int v;
+            if (aligned && win.x0 + 4 * q + 3 < a.frame.width) {
+                v = *(const int*)(a.cells + g);
+            } else {
+                v = 0;
+                for (int b = 0; b < 4; ++b)
+                    if (win.x0 + 4 * q + b < a.frame.width) v |= ((int)(unsigned char)a.cells[g + b]) << (8 * b);
+            }
+            s_map32[i] = v;
+        }
+        __syncthreads();
+    }
+
+    const int j = blockIdx.x * BLOCK + threadIdx.x;
     const bool active = j < a.n_local;
     double t_units = 0, t_x = 0, t_y = 0, t_s = 0, t_c = 0;
 
@@ -203,7 +273,7 @@ __global__ __launch_bounds__(MCL_THREADS) void k_mcl_main(mcl_args a)
                 }
                 float sn, cs;
                 bl_sincosf(theta, &sn, &cs);
-                acc += score_ray_half_units(a.cells, a.frame, sx, sy, range, cs, sn);
+                acc += score_ray_half_units<USE_LDS>(a.cells, s_map, win, a.frame, sx, sy, range, cs, sn);
             }
         }
         // ---- computeNormalizedPosterior (particle_filter.cpp:116-141): w = max(likelihood, 0.001) in units of 0.0005
@@ -226,7 +296,7 @@ __global__ __launch_bounds__(MCL_THREADS) void k_mcl_main(mcl_args a)
     __syncthreads();
     if (threadIdx.x < 5) {
         double v = 0;
-        for (int w = 0; w < MCL_THREADS / 64; ++w) v += s_part[w][threadIdx.x];
+        for (int w = 0; w < BLOCK / 64; ++w) v += s_part[w][threadIdx.x];
         a.partials[(size_t)blockIdx.x * 5 + threadIdx.x] = v;
     }
 }
@@ -386,6 +456,14 @@ static int pf_alloc(bl_pf* pf)
     BL_HIP(hipMalloc((void**)&pf->state, sizeof(pf_state)));
     int blocks = (int)((n + MCL_THREADS - 1) / MCL_THREADS);
     BL_HIP(hipMalloc((void**)&pf->partials, (size_t)blocks * 5 * sizeof(double)));
+    pf->partials_cap = blocks;
+    static bool attr_set = false;
+    if (!attr_set) {
+        const int big = MCL_WIN_BIG * MCL_WIN_BIG;
+        BL_HIP(hipFuncSetAttribute((const void*)k_mcl_main<0, 1024, true>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+        BL_HIP(hipFuncSetAttribute((const void*)k_mcl_main<1, 1024, true>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+        attr_set = true;
+    }
     pf->scan_blocks = (int)((N + SCAN_TILE - 1) / SCAN_TILE);
     BL_HIP(hipMalloc((void**)&pf->block_sums, (size_t)pf->scan_blocks * sizeof(unsigned long long)));
     BL_HIP(hipMalloc((void**)&pf->dbg_idx, n * sizeof(int32_t)));
@@ -407,6 +485,7 @@ extern "C" int bl_pf_create(bl_ctx* ctx, int num_particles, int shard_lo, int sh
     pf->ctx = ctx;
     pf->N = num_particles; pf->lo = shard_lo; pf->hi = shard_hi; pf->n_local = shard_hi - shard_lo;
     pf->noise_seed = 0x243F6A8885A308D3ull;
+    pf->use_lds = getenv("BOTLAB_MCL_NO_LDS") == nullptr;
     *out = pf;
     return BL_OK;
 }
@@ -501,6 +580,10 @@ extern "C" int bl_pf_set_particles(bl_pf* pf, const bl_particle_t* particles, co
     pf->parent_utime = particles[0].parent_pose.utime;
     pf->initialized = true;
     pf->pending_end = false;
+    // posteriorPose_ is not defined by a particle upload; the last particle's pose seeds it (it only centres the LDS
+    // map window of the next update and is what poseEstimate() returns until that update)
+    hipLaunchKernelGGL(k_pf_set_pose, dim3(1), dim3(1), 0, pf->ctx->stream, pf->state, particles[pf->N - 1].pose, 0);
+    BL_HIP(hipGetLastError());
     return pf_scan(pf, 0, 0, 0);
 }
 
@@ -583,12 +666,37 @@ static int pf_launch_main(bl_pf* pf, const bl_grid* map, int R, int rand_value, 
     // MovingLaserScan(scan, parent_pose, pose): parent_pose.utime is the particle's previous pose utime, pose.utime is
     // ActionModel::utime_ == 0 (D3); they differ only on the first moved update after initialisation.
     a.interp = (map && pf->pose_utime != 0) ? 1 : 0;
-    int blocks = (pf->n_local + MCL_THREADS - 1) / MCL_THREADS;
+    // LDS map window: the whole grid when it fits the small-window budget (4 workgroups of 256 per CU), otherwise a
+    // MCL_WIN_BIG^2 window per 1024-thread workgroup (one per CU); action-only updates read no map.
+    int block = MCL_THREADS, lds_bytes = 0;
+    a.win_w = 0; a.win_h = 0;
+    if (map && pf->use_lds) {
+        const size_t whole = (size_t)((map->frame.width + 3) & ~3) * map->frame.height;
+        if (whole <= MCL_WIN_SMALL_BYTES) {
+            a.win_w = map->frame.width; a.win_h = map->frame.height;
+            lds_bytes = (int)whole;
+        } else {
+            a.win_w = map->frame.width < MCL_WIN_BIG ? map->frame.width : MCL_WIN_BIG;
+            a.win_h = map->frame.height < MCL_WIN_BIG ? map->frame.height : MCL_WIN_BIG;
+            lds_bytes = ((a.win_w + 3) & ~3) * a.win_h;
+            block = 1024;
+        }
+    }
+    int blocks = (pf->n_local + block - 1) / block;
+    if (blocks > pf->partials_cap) { bl_set_error("internal: partials buffer too small"); return BL_ERR_STATE; }
     hipEvent_t e0, e1;
     int rc = bl_timer_begin(ctx, BL_K_MCL_MAIN, &e0, &e1);
     if (rc) return rc;
-    if (a.interp) hipLaunchKernelGGL(k_mcl_main<1>, dim3(blocks), dim3(MCL_THREADS), 0, ctx->stream, a);
-    else hipLaunchKernelGGL(k_mcl_main<0>, dim3(blocks), dim3(MCL_THREADS), 0, ctx->stream, a);
+    if (lds_bytes == 0) {
+        if (a.interp) hipLaunchKernelGGL((k_mcl_main<1, MCL_THREADS, false>), dim3(blocks), dim3(MCL_THREADS), 0, ctx->stream, a);
+        else hipLaunchKernelGGL((k_mcl_main<0, MCL_THREADS, false>), dim3(blocks), dim3(MCL_THREADS), 0, ctx->stream, a);
+    } else if (block == MCL_THREADS) {
+        if (a.interp) hipLaunchKernelGGL((k_mcl_main<1, MCL_THREADS, true>), dim3(blocks), dim3(MCL_THREADS), lds_bytes, ctx->stream, a);
+        else hipLaunchKernelGGL((k_mcl_main<0, MCL_THREADS, true>), dim3(blocks), dim3(MCL_THREADS), lds_bytes, ctx->stream, a);
+    } else {
+        if (a.interp) hipLaunchKernelGGL((k_mcl_main<1, 1024, true>), dim3(blocks), dim3(1024), lds_bytes, ctx->stream, a);
+        else hipLaunchKernelGGL((k_mcl_main<0, 1024, true>), dim3(blocks), dim3(1024), lds_bytes, ctx->stream, a);
+    }
     BL_HIP(hipGetLastError());
     rc = bl_timer_end(ctx, BL_K_MCL_MAIN, e0, e1);
     if (rc) return rc;

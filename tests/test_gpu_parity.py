@@ -167,6 +167,45 @@ def test_mcl_parity_with_oracle_noise(oracle, maps, gpu_ctx, N):
     assert moved_updates >= 7
 
 
+@pytest.mark.parametrize("start,kidnap", [((3.3, -7.1, 0.4), False), ((-11.0, 6.0, 2.0), True)])
+def test_mcl_parity_large_grid_lds_window(oracle, maps, gpu_ctx, start, kidnap):
+    """A 1000x1000 grid does not fit the whole-grid LDS staging: the kernel stages a 384x384 window around the predicted
+    pose and falls back to global gathers outside it.  kidnap=True puts the particle cloud far from the pose the
+    window is centred on, so every gather takes the fallback path."""
+    N = 3000
+    world = synth.tile_world(maps["astar_maze"]["cells"], 1000)
+    origin, mpc, cpm = (np.float32(-25.0), np.float32(-25.0)), np.float32(0.05), helpers.CPM_DEFAULT
+    cells = np.where(world > 0, 100, -60).astype(np.int8)
+    g = bl.OccupancyGrid.from_cells(cells, origin, mpc, cellsPerMeter=cpm, ctx=gpu_ctx)
+    poses = synth.square_trajectory(start, 6, step_len=0.05, turn=0.1, side=0.2)
+    rng = np.random.default_rng(5)
+    odo = synth.odometry_from_truth(poses, rng)
+    opf = oracle_lib.OraclePF(oracle, N)
+    opf.init_at_pose(oracle.pose(*start, utime=1000), 99)
+    parts = opf.particles()
+    if kidnap:      # the window is centred on the LAST particle's pose (bl_pf_set_particles); move it far away
+        parts["x"][-1] += 12.0
+        parts["y"][-1] -= 9.0
+        opf.set_particles(parts)
+    pf = bl.ParticleFilter(N, ctx=gpu_ctx)
+    pf.setParticles(parts)
+    for k in range(1, len(poses)):
+        scan = synth.raycast_scan(world, origin, 0.05, poses[k - 1], poses[k], 1000 + 100000 * k)
+        o = odo[k]
+        res = opf.update(oracle.pose(*o, utime=scan.utime), scan, cells, mpc, cpm, origin, 777 + k)
+        pose = pf.updateFilter(bl.make_pose(*o, utime=scan.utime), scan, g, rand_value=777 + k, noise=res["noise"])
+        if not res["moved"]:
+            continue
+        idx, like = pf.debugLast()
+        assert np.array_equal(idx, res["idx"])
+        assert np.array_equal(like.astype(np.float64) * 0.5, res["raw"])
+        got, exp = pf.particles(), opf.particles()
+        for f in ("x", "y", "theta"):
+            assert np.allclose(got[f], exp[f], rtol=REL, atol=1e-7)
+        assert np.allclose(got["weight"], exp["weight"], rtol=REL, atol=0)
+        assert (res["raw"] > 0).sum() > N // 2        # the scans really hit the map
+
+
 def test_mcl_action_only(oracle, maps, gpu_ctx):
     N = 512
     m, g, opf, pf, odo, scans, rands, cells = _mcl_sequence(oracle, maps, gpu_ctx, N, 5)
