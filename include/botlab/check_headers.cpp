@@ -1,0 +1,33 @@
+// Compile check of the drop-in classes (g++ -fsyntax-only): instantiates every template with plain message structs
+// that carry the fields of the lcm-gen types (lcmtypes/*.lcm).  Not part of the product; see tests/cpp/dropin_test.cpp
+// for the run-time check on a GPU.
+#include <botlab/dropin_test_types.hpp>
+
+typedef botlab_hip::MappingT<pose_xyt_t, lidar_t> Mapping;
+typedef botlab_hip::ParticleFilterT<pose_xyt_t, lidar_t, particle_t, particles_t> ParticleFilter;
+
+robot_path_t plan(pose_xyt_t a, pose_xyt_t b, const botlab_hip::ObstacleDistanceGrid& d, const botlab_hip::SearchParams& p)
+{
+    return botlab_hip::search_for_path_t<robot_path_t, pose_xyt_t>(a, b, d, p);
+}
+
+void touch()
+{
+    botlab_hip::OccupancyGrid g(10.0f, 10.0f, 0.05f), g2;
+    g2 = g;
+    occupancy_grid_t m = g.toLCM<occupancy_grid_t>();
+    g2.fromLCM(m);
+    Mapping mapper(5.0f, 4, 1);
+    ParticleFilter pf(200);
+    lidar_t scan;
+    pose_xyt_t p;
+    mapper.updateMap(scan, p, g);
+    pf.initializeFilterAtPose(p);
+    p = pf.updateFilter(p, scan, g);
+    p = pf.updateFilterActionOnly(p);
+    particles_t ps = pf.particles();
+    (void)ps;
+    botlab_hip::ObstacleDistanceGrid d, d2(d);
+    d.setDistances(g);
+    (void)d(0, 0);
+}

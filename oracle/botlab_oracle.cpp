@@ -663,6 +663,16 @@ void orc_estimate_pose(const orc_particle_t* p, int n, orc_pose_t* out)
     *out = ParticleFilter::estimate(v);
 }
 
+// ---- ActionModel alone (for the CPU stand-in engine of the sharding tests)
+void* orc_action_create(void) { return new ActionModel(); }
+void orc_action_destroy(void* a) { delete static_cast<ActionModel*>(a); }
+int orc_action_update(void* a, const orc_pose_t* odom) { return static_cast<ActionModel*>(a)->update(*odom) ? 1 : 0; }
+void orc_action_apply_noise(void* a, orc_particle_t* p, int n, const float* noise)
+{
+    ActionModel* am = static_cast<ActionModel*>(a);
+    for (int i = 0; i < n; ++i) p[i] = am->apply_with_noise(p[i], noise + 3 * i);
+}
+
 // ---- ObstacleDistanceGrid
 void orc_set_distances(const orc_grid_t* map, orc_dist_t* dist) { set_distances(*map, *dist); }
 

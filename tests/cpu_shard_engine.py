@@ -1,0 +1,108 @@
+"""CPU stand-in for botlab_amd.sharded.HipShardEngine, used ONLY to exercise the sharding orchestration
+(ShardedParticleFilter + torch.distributed collectives) under gloo without a GPU.  It implements the same begin / end
+contract with numpy and the oracle: integer weight units, the `U*S <= prefix[i]` resampling rule, a 16-byte exchange
+record per particle.  TEST INFRASTRUCTURE -- never imported by the product."""
+import ctypes as C
+
+import numpy as np
+import torch
+
+import oracle_lib
+from botlab_amd.sharded import shard_bounds
+
+RAND_MAX = 2147483647
+
+
+class CpuShardEngine:
+    def __init__(self, num_particles, rank, world, cells, mpc, cpm, origin):
+        self.N, self.rank, self.world = num_particles, rank, world
+        self.lo, self.hi, self.S = shard_bounds(num_particles, rank, world)
+        self.o = oracle_lib.load_oracle()
+        self.cells, self.mpc, self.cpm, self.origin = cells, mpc, cpm, origin
+        padded = self.S * world
+        self.rec = [torch.zeros(padded, 4, dtype=torch.float32) for _ in range(2)]
+        self.sums = torch.zeros(8, dtype=torch.float64)
+        self.cur = 0
+        self.pending = False
+        self.action = self.o.lib.orc_action_create()
+        self.pose_utime = 0
+        self.parent_utime = 0
+        self.pose = None
+        self.prefix = None
+        self.total = 0
+        self.last_idx = None
+
+    def _units(self, which):
+        return self.rec[which][:self.N, 3].numpy().view(np.uint32)
+
+    def _rescan(self):
+        u = self._units(self.cur).astype(np.uint64)
+        self.prefix = np.cumsum(u)
+        self.total = int(self.prefix[-1])
+
+    def set_particles(self, particles, units=None):
+        r = self.rec[0].numpy()
+        r[:self.N, 0], r[:self.N, 1], r[:self.N, 2] = particles["x"], particles["y"], particles["theta"]
+        r[:self.N, 3] = (np.ones(self.N, np.uint32) if units is None else units.astype(np.uint32)).view(np.float32)
+        self.cur = 0
+        self.pose_utime = int(particles["utime"][0])
+        self.parent_utime = int(particles["p_utime"][0])
+        self.parent = np.stack([particles["p_x"], particles["p_y"], particles["p_theta"]], 1)[self.lo:self.hi].astype(np.float32)
+        self._rescan()
+
+    def begin(self, odometry, scan, grid, rand_value, noise=None):
+        op = self.o.pose(odometry.x, odometry.y, odometry.theta, utime=odometry.utime)
+        moved = bool(self.o.lib.orc_action_update(self.action, C.byref(op)))
+        self.pending_utime = odometry.utime
+        if not moved:
+            return False
+        n = self.hi - self.lo
+        m = np.arange(self.lo, self.hi)
+        M_inv = 1.0 / self.N
+        r = (float(rand_value) / float(RAND_MAX)) * M_inv
+        T = (r + m * M_inv) * float(self.total)
+        idx = np.minimum(np.searchsorted(self.prefix.astype(np.float64), T, side="left"), self.N - 1)
+        self.last_idx = idx
+        src = self.rec[self.cur].numpy()
+        parts = np.zeros(n, dtype=oracle_lib.PARTICLE_DTYPE)
+        parts["x"], parts["y"], parts["theta"] = src[idx, 0], src[idx, 1], src[idx, 2]
+        parts["utime"] = self.pose_utime
+        self.o.lib.orc_action_apply_noise(self.action, parts.ctypes.data, n, np.ascontiguousarray(noise[3 * self.lo:3 * self.hi], np.float32).ctypes.data)
+        like = np.zeros(n, np.float64)
+        g = self.o.grid(self.cells, self.mpc, self.cpm, self.origin)
+        l = self.o.lidar(scan)
+        self.o.lib.orc_likelihood(parts.ctypes.data, n, C.byref(l), C.byref(g), like.ctypes.data)
+        half = np.rint(like * 2.0).astype(np.int64)
+        units = np.where(half > 0, half * 1000, 2).astype(np.uint32)
+        dst = self.rec[self.cur ^ 1].numpy()
+        dst[self.lo:self.hi, 0], dst[self.lo:self.hi, 1], dst[self.lo:self.hi, 2] = parts["x"], parts["y"], parts["theta"]
+        dst[self.lo:self.hi, 3] = units.view(np.float32)
+        self.parent = np.stack([parts["p_x"], parts["p_y"], parts["p_theta"]], 1)
+        u = units.astype(np.float64)
+        th = parts["theta"]
+        sn = np.array([self.o.lib.orc_sinf(float(t)) for t in th], np.float64)
+        cs = np.array([self.o.lib.orc_cosf(float(t)) for t in th], np.float64)
+        s = self.sums.numpy()
+        s[:] = 0
+        s[0], s[1], s[2], s[3], s[4] = u.sum(), (u * parts["x"]).sum(), (u * parts["y"]).sum(), (u * sn).sum(), (u * cs).sum()
+        self.pending = True
+        return True
+
+    def exchange_record(self):
+        return self.rec[self.cur ^ 1]
+
+    def exchange_sums(self):
+        return self.sums
+
+    def end(self, want_pose=True):
+        if self.pending:
+            self.cur ^= 1
+            self._rescan()
+            s = self.sums.numpy()
+            self.pose = (np.float32(s[1] / s[0]), np.float32(s[2] / s[0]), np.float32(np.arctan2(s[3], s[4])))
+            self.parent_utime, self.pose_utime = self.pose_utime, 0
+            self.pending = False
+        return self.pose
+
+    def record(self):
+        return self.rec[self.cur][:self.N].numpy().copy()

@@ -83,6 +83,11 @@ class Oracle:
         L.orc_search_for_path.restype = C.c_int
         L.orc_search_for_path.argtypes = [C.POINTER(OPose), C.POINTER(OPose), C.POINTER(OGrid), C.POINTER(OSearchParams),
                                           C.c_int, C.c_void_p, C.c_int, C.c_void_p]
+        L.orc_action_create.restype = C.c_void_p
+        L.orc_action_destroy.argtypes = [C.c_void_p]
+        L.orc_action_update.restype = C.c_int
+        L.orc_action_update.argtypes = [C.c_void_p, C.POINTER(OPose)]
+        L.orc_action_apply_noise.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
         L.orc_is_valid_goal.restype = C.c_int
         L.orc_is_valid_goal.argtypes = [C.POINTER(OPose), C.POINTER(OGrid), C.c_double, C.c_double, C.c_int, C.POINTER(OPose)]
 
