@@ -7,7 +7,7 @@ odometry are synthesised over the shipped .map (botlab_amd/synth.py) -- "data": 
 
 One step = OccupancyGridSLAM::runSLAMIteration (src/slam/slam.cpp:191-207) + the planner's per-map work
 (src/planning/exploration.cpp:300-317):
-    ParticleFilter::updateFilter(odometry, scan, map)      pre-update map, pose returned to the host
+    ParticleFilter::updateFilter(odometry, scan, map)      pre-update map
     Mapping::updateMap(scan, pose, map)
     ObstacleDistanceGrid::setDistances(map)  +  search_for_path(pose, goal)
 Multi-GPU (--gpus N under torch.distributed.run): the particles are block-sharded over the ranks (RCCL all-gather of
@@ -168,16 +168,22 @@ def main():
 
     pops_total = [0]
 
+    pose_dev = engine.pf.poseDevicePtr()
+
     def step(k):
+        # Everything of one step is enqueued on the ctx stream with the pose estimate staying on the device (it feeds
+        # the map update and the A* start there); ONE synchronisation at the end hands the pose and the path back.
         o = odo[k + 1]
         sc = scans[k]
-        pose = spf.updateFilter(bl.make_pose(o[0], o[1], o[2], utime=sc.utime), sc, grid, int(rands[k]))
-        mapper.updateMap(sc, pose, grid)
+        spf.updateFilter(bl.make_pose(o[0], o[1], o[2], utime=sc.utime), sc, grid, int(rands[k]), want_pose=False)
+        mapper.updateMapDevicePose(sc, pose_dev, sc.utime, grid)
         if goal_pose is not None:
             planner.setMap(grid)
-            path, st = bl.search_for_path(pose, goal_pose, planner.distances_, planner.searchParams_, return_stats=True)
+            bl.search_for_path_begin(goal_pose, planner.distances_, planner.searchParams_, start_dev=pose_dev)
+            path, st = bl.search_for_path_end(planner.distances_, return_stats=True)
             pops_total[0] += st[0]
-        return pose
+            return path[0]                       # the start pose of the path is this step's pose estimate
+        return engine.pf.poseEstimate()
 
     k = 0
     for _ in range(args.warmup):

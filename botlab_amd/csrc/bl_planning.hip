@@ -254,7 +254,7 @@ extern "C" void* bl_dist_device_ptr(bl_dist* d) { return d ? (void*)d->cells : n
 #define ASTAR_ST_CAPACITY 2
 #define ASTAR_ST_LIMIT 3
 
-struct astar_result { int status; int path_len; long long pops; long long pushes; long long stamps[6]; };
+struct astar_result { int status; int path_len; long long pops; long long pushes; bl_pose_xyt_t start; long long stamps[6]; };
 
 // Diagnostic build only (-DBL_ASTAR_STAMPS): s_memtime shares of the search loop, written to the result record's
 // stamps[] (never to an output the search computes from).
@@ -284,7 +284,12 @@ struct bl_astar_state {
     bool pending;
     bl_pose_xyt_t start;
     bl_frame frame;
+    // cost table cache key
+    bool lut_valid; bl_search_params_t lut_params; int lut_n; const void* lut_owner;
+    int32_t* h_path_head;              // pinned: first ASTAR_PATH_HEAD path cells, copied back with the result
 };
+
+#define ASTAR_PATH_HEAD 4096
 
 struct astar_args {
     const uint16_t* l1; int W, H;
@@ -295,6 +300,9 @@ struct astar_args {
     astar_result* result;
     int sx, sy, gx, gy;
     long long max_pops;
+    const bl_pose_xyt_t* start_dev;    // when non-null the start cell is derived on the device from this pose
+    bl_pose_xyt_t start_host;
+    bl_frame frame;
 };
 
 // The LDS part of the heap is addressed through an address_space(3) pointer: a two-way select between an LDS and a
@@ -409,6 +417,11 @@ __global__ __launch_bounds__(64) void k_astar(astar_args a)
     const int lane = threadIdx.x;
     astar_result res; res.status = ASTAR_ST_NOPATH; res.path_len = 0; res.pops = 0; res.pushes = 0;
     for (int q = 0; q < 6; ++q) res.stamps[q] = 0;
+    res.start = a.start_host;
+    if (a.start_dev) {                                   // global_position_to_grid_cell of the device-resident pose
+        res.start = *a.start_dev;
+        bl_global_to_cell((double)res.start.x, (double)res.start.y, a.frame, &a.sx, &a.sy);
+    }
     const bool cost_in_lds = a.cost_n <= AH_COST_LDS;
     lds_int_t* s_cost = (lds_int_t*)s_heap + 2 * (AH_LDS + 1);
     if (cost_in_lds) for (int i = lane; i < a.cost_n; i += 64) s_cost[i] = a.cost_lut[i];
@@ -557,6 +570,7 @@ void bl_astar_free(bl_ctx* ctx)
     if (s->d_result) (void)hipFree(s->d_result);
     if (s->h_result) (void)hipHostFree(s->h_result);
     if (s->h_cost) (void)hipHostFree(s->h_cost);
+    if (s->h_path_head) (void)hipHostFree(s->h_path_head);
     delete s;
     ctx->astar = nullptr;
 }
@@ -575,6 +589,7 @@ static int astar_prepare(bl_ctx* ctx, const bl_dist* d)
         memset((void*)ctx->astar, 0, sizeof(bl_astar_state));
         BL_HIP(hipMalloc((void**)&ctx->astar->d_result, sizeof(astar_result)));
         BL_HIP(hipHostMalloc((void**)&ctx->astar->h_result, sizeof(astar_result), hipHostMallocDefault));
+        BL_HIP(hipHostMalloc((void**)&ctx->astar->h_path_head, ASTAR_PATH_HEAD * 4, hipHostMallocDefault));
     }
     bl_astar_state* s = ctx->astar;
     int64_t want = ctx->astar_capacity > 0 ? ctx->astar_capacity : (int64_t)1 << 24;     // 16M entries = 128 MB
@@ -607,14 +622,16 @@ static int astar_prepare(bl_ctx* ctx, const bl_dist* d)
         BL_HIP(hipMalloc((void**)&s->cost_lut, (size_t)ln * 4));
         BL_HIP(hipHostMalloc((void**)&s->h_cost, (size_t)ln * 4, hipHostMallocDefault));
         s->cost_lut_cap = ln;
+        s->lut_valid = false;
     }
     return BL_OK;
 }
 
-extern "C" int bl_astar_search_async(bl_ctx* ctx, const bl_dist* d, const bl_pose_xyt_t* start, const bl_pose_xyt_t* goal,
-                                     const bl_search_params_t* params)
+static int astar_launch(bl_ctx* ctx, const bl_dist* d, const bl_pose_xyt_t* start, const void* d_start,
+                        const bl_pose_xyt_t* goal, const bl_search_params_t* params)
 {
-    BL_CHECK_ARG(ctx != nullptr && d != nullptr && start != nullptr && goal != nullptr && params != nullptr);
+    BL_CHECK_ARG(ctx != nullptr && d != nullptr && goal != nullptr && params != nullptr);
+    BL_CHECK_ARG(start != nullptr || d_start != nullptr);
     BL_CHECK_ARG(d->valid && d->ctx == ctx);
     BL_CHECK_ARG(d->frame.width <= AH_MAX_DIM && d->frame.height <= AH_MAX_DIM);
     BL_HIP(hipSetDevice(ctx->device));
@@ -623,25 +640,31 @@ extern "C" int bl_astar_search_async(bl_ctx* ctx, const bl_dist* d, const bl_pos
     bl_astar_state* s = ctx->astar;
     if (s->pending) { bl_set_error("an A* search is already pending on this ctx"); return BL_ERR_STATE; }
     // per-distance cell table: validity (astar.cpp:141) and obstacle cost (astar.cpp:181-186) from the float value
-    // f[n] a cell at L1 distance n holds.  The host's pow() is the reference's pow().
-    BL_HIP(hipStreamSynchronize(ctx->stream));          // h_cost is reused by every search
+    // f[n] a cell at L1 distance n holds.  The host's pow() is the reference's pow().  Rebuilt only when the search
+    // parameters or the table length change.
     const int ln = d->frame.width + d->frame.height + 1;
-    const std::vector<float>& f = *d->lut_host;
-    for (int n = 0; n < ln; ++n) {
-        float dist = f[n];
-        int32_t c;
-        if (!(dist > params->minDistanceToObstacle * 1.000001)) c = ASTAR_INVALID_COST;
-        else {
-            c = 0;
-            if (dist > params->minDistanceToObstacle && dist < params->maxDistanceWithCost) {
-                double v = pow(params->maxDistanceWithCost - dist * 2000, params->distanceCostExponent);   // float product
-                c = (v == v && fabs(v) < 2.0e9) ? static_cast<int>(v) : 0;
-                if (c == ASTAR_INVALID_COST) c = ASTAR_INVALID_COST + 1;
+    const bool same = s->lut_valid && s->lut_n == ln && s->lut_owner == (const void*)d &&
+                      memcmp(&s->lut_params, params, sizeof(*params)) == 0;
+    if (!same) {
+        BL_HIP(hipStreamSynchronize(ctx->stream));      // h_cost may still be the source of an earlier copy
+        const std::vector<float>& f = *d->lut_host;
+        for (int n = 0; n < ln; ++n) {
+            float dist = f[n];
+            int32_t c;
+            if (!(dist > params->minDistanceToObstacle * 1.000001)) c = ASTAR_INVALID_COST;
+            else {
+                c = 0;
+                if (dist > params->minDistanceToObstacle && dist < params->maxDistanceWithCost) {
+                    double v = pow(params->maxDistanceWithCost - dist * 2000, params->distanceCostExponent);   // float product
+                    c = (v == v && fabs(v) < 2.0e9) ? static_cast<int>(v) : 0;
+                    if (c == ASTAR_INVALID_COST) c = ASTAR_INVALID_COST + 1;
+                }
             }
+            s->h_cost[n] = c;
         }
-        s->h_cost[n] = c;
+        BL_HIP(hipMemcpyAsync(s->cost_lut, s->h_cost, (size_t)ln * 4, hipMemcpyHostToDevice, ctx->stream));
+        s->lut_valid = true; s->lut_n = ln; s->lut_owner = (const void*)d; s->lut_params = *params;
     }
-    BL_HIP(hipMemcpyAsync(s->cost_lut, s->h_cost, (size_t)ln * 4, hipMemcpyHostToDevice, ctx->stream));
     astar_args a;
     a.l1 = d->l1; a.W = d->frame.width; a.H = d->frame.height;
     a.cost_lut = s->cost_lut; a.cost_n = ln;
@@ -649,8 +672,16 @@ extern "C" int bl_astar_search_async(bl_ctx* ctx, const bl_dist* d, const bl_pos
     a.closed = s->closed;
     a.path = s->path; a.path_cap = (long long)s->path_cap;
     a.result = s->d_result;
+    a.frame = d->frame;
     bl_global_to_cell((double)goal->x, (double)goal->y, d->frame, &a.gx, &a.gy);     // astar.cpp:23-33
-    bl_global_to_cell((double)start->x, (double)start->y, d->frame, &a.sx, &a.sy);
+    a.sx = 0; a.sy = 0;
+    a.start_dev = (const bl_pose_xyt_t*)d_start;
+    if (start) {
+        a.start_host = *start;
+        bl_global_to_cell((double)start->x, (double)start->y, d->frame, &a.sx, &a.sy);
+    } else {
+        memset(&a.start_host, 0, sizeof(a.start_host));
+    }
     a.max_pops = 1ll << 31;
     hipEvent_t e0, e1;
     rc = bl_timer_begin(ctx, BL_K_ASTAR, &e0, &e1);
@@ -661,10 +692,25 @@ extern "C" int bl_astar_search_async(bl_ctx* ctx, const bl_dist* d, const bl_pos
     rc = bl_timer_end(ctx, BL_K_ASTAR, e0, e1);
     if (rc) return rc;
     BL_HIP(hipMemcpyAsync(s->h_result, s->d_result, sizeof(astar_result), hipMemcpyDeviceToHost, ctx->stream));
+    size_t head = s->path_cap < ASTAR_PATH_HEAD ? s->path_cap : ASTAR_PATH_HEAD;
+    BL_HIP(hipMemcpyAsync(s->h_path_head, s->path, head * 4, hipMemcpyDeviceToHost, ctx->stream));
     s->pending = true;
-    s->start = *start;
     s->frame = d->frame;
     return BL_OK;
+}
+
+extern "C" int bl_astar_search_async(bl_ctx* ctx, const bl_dist* d, const bl_pose_xyt_t* start, const bl_pose_xyt_t* goal,
+                                     const bl_search_params_t* params)
+{
+    BL_CHECK_ARG(start != nullptr);
+    return astar_launch(ctx, d, start, nullptr, goal, params);
+}
+
+extern "C" int bl_astar_search_async_dev_start(bl_ctx* ctx, const bl_dist* d, const void* d_start, const bl_pose_xyt_t* goal,
+                                               const bl_search_params_t* params)
+{
+    BL_CHECK_ARG(d_start != nullptr);
+    return astar_launch(ctx, d, nullptr, d_start, goal, params);
 }
 
 extern "C" int bl_astar_search_result(bl_ctx* ctx, bl_pose_xyt_t* out_path, int cap, int* out_len, int64_t* stats)
@@ -682,6 +728,7 @@ extern "C" int bl_astar_search_result(bl_ctx* ctx, bl_pose_xyt_t* out_path, int 
             (double)r.stamps[2] / (double)(r.pops ? r.pops : 1), r.stamps[3],
             r.stamps[3] ? (double)r.stamps[0] / ((double)r.stamps[3] * 10.0) / 1.0 : 0.0, r.stamps[4]);
 #endif
+    s->start = r.start;
     out_path[0] = s->start;                                            // path.path.push_back(start) (astar.cpp:21)
     *out_len = 1;
     if (r.status == ASTAR_ST_CAPACITY) { bl_set_error("A* open list exceeded its capacity (%lld pops)", r.pops); return BL_ERR_CAPACITY; }
@@ -689,7 +736,8 @@ extern "C" int bl_astar_search_result(bl_ctx* ctx, bl_pose_xyt_t* out_path, int 
     if (r.status != ASTAR_ST_FOUND) return BL_OK;
     // makePath (astar.cpp:235-274): cells come goal-first; poses are emitted start-side first
     std::vector<int32_t> cells((size_t)r.path_len);
-    BL_HIP(hipMemcpy(cells.data(), s->path, (size_t)r.path_len * 4, hipMemcpyDeviceToHost));
+    if (r.path_len <= ASTAR_PATH_HEAD) memcpy(cells.data(), s->h_path_head, (size_t)r.path_len * 4);
+    else BL_HIP(hipMemcpy(cells.data(), s->path, (size_t)r.path_len * 4, hipMemcpyDeviceToHost));
     std::vector<bl_pose_xyt_t> rev((size_t)r.path_len);
     float prevX = 0, prevY = 0;
     for (int i = 0; i < r.path_len; ++i) {

@@ -363,6 +363,33 @@ def search_for_path(start, goal, distances, params, return_stats=False, cap=1 <<
     return path
 
 
+def search_for_path_begin(goal, distances, params, start=None, start_dev=None):
+    """Asynchronous form: enqueue the search (start pose from the host, or read on the device from start_dev, e.g.
+    ParticleFilter.poseDevicePtr()); fetch it with search_for_path_end."""
+    ctx = distances.ctx
+    if start_dev is not None:
+        check(ctx.lib.bl_astar_search_async_dev_start(ctx.h, distances.h, start_dev, C.byref(goal), C.byref(params)))
+    else:
+        check(ctx.lib.bl_astar_search_async(ctx.h, distances.h, C.byref(start), C.byref(goal), C.byref(params)))
+
+
+_path_bufs = {}
+
+
+def search_for_path_end(distances, cap=4097, return_stats=False):
+    ctx = distances.ctx
+    buf = _path_bufs.get(cap)
+    if buf is None:
+        buf = _path_bufs[cap] = (Pose * cap)()
+    n = C.c_int()
+    stats = (C.c_int64 * 2)()
+    check(ctx.lib.bl_astar_search_result(ctx.h, buf, cap, C.byref(n), stats))
+    if n.value > cap:
+        raise _capi.BotlabHipError(f"path of {n.value} poses does not fit the {cap}-pose buffer")
+    path = [Pose(p.utime, p.x, p.y, p.theta) for p in buf[:n.value]]
+    return (path, (stats[0], stats[1])) if return_stats else path
+
+
 class MotionPlannerParams:
     def __init__(self, robotRadius=0.2):                                 # motion_planner.hpp:27-35
         self.robotRadius = float(robotRadius)

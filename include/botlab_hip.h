@@ -166,6 +166,10 @@ int bl_astar_set_open_capacity(bl_ctx* ctx, int64_t nodes);
 /* Asynchronous form for step pipelines: enqueue the search, fetch the result later. */
 int bl_astar_search_async(bl_ctx* ctx, const bl_dist* distances, const bl_pose_xyt_t* start, const bl_pose_xyt_t* goal,
                           const bl_search_params_t* params);
+/* Same, the start pose read from device memory (e.g. bl_pf_pose_device_ptr: the estimate of this very step) so a
+ * step pipeline needs no host round trip between localisation and replanning; out_path[0] of the result is that pose. */
+int bl_astar_search_async_dev_start(bl_ctx* ctx, const bl_dist* distances, const void* d_start /* bl_pose_xyt_t* */,
+                                    const bl_pose_xyt_t* goal, const bl_search_params_t* params);
 int bl_astar_search_result(bl_ctx* ctx, bl_pose_xyt_t* out_path, int cap, int* out_len, int64_t* stats);
 
 #ifdef __cplusplus

@@ -313,3 +313,41 @@ def test_astar_on_slam_map_with_default_radius(oracle, maps, gpu_ctx):
         assert got.tobytes() == exp.tobytes()
         n_found += len(path) > 1
     assert n_found >= 3
+
+
+def test_step_pipeline_with_device_pose_equals_host_pose_path(oracle, maps, gpu_ctx):
+    """The single-sync step pipeline (pose estimate stays on the device and feeds the map update and the A* start) gives
+    the same map, pose and path as the call-by-call host-pose form."""
+    m = maps["obstacle_slam_10mx10m_5cm"]
+    truth = np.where(m["cells"] > 0, 127, -127).astype(np.int8)
+    poses = synth.square_trajectory((-0.75, 0.2, 0.0), 8, step_len=0.02, turn=0.05, side=0.8)
+    scans = [synth.raycast_scan(truth, m["origin"], 0.05, poses[k - 1], poses[k], 1_000_000 + k * 100_000) for k in range(1, 9)]
+    goal = bl.make_pose(-0.35, 0.2, 0.0)
+    out = []
+    for dev in (False, True):
+        g = _grid_from_map(m, gpu_ctx)
+        pf = bl.ParticleFilter(2000, ctx=gpu_ctx)
+        pf.initializeFilterAtPose(bl.make_pose(-0.75, 0.2, 0.0, utime=int(scans[0].times[0])), seed=5)
+        pf.setNoiseSeed(9)
+        mapper = bl.Mapping(5.0, 4, 1, ctx=gpu_ctx)
+        planner = bl.MotionPlanner(ctx=gpu_ctx)
+        rec = []
+        for k, sc in enumerate(scans):
+            odo = bl.make_pose(*poses[k + 1], utime=sc.utime)
+            if dev:
+                pf.updateFilter(odo, sc, g, rand_value=1000 + k, want_pose=False)
+                mapper.updateMapDevicePose(sc, pf.poseDevicePtr(), sc.utime, g)
+                planner.setMap(g)
+                bl.search_for_path_begin(goal, planner.distances_, planner.searchParams_, start_dev=pf.poseDevicePtr())
+                path = bl.search_for_path_end(planner.distances_)
+                pose = path[0]
+            else:
+                pose = pf.updateFilter(odo, sc, g, rand_value=1000 + k)
+                mapper.updateMap(sc, pose, g)
+                planner.setMap(g)
+                path = bl.search_for_path(pose, goal, planner.distances_, planner.searchParams_)
+            rec.append(((pose.utime, pose.x, pose.y, pose.theta), [(p.x, p.y, p.theta) for p in path]))
+        out.append((rec, g.cells().copy()))
+    assert out[0][0] == out[1][0]
+    assert np.array_equal(out[0][1], out[1][1])
+    assert max(len(r[1]) for r in out[0][0]) > 3
