@@ -189,14 +189,18 @@ int bl_scan_upload(bl_ctx* ctx, bl_scan_dev* sd, const bl_lidar_t* scan, int64_t
     double* hr = (double*)h;
     float* hrange = (float*)(h + cap * 8);
     float* htheta = (float*)(h + cap * 12);
-    memcpy(hrange, scan->ranges, (size_t)R * 4);
-    memcpy(htheta, scan->thetas, (size_t)R * 4);
-    if (begin_utime != end_utime) {
-        double den = (double)(end_utime - begin_utime);
-        for (int n = 0; n < R; ++n) hr[n] = (double)(scan->times[n] - begin_utime) / den;
-    } else {
-        for (int n = 0; n < R; ++n) hr[n] = 0.0;
+    // MovingLaserScan keeps a ray only if its range exceeds 0.15f (moving_laser_scan.cpp:24); the kept rays are packed
+    // in scan order, so no kernel branches on validity.
+    const double den = (begin_utime != end_utime) ? (double)(end_utime - begin_utime) : 1.0;
+    int kept = 0;
+    for (int n = 0; n < R; ++n) {
+        if (!(scan->ranges[n] > 0.15f)) continue;
+        hrange[kept] = scan->ranges[n];
+        htheta[kept] = scan->thetas[n];
+        hr[kept] = (begin_utime != end_utime) ? (double)(scan->times[n] - begin_utime) / den : 0.0;
+        ++kept;
     }
+    *num_rays = kept;
     (void)per;
     // host slot and device block share one layout, so the whole block goes over in a single copy (8 KB at 512 rays)
     BL_HIP(hipMemcpyAsync(sd->ratio, h, sd->staging_bytes, hipMemcpyHostToDevice, ctx->stream));

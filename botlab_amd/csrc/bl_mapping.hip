@@ -84,7 +84,7 @@ __global__ __launch_bounds__(MAP_THREADS) void k_map_update(map_args a)
         int4 ray = make_int4(0, 0, 0, 0);
         int valid = 0;
         float range = a.ranges[r];
-        if (range > 0.15f && range <= a.max_laser) {
+        if (range <= a.max_laser) {                             // rays with range <= 0.15f were dropped on the host
             bl_pose3 rp = a.interp ? bl_interpolate_pose(pb, pe, a.ratio[r]) : pe;
             float theta = bl_wrap_to_pi(rp.theta - a.thetas[r]);
             float sn, cs, sx, sy;

@@ -19,10 +19,13 @@
 // 2*M_PI and narrowed back to float on every iteration.
 BL_HD float bl_wrap_to_pi(float angle)
 {
-    if ((double)angle < -BL_PI) {
-        for (; (double)angle < -BL_PI; angle = (float)((double)angle + 2.0 * BL_PI)) {}
-    } else if ((double)angle > BL_PI) {
-        for (; (double)angle > BL_PI; angle = (float)((double)angle - 2.0 * BL_PI)) {}
+    // (double)angle < -M_PI  <=>  angle <= -(float)M_PI, because (float)M_PI = 3.14159274... is the float just ABOVE
+    // M_PI and the next float toward zero (3.14159250...) is below it; likewise (double)angle > M_PI <=> angle >= (float)M_PI.
+    const float PI_F = 0x1.921fb6p+1f;
+    if (angle <= -PI_F) {
+        do { angle = (float)((double)angle + 2.0 * BL_PI); } while (angle <= -PI_F);
+    } else if (angle >= PI_F) {
+        do { angle = (float)((double)angle - 2.0 * BL_PI); } while (angle >= PI_F);
     }
     return angle;
 }
@@ -74,30 +77,27 @@ BL_HD void bl_sincosf(float y, float* sn, float* cs)
                  C4 = 0x1.99343027bf8c3p-16, S1 = -0x1.555545995a603p-3, S2 = 0x1.1107605230bc4p-7,
                  S3 = -0x1.994eb3774cf24p-13;
     const double HPI_INV = 0x1.45F306DC9C883p+23, HPI = 0x1.921FB54442D18p0;
-    union { float f; uint32_t u; } bits;
-    bits.f = y;
-    uint32_t top = (bits.u >> 20) & 0x7ff;
-    double x = (double)y;
-    if (top < 0x3f4) {                       // |y| < pi/4
-        if (top < 0x398) { *sn = y; *cs = 1.0f; return; }    // |y| < 2^-12
-        double x2 = x * x;
-        *sn = (float)bl_sin_poly(x, x2, S1, S2, S3);
-        *cs = (float)bl_cos_poly(x2, C0, C1, C2, C3, C4);
-        return;
-    }
-    // reduce_fast: n = round(x * 2/pi), x -= n * pi/2 (one fused step)
-    double r = x * HPI_INV;
-    int n = ((int32_t)r + 0x800000) >> 24;
-    double xr = __builtin_fma(-(double)n, HPI, x);
-    double x2 = xr * xr;
-    double tsign = (n & 2) ? -1.0 : 1.0;                    // second table = cosine coefficients negated
-    double xsig = ((n + 1) & 2) ? -1.0 : 1.0;                // sign[n & 3] = {1, -1, -1, 1}
-    double xs = xr * xsig;
-    // table 1 negates c0..c4 only (s1..s3 are identical in both tables)
-    double pc = bl_cos_poly(x2, tsign * C0, tsign * C1, tsign * C2, tsign * C3, tsign * C4);
-    double ps = bl_sin_poly(xs, x2, S1, S2, S3);
-    if (n & 1) { *sn = (float)pc; *cs = (float)ps; }
-    else       { *sn = (float)ps; *cs = (float)pc; }
+    // One code path for every |y| < 120.  glibc branches three ways (|y| < 2^-12: returns y / 1.0f; |y| < pi/4: the
+    // polynomials on x itself; else reduce_fast).  The reduction with n == 0 leaves x unchanged (fma(-0, hpi, x) == x),
+    // so the middle case is the general case; for |y| < 2^-12 the polynomials round to y and 1.0f as well (the
+    // exhaustive check in tests/tools/sincosf_exhaustive.cpp covers every float).  Signs: sign[n & 3] multiplies the
+    // sine argument and table 1 negates the cosine coefficients; both polynomials are odd/linear in those signs under
+    // round-to-nearest (fma(-a, b, -c) == -fma(a, b, c)), so the signs are applied to the float results instead.
+    const double x = (double)y;
+    const double r = x * HPI_INV;
+    const int n = ((int32_t)r + 0x800000) >> 24;              // round(x * 2/pi)
+    const double xr = __builtin_fma(-(double)n, HPI, x);      // x - n * pi/2, one fused step
+    const double x2 = xr * xr;
+    float ps = (float)bl_sin_poly(xr, x2, S1, S2, S3);
+    float pc = (float)bl_cos_poly(x2, C0, C1, C2, C3, C4);
+    union { float f; uint32_t u; } us, uc, uy;
+    uy.f = y;
+    const bool tiny = ((uy.u >> 20) & 0x7ff) < 0x398;         // |y| < 2^-12: glibc returns y and 1.0f (keeps sin(-0) = -0)
+    us.f = tiny ? y : ps; uc.f = tiny ? 1.0f : pc;
+    us.u ^= ((uint32_t)(n + 1) & 2u) << 30;                   // sign[n & 3] = {1, -1, -1, 1}
+    uc.u ^= ((uint32_t)n & 2u) << 30;                         // table 1 (n & 2): cosine coefficients negated
+    if (n & 1) { *sn = uc.f; *cs = us.f; }
+    else       { *sn = us.f; *cs = uc.f; }
 }
 
 // ---------------------------------------------------------------- pose interpolation

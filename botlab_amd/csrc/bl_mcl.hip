@@ -86,38 +86,49 @@ struct map_window { int x0, y0, w, h, stride; };
 
 typedef __attribute__((address_space(3))) signed char lds_i8_t;
 
-template <bool USE_LDS>
+// MAP_MODE: 0 = gathers from HBM/L2 only; 1 = the whole grid is staged in LDS; 2 = LDS window + HBM/L2 fallback.
+// Branch-free in modes 0 and 1: an off-grid cell reads a dummy slot and is masked to 0 (OccupancyGrid::logOdds,
+// occupancy_grid.cpp:63-71).
+template <int MAP_MODE>
 __device__ __forceinline__ int grid_odds(const int8_t* __restrict__ cells, const lds_i8_t* s_map, const map_window& win,
                                          const bl_frame& f, int x, int y)
 {
-    // OccupancyGrid::logOdds (occupancy_grid.cpp:63-71): 0 outside the grid
-    if (x < 0 || x >= f.width || y < 0 || y >= f.height) return 0;
-    if (USE_LDS) {
-        const unsigned int wx = (unsigned int)(x - win.x0), wy = (unsigned int)(y - win.y0);
-        if (wx < (unsigned int)win.w && wy < (unsigned int)win.h) return s_map[wy * win.stride + wx];
+    const bool in = (unsigned int)x < (unsigned int)f.width && (unsigned int)y < (unsigned int)f.height;
+    if (MAP_MODE == 1) {
+        const int v = s_map[in ? y * win.stride + x : 0];
+        return in ? v : 0;
     }
-    return cells[(size_t)y * f.width + x];
+    if (MAP_MODE == 0) {
+        const int v = cells[in ? (size_t)y * f.width + x : (size_t)0];
+        return in ? v : 0;
+    }
+    const unsigned int wx = (unsigned int)(x - win.x0), wy = (unsigned int)(y - win.y0);
+    const bool inw = in && wx < (unsigned int)win.w && wy < (unsigned int)win.h;
+    int v = s_map[inw ? wy * win.stride + wx : 0];
+    if (in && !inw) v = cells[(size_t)y * f.width + x];       // cloud wider than the window: rare
+    return in ? v : 0;
 }
 
-// SensorModel::scoreRay (sensor_model.cpp:28-59) in half-units: returns 2*odds, o1 or o2 (score = that / 2)
-template <bool USE_LDS>
+// SensorModel::scoreRay (sensor_model.cpp:28-59) in half-units: returns 2*odds, o1 or o2 (score = that / 2).
+// The two neighbour cells are gathered unconditionally: within a 64-lane wave some ray always needs them, so the
+// early-out of the reference would only add divergence.
+template <int MAP_MODE>
 __device__ __forceinline__ int score_ray_half_units(const int8_t* __restrict__ cells, const lds_i8_t* s_map,
                                                      const map_window& win, const bl_frame& f, float sx, float sy,
-                                                     float range, float cs, float sn)
+                                                     int isx, int isy, float range, float cs, float sn)
 {
-    int ex = (int)((range * cs * f.cpm) + sx);
-    int ey = (int)((range * sn * f.cpm) + sy);
-    int odds = grid_odds<USE_LDS>(cells, s_map, win, f, ex, ey);
-    if (odds > 0) return 2 * odds;
-    int xx = (int)((2 * range * cs * f.cpm) + sx);
-    int xy = (int)((2 * range * sn * f.cpm) + sy);
-    int ax, ay;
-    bl_bresenham_first_step(ex, ey, (int)sx, (int)sy, &ax, &ay);
-    int o1 = grid_odds<USE_LDS>(cells, s_map, win, f, ax, ay);
-    if (o1 > 0) return o1;
-    bl_bresenham_first_step(ex, ey, xx, xy, &ax, &ay);
-    int o2 = grid_odds<USE_LDS>(cells, s_map, win, f, ax, ay);
-    return o2 > 0 ? o2 : 0;
+    const float tx = range * cs * f.cpm, ty = range * sn * f.cpm;
+    const int ex = (int)(tx + sx);
+    const int ey = (int)(ty + sy);
+    const int xx = (int)((2 * range * cs * f.cpm) + sx);
+    const int xy = (int)((2 * range * sn * f.cpm) + sy);
+    int ax, ay, bx, by;
+    bl_bresenham_first_step(ex, ey, isx, isy, &ax, &ay);
+    bl_bresenham_first_step(ex, ey, xx, xy, &bx, &by);
+    const int odds = grid_odds<MAP_MODE>(cells, s_map, win, f, ex, ey);
+    const int o1 = grid_odds<MAP_MODE>(cells, s_map, win, f, ax, ay);
+    const int o2 = grid_odds<MAP_MODE>(cells, s_map, win, f, bx, by);
+    return odds > 0 ? 2 * odds : (o1 > 0 ? o1 : (o2 > 0 ? o2 : 0));
 }
 
 struct mcl_args {
@@ -164,7 +175,7 @@ __device__ __forceinline__ void philox_normals3(uint32_t m, uint32_t step, uint3
 
 // One thread per output particle m of the shard: low-variance resample (gather), ActionModel::applyAction,
 // SensorModel::likelihood, weight units, and the block's partial sums for normalisation + pose estimate.
-template <int INTERP, int BLOCK, bool USE_LDS>
+template <int INTERP, int BLOCK, int MAP_MODE>
 __global__ __launch_bounds__(BLOCK) void k_mcl_main(mcl_args a)
 {
     extern __shared__ __align__(16) signed char s_dyn[];
@@ -173,7 +184,7 @@ __global__ __launch_bounds__(BLOCK) void k_mcl_main(mcl_args a)
     const lds_i8_t* s_map = (const lds_i8_t*)s_dyn;
     map_window win = {0, 0, 0, 0, 0};
 
-    if (USE_LDS) {
+    if (MAP_MODE != 0) {
         // ---- stage the map window: centred on the cell the previous pose estimate moves to under the odometry action
         if (threadIdx.x == 0) {
             map_window w;
@@ -259,21 +270,23 @@ __global__ __launch_bounds__(BLOCK) void k_mcl_main(mcl_args a)
             const bl_pose3 pe = {px, py, pth};
             float sx0, sy0;
             bl_global_to_grid(px, py, a.frame, &sx0, &sy0);
-            for (int n = 0; n < a.R; ++n) {
+            const int isx0 = (int)sx0, isy0 = (int)sy0;
+            for (int n = 0; n < a.R; ++n) {                 // the host uploads only rays with range > 0.15f (moving_laser_scan.cpp:24)
                 const float range = a.ranges[n];
-                if (!(range > 0.15f)) continue;             // moving_laser_scan.cpp:24
                 float theta, sx, sy;
+                int isx, isy;
                 if (INTERP) {
                     bl_pose3 rp = bl_interpolate_pose(pb, pe, a.ratio[n]);
                     theta = bl_wrap_to_pi(rp.theta - a.thetas[n]);
                     bl_global_to_grid(rp.x, rp.y, a.frame, &sx, &sy);
+                    isx = (int)sx; isy = (int)sy;
                 } else {
                     theta = bl_wrap_to_pi(pth - a.thetas[n]);
-                    sx = sx0; sy = sy0;
+                    sx = sx0; sy = sy0; isx = isx0; isy = isy0;
                 }
                 float sn, cs;
                 bl_sincosf(theta, &sn, &cs);
-                acc += score_ray_half_units<USE_LDS>(a.cells, s_map, win, a.frame, sx, sy, range, cs, sn);
+                acc += score_ray_half_units<MAP_MODE>(a.cells, s_map, win, a.frame, sx, sy, isx, isy, range, cs, sn);
             }
         }
         // ---- computeNormalizedPosterior (particle_filter.cpp:116-141): w = max(likelihood, 0.001) in units of 0.0005
@@ -460,8 +473,8 @@ static int pf_alloc(bl_pf* pf)
     static bool attr_set = false;
     if (!attr_set) {
         const int big = MCL_WIN_BIG * MCL_WIN_BIG;
-        BL_HIP(hipFuncSetAttribute((const void*)k_mcl_main<0, 1024, true>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
-        BL_HIP(hipFuncSetAttribute((const void*)k_mcl_main<1, 1024, true>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+        BL_HIP(hipFuncSetAttribute((const void*)k_mcl_main<0, 1024, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+        BL_HIP(hipFuncSetAttribute((const void*)k_mcl_main<1, 1024, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
         attr_set = true;
     }
     pf->scan_blocks = (int)((N + SCAN_TILE - 1) / SCAN_TILE);
@@ -688,14 +701,14 @@ static int pf_launch_main(bl_pf* pf, const bl_grid* map, int R, int rand_value, 
     int rc = bl_timer_begin(ctx, BL_K_MCL_MAIN, &e0, &e1);
     if (rc) return rc;
     if (lds_bytes == 0) {
-        if (a.interp) hipLaunchKernelGGL((k_mcl_main<1, MCL_THREADS, false>), dim3(blocks), dim3(MCL_THREADS), 0, ctx->stream, a);
-        else hipLaunchKernelGGL((k_mcl_main<0, MCL_THREADS, false>), dim3(blocks), dim3(MCL_THREADS), 0, ctx->stream, a);
+        if (a.interp) hipLaunchKernelGGL((k_mcl_main<1, MCL_THREADS, 0>), dim3(blocks), dim3(MCL_THREADS), 0, ctx->stream, a);
+        else hipLaunchKernelGGL((k_mcl_main<0, MCL_THREADS, 0>), dim3(blocks), dim3(MCL_THREADS), 0, ctx->stream, a);
     } else if (block == MCL_THREADS) {
-        if (a.interp) hipLaunchKernelGGL((k_mcl_main<1, MCL_THREADS, true>), dim3(blocks), dim3(MCL_THREADS), lds_bytes, ctx->stream, a);
-        else hipLaunchKernelGGL((k_mcl_main<0, MCL_THREADS, true>), dim3(blocks), dim3(MCL_THREADS), lds_bytes, ctx->stream, a);
+        if (a.interp) hipLaunchKernelGGL((k_mcl_main<1, MCL_THREADS, 1>), dim3(blocks), dim3(MCL_THREADS), lds_bytes, ctx->stream, a);
+        else hipLaunchKernelGGL((k_mcl_main<0, MCL_THREADS, 1>), dim3(blocks), dim3(MCL_THREADS), lds_bytes, ctx->stream, a);
     } else {
-        if (a.interp) hipLaunchKernelGGL((k_mcl_main<1, 1024, true>), dim3(blocks), dim3(1024), lds_bytes, ctx->stream, a);
-        else hipLaunchKernelGGL((k_mcl_main<0, 1024, true>), dim3(blocks), dim3(1024), lds_bytes, ctx->stream, a);
+        if (a.interp) hipLaunchKernelGGL((k_mcl_main<1, 1024, 2>), dim3(blocks), dim3(1024), lds_bytes, ctx->stream, a);
+        else hipLaunchKernelGGL((k_mcl_main<0, 1024, 2>), dim3(blocks), dim3(1024), lds_bytes, ctx->stream, a);
     }
     BL_HIP(hipGetLastError());
     rc = bl_timer_end(ctx, BL_K_MCL_MAIN, e0, e1);
