@@ -9,7 +9,7 @@ One step = OccupancyGridSLAM::runSLAMIteration (src/slam/slam.cpp:191-207) + the
 (src/planning/exploration.cpp:300-317):
     ParticleFilter::updateFilter(odometry, scan, map)      pre-update map
     Mapping::updateMap(scan, pose, map)
-    ObstacleDistanceGrid::setDistances(map)  +  search_for_path(pose, goal)
+    ObstacleDistanceGrid::setDistances(map)  +  search_for_path(pose, goal)     on a second stream, on a snapshot
 Multi-GPU (--gpus N under torch.distributed.run): the particles are block-sharded over the ranks (RCCL all-gather of
 the 16-byte exchange record + all-reduce of the weight/pose sums); the map update and the replan are replicated.
 Total work is fixed as N grows ("scaling": "strong").
@@ -121,6 +121,7 @@ def main():
     ap.add_argument("--goal-l1", type=int, default=40, help="without --goal on a non-default grid: max L1 distance (cells) "
                     "of the replan goal from the start")
     ap.add_argument("--cpu-steps", type=int, default=10, help="steps of the CPU baseline sample (0 = skip)")
+    ap.add_argument("--depth", type=int, default=1, help="steps enqueued ahead of fetching a result (0 = synchronous steps)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -137,10 +138,10 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: botlab_amd has no CPU path")
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    if world > 1 or os.environ.get("BOTLAB_FORCE_COLLECTIVES"):
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
-    total = args.steps + args.warmup + 2
+    total = args.steps + args.warmup + 34
     m, truth, poses, odo, scans, rands = build_inputs(args, total)
     cpm = np.float32(1.0 / np.float64(np.float32(0.05)))
 
@@ -151,6 +152,7 @@ def main():
     mapper = bl.Mapping(5.0, 4, 1, ctx=ctx)                 # slam.cpp:24, slam_main.cpp:22-23
     planner = bl.MotionPlanner(ctx=ctx)                       # robotRadius 0.2 (motion_planner.hpp:31)
     planner.setMap(grid)
+    aplanner = bl.AsyncPlanner(ctx=ctx)                       # the replanner on its own stream (the reference's planner process)
     goal = None
     if not args.no_astar:
         if args.goal is not None:
@@ -169,36 +171,68 @@ def main():
     pops_total = [0]
 
     pose_dev = engine.pf.poseDevicePtr()
+    in_flight = []                  # steps enqueued whose result has not been fetched yet
 
-    def step(k):
-        # Everything of one step is enqueued on the ctx stream with the pose estimate staying on the device (it feeds
-        # the map update and the A* start there); ONE synchronisation at the end hands the pose and the path back.
+    def enqueue(k):
+        # Everything of one step is enqueued on the ctx stream; the pose estimate stays on the device and feeds the map
+        # update and the A* start there.
         o = odo[k + 1]
         sc = scans[k]
         spf.updateFilter(bl.make_pose(o[0], o[1], o[2], utime=sc.utime), sc, grid, int(rands[k]), want_pose=False)
         mapper.updateMapDevicePose(sc, pose_dev, sc.utime, grid)
         if goal_pose is not None:
-            planner.setMap(grid)
-            bl.search_for_path_begin(goal_pose, planner.distances_, planner.searchParams_, start_dev=pose_dev)
-            path, st = bl.search_for_path_end(planner.distances_, return_stats=True)
+            aplanner.submit(grid, pose_dev, goal_pose)          # snapshot map + pose; setDistances + search_for_path overlap the next step
+        in_flight.append(k)
+
+    def fetch():
+        # hands back the pose and the path of the oldest enqueued step (waits for that step only)
+        in_flight.pop(0)
+        if goal_pose is not None:
+            path, st = aplanner.fetch(return_stats=True)
             pops_total[0] += st[0]
-            return path[0]                       # the start pose of the path is this step's pose estimate
-        return engine.pf.poseEstimate()
+            return path[0]                       # the start pose of the path is that step's pose estimate
+        return None
+
+    host_t = [0.0, 0.0]
+
+    def step(k):
+        # software pipeline of depth args.depth: step k is enqueued before the result of step k - depth is fetched, so the
+        # GPU never waits for the host between steps; every result is still delivered, in order
+        t0 = time.perf_counter()
+        enqueue(k)
+        t1 = time.perf_counter()
+        last = None
+        while len(in_flight) > args.depth:
+            last = fetch()
+        host_t[0] += t1 - t0
+        host_t[1] += time.perf_counter() - t1
+        return last
+
+    def drain():
+        last = None
+        while in_flight:
+            last = fetch()
+        if goal_pose is None:
+            last = engine.pf.poseEstimate()
+        return last
 
     k = 0
     for _ in range(args.warmup):
         step(k)
         k += 1
+    drain()
     ctx.timing_reset()
-    ctx.timing_enable(True)
+    ctx.timing_enable(True, kernels=[_capi.BL_K_MCL_MAIN])      # HIP events around the dominant kernel only (roofline leg)
     pops_total[0] = 0
+    host_t[0] = host_t[1] = 0.0
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        pose = step(k)
+        step(k)
         k += 1
+    pose = drain()                   # all K results delivered inside the timed region
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -209,11 +243,32 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    main_ms_total, main_n = ctx.timing_get(_capi.BL_K_MCL_MAIN)
+    host_ms = (1e3 * host_t[0] / args.steps, 1e3 * host_t[1] / args.steps)
+    pops_timed = pops_total[0]
+    final_pose, final_k = pose, k
+    # per-stage kernel times: a short untimed pass with every timer on (events between launches cost a few us each, so
+    # they stay out of the timed region)
+    ctx.timing_reset()
+    ctx.timing_enable(True)
+    aplanner.timing(1)
+    for _ in range(min(args.steps, 30, total - k - 1)):
+        step(k)
+        k += 1
+    drain()
+    torch.cuda.synchronize()
+    ctx.timing_enable(False)
     stage_ms = {}
-    for name, kid in (("mcl_main", _capi.BL_K_MCL_MAIN), ("mcl_scan", _capi.BL_K_MCL_SCAN), ("map", _capi.BL_K_MAP),
-                      ("dist", _capi.BL_K_DIST), ("astar", _capi.BL_K_ASTAR)):
+    for name, kid in (("mcl_main", _capi.BL_K_MCL_MAIN), ("mcl_scan", _capi.BL_K_MCL_SCAN), ("map", _capi.BL_K_MAP)):
         ms, n = ctx.timing_get(kid)
         stage_ms[name] = (ms / n if n else 0.0, n)
+    d_ms, a_ms, pn = aplanner.timing(-1)
+    aplanner.timing(0)
+    stage_ms["dist"] = (d_ms / pn if pn else 0.0, pn)
+    stage_ms["astar"] = (a_ms / pn if pn else 0.0, pn)
+    stage_ms["mcl_main"] = (main_ms_total / main_n if main_n else 0.0, main_n)      # the timed-region figure
+    pose, k = final_pose, final_k
+    pops_total[0] = pops_timed
 
     if rank == 0:
         N, R = args.particles, scans[0].num_ranges
@@ -239,7 +294,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"full SLAM step on {W}x{H} @5cm grid (shipped obstacle_slam map), {N} particles, "
                                    f"{R} rays, A* replan {'off' if goal is None else 'on'}",
-                       "particles": N, "grid": [W, H], "rays": R,
+                       "particles": N, "grid": [W, H], "rays": R, "pipeline_depth": args.depth,
                        "parallelism": f"particle-shard x{world}" if world > 1 else "single GPU"},
             "roofline": {"bound": "hbm", "kernel": "k_mcl_main", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
@@ -247,13 +302,14 @@ def main():
                          "particle_rays_per_s": (n_local * R) / (main_ms * 1e-3) if main_ms > 0 else 0.0},
             "stage_ms": {k_: round(v[0], 5) for k_, v in stage_ms.items()},
             "astar_pops_per_step": pops_total[0] / args.steps,
+            "host_ms_per_step": {"enqueue": round(host_ms[0], 4), "fetch_wait": round(host_ms[1], 4)},
             "final_pose": [pose.x, pose.y, pose.theta],
             "truth_pose": [float(v) for v in poses[k]],
         }
         if args.cpu_steps > 0 and world == 1:
             out["cpu_baseline"] = cpu_baseline(args, m, odo, scans, rands, goal, args.cpu_steps)
         print(json.dumps(out))
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
 

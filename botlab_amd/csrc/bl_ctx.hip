@@ -74,13 +74,14 @@ extern "C" int bl_ctx_timing_enable(bl_ctx* ctx, int on)
 {
     BL_CHECK_ARG(ctx != nullptr);
     ctx->timing = on != 0;
+    ctx->timing_mask = (on == 1) ? 0xffffffffu : (unsigned int)on;      // 1: every kernel; otherwise bit i = BL_K_* id i
     return BL_OK;
 }
 
 int bl_timer_begin(bl_ctx* ctx, int id, hipEvent_t* a, hipEvent_t* b)
 {
     *a = nullptr; *b = nullptr;
-    if (!ctx->timing) return BL_OK;
+    if (!ctx->timing || !((ctx->timing_mask >> id) & 1u)) return BL_OK;
     bl_timer& t = ctx->timers[id];
     if (!t.pool.empty()) {
         *a = t.pool.back().first; *b = t.pool.back().second;

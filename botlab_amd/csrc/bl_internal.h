@@ -53,6 +53,7 @@ struct bl_ctx {
     hipStream_t stream = nullptr;
     bool own_stream = false;
     bool timing = false;
+    unsigned int timing_mask = 0xffffffffu;
     bl_timer timers[BL_K_COUNT];
     bl_astar_state* astar = nullptr;
     int64_t astar_capacity = 0;

@@ -13,6 +13,8 @@
 // it is latency-bound, not bandwidth-bound, and a single workgroup keeps every phase boundary a __syncthreads().
 // The LDS window is the bounding box of all ray cells clipped to the grid; if it exceeds the LDS budget it is
 // processed in horizontal strips (each strip re-walks the rays), so any resolution / laser range is handled.
+#include <stdio.h>
+
 #include "bl_internal.h"
 
 #define MAP_THREADS 1024
@@ -48,7 +50,14 @@ struct map_args {
     float max_laser;
     int hit, miss;
     int4* rays;
+    long long* stamps;              // diagnostic build only (-DBL_MAP_STAMPS)
 };
+
+#ifdef BL_MAP_STAMPS
+#define MSTAMP(i) do { if (threadIdx.x == 0) a.stamps[i] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define MSTAMP(i) do { } while (0)
+#endif
 
 __device__ __forceinline__ bool cell_in_grid(const bl_frame& f, int x, int y)
 {
@@ -62,6 +71,7 @@ __global__ __launch_bounds__(MAP_THREADS) void k_map_update(map_args a)
     __shared__ float s_pose[6];                                // prev x,y,theta ; cur x,y,theta
 
     const int tid = threadIdx.x;
+    MSTAMP(0);
     if (tid == 0) {
         bl_pose_xyt_t cur = a.cur_dev ? *a.cur_dev : a.cur_host;
         bl_pose_xyt_t prev = a.apply ? *a.prev : cur;          // mapping.cpp:19-21: first call uses pose for both
@@ -79,6 +89,7 @@ __global__ __launch_bounds__(MAP_THREADS) void k_map_update(map_args a)
     const bl_pose3 pb = {s_pose[0], s_pose[1], s_pose[2]};
     const bl_pose3 pe = {s_pose[3], s_pose[4], s_pose[5]};
 
+    MSTAMP(1);
     // ---- phase A: ray geometry (moving_laser_scan.cpp:22-37, mapping.cpp:45-49)
     for (int r = tid; r < a.R; r += MAP_THREADS) {
         int4 ray = make_int4(0, 0, 0, 0);
@@ -106,21 +117,28 @@ __global__ __launch_bounds__(MAP_THREADS) void k_map_update(map_args a)
     }
     __syncthreads();
 
+    MSTAMP(2);
     // ---- phase B: endpoint pass (mapping.cpp:42-57).  One leader per distinct end cell applies min(127, v + hit*H).
+    // The end cells are packed into the (still unused) LDS window so the R x R comparison reads LDS broadcasts.
     for (int r = tid; r < a.R; r += MAP_THREADS) {
         int4 me = a.rays[r];
-        if (me.x == 0x7fffffff || !cell_in_grid(a.frame, me.z, me.w)) continue;
+        const bool ok = me.x != 0x7fffffff && cell_in_grid(a.frame, me.z, me.w);
+        s_cnt[r] = ok ? ((unsigned int)me.w << 16) | (unsigned int)me.z : 0xffffffffu;
+    }
+    __syncthreads();
+    for (int r = tid; r < a.R; r += MAP_THREADS) {
+        const unsigned int me = s_cnt[r];
+        if (me == 0xffffffffu) continue;
         int H = 0;
         bool leader = true;
+#pragma unroll 8
         for (int q = 0; q < a.R; ++q) {
-            int4 o = a.rays[q];
-            if (o.x != 0x7fffffff && o.z == me.z && o.w == me.w) {
-                H++;
-                if (q < r) leader = false;
-            }
+            const bool same = s_cnt[q] == me;
+            H += same ? 1 : 0;
+            leader = leader && !(same && q < r);
         }
         if (leader) {
-            size_t idx = (size_t)me.w * a.frame.width + me.z;
+            size_t idx = (size_t)(me >> 16) * a.frame.width + (me & 0xffffu);
             int v = a.cells[idx];
             v = min(127, v + a.hit * H);
             a.cells[idx] = (int8_t)v;
@@ -128,6 +146,7 @@ __global__ __launch_bounds__(MAP_THREADS) void k_map_update(map_args a)
     }
     __syncthreads();
 
+    MSTAMP(3);
     // ---- phase C: free-space pass (mapping.cpp:59-71, 101-127) through an LDS window of miss counters
     int bx0 = max(s_box[0], 0), by0 = max(s_box[1], 0);
     int bx1 = min(s_box[2], a.frame.width - 1), by1 = min(s_box[3], a.frame.height - 1);
@@ -145,6 +164,7 @@ __global__ __launch_bounds__(MAP_THREADS) void k_map_update(map_args a)
         const int ncell = (sy1 - sy0 + 1) * ww;
         for (int i = tid; i < (ncell + 1) / 2; i += MAP_THREADS) s_cnt[i] = 0;
         __syncthreads();
+        MSTAMP(4);
         for (int r = tid; r < a.R; r += MAP_THREADS) {
             int4 ray = a.rays[r];
             if (ray.x == 0x7fffffff) continue;
@@ -165,18 +185,34 @@ __global__ __launch_bounds__(MAP_THREADS) void k_map_update(map_args a)
             }
         }
         __syncthreads();
-        for (int ci = tid; ci < ncell; ci += MAP_THREADS) {
-            unsigned int pair = s_cnt[ci >> 1];
-            int M = (ci & 1) ? (int)(pair >> 16) : (int)(pair & 0xffffu);
-            if (M > 0) {
-                int cy = sy0 + ci / ww, cx = bx0 + ci % ww;
-                size_t idx = (size_t)cy * a.frame.width + cx;
-                int v = a.cells[idx];
-                v = max(-128, v - a.miss * M);
-                a.cells[idx] = (int8_t)v;
+        MSTAMP(5);
+        // apply: thread (tx, ty) owns column bx0 + tx (+256, ...) and every 4th row; 8 rows per batch so the byte loads
+        // of a batch are in flight together (a serial load -> store chain per cell cost ~1 us per cell per thread)
+        const int tx = tid & 255, ty = tid >> 8;
+        const int nrows = sy1 - sy0 + 1;
+        for (int cx = tx; cx < ww; cx += 256) {
+            for (int r0 = ty; r0 < nrows; r0 += 32) {
+                int M[8], v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int ry = r0 + 4 * u;
+                    M[u] = 0;
+                    if (ry < nrows) {
+                        const int ci = ry * ww + cx;
+                        const unsigned int pair = s_cnt[ci >> 1];
+                        M[u] = (ci & 1) ? (int)(pair >> 16) : (int)(pair & 0xffffu);
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    if (M[u] > 0) v[u] = a.cells[(size_t)(sy0 + r0 + 4 * u) * a.frame.width + bx0 + cx];
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    if (M[u] > 0) a.cells[(size_t)(sy0 + r0 + 4 * u) * a.frame.width + bx0 + cx] = (int8_t)max(-128, v[u] - a.miss * M[u]);
             }
         }
         __syncthreads();
+        MSTAMP(6);
     }
 }
 
@@ -221,6 +257,7 @@ static int mapping_update_impl(bl_mapping* m, const bl_lidar_t* scan, const bl_p
 {
     BL_CHECK_ARG(m != nullptr && scan != nullptr && map != nullptr);
     BL_CHECK_ARG(scan->num_ranges >= 0 && scan->num_ranges <= MAP_MAX_RAYS);
+    BL_CHECK_ARG(map->frame.width <= 65535 && map->frame.height <= 65535);       // end cells are packed 16+16 bits in LDS
     bl_ctx* ctx = m->ctx;
     BL_HIP(hipSetDevice(ctx->device));
     int64_t begin = m->initialized ? m->prev_utime : pose_utime;
@@ -247,6 +284,12 @@ static int mapping_update_impl(bl_mapping* m, const bl_lidar_t* scan, const bl_p
     a.max_laser = m->max_laser;
     a.hit = m->hit; a.miss = m->miss;
     a.rays = m->d_rays;
+    a.stamps = nullptr;
+#ifdef BL_MAP_STAMPS
+    static long long* d_st = nullptr;
+    if (!d_st) BL_HIP(hipMalloc((void**)&d_st, 64));
+    a.stamps = d_st;
+#endif
     hipEvent_t e0, e1;
     rc = bl_timer_begin(ctx, BL_K_MAP, &e0, &e1);
     if (rc) return rc;
@@ -254,6 +297,14 @@ static int mapping_update_impl(bl_mapping* m, const bl_lidar_t* scan, const bl_p
     BL_HIP(hipGetLastError());
     rc = bl_timer_end(ctx, BL_K_MAP, e0, e1);
     if (rc) return rc;
+#ifdef BL_MAP_STAMPS
+    {
+        long long h[8];
+        BL_HIP(hipMemcpy(h, a.stamps, 56, hipMemcpyDeviceToHost));
+        fprintf(stderr, "[map stamps] pose %lld rays %lld hits %lld zero %lld walk %lld apply %lld cycles\n", h[1] - h[0], h[2] - h[1],
+                h[3] - h[2], h[4] - h[3], h[5] - h[4], h[6] - h[5]);
+    }
+#endif
     m->initialized = true;
     m->prev_utime = pose_utime;
     return BL_OK;

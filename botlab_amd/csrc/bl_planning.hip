@@ -273,20 +273,25 @@ struct astar_result { int status; int path_len; long long pops; long long pushes
 #define AH_MAX_DIM 32767
 #define AH_MAX_CAP (1 << 25)
 
+#define ASTAR_SLOTS 4
+
 struct bl_astar_state {
     int2* heap; int64_t heap_cap;
     int32_t* closed; size_t closed_cap;    // -1: not closed; 0..3: move that produced the FIRST closed entry; 4: start
     int32_t* path; size_t path_cap;
     int32_t* cost_lut; int cost_lut_cap;
     astar_result* d_result;
-    astar_result* h_result;            // pinned
+    astar_result* h_result[ASTAR_SLOTS];   // pinned result ring: searches may be enqueued ahead of fetching results
+    hipEvent_t done[ASTAR_SLOTS];
+    bl_frame slot_frame[ASTAR_SLOTS];
+    int64_t launched, fetched;
     int32_t* h_cost;                   // pinned staging for the cost table
     bool pending;
     bl_pose_xyt_t start;
     bl_frame frame;
     // cost table cache key
     bool lut_valid; bl_search_params_t lut_params; int lut_n; const void* lut_owner;
-    int32_t* h_path_head;              // pinned: first ASTAR_PATH_HEAD path cells, copied back with the result
+    int32_t* h_path_head[ASTAR_SLOTS];  // pinned: first ASTAR_PATH_HEAD path cells, copied back with the result
 };
 
 #define ASTAR_PATH_HEAD 4096
@@ -415,6 +420,7 @@ __global__ __launch_bounds__(64) void k_astar(astar_args a)
 {
     int2* g_heap = a.heap;
     const int lane = threadIdx.x;
+    __builtin_amdgcn_s_setprio(3);          // a lone latency-bound wave: win issue arbitration against co-resident kernels
     astar_result res; res.status = ASTAR_ST_NOPATH; res.path_len = 0; res.pops = 0; res.pushes = 0;
     for (int q = 0; q < 6; ++q) res.stamps[q] = 0;
     res.start = a.start_host;
@@ -568,9 +574,12 @@ void bl_astar_free(bl_ctx* ctx)
     if (s->path) (void)hipFree(s->path);
     if (s->cost_lut) (void)hipFree(s->cost_lut);
     if (s->d_result) (void)hipFree(s->d_result);
-    if (s->h_result) (void)hipHostFree(s->h_result);
+    for (int i = 0; i < ASTAR_SLOTS; ++i) {
+        if (s->h_result[i]) (void)hipHostFree(s->h_result[i]);
+        if (s->h_path_head[i]) (void)hipHostFree(s->h_path_head[i]);
+        if (s->done[i]) (void)hipEventDestroy(s->done[i]);
+    }
     if (s->h_cost) (void)hipHostFree(s->h_cost);
-    if (s->h_path_head) (void)hipHostFree(s->h_path_head);
     delete s;
     ctx->astar = nullptr;
 }
@@ -588,8 +597,11 @@ static int astar_prepare(bl_ctx* ctx, const bl_dist* d)
         ctx->astar = new bl_astar_state();
         memset((void*)ctx->astar, 0, sizeof(bl_astar_state));
         BL_HIP(hipMalloc((void**)&ctx->astar->d_result, sizeof(astar_result)));
-        BL_HIP(hipHostMalloc((void**)&ctx->astar->h_result, sizeof(astar_result), hipHostMallocDefault));
-        BL_HIP(hipHostMalloc((void**)&ctx->astar->h_path_head, ASTAR_PATH_HEAD * 4, hipHostMallocDefault));
+        for (int i = 0; i < ASTAR_SLOTS; ++i) {
+            BL_HIP(hipHostMalloc((void**)&ctx->astar->h_result[i], sizeof(astar_result), hipHostMallocDefault));
+            BL_HIP(hipHostMalloc((void**)&ctx->astar->h_path_head[i], ASTAR_PATH_HEAD * 4, hipHostMallocDefault));
+            BL_HIP(hipEventCreateWithFlags(&ctx->astar->done[i], hipEventDisableTiming));
+        }
     }
     bl_astar_state* s = ctx->astar;
     int64_t want = ctx->astar_capacity > 0 ? ctx->astar_capacity : (int64_t)1 << 24;     // 16M entries = 128 MB
@@ -638,7 +650,10 @@ static int astar_launch(bl_ctx* ctx, const bl_dist* d, const bl_pose_xyt_t* star
     int rc = astar_prepare(ctx, d);
     if (rc) return rc;
     bl_astar_state* s = ctx->astar;
-    if (s->pending) { bl_set_error("an A* search is already pending on this ctx"); return BL_ERR_STATE; }
+    if (s->launched - s->fetched >= ASTAR_SLOTS) {
+        bl_set_error("%d A* searches are already pending on this ctx; fetch a result first", ASTAR_SLOTS);
+        return BL_ERR_STATE;
+    }
     // per-distance cell table: validity (astar.cpp:141) and obstacle cost (astar.cpp:181-186) from the float value
     // f[n] a cell at L1 distance n holds.  The host's pow() is the reference's pow().  Rebuilt only when the search
     // parameters or the table length change.
@@ -691,11 +706,14 @@ static int astar_launch(bl_ctx* ctx, const bl_dist* d, const bl_pose_xyt_t* star
     BL_HIP(hipGetLastError());
     rc = bl_timer_end(ctx, BL_K_ASTAR, e0, e1);
     if (rc) return rc;
-    BL_HIP(hipMemcpyAsync(s->h_result, s->d_result, sizeof(astar_result), hipMemcpyDeviceToHost, ctx->stream));
+    const int slot = (int)(s->launched % ASTAR_SLOTS);
+    BL_HIP(hipMemcpyAsync(s->h_result[slot], s->d_result, sizeof(astar_result), hipMemcpyDeviceToHost, ctx->stream));
     size_t head = s->path_cap < ASTAR_PATH_HEAD ? s->path_cap : ASTAR_PATH_HEAD;
-    BL_HIP(hipMemcpyAsync(s->h_path_head, s->path, head * 4, hipMemcpyDeviceToHost, ctx->stream));
+    BL_HIP(hipMemcpyAsync(s->h_path_head[slot], s->path, head * 4, hipMemcpyDeviceToHost, ctx->stream));
+    BL_HIP(hipEventRecord(s->done[slot], ctx->stream));
+    s->slot_frame[slot] = d->frame;
+    s->launched += 1;
     s->pending = true;
-    s->frame = d->frame;
     return BL_OK;
 }
 
@@ -717,10 +735,13 @@ extern "C" int bl_astar_search_result(bl_ctx* ctx, bl_pose_xyt_t* out_path, int 
 {
     BL_CHECK_ARG(ctx != nullptr && out_path != nullptr && cap >= 1 && out_len != nullptr);
     bl_astar_state* s = ctx->astar;
-    if (!s || !s->pending) { bl_set_error("no A* search pending"); return BL_ERR_STATE; }
-    BL_HIP(hipStreamSynchronize(ctx->stream));
-    s->pending = false;
-    astar_result r = *s->h_result;
+    if (!s || s->launched == s->fetched) { bl_set_error("no A* search pending"); return BL_ERR_STATE; }
+    const int slot = (int)(s->fetched % ASTAR_SLOTS);           // results come back in launch order
+    BL_HIP(hipEventSynchronize(s->done[slot]));                 // waits for THIS search only; later work keeps running
+    s->fetched += 1;
+    s->pending = s->launched != s->fetched;
+    s->frame = s->slot_frame[slot];
+    astar_result r = *s->h_result[slot];
     if (stats) { stats[0] = r.pops; stats[1] = r.pushes; }
 #ifdef BL_ASTAR_STAMPS
     fprintf(stderr, "[astar stamps] pops %lld cycles/pop all %.0f adjust %.0f expand+push %.0f | realtime ticks(100MHz) %lld -> clock %.2f GHz, final len %lld\n",
@@ -736,8 +757,13 @@ extern "C" int bl_astar_search_result(bl_ctx* ctx, bl_pose_xyt_t* out_path, int 
     if (r.status != ASTAR_ST_FOUND) return BL_OK;
     // makePath (astar.cpp:235-274): cells come goal-first; poses are emitted start-side first
     std::vector<int32_t> cells((size_t)r.path_len);
-    if (r.path_len <= ASTAR_PATH_HEAD) memcpy(cells.data(), s->h_path_head, (size_t)r.path_len * 4);
-    else BL_HIP(hipMemcpy(cells.data(), s->path, (size_t)r.path_len * 4, hipMemcpyDeviceToHost));
+    if (r.path_len <= ASTAR_PATH_HEAD) memcpy(cells.data(), s->h_path_head[slot], (size_t)r.path_len * 4);
+    else {
+        // longer than the head copied with the result: only valid if no later search has overwritten the device path
+        if (s->pending) { bl_set_error("A* path of %d cells exceeds the pipelined result head (%d)", r.path_len, ASTAR_PATH_HEAD); return BL_ERR_CAPACITY; }
+        BL_HIP(hipStreamSynchronize(ctx->stream));
+        BL_HIP(hipMemcpy(cells.data(), s->path, (size_t)r.path_len * 4, hipMemcpyDeviceToHost));
+    }
     std::vector<bl_pose_xyt_t> rev((size_t)r.path_len);
     float prevX = 0, prevY = 0;
     for (int i = 0; i < r.path_len; ++i) {
@@ -763,4 +789,116 @@ extern "C" int bl_astar_search(bl_ctx* ctx, const bl_dist* d, const bl_pose_xyt_
     int rc = bl_astar_search_async(ctx, d, start, goal, params);
     if (rc) return rc;
     return bl_astar_search_result(ctx, out_path, cap, out_len, stats);
+}
+
+// =============================================================================================== asynchronous replanner
+// The reference runs its planner in a separate process that consumes the maps and poses the SLAM process publishes
+// (src/planning/exploration.cpp:300-317 on every SLAM_MAP message).  bl_planner is that arrangement on one device: a
+// second HIP stream runs setDistances + search_for_path against a SNAPSHOT of the map and of the pose taken on the
+// SLAM stream, so the one-wavefront A* overlaps the next scan's particle-filter kernels instead of serialising with
+// them.  Two snapshot slots; every hand-off between the two streams is an event.
+#define PLANNER_SLOTS 2
+
+struct bl_planner {
+    bl_ctx* main;                       // the SLAM ctx (not owned)
+    bl_ctx* side;                       // own ctx: second stream, distance grid + A* state
+    bl_dist* dist;
+    bl_grid* snap[PLANNER_SLOTS];
+    bl_pose_xyt_t* pose[PLANNER_SLOTS];
+    hipEvent_t snap_ready[PLANNER_SLOTS];   // recorded on main after the snapshot copies
+    hipEvent_t slot_free[PLANNER_SLOTS];    // recorded on side after the search that read the slot
+    bool slot_used[PLANNER_SLOTS];
+    int64_t submitted;
+};
+
+extern "C" int bl_planner_create(bl_ctx* ctx, bl_planner** out)
+{
+    BL_CHECK_ARG(ctx != nullptr && out != nullptr);
+    BL_HIP(hipSetDevice(ctx->device));
+    bl_planner* p = new bl_planner();
+    memset((void*)p, 0, sizeof(*p));
+    p->main = ctx;
+    int rc = bl_ctx_create(ctx->device, nullptr, &p->side);
+    if (rc) { delete p; return rc; }
+    rc = bl_dist_create(p->side, &p->dist);
+    if (rc) { bl_ctx_destroy(p->side); delete p; return rc; }
+    for (int i = 0; i < PLANNER_SLOTS; ++i) {
+        BL_HIP(hipMalloc((void**)&p->pose[i], sizeof(bl_pose_xyt_t)));
+        BL_HIP(hipEventCreateWithFlags(&p->snap_ready[i], hipEventDisableTiming));
+        BL_HIP(hipEventCreateWithFlags(&p->slot_free[i], hipEventDisableTiming));
+    }
+    *out = p;
+    return BL_OK;
+}
+
+extern "C" void bl_planner_destroy(bl_planner* p)
+{
+    if (!p) return;
+    (void)hipStreamSynchronize(p->main->stream);
+    (void)hipStreamSynchronize(p->side->stream);
+    for (int i = 0; i < PLANNER_SLOTS; ++i) {
+        if (p->snap[i]) bl_grid_destroy(p->snap[i]);
+        if (p->pose[i]) (void)hipFree(p->pose[i]);
+        if (p->snap_ready[i]) (void)hipEventDestroy(p->snap_ready[i]);
+        if (p->slot_free[i]) (void)hipEventDestroy(p->slot_free[i]);
+    }
+    bl_dist_destroy(p->dist);
+    bl_ctx_destroy(p->side);
+    delete p;
+}
+
+extern "C" int bl_planner_submit(bl_planner* p, const bl_grid* map, const void* d_start_pose, const bl_pose_xyt_t* goal,
+                                 const bl_search_params_t* params)
+{
+    BL_CHECK_ARG(p != nullptr && map != nullptr && d_start_pose != nullptr && goal != nullptr && params != nullptr);
+    BL_CHECK_ARG(map->ctx == p->main);
+    BL_HIP(hipSetDevice(p->main->device));
+    const int slot = (int)(p->submitted % PLANNER_SLOTS);
+    bl_grid*& snap = p->snap[slot];
+    if (snap && (snap->frame.width != map->frame.width || snap->frame.height != map->frame.height)) {
+        BL_HIP(hipStreamSynchronize(p->side->stream));
+        bl_grid_destroy(snap);
+        snap = nullptr;
+        p->slot_used[slot] = false;
+    }
+    if (!snap) {
+        int rc = bl_grid_create(p->side, map->frame.width, map->frame.height, map->frame.mpc, map->frame.cpm, map->frame.ox,
+                                map->frame.oy, &snap);
+        if (rc) return rc;
+        BL_HIP(hipStreamSynchronize(p->side->stream));          // its zero-fill ran on the side stream
+    }
+    snap->frame = map->frame;
+    // SLAM stream: wait until the planner has finished with this slot, then snapshot map and pose
+    if (p->slot_used[slot]) BL_HIP(hipStreamWaitEvent(p->main->stream, p->slot_free[slot], 0));
+    BL_HIP(hipMemcpyAsync(snap->cells, map->cells, (size_t)map->frame.width * map->frame.height, hipMemcpyDeviceToDevice,
+                          p->main->stream));
+    BL_HIP(hipMemcpyAsync(p->pose[slot], d_start_pose, sizeof(bl_pose_xyt_t), hipMemcpyDeviceToDevice, p->main->stream));
+    BL_HIP(hipEventRecord(p->snap_ready[slot], p->main->stream));
+    // planner stream: distance grid + search on the snapshot
+    BL_HIP(hipStreamWaitEvent(p->side->stream, p->snap_ready[slot], 0));
+    int rc = bl_dist_set_distances(p->dist, snap);
+    if (rc) return rc;
+    rc = astar_launch(p->side, p->dist, nullptr, p->pose[slot], goal, params);
+    if (rc) return rc;
+    BL_HIP(hipEventRecord(p->slot_free[slot], p->side->stream));
+    p->slot_used[slot] = true;
+    p->submitted += 1;
+    return BL_OK;
+}
+
+extern "C" int bl_planner_fetch(bl_planner* p, bl_pose_xyt_t* out_path, int cap, int* out_len, int64_t* stats)
+{
+    BL_CHECK_ARG(p != nullptr);
+    return bl_astar_search_result(p->side, out_path, cap, out_len, stats);
+}
+
+extern "C" int bl_planner_timing(bl_planner* p, int on, double* dist_ms, double* astar_ms, int64_t* launches)
+{
+    BL_CHECK_ARG(p != nullptr);
+    if (on >= 0) { int rc = bl_ctx_timing_enable(p->side, on); if (rc) return rc; if (on) return bl_ctx_timing_reset(p->side); }
+    int64_t n = 0;
+    if (dist_ms) { int rc = bl_ctx_timing_get(p->side, BL_K_DIST, dist_ms, &n); if (rc) return rc; }
+    if (astar_ms) { int rc = bl_ctx_timing_get(p->side, BL_K_ASTAR, astar_ms, &n); if (rc) return rc; }
+    if (launches) *launches = n;
+    return BL_OK;
 }

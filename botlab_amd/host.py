@@ -64,8 +64,12 @@ class Context:
     def sync(self):
         check(self.lib.bl_ctx_sync(self.h))
 
-    def timing_enable(self, on=True):
-        check(self.lib.bl_ctx_timing_enable(self.h, 1 if on else 0))
+    def timing_enable(self, on=True, kernels=None):
+        """kernels: iterable of BL_K_* ids to time (default: all)."""
+        flag = 0 if not on else (1 if kernels is None else sum(1 << k for k in kernels))
+        if flag == 1 and kernels is not None:      # only kernel 0 requested: bit 0 alone is spelled 1 | (1 << 31)
+            flag = 1 | (1 << 30)
+        check(self.lib.bl_ctx_timing_enable(self.h, flag))
 
     def timing_reset(self):
         check(self.lib.bl_ctx_timing_reset(self.h))
@@ -388,6 +392,40 @@ def search_for_path_end(distances, cap=4097, return_stats=False):
         raise _capi.BotlabHipError(f"path of {n.value} poses does not fit the {cap}-pose buffer")
     path = [Pose(p.utime, p.x, p.y, p.theta) for p in buf[:n.value]]
     return (path, (stats[0], stats[1])) if return_stats else path
+
+
+class AsyncPlanner:
+    """bl_planner: MotionPlanner.setMap + planPath run on a second stream against a snapshot of the map and of the
+    device-resident pose (the reference's planner process, src/planning/exploration.cpp:300-317)."""
+
+    def __init__(self, ctx=None, params=None):
+        self.ctx = ctx or default_context()
+        self.params_ = params or MotionPlannerParams()
+        self.searchParams_ = SearchParams(self.params_.robotRadius, 10.0 * self.params_.robotRadius, 1.0)   # motion_planner.cpp:105-110
+        h = C.c_void_p()
+        check(self.ctx.lib.bl_planner_create(self.ctx.h, C.byref(h)))
+        self.h = h
+        self._buf = (Pose * 4097)()
+
+    def submit(self, grid, start_dev, goal):
+        check(self.ctx.lib.bl_planner_submit(self.h, grid.h, start_dev, C.byref(goal), C.byref(self.searchParams_)))
+
+    def fetch(self, return_stats=False):
+        n = C.c_int()
+        stats = (C.c_int64 * 2)()
+        check(self.ctx.lib.bl_planner_fetch(self.h, self._buf, 4097, C.byref(n), stats))
+        path = [Pose(p.utime, p.x, p.y, p.theta) for p in self._buf[:min(n.value, 4097)]]
+        return (path, (stats[0], stats[1])) if return_stats else path
+
+    def timing(self, on=-1):
+        d, a, n = C.c_double(), C.c_double(), C.c_int64()
+        check(self.ctx.lib.bl_planner_timing(self.h, on, C.byref(d), C.byref(a), C.byref(n)))
+        return d.value, a.value, n.value
+
+    def close(self):
+        if self.h:
+            self.ctx.lib.bl_planner_destroy(self.h)
+            self.h = None
 
 
 class MotionPlannerParams:

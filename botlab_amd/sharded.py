@@ -14,6 +14,7 @@ The engine behind a shard is pluggable so the orchestration is testable without 
 HipShardEngine (libbotlab_hip.so); tests/ supply a CPU stand-in to exercise the collectives under gloo.
 """
 import ctypes as C
+import os
 
 import numpy as np
 import torch
@@ -42,11 +43,16 @@ class HipShardEngine:
         self.lo, self.hi, self.S = shard_bounds(num_particles, rank, world)
         self.device = torch.device("cuda", device)
         torch.cuda.set_device(self.device)
-        stream = torch.cuda.current_stream(self.device).cuda_stream
-        self.ctx = host.Context(device, stream=stream)
+        # ONE explicit stream carries both the library's kernels and the collectives (issued under
+        # torch.cuda.stream(self.stream)), so they are stream-ordered without events.  torch's default stream has the
+        # raw handle 0, which the C ABI reads as "create your own stream" -- never hand that one over.
+        self.stream = torch.cuda.Stream(self.device)
+        assert self.stream.cuda_stream != 0
+        self.ctx = host.Context(device, stream=self.stream.cuda_stream)
         padded = self.S * world
         self.rec = [torch.zeros(padded, 4, dtype=torch.float32, device=self.device) for _ in range(2)]
         self.sums = torch.zeros(8, dtype=torch.float64, device=self.device)
+        torch.cuda.synchronize(self.device)           # the zero-fills ran on the default stream
         self.pf = host.ParticleFilter(num_particles, ctx=self.ctx, shard=(self.lo, self.hi))
         check(self.ctx.lib.bl_pf_set_exchange_buffers(self.pf.h, self.rec[0].data_ptr(), self.rec[1].data_ptr(),
                                                       self.sums.data_ptr()))
@@ -85,6 +91,8 @@ class ShardedParticleFilter:
         self.group = group
         self.world = engine.world
         self.rank = engine.rank
+        # exercise the collectives even with one rank (plumbing check on a 1-GPU box)
+        self.force_collectives = bool(os.environ.get("BOTLAB_FORCE_COLLECTIVES")) and dist.is_initialized()
 
     def initializeFilterAtPose(self, pose, seed=1):
         self.engine.init_at_pose(pose, seed)          # counter-based: every rank generates the identical full record
@@ -94,12 +102,18 @@ class ShardedParticleFilter:
 
     def updateFilter(self, odometry, scan, grid, rand_value, noise=None, want_pose=True):
         moved = self.engine.begin(odometry, scan, grid, rand_value, noise)
-        if moved and self.world > 1:
+        if moved and (self.world > 1 or self.force_collectives):
             rec = self.engine.exchange_record()
             S = self.engine.S
             mine = rec[self.rank * S:(self.rank + 1) * S]
-            dist.all_gather_into_tensor(rec, mine, group=self.group)
-            dist.all_reduce(self.engine.exchange_sums(), op=dist.ReduceOp.SUM, group=self.group)
+            stream = getattr(self.engine, "stream", None)
+            if stream is not None:
+                with torch.cuda.stream(stream):      # collectives ordered on the engine's stream
+                    dist.all_gather_into_tensor(rec, mine, group=self.group)
+                    dist.all_reduce(self.engine.exchange_sums(), op=dist.ReduceOp.SUM, group=self.group)
+            else:
+                dist.all_gather_into_tensor(rec, mine, group=self.group)
+                dist.all_reduce(self.engine.exchange_sums(), op=dist.ReduceOp.SUM, group=self.group)
         return self.engine.end(want_pose)
 
     def particles(self):

@@ -67,7 +67,7 @@ int bl_ctx_create(int device, void* stream, bl_ctx** out);
 void bl_ctx_destroy(bl_ctx* ctx);
 int bl_ctx_sync(bl_ctx* ctx);
 /* Per-kernel HIP-event timing on the ctx stream (bench.py's roofline leg).  kernel ids: BL_K_* below. */
-int bl_ctx_timing_enable(bl_ctx* ctx, int on);
+int bl_ctx_timing_enable(bl_ctx* ctx, int on);   /* 0: off; 1: every kernel; else a bit mask, bit i = kernel id i */
 int bl_ctx_timing_get(bl_ctx* ctx, int kernel_id, double* total_ms, int64_t* launches);
 int bl_ctx_timing_reset(bl_ctx* ctx);
 #define BL_K_MCL_MAIN 0      /* resample-gather + action + sensor model, one thread per particle */
@@ -163,7 +163,8 @@ void* bl_dist_device_ptr(bl_dist* d);                                     /* flo
 int bl_astar_search(bl_ctx* ctx, const bl_dist* distances, const bl_pose_xyt_t* start, const bl_pose_xyt_t* goal,
                     const bl_search_params_t* params, bl_pose_xyt_t* out_path, int cap, int* out_len, int64_t* stats);
 int bl_astar_set_open_capacity(bl_ctx* ctx, int64_t nodes);
-/* Asynchronous form for step pipelines: enqueue the search, fetch the result later. */
+/* Asynchronous form for step pipelines: enqueue the search, fetch the result later.  Up to 4 searches may be in flight;
+ * results are fetched in launch order and fetching waits for that search only (work enqueued after it keeps running). */
 int bl_astar_search_async(bl_ctx* ctx, const bl_dist* distances, const bl_pose_xyt_t* start, const bl_pose_xyt_t* goal,
                           const bl_search_params_t* params);
 /* Same, the start pose read from device memory (e.g. bl_pf_pose_device_ptr: the estimate of this very step) so a
@@ -171,6 +172,21 @@ int bl_astar_search_async(bl_ctx* ctx, const bl_dist* distances, const bl_pose_x
 int bl_astar_search_async_dev_start(bl_ctx* ctx, const bl_dist* distances, const void* d_start /* bl_pose_xyt_t* */,
                                     const bl_pose_xyt_t* goal, const bl_search_params_t* params);
 int bl_astar_search_result(bl_ctx* ctx, bl_pose_xyt_t* out_path, int cap, int* out_len, int64_t* stats);
+
+/* ------------------------------------------------------------------ asynchronous replanner
+ * The reference's planner is a separate process fed by the maps/poses the SLAM process publishes
+ * (src/planning/exploration.cpp:300-317).  bl_planner is the same arrangement on one device: submit() snapshots the
+ * map and the (device-resident) pose on the SLAM ctx's stream and runs setDistances + search_for_path on a second
+ * stream, overlapping the next scan's particle filter; fetch() returns results in submission order (up to 2 in flight;
+ * submit blocks the SLAM stream, not the host, when both snapshot slots are still being read). */
+typedef struct bl_planner bl_planner;
+int bl_planner_create(bl_ctx* ctx, bl_planner** out);
+void bl_planner_destroy(bl_planner* p);
+int bl_planner_submit(bl_planner* p, const bl_grid* map, const void* d_start_pose /* bl_pose_xyt_t* on the device */,
+                      const bl_pose_xyt_t* goal, const bl_search_params_t* params);
+int bl_planner_fetch(bl_planner* p, bl_pose_xyt_t* out_path, int cap, int* out_len, int64_t* stats);
+/* on: -1 = just read; 0/1 = disable/enable(+reset) HIP-event timing of the planner stream's kernels (totals in ms) */
+int bl_planner_timing(bl_planner* p, int on, double* dist_ms, double* astar_ms, int64_t* launches);
 
 #ifdef __cplusplus
 }

@@ -324,8 +324,10 @@ def test_step_pipeline_with_device_pose_equals_host_pose_path(oracle, maps, gpu_
     scans = [synth.raycast_scan(truth, m["origin"], 0.05, poses[k - 1], poses[k], 1_000_000 + k * 100_000) for k in range(1, 9)]
     goal = bl.make_pose(-0.35, 0.2, 0.0)
     out = []
-    for dev in (False, True):
+    for dev in (False, True, "async"):
         g = _grid_from_map(m, gpu_ctx)
+        aplanner = bl.AsyncPlanner(ctx=gpu_ctx) if dev == "async" else None
+        lagged = []
         pf = bl.ParticleFilter(2000, ctx=gpu_ctx)
         pf.initializeFilterAtPose(bl.make_pose(-0.75, 0.2, 0.0, utime=int(scans[0].times[0])), seed=5)
         pf.setNoiseSeed(9)
@@ -334,7 +336,21 @@ def test_step_pipeline_with_device_pose_equals_host_pose_path(oracle, maps, gpu_
         rec = []
         for k, sc in enumerate(scans):
             odo = bl.make_pose(*poses[k + 1], utime=sc.utime)
-            if dev:
+            if dev == "async":
+                # replanner on its own stream against snapshots; results fetched one step late, in order
+                pf.updateFilter(odo, sc, g, rand_value=1000 + k, want_pose=False)
+                mapper.updateMapDevicePose(sc, pf.poseDevicePtr(), sc.utime, g)
+                aplanner.submit(g, pf.poseDevicePtr(), goal)
+                lagged.append(k)
+                if len(lagged) > 1:
+                    lagged.pop(0)
+                    path = aplanner.fetch()
+                    rec.append(((path[0].utime, path[0].x, path[0].y, path[0].theta), [(p.x, p.y, p.theta) for p in path]))
+                if k == len(scans) - 1:
+                    path = aplanner.fetch()
+                    rec.append(((path[0].utime, path[0].x, path[0].y, path[0].theta), [(p.x, p.y, p.theta) for p in path]))
+                continue
+            elif dev:
                 pf.updateFilter(odo, sc, g, rand_value=1000 + k, want_pose=False)
                 mapper.updateMapDevicePose(sc, pf.poseDevicePtr(), sc.utime, g)
                 planner.setMap(g)
@@ -348,6 +364,46 @@ def test_step_pipeline_with_device_pose_equals_host_pose_path(oracle, maps, gpu_
                 path = bl.search_for_path(pose, goal, planner.distances_, planner.searchParams_)
             rec.append(((pose.utime, pose.x, pose.y, pose.theta), [(p.x, p.y, p.theta) for p in path]))
         out.append((rec, g.cells().copy()))
-    assert out[0][0] == out[1][0]
-    assert np.array_equal(out[0][1], out[1][1])
+    assert out[0][0] == out[1][0] == out[2][0]
+    assert np.array_equal(out[0][1], out[1][1]) and np.array_equal(out[0][1], out[2][1])
     assert max(len(r[1]) for r in out[0][0]) > 3
+
+
+def test_shard_engine_single_rank_with_nccl_collectives_matches_plain_filter(maps, gpu_ctx):
+    """HipShardEngine + ShardedParticleFilter (the multi-GPU driver) with world_size 1 over the real nccl/RCCL backend:
+    same particles as the plain ParticleFilter, collectives issued on the engine's own stream."""
+    import os
+    import torch
+    import torch.distributed as dist
+    from botlab_amd import sharded
+    m = maps["obstacle_slam_10mx10m_5cm"]
+    truth = np.where(m["cells"] > 0, 127, -127).astype(np.int8)
+    poses = synth.square_trajectory((-0.75, 0.2, 0.0), 5, step_len=0.02, turn=0.05, side=0.8)
+    scans = [synth.raycast_scan(truth, m["origin"], 0.05, poses[k - 1], poses[k], 1_000_000 + k * 100_000) for k in range(1, 6)]
+    N = 4000
+    os.environ["BOTLAB_FORCE_COLLECTIVES"] = "1"
+    created = False
+    if not dist.is_initialized():
+        dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29533", rank=0, world_size=1,
+                                device_id=torch.device("cuda", 0))
+        created = True
+    try:
+        eng = sharded.HipShardEngine(N, 0, 1, 0)
+        spf = sharded.ShardedParticleFilter(eng)
+        assert spf.force_collectives
+        g1 = _grid_from_map(m, eng.ctx)
+        g2 = _grid_from_map(m, gpu_ctx)
+        pf = bl.ParticleFilter(N, ctx=gpu_ctx)
+        init = bl.make_pose(-0.75, 0.2, 0.0, utime=int(scans[0].times[0]))
+        spf.initializeFilterAtPose(init, seed=3)
+        pf.initializeFilterAtPose(init, seed=3)
+        for k, sc in enumerate(scans):
+            odo = bl.make_pose(*poses[k + 1], utime=sc.utime)
+            a = spf.updateFilter(odo, sc, g1, 500 + k)
+            b = pf.updateFilter(odo, sc, g2, rand_value=500 + k)
+            assert (a.x, a.y, a.theta, a.utime) == (b.x, b.y, b.theta, b.utime)
+        assert spf.particles().tobytes() == pf.particles().tobytes()
+    finally:
+        os.environ.pop("BOTLAB_FORCE_COLLECTIVES", None)
+        if created:
+            dist.destroy_process_group()
