@@ -278,6 +278,15 @@ def main():
         # + the grid once + 20 B per ray
         alg_bytes = 128.0 * n_local + W * H + 20.0 * R
         main_ms = stage_ms["mcl_main"][0]
+        # HBM bytes per launch from the rocprofv3 PMC passes committed under profiles/ (FETCH_SIZE / WRITE_SIZE, separate
+        # passes, gfx950 correction applied); only valid for the configuration they were collected on
+        traffic = None
+        try:
+            tj = json.load(open(os.path.join(ROOT, "profiles", "r01_mcl_main_traffic.json")))
+            if world == 1 and tj["config"] == {"particles": N, "grid": [W, H], "rays": R}:
+                traffic = tj["traffic_bytes_per_launch"]
+        except (OSError, KeyError, ValueError):
+            traffic = None
         achieved = alg_bytes / (main_ms * 1e-3) / 1e9 if main_ms > 0 else 0.0
         out = {
             "metric": "SLAM steps/sec (map+MCL+A*)",
@@ -297,7 +306,7 @@ def main():
                        "particles": N, "grid": [W, H], "rays": R, "pipeline_depth": args.depth,
                        "parallelism": f"particle-shard x{world}" if world > 1 else "single GPU"},
             "roofline": {"bound": "hbm", "kernel": "k_mcl_main", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": main_ms,
                          "particle_rays_per_s": (n_local * R) / (main_ms * 1e-3) if main_ms > 0 else 0.0},
             "stage_ms": {k_: round(v[0], 5) for k_, v in stage_ms.items()},

@@ -51,6 +51,7 @@ struct bl_pf {
     double* partials;         // [blocks][5]
     int partials_cap;
     bool use_lds;
+    bool debug;               // record resample index / likelihood per particle (parity tests)
     unsigned long long* block_sums;   // scan scratch
     int scan_blocks;
     int32_t* dbg_idx;
@@ -662,7 +663,7 @@ static int pf_launch_main(bl_pf* pf, const bl_grid* map, int R, int rand_value, 
     a.state = pf->state;
     a.parent = pf->parent;
     a.partials = pf->partials;
-    a.dbg_idx = pf->dbg_idx; a.dbg_like = pf->dbg_like;
+    a.dbg_idx = pf->debug ? pf->dbg_idx : nullptr; a.dbg_like = pf->debug ? pf->dbg_like : nullptr;
     a.cells = map ? map->cells : nullptr;
     if (map) a.frame = map->frame; else memset(&a.frame, 0, sizeof(a.frame));
     a.ranges = pf->scan.ranges; a.thetas = pf->scan.thetas; a.ratio = pf->scan.ratio;
@@ -803,9 +804,17 @@ extern "C" int bl_pf_pose_estimate(bl_pf* pf, bl_pose_xyt_t* out_pose)
     return BL_OK;
 }
 
+extern "C" int bl_pf_debug_enable(bl_pf* pf, int on)
+{
+    BL_CHECK_ARG(pf != nullptr);
+    pf->debug = on != 0;
+    return BL_OK;
+}
+
 extern "C" int bl_pf_debug_last(bl_pf* pf, int32_t* resample_idx, int32_t* likelihood_half_units)
 {
     BL_CHECK_ARG(pf != nullptr && pf->dbg_idx != nullptr);
+    if (!pf->debug) { bl_set_error("bl_pf_debug_last needs bl_pf_debug_enable(pf, 1) before the update"); return BL_ERR_STATE; }
     if (resample_idx)
         BL_HIP(hipMemcpyAsync(resample_idx, pf->dbg_idx, (size_t)pf->n_local * 4, hipMemcpyDeviceToHost, pf->ctx->stream));
     if (likelihood_half_units)

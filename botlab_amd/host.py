@@ -292,6 +292,9 @@ class ParticleFilter:
         check(self.ctx.lib.bl_pf_get_particles(self.h, out.ctypes.data))
         return out
 
+    def debugEnable(self, on=True):
+        check(self.ctx.lib.bl_pf_debug_enable(self.h, 1 if on else 0))
+
     def debugLast(self):
         n = self.hi - self.lo
         idx = np.empty(n, np.int32)

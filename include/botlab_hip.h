@@ -143,7 +143,9 @@ int bl_pf_update_end(bl_pf* pf, bl_pose_xyt_t* out_pose);
 int bl_pf_update_action_only(bl_pf* pf, const bl_pose_xyt_t* odometry, const float* noise, bl_pose_xyt_t* out_pose);
 int bl_pf_pose_estimate(bl_pf* pf, bl_pose_xyt_t* out_pose);              /* poseEstimate() (synchronises) */
 const void* bl_pf_pose_device_ptr(bl_pf* pf);                             /* bl_pose_xyt_t in HBM */
-/* diagnostics for the parity tests: resample source index and raw likelihood (half-units) of the local shard */
+/* diagnostics for the parity tests: resample source index and raw likelihood (half-units) of the local shard of the last
+ * update; recorded only while enabled (8 B per particle of extra stores) */
+int bl_pf_debug_enable(bl_pf* pf, int on);
 int bl_pf_debug_last(bl_pf* pf, int32_t* resample_idx, int32_t* likelihood_half_units);
 
 /* ------------------------------------------------------------------ ObstacleDistanceGrid  (src/planning/obstacle_distance_grid.hpp:28-96) */

@@ -130,6 +130,7 @@ def _mcl_sequence(oracle, maps, gpu_ctx, N, steps, name="obstacle_slam_10mx10m_5
     opf.init_at_pose(oracle.pose(0.0, 0.0, 0.0, utime=t0), 1234)
     pf = bl.ParticleFilter(N, ctx=gpu_ctx)
     pf.setParticles(opf.particles())
+    pf.debugEnable(True)
     rands = [1804289383, 846930886, 1681692777, 1714636915, 1957747793, 424238335, 719885386, 1649760492, 596516649,
              1189641421, 1025202362, 1350490027, 783368690, 1102520059, 2044897763, 1967513926]     # glibc rand(), unseeded
     return m, g, opf, pf, odo, scans, rands, cells
@@ -189,6 +190,7 @@ def test_mcl_parity_large_grid_lds_window(oracle, maps, gpu_ctx, start, kidnap):
         opf.set_particles(parts)
     pf = bl.ParticleFilter(N, ctx=gpu_ctx)
     pf.setParticles(parts)
+    pf.debugEnable(True)
     for k in range(1, len(poses)):
         scan = synth.raycast_scan(world, origin, 0.05, poses[k - 1], poses[k], 1000 + 100000 * k)
         o = odo[k]
