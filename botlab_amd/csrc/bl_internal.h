@@ -57,6 +57,7 @@ struct bl_ctx {
     bl_timer timers[BL_K_COUNT];
     bl_astar_state* astar = nullptr;
     int64_t astar_capacity = 0;
+    bool astar_small_lds = false;      // k_astar with the 40 KB LDS footprint (co-running searches)
 };
 
 struct bl_grid {

@@ -24,9 +24,10 @@
 
 #include "bl_internal.h"
 
-#define MCL_THREADS 256
-#define MCL_WIN_SMALL_BYTES (40 * 1024)       // whole-grid staging budget per 256-thread workgroup (200x200 int8 = 40 KB)
-#define MCL_WIN_BIG 384                       // window side for larger grids: 384^2 = 144 KB, one 1024-thread workgroup per CU
+#define MCL_BLOCK 1024                        // largest workgroup of k_mcl_main
+#define MCL_MIN_BLOCKS 512                    // split rays over lanes until the launch has at least this many workgroups (2 per CU)
+#define MCL_WIN_SMALL_BYTES (64 * 1024)       // whole-grid staging budget (200x200 int8 = 40 KB -> two workgroups per CU)
+#define MCL_WIN_BIG 384                       // window side for larger grids: 384^2 = 144 KB, one workgroup per CU
 #define SCAN_THREADS 256
 #define SCAN_ITEMS 8
 #define SCAN_TILE (SCAN_THREADS * SCAN_ITEMS)
@@ -51,6 +52,8 @@ struct bl_pf {
     double* partials;         // [blocks][5]
     int partials_cap;
     bool use_lds;
+    int split_log2_override;  // -1: automatic
+    int block_override;       // 0: automatic
     bool debug;               // record resample index / likelihood per particle (parity tests)
     unsigned long long* block_sums;   // scan scratch
     int scan_blocks;
@@ -156,6 +159,7 @@ struct mcl_args {
     int interp;                   // parent utime != pose utime (first moved update)
     int resample;                 // 0: action-only (source = own index)
     int win_w, win_h;             // LDS map window size in cells (0: no staging); >= grid size means the whole grid
+    int split_log2;               // each particle's rays are spread over 2^split_log2 adjacent lanes
 };
 
 __device__ __forceinline__ void philox_normals3(uint32_t m, uint32_t step, uint32_t k0, uint32_t k1, float z[3])
@@ -176,6 +180,11 @@ __device__ __forceinline__ void philox_normals3(uint32_t m, uint32_t step, uint3
 
 // One thread per output particle m of the shard: low-variance resample (gather), ActionModel::applyAction,
 // SensorModel::likelihood, weight units, and the block's partial sums for normalisation + pose estimate.
+// Launch shape: BLOCK = 1024 threads; a particle occupies `split` = 2^split_log2 adjacent lanes of one wave, lane
+// `sub` of them taking rays sub, sub + split, ...  (the host picks split so that the launch has >= ~512 workgroups:
+// at 100k particles a one-thread-per-particle launch is 6 waves per CU and latency-bound on its serial 290-ray loop).
+// Resampling and the action model are evaluated by every lane of the group (identical inputs, identical results);
+// the integer half-unit score is summed across the group with xor-shuffles and lane sub == 0 writes the particle.
 template <int INTERP, int BLOCK, int MAP_MODE>
 __global__ __launch_bounds__(BLOCK) void k_mcl_main(mcl_args a)
 {
@@ -229,7 +238,10 @@ __global__ __launch_bounds__(BLOCK) void k_mcl_main(mcl_args a)
         __syncthreads();
     }
 
-    const int j = blockIdx.x * BLOCK + threadIdx.x;
+    const int split = 1 << a.split_log2;
+    const int gtid = blockIdx.x * BLOCK + threadIdx.x;
+    const int j = gtid >> a.split_log2;
+    const int sub = gtid & (split - 1);
     const bool active = j < a.n_local;
     double t_units = 0, t_x = 0, t_y = 0, t_s = 0, t_c = 0;
 
@@ -272,7 +284,7 @@ __global__ __launch_bounds__(BLOCK) void k_mcl_main(mcl_args a)
             float sx0, sy0;
             bl_global_to_grid(px, py, a.frame, &sx0, &sy0);
             const int isx0 = (int)sx0, isy0 = (int)sy0;
-            for (int n = 0; n < a.R; ++n) {                 // the host uploads only rays with range > 0.15f (moving_laser_scan.cpp:24)
+            for (int n = sub; n < a.R; n += split) {        // the host uploads only rays with range > 0.15f (moving_laser_scan.cpp:24)
                 const float range = a.ranges[n];
                 float theta, sx, sy;
                 int isx, isy;
@@ -290,19 +302,22 @@ __global__ __launch_bounds__(BLOCK) void k_mcl_main(mcl_args a)
                 acc += score_ray_half_units<MAP_MODE>(a.cells, s_map, win, a.frame, sx, sy, isx, isy, range, cs, sn);
             }
         }
-        // ---- computeNormalizedPosterior (particle_filter.cpp:116-141): w = max(likelihood, 0.001) in units of 0.0005
-        const uint32_t units = a.cells ? (acc > 0 ? (uint32_t)acc * 1000u : 2u) : __float_as_uint(s.w);
-        a.dst[m] = make_float4(px, py, pth, __uint_as_float(units));
-        a.parent[j] = make_float4(s.x, s.y, s.z, 0.0f);
-        if (a.dbg_idx) { a.dbg_idx[j] = i; a.dbg_like[j] = acc; }
-        // ---- estimatePosteriorPose (particle_filter.cpp:144-160) partial sums
-        float sth, cth;
-        bl_sincosf(pth, &sth, &cth);
-        t_units = (double)units;
-        t_x = t_units * (double)px;
-        t_y = t_units * (double)py;
-        t_s = t_units * (double)sth;
-        t_c = t_units * (double)cth;
+        for (int off = split >> 1; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);     // exact integer sum over the group
+        if (sub == 0) {
+            // ---- computeNormalizedPosterior (particle_filter.cpp:116-141): w = max(likelihood, 0.001) in units of 0.0005
+            const uint32_t units = a.cells ? (acc > 0 ? (uint32_t)acc * 1000u : 2u) : __float_as_uint(s.w);
+            a.dst[m] = make_float4(px, py, pth, __uint_as_float(units));
+            a.parent[j] = make_float4(s.x, s.y, s.z, 0.0f);
+            if (a.dbg_idx) { a.dbg_idx[j] = i; a.dbg_like[j] = acc; }
+            // ---- estimatePosteriorPose (particle_filter.cpp:144-160) partial sums
+            float sth, cth;
+            bl_sincosf(pth, &sth, &cth);
+            t_units = (double)units;
+            t_x = t_units * (double)px;
+            t_y = t_units * (double)py;
+            t_s = t_units * (double)sth;
+            t_c = t_units * (double)cth;
+        }
     }
     t_units = wave_sum(t_units); t_x = wave_sum(t_x); t_y = wave_sum(t_y); t_s = wave_sum(t_s); t_c = wave_sum(t_c);
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -468,7 +483,7 @@ static int pf_alloc(bl_pf* pf)
     BL_HIP(hipMalloc((void**)&pf->prefix, N * sizeof(unsigned long long)));
     BL_HIP(hipMalloc((void**)&pf->parent, n * sizeof(float4)));
     BL_HIP(hipMalloc((void**)&pf->state, sizeof(pf_state)));
-    int blocks = (int)((n + MCL_THREADS - 1) / MCL_THREADS);
+    int blocks = (int)((n * 64 + 255) / 256) + 1;          // worst case: every particle spread over a whole wave, 256-thread blocks
     BL_HIP(hipMalloc((void**)&pf->partials, (size_t)blocks * 5 * sizeof(double)));
     pf->partials_cap = blocks;
     static bool attr_set = false;
@@ -500,6 +515,10 @@ extern "C" int bl_pf_create(bl_ctx* ctx, int num_particles, int shard_lo, int sh
     pf->N = num_particles; pf->lo = shard_lo; pf->hi = shard_hi; pf->n_local = shard_hi - shard_lo;
     pf->noise_seed = 0x243F6A8885A308D3ull;
     pf->use_lds = getenv("BOTLAB_MCL_NO_LDS") == nullptr;
+    pf->split_log2_override = getenv("BOTLAB_MCL_SPLIT_LOG2") ? atoi(getenv("BOTLAB_MCL_SPLIT_LOG2")) : -1;
+    if (pf->split_log2_override > 6) pf->split_log2_override = 6;
+    pf->block_override = getenv("BOTLAB_MCL_BLOCK") ? atoi(getenv("BOTLAB_MCL_BLOCK")) : 0;
+    if (pf->block_override != 0 && pf->block_override != 256 && pf->block_override != 512 && pf->block_override != 1024) pf->block_override = 0;
     *out = pf;
     return BL_OK;
 }
@@ -680,37 +699,55 @@ static int pf_launch_main(bl_pf* pf, const bl_grid* map, int R, int rand_value, 
     // MovingLaserScan(scan, parent_pose, pose): parent_pose.utime is the particle's previous pose utime, pose.utime is
     // ActionModel::utime_ == 0 (D3); they differ only on the first moved update after initialisation.
     a.interp = (map && pf->pose_utime != 0) ? 1 : 0;
-    // LDS map window: the whole grid when it fits the small-window budget (4 workgroups of 256 per CU), otherwise a
-    // MCL_WIN_BIG^2 window per 1024-thread workgroup (one per CU); action-only updates read no map.
-    int block = MCL_THREADS, lds_bytes = 0;
+    // LDS map window: the whole grid when it fits the whole-grid budget, otherwise a MCL_WIN_BIG^2 window per workgroup;
+    // action-only updates read no map.
+    int lds_bytes = 0, mode = 0;
     a.win_w = 0; a.win_h = 0;
     if (map && pf->use_lds) {
         const size_t whole = (size_t)((map->frame.width + 3) & ~3) * map->frame.height;
         if (whole <= MCL_WIN_SMALL_BYTES) {
             a.win_w = map->frame.width; a.win_h = map->frame.height;
             lds_bytes = (int)whole;
+            mode = 1;
         } else {
             a.win_w = map->frame.width < MCL_WIN_BIG ? map->frame.width : MCL_WIN_BIG;
             a.win_h = map->frame.height < MCL_WIN_BIG ? map->frame.height : MCL_WIN_BIG;
             lds_bytes = ((a.win_w + 3) & ~3) * a.win_h;
-            block = 1024;
+            mode = 2;
         }
     }
-    int blocks = (pf->n_local + block - 1) / block;
+    // Launch shape.  Rays of one particle go over 2^split_log2 adjacent lanes: the smallest split that gives
+    // >= MCL_MIN_BLOCKS workgroups (at most a wave).  512-thread workgroups when the whole grid is staged per workgroup
+    // (40 KB: up to 3 per CU); 1024 threads with the 144 KB window (one workgroup per CU: as many waves as fit).
+    int block = (mode == 2) ? 1024 : 512;        // measured at 100k and 1M particles, 200x200: 512 is within 3 % of the best
+    if (pf->block_override > 0) block = pf->block_override;
+    a.split_log2 = 0;
+    if (map && pf->split_log2_override >= 0) a.split_log2 = pf->split_log2_override;
+    else if (map) {
+        while (a.split_log2 < 6 && ((int64_t)pf->n_local << a.split_log2) < (int64_t)MCL_MIN_BLOCKS * block) a.split_log2++;
+    }
+    while (a.split_log2 > 0 && (1 << a.split_log2) > R) a.split_log2--;
+    int blocks = (int)((((int64_t)pf->n_local << a.split_log2) + block - 1) / block);
     if (blocks > pf->partials_cap) { bl_set_error("internal: partials buffer too small"); return BL_ERR_STATE; }
     hipEvent_t e0, e1;
     int rc = bl_timer_begin(ctx, BL_K_MCL_MAIN, &e0, &e1);
     if (rc) return rc;
-    if (lds_bytes == 0) {
-        if (a.interp) hipLaunchKernelGGL((k_mcl_main<1, MCL_THREADS, 0>), dim3(blocks), dim3(MCL_THREADS), 0, ctx->stream, a);
-        else hipLaunchKernelGGL((k_mcl_main<0, MCL_THREADS, 0>), dim3(blocks), dim3(MCL_THREADS), 0, ctx->stream, a);
-    } else if (block == MCL_THREADS) {
-        if (a.interp) hipLaunchKernelGGL((k_mcl_main<1, MCL_THREADS, 1>), dim3(blocks), dim3(MCL_THREADS), lds_bytes, ctx->stream, a);
-        else hipLaunchKernelGGL((k_mcl_main<0, MCL_THREADS, 1>), dim3(blocks), dim3(MCL_THREADS), lds_bytes, ctx->stream, a);
-    } else {
-        if (a.interp) hipLaunchKernelGGL((k_mcl_main<1, 1024, 2>), dim3(blocks), dim3(1024), lds_bytes, ctx->stream, a);
-        else hipLaunchKernelGGL((k_mcl_main<0, 1024, 2>), dim3(blocks), dim3(1024), lds_bytes, ctx->stream, a);
-    }
+#define MCL_LAUNCH(B, M)                                                                                          \
+    do {                                                                                                          \
+        if (a.interp) hipLaunchKernelGGL((k_mcl_main<1, B, M>), dim3(blocks), dim3(B), lds_bytes, ctx->stream, a); \
+        else hipLaunchKernelGGL((k_mcl_main<0, B, M>), dim3(blocks), dim3(B), lds_bytes, ctx->stream, a);          \
+    } while (0)
+#define MCL_LAUNCH_MODE(B)                                    \
+    do {                                                      \
+        if (mode == 0) MCL_LAUNCH(B, 0);                      \
+        else if (mode == 1) MCL_LAUNCH(B, 1);                 \
+        else MCL_LAUNCH(B, 2);                                \
+    } while (0)
+    if (block == 256) MCL_LAUNCH_MODE(256);
+    else if (block == 512) MCL_LAUNCH_MODE(512);
+    else MCL_LAUNCH_MODE(1024);
+#undef MCL_LAUNCH_MODE
+#undef MCL_LAUNCH
     BL_HIP(hipGetLastError());
     rc = bl_timer_end(ctx, BL_K_MCL_MAIN, e0, e1);
     if (rc) return rc;

@@ -267,9 +267,16 @@ struct astar_result { int status; int path_len; long long pops; long long pushes
 // Open-list entry: x = fCost, y = (cy << 17) | (cx << 2) | k where the cell (cx, cy) was generated from its parent by
 // move k (cell = parent + delta[k]).  gCost is not stored: fCost = gCost + hCost(cell) + oCost(cell) and the last two
 // are functions of the cell alone, so gCost is recovered when the entry is popped.
-#define AH_LDS 16383                 // heap levels 0..13 live in LDS; deeper levels in HBM/L2
-#define AH_COST_LDS 8000             // per-L1-distance cost table in LDS when it fits (W + H + 1 <= 8000)
+// Two LDS footprints: BIG keeps heap levels 0..13 (16383 entries, 128 KB) + an 8000-entry cost table in LDS -- the
+// whole CU's LDS, for a search that runs alone; SMALL keeps levels 0..11 (4095 entries, 32 KB) + 2000 cost entries
+// (40 KB in all) so the search can start on a CU that a co-running kernel (the particle filter: 40 KB per workgroup)
+// already occupies instead of waiting for one to drain.  Deeper levels live in HBM/L2.
+#define AH_LDS 16383
+#define AH_COST_LDS 8000
 #define AH_LDS_BYTES ((AH_LDS + 1) * 8 + AH_COST_LDS * 4)
+#define AH_LDS_SMALL 4095
+#define AH_COST_LDS_SMALL 2000
+#define AH_LDS_SMALL_BYTES ((AH_LDS_SMALL + 1) * 8 + AH_COST_LDS_SMALL * 4)
 #define AH_MAX_DIM 32767
 #define AH_MAX_CAP (1 << 25)
 
@@ -326,23 +333,25 @@ __device__ __forceinline__ void lds_entry_store(int i, int2 v)
 {
     ((volatile lds_ll_t*)s_heap)[i] = ((long long)(unsigned int)v.x) | ((long long)v.y << 32);
 }
+template <int LDSN>
 __device__ __forceinline__ int2 heap_read(const int2* g_heap, int i)
 {
-    int2 v = lds_entry(i < AH_LDS ? i : AH_LDS);
-    if (i >= AH_LDS) v = g_heap[i];
+    int2 v = lds_entry(i < LDSN ? i : LDSN);
+    if (i >= LDSN) v = g_heap[i];
     return v;
 }
+template <int LDSN>
 __device__ __forceinline__ void heap_write(int2* g_heap, int i, int2 v)
 {
-    lds_entry_store(i < AH_LDS ? i : AH_LDS, v);
-    if (i >= AH_LDS) g_heap[i] = v;
+    lds_entry_store(i < LDSN ? i : LDSN, v);
+    if (i >= LDSN) g_heap[i] = v;
 }
 
 // std::__push_heap(first, hole, 0, value, greater-by-fCost) (stl_heap.h:128-146) by one wavefront: lane a holds the
 // (a+1)-th ancestor of the hole; the value rises past the leading run of ancestors with a larger fCost, each of which
 // drops one level.  IN_LDS: the hole (and therefore its whole ancestor chain) is below AH_LDS -- that instantiation
 // contains no vector-memory instruction, so the loads the caller left in flight are not waited for here.
-template <bool IN_LDS>
+template <bool IN_LDS, int LDSN>
 __device__ __forceinline__ void heap_sift_up(int2* g_heap, int hole, int2 value, int lane)
 {
     const unsigned int hp = (unsigned int)hole + 1u;
@@ -351,15 +360,15 @@ __device__ __forceinline__ void heap_sift_up(int2* g_heap, int hole, int2 value,
     const int anc = (int)(hp >> (lane + 1)) - 1;
     const int below = (int)(hp >> lane) - 1;            // where this ancestor lands if it drops one level
     int2 e = make_int2(0, 0);
-    if (v) e = IN_LDS ? lds_entry(anc) : heap_read(g_heap, anc);
+    if (v) e = IN_LDS ? lds_entry(anc) : heap_read<LDSN>(g_heap, anc);
     const unsigned long long m = __ballot(v && (e.x > value.x));
     const int t = __ffsll((long long)~m) - 1;           // length of the leading run
     if (IN_LDS) {
         if (lane < t) lds_entry_store(below, e);
         if (lane == 0) lds_entry_store((int)(hp >> t) - 1, value);
     } else {
-        if (lane < t) heap_write(g_heap, below, e);
-        if (lane == 0) heap_write(g_heap, (int)(hp >> t) - 1, value);
+        if (lane < t) heap_write<LDSN>(g_heap, below, e);
+        if (lane == 0) heap_write<LDSN>(g_heap, (int)(hp >> t) - 1, value);
         __threadfence_block();                          // drain the wave's HBM stores before dependent loads
     }
     __builtin_amdgcn_wave_barrier();
@@ -373,7 +382,7 @@ __device__ __forceinline__ void heap_sift_up(int2* g_heap, int hole, int2 value,
 // against two per-lane constant masks (amask: its ancestors' lanes, areq: the branch bit required at each).  Each
 // on-path lane moves its entry to its parent; the deepest on-path lane is the new hole.
 // IN_LDS: len <= AH_LDS, the whole heap is in LDS (no vector-memory instruction in that instantiation).
-template <bool IN_LDS>
+template <bool IN_LDS, int LDSN>
 __device__ __forceinline__ void heap_adjust(int2* g_heap, int len, int2 value, int lane, int lk, int ljm1,
                                             unsigned long long amask, unsigned long long areq)
 {
@@ -391,8 +400,8 @@ __device__ __forceinline__ void heap_adjust(int2* g_heap, int len, int2 value, i
                 e = lds_entry(node);
                 if (two) { fl = lds_entry(cl).x; fr = lds_entry(cl + 1).x; }
             } else {
-                e = heap_read(g_heap, node);
-                if (two) { fl = heap_read(g_heap, cl).x; fr = heap_read(g_heap, cl + 1).x; }
+                e = heap_read<LDSN>(g_heap, node);
+                if (two) { fl = heap_read<LDSN>(g_heap, cl).x; fr = heap_read<LDSN>(g_heap, cl + 1).x; }
             }
         }
         // right child preferred unless comp(right, left), i.e. right.fCost > left.fCost; a lone left child -> left
@@ -402,20 +411,21 @@ __device__ __forceinline__ void heap_adjust(int2* g_heap, int len, int2 value, i
         const int cur = 63 - __clzll((long long)P);     // deepest on-path lane
         if (on_path && lane > 0) {
             if (IN_LDS) lds_entry_store((node - 1) >> 1, e);
-            else heap_write(g_heap, (node - 1) >> 1, e);
+            else heap_write<LDSN>(g_heap, (node - 1) >> 1, e);
         }
         hole = __builtin_amdgcn_readlane(node, cur);
         if (!(cur >= 31 && 2 * hole + 1 < len)) break;
     }
     if (!IN_LDS) __threadfence_block();
     __builtin_amdgcn_wave_barrier();
-    heap_sift_up<IN_LDS>(g_heap, hole, value, lane);
+    heap_sift_up<IN_LDS, LDSN>(g_heap, hole, value, lane);
 }
 
 // One wavefront runs the reference's search loop (astar.cpp:75-135) with libstdc++'s heap operations executed
 // cooperatively; lanes 0..3 evaluate the four neighbours of the popped node, lane 4 re-derives its gCost.
 // Closed cells: closed[] is written with a no-return atomic compare-and-swap (first closing wins) and read with
 // L1-bypassing loads, so no lane ever waits on the closing store of the popped cell.
+template <int LDSN, int COSTN>
 __global__ __launch_bounds__(64) void k_astar(astar_args a)
 {
     int2* g_heap = a.heap;
@@ -428,8 +438,8 @@ __global__ __launch_bounds__(64) void k_astar(astar_args a)
         res.start = *a.start_dev;
         bl_global_to_cell((double)res.start.x, (double)res.start.y, a.frame, &a.sx, &a.sy);
     }
-    const bool cost_in_lds = a.cost_n <= AH_COST_LDS;
-    lds_int_t* s_cost = (lds_int_t*)s_heap + 2 * (AH_LDS + 1);
+    const bool cost_in_lds = a.cost_n <= COSTN;
+    lds_int_t* s_cost = (lds_int_t*)s_heap + 2 * (LDSN + 1);
     if (cost_in_lds) for (int i = lane; i < a.cost_n; i += 64) s_cost[i] = a.cost_lut[i];
     __syncthreads();
     // isValid (astar.cpp:140-149, D5) folded with get_oCost (astar.cpp:181-186): both depend only on the cell's distance
@@ -490,12 +500,12 @@ __global__ __launch_bounds__(64) void k_astar(astar_args a)
         STAMP(t1);
         len -= 1;
         if (len > 0) {
-            if (len <= AH_LDS) {
-                const int2 value = lds_entry(len);
-                heap_adjust<true>(g_heap, len, value, lane, lk, lj - 1, amask, areq);
+            if (len <= LDSN) {
+                const int2 value = heap_read<LDSN>(g_heap, len);
+                heap_adjust<true, LDSN>(g_heap, len, value, lane, lk, lj - 1, amask, areq);
             } else {
-                const int2 value = heap_read(g_heap, len);
-                heap_adjust<false>(g_heap, len, value, lane, lk, lj - 1, amask, areq);
+                const int2 value = heap_read<LDSN>(g_heap, len);
+                heap_adjust<false, LDSN>(g_heap, len, value, lane, lk, lj - 1, amask, areq);
             }
         }
         asm volatile("s_waitcnt vmcnt(0)" : "+v"(my_l1), "+v"(my_closed) :: "memory");
@@ -527,8 +537,8 @@ __global__ __launch_bounds__(64) void k_astar(astar_args a)
             if (len >= a.heap_cap) { res.status = ASTAR_ST_CAPACITY; done = true; break; }
             const int fk = __builtin_amdgcn_readlane(f, kk);
             const int yk = __builtin_amdgcn_readlane(ey, kk);
-            if (len < AH_LDS) heap_sift_up<true>(g_heap, len, make_int2(fk, yk), lane);      // push_back + std::push_heap
-            else heap_sift_up<false>(g_heap, len, make_int2(fk, yk), lane);
+            if (len < LDSN) heap_sift_up<true, LDSN>(g_heap, len, make_int2(fk, yk), lane);      // push_back + std::push_heap
+            else heap_sift_up<false, LDSN>(g_heap, len, make_int2(fk, yk), lane);
             len += 1;
             res.pushes += 1;
         }
@@ -613,7 +623,7 @@ static int astar_prepare(bl_ctx* ctx, const bl_dist* d)
         s->heap = nullptr;
         BL_HIP(hipMalloc((void**)&s->heap, (size_t)want * sizeof(int2)));
         s->heap_cap = want;
-        BL_HIP(hipFuncSetAttribute((const void*)k_astar, hipFuncAttributeMaxDynamicSharedMemorySize, AH_LDS_BYTES));
+        BL_HIP(hipFuncSetAttribute((const void*)k_astar<AH_LDS, AH_COST_LDS>, hipFuncAttributeMaxDynamicSharedMemorySize, AH_LDS_BYTES));
     }
     size_t n = (size_t)d->frame.width * d->frame.height;
     if (n > s->closed_cap) {
@@ -702,7 +712,10 @@ static int astar_launch(bl_ctx* ctx, const bl_dist* d, const bl_pose_xyt_t* star
     rc = bl_timer_begin(ctx, BL_K_ASTAR, &e0, &e1);
     if (rc) return rc;
     BL_HIP(hipMemsetAsync(s->closed, 0xFF, (size_t)a.W * a.H * 4, ctx->stream));
-    hipLaunchKernelGGL(k_astar, dim3(1), dim3(64), AH_LDS_BYTES, ctx->stream, a);
+    if (ctx->astar_small_lds)
+        hipLaunchKernelGGL((k_astar<AH_LDS_SMALL, AH_COST_LDS_SMALL>), dim3(1), dim3(64), AH_LDS_SMALL_BYTES, ctx->stream, a);
+    else
+        hipLaunchKernelGGL((k_astar<AH_LDS, AH_COST_LDS>), dim3(1), dim3(64), AH_LDS_BYTES, ctx->stream, a);
     BL_HIP(hipGetLastError());
     rc = bl_timer_end(ctx, BL_K_ASTAR, e0, e1);
     if (rc) return rc;
@@ -820,6 +833,7 @@ extern "C" int bl_planner_create(bl_ctx* ctx, bl_planner** out)
     p->main = ctx;
     int rc = bl_ctx_create(ctx->device, nullptr, &p->side);
     if (rc) { delete p; return rc; }
+    p->side->astar_small_lds = true;         // co-runs with the SLAM stream's kernels
     rc = bl_dist_create(p->side, &p->dist);
     if (rc) { bl_ctx_destroy(p->side); delete p; return rc; }
     for (int i = 0; i < PLANNER_SLOTS; ++i) {
