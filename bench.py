@@ -121,7 +121,8 @@ def main():
     ap.add_argument("--goal-l1", type=int, default=40, help="without --goal on a non-default grid: max L1 distance (cells) "
                     "of the replan goal from the start")
     ap.add_argument("--cpu-steps", type=int, default=10, help="steps of the CPU baseline sample (0 = skip)")
-    ap.add_argument("--depth", type=int, default=1, help="steps enqueued ahead of fetching a result (0 = synchronous steps)")
+    ap.add_argument("--depth", type=int, default=3, help="steps enqueued ahead of fetching a result (0 = synchronous steps)")
+    ap.add_argument("--lanes", type=int, default=3, help="replanner streams: consecutive replans run concurrently (1..4)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -152,7 +153,8 @@ def main():
     mapper = bl.Mapping(5.0, 4, 1, ctx=ctx)                 # slam.cpp:24, slam_main.cpp:22-23
     planner = bl.MotionPlanner(ctx=ctx)                       # robotRadius 0.2 (motion_planner.hpp:31)
     planner.setMap(grid)
-    aplanner = bl.AsyncPlanner(ctx=ctx)                       # the replanner on its own stream (the reference's planner process)
+    # the replanner on its own stream(s) (the reference's planner process); consecutive replans overlap on `lanes` streams
+    aplanner = bl.AsyncPlanner(ctx=ctx, lanes=args.lanes)
     goal = None
     if not args.no_astar:
         if args.goal is not None:
@@ -194,6 +196,7 @@ def main():
         return None
 
     host_t = [0.0, 0.0]
+    step_wall = []
 
     def step(k):
         # software pipeline of depth args.depth: step k is enqueued before the result of step k - depth is fetched, so the
@@ -204,8 +207,10 @@ def main():
         last = None
         while len(in_flight) > args.depth:
             last = fetch()
+        t2 = time.perf_counter()
         host_t[0] += t1 - t0
-        host_t[1] += time.perf_counter() - t1
+        host_t[1] += t2 - t1
+        step_wall.append((t2 - t0, k))
         return last
 
     def drain():
@@ -216,15 +221,24 @@ def main():
             last = engine.pf.poseEstimate()
         return last
 
+    # The measured loop is a few hundred microseconds per step; a generational GC pass over the interpreter's (torch-sized)
+    # heap is tens of milliseconds.  Collect once now and keep the collector out of the timed region.
+    import gc
+    gc.collect()
+    gc.freeze()
+    gc.disable()
+
     k = 0
     for _ in range(args.warmup):
         step(k)
         k += 1
     drain()
     ctx.timing_reset()
-    ctx.timing_enable(True, kernels=[_capi.BL_K_MCL_MAIN])      # HIP events around the dominant kernel only (roofline leg)
+    if not os.environ.get("BENCH_NO_EVENTS"):
+        ctx.timing_enable(True, kernels=[_capi.BL_K_MCL_MAIN])      # HIP events around the dominant kernel only (roofline leg)
     pops_total[0] = 0
     host_t[0] = host_t[1] = 0.0
+    del step_wall[:]
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -245,6 +259,7 @@ def main():
 
     main_ms_total, main_n = ctx.timing_get(_capi.BL_K_MCL_MAIN)
     host_ms = (1e3 * host_t[0] / args.steps, 1e3 * host_t[1] / args.steps)
+    slowest = sorted(step_wall, reverse=True)[:4]
     pops_timed = pops_total[0]
     final_pose, final_k = pose, k
     # per-stage kernel times: a short untimed pass with every timer on (events between launches cost a few us each, so
@@ -303,7 +318,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"full SLAM step on {W}x{H} @5cm grid (shipped obstacle_slam map), {N} particles, "
                                    f"{R} rays, A* replan {'off' if goal is None else 'on'}",
-                       "particles": N, "grid": [W, H], "rays": R, "pipeline_depth": args.depth,
+                       "particles": N, "grid": [W, H], "rays": R, "pipeline_depth": args.depth, "planner_lanes": args.lanes,
                        "parallelism": f"particle-shard x{world}" if world > 1 else "single GPU"},
             "roofline": {"bound": "hbm", "kernel": "k_mcl_main", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
@@ -312,6 +327,7 @@ def main():
             "stage_ms": {k_: round(v[0], 5) for k_, v in stage_ms.items()},
             "astar_pops_per_step": pops_total[0] / args.steps,
             "host_ms_per_step": {"enqueue": round(host_ms[0], 4), "fetch_wait": round(host_ms[1], 4)},
+            "slowest_steps_ms": [[round(1e3 * t, 3), kk] for t, kk in slowest],
             "final_pose": [pose.x, pose.y, pose.theta],
             "truth_pose": [float(v) for v in poses[k]],
         }

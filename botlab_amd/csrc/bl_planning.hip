@@ -28,6 +28,8 @@ struct bl_dist {
     uint16_t* l1;             // L1 distance (0xFFFF: no source anywhere)
     float* cells;             // float distances handed to callers
     float* lut;               // device f[n]
+    int32_t* closed;          // A* closed-cell scratch of this grid (-1 = not closed); cleared by setDistances
+    bool closed_clean;        // no search has written closed[] since it was last cleared
     int lut_n;
     std::vector<float>* lut_host;
     bool valid;
@@ -96,7 +98,7 @@ __global__ __launch_bounds__(256) void k_dist_rows(const int8_t* __restrict__ ce
 #define DCOL_TY 16
 __global__ __launch_bounds__(DCOL_TX * DCOL_TY) void k_dist_cols(const uint16_t* __restrict__ row, int W, int H,
                                                                  uint16_t* __restrict__ l1, float* __restrict__ out,
-                                                                 const float* __restrict__ lut)
+                                                                 const float* __restrict__ lut, int32_t* __restrict__ closed)
 {
     __shared__ int s_fwd[DCOL_TY][DCOL_TX];
     __shared__ int s_bwd[DCOL_TY][DCOL_TX];
@@ -147,6 +149,7 @@ __global__ __launch_bounds__(DCOL_TX * DCOL_TY) void k_dist_cols(const uint16_t*
         bool none = v >= 0xFFFF;
         l1[(size_t)y * W + x] = none ? (uint16_t)0xFFFF : (uint16_t)v;
         out[(size_t)y * W + x] = none ? -1.0f : lut[v];
+        closed[(size_t)y * W + x] = -1;                     // the first search on this grid needs no separate clear
     }
 }
 
@@ -169,6 +172,7 @@ extern "C" void bl_dist_destroy(bl_dist* d)
     if (d->row) (void)hipFree(d->row);
     if (d->l1) (void)hipFree(d->l1);
     if (d->cells) (void)hipFree(d->cells);
+    if (d->closed) (void)hipFree(d->closed);
     if (d->lut) (void)hipFree(d->lut);
     delete d->lut_host;
     delete d;
@@ -187,10 +191,12 @@ extern "C" int bl_dist_set_distances(bl_dist* d, const bl_grid* map)
         if (d->row) BL_HIP(hipFree(d->row));
         if (d->l1) BL_HIP(hipFree(d->l1));
         if (d->cells) BL_HIP(hipFree(d->cells));
-        d->row = nullptr; d->l1 = nullptr; d->cells = nullptr;
+        if (d->closed) BL_HIP(hipFree(d->closed));
+        d->row = nullptr; d->l1 = nullptr; d->cells = nullptr; d->closed = nullptr;
         BL_HIP(hipMalloc((void**)&d->row, n * 2));
         BL_HIP(hipMalloc((void**)&d->l1, n * 2));
         BL_HIP(hipMalloc((void**)&d->cells, n * 4));
+        BL_HIP(hipMalloc((void**)&d->closed, n * 4));
         d->capacity = n;
     }
     d->frame = map->frame;
@@ -211,10 +217,11 @@ extern "C" int bl_dist_set_distances(bl_dist* d, const bl_grid* map)
     if (rc) return rc;
     hipLaunchKernelGGL(k_dist_rows, dim3(H), dim3(256), 0, ctx->stream, map->cells, W, d->row);
     hipLaunchKernelGGL(k_dist_cols, dim3((W + DCOL_TX - 1) / DCOL_TX), dim3(DCOL_TX, DCOL_TY), 0, ctx->stream, d->row, W, H,
-                       d->l1, d->cells, d->lut);
+                       d->l1, d->cells, d->lut, d->closed);
     BL_HIP(hipGetLastError());
     rc = bl_timer_end(ctx, BL_K_DIST, e0, e1);
     if (rc) return rc;
+    d->closed_clean = true;
     d->valid = true;
     return BL_OK;
 }
@@ -284,11 +291,12 @@ struct astar_result { int status; int path_len; long long pops; long long pushes
 
 struct bl_astar_state {
     int2* heap; int64_t heap_cap;
-    int32_t* closed; size_t closed_cap;    // -1: not closed; 0..3: move that produced the FIRST closed entry; 4: start
-    int32_t* path; size_t path_cap;
+    // closed cells live with the distance grid (bl_dist::closed): -1 not closed; 0..3 move that produced the FIRST
+    // closed entry; 4 start.  d_out = [astar_result, padded to ASTAR_HDR bytes][path cells]: one D2H brings back the
+    // result record and the head of the path.
+    char* d_out; size_t path_cap;
     int32_t* cost_lut; int cost_lut_cap;
-    astar_result* d_result;
-    astar_result* h_result[ASTAR_SLOTS];   // pinned result ring: searches may be enqueued ahead of fetching results
+    char* h_out[ASTAR_SLOTS];              // pinned result ring ([result][path head]): searches may be enqueued ahead of fetching
     hipEvent_t done[ASTAR_SLOTS];
     bl_frame slot_frame[ASTAR_SLOTS];
     int64_t launched, fetched;
@@ -298,10 +306,11 @@ struct bl_astar_state {
     bl_frame frame;
     // cost table cache key
     bool lut_valid; bl_search_params_t lut_params; int lut_n; const void* lut_owner;
-    int32_t* h_path_head[ASTAR_SLOTS];  // pinned: first ASTAR_PATH_HEAD path cells, copied back with the result
 };
 
 #define ASTAR_PATH_HEAD 4096
+#define ASTAR_HDR 256
+static_assert(sizeof(astar_result) <= ASTAR_HDR, "result record must fit the header of the output buffer");
 
 struct astar_args {
     const uint16_t* l1; int W, H;
@@ -580,13 +589,10 @@ void bl_astar_free(bl_ctx* ctx)
     bl_astar_state* s = ctx->astar;
     if (!s) return;
     if (s->heap) (void)hipFree(s->heap);
-    if (s->closed) (void)hipFree(s->closed);
-    if (s->path) (void)hipFree(s->path);
+    if (s->d_out) (void)hipFree(s->d_out);
     if (s->cost_lut) (void)hipFree(s->cost_lut);
-    if (s->d_result) (void)hipFree(s->d_result);
     for (int i = 0; i < ASTAR_SLOTS; ++i) {
-        if (s->h_result[i]) (void)hipHostFree(s->h_result[i]);
-        if (s->h_path_head[i]) (void)hipHostFree(s->h_path_head[i]);
+        if (s->h_out[i]) (void)hipHostFree(s->h_out[i]);
         if (s->done[i]) (void)hipEventDestroy(s->done[i]);
     }
     if (s->h_cost) (void)hipHostFree(s->h_cost);
@@ -606,10 +612,8 @@ static int astar_prepare(bl_ctx* ctx, const bl_dist* d)
     if (!ctx->astar) {
         ctx->astar = new bl_astar_state();
         memset((void*)ctx->astar, 0, sizeof(bl_astar_state));
-        BL_HIP(hipMalloc((void**)&ctx->astar->d_result, sizeof(astar_result)));
         for (int i = 0; i < ASTAR_SLOTS; ++i) {
-            BL_HIP(hipHostMalloc((void**)&ctx->astar->h_result[i], sizeof(astar_result), hipHostMallocDefault));
-            BL_HIP(hipHostMalloc((void**)&ctx->astar->h_path_head[i], ASTAR_PATH_HEAD * 4, hipHostMallocDefault));
+            BL_HIP(hipHostMalloc((void**)&ctx->astar->h_out[i], ASTAR_HDR + ASTAR_PATH_HEAD * 4, hipHostMallocDefault));
             BL_HIP(hipEventCreateWithFlags(&ctx->astar->done[i], hipEventDisableTiming));
         }
     }
@@ -626,14 +630,13 @@ static int astar_prepare(bl_ctx* ctx, const bl_dist* d)
         BL_HIP(hipFuncSetAttribute((const void*)k_astar<AH_LDS, AH_COST_LDS>, hipFuncAttributeMaxDynamicSharedMemorySize, AH_LDS_BYTES));
     }
     size_t n = (size_t)d->frame.width * d->frame.height;
-    if (n > s->closed_cap) {
+    if (n < ASTAR_PATH_HEAD) n = ASTAR_PATH_HEAD;
+    if (n > s->path_cap) {
         BL_HIP(hipStreamSynchronize(ctx->stream));
-        if (s->closed) BL_HIP(hipFree(s->closed));
-        if (s->path) BL_HIP(hipFree(s->path));
-        s->closed = nullptr; s->path = nullptr;
-        BL_HIP(hipMalloc((void**)&s->closed, n * 4));
-        BL_HIP(hipMalloc((void**)&s->path, n * 4));
-        s->closed_cap = n; s->path_cap = n;
+        if (s->d_out) BL_HIP(hipFree(s->d_out));
+        s->d_out = nullptr;
+        BL_HIP(hipMalloc((void**)&s->d_out, ASTAR_HDR + n * 4));
+        s->path_cap = n;
     }
     int ln = d->frame.width + d->frame.height + 1;
     if (ln > s->cost_lut_cap) {
@@ -694,9 +697,9 @@ static int astar_launch(bl_ctx* ctx, const bl_dist* d, const bl_pose_xyt_t* star
     a.l1 = d->l1; a.W = d->frame.width; a.H = d->frame.height;
     a.cost_lut = s->cost_lut; a.cost_n = ln;
     a.heap = s->heap; a.heap_cap = (int)s->heap_cap;
-    a.closed = s->closed;
-    a.path = s->path; a.path_cap = (long long)s->path_cap;
-    a.result = s->d_result;
+    a.closed = d->closed;
+    a.path = (int32_t*)(s->d_out + ASTAR_HDR); a.path_cap = (long long)s->path_cap;
+    a.result = (astar_result*)s->d_out;
     a.frame = d->frame;
     bl_global_to_cell((double)goal->x, (double)goal->y, d->frame, &a.gx, &a.gy);     // astar.cpp:23-33
     a.sx = 0; a.sy = 0;
@@ -711,7 +714,9 @@ static int astar_launch(bl_ctx* ctx, const bl_dist* d, const bl_pose_xyt_t* star
     hipEvent_t e0, e1;
     rc = bl_timer_begin(ctx, BL_K_ASTAR, &e0, &e1);
     if (rc) return rc;
-    BL_HIP(hipMemsetAsync(s->closed, 0xFF, (size_t)a.W * a.H * 4, ctx->stream));
+    bl_dist* dm = const_cast<bl_dist*>(d);           // closed[] is search scratch that travels with the grid
+    if (!dm->closed_clean) BL_HIP(hipMemsetAsync(dm->closed, 0xFF, (size_t)a.W * a.H * 4, ctx->stream));
+    dm->closed_clean = false;
     if (ctx->astar_small_lds)
         hipLaunchKernelGGL((k_astar<AH_LDS_SMALL, AH_COST_LDS_SMALL>), dim3(1), dim3(64), AH_LDS_SMALL_BYTES, ctx->stream, a);
     else
@@ -720,9 +725,7 @@ static int astar_launch(bl_ctx* ctx, const bl_dist* d, const bl_pose_xyt_t* star
     rc = bl_timer_end(ctx, BL_K_ASTAR, e0, e1);
     if (rc) return rc;
     const int slot = (int)(s->launched % ASTAR_SLOTS);
-    BL_HIP(hipMemcpyAsync(s->h_result[slot], s->d_result, sizeof(astar_result), hipMemcpyDeviceToHost, ctx->stream));
-    size_t head = s->path_cap < ASTAR_PATH_HEAD ? s->path_cap : ASTAR_PATH_HEAD;
-    BL_HIP(hipMemcpyAsync(s->h_path_head[slot], s->path, head * 4, hipMemcpyDeviceToHost, ctx->stream));
+    BL_HIP(hipMemcpyAsync(s->h_out[slot], s->d_out, ASTAR_HDR + ASTAR_PATH_HEAD * 4, hipMemcpyDeviceToHost, ctx->stream));
     BL_HIP(hipEventRecord(s->done[slot], ctx->stream));
     s->slot_frame[slot] = d->frame;
     s->launched += 1;
@@ -754,7 +757,7 @@ extern "C" int bl_astar_search_result(bl_ctx* ctx, bl_pose_xyt_t* out_path, int 
     s->fetched += 1;
     s->pending = s->launched != s->fetched;
     s->frame = s->slot_frame[slot];
-    astar_result r = *s->h_result[slot];
+    astar_result r = *(const astar_result*)s->h_out[slot];
     if (stats) { stats[0] = r.pops; stats[1] = r.pushes; }
 #ifdef BL_ASTAR_STAMPS
     fprintf(stderr, "[astar stamps] pops %lld cycles/pop all %.0f adjust %.0f expand+push %.0f | realtime ticks(100MHz) %lld -> clock %.2f GHz, final len %lld\n",
@@ -770,12 +773,12 @@ extern "C" int bl_astar_search_result(bl_ctx* ctx, bl_pose_xyt_t* out_path, int 
     if (r.status != ASTAR_ST_FOUND) return BL_OK;
     // makePath (astar.cpp:235-274): cells come goal-first; poses are emitted start-side first
     std::vector<int32_t> cells((size_t)r.path_len);
-    if (r.path_len <= ASTAR_PATH_HEAD) memcpy(cells.data(), s->h_path_head[slot], (size_t)r.path_len * 4);
+    if (r.path_len <= ASTAR_PATH_HEAD) memcpy(cells.data(), s->h_out[slot] + ASTAR_HDR, (size_t)r.path_len * 4);
     else {
         // longer than the head copied with the result: only valid if no later search has overwritten the device path
         if (s->pending) { bl_set_error("A* path of %d cells exceeds the pipelined result head (%d)", r.path_len, ASTAR_PATH_HEAD); return BL_ERR_CAPACITY; }
         BL_HIP(hipStreamSynchronize(ctx->stream));
-        BL_HIP(hipMemcpy(cells.data(), s->path, (size_t)r.path_len * 4, hipMemcpyDeviceToHost));
+        BL_HIP(hipMemcpy(cells.data(), s->d_out + ASTAR_HDR, (size_t)r.path_len * 4, hipMemcpyDeviceToHost));
     }
     std::vector<bl_pose_xyt_t> rev((size_t)r.path_len);
     float prevX = 0, prevY = 0;
@@ -811,10 +814,13 @@ extern "C" int bl_astar_search(bl_ctx* ctx, const bl_dist* d, const bl_pose_xyt_
 // SLAM stream, so the one-wavefront A* overlaps the next scan's particle-filter kernels instead of serialising with
 // them.  Two snapshot slots; every hand-off between the two streams is an event.
 #define PLANNER_SLOTS 2
+#define PLANNER_MAX_LANES 4
 
-struct bl_planner {
-    bl_ctx* main;                       // the SLAM ctx (not owned)
-    bl_ctx* side;                       // own ctx: second stream, distance grid + A* state
+// A lane = one side stream with its own distance grid, A* state and snapshot slots.  Consecutive submissions go to
+// consecutive lanes, so up to `lanes` replans (independent searches on independent snapshots) run concurrently, each
+// one wavefront on its own CU; results are fetched in submission order.
+struct planner_lane {
+    bl_ctx* side;                       // own ctx: stream, distance grid + A* state
     bl_dist* dist;
     bl_grid* snap[PLANNER_SLOTS];
     bl_pose_xyt_t* pose[PLANNER_SLOTS];
@@ -824,22 +830,33 @@ struct bl_planner {
     int64_t submitted;
 };
 
-extern "C" int bl_planner_create(bl_ctx* ctx, bl_planner** out)
+struct bl_planner {
+    bl_ctx* main;                       // the SLAM ctx (not owned)
+    int lanes;
+    planner_lane lane[PLANNER_MAX_LANES];
+    int64_t submitted, fetched;
+};
+
+extern "C" int bl_planner_create(bl_ctx* ctx, int lanes, bl_planner** out)
 {
-    BL_CHECK_ARG(ctx != nullptr && out != nullptr);
+    BL_CHECK_ARG(ctx != nullptr && out != nullptr && lanes >= 1 && lanes <= PLANNER_MAX_LANES);
     BL_HIP(hipSetDevice(ctx->device));
     bl_planner* p = new bl_planner();
     memset((void*)p, 0, sizeof(*p));
     p->main = ctx;
-    int rc = bl_ctx_create(ctx->device, nullptr, &p->side);
-    if (rc) { delete p; return rc; }
-    p->side->astar_small_lds = true;         // co-runs with the SLAM stream's kernels
-    rc = bl_dist_create(p->side, &p->dist);
-    if (rc) { bl_ctx_destroy(p->side); delete p; return rc; }
-    for (int i = 0; i < PLANNER_SLOTS; ++i) {
-        BL_HIP(hipMalloc((void**)&p->pose[i], sizeof(bl_pose_xyt_t)));
-        BL_HIP(hipEventCreateWithFlags(&p->snap_ready[i], hipEventDisableTiming));
-        BL_HIP(hipEventCreateWithFlags(&p->slot_free[i], hipEventDisableTiming));
+    p->lanes = lanes;
+    for (int l = 0; l < lanes; ++l) {
+        planner_lane& L = p->lane[l];
+        int rc = bl_ctx_create(ctx->device, nullptr, &L.side);
+        if (rc) return rc;
+        L.side->astar_small_lds = true;      // co-runs with the SLAM stream's kernels
+        rc = bl_dist_create(L.side, &L.dist);
+        if (rc) return rc;
+        for (int i = 0; i < PLANNER_SLOTS; ++i) {
+            BL_HIP(hipMalloc((void**)&L.pose[i], sizeof(bl_pose_xyt_t)));
+            BL_HIP(hipEventCreateWithFlags(&L.snap_ready[i], hipEventDisableTiming));
+            BL_HIP(hipEventCreateWithFlags(&L.slot_free[i], hipEventDisableTiming));
+        }
     }
     *out = p;
     return BL_OK;
@@ -849,15 +866,19 @@ extern "C" void bl_planner_destroy(bl_planner* p)
 {
     if (!p) return;
     (void)hipStreamSynchronize(p->main->stream);
-    (void)hipStreamSynchronize(p->side->stream);
-    for (int i = 0; i < PLANNER_SLOTS; ++i) {
-        if (p->snap[i]) bl_grid_destroy(p->snap[i]);
-        if (p->pose[i]) (void)hipFree(p->pose[i]);
-        if (p->snap_ready[i]) (void)hipEventDestroy(p->snap_ready[i]);
-        if (p->slot_free[i]) (void)hipEventDestroy(p->slot_free[i]);
+    for (int l = 0; l < p->lanes; ++l) {
+        planner_lane& L = p->lane[l];
+        if (!L.side) continue;
+        (void)hipStreamSynchronize(L.side->stream);
+        for (int i = 0; i < PLANNER_SLOTS; ++i) {
+            if (L.snap[i]) bl_grid_destroy(L.snap[i]);
+            if (L.pose[i]) (void)hipFree(L.pose[i]);
+            if (L.snap_ready[i]) (void)hipEventDestroy(L.snap_ready[i]);
+            if (L.slot_free[i]) (void)hipEventDestroy(L.slot_free[i]);
+        }
+        if (L.dist) bl_dist_destroy(L.dist);
+        bl_ctx_destroy(L.side);
     }
-    bl_dist_destroy(p->dist);
-    bl_ctx_destroy(p->side);
     delete p;
 }
 
@@ -867,35 +888,37 @@ extern "C" int bl_planner_submit(bl_planner* p, const bl_grid* map, const void* 
     BL_CHECK_ARG(p != nullptr && map != nullptr && d_start_pose != nullptr && goal != nullptr && params != nullptr);
     BL_CHECK_ARG(map->ctx == p->main);
     BL_HIP(hipSetDevice(p->main->device));
-    const int slot = (int)(p->submitted % PLANNER_SLOTS);
-    bl_grid*& snap = p->snap[slot];
+    planner_lane& L = p->lane[p->submitted % p->lanes];
+    const int slot = (int)(L.submitted % PLANNER_SLOTS);
+    bl_grid*& snap = L.snap[slot];
     if (snap && (snap->frame.width != map->frame.width || snap->frame.height != map->frame.height)) {
-        BL_HIP(hipStreamSynchronize(p->side->stream));
+        BL_HIP(hipStreamSynchronize(L.side->stream));
         bl_grid_destroy(snap);
         snap = nullptr;
-        p->slot_used[slot] = false;
+        L.slot_used[slot] = false;
     }
     if (!snap) {
-        int rc = bl_grid_create(p->side, map->frame.width, map->frame.height, map->frame.mpc, map->frame.cpm, map->frame.ox,
+        int rc = bl_grid_create(L.side, map->frame.width, map->frame.height, map->frame.mpc, map->frame.cpm, map->frame.ox,
                                 map->frame.oy, &snap);
         if (rc) return rc;
-        BL_HIP(hipStreamSynchronize(p->side->stream));          // its zero-fill ran on the side stream
+        BL_HIP(hipStreamSynchronize(L.side->stream));          // its zero-fill ran on the side stream
     }
     snap->frame = map->frame;
-    // SLAM stream: wait until the planner has finished with this slot, then snapshot map and pose
-    if (p->slot_used[slot]) BL_HIP(hipStreamWaitEvent(p->main->stream, p->slot_free[slot], 0));
+    // SLAM stream: wait until the lane has finished with this slot, then snapshot map and pose
+    if (L.slot_used[slot]) BL_HIP(hipStreamWaitEvent(p->main->stream, L.slot_free[slot], 0));
     BL_HIP(hipMemcpyAsync(snap->cells, map->cells, (size_t)map->frame.width * map->frame.height, hipMemcpyDeviceToDevice,
                           p->main->stream));
-    BL_HIP(hipMemcpyAsync(p->pose[slot], d_start_pose, sizeof(bl_pose_xyt_t), hipMemcpyDeviceToDevice, p->main->stream));
-    BL_HIP(hipEventRecord(p->snap_ready[slot], p->main->stream));
-    // planner stream: distance grid + search on the snapshot
-    BL_HIP(hipStreamWaitEvent(p->side->stream, p->snap_ready[slot], 0));
-    int rc = bl_dist_set_distances(p->dist, snap);
+    BL_HIP(hipMemcpyAsync(L.pose[slot], d_start_pose, sizeof(bl_pose_xyt_t), hipMemcpyDeviceToDevice, p->main->stream));
+    BL_HIP(hipEventRecord(L.snap_ready[slot], p->main->stream));
+    // lane stream: distance grid + search on the snapshot
+    BL_HIP(hipStreamWaitEvent(L.side->stream, L.snap_ready[slot], 0));
+    int rc = bl_dist_set_distances(L.dist, snap);
     if (rc) return rc;
-    rc = astar_launch(p->side, p->dist, nullptr, p->pose[slot], goal, params);
+    rc = astar_launch(L.side, L.dist, nullptr, L.pose[slot], goal, params);
     if (rc) return rc;
-    BL_HIP(hipEventRecord(p->slot_free[slot], p->side->stream));
-    p->slot_used[slot] = true;
+    BL_HIP(hipEventRecord(L.slot_free[slot], L.side->stream));
+    L.slot_used[slot] = true;
+    L.submitted += 1;
     p->submitted += 1;
     return BL_OK;
 }
@@ -903,16 +926,27 @@ extern "C" int bl_planner_submit(bl_planner* p, const bl_grid* map, const void* 
 extern "C" int bl_planner_fetch(bl_planner* p, bl_pose_xyt_t* out_path, int cap, int* out_len, int64_t* stats)
 {
     BL_CHECK_ARG(p != nullptr);
-    return bl_astar_search_result(p->side, out_path, cap, out_len, stats);
+    if (p->fetched == p->submitted) { bl_set_error("no replan pending"); return BL_ERR_STATE; }
+    planner_lane& L = p->lane[p->fetched % p->lanes];          // results come back in submission order
+    int rc = bl_astar_search_result(L.side, out_path, cap, out_len, stats);
+    p->fetched += 1;
+    return rc;
 }
 
 extern "C" int bl_planner_timing(bl_planner* p, int on, double* dist_ms, double* astar_ms, int64_t* launches)
 {
     BL_CHECK_ARG(p != nullptr);
-    if (on >= 0) { int rc = bl_ctx_timing_enable(p->side, on); if (rc) return rc; if (on) return bl_ctx_timing_reset(p->side); }
-    int64_t n = 0;
-    if (dist_ms) { int rc = bl_ctx_timing_get(p->side, BL_K_DIST, dist_ms, &n); if (rc) return rc; }
-    if (astar_ms) { int rc = bl_ctx_timing_get(p->side, BL_K_ASTAR, astar_ms, &n); if (rc) return rc; }
+    double d = 0, a = 0; int64_t n = 0;
+    for (int l = 0; l < p->lanes; ++l) {
+        bl_ctx* c = p->lane[l].side;
+        if (on >= 0) { int rc = bl_ctx_timing_enable(c, on); if (rc) return rc; if (on) { rc = bl_ctx_timing_reset(c); if (rc) return rc; } }
+        double dl = 0, al = 0; int64_t nl = 0;
+        int rc = bl_ctx_timing_get(c, BL_K_DIST, &dl, &nl); if (rc) return rc;
+        rc = bl_ctx_timing_get(c, BL_K_ASTAR, &al, &nl); if (rc) return rc;
+        d += dl; a += al; n += nl;
+    }
+    if (dist_ms) *dist_ms = d;
+    if (astar_ms) *astar_ms = a;
     if (launches) *launches = n;
     return BL_OK;
 }

@@ -179,10 +179,12 @@ int bl_astar_search_result(bl_ctx* ctx, bl_pose_xyt_t* out_path, int cap, int* o
  * The reference's planner is a separate process fed by the maps/poses the SLAM process publishes
  * (src/planning/exploration.cpp:300-317).  bl_planner is the same arrangement on one device: submit() snapshots the
  * map and the (device-resident) pose on the SLAM ctx's stream and runs setDistances + search_for_path on a second
- * stream, overlapping the next scan's particle filter; fetch() returns results in submission order (up to 2 in flight;
- * submit blocks the SLAM stream, not the host, when both snapshot slots are still being read). */
+ * stream, overlapping the next scan's particle filter; fetch() returns results in submission order (up to 2 per lane in
+ * flight; submit blocks the SLAM stream, not the host, while both snapshot slots of the lane are still being read). */
 typedef struct bl_planner bl_planner;
-int bl_planner_create(bl_ctx* ctx, bl_planner** out);
+/* lanes (1..4): consecutive submissions go to consecutive side streams, so up to `lanes` replans run concurrently (each
+ * is one wavefront on its own CU and latency-bound; independent searches are what the GPU can overlap). */
+int bl_planner_create(bl_ctx* ctx, int lanes, bl_planner** out);
 void bl_planner_destroy(bl_planner* p);
 int bl_planner_submit(bl_planner* p, const bl_grid* map, const void* d_start_pose /* bl_pose_xyt_t* on the device */,
                       const bl_pose_xyt_t* goal, const bl_search_params_t* params);

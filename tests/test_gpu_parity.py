@@ -328,7 +328,7 @@ def test_step_pipeline_with_device_pose_equals_host_pose_path(oracle, maps, gpu_
     out = []
     for dev in (False, True, "async"):
         g = _grid_from_map(m, gpu_ctx)
-        aplanner = bl.AsyncPlanner(ctx=gpu_ctx) if dev == "async" else None
+        aplanner = bl.AsyncPlanner(ctx=gpu_ctx, lanes=3) if dev == "async" else None
         lagged = []
         pf = bl.ParticleFilter(2000, ctx=gpu_ctx)
         pf.initializeFilterAtPose(bl.make_pose(-0.75, 0.2, 0.0, utime=int(scans[0].times[0])), seed=5)
@@ -344,13 +344,15 @@ def test_step_pipeline_with_device_pose_equals_host_pose_path(oracle, maps, gpu_
                 mapper.updateMapDevicePose(sc, pf.poseDevicePtr(), sc.utime, g)
                 aplanner.submit(g, pf.poseDevicePtr(), goal)
                 lagged.append(k)
-                if len(lagged) > 1:
+                if len(lagged) > 3:
                     lagged.pop(0)
                     path = aplanner.fetch()
                     rec.append(((path[0].utime, path[0].x, path[0].y, path[0].theta), [(p.x, p.y, p.theta) for p in path]))
                 if k == len(scans) - 1:
-                    path = aplanner.fetch()
-                    rec.append(((path[0].utime, path[0].x, path[0].y, path[0].theta), [(p.x, p.y, p.theta) for p in path]))
+                    while lagged:
+                        lagged.pop(0)
+                        path = aplanner.fetch()
+                        rec.append(((path[0].utime, path[0].x, path[0].y, path[0].theta), [(p.x, p.y, p.theta) for p in path]))
                 continue
             elif dev:
                 pf.updateFilter(odo, sc, g, rand_value=1000 + k, want_pose=False)
