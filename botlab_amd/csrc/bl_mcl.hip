@@ -24,6 +24,9 @@
 
 #include "bl_internal.h"
 
+#ifndef MCL_RAY_UNROLL
+#define MCL_RAY_UNROLL 2
+#endif
 #define MCL_BLOCK 1024                        // largest workgroup of k_mcl_main
 #define MCL_MIN_BLOCKS 512                    // split rays over lanes until the launch has at least this many workgroups (2 per CU)
 #define MCL_WIN_SMALL_BYTES (64 * 1024)       // whole-grid staging budget (200x200 int8 = 40 KB -> two workgroups per CU)
@@ -52,6 +55,9 @@ struct bl_pf {
     double* partials;         // [blocks][5]
     int partials_cap;
     bool use_lds;
+    int last_blocks, last_tile;   // launch shape of the last k_mcl_main
+    bool fused_finish, no_fused_finish;
+    unsigned long long* tile_offsets; // [partials_cap]
     int split_log2_override;  // -1: automatic
     int block_override;       // 0: automatic
     bool debug;               // record resample index / likelihood per particle (parity tests)
@@ -97,11 +103,13 @@ template <int MAP_MODE>
 __device__ __forceinline__ int grid_odds(const int8_t* __restrict__ cells, const lds_i8_t* s_map, const map_window& win,
                                          const bl_frame& f, int x, int y)
 {
-    const bool in = (unsigned int)x < (unsigned int)f.width && (unsigned int)y < (unsigned int)f.height;
     if (MAP_MODE == 1) {
-        const int v = s_map[in ? y * win.stride + x : 0];
-        return in ? v : 0;
+        // whole grid staged with a zero frame (one row above/below, four columns left, >= four right): clamping the cell
+        // to the frame replaces the bounds test, the index select and the result mask
+        const int cx = min(max(x, -1), f.width), cy = min(max(y, -1), f.height);
+        return s_map[(cy + 1) * win.stride + cx + 4];
     }
+    const bool in = (unsigned int)x < (unsigned int)f.width && (unsigned int)y < (unsigned int)f.height;
     if (MAP_MODE == 0) {
         const int v = cells[in ? (size_t)y * f.width + x : (size_t)0];
         return in ? v : 0;
@@ -219,21 +227,42 @@ __global__ __launch_bounds__(BLOCK) void k_mcl_main(mcl_args a)
         }
         __syncthreads();
         win = s_win;
-        const int wq = win.stride >> 2;                       // dwords per staged row
         int* s_map32 = (int*)s_dyn;
-        const bool aligned = ((a.frame.width & 3) == 0) && ((win.x0 & 3) == 0);
-        for (int i = threadIdx.x; i < wq * win.h; i += BLOCK) {
-            const int ry = i / wq, q = i - ry * wq;
-            const size_t g = (size_t)(win.y0 + ry) * a.frame.width + win.x0 + 4 * q;
-            int v;
-            if (aligned && win.x0 + 4 * q + 3 < a.frame.width) {
-                v = *(const int*)(a.cells + g);
-            } else {
-                v = 0;
-                for (int b = 0; b < 4; ++b)
-                    if (win.x0 + 4 * q + b < a.frame.width) v |= ((int)(unsigned char)a.cells[g + b]) << (8 * b);
+        if (MAP_MODE == 1) {
+            // framed image: rows -1..H, columns -4..stride-5 (zeros outside the grid)
+            const int stride = ((a.frame.width + 3) & ~3) + 8;
+            win.stride = stride;
+            const int wq = stride >> 2;
+            const bool aligned = (a.frame.width & 3) == 0;
+            for (int i = threadIdx.x; i < wq * (a.frame.height + 2); i += BLOCK) {
+                const int ry = i / wq, q = i - ry * wq;
+                const int y = ry - 1, x = 4 * q - 4;
+                int v = 0;
+                if (y >= 0 && y < a.frame.height && x >= 0 && x < a.frame.width) {
+                    const size_t g = (size_t)y * a.frame.width + x;
+                    if (aligned) v = *(const int*)(a.cells + g);
+                    else
+                        for (int b = 0; b < 4; ++b)
+                            if (x + b < a.frame.width) v |= ((int)(unsigned char)a.cells[g + b]) << (8 * b);
+                }
+                s_map32[i] = v;
             }
-            s_map32[i] = v;
+        } else {
+            const int wq = win.stride >> 2;                       // dwords per staged row
+            const bool aligned = ((a.frame.width & 3) == 0) && ((win.x0 & 3) == 0);
+            for (int i = threadIdx.x; i < wq * win.h; i += BLOCK) {
+                const int ry = i / wq, q = i - ry * wq;
+                const size_t g = (size_t)(win.y0 + ry) * a.frame.width + win.x0 + 4 * q;
+                int v;
+                if (aligned && win.x0 + 4 * q + 3 < a.frame.width) {
+                    v = *(const int*)(a.cells + g);
+                } else {
+                    v = 0;
+                    for (int b = 0; b < 4; ++b)
+                        if (win.x0 + 4 * q + b < a.frame.width) v |= ((int)(unsigned char)a.cells[g + b]) << (8 * b);
+                }
+                s_map32[i] = v;
+            }
         }
         __syncthreads();
     }
@@ -284,6 +313,9 @@ __global__ __launch_bounds__(BLOCK) void k_mcl_main(mcl_args a)
             float sx0, sy0;
             bl_global_to_grid(px, py, a.frame, &sx0, &sy0);
             const int isx0 = (int)sx0, isy0 = (int)sy0;
+            // two rays per trip: their sincos polynomial chains (dependent FP64 fma) are independent, which is what the
+            // scheduler needs to fill the issue slots a single chain leaves empty
+#pragma unroll MCL_RAY_UNROLL
             for (int n = sub; n < a.R; n += split) {        // the host uploads only rays with range > 0.15f (moving_laser_scan.cpp:24)
                 const float range = a.ranges[n];
                 float theta, sx, sy;
@@ -434,6 +466,91 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan_write_prefix(const float4
         if (base + k < N) prefix[base + k] = off0 + loc[k];
 }
 
+// Single-shard fast path (the whole particle set on this device): k_mcl_main's per-workgroup partials already hold the
+// weight-unit sum of each workgroup's particles, i.e. the tile sums of a prefix scan whose tile is "particles per
+// k_mcl_main workgroup".  k_mcl_finish (one workgroup) reduces the five partial sums in a fixed order, scans the tile
+// sums and forms the pose estimate; k_scan_write_prefix_tile writes the prefix.  Two launches instead of five.
+__global__ __launch_bounds__(1024) void k_mcl_finish(const double* __restrict__ partials, int nblocks,
+                                                     unsigned long long* __restrict__ tile_offsets, double* __restrict__ sums,
+                                                     pf_state* state, int64_t utime)
+{
+    __shared__ double s_red[1024 / 64][5];
+    __shared__ unsigned long long s_wave[16];
+    __shared__ unsigned long long s_carry;
+    // ---- five sums, fixed order: thread-strided partial sums, then wave shuffles, then 16 wave results in order
+    double v[5] = {0, 0, 0, 0, 0};
+    for (int b = threadIdx.x; b < nblocks; b += 1024)
+        for (int k = 0; k < 5; ++k) v[k] += partials[(size_t)b * 5 + k];
+    for (int k = 0; k < 5; ++k) v[k] = wave_sum(v[k]);
+    if ((threadIdx.x & 63) == 0) for (int k = 0; k < 5; ++k) s_red[threadIdx.x >> 6][k] = v[k];
+    if (threadIdx.x == 0) s_carry = 0;
+    __syncthreads();
+    double tot[5] = {0, 0, 0, 0, 0};
+    if (threadIdx.x == 0) {
+        for (int w = 0; w < 16; ++w) for (int k = 0; k < 5; ++k) tot[k] += s_red[w][k];
+        for (int k = 0; k < 5; ++k) sums[k] = tot[k];
+        sums[5] = sums[6] = sums[7] = 0.0;
+    }
+    // ---- exclusive scan of the tile sums (partials[b][0] is an exact integer below 2^53)
+    for (int base = 0; base < nblocks; base += 1024) {
+        int idx = base + threadIdx.x;
+        unsigned long long t = idx < nblocks ? (unsigned long long)partials[(size_t)idx * 5] : 0ull;
+        unsigned long long incl = t;
+        for (int off = 1; off < 64; off <<= 1) {
+            unsigned long long u = __shfl_up(incl, off, 64);
+            if ((threadIdx.x & 63) >= off) incl += u;
+        }
+        if ((threadIdx.x & 63) == 63) s_wave[threadIdx.x >> 6] = incl;
+        __syncthreads();
+        unsigned long long wave_off = 0;
+        for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) wave_off += s_wave[w];
+        unsigned long long carry = s_carry;
+        if (idx < nblocks) tile_offsets[idx] = carry + wave_off + incl - t;
+        __syncthreads();
+        if (threadIdx.x == 1023) s_carry = carry + wave_off + incl;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        state->S = (double)s_carry;
+        bl_pose_xyt_t p;
+        p.utime = utime;
+        p.x = (float)(tot[1] / tot[0]);
+        p.y = (float)(tot[2] / tot[0]);
+        p.theta = (float)atan2(tot[3], tot[4]);
+        state->pose = p;
+        for (int k = 0; k < 5; ++k) state->sums_used[k] = tot[k];
+    }
+}
+
+// tile = particles per tile (<= 2048); one workgroup of 256 threads per tile
+__global__ __launch_bounds__(SCAN_THREADS) void k_scan_write_prefix_tile(const float4* __restrict__ rec, int N, int tile,
+                                                                         const unsigned long long* __restrict__ tile_offsets,
+                                                                         unsigned long long* __restrict__ prefix)
+{
+    __shared__ unsigned long long s_wave[SCAN_THREADS / 64];
+    const int ipt = (tile + SCAN_THREADS - 1) / SCAN_THREADS;                 // items per thread (<= 8)
+    const int tile_lo = blockIdx.x * tile;
+    const int tile_hi = min(N, tile_lo + tile);
+    const int base = tile_lo + threadIdx.x * ipt;
+    unsigned long long loc[SCAN_ITEMS];
+    unsigned long long run = 0;
+    for (int k = 0; k < SCAN_ITEMS; ++k) {
+        if (k < ipt && base + k < tile_hi) run += __float_as_uint(rec[base + k].w);
+        loc[k] = run;
+    }
+    unsigned long long incl = run;
+    for (int off = 1; off < 64; off <<= 1) {
+        unsigned long long t = __shfl_up(incl, off, 64);
+        if ((threadIdx.x & 63) >= off) incl += t;
+    }
+    if ((threadIdx.x & 63) == 63) s_wave[threadIdx.x >> 6] = incl;
+    __syncthreads();
+    unsigned long long off0 = tile_offsets[blockIdx.x] + incl - run;
+    for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) off0 += s_wave[w];
+    for (int k = 0; k < SCAN_ITEMS; ++k)
+        if (k < ipt && base + k < tile_hi) prefix[base + k] = off0 + loc[k];
+}
+
 // ---------------------------------------------------------------- init / export / small state kernels
 __global__ void k_pf_init(float4* rec, float4* parent, int N, int lo, int n_local, bl_pose_xyt_t pose, uint32_t k0, uint32_t k1)
 {
@@ -486,6 +603,7 @@ static int pf_alloc(bl_pf* pf)
     int blocks = (int)((n * 64 + 255) / 256) + 1;          // worst case: every particle spread over a whole wave, 256-thread blocks
     BL_HIP(hipMalloc((void**)&pf->partials, (size_t)blocks * 5 * sizeof(double)));
     pf->partials_cap = blocks;
+    BL_HIP(hipMalloc((void**)&pf->tile_offsets, (size_t)blocks * sizeof(unsigned long long)));
     static bool attr_set = false;
     if (!attr_set) {
         const int big = MCL_WIN_BIG * MCL_WIN_BIG;
@@ -515,6 +633,7 @@ extern "C" int bl_pf_create(bl_ctx* ctx, int num_particles, int shard_lo, int sh
     pf->N = num_particles; pf->lo = shard_lo; pf->hi = shard_hi; pf->n_local = shard_hi - shard_lo;
     pf->noise_seed = 0x243F6A8885A308D3ull;
     pf->use_lds = getenv("BOTLAB_MCL_NO_LDS") == nullptr;
+    pf->no_fused_finish = getenv("BOTLAB_MCL_NO_FUSED_FINISH") != nullptr;
     pf->split_log2_override = getenv("BOTLAB_MCL_SPLIT_LOG2") ? atoi(getenv("BOTLAB_MCL_SPLIT_LOG2")) : -1;
     if (pf->split_log2_override > 6) pf->split_log2_override = 6;
     pf->block_override = getenv("BOTLAB_MCL_BLOCK") ? atoi(getenv("BOTLAB_MCL_BLOCK")) : 0;
@@ -529,7 +648,7 @@ extern "C" void bl_pf_destroy(bl_pf* pf)
     (void)hipStreamSynchronize(pf->ctx->stream);
     if (!pf->rec_external) { if (pf->rec[0]) (void)hipFree(pf->rec[0]); if (pf->rec[1]) (void)hipFree(pf->rec[1]); }
     if (!pf->sums_external && pf->sums) (void)hipFree(pf->sums);
-    void* ptrs[] = {pf->prefix, pf->parent, pf->state, pf->partials, pf->block_sums, pf->dbg_idx, pf->dbg_like,
+    void* ptrs[] = {pf->prefix, pf->parent, pf->state, pf->partials, pf->tile_offsets, pf->block_sums, pf->dbg_idx, pf->dbg_like,
                     pf->d_noise, pf->d_export};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     bl_scan_free(&pf->scan);
@@ -704,7 +823,7 @@ static int pf_launch_main(bl_pf* pf, const bl_grid* map, int R, int rand_value, 
     int lds_bytes = 0, mode = 0;
     a.win_w = 0; a.win_h = 0;
     if (map && pf->use_lds) {
-        const size_t whole = (size_t)((map->frame.width + 3) & ~3) * map->frame.height;
+        const size_t whole = (size_t)(((map->frame.width + 3) & ~3) + 8) * (map->frame.height + 2);      // framed image
         if (whole <= MCL_WIN_SMALL_BYTES) {
             a.win_w = map->frame.width; a.win_h = map->frame.height;
             lds_bytes = (int)whole;
@@ -751,9 +870,29 @@ static int pf_launch_main(bl_pf* pf, const bl_grid* map, int R, int rand_value, 
     BL_HIP(hipGetLastError());
     rc = bl_timer_end(ctx, BL_K_MCL_MAIN, e0, e1);
     if (rc) return rc;
-    hipLaunchKernelGGL(k_mcl_reduce, dim3(1), dim3(256), 0, ctx->stream, pf->partials, blocks, pf->sums);
-    BL_HIP(hipGetLastError());
+    pf->last_blocks = blocks;
+    pf->last_tile = block >> a.split_log2;               // particles per k_mcl_main workgroup
+    pf->fused_finish = (pf->n_local == pf->N) && pf->last_tile >= 1 && pf->last_tile <= SCAN_TILE && !pf->no_fused_finish;
+    if (!pf->fused_finish) {
+        hipLaunchKernelGGL(k_mcl_reduce, dim3(1), dim3(256), 0, ctx->stream, pf->partials, blocks, pf->sums);
+        BL_HIP(hipGetLastError());
+    }
     return BL_OK;
+}
+
+// single-shard finish of an update: reduce + tile scan + estimate, then the prefix (timed as BL_K_MCL_SCAN)
+static int pf_finish_fused(bl_pf* pf, int which, int64_t utime)
+{
+    bl_ctx* ctx = pf->ctx;
+    hipEvent_t e0, e1;
+    int rc = bl_timer_begin(ctx, BL_K_MCL_SCAN, &e0, &e1);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_mcl_finish, dim3(1), dim3(1024), 0, ctx->stream, pf->partials, pf->last_blocks, pf->tile_offsets,
+                       pf->sums, pf->state, utime);
+    hipLaunchKernelGGL(k_scan_write_prefix_tile, dim3(pf->last_blocks), dim3(SCAN_THREADS), 0, ctx->stream, pf->rec[which], pf->N,
+                       pf->last_tile, pf->tile_offsets, pf->prefix);
+    BL_HIP(hipGetLastError());
+    return bl_timer_end(ctx, BL_K_MCL_SCAN, e0, e1);
 }
 
 extern "C" int bl_pf_update_begin(bl_pf* pf, const bl_pose_xyt_t* odometry, const bl_lidar_t* scan, const bl_grid* map,
@@ -788,7 +927,8 @@ extern "C" int bl_pf_update_end(bl_pf* pf, bl_pose_xyt_t* out_pose)
     BL_CHECK_ARG(pf != nullptr);
     BL_HIP(hipSetDevice(pf->ctx->device));
     if (pf->pending_end) {
-        int rc = pf_scan(pf, pf->cur ^ 1, 1, pf->pending_utime);
+        int rc = pf->fused_finish ? pf_finish_fused(pf, pf->cur ^ 1, pf->pending_utime)
+                                  : pf_scan(pf, pf->cur ^ 1, 1, pf->pending_utime);
         if (rc) return rc;
         pf->cur ^= 1;
         pf->parent_utime = pf->pose_utime;       // parent_pose = sample.pose (action_model.cpp:92)
@@ -820,6 +960,7 @@ extern "C" int bl_pf_update_action_only(bl_pf* pf, const bl_pose_xyt_t* odometry
         if (noise) { int rc = pf_upload_noise(pf, noise); if (rc) return rc; }
         int rc = pf_launch_main(pf, nullptr, 0, 0, noise, 0);     // proposal = applyAction(posterior_) (particle_filter.cpp:60-61)
         if (rc) return rc;
+        pf->fused_finish = false;                                 // weights are carried over: plain scan, no estimate
         rc = pf_scan(pf, pf->cur ^ 1, 0, 0);
         if (rc) return rc;
         pf->cur ^= 1;
