@@ -1,0 +1,101 @@
+"""Full-size checks (BASELINE.json configs) through size-independent properties, where the CPU oracle would take
+minutes: 100k / 1M particles, 2000x2000 and 4096x4096 grids."""
+import numpy as np
+import pytest
+
+import helpers
+import botlab_amd as bl
+from botlab_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _world(maps, size):
+    world = synth.tile_world(maps["astar_maze"]["cells"], size)
+    half = size * 0.05 / 2.0
+    return world, (np.float32(-half), np.float32(-half))
+
+
+@pytest.mark.parametrize("N", [100_000, 1_000_000])
+def test_mcl_full_size_invariants(maps, gpu_ctx, N):
+    m = maps["obstacle_slam_10mx10m_5cm"]
+    truth = np.where(m["cells"] > 0, 127, -127).astype(np.int8)
+    g = bl.OccupancyGrid.from_cells(m["cells"], m["origin"], m["mpc"], cellsPerMeter=helpers.CPM_DEFAULT, ctx=gpu_ctx)
+    pf = bl.ParticleFilter(N, ctx=gpu_ctx)
+    pf.debugEnable(True)
+    pf.initializeFilterAtPose(bl.make_pose(-0.75, 0.2, 0.0, utime=1000), seed=11)
+    poses = synth.square_trajectory((-0.75, 0.2, 0.0), 4, step_len=0.02, turn=0.05, side=0.8)
+    prev = pf.particles()
+    for k in range(1, len(poses)):
+        scan = synth.raycast_scan(truth, m["origin"], 0.05, poses[k - 1], poses[k], 1000 + 100000 * k)
+        est = pf.updateFilter(bl.make_pose(*poses[k], utime=scan.utime), scan, g, rand_value=4242 + k)
+        if k == 1:
+            continue                                   # first call latches the odometry (robot "did not move")
+        idx, like = pf.debugLast()
+        cur = pf.particles()
+        # low-variance resampling: source indices are non-decreasing, in range, and parents are the sources' poses
+        assert idx.min() >= 0 and idx.max() < N and np.all(np.diff(idx) >= 0)
+        assert np.array_equal(cur["p_x"], prev["x"][idx]) and np.array_equal(cur["p_theta"], prev["theta"][idx])
+        # weights: positive, normalised, proportional to max(likelihood, 0.001)
+        w = cur["weight"]
+        assert (w > 0).all() and abs(w.sum() - 1.0) < 1e-9
+        raw = np.maximum(like * 0.5, 0.001)
+        assert np.allclose(w, raw / raw.sum(), rtol=1e-12)
+        # the estimate is the weighted mean (float32 result of a double reduction)
+        assert abs(est.x - np.sum(w * cur["x"].astype(np.float64))) < 2e-6
+        assert abs(est.y - np.sum(w * cur["y"].astype(np.float64))) < 2e-6
+        assert abs(est.x - poses[k][0]) < 0.05 and abs(est.y - poses[k][1]) < 0.05
+        prev = cur
+
+
+@pytest.mark.parametrize("size", [2000, 4096])
+def test_distance_grid_full_size_properties(maps, gpu_ctx, size):
+    world, origin = _world(maps, size)
+    g = bl.OccupancyGrid.from_cells(world, origin, 0.05, ctx=gpu_ctx)
+    d = bl.ObstacleDistanceGrid(ctx=gpu_ctx)
+    d.setDistances(g)
+    dist = d.cells()
+    # f[n] table (obstacle_distance_grid.cpp:174): every value is one of f[0..W+H]
+    f = np.zeros(2 * size + 1, np.float32)
+    for i in range(1, f.size):
+        f[i] = np.float32(f[i - 1] + np.float32(0.1))
+    n = np.searchsorted(f, dist)
+    assert np.array_equal(f[n], dist)
+    # zero exactly on the non-free cells; neighbours differ by at most one step of the integer transform
+    assert np.array_equal(dist == 0, world >= 0)
+    assert np.abs(np.diff(n.astype(np.int64), axis=0)).max() <= 1 and np.abs(np.diff(n.astype(np.int64), axis=1)).max() <= 1
+    # every free cell has a neighbour one step closer (it is a true distance, not just 1-Lipschitz)
+    ni = n.astype(np.int64)
+    pad = np.pad(ni, 1, constant_values=10**9)
+    nb_min = np.minimum(np.minimum(pad[:-2, 1:-1], pad[2:, 1:-1]), np.minimum(pad[1:-1, :-2], pad[1:-1, 2:]))
+    free = ni > 0
+    assert np.array_equal(nb_min[free] + 1, ni[free])
+
+
+def test_astar_on_2000x2000_maze_path_is_valid(maps, gpu_ctx):
+    world, origin = _world(maps, 2000)
+    g = bl.OccupancyGrid.from_cells(world, origin, 0.05, ctx=gpu_ctx)
+    planner = bl.MotionPlanner(bl.MotionPlannerParams(0.1), ctx=gpu_ctx)
+    planner.setMap(g)
+    dist = planner.distances_.cells()
+    ys, xs = np.nonzero(dist > 0.25)
+    c0 = np.argmin(np.abs(xs - 1000) + np.abs(ys - 1000))
+    near = np.nonzero((np.abs(xs - xs[c0]) + np.abs(ys - ys[c0]) < 25) & (np.abs(xs - xs[c0]) + np.abs(ys - ys[c0]) > 8))[0]
+    assert near.size > 0
+    found = 0
+    for c1 in near[:: max(1, near.size // 6)][:6]:
+        sp = (float(origin[0]) + (xs[c0] + 0.5) * 0.05, float(origin[1]) + (ys[c0] + 0.5) * 0.05)
+        gp = (float(origin[0]) + (xs[c1] + 0.5) * 0.05, float(origin[1]) + (ys[c1] + 0.5) * 0.05)
+        path, stats = bl.search_for_path(bl.make_pose(*sp, 0.0), bl.make_pose(*gp, 0.0), planner.distances_,
+                                         planner.searchParams_, return_stats=True)
+        if len(path) == 1:
+            continue
+        found += 1
+        cells = [(int(round((p.x - float(origin[0])) / 0.05)), int(round((p.y - float(origin[1])) / 0.05))) for p in path[1:]]
+        assert cells[-1] == (xs[c1], ys[c1])
+        full = [(xs[c0], ys[c0])] + cells
+        for a, b in zip(full[:-1], full[1:]):
+            assert abs(a[0] - b[0]) + abs(a[1] - b[1]) == 1                 # 4-connected steps
+        for cx, cy in cells:
+            assert dist[cy, cx] > 0.1 * 1.000001                             # every cell is valid (astar.cpp:141)
+    assert found >= 1
