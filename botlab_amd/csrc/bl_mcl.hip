@@ -132,8 +132,10 @@ __device__ __forceinline__ int score_ray_half_units(const int8_t* __restrict__ c
     const float tx = range * cs * f.cpm, ty = range * sn * f.cpm;
     const int ex = (int)(tx + sx);
     const int ey = (int)(ty + sy);
-    const int xx = (int)((2 * range * cs * f.cpm) + sx);
-    const int xy = (int)((2 * range * sn * f.cpm) + sy);
+    // (2 * range * cos) * cpm == 2 * ((range * cos) * cpm) bit for bit: scaling by two is exact and commutes with
+    // rounding for normal floats (range > 0.15 and |cos| >= 4e-8 keep every product far from the subnormal range)
+    const int xx = (int)((2.0f * tx) + sx);
+    const int xy = (int)((2.0f * ty) + sy);
     int ax, ay, bx, by;
     bl_bresenham_first_step(ex, ey, isx, isy, &ax, &ay);
     bl_bresenham_first_step(ex, ey, xx, xy, &bx, &by);
