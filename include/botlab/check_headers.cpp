@@ -31,3 +31,17 @@ void touch()
     d.setDistances(g);
     (void)d(0, 0);
 }
+
+// slam_driver.hpp (row f2)
+#include <botlab/slam_driver.hpp>
+struct odometry_t { int64_t utime = 0; float x = 0, y = 0, theta = 0; };
+typedef botlab_hip::OccupancyGridSLAMT<pose_xyt_t, lidar_t, odometry_t, particle_t, particles_t, occupancy_grid_t> OccupancyGridSLAM;
+void touch_driver()
+{
+    OccupancyGridSLAM::Publisher pub;
+    OccupancyGridSLAM slam(200, 4, 1, pub, false, false, false, "");
+    lidar_t scan; odometry_t odo; pose_xyt_t p;
+    slam.handleOdometry(odo); slam.handlePose(p); slam.handleOptitrack(p); slam.handleLaser(scan);
+    if (slam.isReadyToUpdate()) slam.runSLAMIteration();
+    botlab_hip::PoseTraceT<pose_xyt_t> t; t.addPose(p); (void)t.poseAt(0); t.setReferencePose(p); (void)t.eraseTraceUntil(0);
+}

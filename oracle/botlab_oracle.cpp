@@ -33,6 +33,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <deque>
 #include <functional>
 #include <limits>
 #include <queue>
@@ -567,6 +568,164 @@ std::vector<orc_pose_t> search_for_path(orc_pose_t start, orc_pose_t goal, const
     return path;   // D5
 }
 
+// ---------------------------------------------------------------- src/common/pose_trace.cpp
+struct PoseTrace {
+    std::vector<orc_pose_t> trace;
+    orc_pose_t frameTransform;
+    PoseTrace() { std::memset(&frameTransform, 0, sizeof(frameTransform)); }          // :11-16
+    static orc_pose_t apply_frame_transform(const orc_pose_t& pose, const orc_pose_t& t)   // :117-128
+    {
+        orc_pose_t n;
+        n.utime = pose.utime;
+        n.x = (pose.x * std::cos(t.theta) - pose.y * std::sin(t.theta)) + t.x;
+        n.y = (pose.x * std::sin(t.theta) + pose.y * std::cos(t.theta)) + t.y;
+        n.theta = wrap_to_pi(pose.theta + t.theta);
+        return n;
+    }
+    void addPose(const orc_pose_t& p) { trace.push_back(apply_frame_transform(p, frameTransform)); }   // :19-22
+    int eraseTraceUntil(int64_t time)                                                                   // :25-35
+    {
+        auto it = std::remove_if(trace.begin(), trace.end(), [time](const orc_pose_t& p) { return p.utime < time; });
+        int n = std::distance(it, trace.end());
+        trace.erase(it, trace.end());
+        return n;
+    }
+    orc_pose_t poseAt(int64_t time) const                                                                // :38-68
+    {
+        orc_pose_t zero; std::memset(&zero, 0, sizeof(zero));
+        if (trace.empty()) return zero;
+        else if (time < trace.front().utime) return trace.front();
+        else if (time > trace.back().utime) return trace.back();
+        orc_pose_t interpolated = zero;
+        for (std::size_t i = 1; i < trace.size(); ++i) {
+            if ((trace[i - 1].utime <= time) && (time <= trace[i].utime)) {
+                interpolated = interpolate_pose_by_time(time, trace[i - 1], trace[i]);
+                break;
+            }
+        }
+        return interpolated;
+    }
+    bool containsPoseAtTime(int64_t time) const                                                          // :71-79
+    {
+        if (trace.empty()) return false;
+        return (trace.front().utime <= time) && (time <= trace.back().utime);
+    }
+    void setReferencePose(const orc_pose_t& ref)                                                         // :82-114
+    {
+        orc_pose_t initialPose; std::memset(&initialPose, 0, sizeof(initialPose));
+        if (!trace.empty()) { initialPose.x = trace.front().x; initialPose.y = trace.front().y; initialPose.theta = trace.front().theta; }
+        double deltaTheta = ref.theta - initialPose.theta;
+        double xRotated = initialPose.x * std::cos(deltaTheta) - initialPose.y * std::sin(deltaTheta);
+        double yRotated = initialPose.x * std::sin(deltaTheta) + initialPose.y * std::cos(deltaTheta);
+        frameTransform.x = ref.x - xRotated;
+        frameTransform.y = ref.y - yRotated;
+        frameTransform.theta = deltaTheta;
+        for (auto& p : trace) p = apply_frame_transform(p, frameTransform);
+    }
+};
+
+// ---------------------------------------------------------------- src/slam/slam.cpp (LCM replaced by direct calls)
+struct OwnedScan { int64_t utime; std::vector<float> ranges, thetas; std::vector<int64_t> times; };
+struct SlamDriver {
+    enum Mode { mapping_only, localization_only, action_only, full_slam } mode;
+    std::deque<OwnedScan> incoming;
+    PoseTrace groundTruth, odometry;
+    OwnedScan currentScan;
+    orc_pose_t currentOdometry, initialPose, previousPose, currentPose;
+    bool haveInitializedPoses, waitingForOptitrack, haveMap;
+    int numIgnoredScans;
+    ParticleFilter filter;
+    std::vector<int8_t> cells;
+    orc_grid_t map;
+    Mapping mapper;
+    int mapUpdateCount;
+    int publishedPoses, publishedMaps;
+    uint32_t initSeed;
+
+    SlamDriver(int numParticles, int8_t hit, int8_t miss, bool waitOpti, bool mappingOnly, bool actionOnly,
+               const orc_grid_t* locMap)                                                                 // :9-67
+        : mode(full_slam), haveInitializedPoses(false), waitingForOptitrack(waitOpti), haveMap(false), numIgnoredScans(0),
+          filter(numParticles), mapUpdateCount(0), publishedPoses(0), publishedMaps(0), initSeed(1)
+    {
+        // map_(10.0f, 10.0f, 0.05f): occupancy_grid.cpp:19-36
+        float mpc = 0.05f, cpm = 1.0f / mpc;
+        map.width = 10.0f * cpm; map.height = 10.0f * cpm; map.meters_per_cell = mpc; map.cells_per_meter = cpm;
+        map.origin_x = -10.0f / 2.0f; map.origin_y = -10.0f / 2.0f;
+        cells.assign(static_cast<size_t>(map.width) * map.height, 0);
+        mapper.maxLaser = 5.0f; mapper.hit = hit; mapper.miss = miss; mapper.initialized = false;
+        std::memset(&mapper.prev, 0, sizeof(mapper.prev));
+        if (mappingOnly) mode = mapping_only;
+        else if (locMap) {
+            map = *locMap;                                   // loadFromFile keeps cellsPerMeter_ (caller passes both)
+            cells.assign(locMap->cells, locMap->cells + static_cast<size_t>(locMap->width) * locMap->height);
+            haveMap = true;
+            mode = actionOnly ? action_only : localization_only;
+        }
+        map.cells = cells.data();
+        std::memset(&currentOdometry, 0, sizeof(orc_pose_t)); std::memset(&initialPose, 0, sizeof(orc_pose_t));
+        std::memset(&previousPose, 0, sizeof(orc_pose_t)); std::memset(&currentPose, 0, sizeof(orc_pose_t));
+        currentScan.utime = 0;
+    }
+    void handleLaser(const OwnedScan& scan)                                                              // :90-127
+    {
+        bool haveOdom = (mode != mapping_only) && !odometry.trace.empty() && (odometry.trace.front().utime <= scan.times.front());
+        bool havePose = (mode == mapping_only) && !groundTruth.trace.empty() && (groundTruth.trace.front().utime <= scan.times.front());
+        if (haveOdom || havePose) { incoming.push_back(scan); if (numIgnoredScans >= 10) numIgnoredScans = 0; }
+        else ++numIgnoredScans;
+    }
+    bool isReady() const                                                                                 // :163-188
+    {
+        bool haveData = false;
+        if (!incoming.empty()) {
+            const OwnedScan& next = incoming.front();
+            bool haveNewOdom = (mode != mapping_only) && odometry.containsPoseAtTime(next.times.front());
+            bool haveNewPose = (mode == mapping_only) && groundTruth.containsPoseAtTime(next.times.front());
+            haveData = haveNewOdom || haveNewPose;
+        }
+        return haveData && !waitingForOptitrack;
+    }
+    void iterate(int rand_value)                                                                         // :191-294
+    {
+        currentScan = incoming.front();
+        incoming.pop_front();
+        if (mode == mapping_only) { previousPose = currentPose; currentPose = groundTruth.poseAt(currentScan.times.back()); }
+        else currentOdometry = odometry.poseAt(currentScan.times.back());
+        if (!haveInitializedPoses) {
+            previousPose = initialPose; previousPose.utime = currentScan.times.front();
+            currentPose = previousPose; currentPose.utime = currentScan.times.back();
+            haveInitializedPoses = true;
+            // initializeFilterAtPose with a caller-seeded generator (reference: random_device) and D2
+            double sampleWeight = 1.0 / filter.N;
+            filter.posteriorPose = previousPose;
+            std::mt19937 generator(initSeed);
+            std::normal_distribution<> dist(0.0, 0.01);
+            for (auto& p : filter.posterior) {
+                p.pose.x = previousPose.x + dist(generator);
+                p.pose.y = previousPose.y + dist(generator);
+                p.pose.theta = wrap_to_pi(previousPose.theta + dist(generator));
+                p.pose.utime = previousPose.utime;
+                p.parent_pose = p.pose;
+                p.weight = sampleWeight;
+            }
+            filter.posterior.back().pose = previousPose;
+        }
+        orc_lidar_t view; view.utime = currentScan.utime; view.num_ranges = static_cast<int32_t>(currentScan.ranges.size());
+        view.ranges = currentScan.ranges.data(); view.thetas = currentScan.thetas.data(); view.times = currentScan.times.data();
+        if (view.num_ranges > 100) {
+            if (haveMap && mode != mapping_only) {
+                previousPose = currentPose;
+                if (mode == action_only) currentPose = filter.update_action_only(currentOdometry, 0, nullptr);
+                else currentPose = filter.update(currentOdometry, view, map, rand_value, 0, nullptr, nullptr, nullptr);
+                ++publishedPoses;
+            }
+            mapper.update(view, currentPose, map);
+            haveMap = true;
+            if (mapUpdateCount % 5 == 0) ++publishedMaps;
+            ++mapUpdateCount;
+        }
+    }
+};
+
 }  // namespace
 
 // =============================================================================================== C API
@@ -698,6 +857,53 @@ int orc_is_valid_goal(const orc_pose_t* goal, const orc_dist_t* d, double robotR
     int gy = static_cast<int>((static_cast<double>(goal->y) - d->origin_y) * d->cells_per_meter);
     if (dist_in_grid(*d, gx, gy)) return d->cells[gy * d->width + gx] > robotRadius;
     return 0;
+}
+
+// ---- PoseTrace
+void* orc_trace_create(void) { return new PoseTrace(); }
+void orc_trace_destroy(void* t) { delete static_cast<PoseTrace*>(t); }
+void orc_trace_add(void* t, const orc_pose_t* p) { static_cast<PoseTrace*>(t)->addPose(*p); }
+int orc_trace_erase_until(void* t, int64_t time) { return static_cast<PoseTrace*>(t)->eraseTraceUntil(time); }
+void orc_trace_pose_at(void* t, int64_t time, orc_pose_t* out) { *out = static_cast<PoseTrace*>(t)->poseAt(time); }
+int orc_trace_contains(void* t, int64_t time) { return static_cast<PoseTrace*>(t)->containsPoseAtTime(time) ? 1 : 0; }
+void orc_trace_set_reference(void* t, const orc_pose_t* ref) { static_cast<PoseTrace*>(t)->setReferencePose(*ref); }
+int orc_trace_size(void* t) { return static_cast<int>(static_cast<PoseTrace*>(t)->trace.size()); }
+void orc_trace_get(void* t, int i, orc_pose_t* out) { *out = static_cast<PoseTrace*>(t)->trace[i]; }
+
+// ---- OccupancyGridSLAM driver
+void* orc_slam_create(int numParticles, int8_t hit, int8_t miss, int waitOptitrack, int mappingOnly, int actionOnly,
+                      const orc_grid_t* locMap, uint32_t initSeed)
+{
+    SlamDriver* d = new SlamDriver(numParticles, hit, miss, waitOptitrack != 0, mappingOnly != 0, actionOnly != 0, locMap);
+    d->initSeed = initSeed;
+    return d;
+}
+void orc_slam_destroy(void* d) { delete static_cast<SlamDriver*>(d); }
+void orc_slam_handle_laser(void* d, const orc_lidar_t* scan)
+{
+    OwnedScan s; s.utime = scan->utime;
+    s.ranges.assign(scan->ranges, scan->ranges + scan->num_ranges);
+    s.thetas.assign(scan->thetas, scan->thetas + scan->num_ranges);
+    s.times.assign(scan->times, scan->times + scan->num_ranges);
+    static_cast<SlamDriver*>(d)->handleLaser(s);
+}
+void orc_slam_handle_odometry(void* d, const orc_pose_t* p) { static_cast<SlamDriver*>(d)->odometry.addPose(*p); }
+void orc_slam_handle_pose(void* d, const orc_pose_t* p) { static_cast<SlamDriver*>(d)->groundTruth.addPose(*p); }
+void orc_slam_handle_optitrack(void* d, const orc_pose_t* p)
+{
+    SlamDriver* s = static_cast<SlamDriver*>(d);
+    if (s->waitingForOptitrack) { s->initialPose = *p; s->waitingForOptitrack = false; }
+}
+int orc_slam_ready(void* d) { return static_cast<SlamDriver*>(d)->isReady() ? 1 : 0; }
+void orc_slam_iterate(void* d, int rand_value) { static_cast<SlamDriver*>(d)->iterate(rand_value); }
+// state: [numIgnoredScans, queued, mapUpdateCount, publishedPoses, publishedMaps, haveMap]
+void orc_slam_state(void* d, int* out6, orc_pose_t* currentPose, int8_t* cells)
+{
+    SlamDriver* s = static_cast<SlamDriver*>(d);
+    out6[0] = s->numIgnoredScans; out6[1] = static_cast<int>(s->incoming.size()); out6[2] = s->mapUpdateCount;
+    out6[3] = s->publishedPoses; out6[4] = s->publishedMaps; out6[5] = s->haveMap ? 1 : 0;
+    if (currentPose) *currentPose = s->currentPose;
+    if (cells) std::memcpy(cells, s->cells.data(), s->cells.size());
 }
 
 }  // extern "C"

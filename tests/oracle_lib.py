@@ -88,6 +88,29 @@ class Oracle:
         L.orc_action_update.restype = C.c_int
         L.orc_action_update.argtypes = [C.c_void_p, C.POINTER(OPose)]
         L.orc_action_apply_noise.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+        L.orc_trace_create.restype = C.c_void_p
+        L.orc_trace_destroy.argtypes = [C.c_void_p]
+        L.orc_trace_add.argtypes = [C.c_void_p, C.POINTER(OPose)]
+        L.orc_trace_erase_until.restype = C.c_int
+        L.orc_trace_erase_until.argtypes = [C.c_void_p, C.c_int64]
+        L.orc_trace_pose_at.argtypes = [C.c_void_p, C.c_int64, C.POINTER(OPose)]
+        L.orc_trace_contains.restype = C.c_int
+        L.orc_trace_contains.argtypes = [C.c_void_p, C.c_int64]
+        L.orc_trace_set_reference.argtypes = [C.c_void_p, C.POINTER(OPose)]
+        L.orc_trace_size.restype = C.c_int
+        L.orc_trace_size.argtypes = [C.c_void_p]
+        L.orc_trace_get.argtypes = [C.c_void_p, C.c_int, C.POINTER(OPose)]
+        L.orc_slam_create.restype = C.c_void_p
+        L.orc_slam_create.argtypes = [C.c_int, C.c_int8, C.c_int8, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_uint32]
+        L.orc_slam_destroy.argtypes = [C.c_void_p]
+        L.orc_slam_handle_laser.argtypes = [C.c_void_p, C.POINTER(OLidar)]
+        L.orc_slam_handle_odometry.argtypes = [C.c_void_p, C.POINTER(OPose)]
+        L.orc_slam_handle_pose.argtypes = [C.c_void_p, C.POINTER(OPose)]
+        L.orc_slam_handle_optitrack.argtypes = [C.c_void_p, C.POINTER(OPose)]
+        L.orc_slam_ready.restype = C.c_int
+        L.orc_slam_ready.argtypes = [C.c_void_p]
+        L.orc_slam_iterate.argtypes = [C.c_void_p, C.c_int]
+        L.orc_slam_state.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(OPose), C.c_void_p]
         L.orc_is_valid_goal.restype = C.c_int
         L.orc_is_valid_goal.argtypes = [C.POINTER(OPose), C.POINTER(OGrid), C.c_double, C.c_double, C.c_int, C.POINTER(OPose)]
 
