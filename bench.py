@@ -11,7 +11,7 @@ One step = OccupancyGridSLAM::runSLAMIteration (src/slam/slam.cpp:191-207) + the
     Mapping::updateMap(scan, pose, map)
     ObstacleDistanceGrid::setDistances(map)  +  search_for_path(pose, goal)     on a second stream, on a snapshot
 Multi-GPU (--gpus N under torch.distributed.run): the particles are block-sharded over the ranks (RCCL all-gather of
-the 16-byte exchange record + all-reduce of the weight/pose sums); the map update and the replan are replicated.
+the 16-byte exchange record, the only collective); the map update and the replan are replicated.
 Total work is fixed as N grows ("scaling": "strong").
 
 Prints ONE JSON line on rank 0.

@@ -66,9 +66,8 @@ SIGNATURES = {
     "bl_mapping_update_dev_pose": (C.c_int, [_vp, _P(Lidar), _vp, C.c_int64, _vp]),
     "bl_pf_create": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _P(_vp)]),
     "bl_pf_destroy": (None, [_vp]),
-    "bl_pf_set_exchange_buffers": (C.c_int, [_vp, _vp, _vp, _vp]),
+    "bl_pf_set_exchange_buffers": (C.c_int, [_vp, _vp, _vp]),
     "bl_pf_exchange_rec_ptr": (_vp, [_vp]),
-    "bl_pf_exchange_sums_ptr": (_vp, [_vp]),
     "bl_pf_init_at_pose": (C.c_int, [_vp, _P(Pose), C.c_uint64]),
     "bl_pf_set_particles": (C.c_int, [_vp, _vp, _vp]),
     "bl_pf_get_particles": (C.c_int, [_vp, _vp]),

@@ -38,7 +38,7 @@
 struct pf_state {
     double S;                 // total weight units of rec[cur]
     bl_pose_xyt_t pose;       // posteriorPose_
-    double sums_used[5];      // the (all-reduced) sums the estimate was formed from (diagnostic)
+    double sums_used[5];      // the sums the estimate was formed from (diagnostic)
 };
 
 struct bl_pf {
@@ -47,8 +47,7 @@ struct bl_pf {
     float4* rec[2];
     bool rec_external;
     int cur;
-    double* sums;             // 8 doubles
-    bool sums_external;
+    double* tile_pose;        // [scan_blocks][4]: per-tile sums of units*(x, y, sin, cos) (non-fused finish)
     unsigned long long* prefix;
     float4* parent;
     pf_state* state;
@@ -364,51 +363,71 @@ __global__ __launch_bounds__(BLOCK) void k_mcl_main(mcl_args a)
     }
 }
 
-// fixed-order reduction of the block partials -> sums[0..4] (sums[5..7] = 0)
-__global__ __launch_bounds__(256) void k_mcl_reduce(const double* __restrict__ partials, int nblocks, double* __restrict__ sums)
-{
-    __shared__ double s[256][5];
-    double v[5] = {0, 0, 0, 0, 0};
-    for (int b = threadIdx.x; b < nblocks; b += 256)
-        for (int k = 0; k < 5; ++k) v[k] += partials[(size_t)b * 5 + k];
-    for (int k = 0; k < 5; ++k) s[threadIdx.x][k] = v[k];
-    __syncthreads();
-    for (int stride = 128; stride > 0; stride >>= 1) {
-        if (threadIdx.x < stride)
-            for (int k = 0; k < 5; ++k) s[threadIdx.x][k] += s[threadIdx.x + stride][k];
-        __syncthreads();
-    }
-    if (threadIdx.x < 8) sums[threadIdx.x] = threadIdx.x < 5 ? s[0][threadIdx.x] : 0.0;
-}
-
 // ---------------------------------------------------------------- weight-unit prefix scan over all N (3 launches)
+// Tile sums of the weight units and, when tile_pose != nullptr, of the estimatePosteriorPose terms
+// (particle_filter.cpp:144-160) units*(x, y, sinf(theta), cosf(theta)) in double.  The order of every addition is a
+// function of N alone (items in a thread, shuffle tree in a wave, waves in order), so the estimate does not depend on how
+// the particles were sharded: after the all-gather every rank derives it from the record itself, no all-reduce needed.
 __global__ __launch_bounds__(SCAN_THREADS) void k_scan_tile_sums(const float4* __restrict__ rec, int N,
-                                                                 unsigned long long* __restrict__ tile_sums)
+                                                                 unsigned long long* __restrict__ tile_sums,
+                                                                 double* __restrict__ tile_pose)
 {
     __shared__ unsigned long long s[SCAN_THREADS / 64];
+    __shared__ double s_pose[SCAN_THREADS / 64][4];
     const int base = blockIdx.x * SCAN_TILE + threadIdx.x * SCAN_ITEMS;
     unsigned long long v = 0;
-    for (int k = 0; k < SCAN_ITEMS; ++k)
-        if (base + k < N) v += __float_as_uint(rec[base + k].w);
+    double e[4] = {0, 0, 0, 0};
+    if (tile_pose) {
+        for (int k = 0; k < SCAN_ITEMS; ++k)
+            if (base + k < N) {
+                const float4 r = rec[base + k];
+                const uint32_t u = __float_as_uint(r.w);
+                v += u;
+                float sth, cth;
+                bl_sincosf(r.z, &sth, &cth);
+                const double du = (double)u;
+                e[0] += du * (double)r.x; e[1] += du * (double)r.y; e[2] += du * (double)sth; e[3] += du * (double)cth;
+            }
+        for (int k = 0; k < 4; ++k) e[k] = wave_sum(e[k]);
+    } else {
+        for (int k = 0; k < SCAN_ITEMS; ++k)
+            if (base + k < N) v += __float_as_uint(rec[base + k].w);
+    }
     for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-    if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = v;
+    if ((threadIdx.x & 63) == 0) {
+        s[threadIdx.x >> 6] = v;
+        for (int k = 0; k < 4; ++k) s_pose[threadIdx.x >> 6][k] = e[k];
+    }
     __syncthreads();
     if (threadIdx.x == 0) {
         unsigned long long t = 0;
         for (int w = 0; w < SCAN_THREADS / 64; ++w) t += s[w];
         tile_sums[blockIdx.x] = t;
     }
+    if (tile_pose && threadIdx.x < 4) {
+        double t = 0;
+        for (int w = 0; w < SCAN_THREADS / 64; ++w) t += s_pose[w][threadIdx.x];
+        tile_pose[(size_t)blockIdx.x * 4 + threadIdx.x] = t;
+    }
 }
 
 // single workgroup: exclusive scan of the tile sums (in place), total -> state.S, and the pose estimate
-// (estimatePosteriorPose, particle_filter.cpp:144-160) from the five (all-reduced) sums.
+// (estimatePosteriorPose, particle_filter.cpp:144-160) from the per-tile sums, reduced in a fixed order.
 __global__ __launch_bounds__(1024) void k_scan_tiles_and_estimate(unsigned long long* __restrict__ tile_sums, int ntiles,
-                                                                  const double* __restrict__ sums, pf_state* state,
+                                                                  const double* __restrict__ tile_pose, pf_state* state,
                                                                   int64_t utime, int write_pose)
 {
     __shared__ unsigned long long s_wave[16];
     __shared__ unsigned long long s_carry;
+    __shared__ double s_red[16][4];
     if (threadIdx.x == 0) s_carry = 0;
+    if (write_pose) {
+        double v[4] = {0, 0, 0, 0};
+        for (int b = threadIdx.x; b < ntiles; b += 1024)
+            for (int k = 0; k < 4; ++k) v[k] += tile_pose[(size_t)b * 4 + k];
+        for (int k = 0; k < 4; ++k) v[k] = wave_sum(v[k]);
+        if ((threadIdx.x & 63) == 0) for (int k = 0; k < 4; ++k) s_red[threadIdx.x >> 6][k] = v[k];
+    }
     __syncthreads();
     for (int base = 0; base < ntiles; base += 1024) {
         int idx = base + threadIdx.x;
@@ -431,14 +450,17 @@ __global__ __launch_bounds__(1024) void k_scan_tiles_and_estimate(unsigned long 
     if (threadIdx.x == 0) {
         state->S = (double)s_carry;
         if (write_pose) {
-            double su = sums[0];
+            double tot[4] = {0, 0, 0, 0};
+            for (int w = 0; w < 16; ++w) for (int k = 0; k < 4; ++k) tot[k] += s_red[w][k];
+            const double su = (double)s_carry;           // exact: the total of the integer units is below 2^53
             bl_pose_xyt_t p;
             p.utime = utime;
-            p.x = (float)(sums[1] / su);
-            p.y = (float)(sums[2] / su);
-            p.theta = (float)atan2(sums[3], sums[4]);
+            p.x = (float)(tot[0] / su);
+            p.y = (float)(tot[1] / su);
+            p.theta = (float)atan2(tot[2], tot[3]);
             state->pose = p;
-            for (int k = 0; k < 5; ++k) state->sums_used[k] = sums[k];
+            state->sums_used[0] = su;
+            for (int k = 0; k < 4; ++k) state->sums_used[k + 1] = tot[k];
         }
     }
 }
@@ -473,8 +495,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan_write_prefix(const float4
 // k_mcl_main workgroup".  k_mcl_finish (one workgroup) reduces the five partial sums in a fixed order, scans the tile
 // sums and forms the pose estimate; k_scan_write_prefix_tile writes the prefix.  Two launches instead of five.
 __global__ __launch_bounds__(1024) void k_mcl_finish(const double* __restrict__ partials, int nblocks,
-                                                     unsigned long long* __restrict__ tile_offsets, double* __restrict__ sums,
-                                                     pf_state* state, int64_t utime)
+                                                     unsigned long long* __restrict__ tile_offsets, pf_state* state, int64_t utime)
 {
     __shared__ double s_red[1024 / 64][5];
     __shared__ unsigned long long s_wave[16];
@@ -490,8 +511,6 @@ __global__ __launch_bounds__(1024) void k_mcl_finish(const double* __restrict__ 
     double tot[5] = {0, 0, 0, 0, 0};
     if (threadIdx.x == 0) {
         for (int w = 0; w < 16; ++w) for (int k = 0; k < 5; ++k) tot[k] += s_red[w][k];
-        for (int k = 0; k < 5; ++k) sums[k] = tot[k];
-        sums[5] = sums[6] = sums[7] = 0.0;
     }
     // ---- exclusive scan of the tile sums (partials[b][0] is an exact integer below 2^53)
     for (int base = 0; base < nblocks; base += 1024) {
@@ -598,7 +617,6 @@ static int pf_alloc(bl_pf* pf)
         BL_HIP(hipMalloc((void**)&pf->rec[0], N * sizeof(float4)));
         BL_HIP(hipMalloc((void**)&pf->rec[1], N * sizeof(float4)));
     }
-    if (!pf->sums) BL_HIP(hipMalloc((void**)&pf->sums, 8 * sizeof(double)));
     BL_HIP(hipMalloc((void**)&pf->prefix, N * sizeof(unsigned long long)));
     BL_HIP(hipMalloc((void**)&pf->parent, n * sizeof(float4)));
     BL_HIP(hipMalloc((void**)&pf->state, sizeof(pf_state)));
@@ -615,10 +633,10 @@ static int pf_alloc(bl_pf* pf)
     }
     pf->scan_blocks = (int)((N + SCAN_TILE - 1) / SCAN_TILE);
     BL_HIP(hipMalloc((void**)&pf->block_sums, (size_t)pf->scan_blocks * sizeof(unsigned long long)));
+    BL_HIP(hipMalloc((void**)&pf->tile_pose, (size_t)pf->scan_blocks * 4 * sizeof(double)));
     BL_HIP(hipMalloc((void**)&pf->dbg_idx, n * sizeof(int32_t)));
     BL_HIP(hipMalloc((void**)&pf->dbg_like, n * sizeof(int32_t)));
     BL_HIP(hipMemsetAsync(pf->state, 0, sizeof(pf_state), pf->ctx->stream));
-    BL_HIP(hipMemsetAsync(pf->sums, 0, 8 * sizeof(double), pf->ctx->stream));
     return BL_OK;
 }
 
@@ -649,25 +667,22 @@ extern "C" void bl_pf_destroy(bl_pf* pf)
     if (!pf) return;
     (void)hipStreamSynchronize(pf->ctx->stream);
     if (!pf->rec_external) { if (pf->rec[0]) (void)hipFree(pf->rec[0]); if (pf->rec[1]) (void)hipFree(pf->rec[1]); }
-    if (!pf->sums_external && pf->sums) (void)hipFree(pf->sums);
-    void* ptrs[] = {pf->prefix, pf->parent, pf->state, pf->partials, pf->tile_offsets, pf->block_sums, pf->dbg_idx, pf->dbg_like,
+    void* ptrs[] = {pf->tile_pose, pf->prefix, pf->parent, pf->state, pf->partials, pf->tile_offsets, pf->block_sums, pf->dbg_idx, pf->dbg_like,
                     pf->d_noise, pf->d_export};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     bl_scan_free(&pf->scan);
     delete pf;
 }
 
-extern "C" int bl_pf_set_exchange_buffers(bl_pf* pf, void* d_rec0, void* d_rec1, void* d_sums)
+extern "C" int bl_pf_set_exchange_buffers(bl_pf* pf, void* d_rec0, void* d_rec1)
 {
-    BL_CHECK_ARG(pf != nullptr && d_rec0 && d_rec1 && d_sums);
+    BL_CHECK_ARG(pf != nullptr && d_rec0 && d_rec1);
     if (pf->prefix) { bl_set_error("exchange buffers must be set before the filter is initialised"); return BL_ERR_STATE; }
     pf->rec[0] = (float4*)d_rec0; pf->rec[1] = (float4*)d_rec1; pf->rec_external = true;
-    pf->sums = (double*)d_sums; pf->sums_external = true;
     return BL_OK;
 }
 
 extern "C" void* bl_pf_exchange_rec_ptr(bl_pf* pf) { return pf && pf->prefix ? (void*)pf->rec[pf->pending_end ? pf->cur ^ 1 : pf->cur] : nullptr; }
-extern "C" void* bl_pf_exchange_sums_ptr(bl_pf* pf) { return pf ? (void*)pf->sums : nullptr; }
 extern "C" const void* bl_pf_pose_device_ptr(bl_pf* pf) { return pf && pf->state ? (const void*)&pf->state->pose : nullptr; }
 
 // prefix scan of rec[which] + (optionally) the pose estimate; timed as BL_K_MCL_SCAN
@@ -678,9 +693,9 @@ static int pf_scan(bl_pf* pf, int which, int write_pose, int64_t utime)
     int rc = bl_timer_begin(ctx, BL_K_MCL_SCAN, &e0, &e1);
     if (rc) return rc;
     hipLaunchKernelGGL(k_scan_tile_sums, dim3(pf->scan_blocks), dim3(SCAN_THREADS), 0, ctx->stream, pf->rec[which], pf->N,
-                       pf->block_sums);
+                       pf->block_sums, write_pose ? pf->tile_pose : (double*)nullptr);
     hipLaunchKernelGGL(k_scan_tiles_and_estimate, dim3(1), dim3(1024), 0, ctx->stream, pf->block_sums, pf->scan_blocks,
-                       pf->sums, pf->state, utime, write_pose);
+                       pf->tile_pose, pf->state, utime, write_pose);
     hipLaunchKernelGGL(k_scan_write_prefix, dim3(pf->scan_blocks), dim3(SCAN_THREADS), 0, ctx->stream, pf->rec[which], pf->N,
                        pf->block_sums, pf->prefix);
     BL_HIP(hipGetLastError());
@@ -875,10 +890,6 @@ static int pf_launch_main(bl_pf* pf, const bl_grid* map, int R, int rand_value, 
     pf->last_blocks = blocks;
     pf->last_tile = block >> a.split_log2;               // particles per k_mcl_main workgroup
     pf->fused_finish = (pf->n_local == pf->N) && pf->last_tile >= 1 && pf->last_tile <= SCAN_TILE && !pf->no_fused_finish;
-    if (!pf->fused_finish) {
-        hipLaunchKernelGGL(k_mcl_reduce, dim3(1), dim3(256), 0, ctx->stream, pf->partials, blocks, pf->sums);
-        BL_HIP(hipGetLastError());
-    }
     return BL_OK;
 }
 
@@ -890,7 +901,7 @@ static int pf_finish_fused(bl_pf* pf, int which, int64_t utime)
     int rc = bl_timer_begin(ctx, BL_K_MCL_SCAN, &e0, &e1);
     if (rc) return rc;
     hipLaunchKernelGGL(k_mcl_finish, dim3(1), dim3(1024), 0, ctx->stream, pf->partials, pf->last_blocks, pf->tile_offsets,
-                       pf->sums, pf->state, utime);
+                       pf->state, utime);
     hipLaunchKernelGGL(k_scan_write_prefix_tile, dim3(pf->last_blocks), dim3(SCAN_THREADS), 0, ctx->stream, pf->rec[which], pf->N,
                        pf->last_tile, pf->tile_offsets, pf->prefix);
     BL_HIP(hipGetLastError());

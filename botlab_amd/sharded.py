@@ -4,10 +4,10 @@ xGMI; "gloo" in the CPU tests).
 Exchange per moved update:
   1. every rank runs resample-gather + action + sensor model for its block of output particles [lo, hi) and writes its
      slice of the 16-byte exchange record (x, y, theta, weight-units);
-  2. ONE all-gather of the record (in place: each rank's slice already sits at its offset) and ONE all-reduce of the
-     8-double partial sums;
+  2. ONE all-gather of the record (in place: each rank's slice already sits at its offset) -- the only collective;
   3. every rank scans the integer weight units of all N particles (exact, so every rank derives the same cumulative
-     and the same total) and forms the pose estimate from the reduced sums.
+     and the same total) and forms the pose estimate from the gathered record in an addition order fixed by N alone,
+     so the estimate is bit-identical on every rank and for every shard count.
 The map update, distance grid and A* are replicated (every rank applies the identical integer update; no traffic).
 
 The engine behind a shard is pluggable so the orchestration is testable without a GPU: the product engine is
@@ -51,11 +51,9 @@ class HipShardEngine:
         self.ctx = host.Context(device, stream=self.stream.cuda_stream)
         padded = self.S * world
         self.rec = [torch.zeros(padded, 4, dtype=torch.float32, device=self.device) for _ in range(2)]
-        self.sums = torch.zeros(8, dtype=torch.float64, device=self.device)
         torch.cuda.synchronize(self.device)           # the zero-fills ran on the default stream
         self.pf = host.ParticleFilter(num_particles, ctx=self.ctx, shard=(self.lo, self.hi))
-        check(self.ctx.lib.bl_pf_set_exchange_buffers(self.pf.h, self.rec[0].data_ptr(), self.rec[1].data_ptr(),
-                                                      self.sums.data_ptr()))
+        check(self.ctx.lib.bl_pf_set_exchange_buffers(self.pf.h, self.rec[0].data_ptr(), self.rec[1].data_ptr()))
 
     def init_at_pose(self, pose, seed):
         self.pf.initializeFilterAtPose(pose, seed=seed)
@@ -72,9 +70,6 @@ class HipShardEngine:
             if t.data_ptr() == ptr:
                 return t
         raise RuntimeError("exchange record pointer does not match a bound buffer")
-
-    def exchange_sums(self):
-        return self.sums
 
     def end(self, want_pose=True):
         return self.pf.updateEnd(want_pose)
@@ -108,12 +103,10 @@ class ShardedParticleFilter:
             mine = rec[self.rank * S:(self.rank + 1) * S]
             stream = getattr(self.engine, "stream", None)
             if stream is not None:
-                with torch.cuda.stream(stream):      # collectives ordered on the engine's stream
+                with torch.cuda.stream(stream):      # the collective is ordered on the engine's stream
                     dist.all_gather_into_tensor(rec, mine, group=self.group)
-                    dist.all_reduce(self.engine.exchange_sums(), op=dist.ReduceOp.SUM, group=self.group)
             else:
                 dist.all_gather_into_tensor(rec, mine, group=self.group)
-                dist.all_reduce(self.engine.exchange_sums(), op=dist.ReduceOp.SUM, group=self.group)
         return self.engine.end(want_pose)
 
     def particles(self):

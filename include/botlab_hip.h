@@ -110,11 +110,10 @@ int bl_mapping_update_dev_pose(bl_mapping* m, const bl_lidar_t* scan, const void
 typedef struct bl_pf bl_pf;
 int bl_pf_create(bl_ctx* ctx, int num_particles, int shard_lo, int shard_hi, bl_pf** out);
 void bl_pf_destroy(bl_pf* pf);
-/* Optional, before init: use caller-allocated device buffers for the two exchange records (each num_particles*16 B)
- * and the partial sums (8 doubles) so a caller can run collectives on them without copies. */
-int bl_pf_set_exchange_buffers(bl_pf* pf, void* d_rec0, void* d_rec1, void* d_sums);
+/* Optional, before init: use caller-allocated device buffers for the two exchange records (each at least
+ * num_particles*16 B) so a caller can run the all-gather on them in place. */
+int bl_pf_set_exchange_buffers(bl_pf* pf, void* d_rec0, void* d_rec1);
 void* bl_pf_exchange_rec_ptr(bl_pf* pf);     /* the record written by the last update_begin (all N; own slice filled) */
-void* bl_pf_exchange_sums_ptr(bl_pf* pf);    /* 8 doubles: units, units*x, units*y, units*sin, units*cos, 0,0,0 */
 /* initializeFilterAtPose (particle_filter.cpp:16-34): N(pose, 0.01) per coordinate from a counter-based Philox stream
  * keyed by seed (reference: std::random_device), last particle = pose, weights 1/N. */
 int bl_pf_init_at_pose(bl_pf* pf, const bl_pose_xyt_t* pose, uint64_t seed);
@@ -133,9 +132,10 @@ int bl_pf_set_noise_seed(bl_pf* pf, uint64_t seed);
  *   out_pose may be NULL (pose stays on device, see bl_pf_pose_device_ptr). */
 int bl_pf_update(bl_pf* pf, const bl_pose_xyt_t* odometry, const bl_lidar_t* scan, const bl_grid* map, int rand_value,
                  const float* noise, bl_pose_xyt_t* out_pose);
-/* Sharded form: begin enqueues action + sensor model for the shard and fills its slice of the exchange record and
- * its partial sums; the caller then all-gathers the record and all-reduces the sums; end scans the weights of all
- * N particles and forms the pose estimate.  *moved == 0 -> nothing was enqueued (robot did not move). */
+/* Sharded form: begin enqueues action + sensor model for the shard and fills its slice of the exchange record; the
+ * caller then all-gathers the record (the ONLY collective of an update); end scans the weight units of all N particles
+ * and forms the pose estimate from the gathered record, in an addition order that depends on N alone -- every rank, and
+ * every shard count, gets the identical estimate.  *moved == 0 -> nothing was enqueued (robot did not move). */
 int bl_pf_update_begin(bl_pf* pf, const bl_pose_xyt_t* odometry, const bl_lidar_t* scan, const bl_grid* map,
                        int rand_value, const float* noise, int* moved);
 int bl_pf_update_end(bl_pf* pf, bl_pose_xyt_t* out_pose);

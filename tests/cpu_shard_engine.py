@@ -21,7 +21,6 @@ class CpuShardEngine:
         self.cells, self.mpc, self.cpm, self.origin = cells, mpc, cpm, origin
         padded = self.S * world
         self.rec = [torch.zeros(padded, 4, dtype=torch.float32) for _ in range(2)]
-        self.sums = torch.zeros(8, dtype=torch.float64)
         self.cur = 0
         self.pending = False
         self.action = self.o.lib.orc_action_create()
@@ -78,27 +77,22 @@ class CpuShardEngine:
         dst[self.lo:self.hi, 0], dst[self.lo:self.hi, 1], dst[self.lo:self.hi, 2] = parts["x"], parts["y"], parts["theta"]
         dst[self.lo:self.hi, 3] = units.view(np.float32)
         self.parent = np.stack([parts["p_x"], parts["p_y"], parts["p_theta"]], 1)
-        u = units.astype(np.float64)
-        th = parts["theta"]
-        sn = np.array([self.o.lib.orc_sinf(float(t)) for t in th], np.float64)
-        cs = np.array([self.o.lib.orc_cosf(float(t)) for t in th], np.float64)
-        s = self.sums.numpy()
-        s[:] = 0
-        s[0], s[1], s[2], s[3], s[4] = u.sum(), (u * parts["x"]).sum(), (u * parts["y"]).sum(), (u * sn).sum(), (u * cs).sum()
         self.pending = True
         return True
 
     def exchange_record(self):
         return self.rec[self.cur ^ 1]
 
-    def exchange_sums(self):
-        return self.sums
-
     def end(self, want_pose=True):
         if self.pending:
             self.cur ^= 1
             self._rescan()
-            s = self.sums.numpy()
+            # the estimate comes from the gathered record of ALL particles, in an order fixed by N (here: np.sum's)
+            r = self.rec[self.cur][:self.N].numpy()
+            u = self._units(self.cur).astype(np.float64)
+            sn = np.array([self.o.lib.orc_sinf(float(t)) for t in r[:, 2]], np.float64)
+            cs = np.array([self.o.lib.orc_cosf(float(t)) for t in r[:, 2]], np.float64)
+            s = [u.sum(), (u * r[:, 0]).sum(), (u * r[:, 1]).sum(), (u * sn).sum(), (u * cs).sum()]
             self.pose = (np.float32(s[1] / s[0]), np.float32(s[2] / s[0]), np.float32(np.arctan2(s[3], s[4])))
             self.parent_utime, self.pose_utime = self.pose_utime, 0
             self.pending = False

@@ -1,5 +1,5 @@
 """Multi-process CPU test of the particle sharding (botlab_amd/sharded.py): world_size 2 over gloo.  The orchestration
-(shard bounds, in-place all-gather of the exchange record, all-reduce of the partial sums) must give every rank the
+(shard bounds, in-place all-gather of the exchange record -- the only collective) must give every rank the
 record a single-rank run produces, bit for bit, and the resampled poses must match the oracle's ParticleFilter."""
 import os
 import sys
@@ -78,7 +78,7 @@ def test_two_rank_gloo_matches_single_rank_and_oracle(tmp_path):
         two = np.load(os.path.join(out, f"rec_w2_r{r}.npy"))
         assert one.view(np.uint32).tobytes() == two.view(np.uint32).tobytes(), f"rank {r} record differs from the single-rank run"
         p1, p2 = np.load(os.path.join(out, "pose_w1_r0.npy")), np.load(os.path.join(out, f"pose_w2_r{r}.npy"))
-        assert np.allclose(p1, p2, rtol=1e-6, atol=1e-7)        # reduced sums associate differently across ranks
+        assert p1.tobytes() == p2.tobytes()      # the estimate is formed from the gathered record: independent of the shard count
 
     # and the same sequence through the oracle's ParticleFilter consuming the same noise
     m, odo, scans, noise, rands, parts = _inputs()
