@@ -148,13 +148,15 @@ def main():
 
     engine = sharded.HipShardEngine(args.particles, rank, world, local_rank)
     ctx = engine.ctx
+    # The replanner on its own stream(s) (the reference's planner process); consecutive replans overlap on `lanes` streams.
+    # Created before anything touches the null stream: the HIP runtime multiplexes streams onto 4 hardware queues (raising
+    # GPU_MAX_HW_QUEUES costs ~50 us of launch latency per kernel, measured), and two lanes sharing a queue serialise.
+    aplanner = bl.AsyncPlanner(ctx=ctx, lanes=args.lanes)
     spf = sharded.ShardedParticleFilter(engine)
     grid = bl.OccupancyGrid.from_cells(m["cells"], m["origin"], m["mpc"], cellsPerMeter=cpm, ctx=ctx)
     mapper = bl.Mapping(5.0, 4, 1, ctx=ctx)                 # slam.cpp:24, slam_main.cpp:22-23
     planner = bl.MotionPlanner(ctx=ctx)                       # robotRadius 0.2 (motion_planner.hpp:31)
     planner.setMap(grid)
-    # the replanner on its own stream(s) (the reference's planner process); consecutive replans overlap on `lanes` streams
-    aplanner = bl.AsyncPlanner(ctx=ctx, lanes=args.lanes)
     goal = None
     if not args.no_astar:
         if args.goal is not None:

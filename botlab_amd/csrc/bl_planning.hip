@@ -717,7 +717,10 @@ static int astar_launch(bl_ctx* ctx, const bl_dist* d, const bl_pose_xyt_t* star
     bl_dist* dm = const_cast<bl_dist*>(d);           // closed[] is search scratch that travels with the grid
     if (!dm->closed_clean) BL_HIP(hipMemsetAsync(dm->closed, 0xFF, (size_t)a.W * a.H * 4, ctx->stream));
     dm->closed_clean = false;
-    if (ctx->astar_small_lds)
+    // The 40 KB heap is for searches that share CUs with the particle filter's whole-grid LDS image (grids up to 64 K
+    // cells: 3 x 40 KB + 40 KB fit one CU).  On larger grids the filter's 144 KB window leaves no room beside it either
+    // way, and an open list spilling past 4095 entries pays an HBM round trip per heap level: take the 147 KB heap.
+    if (ctx->astar_small_lds && (int64_t)a.W * a.H <= 65536)
         hipLaunchKernelGGL((k_astar<AH_LDS_SMALL, AH_COST_LDS_SMALL>), dim3(1), dim3(64), AH_LDS_SMALL_BYTES, ctx->stream, a);
     else
         hipLaunchKernelGGL((k_astar<AH_LDS, AH_COST_LDS>), dim3(1), dim3(64), AH_LDS_BYTES, ctx->stream, a);

@@ -50,8 +50,9 @@ class HipShardEngine:
         assert self.stream.cuda_stream != 0
         self.ctx = host.Context(device, stream=self.stream.cuda_stream)
         padded = self.S * world
-        self.rec = [torch.zeros(padded, 4, dtype=torch.float32, device=self.device) for _ in range(2)]
-        torch.cuda.synchronize(self.device)           # the zero-fills ran on the default stream
+        with torch.cuda.stream(self.stream):          # zero-fills on OUR stream: the null stream (and its hardware queue) stays unused
+            self.rec = [torch.zeros(padded, 4, dtype=torch.float32, device=self.device) for _ in range(2)]
+        self.stream.synchronize()
         self.pf = host.ParticleFilter(num_particles, ctx=self.ctx, shard=(self.lo, self.hi))
         check(self.ctx.lib.bl_pf_set_exchange_buffers(self.pf.h, self.rec[0].data_ptr(), self.rec[1].data_ptr()))
 
