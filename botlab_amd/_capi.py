@@ -35,7 +35,12 @@ class SearchParams(C.Structure):
 
 assert C.sizeof(Pose) == 24 and C.sizeof(Particle) == 56
 
-BL_K_MCL_MAIN, BL_K_MCL_SCAN, BL_K_MAP, BL_K_DIST, BL_K_ASTAR = range(5)
+class MotionPlannerState(C.Structure):
+    """bl_motion_planner_t: the MotionPlanner members plan_path_to_frontier reads (motion_planner.hpp:153-165)."""
+    _fields_ = [("robot_radius", C.c_double), ("search", SearchParams), ("num_frontiers", C.c_int32), ("prev_goal", Pose)]
+
+
+BL_K_MCL_MAIN, BL_K_MCL_SCAN, BL_K_MAP, BL_K_DIST, BL_K_ASTAR, BL_K_FRONTIERS = range(6)
 BL_OK, BL_ERR_HIP, BL_ERR_ARG, BL_ERR_CAPACITY, BL_ERR_STATE = range(5)
 
 _vp = C.c_void_p
@@ -98,6 +103,17 @@ SIGNATURES = {
     "bl_planner_submit": (C.c_int, [_vp, _vp, _vp, _P(Pose), _P(SearchParams)]),
     "bl_planner_fetch": (C.c_int, [_vp, _vp, C.c_int, _P(C.c_int), _P(C.c_int64)]),
     "bl_planner_timing": (C.c_int, [_vp, C.c_int, _P(C.c_double), _P(C.c_double), _P(C.c_int64)]),
+    "bl_astar_search_batch": (C.c_int, [_vp, _vp, _P(Pose), _vp, C.c_int, _P(SearchParams), _vp, C.c_int, _vp, _vp]),
+    "bl_dist_gather": (C.c_int, [_vp, _vp, C.c_int, _vp]),
+    "bl_frontiers_find": (C.c_int, [_vp, _vp, _P(Pose), C.c_double, _P(_vp)]),
+    "bl_frontiers_from_host": (C.c_int, [_vp, C.c_int, _vp, _P(_vp)]),
+    "bl_frontiers_count": (C.c_int, [_vp]),
+    "bl_frontiers_total_cells": (C.c_int, [_vp]),
+    "bl_frontiers_get": (C.c_int, [_vp, _vp, _vp]),
+    "bl_frontiers_stats": (C.c_int, [_vp, _P(C.c_int), _P(C.c_int)]),
+    "bl_frontiers_destroy": (None, [_vp]),
+    "bl_plan_path_to_frontier": (C.c_int, [_vp, _vp, _P(Pose), _vp, _P(MotionPlannerState), _vp, C.c_int, _P(C.c_int), _P(Pose),
+                                           _vp]),
 }
 
 _lib = None

@@ -19,6 +19,7 @@ extern "C" const char* bl_last_error(void) { return g_err; }
 extern "C" const char* bl_version(void) { return "botlab_hip 0.1 (gfx950)"; }
 
 void bl_astar_free(bl_ctx* ctx);   // bl_planning.hip
+void bl_frontier_scratch_free(bl_ctx* ctx);   // bl_frontiers.hip
 
 extern "C" int bl_ctx_create(int device, void* stream, bl_ctx** out)
 {
@@ -54,6 +55,7 @@ extern "C" void bl_ctx_destroy(bl_ctx* ctx)
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     bl_astar_free(ctx);
+    bl_frontier_scratch_free(ctx);
     for (int i = 0; i < BL_K_COUNT; ++i) {
         for (auto& p : ctx->timers[i].pending) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
         for (auto& p : ctx->timers[i].pool) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }

@@ -47,6 +47,7 @@ struct bl_scan_dev {
 };
 
 struct bl_astar_state;
+struct bl_frontier_scratch;
 
 struct bl_ctx {
     int device = 0;
@@ -58,6 +59,14 @@ struct bl_ctx {
     bl_astar_state* astar = nullptr;
     int64_t astar_capacity = 0;
     bool astar_small_lds = false;      // k_astar with the 40 KB LDS footprint (co-running searches)
+    bl_frontier_scratch* frontier = nullptr;
+};
+
+// find_map_frontiers' result: frontier k = cells offsets[k]..offsets[k+1] of xy (x, y per cell, global metres)
+struct bl_frontiers {
+    std::vector<int32_t> offsets;
+    std::vector<float> xy;
+    int bfs_cells = 0, bfs_levels = 0;
 };
 
 struct bl_grid {

@@ -16,6 +16,8 @@
 #include <math.h>
 #include <stdio.h>
 #include <string.h>
+#include <cmath>
+#include <map>
 
 #include "bl_internal.h"
 
@@ -261,7 +263,8 @@ extern "C" void* bl_dist_device_ptr(bl_dist* d) { return d ? (void*)d->cells : n
 #define ASTAR_ST_CAPACITY 2
 #define ASTAR_ST_LIMIT 3
 
-struct astar_result { int status; int path_len; long long pops; long long pushes; bl_pose_xyt_t start; long long stamps[6]; };
+struct astar_result { int status; int path_len; long long pops; long long pushes; bl_pose_xyt_t start; long long stamps[6];
+                      long long path_off; };           // batch form: where the path went in the shared pool
 
 // Diagnostic build only (-DBL_ASTAR_STAMPS): s_memtime shares of the search loop, written to the result record's
 // stamps[] (never to an output the search computes from).
@@ -306,6 +309,13 @@ struct bl_astar_state {
     bl_frame frame;
     // cost table cache key
     bool lut_valid; bl_search_params_t lut_params; int lut_n; const void* lut_owner;
+    // batch form
+    int b_cap; size_t b_cells; int64_t b_heap_each; size_t b_path_each;
+    int2* b_heap; int32_t* b_closed; int32_t* b_path; int32_t* b_pool; char* b_results; int2* b_goals;
+    unsigned long long* b_cursor;
+    char* hb_results; int2* hb_goals; int32_t* hb_pool; size_t hb_pool_cap;
+    // distance gather (bl_dist_gather)
+    int g_cap; int2* g_cells; float* g_vals; int2* hg_cells; float* hg_vals;
 };
 
 #define ASTAR_PATH_HEAD 4096
@@ -324,6 +334,11 @@ struct astar_args {
     const bl_pose_xyt_t* start_dev;    // when non-null the start cell is derived on the device from this pose
     bl_pose_xyt_t start_host;
     bl_frame frame;
+    // batch form (bl_astar_search_batch): workgroup b runs search b -- same start, own goal cell, own heap / closed grid /
+    // path scratch / result record at the strides below; found paths are compacted into one pool for a single D2H.
+    const int2* batch_goals;           // null: single search
+    long long heap_stride, closed_stride, path_stride;
+    int32_t* pool; unsigned long long* pool_cursor;
 };
 
 // The LDS part of the heap is addressed through an address_space(3) pointer: a two-way select between an LDS and a
@@ -437,11 +452,19 @@ __device__ __forceinline__ void heap_adjust(int2* g_heap, int len, int2 value, i
 template <int LDSN, int COSTN>
 __global__ __launch_bounds__(64) void k_astar(astar_args a)
 {
+    if (a.batch_goals) {
+        const long long b = blockIdx.x;
+        const int2 g = a.batch_goals[b];
+        a.gx = g.x; a.gy = g.y;
+        a.heap += b * a.heap_stride; a.closed += b * a.closed_stride; a.path += b * a.path_stride;
+        a.result = (astar_result*)((char*)a.result + b * ASTAR_HDR);
+    }
     int2* g_heap = a.heap;
     const int lane = threadIdx.x;
     __builtin_amdgcn_s_setprio(3);          // a lone latency-bound wave: win issue arbitration against co-resident kernels
     astar_result res; res.status = ASTAR_ST_NOPATH; res.path_len = 0; res.pops = 0; res.pushes = 0;
     for (int q = 0; q < 6; ++q) res.stamps[q] = 0;
+    res.path_off = 0;
     res.start = a.start_host;
     if (a.start_dev) {                                   // global_position_to_grid_cell of the device-resident pose
         res.start = *a.start_dev;
@@ -581,6 +604,18 @@ __global__ __launch_bounds__(64) void k_astar(astar_args a)
     res.stamps[0] = (long long)acc_all; res.stamps[1] = (long long)acc_adj; res.stamps[2] = (long long)acc_nb;
     res.stamps[3] = (long long)(tr1 - tr0); res.stamps[4] = len; res.stamps[5] = 0;
 #endif
+    if (a.pool && res.status == ASTAR_ST_FOUND) {
+        // lane 0 wrote the path to this search's scratch; the wave moves it into the shared pool
+        __threadfence();
+        int n = __builtin_amdgcn_readfirstlane(res.path_len);
+        if ((long long)n > a.path_cap) n = (int)a.path_cap;
+        unsigned long long off = 0;
+        if (lane == 0) off = atomicAdd(a.pool_cursor, (unsigned long long)n);
+        off = ((unsigned long long)__builtin_amdgcn_readfirstlane((int)(off >> 32)) << 32) | (unsigned int)__builtin_amdgcn_readfirstlane((int)off);
+        for (int i = lane; i < n; i += 64)
+            a.pool[off + i] = __hip_atomic_load(&a.path[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        res.path_off = (long long)off;
+    }
     if (lane == 0) *a.result = res;
 }
 
@@ -596,6 +631,10 @@ void bl_astar_free(bl_ctx* ctx)
         if (s->done[i]) (void)hipEventDestroy(s->done[i]);
     }
     if (s->h_cost) (void)hipHostFree(s->h_cost);
+    void* dev[] = {s->b_heap, s->b_closed, s->b_path, s->b_pool, s->b_results, s->b_goals, s->b_cursor, s->g_cells, s->g_vals};
+    for (void* q : dev) if (q) (void)hipFree(q);
+    void* hst[] = {s->hb_results, s->hb_goals, s->hb_pool, s->hg_cells, s->hg_vals};
+    for (void* q : hst) if (q) (void)hipHostFree(q);
     delete s;
     ctx->astar = nullptr;
 }
@@ -606,6 +645,9 @@ extern "C" int bl_astar_set_open_capacity(bl_ctx* ctx, int64_t nodes)
     ctx->astar_capacity = nodes;
     return BL_OK;
 }
+
+static int astar_cells_to_path(const bl_frame& frame, const bl_pose_xyt_t& start, const int32_t* cells, int n,
+                               bl_pose_xyt_t* out_path, int cap);
 
 static int astar_prepare(bl_ctx* ctx, const bl_dist* d)
 {
@@ -652,6 +694,37 @@ static int astar_prepare(bl_ctx* ctx, const bl_dist* d)
     return BL_OK;
 }
 
+// per-distance cell table: validity (astar.cpp:141) and obstacle cost (astar.cpp:181-186) from the float value f[n] a
+// cell at L1 distance n holds.  The host's pow() is the reference's pow().  Rebuilt only when the search parameters or
+// the table length change.
+static int astar_prepare_lut(bl_ctx* ctx, const bl_dist* d, const bl_search_params_t* params)
+{
+    bl_astar_state* s = ctx->astar;
+    const int ln = d->frame.width + d->frame.height + 1;
+    const bool same = s->lut_valid && s->lut_n == ln && s->lut_owner == (const void*)d &&
+                      memcmp(&s->lut_params, params, sizeof(*params)) == 0;
+    if (same) return BL_OK;
+    BL_HIP(hipStreamSynchronize(ctx->stream));      // h_cost may still be the source of an earlier copy
+    const std::vector<float>& f = *d->lut_host;
+    for (int n = 0; n < ln; ++n) {
+        float dist = f[n];
+        int32_t c;
+        if (!(dist > params->minDistanceToObstacle * 1.000001)) c = ASTAR_INVALID_COST;
+        else {
+            c = 0;
+            if (dist > params->minDistanceToObstacle && dist < params->maxDistanceWithCost) {
+                double v = pow(params->maxDistanceWithCost - dist * 2000, params->distanceCostExponent);   // float product
+                c = (v == v && fabs(v) < 2.0e9) ? static_cast<int>(v) : 0;
+                if (c == ASTAR_INVALID_COST) c = ASTAR_INVALID_COST + 1;
+            }
+        }
+        s->h_cost[n] = c;
+    }
+    BL_HIP(hipMemcpyAsync(s->cost_lut, s->h_cost, (size_t)ln * 4, hipMemcpyHostToDevice, ctx->stream));
+    s->lut_valid = true; s->lut_n = ln; s->lut_owner = (const void*)d; s->lut_params = *params;
+    return BL_OK;
+}
+
 static int astar_launch(bl_ctx* ctx, const bl_dist* d, const bl_pose_xyt_t* start, const void* d_start,
                         const bl_pose_xyt_t* goal, const bl_search_params_t* params)
 {
@@ -667,32 +740,9 @@ static int astar_launch(bl_ctx* ctx, const bl_dist* d, const bl_pose_xyt_t* star
         bl_set_error("%d A* searches are already pending on this ctx; fetch a result first", ASTAR_SLOTS);
         return BL_ERR_STATE;
     }
-    // per-distance cell table: validity (astar.cpp:141) and obstacle cost (astar.cpp:181-186) from the float value
-    // f[n] a cell at L1 distance n holds.  The host's pow() is the reference's pow().  Rebuilt only when the search
-    // parameters or the table length change.
+    rc = astar_prepare_lut(ctx, d, params);
+    if (rc) return rc;
     const int ln = d->frame.width + d->frame.height + 1;
-    const bool same = s->lut_valid && s->lut_n == ln && s->lut_owner == (const void*)d &&
-                      memcmp(&s->lut_params, params, sizeof(*params)) == 0;
-    if (!same) {
-        BL_HIP(hipStreamSynchronize(ctx->stream));      // h_cost may still be the source of an earlier copy
-        const std::vector<float>& f = *d->lut_host;
-        for (int n = 0; n < ln; ++n) {
-            float dist = f[n];
-            int32_t c;
-            if (!(dist > params->minDistanceToObstacle * 1.000001)) c = ASTAR_INVALID_COST;
-            else {
-                c = 0;
-                if (dist > params->minDistanceToObstacle && dist < params->maxDistanceWithCost) {
-                    double v = pow(params->maxDistanceWithCost - dist * 2000, params->distanceCostExponent);   // float product
-                    c = (v == v && fabs(v) < 2.0e9) ? static_cast<int>(v) : 0;
-                    if (c == ASTAR_INVALID_COST) c = ASTAR_INVALID_COST + 1;
-                }
-            }
-            s->h_cost[n] = c;
-        }
-        BL_HIP(hipMemcpyAsync(s->cost_lut, s->h_cost, (size_t)ln * 4, hipMemcpyHostToDevice, ctx->stream));
-        s->lut_valid = true; s->lut_n = ln; s->lut_owner = (const void*)d; s->lut_params = *params;
-    }
     astar_args a;
     a.l1 = d->l1; a.W = d->frame.width; a.H = d->frame.height;
     a.cost_lut = s->cost_lut; a.cost_n = ln;
@@ -701,6 +751,7 @@ static int astar_launch(bl_ctx* ctx, const bl_dist* d, const bl_pose_xyt_t* star
     a.path = (int32_t*)(s->d_out + ASTAR_HDR); a.path_cap = (long long)s->path_cap;
     a.result = (astar_result*)s->d_out;
     a.frame = d->frame;
+    a.batch_goals = nullptr; a.heap_stride = a.closed_stride = a.path_stride = 0; a.pool = nullptr; a.pool_cursor = nullptr;
     bl_global_to_cell((double)goal->x, (double)goal->y, d->frame, &a.gx, &a.gy);     // astar.cpp:23-33
     a.sx = 0; a.sy = 0;
     a.start_dev = (const bl_pose_xyt_t*)d_start;
@@ -783,21 +834,7 @@ extern "C" int bl_astar_search_result(bl_ctx* ctx, bl_pose_xyt_t* out_path, int 
         BL_HIP(hipStreamSynchronize(ctx->stream));
         BL_HIP(hipMemcpy(cells.data(), s->d_out + ASTAR_HDR, (size_t)r.path_len * 4, hipMemcpyDeviceToHost));
     }
-    std::vector<bl_pose_xyt_t> rev((size_t)r.path_len);
-    float prevX = 0, prevY = 0;
-    for (int i = 0; i < r.path_len; ++i) {
-        int cx = cells[i] % s->frame.width, cy = cells[i] / s->frame.width;
-        bl_pose_xyt_t p;
-        p.utime = 0;                                                   // D6
-        p.x = (float)((double)s->frame.ox + (double)cx * (double)s->frame.mpc);     // grid_utils.hpp:14-19
-        p.y = (float)((double)s->frame.oy + (double)cy * (double)s->frame.mpc);
-        if (i == 0) p.theta = (float)(double)s->start.theta;
-        else p.theta = (float)atan2((double)prevY - (double)cy, (double)prevX - (double)cx);
-        prevX = (float)cx; prevY = (float)cy;
-        rev[i] = p;
-    }
-    int total = 1 + r.path_len;
-    for (int i = 0; i < r.path_len && 1 + i < cap; ++i) out_path[1 + i] = rev[r.path_len - 1 - i];
+    const int total = astar_cells_to_path(s->frame, s->start, cells.data(), r.path_len, out_path, cap);
     *out_len = total;
     return BL_OK;
 }
@@ -808,6 +845,206 @@ extern "C" int bl_astar_search(bl_ctx* ctx, const bl_dist* d, const bl_pose_xyt_
     int rc = bl_astar_search_async(ctx, d, start, goal, params);
     if (rc) return rc;
     return bl_astar_search_result(ctx, out_path, cap, out_len, stats);
+}
+
+// makePath's pose list (astar.cpp:235-274) from the goal-first cell chain the kernel produced: [start pose] + cells from
+// the start side to the goal.  Returns the path length; writes at most cap poses.
+static int astar_cells_to_path(const bl_frame& frame, const bl_pose_xyt_t& start, const int32_t* cells, int n,
+                               bl_pose_xyt_t* out_path, int cap)
+{
+    if (cap >= 1) out_path[0] = start;                                 // path.path.push_back(start) (astar.cpp:21)
+    float prevX = 0, prevY = 0;
+    for (int i = 0; i < n; ++i) {
+        int cx = cells[i] % frame.width, cy = cells[i] / frame.width;
+        bl_pose_xyt_t p;
+        p.utime = 0;                                                   // D6
+        p.x = (float)((double)frame.ox + (double)cx * (double)frame.mpc);     // grid_utils.hpp:14-19
+        p.y = (float)((double)frame.oy + (double)cy * (double)frame.mpc);
+        if (i == 0) p.theta = (float)(double)start.theta;
+        else p.theta = (float)atan2((double)prevY - (double)cy, (double)prevX - (double)cx);
+        prevX = (float)cx; prevY = (float)cy;
+        const int at = n - i;                                          // poses are emitted start-side first
+        if (at < cap) out_path[at] = p;
+    }
+    return 1 + n;
+}
+
+// ------------------------------------------------------------------------------------------------ batched searches
+// n independent search_for_path calls from ONE start on one distance grid, one wavefront (workgroup) each, concurrently.
+// This is what plan_path_to_frontier's candidate sweep (frontiers.cpp:145-204: up to 164 planPath calls per ring) and
+// any "try several goals" caller needs; each search is the same exact emulation as the single form.
+#define ASTAR_BATCH_MAX 64
+static int astar_batch_prepare(bl_ctx* ctx, const bl_dist* d, int want)
+{
+    bl_astar_state* s = ctx->astar;
+    const size_t cells = (size_t)d->frame.width * d->frame.height;
+    // searches per launch: bounded by 2 GB of closed grids
+    int cap = ASTAR_BATCH_MAX;
+    while (cap > 1 && (size_t)cap * cells * 4 > ((size_t)2 << 30)) cap >>= 1;
+    if (want < cap) cap = want < 8 ? 8 : want;
+    if (cap > ASTAR_BATCH_MAX) cap = ASTAR_BATCH_MAX;
+    if (s->b_cap >= cap && s->b_cells >= cells) return BL_OK;
+    BL_HIP(hipStreamSynchronize(ctx->stream));
+    void* dev[] = {s->b_heap, s->b_closed, s->b_path, s->b_pool, s->b_results, s->b_goals, s->b_cursor};
+    for (void* q : dev) if (q) BL_HIP(hipFree(q));
+    void* hst[] = {s->hb_results, s->hb_goals, s->hb_pool};
+    for (void* q : hst) if (q) BL_HIP(hipHostFree(q));
+    s->b_heap = nullptr; s->b_closed = nullptr; s->b_path = nullptr; s->b_pool = nullptr; s->b_results = nullptr;
+    s->b_goals = nullptr; s->b_cursor = nullptr; s->hb_results = nullptr; s->hb_goals = nullptr; s->hb_pool = nullptr;
+    s->b_cap = 0;
+    if (cap < s->b_cap) cap = s->b_cap;
+    int64_t heap_each = ctx->astar_capacity > 0 ? ctx->astar_capacity : (int64_t)1 << 21;     // 2M entries = 16 MB per search
+    if (heap_each > AH_MAX_CAP) heap_each = AH_MAX_CAP;
+    if (heap_each < AH_LDS + 1) heap_each = AH_LDS + 1;
+    size_t path_each = cells < 65536 ? cells : 65536;
+    if (path_each < 64) path_each = 64;
+    BL_HIP(hipMalloc((void**)&s->b_heap, (size_t)cap * heap_each * sizeof(int2)));
+    BL_HIP(hipMalloc((void**)&s->b_closed, (size_t)cap * cells * 4));
+    BL_HIP(hipMalloc((void**)&s->b_path, (size_t)cap * path_each * 4));
+    BL_HIP(hipMalloc((void**)&s->b_pool, (size_t)cap * path_each * 4));
+    BL_HIP(hipMalloc((void**)&s->b_results, (size_t)cap * ASTAR_HDR));
+    BL_HIP(hipMalloc((void**)&s->b_goals, (size_t)cap * sizeof(int2)));
+    BL_HIP(hipMalloc((void**)&s->b_cursor, 8));
+    BL_HIP(hipHostMalloc((void**)&s->hb_results, (size_t)cap * ASTAR_HDR, hipHostMallocDefault));
+    BL_HIP(hipHostMalloc((void**)&s->hb_goals, (size_t)cap * sizeof(int2), hipHostMallocDefault));
+    s->hb_pool_cap = (size_t)cap * path_each;
+    BL_HIP(hipHostMalloc((void**)&s->hb_pool, s->hb_pool_cap * 4, hipHostMallocDefault));
+    s->b_cap = cap; s->b_cells = cells; s->b_heap_each = heap_each; s->b_path_each = path_each;
+    BL_HIP(hipFuncSetAttribute((const void*)k_astar<AH_LDS, AH_COST_LDS>, hipFuncAttributeMaxDynamicSharedMemorySize, AH_LDS_BYTES));
+    return BL_OK;
+}
+
+// Runs the searches for goal CELLS goals[0..n) (duplicates allowed) and hands each result to `sink(i, status, cells, len, pops, pushes)`.
+template <class Sink>
+static int astar_batch_cells(bl_ctx* ctx, const bl_dist* d, const bl_pose_xyt_t* start, const int2* goals, int n,
+                             const bl_search_params_t* params, Sink sink)
+{
+    BL_CHECK_ARG(ctx != nullptr && d != nullptr && start != nullptr && params != nullptr && n >= 0);
+    BL_CHECK_ARG(d->valid && d->ctx == ctx);
+    BL_CHECK_ARG(d->frame.width <= AH_MAX_DIM && d->frame.height <= AH_MAX_DIM);
+    if (n == 0) return BL_OK;
+    BL_HIP(hipSetDevice(ctx->device));
+    int rc = astar_prepare(ctx, d);
+    if (rc) return rc;
+    bl_astar_state* s = ctx->astar;
+    if (s->launched != s->fetched) { bl_set_error("a single A* search is pending on this ctx; fetch it before a batch"); return BL_ERR_STATE; }
+    rc = astar_batch_prepare(ctx, d, n);
+    if (rc) return rc;
+    rc = astar_prepare_lut(ctx, d, params);
+    if (rc) return rc;
+    const size_t cells = (size_t)d->frame.width * d->frame.height;
+    for (int base = 0; base < n; base += s->b_cap) {
+        const int m = (n - base) < s->b_cap ? (n - base) : s->b_cap;
+        memcpy(s->hb_goals, goals + base, (size_t)m * sizeof(int2));
+        BL_HIP(hipMemcpyAsync(s->b_goals, s->hb_goals, (size_t)m * sizeof(int2), hipMemcpyHostToDevice, ctx->stream));
+        BL_HIP(hipMemsetAsync(s->b_closed, 0xFF, (size_t)m * cells * 4, ctx->stream));
+        BL_HIP(hipMemsetAsync(s->b_cursor, 0, 8, ctx->stream));
+        astar_args a;
+        a.l1 = d->l1; a.W = d->frame.width; a.H = d->frame.height;
+        a.cost_lut = s->cost_lut; a.cost_n = d->frame.width + d->frame.height + 1;
+        a.heap = s->b_heap; a.heap_cap = (int)s->b_heap_each;
+        a.closed = s->b_closed;
+        a.path = s->b_path; a.path_cap = (long long)s->b_path_each;
+        a.result = (astar_result*)s->b_results;
+        a.frame = d->frame;
+        a.gx = a.gy = 0;
+        a.start_dev = nullptr;
+        a.start_host = *start;
+        bl_global_to_cell((double)start->x, (double)start->y, d->frame, &a.sx, &a.sy);
+        a.max_pops = 1ll << 31;
+        a.batch_goals = s->b_goals;
+        a.heap_stride = s->b_heap_each; a.closed_stride = (long long)cells; a.path_stride = (long long)s->b_path_each;
+        a.pool = s->b_pool; a.pool_cursor = s->b_cursor;
+        hipEvent_t e0, e1;
+        rc = bl_timer_begin(ctx, BL_K_ASTAR, &e0, &e1);
+        if (rc) return rc;
+        hipLaunchKernelGGL((k_astar<AH_LDS, AH_COST_LDS>), dim3(m), dim3(64), AH_LDS_BYTES, ctx->stream, a);
+        BL_HIP(hipGetLastError());
+        rc = bl_timer_end(ctx, BL_K_ASTAR, e0, e1);
+        if (rc) return rc;
+        BL_HIP(hipMemcpyAsync(s->hb_results, s->b_results, (size_t)m * ASTAR_HDR, hipMemcpyDeviceToHost, ctx->stream));
+        BL_HIP(hipStreamSynchronize(ctx->stream));
+        size_t total = 0;
+        for (int i = 0; i < m; ++i) {
+            const astar_result* r = (const astar_result*)(s->hb_results + (size_t)i * ASTAR_HDR);
+            if (r->status == ASTAR_ST_CAPACITY) { bl_set_error("A* open list exceeded its capacity (%lld pops)", r->pops); return BL_ERR_CAPACITY; }
+            if (r->status == ASTAR_ST_LIMIT) { bl_set_error("A* pop limit reached"); return BL_ERR_CAPACITY; }
+            if (r->status == ASTAR_ST_FOUND) {
+                if ((size_t)r->path_len > s->b_path_each) { bl_set_error("A* path of %d cells exceeds the batch path capacity", r->path_len); return BL_ERR_CAPACITY; }
+                total += (size_t)r->path_len;
+            }
+        }
+        if (total > 0) {
+            BL_HIP(hipMemcpyAsync(s->hb_pool, s->b_pool, total * 4, hipMemcpyDeviceToHost, ctx->stream));
+            BL_HIP(hipStreamSynchronize(ctx->stream));
+        }
+        for (int i = 0; i < m; ++i) {
+            const astar_result* r = (const astar_result*)(s->hb_results + (size_t)i * ASTAR_HDR);
+            const bool found = r->status == ASTAR_ST_FOUND;
+            sink(base + i, found, found ? s->hb_pool + r->path_off : nullptr, found ? r->path_len : 0, r->pops, r->pushes);
+        }
+    }
+    return BL_OK;
+}
+
+extern "C" int bl_astar_search_batch(bl_ctx* ctx, const bl_dist* d, const bl_pose_xyt_t* start, const bl_pose_xyt_t* goals, int n,
+                                     const bl_search_params_t* params, bl_pose_xyt_t* out_paths, int cap_each, int* out_lens,
+                                     int64_t* stats)
+{
+    BL_CHECK_ARG(goals != nullptr && out_paths != nullptr && out_lens != nullptr && cap_each >= 1 && d != nullptr);
+    std::vector<int2> cells((size_t)(n > 0 ? n : 0));
+    for (int i = 0; i < n; ++i) bl_global_to_cell((double)goals[i].x, (double)goals[i].y, d->frame, &cells[i].x, &cells[i].y);   // astar.cpp:23-33
+    const bl_frame frame = d->frame;
+    const bl_pose_xyt_t st = *start;
+    return astar_batch_cells(ctx, d, start, cells.data(), n, params,
+                             [&](int i, bool found, const int32_t* pc, int len, long long pops, long long pushes) {
+                                 (void)found;
+                                 out_lens[i] = astar_cells_to_path(frame, st, pc, len, out_paths + (size_t)i * cap_each, cap_each);
+                                 if (stats) { stats[2 * i] = pops; stats[2 * i + 1] = pushes; }
+                             });
+}
+
+// distances_(x, y) for n cells in one round trip (isValidGoal / isPathSafe of many candidates); off-grid -> NaN
+__global__ void k_dist_gather(const float* __restrict__ cells, int W, int H, const int2* __restrict__ q, int n, float* __restrict__ out)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int2 c = q[i];
+    out[i] = (c.x >= 0 && c.y >= 0 && c.x < W && c.y < H) ? cells[(size_t)c.y * W + c.x] : __int_as_float(0x7fc00000);
+}
+
+extern "C" int bl_dist_gather(bl_dist* d, const int32_t* xy_cells, int n, float* out)
+{
+    BL_CHECK_ARG(d != nullptr && d->valid && n >= 0 && (n == 0 || (xy_cells != nullptr && out != nullptr)));
+    if (n == 0) return BL_OK;
+    bl_ctx* ctx = d->ctx;
+    BL_HIP(hipSetDevice(ctx->device));
+    int rc = astar_prepare(ctx, d);
+    if (rc) return rc;
+    bl_astar_state* s = ctx->astar;
+    if (s->g_cap < n) {
+        BL_HIP(hipStreamSynchronize(ctx->stream));
+        if (s->g_cells) BL_HIP(hipFree(s->g_cells));
+        if (s->g_vals) BL_HIP(hipFree(s->g_vals));
+        if (s->hg_cells) BL_HIP(hipHostFree(s->hg_cells));
+        if (s->hg_vals) BL_HIP(hipHostFree(s->hg_vals));
+        s->g_cells = nullptr; s->g_vals = nullptr; s->hg_cells = nullptr; s->hg_vals = nullptr; s->g_cap = 0;
+        int cap = n < 4096 ? 4096 : n * 2;
+        BL_HIP(hipMalloc((void**)&s->g_cells, (size_t)cap * sizeof(int2)));
+        BL_HIP(hipMalloc((void**)&s->g_vals, (size_t)cap * 4));
+        BL_HIP(hipHostMalloc((void**)&s->hg_cells, (size_t)cap * sizeof(int2), hipHostMallocDefault));
+        BL_HIP(hipHostMalloc((void**)&s->hg_vals, (size_t)cap * 4, hipHostMallocDefault));
+        s->g_cap = cap;
+    }
+    memcpy(s->hg_cells, xy_cells, (size_t)n * sizeof(int2));
+    BL_HIP(hipMemcpyAsync(s->g_cells, s->hg_cells, (size_t)n * sizeof(int2), hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(k_dist_gather, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, d->cells, d->frame.width, d->frame.height,
+                       s->g_cells, n, s->g_vals);
+    BL_HIP(hipGetLastError());
+    BL_HIP(hipMemcpyAsync(s->hg_vals, s->g_vals, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
+    BL_HIP(hipStreamSynchronize(ctx->stream));
+    memcpy(out, s->hg_vals, (size_t)n * 4);
+    return BL_OK;
 }
 
 // =============================================================================================== asynchronous replanner
@@ -951,5 +1188,167 @@ extern "C" int bl_planner_timing(bl_planner* p, int on, double* dist_ms, double*
     if (dist_ms) *dist_ms = d;
     if (astar_ms) *astar_ms = a;
     if (launches) *launches = n;
+    return BL_OK;
+}
+
+// =============================================================================================== plan_path_to_frontier
+// Host logic of frontiers.cpp:87-214 over the batched search: the candidate goals of one ring of the expanding square
+// are checked together -- isValidGoal (one gather of the goal cells' distances), planPath (one batch of searches, one
+// per distinct goal cell: the path does not depend on where inside the cell the goal lies), isPathSafe (one gather of
+// every path pose's cell) -- and the reference's "last valid candidate of the sweep wins" rule is then applied in order.
+namespace {
+struct frontier_search { bool done = false; std::vector<bl_pose_xyt_t> path; };
+
+// MotionPlanner::isValidGoal (motion_planner.cpp:52-74) given distances_(goalCell) (NaN when outside the grid)
+inline bool mp_is_valid_goal(const bl_motion_planner_t& pl, float gx, float gy, float dist_at_cell)
+{
+    float dx = gx - pl.prev_goal.x, dy = gy - pl.prev_goal.y;
+    float distanceFromPrev = std::sqrt(dx * dx + dy * dy);
+    if (pl.num_frontiers != 1 && distanceFromPrev < 2 * pl.search.minDistanceToObstacle) return false;
+    if (dist_at_cell != dist_at_cell) return false;                     // not in the grid
+    return dist_at_cell > pl.robot_radius;
+}
+}  // namespace
+
+extern "C" int bl_plan_path_to_frontier(bl_ctx* ctx, const bl_frontiers* frontiers, const bl_pose_xyt_t* robot_pose, bl_dist* dist,
+                                        const bl_motion_planner_t* planner, bl_pose_xyt_t* out_path, int cap, int* out_len,
+                                        bl_pose_xyt_t* chosen_goal, int64_t* stats)
+{
+    BL_CHECK_ARG(ctx != nullptr && frontiers != nullptr && robot_pose != nullptr && dist != nullptr && planner != nullptr);
+    BL_CHECK_ARG(out_path != nullptr && cap >= 1 && out_len != nullptr && dist->valid && dist->ctx == ctx);
+    const bl_motion_planner_t& pl = *planner;
+    const bl_pose_xyt_t robotPose = *robot_pose;
+    const bl_frame frame = dist->frame;
+    int64_t pops = 0, pushes = 0, searches = 0;
+    if (stats) stats[0] = stats[1] = stats[2] = 0;
+    if (chosen_goal) memset(chosen_goal, 0, sizeof(*chosen_goal));
+    *out_len = 0;
+    const int nfr = (int)frontiers->offsets.size() - 1;
+    if (nfr <= 0) return BL_OK;                                         // emptyPath (:118-120)
+    // ---- closest frontier by squared distance to any of its cells, first minimum wins (:122-138); then its middle cell (:140)
+    float min_dist = (float)99999999999999LL;                           // float min_dist = 99999999999999 (:122)
+    int closest = -1;
+    for (int k = 0; k < nfr; ++k)
+        for (int i = frontiers->offsets[k]; i < frontiers->offsets[k + 1]; ++i) {
+            const float px = frontiers->xy[2 * (size_t)i], py = frontiers->xy[2 * (size_t)i + 1];
+            const float distance_sq = (robotPose.x - px) * (robotPose.x - px) + (robotPose.y - py) * (robotPose.y - py);
+            if (distance_sq < min_dist) { closest = k; min_dist = distance_sq; }
+        }
+    out_path[0] = robotPose;
+    if (closest < 0) { *out_len = 1; return BL_OK; }                    // no cell beat min_dist (reference: out-of-bounds read)
+    const int nc = frontiers->offsets[closest + 1] - frontiers->offsets[closest];
+    const int mid = frontiers->offsets[closest] + (int)((size_t)(nc - 1) / 2);
+    const float cpx = frontiers->xy[2 * (size_t)mid], cpy = frontiers->xy[2 * (size_t)mid + 1];
+
+    std::map<long long, frontier_search> cache;                         // goal cell -> planPath result
+    struct cand { float x, y; int cx, cy; bool valid; };
+    std::vector<cand> cands;
+    std::vector<int32_t> q;
+    std::vector<float> qv;
+
+    // check_valid (:87-102) for every candidate of `cands`, in three batched rounds
+    auto evaluate = [&]() -> int {
+        const int n = (int)cands.size();
+        q.resize(2 * (size_t)n); qv.resize((size_t)n);
+        for (int i = 0; i < n; ++i) {
+            bl_global_to_cell((double)cands[i].x, (double)cands[i].y, frame, &cands[i].cx, &cands[i].cy);    // motion_planner.cpp:61
+            q[2 * (size_t)i] = cands[i].cx; q[2 * (size_t)i + 1] = cands[i].cy;
+        }
+        int rc = bl_dist_gather(dist, q.data(), n, qv.data());
+        if (rc) return rc;
+        std::vector<int2> todo;
+        std::vector<long long> todo_key;
+        for (int i = 0; i < n; ++i) {
+            cands[i].valid = mp_is_valid_goal(pl, cands[i].x, cands[i].y, qv[i]);
+            if (!cands[i].valid) continue;
+            const long long key = ((long long)cands[i].cy << 32) | (unsigned int)cands[i].cx;
+            if (cache.find(key) == cache.end()) { cache[key] = frontier_search(); todo.push_back(make_int2(cands[i].cx, cands[i].cy)); todo_key.push_back(key); }
+        }
+        if (!todo.empty()) {
+            rc = astar_batch_cells(ctx, dist, &robotPose, todo.data(), (int)todo.size(), &pl.search,
+                                   [&](int i, bool found, const int32_t* pc, int len, long long po, long long pu) {
+                                       (void)found;
+                                       frontier_search& fs = cache[todo_key[i]];
+                                       fs.path.resize((size_t)1 + len);
+                                       astar_cells_to_path(frame, robotPose, pc, len, fs.path.data(), 1 + len);
+                                       fs.done = true;
+                                       pops += po; pushes += pu; searches += 1;
+                                   });
+            if (rc) return rc;
+        }
+        // isPathSafe (motion_planner.cpp:77-96) of every candidate path with >= 3 poses: one gather for all poses
+        q.clear();
+        std::vector<int> first((size_t)n, -1);
+        for (int i = 0; i < n; ++i) {
+            if (!cands[i].valid) continue;
+            const frontier_search& fs = cache[((long long)cands[i].cy << 32) | (unsigned int)cands[i].cx];
+            if (fs.path.size() < 3) { cands[i].valid = false; continue; }     // temp_path.path_length < 3 (:95)
+            first[i] = (int)(q.size() / 2);
+            for (const bl_pose_xyt_t& p : fs.path) {
+                const int x = p.x / frame.mpc + frame.width / 2;              // float / float + int -> float -> int (:83-84)
+                const int y = p.y / frame.mpc + frame.height / 2;
+                q.push_back(x); q.push_back(y);
+            }
+        }
+        qv.resize(q.size() / 2);
+        rc = bl_dist_gather(dist, q.data(), (int)(q.size() / 2), qv.data());
+        if (rc) return rc;
+        for (int i = 0; i < n; ++i) {
+            if (first[i] < 0) continue;
+            const size_t np = cache[((long long)cands[i].cy << 32) | (unsigned int)cands[i].cx].path.size();
+            for (size_t k = 0; k < np; ++k) {
+                const float dv = qv[(size_t)first[i] + k];
+                if (dv != dv || dv <= pl.search.minDistanceToObstacle) { cands[i].valid = false; break; }   // D9: outside the grid is unsafe
+            }
+        }
+        return BL_OK;
+    };
+
+    bool foundPose = false;
+    float square_radius = .025;
+    float sq_len = .025;
+    bl_pose_xyt_t goal_pose; memset(&goal_pose, 0, sizeof(goal_pose));    // D1
+    int wraps = 0;
+    while (!foundPose) {
+        const float top_height = cpy + square_radius;
+        const float bot_height = cpy - square_radius;
+        const float left_bound = cpy + square_radius;       // sic: built from the y coordinate (:176-177)
+        const float right_bound = cpy - square_radius;
+        cands.clear();
+        for (float i = -square_radius; i <= square_radius; i += sq_len) {
+            cands.push_back(cand{cpx + i, top_height, 0, 0, false});
+            cands.push_back(cand{cpx + i, bot_height, 0, 0, false});
+        }
+        for (float i = -square_radius; i <= square_radius; i += sq_len) {
+            cands.push_back(cand{right_bound, cpy + i, 0, 0, false});
+            cands.push_back(cand{left_bound, cpy + i, 0, 0, false});
+        }
+        int rc = evaluate();
+        if (rc) return rc;
+        // the sweep's assignments in the reference's order: first of each pair if valid, else the second (:153-193)
+        for (size_t i = 0; i + 1 < cands.size(); i += 2) {
+            if (cands[i].valid) { foundPose = true; goal_pose.x = cands[i].x; goal_pose.y = cands[i].y; }
+            else if (cands[i + 1].valid) { foundPose = true; goal_pose.x = cands[i + 1].x; goal_pose.y = cands[i + 1].y; }
+        }
+        if (square_radius < 0.5) square_radius += sq_len;
+        else {
+            square_radius = 0.05;
+            if (++wraps == 2 && !foundPose) {                                    // D8
+                if (stats) { stats[0] = pops; stats[1] = pushes; stats[2] = searches; }
+                *out_len = 1;
+                return BL_OK;
+            }
+        }
+    }
+    goal_pose.theta = robotPose.theta;                                           // :209
+    if (chosen_goal) *chosen_goal = goal_pose;
+    // planner.planPath(robotPose, goal_pose) (:210): the chosen candidate's search has already run
+    int gcx, gcy;
+    bl_global_to_cell((double)goal_pose.x, (double)goal_pose.y, frame, &gcx, &gcy);
+    const frontier_search& fs = cache[((long long)gcy << 32) | (unsigned int)gcx];
+    const int n = (int)fs.path.size();
+    for (int i = 0; i < n && i < cap; ++i) out_path[i] = fs.path[i];
+    *out_len = n;
+    if (stats) { stats[0] = pops; stats[1] = pushes; stats[2] = searches; }
     return BL_OK;
 }

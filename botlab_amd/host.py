@@ -397,6 +397,96 @@ def search_for_path_end(distances, cap=4097, return_stats=False):
     return (path, (stats[0], stats[1])) if return_stats else path
 
 
+def search_for_path_batch(start, goals, distances, params, cap_each=4097, return_stats=False):
+    """n independent search_for_path calls from one start, run concurrently on the device (bl_astar_search_batch).
+    Returns a list of paths (each a list of poses)."""
+    ctx = distances.ctx
+    n = len(goals)
+    g = (Pose * max(n, 1))(*goals)
+    buf = (Pose * (max(n, 1) * cap_each))()
+    lens = (C.c_int * max(n, 1))()
+    stats = (C.c_int64 * (2 * max(n, 1)))()
+    check(ctx.lib.bl_astar_search_batch(ctx.h, distances.h, C.byref(start), g, n, C.byref(params), buf, cap_each, lens, stats))
+    paths = []
+    for i in range(n):
+        if lens[i] > cap_each:
+            raise _capi.BotlabHipError(f"path {i} of {lens[i]} poses does not fit the {cap_each}-pose buffer")
+        paths.append([Pose(p.utime, p.x, p.y, p.theta) for p in buf[i * cap_each:i * cap_each + lens[i]]])
+    if return_stats:
+        return paths, [(stats[2 * i], stats[2 * i + 1]) for i in range(n)]
+    return paths
+
+
+class Frontiers:
+    """std::vector<frontier_t> (frontiers.hpp:17-20) as a library handle; .cells() gives the list of (n, 2) float32 arrays."""
+
+    def __init__(self, ctx, h):
+        self.ctx, self.h = ctx, h
+
+    @classmethod
+    def from_lists(cls, ctx, frontiers):
+        offs = np.zeros(len(frontiers) + 1, np.int32)
+        for k, f in enumerate(frontiers):
+            offs[k + 1] = offs[k] + len(f)
+        xy = np.ascontiguousarray(np.concatenate(frontiers) if len(frontiers) else np.zeros((0, 2)), dtype=np.float32)
+        h = C.c_void_p()
+        check(ctx.lib.bl_frontiers_from_host(offs.ctypes.data, len(frontiers), xy.ctypes.data, C.byref(h)))
+        return cls(ctx, h)
+
+    def __len__(self):
+        return self.ctx.lib.bl_frontiers_count(self.h)
+
+    def cells(self):
+        n, tot = len(self), self.ctx.lib.bl_frontiers_total_cells(self.h)
+        offs = np.zeros(n + 1, np.int32)
+        xy = np.zeros((max(tot, 1), 2), np.float32)
+        check(self.ctx.lib.bl_frontiers_get(self.h, offs.ctypes.data, xy.ctypes.data))
+        return [xy[offs[k]:offs[k + 1]].copy() for k in range(n)]
+
+    def stats(self):
+        a, b = C.c_int(), C.c_int()
+        check(self.ctx.lib.bl_frontiers_stats(self.h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def close(self):
+        if self.h:
+            self.ctx.lib.bl_frontiers_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def find_map_frontiers(grid, robotPose, minFrontierLength=0.35):
+    """find_map_frontiers (frontiers.hpp:34-36)."""
+    h = C.c_void_p()
+    check(grid.ctx.lib.bl_frontiers_find(grid.ctx.h, grid.h, C.byref(robotPose), float(minFrontierLength), C.byref(h)))
+    return Frontiers(grid.ctx, h)
+
+
+def plan_path_to_frontier(frontiers, robotPose, grid, planner, cap=1 << 16, return_info=False):
+    """plan_path_to_frontier (frontiers.hpp:50-53).  `grid` is unused by the reference too; the planner's distance grid is."""
+    ctx = planner.distances_.ctx
+    if not isinstance(frontiers, Frontiers):
+        frontiers = Frontiers.from_lists(ctx, frontiers)
+    st = _capi.MotionPlannerState(planner.params_.robotRadius, planner.searchParams_, planner.num_frontiers, planner.prev_goal)
+    buf = (Pose * cap)()
+    n = C.c_int()
+    goal = Pose()
+    stats = (C.c_int64 * 3)()
+    check(ctx.lib.bl_plan_path_to_frontier(ctx.h, frontiers.h, C.byref(robotPose), planner.distances_.h, C.byref(st), buf, cap,
+                                           C.byref(n), C.byref(goal), stats))
+    if n.value > cap:
+        raise _capi.BotlabHipError(f"path of {n.value} poses does not fit the {cap}-pose buffer")
+    path = [Pose(p.utime, p.x, p.y, p.theta) for p in buf[:n.value]]
+    if return_info:
+        return path, goal, (stats[0], stats[1], stats[2])
+    return path
+
+
 class AsyncPlanner:
     """bl_planner: MotionPlanner.setMap + planPath run on a second stream against a snapshot of the map and of the
     device-resident pose (the reference's planner process, src/planning/exploration.cpp:300-317)."""
@@ -478,3 +568,15 @@ class MotionPlanner:
         if not self.isValidGoal(goal):
             return [Pose(start.utime, start.x, start.y, start.theta)]   # failedPath (motion_planner.cpp:28-40)
         return search_for_path(start, goal, self.distances_, searchParams or self.searchParams_)
+
+    def isPathSafe(self, path):
+        # motion_planner.cpp:77-96 (one gather for all poses); a pose outside the grid is unsafe
+        mpc = np.float32(self.distances_.frame()[0])
+        w, h = self.distances_.shape()
+        q = np.zeros((len(path), 2), np.int32)
+        for i, p in enumerate(path):
+            q[i, 0] = int(np.float32(np.float32(p.x) / mpc) + np.float32(w // 2))
+            q[i, 1] = int(np.float32(np.float32(p.y) / mpc) + np.float32(h // 2))
+        out = np.zeros(len(path), np.float32)
+        check(self.distances_.ctx.lib.bl_dist_gather(self.distances_.h, q.ctypes.data, len(path), out.ctypes.data))
+        return bool(np.all(out > self.searchParams_.minDistanceToObstacle))

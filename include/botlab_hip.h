@@ -75,7 +75,8 @@ int bl_ctx_timing_reset(bl_ctx* ctx);
 #define BL_K_MAP 2           /* Mapping::updateMap */
 #define BL_K_DIST 3          /* ObstacleDistanceGrid::setDistances (2 launches, timed together) */
 #define BL_K_ASTAR 4         /* search_for_path */
-#define BL_K_COUNT 5
+#define BL_K_FRONTIERS 5     /* find_map_frontiers */
+#define BL_K_COUNT 6
 
 /* ------------------------------------------------------------------ OccupancyGrid  (src/slam/occupancy_grid.hpp:51-209)
  * Device-resident int8 log-odds cells, row-major y*width+x.  meters_per_cell and cells_per_meter are both carried
@@ -191,6 +192,45 @@ int bl_planner_submit(bl_planner* p, const bl_grid* map, const void* d_start_pos
 int bl_planner_fetch(bl_planner* p, bl_pose_xyt_t* out_path, int cap, int* out_len, int64_t* stats);
 /* on: -1 = just read; 0/1 = disable/enable(+reset) HIP-event timing of the planner stream's kernels (totals in ms) */
 int bl_planner_timing(bl_planner* p, int on, double* dist_ms, double* astar_ms, int64_t* launches);
+
+/* ------------------------------------------------------------------ batched searches, frontiers  
+ * n independent search_for_path calls (astar.hpp:58-61) from ONE start on one distance grid, run concurrently (one
+ * wavefront each).  Path i is written to out_paths + i*cap_each (at most cap_each poses; out_lens[i] is the true
+ * length, 1 = no path); stats, if given, receives {pops, pushes} per search. */
+int bl_astar_search_batch(bl_ctx* ctx, const bl_dist* d, const bl_pose_xyt_t* start, const bl_pose_xyt_t* goals, int n,
+                          const bl_search_params_t* params, bl_pose_xyt_t* out_paths, int cap_each, int* out_lens,
+                          int64_t* stats);
+/* distances_(x, y) (obstacle_distance_grid.hpp:63) for n cells given as x0,y0,x1,y1,... in one round trip; a cell
+ * outside the grid yields NaN. */
+int bl_dist_gather(bl_dist* d, const int32_t* xy_cells, int n, float* out);
+
+/* find_map_frontiers (src/planning/frontiers.hpp:34-36, frontiers.cpp:25-85): the frontiers reachable through free
+ * space from the robot cell, in the reference's discovery order, each frontier's cells in its growth order; frontier k
+ * = cells offsets[k] .. offsets[k+1] of xy (global x, y per cell). */
+typedef struct bl_frontiers bl_frontiers;
+int bl_frontiers_find(bl_ctx* ctx, const bl_grid* map, const bl_pose_xyt_t* robot_pose, double min_frontier_length,
+                      bl_frontiers** out);
+int bl_frontiers_from_host(const int32_t* offsets, int count, const float* xy, bl_frontiers** out);   /* caller-made std::vector<frontier_t> */
+int bl_frontiers_count(const bl_frontiers* f);
+int bl_frontiers_total_cells(const bl_frontiers* f);
+int bl_frontiers_get(const bl_frontiers* f, int32_t* offsets /* count + 1 */, float* xy /* 2 * total_cells */);
+int bl_frontiers_stats(const bl_frontiers* f, int* bfs_cells, int* bfs_levels);   /* free-space flood size / depth (diagnostic) */
+void bl_frontiers_destroy(bl_frontiers* f);
+
+/* The MotionPlanner members plan_path_to_frontier reads (motion_planner.hpp:153-165). */
+typedef struct {
+    double robot_radius;               /* params_.robotRadius */
+    bl_search_params_t search;         /* searchParams_ */
+    int32_t num_frontiers;             /* setNumFrontiers() */
+    bl_pose_xyt_t prev_goal;           /* setPrevGoal() */
+} bl_motion_planner_t;
+/* plan_path_to_frontier (frontiers.hpp:50-53, frontiers.cpp:104-214): closest frontier, its middle cell, then the
+ * expanding-square sweep of candidate goals -- every ring's planPath calls run as one batch of searches.  An empty
+ * frontier list gives *out_len = 0 (the reference's empty path); a sweep that never finds a goal gives the 1-pose path
+ * (DESIGN.md D8).  stats, if given: {pops, pushes, searches run}. */
+int bl_plan_path_to_frontier(bl_ctx* ctx, const bl_frontiers* frontiers, const bl_pose_xyt_t* robot_pose, bl_dist* dist,
+                             const bl_motion_planner_t* planner, bl_pose_xyt_t* out_path, int cap, int* out_len,
+                             bl_pose_xyt_t* chosen_goal, int64_t* stats);
 
 #ifdef __cplusplus
 }

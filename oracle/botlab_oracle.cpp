@@ -26,6 +26,12 @@
 //       isValid() of an off-grid cell (reads before its bounds check, astar.cpp:140-149) is false.
 //   D6  poses appended by makePath carry utime 0 (uninitialised in astar.cpp:250).
 //   D7  MotionPlanner::num_frontiers / prev_goal (uninitialised, motion_planner.hpp:164-165) are passed explicitly.
+//   D8  plan_path_to_frontier's goal search (frontiers.cpp:145-204) never terminates when no candidate is ever valid (the
+//       radius wraps from >= 0.5 back to 0.05 forever).  From the wrap on, every sweep repeats the previous one exactly,
+//       so the search is cut after the SECOND time the radius reaches >= 0.5 and the 1-pose failure path documented in
+//       frontiers.hpp:41-43 is returned.
+//   D9  MotionPlanner::isPathSafe (motion_planner.cpp:77-96) reads distances_(x, y) unchecked; a pose that maps outside the
+//       grid makes the path unsafe.
 
 #include <algorithm>
 #include <cmath>
@@ -726,6 +732,176 @@ struct SlamDriver {
     }
 };
 
+
+// ---------------------------------------------------------------- frontiers (src/planning/frontiers.cpp)
+struct PlannerState {                                  // the MotionPlanner members the frontier code reads
+    const orc_dist_t* dist;
+    double robotRadius;                                // params_.robotRadius
+    orc_search_params_t search;                        // searchParams_
+    int num_frontiers;                                 // D7
+    orc_pose_t prev_goal;                              // D7
+};
+struct Frontier { std::vector<float> xy; };            // frontier_t::cells as x0, y0, x1, y1, ...
+
+bool is_frontier_cell(int x, int y, const orc_grid_t& m)   // :217-246
+{
+    if (!in_grid(m, x, y)) return false;
+    const int8_t v = m.cells[y * m.width + x];
+    if (v > .1 || v < -5) return false;
+    const int xDeltas[4] = {-1, 1, 0, 0};
+    const int yDeltas[4] = {0, 0, 1, -1};
+    for (int n = 0; n < 4; ++n)
+        if (log_odds(m, x + xDeltas[n], y + yDeltas[n]) < 0) return true;
+    return false;
+}
+// visitedCells (a std::set<Point<int>> in the reference) as a bitmap: every cell ever inserted is in the grid except,
+// possibly, the robot cell, which is kept beside it.
+struct Visited {
+    const orc_grid_t& m; std::vector<uint8_t> bits; int rx, ry;
+    Visited(const orc_grid_t& g, int x, int y) : m(g), bits(static_cast<size_t>(g.width) * g.height, 0), rx(x), ry(y) {}
+    bool has(int x, int y) const { return (x == rx && y == ry) || (in_grid(m, x, y) && bits[static_cast<size_t>(y) * m.width + x]); }
+    void insert(int x, int y) { if (in_grid(m, x, y)) bits[static_cast<size_t>(y) * m.width + x] = 1; }
+};
+Frontier grow_frontier(int cx, int cy, const orc_grid_t& m, Visited& visited)   // :249-288
+{
+    std::queue<std::pair<int, int>> q;
+    q.push({cx, cy});
+    visited.insert(cx, cy);
+    const int xDeltas[8] = {-1, -1, -1, 1, 1, 1, 0, 0};
+    const int yDeltas[8] = {0, 1, -1, 0, 1, -1, 1, -1};
+    Frontier f;
+    while (!q.empty()) {
+        std::pair<int, int> c = q.front(); q.pop();
+        // grid_position_to_global_position(Point<int> -> Point<double>) narrowed to Point<float> (grid_utils.hpp:14-19)
+        f.xy.push_back(static_cast<float>(static_cast<double>(m.origin_x) + static_cast<double>(c.first) * static_cast<double>(m.meters_per_cell)));
+        f.xy.push_back(static_cast<float>(static_cast<double>(m.origin_y) + static_cast<double>(c.second) * static_cast<double>(m.meters_per_cell)));
+        for (int n = 0; n < 8; ++n) {
+            int nx = c.first + xDeltas[n], ny = c.second + yDeltas[n];
+            if (!visited.has(nx, ny) && is_frontier_cell(nx, ny, m)) { visited.insert(nx, ny); q.push({nx, ny}); }
+        }
+    }
+    return f;
+}
+std::vector<Frontier> find_map_frontiers(const orc_grid_t& m, const orc_pose_t& robot, double minFrontierLength)   // :25-85
+{
+    std::vector<Frontier> frontiers;
+    // global_position_to_grid_cell(Point<float> -> Point<double>) (grid_utils.hpp:33-38)
+    int rx = static_cast<int>((static_cast<double>(robot.x) - m.origin_x) * m.cells_per_meter);
+    int ry = static_cast<int>((static_cast<double>(robot.y) - m.origin_y) * m.cells_per_meter);
+    Visited visited(m, rx, ry);
+    std::queue<std::pair<int, int>> q;
+    q.push({rx, ry});
+    const int xDeltas[4] = {-1, 1, 0, 0};
+    const int yDeltas[4] = {0, 0, 1, -1};
+    while (!q.empty()) {
+        std::pair<int, int> c = q.front(); q.pop();
+        for (int n = 0; n < 4; ++n) {
+            int nx = c.first + xDeltas[n], ny = c.second + yDeltas[n];
+            if (visited.has(nx, ny) || !in_grid(m, nx, ny)) continue;
+            else if (is_frontier_cell(nx, ny, m)) {
+                Frontier f = grow_frontier(nx, ny, m, visited);
+                if ((f.xy.size() / 2) * m.meters_per_cell >= minFrontierLength) frontiers.push_back(f);   // size_t * float -> float
+            } else if (m.cells[ny * m.width + nx] < 0) { visited.insert(nx, ny); q.push({nx, ny}); }
+        }
+    }
+    return frontiers;
+}
+bool planner_is_valid_goal(const PlannerState& pl, const orc_pose_t& goal)   // motion_planner.cpp:52-74
+{
+    float dx = goal.x - pl.prev_goal.x, dy = goal.y - pl.prev_goal.y;
+    float distanceFromPrev = std::sqrt(dx * dx + dy * dy);
+    if (pl.num_frontiers != 1 && distanceFromPrev < 2 * pl.search.minDistanceToObstacle) return false;
+    const orc_dist_t& d = *pl.dist;
+    int gx = static_cast<int>((static_cast<double>(goal.x) - d.origin_x) * d.cells_per_meter);
+    int gy = static_cast<int>((static_cast<double>(goal.y) - d.origin_y) * d.cells_per_meter);
+    if (dist_in_grid(d, gx, gy)) return d.cells[gy * d.width + gx] > pl.robotRadius;
+    return false;
+}
+std::vector<orc_pose_t> planner_plan_path(const PlannerState& pl, const orc_pose_t& start, const orc_pose_t& goal, SearchStats* st)   // :23-43
+{
+    if (st) { st->pops = 0; st->pushes = 0; }
+    if (!planner_is_valid_goal(pl, goal)) return std::vector<orc_pose_t>(1, start);
+    return search_for_path(start, goal, *pl.dist, pl.search, 0, st);
+}
+bool planner_is_path_safe(const PlannerState& pl, const std::vector<orc_pose_t>& path)   // :77-96 with D9
+{
+    const orc_dist_t& d = *pl.dist;
+    for (size_t i = 0; i < path.size(); ++i) {
+        int x = path[i].x / d.meters_per_cell + d.width / 2;      // float / float + int -> float -> int
+        int y = path[i].y / d.meters_per_cell + d.height / 2;
+        if (!dist_in_grid(d, x, y)) return false;                 // D9
+        if (d.cells[y * d.width + x] <= pl.search.minDistanceToObstacle) return false;
+    }
+    return true;
+}
+bool check_valid(const PlannerState& pl, float x, float y, const orc_pose_t& curr, SearchStats* tot)   // :87-102
+{
+    orc_pose_t pose; pose.utime = 0; pose.theta = 0;              // D1
+    pose.x = x; pose.y = y;
+    if (!planner_is_valid_goal(pl, pose)) return false;
+    SearchStats st;
+    std::vector<orc_pose_t> p = planner_plan_path(pl, curr, pose, &st);
+    if (tot) { tot->pops += st.pops; tot->pushes += st.pushes; }
+    if (p.size() < 3) return false;
+    return planner_is_path_safe(pl, p);
+}
+// :104-214.  *searches counts the planPath calls that reached search_for_path (a size for the batched GPU form).
+std::vector<orc_pose_t> plan_path_to_frontier(const std::vector<Frontier>& frontiers, const orc_pose_t& robotPose,
+                                              const PlannerState& pl, SearchStats* tot, orc_pose_t* chosen_goal)
+{
+    std::vector<orc_pose_t> emptyPath;
+    if (frontiers.size() == 0) return emptyPath;
+    float min_dist = 99999999999999;
+    const Frontier* closest = &frontiers[0];
+    bool any = false;
+    for (const Frontier& f : frontiers)
+        for (size_t k = 0; k + 1 < f.xy.size(); k += 2) {
+            float px = f.xy[k], py = f.xy[k + 1];
+            float distance_sq = (robotPose.x - px) * (robotPose.x - px) + (robotPose.y - py) * (robotPose.y - py);
+            if (distance_sq < min_dist) { closest = &f; min_dist = distance_sq; any = true; }
+        }
+    // closest_frontier is default-constructed (empty) when no cell beats min_dist; cells[int((0-1)/2)] would then be out
+    // of bounds.  Cells are finite floats on a <= 32767-cell grid, so some cell always does.
+    if (!any) return std::vector<orc_pose_t>(1, robotPose);
+    const size_t nc = closest->xy.size() / 2;
+    const size_t mid = static_cast<size_t>(static_cast<int>((nc - 1) / 2));
+    const float cpx = closest->xy[2 * mid], cpy = closest->xy[2 * mid + 1];
+    bool foundPose = false;
+    float square_radius = .025;
+    float sq_len = .025;
+    orc_pose_t goal_pose; std::memset(&goal_pose, 0, sizeof(goal_pose));   // D1
+    int wraps = 0;
+    while (!foundPose) {
+        float top_height = cpy + square_radius;
+        float bot_height = cpy - square_radius;
+        for (float i = -square_radius; i <= square_radius; i += sq_len) {
+            bool valid_point_top = check_valid(pl, cpx + i, top_height, robotPose, tot);
+            bool valid_point_bot = check_valid(pl, cpx + i, bot_height, robotPose, tot);
+            if (valid_point_top) { foundPose = true; goal_pose.x = cpx + i; goal_pose.y = top_height; }
+            else if (valid_point_bot) { foundPose = true; goal_pose.x = cpx + i; goal_pose.y = bot_height; }
+        }
+        float left_bound = cpy + square_radius;           // sic: built from the y coordinate (:176-177)
+        float right_bound = cpy - square_radius;
+        for (float i = -square_radius; i <= square_radius; i += sq_len) {
+            bool valid_point_right = check_valid(pl, right_bound, cpy + i, robotPose, tot);
+            bool valid_point_left = check_valid(pl, left_bound, cpy + i, robotPose, tot);
+            if (valid_point_right) { foundPose = true; goal_pose.x = right_bound; goal_pose.y = cpy + i; }
+            else if (valid_point_left) { foundPose = true; goal_pose.x = left_bound; goal_pose.y = cpy + i; }
+        }
+        if (square_radius < 0.5) square_radius += sq_len;
+        else {
+            square_radius = 0.05;
+            if (++wraps == 2 && !foundPose) return std::vector<orc_pose_t>(1, robotPose);   // D8
+        }
+    }
+    goal_pose.theta = robotPose.theta;
+    if (chosen_goal) *chosen_goal = goal_pose;
+    SearchStats st;
+    std::vector<orc_pose_t> p = planner_plan_path(pl, robotPose, goal_pose, &st);
+    if (tot) { tot->pops += st.pops; tot->pushes += st.pushes; }
+    return p;
+}
+
 }  // namespace
 
 // =============================================================================================== C API
@@ -857,6 +1033,46 @@ int orc_is_valid_goal(const orc_pose_t* goal, const orc_dist_t* d, double robotR
     int gy = static_cast<int>((static_cast<double>(goal->y) - d->origin_y) * d->cells_per_meter);
     if (dist_in_grid(*d, gx, gy)) return d->cells[gy * d->width + gx] > robotRadius;
     return 0;
+}
+
+// ---- frontiers
+// find_map_frontiers: returns the number of frontiers; offsets[k]..offsets[k+1] index cells (cell units = points) of
+// frontier k in xy (2 floats per cell).  Capacities are in frontiers / cells; the return values are the true counts.
+int orc_find_frontiers(const orc_grid_t* map, const orc_pose_t* robot, double minLen, int32_t* offsets, int cap_frontiers,
+                       float* xy, int cap_cells, int* total_cells)
+{
+    std::vector<Frontier> fr = find_map_frontiers(*map, *robot, minLen);
+    int total = 0;
+    for (size_t k = 0; k < fr.size(); ++k) {
+        int n = static_cast<int>(fr[k].xy.size() / 2);
+        if (static_cast<int>(k) < cap_frontiers) offsets[k] = total;
+        if (total + n <= cap_cells) std::memcpy(xy + 2 * static_cast<size_t>(total), fr[k].xy.data(), sizeof(float) * 2 * n);
+        total += n;
+    }
+    if (static_cast<int>(fr.size()) < cap_frontiers + 1) offsets[fr.size()] = total;
+    if (total_cells) *total_cells = total;
+    return static_cast<int>(fr.size());
+}
+int orc_is_path_safe(const orc_pose_t* path, int n, const orc_dist_t* d, double minDist)
+{
+    PlannerState pl; pl.dist = d; pl.robotRadius = minDist; pl.search.minDistanceToObstacle = minDist;
+    return planner_is_path_safe(pl, std::vector<orc_pose_t>(path, path + n)) ? 1 : 0;
+}
+// plan_path_to_frontier over frontiers given in the orc_find_frontiers layout; returns the path length (0 = the empty
+// path of "no frontiers").  stats = {pops, pushes} summed over every search the call ran.
+int orc_plan_path_to_frontier(const int32_t* offsets, int num_frontiers_in, const float* xy, const orc_pose_t* robot,
+                              const orc_dist_t* d, double robotRadius, const orc_search_params_t* sp, int num_frontiers,
+                              const orc_pose_t* prev_goal, orc_pose_t* out, int cap, orc_pose_t* chosen_goal, int64_t* stats)
+{
+    std::vector<Frontier> fr(num_frontiers_in);
+    for (int k = 0; k < num_frontiers_in; ++k) fr[k].xy.assign(xy + 2 * offsets[k], xy + 2 * offsets[k + 1]);
+    PlannerState pl; pl.dist = d; pl.robotRadius = robotRadius; pl.search = *sp; pl.num_frontiers = num_frontiers; pl.prev_goal = *prev_goal;
+    SearchStats tot; tot.pops = 0; tot.pushes = 0;
+    std::vector<orc_pose_t> p = plan_path_to_frontier(fr, *robot, pl, &tot, chosen_goal);
+    int n = std::min<int>(cap, p.size());
+    std::memcpy(out, p.data(), n * sizeof(orc_pose_t));
+    if (stats) { stats[0] = tot.pops; stats[1] = tot.pushes; }
+    return static_cast<int>(p.size());
 }
 
 // ---- PoseTrace

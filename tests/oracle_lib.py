@@ -88,6 +88,15 @@ class Oracle:
         L.orc_action_update.restype = C.c_int
         L.orc_action_update.argtypes = [C.c_void_p, C.POINTER(OPose)]
         L.orc_action_apply_noise.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+        L.orc_find_frontiers.restype = C.c_int
+        L.orc_find_frontiers.argtypes = [C.POINTER(OGrid), C.POINTER(OPose), C.c_double, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
+                                         C.POINTER(C.c_int)]
+        L.orc_is_path_safe.restype = C.c_int
+        L.orc_is_path_safe.argtypes = [C.c_void_p, C.c_int, C.POINTER(OGrid), C.c_double]
+        L.orc_plan_path_to_frontier.restype = C.c_int
+        L.orc_plan_path_to_frontier.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.POINTER(OPose), C.POINTER(OGrid), C.c_double,
+                                                C.POINTER(OSearchParams), C.c_int, C.POINTER(OPose), C.c_void_p, C.c_int,
+                                                C.POINTER(OPose), C.c_void_p]
         L.orc_trace_create.restype = C.c_void_p
         L.orc_trace_destroy.argtypes = [C.c_void_p]
         L.orc_trace_add.argtypes = [C.c_void_p, C.POINTER(OPose)]
@@ -156,6 +165,37 @@ class Oracle:
         path = np.array([(p.utime, p.x, p.y, p.theta) for p in out[:n]],
                         dtype=[("utime", "<i8"), ("x", "<f4"), ("y", "<f4"), ("theta", "<f4")])
         return path, (st[0], st[1])
+
+    def find_frontiers(self, cells, mpc, cpm, origin, robot, min_len=0.35):
+        """find_map_frontiers: list of (n, 2) float32 arrays of cell coordinates, in the reference's order."""
+        cells = np.ascontiguousarray(cells, dtype=np.int8)
+        g = self.grid(cells, mpc, cpm, origin)
+        cap = cells.size + 1
+        offs = np.zeros(cap + 1, np.int32)
+        xy = np.zeros((cap, 2), np.float32)
+        tot = C.c_int(0)
+        n = self.lib.orc_find_frontiers(C.byref(g), C.byref(robot), float(min_len), offs.ctypes.data, cap, xy.ctypes.data, cap, C.byref(tot))
+        return [xy[offs[k]:offs[k + 1]].copy() for k in range(n)]
+
+    def plan_path_to_frontier(self, frontiers, robot, dist, mpc, cpm, origin, robot_radius, min_dist, max_dist, exponent=1.0,
+                              num_frontiers=None, prev_goal=None, cap=1 << 16):
+        """plan_path_to_frontier (frontiers.cpp:104-214): (path, chosen goal, (pops, pushes))."""
+        d = self.grid(np.ascontiguousarray(dist, dtype=np.float32), mpc, cpm, origin)
+        offs = np.zeros(len(frontiers) + 1, np.int32)
+        for k, f in enumerate(frontiers):
+            offs[k + 1] = offs[k] + len(f)
+        xy = np.ascontiguousarray(np.concatenate(frontiers) if frontiers else np.zeros((0, 2)), dtype=np.float32)
+        sp = OSearchParams(min_dist, max_dist, exponent)
+        pg = prev_goal if prev_goal is not None else self.pose(1e9, 1e9, 0.0)
+        out = (OPose * cap)()
+        goal = OPose()
+        st = (C.c_int64 * 2)()
+        n = self.lib.orc_plan_path_to_frontier(offs.ctypes.data, len(frontiers), xy.ctypes.data, C.byref(robot), C.byref(d),
+                                               float(robot_radius), C.byref(sp), len(frontiers) if num_frontiers is None else num_frontiers,
+                                               C.byref(pg), out, cap, C.byref(goal), st)
+        path = np.array([(p.utime, p.x, p.y, p.theta) for p in out[:n]],
+                        dtype=[("utime", "<i8"), ("x", "<f4"), ("y", "<f4"), ("theta", "<f4")])
+        return path, (goal.x, goal.y, goal.theta), (st[0], st[1])
 
     def is_valid_goal(self, goal, dist, mpc, cpm, origin, robot_radius, min_dist, num_frontiers=1, prev_goal=None):
         d = self.grid(np.ascontiguousarray(dist, dtype=np.float32), mpc, cpm, origin)

@@ -1,0 +1,202 @@
+"""Row f3: find_map_frontiers, the batched search_for_path and plan_path_to_frontier on the GPU
+against the oracle's restatement of src/planning/frontiers.cpp / motion_planner.cpp.  Everything here is integer / index
+work or float arithmetic restated operation by operation, so the bar is bit-exact: same frontiers in the same order,
+same cells in the same order, same goal, same path."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import botlab_amd as bl
+import helpers
+import oracle_lib
+
+pytestmark = pytest.mark.gpu
+
+
+def _blob_map(seed, shape=(200, 200)):
+    """Random partially explored map: free blobs (strongly negative), weak values -7..1 along their rim (exercises the
+    [-5, 0] frontier test), occupied blobs, unknown (0) elsewhere."""
+    from scipy.ndimage import gaussian_filter
+    rng = np.random.default_rng(seed)
+    f = gaussian_filter(rng.normal(size=shape), 4)
+    g = gaussian_filter(rng.normal(size=shape), 3)
+    c = np.zeros(shape, np.int8)
+    c[f > 0.02] = -20
+    rim = (f > 0.0) & (f <= 0.02)
+    c[rim] = rng.integers(-7, 2, size=int(rim.sum()))
+    c[g > 0.09] = 60
+    return c
+
+
+def _frame(shape):
+    h, w = shape
+    return (np.float32(-w * 0.05 / 2), np.float32(-h * 0.05 / 2)), np.float32(0.05)
+
+
+def _same_frontiers(got, exp):
+    assert len(got) == len(exp), (len(got), len(exp))
+    for k, (a, b) in enumerate(zip(got, exp)):
+        assert a.shape == b.shape and a.tobytes() == b.tobytes(), f"frontier {k} differs"
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2, 3, 4, 5])
+def test_find_map_frontiers_random_maps(oracle, gpu_ctx, seed):
+    shape = (200, 200) if seed < 4 else (150, 333)
+    cells = _blob_map(seed, shape)
+    origin, mpc = _frame(shape)
+    grid = bl.OccupancyGrid.from_cells(cells, origin, mpc, cellsPerMeter=helpers.CPM_DEFAULT, ctx=gpu_ctx)
+    rng = np.random.default_rng(100 + seed)
+    ys, xs = np.nonzero(cells < -5)
+    robots = []
+    for _ in range(3):                                     # robots in free space
+        k = rng.integers(len(xs))
+        robots.append((float(origin[0]) + (xs[k] + 0.5) * 0.05, float(origin[1]) + (ys[k] + 0.5) * 0.05))
+    ys2, xs2 = np.nonzero((cells >= -5) & (cells <= 0))    # a robot standing on a frontier-valued / unknown cell
+    k = rng.integers(len(xs2))
+    robots.append((float(origin[0]) + (xs2[k] + 0.5) * 0.05, float(origin[1]) + (ys2[k] + 0.5) * 0.05))
+    robots.append((float(origin[0]) - 0.02, float(origin[1]) + 2.0))        # just outside the grid, next to column 0
+    robots.append((1000.0, 1000.0))                                          # far outside
+    total = 0
+    for (rx, ry) in robots:
+        for min_len in (0.35, 0.1):
+            exp = oracle.find_frontiers(cells, mpc, helpers.CPM_DEFAULT, origin, oracle.pose(rx, ry, 0.0), min_len)
+            got = bl.find_map_frontiers(grid, bl.make_pose(rx, ry, 0.0), min_len).cells()
+            _same_frontiers(got, exp)
+            total += len(exp)
+    assert total > 10
+
+
+def test_find_map_frontiers_cut_reference_map(oracle, maps, gpu_ctx):
+    m = maps["obstacle_slam_10mx10m_5cm"]
+    cells = m["cells"].copy()
+    cells[:, 110:] = 0                                     # the right part of the arena has not been seen yet
+    grid = bl.OccupancyGrid.from_cells(cells, m["origin"], m["mpc"], cellsPerMeter=helpers.CPM_DEFAULT, ctx=gpu_ctx)
+    exp = oracle.find_frontiers(cells, m["mpc"], helpers.CPM_DEFAULT, m["origin"], oracle.pose(-0.75, 0.2, 0.0))
+    fr = bl.find_map_frontiers(grid, bl.make_pose(-0.75, 0.2, 0.0))
+    _same_frontiers(fr.cells(), exp)
+    assert len(exp) >= 2
+    # a finished map has no frontier (every shipped map is closed)
+    full = bl.OccupancyGrid.from_cells(m["cells"], m["origin"], m["mpc"], cellsPerMeter=helpers.CPM_DEFAULT, ctx=gpu_ctx)
+    assert len(bl.find_map_frontiers(full, bl.make_pose(-0.75, 0.2, 0.0))) == 0
+
+
+def test_batched_searches_equal_single_searches(maps, gpu_ctx):
+    cases = helpers.load_astar_cases()
+    m = maps["astar_maze"]
+    grid = bl.OccupancyGrid.from_cells(m["cells"], m["origin"], m["mpc"], cellsPerMeter=helpers.CPM_DEFAULT, ctx=gpu_ctx)
+    pl = bl.MotionPlanner(bl.MotionPlannerParams(0.1), ctx=gpu_ctx)
+    pl.setMap(grid)
+    start = bl.make_pose(*cases["maze"][0]["start"], 0.3)
+    goals = [bl.make_pose(*row["goal"], 0.0) for row in cases["maze"]]
+    rng = np.random.default_rng(5)
+    for _ in range(30):                                    # anywhere, mostly invalid goals (walls, unknown space, off the grid)
+        goals.append(bl.make_pose(float(rng.uniform(-5.2, 5.2)), float(rng.uniform(-5.2, 5.2)), 0.0))
+    ys, xs = np.nonzero(pl.distances_.cells() > 0.12)
+    for k in rng.integers(len(xs), size=40):               # goals with clearance; with the 4 + 30 above: more than one launch
+        goals.append(bl.make_pose(float(m["origin"][0]) + (xs[k] + 0.3) * 0.05, float(m["origin"][1]) + (ys[k] + 0.6) * 0.05, 0.0))
+    paths, stats = bl.search_for_path_batch(start, goals, pl.distances_, pl.searchParams_, return_stats=True)
+    found = 0
+    for g, p, st in zip(goals, paths, stats):
+        ref, rst = bl.search_for_path(start, g, pl.distances_, pl.searchParams_, return_stats=True)
+        assert len(ref) == len(p) and tuple(rst) == tuple(st)
+        assert all((a.utime, a.x, a.y, a.theta) == (b.utime, b.x, b.y, b.theta) for a, b in zip(ref, p))
+        found += len(p) > 1
+    assert found >= 10
+
+
+def test_dist_gather_and_is_path_safe(oracle, maps, gpu_ctx):
+    m = maps["obstacle_slam_10mx10m_5cm"]
+    grid = bl.OccupancyGrid.from_cells(m["cells"], m["origin"], m["mpc"], cellsPerMeter=helpers.CPM_DEFAULT, ctx=gpu_ctx)
+    pl = bl.MotionPlanner(ctx=gpu_ctx)
+    pl.setMap(grid)
+    dist = pl.distances_.cells()
+    rng = np.random.default_rng(2)
+    q = rng.integers(-3, 204, size=(500, 2)).astype(np.int32)
+    out = np.zeros(500, np.float32)
+    bl._capi.check(gpu_ctx.lib.bl_dist_gather(pl.distances_.h, q.ctypes.data, 500, out.ctypes.data))
+    inside = (q[:, 0] >= 0) & (q[:, 0] < 200) & (q[:, 1] >= 0) & (q[:, 1] < 200)
+    assert np.all(np.isnan(out[~inside])) and (~inside).sum() > 5
+    assert np.array_equal(out[inside], dist[q[inside, 1], q[inside, 0]])
+    start = bl.make_pose(-0.75, 0.2, 0.0)
+    n_safe = 0
+    for goal in ((-0.35, 0.2), (-0.75, 0.9), (0.0, 0.0), (-0.6, 0.25)):
+        path = pl.planPath(start, bl.make_pose(goal[0], goal[1], 0.0))
+        arr = (oracle_lib.OPose * len(path))(*[oracle_lib.OPose(p.utime, p.x, p.y, p.theta) for p in path])
+        d = oracle.grid(np.ascontiguousarray(dist, dtype=np.float32), m["mpc"], helpers.CPM_DEFAULT, m["origin"])
+        exp = bool(oracle.lib.orc_is_path_safe(arr, len(path), C.byref(d), pl.searchParams_.minDistanceToObstacle))
+        assert pl.isPathSafe(path) == exp
+        n_safe += exp
+    assert n_safe >= 1
+
+
+def _plan_both(oracle, cells, origin, mpc, robot, ctx, num_frontiers=None, prev_goal=None, radius=0.2):
+    grid = bl.OccupancyGrid.from_cells(cells, origin, mpc, cellsPerMeter=helpers.CPM_DEFAULT, ctx=ctx)
+    pl = bl.MotionPlanner(bl.MotionPlannerParams(radius), ctx=ctx)
+    pl.setMap(grid)
+    fr = bl.find_map_frontiers(grid, bl.make_pose(*robot))
+    lists = fr.cells()
+    pl.setNumFrontiers(len(lists) if num_frontiers is None else num_frontiers)
+    if prev_goal is not None:
+        pl.setPrevGoal(bl.make_pose(*prev_goal))
+    path, goal, stats = bl.plan_path_to_frontier(fr, bl.make_pose(*robot), grid, pl, return_info=True)
+    dist = oracle.set_distances(cells, mpc, helpers.CPM_DEFAULT, origin)
+    exp_fr = oracle.find_frontiers(cells, mpc, helpers.CPM_DEFAULT, origin, oracle.pose(*robot))
+    _same_frontiers(lists, exp_fr)
+    sp = pl.searchParams_
+    pg = None if prev_goal is None else oracle.pose(*prev_goal)
+    epath, egoal, est = oracle.plan_path_to_frontier(exp_fr, oracle.pose(*robot), dist, mpc, helpers.CPM_DEFAULT, origin, radius,
+                                                     sp.minDistanceToObstacle, sp.maxDistanceWithCost, sp.distanceCostExponent,
+                                                     num_frontiers=pl.num_frontiers, prev_goal=pg)
+    assert len(path) == len(epath), (len(path), len(epath))
+    for a, b in zip(path, epath):
+        assert (a.utime, a.x, a.y, a.theta) == (int(b["utime"]), b["x"], b["y"], b["theta"])
+    if len(epath) > 1:
+        assert (goal.x, goal.y, goal.theta) == egoal
+    return path, lists, stats
+
+
+def test_plan_path_to_frontier_cut_map(oracle, maps, gpu_ctx):
+    m = maps["obstacle_slam_10mx10m_5cm"]
+    cells = m["cells"].copy()
+    cells[:, 110:] = 0
+    path, lists, stats = _plan_both(oracle, cells, m["origin"], m["mpc"], (-0.75, 0.2, 0.4), gpu_ctx)
+    assert len(lists) >= 2 and len(path) > 3 and stats[2] >= 1
+    # prev_goal next to the frontier: every nearby candidate is rejected by isValidGoal until the ring is 0.4 m away
+    mid = lists[0][(len(lists[0]) - 1) // 2]
+    path2, _, _ = _plan_both(oracle, cells, m["origin"], m["mpc"], (-0.75, 0.2, 0.4), gpu_ctx, prev_goal=(float(mid[0]), float(mid[1]), 0.0))
+    assert len(path2) > 3
+    # no frontier at all: the empty path
+    full = bl.OccupancyGrid.from_cells(m["cells"], m["origin"], m["mpc"], cellsPerMeter=helpers.CPM_DEFAULT, ctx=gpu_ctx)
+    pl = bl.MotionPlanner(ctx=gpu_ctx)
+    pl.setMap(full)
+    assert bl.plan_path_to_frontier(bl.find_map_frontiers(full, bl.make_pose(-0.75, 0.2, 0.0)), bl.make_pose(-0.75, 0.2, 0.0), full, pl) == []
+
+
+@pytest.mark.parametrize("seed", [0, 2, 5])
+def test_plan_path_to_frontier_random_maps(oracle, gpu_ctx, seed):
+    shape = (200, 200)
+    cells = _blob_map(seed, shape)
+    cells[cells == 60] = 0                                 # keep the free blobs roomy enough for a 0.1 m robot
+    origin, mpc = _frame(shape)
+    dist = oracle.set_distances(cells, mpc, helpers.CPM_DEFAULT, origin)
+    ys, xs = np.nonzero(dist > 0.35)
+    rng = np.random.default_rng(seed)
+    planned = 0
+    for _ in range(3):
+        k = rng.integers(len(xs))
+        robot = (float(origin[0]) + (xs[k] + 0.5) * 0.05, float(origin[1]) + (ys[k] + 0.5) * 0.05, 0.7)
+        path, lists, stats = _plan_both(oracle, cells, origin, mpc, robot, gpu_ctx, radius=0.1)
+        planned += len(path) > 1
+    assert planned >= 1
+
+
+def test_plan_path_to_frontier_unreachable_gives_failure_path(oracle, gpu_ctx):
+    """D8: no candidate goal is ever valid (the robot radius exceeds every clearance) -> the sweep is cut after its
+    second wrap and the 1-pose failure path comes back, on both sides."""
+    shape = (120, 120)
+    cells = np.zeros(shape, np.int8)
+    cells[50:70, 50:70] = -30
+    origin, mpc = _frame(shape)
+    path, lists, stats = _plan_both(oracle, cells, origin, mpc, (0.0, 0.0, 0.0), gpu_ctx, radius=2.0)
+    assert len(lists) >= 1 and len(path) == 1 and stats[2] == 0
