@@ -504,8 +504,8 @@ __global__ __launch_bounds__(64) void k_astar(astar_args a)
     if (lane == 0) lds_entry_store(0, make_int2(0, (a.sy << 17) | (a.sx << 2)));      // firstNode: all costs 0
     __builtin_amdgcn_wave_barrier();
     bool done = false;
-    unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0, tr0 = 0, tr1 = 0, acc_adj = 0, acc_nb = 0, acc_all = 0;
-    (void)t0; (void)t1; (void)t2; (void)t3; (void)tr0; (void)tr1; (void)acc_adj; (void)acc_nb; (void)acc_all;
+    unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0, ta = 0, tb = 0, tr0 = 0, tr1 = 0, acc_adj = 0, acc_nb = 0, acc_all = 0, acc_wait = 0, acc_push = 0;
+    (void)t0; (void)t1; (void)t2; (void)t3; (void)ta; (void)tb; (void)tr0; (void)tr1; (void)acc_adj; (void)acc_nb; (void)acc_all; (void)acc_wait; (void)acc_push;
 #ifdef BL_ASTAR_STAMPS
     tr0 = __builtin_amdgcn_s_memrealtime();
 #endif
@@ -540,6 +540,7 @@ __global__ __launch_bounds__(64) void k_astar(astar_args a)
                 heap_adjust<false, LDSN>(g_heap, len, value, lane, lk, lj - 1, amask, areq);
             }
         }
+        STAMP(ta);
         asm volatile("s_waitcnt vmcnt(0)" : "+v"(my_l1), "+v"(my_closed) :: "memory");
         if (!inb) { my_l1 = 0xFFFF; my_closed = -1; }
         if (lane >= 4) my_closed = -1;
@@ -563,6 +564,7 @@ __global__ __launch_bounds__(64) void k_astar(astar_args a)
         unsigned int push_m = (unsigned int)__ballot(nvalid && my_closed < 0 && 32767 > f);
         const int ey = (ny << 17) | (nx << 2) | lane;
         if (goal_m) push_m &= (goal_m & (0u - goal_m)) - 1u;                    // neighbours before the goal neighbour only
+        STAMP(tb);
         while (push_m) {
             const int kk = __ffs((int)push_m) - 1;
             push_m &= push_m - 1u;
@@ -596,13 +598,13 @@ __global__ __launch_bounds__(64) void k_astar(astar_args a)
         }
         STAMP(t3);
 #ifdef BL_ASTAR_STAMPS
-        acc_adj += t2 - t1; acc_nb += t3 - t2; acc_all += t3 - t0;
+        acc_adj += ta - t1; acc_wait += t2 - ta; acc_nb += tb - t2; acc_push += t3 - tb; acc_all += t3 - t0;
 #endif
     }
 #ifdef BL_ASTAR_STAMPS
     tr1 = __builtin_amdgcn_s_memrealtime();
     res.stamps[0] = (long long)acc_all; res.stamps[1] = (long long)acc_adj; res.stamps[2] = (long long)acc_nb;
-    res.stamps[3] = (long long)(tr1 - tr0); res.stamps[4] = len; res.stamps[5] = 0;
+    res.stamps[3] = (long long)(tr1 - tr0); res.stamps[4] = (long long)acc_wait; res.stamps[5] = (long long)acc_push;
 #endif
     if (a.pool && res.status == ASTAR_ST_FOUND) {
         // lane 0 wrote the path to this search's scratch; the wave moves it into the shared pool
@@ -814,10 +816,14 @@ extern "C" int bl_astar_search_result(bl_ctx* ctx, bl_pose_xyt_t* out_path, int 
     astar_result r = *(const astar_result*)s->h_out[slot];
     if (stats) { stats[0] = r.pops; stats[1] = r.pushes; }
 #ifdef BL_ASTAR_STAMPS
-    fprintf(stderr, "[astar stamps] pops %lld cycles/pop all %.0f adjust %.0f expand+push %.0f | realtime ticks(100MHz) %lld -> clock %.2f GHz, final len %lld\n",
-            r.pops, (double)r.stamps[0] / (double)(r.pops ? r.pops : 1), (double)r.stamps[1] / (double)(r.pops ? r.pops : 1),
-            (double)r.stamps[2] / (double)(r.pops ? r.pops : 1), r.stamps[3],
-            r.stamps[3] ? (double)r.stamps[0] / ((double)r.stamps[3] * 10.0) / 1.0 : 0.0, r.stamps[4]);
+    {
+        const double pp = (double)(r.pops ? r.pops : 1);
+        fprintf(stderr, "[astar stamps] pops %lld pushes %lld cycles/pop: all %.0f = issue %.0f + adjust %.0f + loadwait %.0f + expand %.0f + pushes %.0f | clock %.2f GHz\n",
+                r.pops, r.pushes, (double)r.stamps[0] / pp,
+                ((double)r.stamps[0] - (double)r.stamps[1] - (double)r.stamps[2] - (double)r.stamps[4] - (double)r.stamps[5]) / pp,
+                (double)r.stamps[1] / pp, (double)r.stamps[4] / pp, (double)r.stamps[2] / pp, (double)r.stamps[5] / pp,
+                r.stamps[3] ? (double)r.stamps[0] / ((double)r.stamps[3] * 10.0) : 0.0);
+    }
 #endif
     s->start = r.start;
     out_path[0] = s->start;                                            // path.path.push_back(start) (astar.cpp:21)
@@ -893,7 +899,7 @@ static int astar_batch_prepare(bl_ctx* ctx, const bl_dist* d, int want)
     s->b_goals = nullptr; s->b_cursor = nullptr; s->hb_results = nullptr; s->hb_goals = nullptr; s->hb_pool = nullptr;
     s->b_cap = 0;
     if (cap < s->b_cap) cap = s->b_cap;
-    int64_t heap_each = ctx->astar_capacity > 0 ? ctx->astar_capacity : (int64_t)1 << 21;     // 2M entries = 16 MB per search
+    int64_t heap_each = ctx->astar_capacity > 0 ? ctx->astar_capacity : (int64_t)1 << 23;     // 8M entries = 64 MB per search
     if (heap_each > AH_MAX_CAP) heap_each = AH_MAX_CAP;
     if (heap_each < AH_LDS + 1) heap_each = AH_LDS + 1;
     size_t path_each = cells < 65536 ? cells : 65536;

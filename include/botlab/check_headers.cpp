@@ -45,3 +45,16 @@ void touch_driver()
     if (slam.isReadyToUpdate()) slam.runSLAMIteration();
     botlab_hip::PoseTraceT<pose_xyt_t> t; t.addPose(p); (void)t.poseAt(0); t.setReferencePose(p); (void)t.eraseTraceUntil(0);
 }
+
+// planning_dropin.hpp instantiations
+#include <botlab/planning_dropin.hpp>
+typedef botlab_hip::MotionPlannerT<pose_xyt_t, robot_path_t> CheckMotionPlanner;
+static void check_planning_dropin(const botlab_hip::OccupancyGrid& map, const pose_xyt_t& pose)
+{
+    CheckMotionPlanner planner;
+    planner.setMap(map);
+    std::vector<botlab_hip::frontier_t> fr = botlab_hip::find_map_frontiers_t(map, pose);
+    planner.setNumFrontiers(fr.size());
+    robot_path_t p = botlab_hip::plan_path_to_frontier_t<robot_path_t>(fr, pose, map, planner);
+    (void)planner.isPathSafe(p); (void)planner.isValidGoal(pose); (void)planner.planPath(pose, pose); (void)planner.obstacleDistances();
+}

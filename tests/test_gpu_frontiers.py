@@ -200,3 +200,46 @@ def test_plan_path_to_frontier_unreachable_gives_failure_path(oracle, gpu_ctx):
     origin, mpc = _frame(shape)
     path, lists, stats = _plan_both(oracle, cells, origin, mpc, (0.0, 0.0, 0.0), gpu_ctx, radius=2.0)
     assert len(lists) >= 1 and len(path) == 1 and stats[2] == 0
+
+
+def test_cpp_planning_dropin_matches_oracle(oracle, maps, tmp_path):
+    """include/botlab/planning_dropin.hpp (MotionPlanner, find_map_frontiers, plan_path_to_frontier with the reference's
+    signatures) driven like Exploration::executeExploringMap, against the oracle."""
+    import os
+    import struct
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "tests", "cpp", "planning_test")
+    subprocess.check_call(["g++", "-std=c++11", "-O2", "-I" + os.path.join(root, "include"), os.path.join(root, "tests", "cpp", "planning_test.cpp"),
+                           "-L" + os.path.join(root, "botlab_amd"), "-lbotlab_hip", "-Wl,-rpath," + os.path.join(root, "botlab_amd"), "-o", exe])
+    m = maps["obstacle_slam_10mx10m_5cm"]
+    cells = m["cells"].copy()
+    cells[:, 110:] = 0
+    map_path, outp = str(tmp_path / "in.map"), str(tmp_path / "out.bin")
+    with open(map_path, "w") as f:                          # .map text format (occupancy_grid.cpp:111-136)
+        f.write(f"{m['origin'][0]:g} {m['origin'][1]:g} 200 200 {m['mpc']:g}\n")
+        for row in cells:
+            f.write(" ".join(str(int(v)) for v in row) + " \n")
+    robot = (-0.75, 0.2, 0.4)
+    out = subprocess.check_output([exe, map_path, repr(robot[0]), repr(robot[1]), repr(robot[2]), "0.2", outp]).decode()
+    assert "planning_test ok" in out
+    raw = open(outp, "rb").read()
+    off = 0
+    nf = struct.unpack_from("<i", raw, off)[0]; off += 4
+    got = []
+    for _ in range(nf):
+        n = struct.unpack_from("<i", raw, off)[0]; off += 4
+        got.append(np.frombuffer(raw, np.float32, 2 * n, off).reshape(n, 2)); off += 8 * n
+    plen, safe, valid = struct.unpack_from("<iii", raw, off); off += 12
+    path = [struct.unpack_from("<qfff", raw, off + 20 * i) for i in range(plen)]; off += 20 * plen
+    failed_len = struct.unpack_from("<i", raw, off)[0]
+    rp = oracle.pose(np.float32(robot[0]), np.float32(robot[1]), np.float32(robot[2]), utime=42)
+    exp_fr = oracle.find_frontiers(cells, m["mpc"], helpers.CPM_DEFAULT, m["origin"], rp)
+    _same_frontiers(got, exp_fr)
+    dist = oracle.set_distances(cells, m["mpc"], helpers.CPM_DEFAULT, m["origin"])
+    epath, egoal, _ = oracle.plan_path_to_frontier(exp_fr, rp, dist, m["mpc"], helpers.CPM_DEFAULT, m["origin"], 0.2, 0.2, 2.0, 1.0,
+                                                   num_frontiers=len(exp_fr))
+    assert plen == len(epath) > 3
+    for a, b in zip(path, epath):
+        assert a[1:] == (b["x"], b["y"], b["theta"])
+    assert path[0][0] == 42 and safe == 1 and valid == 1 and failed_len == 1
