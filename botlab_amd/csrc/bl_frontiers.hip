@@ -72,12 +72,22 @@ __device__ __forceinline__ int fr_log_odds(const frontier_args& a, int x, int y)
     return (x >= 0 && y >= 0 && x < a.W && y < a.H) ? (int)a.cells[(size_t)y * a.W + x] : 0;
 }
 
+// CLS_LDS: the class bytes of the whole grid live in LDS (grids up to FR_CLS_LDS cells); otherwise in the global scratch.
+// All communication is inside ONE workgroup (one CU, one vector L1): __syncthreads() orders plain stores/loads and makes
+// the claim atomics (performed at L2) complete; claim words are read back with L2-scope loads only.
+#define FR_CLS_LDS (96 * 1024)
+#define FR_LQ 2048                // next-level queue entries mirrored in LDS (wider levels are re-read from the global queue)
+
+template <bool CLS_LDS>
 __global__ __launch_bounds__(FR_T) void k_frontiers(frontier_args a)
 {
+    extern __shared__ uint8_t s_cls[];
     __shared__ int s_wave[FR_T / 64];
     __shared__ unsigned int s_umin[FR_T / 64];
+    __shared__ int s_q[2][FR_LQ];
     const int tid = threadIdx.x;
     const long long ncell = (long long)a.W * a.H;
+    uint8_t* cls = CLS_LDS ? s_cls : a.cls;
     // ---- classification: is_frontier_cell (frontiers.cpp:217-246) / free (:77)
     for (long long c = tid; c < ncell; c += FR_T) {
         const int x = (int)(c % a.W), y = (int)(c / a.W);
@@ -88,50 +98,66 @@ __global__ __launch_bounds__(FR_T) void k_frontiers(frontier_args a)
         }
         if (k == 0 && v < 0) k = 1;
         if (x == a.rx && y == a.ry) k = 3;                  // visitedCells.insert(robotCell) before anything else (:42)
-        a.cls[c] = (uint8_t)k;
+        cls[c] = (uint8_t)k;
         a.claim[c] = FR_INF;
         a.fclaim[c] = FR_INF;
     }
     __threadfence();
     __syncthreads();
     // ---- free-space flood (:47-82), xDeltas {-1,1,0,0}, yDeltas {0,0,1,-1}
-    int lo = 0, hi = 1, levels = 0;
+    int lo = 0, hi = 1, levels = 0, cur = 0;
     while (lo < hi) {
+        const bool one_pass = hi - lo <= FR_T;              // the common case: this thread's neighbours stay in registers
+        const bool from_lds = hi - lo <= FR_LQ && lo > 0;
+        int rc[4], rn = 0; unsigned int rk[4];
         for (int p = lo + tid; p < hi; p += FR_T) {
             int x, y;
-            if (p == 0) { x = a.rx; y = a.ry; } else { const int c = a.queue[p]; x = c % a.W; y = c / a.W; }
+            if (p == 0) { x = a.rx; y = a.ry; } else { const int c = from_lds ? s_q[cur][p - lo] : a.queue[p]; x = c % a.W; y = c / a.W; }
+            rn = 0;
             for (int n = 0; n < 4; ++n) {
                 const int nx = x + (n == 0 ? -1 : (n == 1 ? 1 : 0)), ny = y + (n == 2 ? 1 : (n == 3 ? -1 : 0));
                 if (nx < 0 || ny < 0 || nx >= a.W || ny >= a.H) continue;
                 const int c = ny * a.W + nx;
-                const int k = a.cls[c];
-                if (k == 1 || k == 2) atomicMin(&a.claim[c], ((unsigned int)p << 2) | (unsigned int)n);
+                const int k = cls[c];
+                if (k == 1 || k == 2) {
+                    const unsigned int key = ((unsigned int)p << 2) | (unsigned int)n;
+                    atomicMin(&a.claim[c], key);
+                    if (k == 1) { rc[rn] = c; rk[rn] = key; rn++; }
+                }
             }
         }
-        __threadfence();
         __syncthreads();
         int newhi = hi;
         for (int base = lo; base < hi; base += FR_T) {
             const int p = base + tid;
             int wins = 0, wc[4];
             if (p < hi) {
-                int x, y;
-                if (p == 0) { x = a.rx; y = a.ry; } else { const int c = a.queue[p]; x = c % a.W; y = c / a.W; }
-                for (int n = 0; n < 4; ++n) {
-                    const int nx = x + (n == 0 ? -1 : (n == 1 ? 1 : 0)), ny = y + (n == 2 ? 1 : (n == 3 ? -1 : 0));
-                    if (nx < 0 || ny < 0 || nx >= a.W || ny >= a.H) continue;
-                    const int c = ny * a.W + nx;
-                    if (a.cls[c] == 1 && ld_claim(&a.claim[c]) == (((unsigned int)p << 2) | (unsigned int)n)) wc[wins++] = c;
+                if (one_pass) {
+                    for (int j = 0; j < rn; ++j)
+                        if (ld_claim(&a.claim[rc[j]]) == rk[j]) wc[wins++] = rc[j];
+                } else {
+                    const int c0 = a.queue[p];
+                    const int x = c0 % a.W, y = c0 / a.W;
+                    for (int n = 0; n < 4; ++n) {
+                        const int nx = x + (n == 0 ? -1 : (n == 1 ? 1 : 0)), ny = y + (n == 2 ? 1 : (n == 3 ? -1 : 0));
+                        if (nx < 0 || ny < 0 || nx >= a.W || ny >= a.H) continue;
+                        const int c = ny * a.W + nx;
+                        if (cls[c] == 1 && ld_claim(&a.claim[c]) == (((unsigned int)p << 2) | (unsigned int)n)) wc[wins++] = c;
+                    }
                 }
             }
             int total;
             const int off = block_excl_scan(wins, s_wave, &total);
-            for (int j = 0; j < wins; ++j) a.queue[newhi + off + j] = wc[j];
+            for (int j = 0; j < wins; ++j) {
+                const int at = newhi + off + j;
+                a.queue[at] = wc[j];
+                cls[wc[j]] = 4;                             // visited: never claimed again (its claim key stays the smallest anyway)
+                if (at - hi < FR_LQ) s_q[cur ^ 1][at - hi] = wc[j];
+            }
             newhi += total;
         }
-        __threadfence();
         __syncthreads();
-        lo = hi; hi = newhi; levels += 1;
+        lo = hi; hi = newhi; levels += 1; cur ^= 1;
     }
     const int qn = hi;
     // ---- frontiers in discovery order (:66-75): touches in key order; a touched frontier cell that is not part of a grown
@@ -148,13 +174,13 @@ __global__ __launch_bounds__(FR_T) void k_frontiers(frontier_args a)
                 if (nx < 0 || ny < 0 || nx >= a.W || ny >= a.H) continue;
                 const int c = ny * a.W + nx;
                 const unsigned int key = ((unsigned int)p << 2) | (unsigned int)n;
-                if (a.cls[c] == 2 && ld_claim(&a.claim[c]) == key) { cc[cand] = c; ck[cand] = key; cand++; }
+                if (cls[c] == 2 && ld_claim(&a.claim[c]) == key) { cc[cand] = c; ck[cand] = key; cand++; }
             }
         }
         while (true) {
             unsigned int mine = FR_INF;
             for (int j = 0; j < cand; ++j)
-                if (ck[j] < mine && ld_claim(&a.fclaim[cc[j]]) == FR_INF) mine = ck[j];
+                if (ck[j] < mine && cls[cc[j]] == 2) mine = ck[j];          // class 5 = already part of a grown frontier
             const unsigned int best = block_min(mine, s_umin);
             if (best == FR_INF) break;
             // the seed is the neighbour (best & 3) of queue position (best >> 2)
@@ -166,47 +192,65 @@ __global__ __launch_bounds__(FR_T) void k_frontiers(frontier_args a)
                 seed = (y + (n == 2 ? 1 : (n == 3 ? -1 : 0))) * a.W + x + (n == 0 ? -1 : (n == 1 ? 1 : 0));
             }
             int32_t* fq = a.out_cells + total_cells;
-            if (tid == 0) { fq[0] = seed; atomicMin(&a.fclaim[seed], 0u); }
-            __threadfence();
+            if (tid == 0) { fq[0] = seed; cls[seed] = 5; s_q[0][0] = seed; }
             __syncthreads();
-            int flo = 0, fhi = 1;
+            int flo = 0, fhi = 1, fcur = 0;
             while (flo < fhi) {
+                const bool one_pass = fhi - flo <= FR_T;
+                const bool from_lds = fhi - flo <= FR_LQ;
+                int rc[8], rn = 0; unsigned int rk[8];
                 for (int q = flo + tid; q < fhi; q += FR_T) {
-                    const int c = fq[q];
+                    const int c = from_lds ? s_q[fcur][q - flo] : fq[q];
                     const int x = c % a.W, y = c / a.W;
+                    rn = 0;
                     for (int n = 0; n < 8; ++n) {
                         const int nx = x + (n < 3 ? -1 : (n < 6 ? 1 : 0));
                         const int ny = y + ((n == 1 || n == 4 || n == 6) ? 1 : ((n == 2 || n == 5 || n == 7) ? -1 : 0));
                         if (nx < 0 || ny < 0 || nx >= a.W || ny >= a.H) continue;
                         const int nc = ny * a.W + nx;
-                        if (a.cls[nc] == 2) atomicMin(&a.fclaim[nc], (((unsigned int)q << 3) | (unsigned int)n) + 1u);
+                        if (cls[nc] == 2) {
+                            const unsigned int key = ((unsigned int)q << 3) | (unsigned int)n;
+                            atomicMin(&a.fclaim[nc], key);
+                            rc[rn] = nc; rk[rn] = key; rn++;
+                        }
                     }
                 }
-                __threadfence();
                 __syncthreads();
                 int fnew = fhi;
                 for (int fb = flo; fb < fhi; fb += FR_T) {
                     const int q = fb + tid;
                     int wins = 0, wc[8];
                     if (q < fhi) {
-                        const int c = fq[q];
-                        const int x = c % a.W, y = c / a.W;
-                        for (int n = 0; n < 8; ++n) {
-                            const int nx = x + (n < 3 ? -1 : (n < 6 ? 1 : 0));
-                            const int ny = y + ((n == 1 || n == 4 || n == 6) ? 1 : ((n == 2 || n == 5 || n == 7) ? -1 : 0));
-                            if (nx < 0 || ny < 0 || nx >= a.W || ny >= a.H) continue;
-                            const int nc = ny * a.W + nx;
-                            if (a.cls[nc] == 2 && ld_claim(&a.fclaim[nc]) == (((unsigned int)q << 3) | (unsigned int)n) + 1u) wc[wins++] = nc;
+                        if (one_pass) {
+                            for (int j = 0; j < rn; ++j)
+                                if (ld_claim(&a.fclaim[rc[j]]) == rk[j]) wc[wins++] = rc[j];
+                        } else {
+                            const int c = fq[q];
+                            const int x = c % a.W, y = c / a.W;
+                            for (int n = 0; n < 8; ++n) {
+                                const int nx = x + (n < 3 ? -1 : (n < 6 ? 1 : 0));
+                                const int ny = y + ((n == 1 || n == 4 || n == 6) ? 1 : ((n == 2 || n == 5 || n == 7) ? -1 : 0));
+                                if (nx < 0 || ny < 0 || nx >= a.W || ny >= a.H) continue;
+                                const int nc = ny * a.W + nx;
+                                if (cls[nc] == 2 && ld_claim(&a.fclaim[nc]) == (((unsigned int)q << 3) | (unsigned int)n)) wc[wins++] = nc;
+                            }
                         }
                     }
                     int total;
                     const int off = block_excl_scan(wins, s_wave, &total);
-                    for (int j = 0; j < wins; ++j) fq[fnew + off + j] = wc[j];
+                    for (int j = 0; j < wins; ++j) {
+                        const int at = fnew + off + j;
+                        fq[at] = wc[j];
+                        if (at - fhi < FR_LQ) s_q[fcur ^ 1][at - fhi] = wc[j];
+                    }
                     fnew += total;
                 }
-                __threadfence();
                 __syncthreads();
-                flo = fhi; fhi = fnew;
+                // winners leave class 2 only now: a cell claimed in this level must still look unvisited to every
+                // claimer of the level (the smallest key wins), but visited to the next level
+                for (int q = fhi + tid; q < fnew; q += FR_T) cls[fq[q]] = 5;
+                __syncthreads();
+                flo = fhi; fhi = fnew; fcur ^= 1;
             }
             if (nf < a.cap_frontiers) { if (tid == 0) a.out_offsets[nf] = total_cells; } else overflow = 1;
             nf += 1;
@@ -274,7 +318,16 @@ extern "C" int bl_frontiers_find(bl_ctx* ctx, const bl_grid* map, const bl_pose_
     hipEvent_t e0, e1;
     int rc = bl_timer_begin(ctx, BL_K_FRONTIERS, &e0, &e1);
     if (rc) return rc;
-    hipLaunchKernelGGL(k_frontiers, dim3(1), dim3(FR_T), 0, ctx->stream, a);
+    if (n <= (size_t)FR_CLS_LDS) {
+        static bool attr_set = false;
+        if (!attr_set) {
+            BL_HIP(hipFuncSetAttribute((const void*)k_frontiers<true>, hipFuncAttributeMaxDynamicSharedMemorySize, FR_CLS_LDS));
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(k_frontiers<true>, dim3(1), dim3(FR_T), (n + 15) & ~(size_t)15, ctx->stream, a);
+    } else {
+        hipLaunchKernelGGL(k_frontiers<false>, dim3(1), dim3(FR_T), 0, ctx->stream, a);
+    }
     BL_HIP(hipGetLastError());
     rc = bl_timer_end(ctx, BL_K_FRONTIERS, e0, e1);
     if (rc) return rc;
