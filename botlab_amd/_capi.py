@@ -54,6 +54,7 @@ SIGNATURES = {
     "bl_ctx_destroy": (None, [_vp]),
     "bl_ctx_sync": (C.c_int, [_vp]),
     "bl_ctx_timing_enable": (C.c_int, [_vp, C.c_int]),
+    "bl_ctx_timing_stride": (C.c_int, [_vp, C.c_int]),
     "bl_ctx_timing_get": (C.c_int, [_vp, C.c_int, _P(C.c_double), _P(C.c_int64)]),
     "bl_ctx_timing_reset": (C.c_int, [_vp]),
     "bl_grid_create": (C.c_int, [_vp, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, _P(_vp)]),

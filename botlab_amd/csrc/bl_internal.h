@@ -32,6 +32,7 @@ void bl_set_error(const char* fmt, ...);
 struct bl_timer {
     double total_ms = 0;
     int64_t launches = 0;
+    int64_t seen = 0;                       // launches offered to the timer (timed: every timing_stride-th)
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;   // recorded, not yet read
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pool;
 };
@@ -55,6 +56,7 @@ struct bl_ctx {
     bool own_stream = false;
     bool timing = false;
     unsigned int timing_mask = 0xffffffffu;
+    int timing_stride = 1;
     bl_timer timers[BL_K_COUNT];
     bl_astar_state* astar = nullptr;
     int64_t astar_capacity = 0;

@@ -1128,6 +1128,19 @@ extern "C" void bl_planner_destroy(bl_planner* p)
     delete p;
 }
 
+// map + pose snapshot as ONE kernel on the SLAM stream (two hipMemcpyAsync D2D cost two copy-engine handshakes there)
+__global__ __launch_bounds__(256) void k_planner_snapshot(const int8_t* __restrict__ src, int8_t* __restrict__ dst, size_t n,
+                                                          const bl_pose_xyt_t* __restrict__ src_pose, bl_pose_xyt_t* __restrict__ dst_pose)
+{
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    const size_t n16 = n / 16;
+    const int4* s4 = (const int4*)src;
+    int4* d4 = (int4*)dst;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += stride) d4[i] = s4[i];
+    for (size_t i = n16 * 16 + (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) dst[i] = src[i];
+    if (blockIdx.x == 0 && threadIdx.x == 0) *dst_pose = *src_pose;
+}
+
 extern "C" int bl_planner_submit(bl_planner* p, const bl_grid* map, const void* d_start_pose, const bl_pose_xyt_t* goal,
                                  const bl_search_params_t* params)
 {
@@ -1152,9 +1165,15 @@ extern "C" int bl_planner_submit(bl_planner* p, const bl_grid* map, const void* 
     snap->frame = map->frame;
     // SLAM stream: wait until the lane has finished with this slot, then snapshot map and pose
     if (L.slot_used[slot]) BL_HIP(hipStreamWaitEvent(p->main->stream, L.slot_free[slot], 0));
-    BL_HIP(hipMemcpyAsync(snap->cells, map->cells, (size_t)map->frame.width * map->frame.height, hipMemcpyDeviceToDevice,
-                          p->main->stream));
-    BL_HIP(hipMemcpyAsync(L.pose[slot], d_start_pose, sizeof(bl_pose_xyt_t), hipMemcpyDeviceToDevice, p->main->stream));
+    {
+        const size_t n = (size_t)map->frame.width * map->frame.height;
+        int blocks = (int)((n / 16 + 255) / 256);
+        if (blocks < 1) blocks = 1;
+        if (blocks > 2048) blocks = 2048;
+        hipLaunchKernelGGL(k_planner_snapshot, dim3(blocks), dim3(256), 0, p->main->stream, map->cells, snap->cells, n,
+                           (const bl_pose_xyt_t*)d_start_pose, L.pose[slot]);
+        BL_HIP(hipGetLastError());
+    }
     BL_HIP(hipEventRecord(L.snap_ready[slot], p->main->stream));
     // lane stream: distance grid + search on the snapshot
     BL_HIP(hipStreamWaitEvent(L.side->stream, L.snap_ready[slot], 0));

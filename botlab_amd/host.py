@@ -71,6 +71,10 @@ class Context:
             flag = 1 | (1 << 30)
         check(self.lib.bl_ctx_timing_enable(self.h, flag))
 
+    def timing_stride(self, every):
+        """Time only every `every`-th launch of each enabled kernel."""
+        check(self.lib.bl_ctx_timing_stride(self.h, int(every)))
+
     def timing_reset(self):
         check(self.lib.bl_ctx_timing_reset(self.h))
 

@@ -68,6 +68,9 @@ void bl_ctx_destroy(bl_ctx* ctx);
 int bl_ctx_sync(bl_ctx* ctx);
 /* Per-kernel HIP-event timing on the ctx stream (bench.py's roofline leg).  kernel ids: BL_K_* below. */
 int bl_ctx_timing_enable(bl_ctx* ctx, int on);   /* 0: off; 1: every kernel; else a bit mask, bit i = kernel id i */
+/* Time only every `every`-th launch of each enabled kernel (default 1): an event pair costs ~13 us of stream time per
+ * launch on this stack, which would distort a pipelined step. */
+int bl_ctx_timing_stride(bl_ctx* ctx, int every);
 int bl_ctx_timing_get(bl_ctx* ctx, int kernel_id, double* total_ms, int64_t* launches);
 int bl_ctx_timing_reset(bl_ctx* ctx);
 #define BL_K_MCL_MAIN 0      /* resample-gather + action + sensor model, one thread per particle */
