@@ -5,9 +5,10 @@
 // excluded) subtracting missOdds (saturating at -128).  Because every pass-1 update precedes every pass-2 update and
 // both saturate monotonically, a cell that is the end of H rays and is crossed by M rays ends at
 //     v' = max(-128, min(127, v + hit*H) - miss*M)
-// which is order-independent.  The kernel counts H per end cell (rays are few: a leader thread per distinct end
-// cell) and M per crossed cell in an LDS window (uint16 counters), then applies the closed form with one owner
-// thread per cell -- no global atomics, bit-exact int8 results.
+// which is order-independent.  The kernel counts H per end cell and M per crossed cell in an LDS window (uint16
+// counters; the ray whose increment finds an end cell's counter at zero becomes that cell's leader), walks the rays in
+// independent 16-cell segments spread over all 1024 threads (closed form of the Bresenham variant), then applies the
+// closed form with one owner thread per cell -- no global atomics, bit-exact int8 results.
 //
 // Launch shape: ONE workgroup of 1024 threads.  The whole update touches ~20 KB (290 rays x <=142 cells @5 cm / 5 m);
 // it is latency-bound, not bandwidth-bound, and a single workgroup keeps every phase boundary a __syncthreads().
@@ -64,11 +65,23 @@ __device__ __forceinline__ bool cell_in_grid(const bl_frame& f, int x, int y)
     return x >= 0 && x < f.width && y >= 0 && y < f.height;
 }
 
+// Cell k (k = 0 .. K-1, K = max(dx, dy); start cell included, end cell excluded) of the reference's Bresenham walk
+// (mapping.cpp:101-127: e2 = 2*err; if (e2 >= -dy) {err -= dy; x += sx;} if (e2 <= dx) {err += dx; y += sy;}) has a closed
+// form: the major axis advances k, the minor axis floor((2*k*dmin + dmaj) / (2*dmaj)).  Checked against the loop for every
+// dx, dy < 230 and all sign combinations (tests/tools/bresenham_closed_form.py), so the walk of one ray can be cut
+// into independent segments.
+#define MAP_SEG 16                            // cells per walk segment
+#define MAP_SEG_RAYS 1024                     // rays whose segment table fits the static LDS array (more rays: serial walk per ray)
+
+__device__ __forceinline__ unsigned int half_of(unsigned int pair, int ci) { return (ci & 1) ? (pair >> 16) : (pair & 0xffffu); }
+
 __global__ __launch_bounds__(MAP_THREADS) void k_map_update(map_args a)
 {
     extern __shared__ __align__(16) unsigned int s_cnt[];     // MAP_LDS_COUNTERS/2 dwords, two uint16 counters each
     __shared__ int s_box[4];                                   // xmin, ymin, xmax, ymax over all traced cells
     __shared__ float s_pose[6];                                // prev x,y,theta ; cur x,y,theta
+    __shared__ int s_segp[MAP_SEG_RAYS + 1];                   // exclusive prefix of the rays' segment counts
+    __shared__ int s_wsum[MAP_THREADS / 64];
 
     const int tid = threadIdx.x;
     MSTAMP(0);
@@ -88,9 +101,12 @@ __global__ __launch_bounds__(MAP_THREADS) void k_map_update(map_args a)
 
     const bl_pose3 pb = {s_pose[0], s_pose[1], s_pose[2]};
     const bl_pose3 pe = {s_pose[3], s_pose[4], s_pose[5]};
+    const bool seg_walk = a.R <= MAP_SEG_RAYS;                  // then thread tid owns ray tid in phases A and B
 
     MSTAMP(1);
     // ---- phase A: ray geometry (moving_laser_scan.cpp:22-37, mapping.cpp:45-49)
+    int bx_lo = 0x7fffffff, by_lo = 0x7fffffff, bx_hi = -0x7fffffff, by_hi = -0x7fffffff;
+    int4 my_ray = make_int4(0x7fffffff, 0, 0, 0);
     for (int r = tid; r < a.R; r += MAP_THREADS) {
         int4 ray = make_int4(0, 0, 0, 0);
         int valid = 0;
@@ -108,46 +124,47 @@ __global__ __launch_bounds__(MAP_THREADS) void k_map_update(map_args a)
                 ray.x = (int)sx; ray.y = (int)sy;               // float -> int truncation at the bresenham() call
                 ray.z = (int)fx; ray.w = (int)fy;
                 valid = 1;
-                atomicMin(&s_box[0], min(ray.x, ray.z)); atomicMin(&s_box[1], min(ray.y, ray.w));
-                atomicMax(&s_box[2], max(ray.x, ray.z)); atomicMax(&s_box[3], max(ray.y, ray.w));
+                bx_lo = min(bx_lo, min(ray.x, ray.z)); by_lo = min(by_lo, min(ray.y, ray.w));
+                bx_hi = max(bx_hi, max(ray.x, ray.z)); by_hi = max(by_hi, max(ray.y, ray.w));
             }
         }
         if (!valid) ray.x = 0x7fffffff;
         a.rays[r] = ray;
+        my_ray = ray;
+    }
+    // one LDS atomic per wave and bound (290 lanes hammering four words serialised this phase)
+    for (int off = 32; off > 0; off >>= 1) {
+        bx_lo = min(bx_lo, __shfl_xor(bx_lo, off, 64)); by_lo = min(by_lo, __shfl_xor(by_lo, off, 64));
+        bx_hi = max(bx_hi, __shfl_xor(bx_hi, off, 64)); by_hi = max(by_hi, __shfl_xor(by_hi, off, 64));
+    }
+    if ((tid & 63) == 0 && bx_lo != 0x7fffffff) {
+        atomicMin(&s_box[0], bx_lo); atomicMin(&s_box[1], by_lo);
+        atomicMax(&s_box[2], bx_hi); atomicMax(&s_box[3], by_hi);
+    }
+    // segment table: ray r contributes ceil(K / MAP_SEG) segments, K = max(dx, dy)
+    if (seg_walk) {
+        int segs = 0;
+        if (tid < a.R && my_ray.x != 0x7fffffff) {
+            const int K = max(abs(my_ray.z - my_ray.x), abs(my_ray.w - my_ray.y));
+            segs = (K + MAP_SEG - 1) / MAP_SEG;
+        }
+        int incl = segs;
+        for (int off = 1; off < 64; off <<= 1) {
+            int t = __shfl_up(incl, off, 64);
+            if ((tid & 63) >= off) incl += t;
+        }
+        if ((tid & 63) == 63) s_wsum[tid >> 6] = incl;
+        __syncthreads();
+        int base = 0;
+        for (int w = 0; w < (tid >> 6); ++w) base += s_wsum[w];
+        if (tid < a.R) s_segp[tid] = base + incl - segs;
+        if (tid == a.R - 1) s_segp[a.R] = base + incl;
     }
     __syncthreads();
 
     MSTAMP(2);
-    // ---- phase B: endpoint pass (mapping.cpp:42-57).  One leader per distinct end cell applies min(127, v + hit*H).
-    // The end cells are packed into the (still unused) LDS window so the R x R comparison reads LDS broadcasts.
-    for (int r = tid; r < a.R; r += MAP_THREADS) {
-        int4 me = a.rays[r];
-        const bool ok = me.x != 0x7fffffff && cell_in_grid(a.frame, me.z, me.w);
-        s_cnt[r] = ok ? ((unsigned int)me.w << 16) | (unsigned int)me.z : 0xffffffffu;
-    }
-    __syncthreads();
-    for (int r = tid; r < a.R; r += MAP_THREADS) {
-        const unsigned int me = s_cnt[r];
-        if (me == 0xffffffffu) continue;
-        int H = 0;
-        bool leader = true;
-#pragma unroll 8
-        for (int q = 0; q < a.R; ++q) {
-            const bool same = s_cnt[q] == me;
-            H += same ? 1 : 0;
-            leader = leader && !(same && q < r);
-        }
-        if (leader) {
-            size_t idx = (size_t)(me >> 16) * a.frame.width + (me & 0xffffu);
-            int v = a.cells[idx];
-            v = min(127, v + a.hit * H);
-            a.cells[idx] = (int8_t)v;
-        }
-    }
-    __syncthreads();
-
-    MSTAMP(3);
-    // ---- phase C: free-space pass (mapping.cpp:59-71, 101-127) through an LDS window of miss counters
+    // ---- the update runs through an LDS window of uint16 counters: the bounding box of all ray cells clipped to the grid,
+    // in horizontal strips when it exceeds the LDS budget
     int bx0 = max(s_box[0], 0), by0 = max(s_box[1], 0);
     int bx1 = min(s_box[2], a.frame.width - 1), by1 = min(s_box[3], a.frame.height - 1);
     if (bx1 < bx0 || by1 < by0) return;                         // nothing inside the grid
@@ -164,29 +181,103 @@ __global__ __launch_bounds__(MAP_THREADS) void k_map_update(map_args a)
         const int ncell = (sy1 - sy0 + 1) * ww;
         for (int i = tid; i < (ncell + 1) / 2; i += MAP_THREADS) s_cnt[i] = 0;
         __syncthreads();
-        MSTAMP(4);
-        for (int r = tid; r < a.R; r += MAP_THREADS) {
-            int4 ray = a.rays[r];
-            if (ray.x == 0x7fffffff) continue;
-            int x = ray.x, y = ray.y;
-            const int x2 = ray.z, y2 = ray.w;
-            const int dx = abs(x2 - x), dy = abs(y2 - y);
-            const int sx = x < x2 ? 1 : -1, sy = y < y2 ? 1 : -1;
-            int err = dx - dy;
-            int guard = dx + dy + 2;                             // the walk needs max(dx,dy) steps; bound it regardless
-            while ((x != x2 || y != y2) && guard-- > 0) {
-                if (x >= bx0 && x <= bx1 && y >= sy0 && y <= sy1) {   // window is already clipped to the grid
-                    int ci = (y - sy0) * ww + (x - bx0);
-                    atomicAdd(&s_cnt[ci >> 1], (ci & 1) ? 0x10000u : 1u);
+        // ---- phase B: endpoint pass (mapping.cpp:42-57).  H = rays ending in a cell; the ray whose increment found the
+        // counter at zero is the cell's leader and applies the whole closed form for that cell after the walk.
+        MSTAMP(3);
+        for (int r0 = 0; r0 < a.R; r0 += MAP_THREADS) {         // one round when R <= 1024
+            const int r = r0 + tid;
+            int ci = -1;
+            bool leader = false;
+            if (r < a.R) {
+                const int4 me = seg_walk ? my_ray : a.rays[r];
+                if (me.x != 0x7fffffff && me.z >= bx0 && me.z <= bx1 && me.w >= sy0 && me.w <= sy1) {   // window = clipped grid
+                    ci = (me.w - sy0) * ww + (me.z - bx0);
+                    const unsigned int old = atomicAdd(&s_cnt[ci >> 1], (ci & 1) ? 0x10000u : 1u);
+                    leader = half_of(old, ci) == 0u;
                 }
-                int e2 = 2 * err;                                // float e2 in the reference; exact for these magnitudes
-                if (e2 >= -dy) { err -= dy; x += sx; }
-                if (e2 <= dx) { err += dx; y += sy; }
             }
+            __syncthreads();
+            int H = 0;
+            size_t idx = 0;
+            if (leader) {
+                H = (int)half_of(s_cnt[ci >> 1], ci);
+                const int4 me = seg_walk ? my_ray : a.rays[r];
+                idx = (size_t)me.w * a.frame.width + me.z;
+            }
+            __syncthreads();
+            if (a.R > MAP_THREADS) {
+                // more rays than threads (never the case for a 290-ray lidar): hits of this round go straight to the grid;
+                // the free-space pass of an end cell then sees the already saturated value, as in the reference
+                if (leader) { int v = a.cells[idx]; a.cells[idx] = (int8_t)min(127, v + a.hit * H); }
+                if (ci >= 0) atomicAnd(&s_cnt[ci >> 1], (ci & 1) ? 0x0000ffffu : 0xffff0000u);
+                __syncthreads();
+                continue;
+            }
+            // ---- phase C: free-space pass (mapping.cpp:59-71, 101-127): M = rays crossing a cell
+            for (int i = tid; i < (ncell + 1) / 2; i += MAP_THREADS) s_cnt[i] = 0;
+            __syncthreads();
+            MSTAMP(4);
+            const int nseg = s_segp[a.R];
+            for (int sg = tid; sg < nseg; sg += MAP_THREADS) {
+                int lo = 0, hi = a.R - 1;                       // last ray whose prefix <= sg
+                while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (s_segp[mid] <= sg) lo = mid; else hi = mid - 1; }
+                const int4 ray = a.rays[lo];
+                const int k0 = (sg - s_segp[lo]) * MAP_SEG;
+                const int dx = abs(ray.z - ray.x), dy = abs(ray.w - ray.y);
+                const int sx = ray.x < ray.z ? 1 : -1, sy = ray.y < ray.w ? 1 : -1;
+                const int K = max(dx, dy), k1 = min(K, k0 + MAP_SEG);
+                const bool xmajor = dx >= dy;
+                const int dmaj = xmajor ? dx : dy, dmin = xmajor ? dy : dx;
+                const long long num = 2ll * k0 * dmin + dmaj;
+                int n = (int)(num / (2ll * dmaj));
+                int rem = (int)(num - (long long)n * 2ll * dmaj);
+                for (int k = k0; k < k1; ++k) {
+                    const int x = xmajor ? ray.x + sx * k : ray.x + sx * n;
+                    const int y = xmajor ? ray.y + sy * n : ray.y + sy * k;
+                    if (x >= bx0 && x <= bx1 && y >= sy0 && y <= sy1) {   // window is already clipped to the grid
+                        const int c = (y - sy0) * ww + (x - bx0);
+                        atomicAdd(&s_cnt[c >> 1], (c & 1) ? 0x10000u : 1u);
+                    }
+                    rem += 2 * dmin;
+                    if (rem >= 2 * dmaj) { rem -= 2 * dmaj; n += 1; }
+                }
+            }
+            __syncthreads();
+            MSTAMP(5);
+            // leaders finish their end cell: v' = max(-128, min(127, v + hit*H) - miss*M), then hide it from the window pass
+            if (leader) {
+                const int M = (int)half_of(s_cnt[ci >> 1], ci);
+                int v = a.cells[idx];
+                v = max(-128, min(127, v + a.hit * H) - a.miss * M);
+                a.cells[idx] = (int8_t)v;
+                atomicAnd(&s_cnt[ci >> 1], (ci & 1) ? 0x0000ffffu : 0xffff0000u);
+            }
+            __syncthreads();
         }
-        __syncthreads();
-        MSTAMP(5);
-        // apply: thread (tx, ty) owns column bx0 + tx (+256, ...) and every 4th row; 8 rows per batch so the byte loads
+        if (a.R > MAP_THREADS) {
+            // serial walk per ray (the pre-segment form), all hits already applied
+            for (int r = tid; r < a.R; r += MAP_THREADS) {
+                int4 ray = a.rays[r];
+                if (ray.x == 0x7fffffff) continue;
+                int x = ray.x, y = ray.y;
+                const int x2 = ray.z, y2 = ray.w;
+                const int dx = abs(x2 - x), dy = abs(y2 - y);
+                const int sx = x < x2 ? 1 : -1, sy = y < y2 ? 1 : -1;
+                int err = dx - dy;
+                int guard = dx + dy + 2;
+                while ((x != x2 || y != y2) && guard-- > 0) {
+                    if (x >= bx0 && x <= bx1 && y >= sy0 && y <= sy1) {
+                        int c = (y - sy0) * ww + (x - bx0);
+                        atomicAdd(&s_cnt[c >> 1], (c & 1) ? 0x10000u : 1u);
+                    }
+                    int e2 = 2 * err;
+                    if (e2 >= -dy) { err -= dy; x += sx; }
+                    if (e2 <= dx) { err += dx; y += sy; }
+                }
+            }
+            __syncthreads();
+        }
+        // window pass: thread (tx, ty) owns column bx0 + tx (+256, ...) and every 4th row; 8 rows per batch so the byte loads
         // of a batch are in flight together (a serial load -> store chain per cell cost ~1 us per cell per thread)
         const int tx = tid & 255, ty = tid >> 8;
         const int nrows = sy1 - sy0 + 1;
@@ -198,9 +289,8 @@ __global__ __launch_bounds__(MAP_THREADS) void k_map_update(map_args a)
                     const int ry = r0 + 4 * u;
                     M[u] = 0;
                     if (ry < nrows) {
-                        const int ci = ry * ww + cx;
-                        const unsigned int pair = s_cnt[ci >> 1];
-                        M[u] = (ci & 1) ? (int)(pair >> 16) : (int)(pair & 0xffffu);
+                        const int ci2 = ry * ww + cx;
+                        M[u] = (int)half_of(s_cnt[ci2 >> 1], ci2);
                     }
                 }
 #pragma unroll
