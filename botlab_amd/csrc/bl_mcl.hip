@@ -56,7 +56,6 @@ struct bl_pf {
     bool use_lds;
     int last_blocks, last_tile;   // launch shape of the last k_mcl_main
     bool fused_finish, no_fused_finish;
-    unsigned long long* tile_offsets; // [partials_cap]
     int split_log2_override;  // -1: automatic
     int block_override;       // 0: automatic
     bool debug;               // record resample index / likelihood per particle (parity tests)
@@ -492,63 +491,27 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan_write_prefix(const float4
 
 // Single-shard fast path (the whole particle set on this device): k_mcl_main's per-workgroup partials already hold the
 // weight-unit sum of each workgroup's particles, i.e. the tile sums of a prefix scan whose tile is "particles per
-// k_mcl_main workgroup".  k_mcl_finish (one workgroup) reduces the five partial sums in a fixed order, scans the tile
-// sums and forms the pose estimate; k_scan_write_prefix_tile writes the prefix.  Two launches instead of five.
-__global__ __launch_bounds__(1024) void k_mcl_finish(const double* __restrict__ partials, int nblocks,
-                                                     unsigned long long* __restrict__ tile_offsets, pf_state* state, int64_t utime)
-{
-    __shared__ double s_red[1024 / 64][5];
-    __shared__ unsigned long long s_wave[16];
-    __shared__ unsigned long long s_carry;
-    // ---- five sums, fixed order: thread-strided partial sums, then wave shuffles, then 16 wave results in order
-    double v[5] = {0, 0, 0, 0, 0};
-    for (int b = threadIdx.x; b < nblocks; b += 1024)
-        for (int k = 0; k < 5; ++k) v[k] += partials[(size_t)b * 5 + k];
-    for (int k = 0; k < 5; ++k) v[k] = wave_sum(v[k]);
-    if ((threadIdx.x & 63) == 0) for (int k = 0; k < 5; ++k) s_red[threadIdx.x >> 6][k] = v[k];
-    if (threadIdx.x == 0) s_carry = 0;
-    __syncthreads();
-    double tot[5] = {0, 0, 0, 0, 0};
-    if (threadIdx.x == 0) {
-        for (int w = 0; w < 16; ++w) for (int k = 0; k < 5; ++k) tot[k] += s_red[w][k];
-    }
-    // ---- exclusive scan of the tile sums (partials[b][0] is an exact integer below 2^53)
-    for (int base = 0; base < nblocks; base += 1024) {
-        int idx = base + threadIdx.x;
-        unsigned long long t = idx < nblocks ? (unsigned long long)partials[(size_t)idx * 5] : 0ull;
-        unsigned long long incl = t;
-        for (int off = 1; off < 64; off <<= 1) {
-            unsigned long long u = __shfl_up(incl, off, 64);
-            if ((threadIdx.x & 63) >= off) incl += u;
-        }
-        if ((threadIdx.x & 63) == 63) s_wave[threadIdx.x >> 6] = incl;
-        __syncthreads();
-        unsigned long long wave_off = 0;
-        for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) wave_off += s_wave[w];
-        unsigned long long carry = s_carry;
-        if (idx < nblocks) tile_offsets[idx] = carry + wave_off + incl - t;
-        __syncthreads();
-        if (threadIdx.x == 1023) s_carry = carry + wave_off + incl;
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) {
-        state->S = (double)s_carry;
-        bl_pose_xyt_t p;
-        p.utime = utime;
-        p.x = (float)(tot[1] / tot[0]);
-        p.y = (float)(tot[2] / tot[0]);
-        p.theta = (float)atan2(tot[3], tot[4]);
-        state->pose = p;
-        for (int k = 0; k < 5; ++k) state->sums_used[k] = tot[k];
-    }
-}
-
-// tile = particles per tile (<= 2048); one workgroup of 256 threads per tile
-__global__ __launch_bounds__(SCAN_THREADS) void k_scan_write_prefix_tile(const float4* __restrict__ rec, int N, int tile,
-                                                                         const unsigned long long* __restrict__ tile_offsets,
-                                                                         unsigned long long* __restrict__ prefix)
+// k_mcl_main workgroup".
+// ONE launch: workgroup b (256 threads, tile b) forms its own tile offset as the exact integer sum of the unit sums of
+// the tiles before it (<= a few thousand L2-resident values), scans its tile and writes the prefix; workgroup 0 also
+// reduces the five partial sums in a fixed order and forms the pose estimate (estimatePosteriorPose,
+// particle_filter.cpp:144-160).  No workgroup waits on another, so nothing separates this from k_mcl_main but one
+// kernel boundary (a dependent single-workgroup launch costs ~6 us here).
+__global__ __launch_bounds__(SCAN_THREADS) void k_mcl_finish_prefix(const double* __restrict__ partials, int nblocks,
+                                                                    const float4* __restrict__ rec, int N, int tile,
+                                                                    unsigned long long* __restrict__ prefix, pf_state* state,
+                                                                    int64_t utime)
 {
     __shared__ unsigned long long s_wave[SCAN_THREADS / 64];
+    __shared__ unsigned long long s_off[SCAN_THREADS / 64];
+    __shared__ double s_red[SCAN_THREADS / 64][5];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // ---- tile offset: sum of partials[j][0] (exact integers below 2^53) over the tiles j < blockIdx.x
+    unsigned long long before = 0;
+    for (int j = threadIdx.x; j < (int)blockIdx.x; j += SCAN_THREADS) before += (unsigned long long)partials[(size_t)j * 5];
+    for (int off = 32; off > 0; off >>= 1) before += __shfl_xor(before, off, 64);
+    if (lane == 0) s_off[wave] = before;
+    // ---- local inclusive scan of the tile
     const int ipt = (tile + SCAN_THREADS - 1) / SCAN_THREADS;                 // items per thread (<= 8)
     const int tile_lo = blockIdx.x * tile;
     const int tile_hi = min(N, tile_lo + tile);
@@ -562,14 +525,34 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan_write_prefix_tile(const f
     unsigned long long incl = run;
     for (int off = 1; off < 64; off <<= 1) {
         unsigned long long t = __shfl_up(incl, off, 64);
-        if ((threadIdx.x & 63) >= off) incl += t;
+        if (lane >= off) incl += t;
     }
-    if ((threadIdx.x & 63) == 63) s_wave[threadIdx.x >> 6] = incl;
+    if (lane == 63) s_wave[wave] = incl;
+    // ---- workgroup 0: the five sums, fixed order (thread-strided, wave shuffles, waves in order)
+    if (blockIdx.x == 0) {
+        double v[5] = {0, 0, 0, 0, 0};
+        for (int b = threadIdx.x; b < nblocks; b += SCAN_THREADS)
+            for (int k = 0; k < 5; ++k) v[k] += partials[(size_t)b * 5 + k];
+        for (int k = 0; k < 5; ++k) v[k] = wave_sum(v[k]);
+        if (lane == 0) for (int k = 0; k < 5; ++k) s_red[wave][k] = v[k];
+    }
     __syncthreads();
-    unsigned long long off0 = tile_offsets[blockIdx.x] + incl - run;
-    for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) off0 += s_wave[w];
+    unsigned long long off0 = incl - run;
+    for (int w = 0; w < SCAN_THREADS / 64; ++w) { off0 += s_off[w]; if (w < wave) off0 += s_wave[w]; }
     for (int k = 0; k < SCAN_ITEMS; ++k)
         if (k < ipt && base + k < tile_hi) prefix[base + k] = off0 + loc[k];
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        double tot[5] = {0, 0, 0, 0, 0};
+        for (int w = 0; w < SCAN_THREADS / 64; ++w) for (int k = 0; k < 5; ++k) tot[k] += s_red[w][k];
+        state->S = tot[0];                                   // the unit total: an exact integer below 2^53, any order gives it
+        bl_pose_xyt_t p;
+        p.utime = utime;
+        p.x = (float)(tot[1] / tot[0]);
+        p.y = (float)(tot[2] / tot[0]);
+        p.theta = (float)atan2(tot[3], tot[4]);
+        state->pose = p;
+        for (int k = 0; k < 5; ++k) state->sums_used[k] = tot[k];
+    }
 }
 
 // ---------------------------------------------------------------- init / export / small state kernels
@@ -623,7 +606,6 @@ static int pf_alloc(bl_pf* pf)
     int blocks = (int)((n * 64 + 255) / 256) + 1;          // worst case: every particle spread over a whole wave, 256-thread blocks
     BL_HIP(hipMalloc((void**)&pf->partials, (size_t)blocks * 5 * sizeof(double)));
     pf->partials_cap = blocks;
-    BL_HIP(hipMalloc((void**)&pf->tile_offsets, (size_t)blocks * sizeof(unsigned long long)));
     static bool attr_set = false;
     if (!attr_set) {
         const int big = MCL_WIN_BIG * MCL_WIN_BIG;
@@ -667,7 +649,7 @@ extern "C" void bl_pf_destroy(bl_pf* pf)
     if (!pf) return;
     (void)hipStreamSynchronize(pf->ctx->stream);
     if (!pf->rec_external) { if (pf->rec[0]) (void)hipFree(pf->rec[0]); if (pf->rec[1]) (void)hipFree(pf->rec[1]); }
-    void* ptrs[] = {pf->tile_pose, pf->prefix, pf->parent, pf->state, pf->partials, pf->tile_offsets, pf->block_sums, pf->dbg_idx, pf->dbg_like,
+    void* ptrs[] = {pf->tile_pose, pf->prefix, pf->parent, pf->state, pf->partials, pf->block_sums, pf->dbg_idx, pf->dbg_like,
                     pf->d_noise, pf->d_export};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     bl_scan_free(&pf->scan);
@@ -900,10 +882,8 @@ static int pf_finish_fused(bl_pf* pf, int which, int64_t utime)
     hipEvent_t e0, e1;
     int rc = bl_timer_begin(ctx, BL_K_MCL_SCAN, &e0, &e1);
     if (rc) return rc;
-    hipLaunchKernelGGL(k_mcl_finish, dim3(1), dim3(1024), 0, ctx->stream, pf->partials, pf->last_blocks, pf->tile_offsets,
-                       pf->state, utime);
-    hipLaunchKernelGGL(k_scan_write_prefix_tile, dim3(pf->last_blocks), dim3(SCAN_THREADS), 0, ctx->stream, pf->rec[which], pf->N,
-                       pf->last_tile, pf->tile_offsets, pf->prefix);
+    hipLaunchKernelGGL(k_mcl_finish_prefix, dim3(pf->last_blocks), dim3(SCAN_THREADS), 0, ctx->stream, pf->partials, pf->last_blocks,
+                       pf->rec[which], pf->N, pf->last_tile, pf->prefix, pf->state, utime);
     BL_HIP(hipGetLastError());
     return bl_timer_end(ctx, BL_K_MCL_SCAN, e0, e1);
 }
