@@ -184,9 +184,12 @@ def main():
         o = odo[k + 1]
         sc = scans[k]
         spf.updateFilter(bl.make_pose(o[0], o[1], o[2], utime=sc.utime), sc, grid, int(rands[k]), want_pose=False)
-        mapper.updateMapDevicePose(sc, pose_dev, sc.utime, grid)
         if goal_pose is not None:
-            aplanner.submit(grid, pose_dev, goal_pose)          # snapshot map + pose; setDistances + search_for_path overlap the next step
+            # updateMap with the device-resident pose, then snapshot map + pose for the replanner (one library call);
+            # setDistances + search_for_path overlap the next step on a replanner lane
+            aplanner.submit_with_map_update(mapper, sc, pose_dev, sc.utime, grid, goal_pose)
+        else:
+            mapper.updateMapDevicePose(sc, pose_dev, sc.utime, grid)
         in_flight.append(k)
 
     def fetch():

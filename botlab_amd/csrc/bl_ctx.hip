@@ -57,6 +57,7 @@ extern "C" void bl_ctx_destroy(bl_ctx* ctx)
     (void)hipStreamSynchronize(ctx->stream);
     bl_astar_free(ctx);
     bl_frontier_scratch_free(ctx);
+    bl_scan_free(ctx);
     for (int i = 0; i < BL_K_COUNT; ++i) {
         for (auto& p : ctx->timers[i].pending) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
         for (auto& p : ctx->timers[i].pool) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
@@ -151,23 +152,22 @@ extern "C" int bl_ctx_timing_reset(bl_ctx* ctx)
 }
 
 // ---------------------------------------------------------------- scan staging
-// One lidar_t (lcmtypes/lidar_t.lcm) is packed [ranges | thetas | ratio] into a pinned slot and copied with one
-// async H2D.  ratio[n] = (double)(times[n] - begin) / (double)(end - begin) is the interpolateRatio of
-// interpolate_pose_by_time (src/common/interpolation.hpp:35) for the (begin, end) pose pair of this call; it is the
-// same for every particle / every ray origin, so it is formed once on the host.
+// One lidar_t (lcmtypes/lidar_t.lcm) is packed [times | ranges | thetas] (kept rays only) into a pinned slot and pulled
+// into the ctx's device block by a one-workgroup kernel.  A scan identical to the previous one (same kept rays, bit for
+// bit: the two calls of one SLAM step) is not fetched again.
 static const int kScanSlots = 16;
 
-// The scan block is pulled out of the pinned slot by a one-workgroup kernel instead of a hipMemcpyAsync: on the SLAM stream
-// every kernel <-> copy-engine transition costs ~7 us of queue handshake, a kernel -> kernel transition costs none.
+// The scan block is pulled out of the pinned slot by a kernel instead of a hipMemcpyAsync: on the SLAM stream every
+// kernel <-> copy-engine transition costs ~7 us of queue handshake, a kernel -> kernel transition costs none.
 // When the block has been read, the kernel publishes its sequence number to a pinned word: the host reuses a slot once
 // the number has passed the slot's last use -- no HIP event (an event record costs ~6.5 us of stream time here).
-__global__ __launch_bounds__(256) void k_scan_fetch(const double* __restrict__ h_ratio, const float* __restrict__ h_ranges,
-                                                    const float* __restrict__ h_thetas, int kept, double* __restrict__ d_ratio,
+__global__ __launch_bounds__(256) void k_scan_fetch(const int64_t* __restrict__ h_times, const float* __restrict__ h_ranges,
+                                                    const float* __restrict__ h_thetas, int kept, int64_t* __restrict__ d_times,
                                                     float* __restrict__ d_ranges, float* __restrict__ d_thetas,
                                                     unsigned long long* h_seq, unsigned long long seq)
 {
     for (int i = threadIdx.x; i < kept; i += 256) {
-        d_ratio[i] = h_ratio[i];
+        d_times[i] = h_times[i];
         d_ranges[i] = h_ranges[i];
         d_thetas[i] = h_thetas[i];
     }
@@ -183,6 +183,7 @@ struct bl_scan_slots {
     unsigned long long* h_seq;           // pinned: sequence number of the last COMPLETED fetch (written by the kernel)
     unsigned long long* h_seq_dev;
     int next;
+    int last;                            // slot holding the scan that is in the device block (-1: none)
 };
 
 // wait until fetch number `seq` has read its slot (fetches complete in stream order)
@@ -197,27 +198,28 @@ static int scan_wait_seq(bl_scan_slots* sl, unsigned long long seq)
     return BL_OK;
 }
 
-int bl_scan_upload(bl_ctx* ctx, bl_scan_dev* sd, const bl_lidar_t* scan, int64_t begin_utime, int64_t end_utime,
-                   int* num_rays)
+int bl_scan_upload(bl_ctx* ctx, const bl_lidar_t* scan, int* num_rays)
 {
     BL_CHECK_ARG(scan != nullptr && scan->num_ranges >= 0);
+    bl_scan_dev* sd = &ctx->scan;
     int R = scan->num_ranges;
-    *num_rays = R;
-    if (R == 0) return BL_OK;
+    *num_rays = 0;
+    if (R == 0) { sd->kept = 0; if (sd->staging) ((bl_scan_slots*)sd->staging)->last = -1; return BL_OK; }
     BL_CHECK_ARG(scan->ranges && scan->thetas && scan->times);
-    size_t per = (size_t)R * (4 + 4 + 8);
     if (R > sd->capacity) {
         int cap = R < 512 ? 512 : R;
-        bl_scan_free(sd);
-        size_t bytes = (size_t)cap * (4 + 4 + 8);
+        BL_HIP(hipStreamSynchronize(ctx->stream));
+        bl_scan_free(ctx);
+        size_t bytes = (size_t)cap * (8 + 4 + 4);
         char* d = nullptr;
         BL_HIP(hipMalloc((void**)&d, bytes));
         sd->capacity = cap;
-        sd->ratio = (double*)d;                                  // 8-byte aligned part first
+        sd->times = (int64_t*)d;                                 // 8-byte aligned part first
         sd->ranges = (float*)(d + (size_t)cap * 8);
         sd->thetas = (float*)(d + (size_t)cap * 12);
         bl_scan_slots* sl = new bl_scan_slots();
         memset(sl, 0, sizeof(*sl));
+        sl->last = -1;
         sd->staging_bytes = bytes;
         for (int i = 0; i < kScanSlots; ++i) {
             BL_HIP(hipHostMalloc(&sl->host[i], bytes, hipHostMallocDefault));
@@ -229,42 +231,47 @@ int bl_scan_upload(bl_ctx* ctx, bl_scan_dev* sd, const bl_lidar_t* scan, int64_t
         sd->staging = sl;
     }
     bl_scan_slots* sl = (bl_scan_slots*)sd->staging;
-    int s = sl->next;
-    sl->next = (s + 1) % kScanSlots;
+    const int s = sl->next;
     { int wrc = scan_wait_seq(sl, sl->slot_seq[s]); if (wrc) return wrc; }
     char* h = (char*)sl->host[s];
-    size_t cap = (size_t)sd->capacity;
-    double* hr = (double*)h;
+    const size_t cap = (size_t)sd->capacity;
+    int64_t* ht = (int64_t*)h;
     float* hrange = (float*)(h + cap * 8);
     float* htheta = (float*)(h + cap * 12);
     // MovingLaserScan keeps a ray only if its range exceeds 0.15f (moving_laser_scan.cpp:24); the kept rays are packed
     // in scan order, so no kernel branches on validity.
-    const double den = (begin_utime != end_utime) ? (double)(end_utime - begin_utime) : 1.0;
     int kept = 0;
     for (int n = 0; n < R; ++n) {
         if (!(scan->ranges[n] > 0.15f)) continue;
         hrange[kept] = scan->ranges[n];
         htheta[kept] = scan->thetas[n];
-        hr[kept] = (begin_utime != end_utime) ? (double)(scan->times[n] - begin_utime) / den : 0.0;
+        ht[kept] = scan->times[n];
         ++kept;
     }
     *num_rays = kept;
-    (void)per;
-    // host slot and device block share one layout
-    if (kept > 0) {
-        const char* hd = (const char*)sl->host_dev[s];
-        hipLaunchKernelGGL(k_scan_fetch, dim3(1), dim3(256), 0, ctx->stream, (const double*)hd, (const float*)(hd + cap * 8),
-                           (const float*)(hd + cap * 12), kept, sd->ratio, sd->ranges, sd->thetas, sl->h_seq_dev, sl->seq + 1);
-        BL_HIP(hipGetLastError());
-        sl->seq += 1;
-        sl->slot_seq[s] = sl->seq;
+    if (kept == 0) { sd->kept = 0; sl->last = -1; return BL_OK; }
+    if (sl->last >= 0 && sd->kept == kept) {                     // the same scan as the one in the device block?
+        const char* p = (const char*)sl->host[sl->last];
+        if (memcmp(p, h, (size_t)kept * 8) == 0 && memcmp(p + cap * 8, hrange, (size_t)kept * 4) == 0 &&
+            memcmp(p + cap * 12, htheta, (size_t)kept * 4) == 0)
+            return BL_OK;                                        // slot s stays free for the next scan
     }
+    const char* hd = (const char*)sl->host_dev[s];
+    hipLaunchKernelGGL(k_scan_fetch, dim3(1), dim3(256), 0, ctx->stream, (const int64_t*)hd, (const float*)(hd + cap * 8),
+                       (const float*)(hd + cap * 12), kept, sd->times, sd->ranges, sd->thetas, sl->h_seq_dev, sl->seq + 1);
+    BL_HIP(hipGetLastError());
+    sl->seq += 1;
+    sl->slot_seq[s] = sl->seq;
+    sl->last = s;
+    sl->next = (s + 1) % kScanSlots;
+    sd->kept = kept;
     return BL_OK;
 }
 
-void bl_scan_free(bl_scan_dev* sd)
+void bl_scan_free(bl_ctx* ctx)
 {
-    if (sd->ratio) (void)hipFree(sd->ratio);
+    bl_scan_dev* sd = &ctx->scan;
+    if (sd->times) (void)hipFree(sd->times);
     if (sd->staging) {
         bl_scan_slots* sl = (bl_scan_slots*)sd->staging;
         (void)scan_wait_seq(sl, sl->seq);                 // no fetch still reads a slot
@@ -273,8 +280,8 @@ void bl_scan_free(bl_scan_dev* sd)
         if (sl->h_seq) (void)hipHostFree(sl->h_seq);
         delete sl;
     }
-    sd->capacity = 0;
-    sd->ratio = nullptr; sd->ranges = nullptr; sd->thetas = nullptr; sd->staging = nullptr;
+    sd->capacity = 0; sd->kept = 0;
+    sd->times = nullptr; sd->ranges = nullptr; sd->thetas = nullptr; sd->staging = nullptr;
 }
 
 // ---------------------------------------------------------------- OccupancyGrid (src/slam/occupancy_grid.cpp)

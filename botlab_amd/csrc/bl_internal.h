@@ -37,14 +37,16 @@ struct bl_timer {
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pool;
 };
 
-// device-side scan description shared by the mapping and the MCL kernels (uploaded once per scan)
+// device-side scan block of a ctx, shared by the mapping and the MCL kernels: the kept rays of the last lidar_t handed to
+// either of them.  A call that brings the same scan again (updateFilter then updateMap of one SLAM step) reuses it.
 struct bl_scan_dev {
     int capacity = 0;        // rays allocated
     float* ranges = nullptr;
     float* thetas = nullptr;
-    double* ratio = nullptr; // per-ray interpolation ratio for the current (begin, end) utime pair
-    void* staging = nullptr; // pinned host staging: ranges | thetas | ratio
+    int64_t* times = nullptr;   // per-ray time stamps: interpolateRatio = (double)(t - begin) / (double)(end - begin) is formed in the kernels
+    void* staging = nullptr;    // pinned host slots: times | ranges | thetas
     size_t staging_bytes = 0;
+    int kept = 0;               // rays in the block
 };
 
 struct bl_astar_state;
@@ -62,6 +64,7 @@ struct bl_ctx {
     int64_t astar_capacity = 0;
     bool astar_small_lds = false;      // k_astar with the 40 KB LDS footprint (co-running searches)
     bl_frontier_scratch* frontier = nullptr;
+    bl_scan_dev scan;
 };
 
 // find_map_frontiers' result: frontier k = cells offsets[k]..offsets[k+1] of xy (x, y per cell, global metres)
@@ -77,11 +80,24 @@ struct bl_grid {
     int8_t* cells;      // device
 };
 
+// where a replanner submission wants its map + pose snapshot, and the number to publish in *flag when it is complete
+struct bl_planner_snap {
+    int8_t* cells; bl_pose_xyt_t* pose;
+    unsigned long long* flag; unsigned long long seq;
+    unsigned int* done_count;
+};
+int bl_planner_reserve(bl_planner* p, const bl_grid* map, bl_planner_snap* out);                    // bl_planning.hip
+int bl_planner_commit(bl_planner* p, const bl_pose_xyt_t* goal, const bl_search_params_t* params);
+void bl_planner_cancel(bl_planner* p);
+
 // RAII-less helpers
 int bl_timer_begin(bl_ctx* ctx, int id, hipEvent_t* a, hipEvent_t* b);
 int bl_timer_end(bl_ctx* ctx, int id, hipEvent_t a, hipEvent_t b);
-int bl_scan_upload(bl_ctx* ctx, bl_scan_dev* sd, const bl_lidar_t* scan, int64_t begin_utime, int64_t end_utime,
-                   int* num_rays);
-void bl_scan_free(bl_scan_dev* sd);
+int bl_scan_upload(bl_ctx* ctx, const bl_lidar_t* scan, int* num_rays);
+void bl_scan_free(bl_ctx* ctx);
+
+// interpolateRatio of interpolate_pose_by_time (src/common/interpolation.hpp:35) for a ray stamped t and the pose pair
+// (begin, end), den = (double)(end - begin)
+__host__ __device__ inline double bl_interp_ratio(int64_t t, int64_t begin, double den) { return (double)(t - begin) / den; }
 
 #endif

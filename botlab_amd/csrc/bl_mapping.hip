@@ -32,7 +32,6 @@ struct bl_mapping {
     bl_pose_xyt_t* d_prev;      // previousPose_ (device)
     int4* d_rays;               // scratch: (x0, y0, x1, y1) per ray
     int ray_capacity;
-    bl_scan_dev scan;
 };
 
 struct map_args {
@@ -40,7 +39,8 @@ struct map_args {
     bl_frame frame;
     const float* ranges;
     const float* thetas;
-    const double* ratio;
+    const int64_t* times;           // per-ray stamps; interpolateRatio = (t - t_begin) / t_den
+    int64_t t_begin; double t_den;
     int R;
     bl_pose_xyt_t* prev;            // device previousPose_
     const bl_pose_xyt_t* cur_dev;   // device pose of this update, or null
@@ -52,6 +52,10 @@ struct map_args {
     int hit, miss;
     int4* rays;
     long long* stamps;              // diagnostic build only (-DBL_MAP_STAMPS)
+    // optional tail: copy the updated grid and the pose to a replanner snapshot and publish its submission number
+    // (bl_planner_submit_with_map_update: saves a dependent launch on the SLAM stream)
+    int8_t* snap_cells; bl_pose_xyt_t* snap_pose; const bl_pose_xyt_t* snap_pose_src;
+    unsigned long long* snap_flag; unsigned long long snap_seq;
 };
 
 #ifdef BL_MAP_STAMPS
@@ -75,7 +79,35 @@ __device__ __forceinline__ bool cell_in_grid(const bl_frame& f, int x, int y)
 
 __device__ __forceinline__ unsigned int half_of(unsigned int pair, int ci) { return (ci & 1) ? (pair >> 16) : (pair & 0xffffu); }
 
+__device__ void map_update_body(const map_args& a);
+
 __global__ __launch_bounds__(MAP_THREADS) void k_map_update(map_args a)
+{
+    map_update_body(a);                                         // every return inside is uniform over the workgroup
+    if (a.snap_cells) {
+        __syncthreads();                                        // the grid stores of this workgroup are visible to its own loads
+        const size_t n = (size_t)a.frame.width * a.frame.height;
+        const size_t n16 = n / 16;
+        const int4* s4 = (const int4*)a.cells;
+        int4* d4 = (int4*)a.snap_cells;
+        for (size_t base = 0; base < n16; base += 4 * MAP_THREADS) {       // four loads in flight per thread, then the stores
+            int4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { const size_t i = base + (size_t)u * MAP_THREADS + threadIdx.x; if (i < n16) v[u] = s4[i]; }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { const size_t i = base + (size_t)u * MAP_THREADS + threadIdx.x; if (i < n16) d4[i] = v[u]; }
+        }
+        for (size_t i = n16 * 16 + threadIdx.x; i < n; i += MAP_THREADS) a.snap_cells[i] = a.cells[i];
+        if (threadIdx.x == 0) *a.snap_pose = *a.snap_pose_src;
+        if (a.snap_flag) {                                              // flag hand-off only; an event hand-off needs nothing here
+            __threadfence();
+            __syncthreads();
+            if (threadIdx.x == 0) __hip_atomic_store(a.snap_flag, a.snap_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+}
+
+__device__ void map_update_body(const map_args& a)
 {
     extern __shared__ __align__(16) unsigned int s_cnt[];     // MAP_LDS_COUNTERS/2 dwords, two uint16 counters each
     __shared__ int s_box[4];                                   // xmin, ymin, xmax, ymax over all traced cells
@@ -112,7 +144,7 @@ __global__ __launch_bounds__(MAP_THREADS) void k_map_update(map_args a)
         int valid = 0;
         float range = a.ranges[r];
         if (range <= a.max_laser) {                             // rays with range <= 0.15f were dropped on the host
-            bl_pose3 rp = a.interp ? bl_interpolate_pose(pb, pe, a.ratio[r]) : pe;
+            bl_pose3 rp = a.interp ? bl_interpolate_pose(pb, pe, bl_interp_ratio(a.times[r], a.t_begin, a.t_den)) : pe;
             float theta = bl_wrap_to_pi(rp.theta - a.thetas[r]);
             float sn, cs, sx, sy;
             bl_sincosf(theta, &sn, &cs);
@@ -336,14 +368,15 @@ extern "C" void bl_mapping_destroy(bl_mapping* m)
 {
     if (!m) return;
     (void)hipStreamSynchronize(m->ctx->stream);
-    bl_scan_free(&m->scan);
     (void)hipFree(m->d_prev);
     if (m->d_rays) (void)hipFree(m->d_rays);
     delete m;
 }
 
+#define MAP_SNAPSHOT_IN_KERNEL_CELLS (256 * 1024)      // larger grids: one workgroup would copy for too long
+
 static int mapping_update_impl(bl_mapping* m, const bl_lidar_t* scan, const bl_pose_xyt_t* h_pose, const void* d_pose,
-                               int64_t pose_utime, bl_grid* map)
+                               int64_t pose_utime, bl_grid* map, const bl_planner_snap* snap = nullptr)
 {
     BL_CHECK_ARG(m != nullptr && scan != nullptr && map != nullptr);
     BL_CHECK_ARG(scan->num_ranges >= 0 && scan->num_ranges <= MAP_MAX_RAYS);
@@ -352,7 +385,7 @@ static int mapping_update_impl(bl_mapping* m, const bl_lidar_t* scan, const bl_p
     BL_HIP(hipSetDevice(ctx->device));
     int64_t begin = m->initialized ? m->prev_utime : pose_utime;
     int R = 0;
-    int rc = bl_scan_upload(ctx, &m->scan, scan, begin, pose_utime, &R);
+    int rc = bl_scan_upload(ctx, scan, &R);
     if (rc) return rc;
     if (R > m->ray_capacity) {
         if (m->d_rays) { BL_HIP(hipStreamSynchronize(ctx->stream)); BL_HIP(hipFree(m->d_rays)); }
@@ -363,7 +396,8 @@ static int mapping_update_impl(bl_mapping* m, const bl_lidar_t* scan, const bl_p
     map_args a;
     a.cells = map->cells;
     a.frame = map->frame;
-    a.ranges = m->scan.ranges; a.thetas = m->scan.thetas; a.ratio = m->scan.ratio;
+    a.ranges = ctx->scan.ranges; a.thetas = ctx->scan.thetas; a.times = ctx->scan.times;
+    a.t_begin = begin; a.t_den = (begin != pose_utime) ? (double)(pose_utime - begin) : 1.0;
     a.R = R;
     a.prev = m->d_prev;
     a.cur_dev = (const bl_pose_xyt_t*)d_pose;
@@ -375,6 +409,11 @@ static int mapping_update_impl(bl_mapping* m, const bl_lidar_t* scan, const bl_p
     a.hit = m->hit; a.miss = m->miss;
     a.rays = m->d_rays;
     a.stamps = nullptr;
+    a.snap_cells = nullptr; a.snap_pose = nullptr; a.snap_pose_src = nullptr; a.snap_flag = nullptr; a.snap_seq = 0;
+    if (snap) {
+        a.snap_cells = snap->cells; a.snap_pose = snap->pose; a.snap_pose_src = (const bl_pose_xyt_t*)d_pose;
+        a.snap_flag = snap->flag; a.snap_seq = snap->seq;
+    }
 #ifdef BL_MAP_STAMPS
     static long long* d_st = nullptr;
     if (!d_st) BL_HIP(hipMalloc((void**)&d_st, 64));
@@ -411,4 +450,24 @@ extern "C" int bl_mapping_update_dev_pose(bl_mapping* m, const bl_lidar_t* scan,
 {
     BL_CHECK_ARG(d_pose != nullptr);
     return mapping_update_impl(m, scan, nullptr, d_pose, pose_utime, map);
+}
+
+// Mapping::updateMap with the pose read on the device, followed by a replanner submission (bl_planner_submit) whose map +
+// pose snapshot is taken by the map kernel itself when the grid is small enough for one workgroup to copy.
+extern "C" int bl_planner_submit_with_map_update(bl_planner* p, bl_mapping* m, const bl_lidar_t* scan, const void* d_pose,
+                                                 int64_t pose_utime, bl_grid* map, const bl_pose_xyt_t* goal,
+                                                 const bl_search_params_t* params)
+{
+    BL_CHECK_ARG(p != nullptr && m != nullptr && d_pose != nullptr && map != nullptr && goal != nullptr && params != nullptr);
+    if ((size_t)map->frame.width * map->frame.height > (size_t)MAP_SNAPSHOT_IN_KERNEL_CELLS) {
+        int rc = mapping_update_impl(m, scan, nullptr, d_pose, pose_utime, map);
+        if (rc) return rc;
+        return bl_planner_submit(p, map, d_pose, goal, params);
+    }
+    bl_planner_snap sn;
+    int rc = bl_planner_reserve(p, map, &sn);
+    if (rc) return rc;
+    rc = mapping_update_impl(m, scan, nullptr, d_pose, pose_utime, map, &sn);
+    if (rc) { bl_planner_cancel(p); return rc; }
+    return bl_planner_commit(p, goal, params);
 }

@@ -65,7 +65,6 @@ struct bl_pf {
     int32_t* dbg_like;
     float* d_noise;           // 3 * n_local (parity mode)
     bl_particle_t* d_export;  // n_local
-    bl_scan_dev scan;
     // uniform utimes of the particle set (every particle carries the same pair; DESIGN.md "Particle utimes")
     int64_t pose_utime, parent_utime;
     // ActionModel state (action_model.hpp:60-78)
@@ -156,7 +155,8 @@ struct mcl_args {
     bl_frame frame;
     const float* ranges;
     const float* thetas;
-    const double* ratio;
+    const int64_t* times;         // per-ray stamps; interpolateRatio = (t - t_begin) / t_den (first moved update only)
+    int64_t t_begin; double t_den;
     int R;
     int N, lo, n_local;
     double r;                     // (rand/RAND_MAX) * (1/N)
@@ -321,7 +321,7 @@ __global__ __launch_bounds__(BLOCK) void k_mcl_main(mcl_args a)
                 float theta, sx, sy;
                 int isx, isy;
                 if (INTERP) {
-                    bl_pose3 rp = bl_interpolate_pose(pb, pe, a.ratio[n]);
+                    bl_pose3 rp = bl_interpolate_pose(pb, pe, bl_interp_ratio(a.times[n], a.t_begin, a.t_den));
                     theta = bl_wrap_to_pi(rp.theta - a.thetas[n]);
                     bl_global_to_grid(rp.x, rp.y, a.frame, &sx, &sy);
                     isx = (int)sx; isy = (int)sy;
@@ -630,7 +630,6 @@ extern "C" int bl_pf_create(bl_ctx* ctx, int num_particles, int shard_lo, int sh
     BL_HIP(hipSetDevice(ctx->device));
     bl_pf* pf = new bl_pf();
     memset((void*)pf, 0, sizeof(*pf));
-    new (&pf->scan) bl_scan_dev();
     pf->ctx = ctx;
     pf->N = num_particles; pf->lo = shard_lo; pf->hi = shard_hi; pf->n_local = shard_hi - shard_lo;
     pf->noise_seed = 0x243F6A8885A308D3ull;
@@ -652,7 +651,6 @@ extern "C" void bl_pf_destroy(bl_pf* pf)
     void* ptrs[] = {pf->tile_pose, pf->prefix, pf->parent, pf->state, pf->partials, pf->block_sums, pf->dbg_idx, pf->dbg_like,
                     pf->d_noise, pf->d_export};
     for (void* p : ptrs) if (p) (void)hipFree(p);
-    bl_scan_free(&pf->scan);
     delete pf;
 }
 
@@ -803,7 +801,9 @@ static int pf_launch_main(bl_pf* pf, const bl_grid* map, int R, int rand_value, 
     a.dbg_idx = pf->debug ? pf->dbg_idx : nullptr; a.dbg_like = pf->debug ? pf->dbg_like : nullptr;
     a.cells = map ? map->cells : nullptr;
     if (map) a.frame = map->frame; else memset(&a.frame, 0, sizeof(a.frame));
-    a.ranges = pf->scan.ranges; a.thetas = pf->scan.thetas; a.ratio = pf->scan.ratio;
+    a.ranges = ctx->scan.ranges; a.thetas = ctx->scan.thetas; a.times = ctx->scan.times;
+    // MovingLaserScan(scan, parent_pose, pose) (sensor_model.cpp:18): begin = parent utime, end = ActionModel::utime_ = 0 (D3)
+    a.t_begin = pf->pose_utime; a.t_den = (pf->pose_utime != 0) ? (double)(0 - pf->pose_utime) : 1.0;
     a.R = R;
     a.N = pf->N; a.lo = pf->lo; a.n_local = pf->n_local;
     a.M_inv = 1.0 / pf->N;                                           // particle_filter.cpp:89
@@ -906,7 +906,7 @@ extern "C" int bl_pf_update_begin(bl_pf* pf, const bl_pose_xyt_t* odometry, cons
         return BL_OK;
     }
     int R = 0;
-    int rc = bl_scan_upload(pf->ctx, &pf->scan, scan, pf->pose_utime, 0 /* ActionModel::utime_ (D3) */, &R);
+    int rc = bl_scan_upload(pf->ctx, scan, &R);
     if (rc) return rc;
     if (noise) { rc = pf_upload_noise(pf, noise); if (rc) return rc; }
     rc = pf_launch_main(pf, map, R, rand_value, noise, 1);

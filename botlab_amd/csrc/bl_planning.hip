@@ -15,6 +15,7 @@
 // dependent memory accesses, not bandwidth (DESIGN.md "A*").
 #include <math.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include <cmath>
 #include <map>
@@ -1081,6 +1082,10 @@ struct bl_planner {
     int lanes;
     planner_lane lane[PLANNER_MAX_LANES];
     int64_t submitted, fetched;
+    unsigned long long* d_flag;         // number of the last submission whose snapshot is complete (written by the snapshot kernel)
+    unsigned int* d_done;               // workgroup counter of the multi-workgroup snapshot kernel
+    bool reserved;
+    bool handoff_flag;                  // lane waits on the flag word (hipStreamWaitValue64) instead of an event
 };
 
 extern "C" int bl_planner_create(bl_ctx* ctx, int lanes, bl_planner** out)
@@ -1091,6 +1096,12 @@ extern "C" int bl_planner_create(bl_ctx* ctx, int lanes, bl_planner** out)
     memset((void*)p, 0, sizeof(*p));
     p->main = ctx;
     p->lanes = lanes;
+    p->handoff_flag = getenv("BOTLAB_PLANNER_HANDOFF_FLAG") != nullptr;
+    BL_HIP(hipMalloc((void**)&p->d_flag, 8));
+    BL_HIP(hipMalloc((void**)&p->d_done, 4));
+    BL_HIP(hipMemsetAsync(p->d_flag, 0, 8, ctx->stream));        // on the SLAM stream: the null stream (and its hardware queue) stays untouched
+    BL_HIP(hipMemsetAsync(p->d_done, 0, 4, ctx->stream));
+    BL_HIP(hipStreamSynchronize(ctx->stream));
     for (int l = 0; l < lanes; ++l) {
         planner_lane& L = p->lane[l];
         int rc = bl_ctx_create(ctx->device, nullptr, &L.side);
@@ -1125,12 +1136,17 @@ extern "C" void bl_planner_destroy(bl_planner* p)
         if (L.dist) bl_dist_destroy(L.dist);
         bl_ctx_destroy(L.side);
     }
+    if (p->d_flag) (void)hipFree(p->d_flag);
+    if (p->d_done) (void)hipFree(p->d_done);
     delete p;
 }
 
-// map + pose snapshot as ONE kernel on the SLAM stream (two hipMemcpyAsync D2D cost two copy-engine handshakes there)
+// map + pose snapshot as ONE kernel on the SLAM stream (two hipMemcpyAsync D2D cost two copy-engine handshakes there).
+// The last workgroup to finish publishes the submission number to the planner's flag word; the lane stream waits for it
+// with hipStreamWaitValue64 -- nothing is recorded on the SLAM stream (an event record costs ~4-7 us of stream time).
 __global__ __launch_bounds__(256) void k_planner_snapshot(const int8_t* __restrict__ src, int8_t* __restrict__ dst, size_t n,
-                                                          const bl_pose_xyt_t* __restrict__ src_pose, bl_pose_xyt_t* __restrict__ dst_pose)
+                                                          const bl_pose_xyt_t* __restrict__ src_pose, bl_pose_xyt_t* __restrict__ dst_pose,
+                                                          unsigned int* done_count, unsigned long long* flag, unsigned long long seq)
 {
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     const size_t n16 = n / 16;
@@ -1139,13 +1155,25 @@ __global__ __launch_bounds__(256) void k_planner_snapshot(const int8_t* __restri
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += stride) d4[i] = s4[i];
     for (size_t i = n16 * 16 + (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) dst[i] = src[i];
     if (blockIdx.x == 0 && threadIdx.x == 0) *dst_pose = *src_pose;
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned int old = atomicAdd(done_count, 1u);
+        if (old == gridDim.x - 1) {
+            *done_count = 0;
+            __threadfence();
+            if (flag) __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
 }
 
-extern "C" int bl_planner_submit(bl_planner* p, const bl_grid* map, const void* d_start_pose, const bl_pose_xyt_t* goal,
-                                 const bl_search_params_t* params)
+// First half of a submission: pick the lane and snapshot slot, make the SLAM stream safe to overwrite the slot, and
+// say where the snapshot goes and which number to publish when it is complete.
+int bl_planner_reserve(bl_planner* p, const bl_grid* map, bl_planner_snap* out)
 {
-    BL_CHECK_ARG(p != nullptr && map != nullptr && d_start_pose != nullptr && goal != nullptr && params != nullptr);
+    BL_CHECK_ARG(p != nullptr && map != nullptr && out != nullptr);
     BL_CHECK_ARG(map->ctx == p->main);
+    if (p->reserved) { bl_set_error("a replanner submission is already reserved"); return BL_ERR_STATE; }
     BL_HIP(hipSetDevice(p->main->device));
     planner_lane& L = p->lane[p->submitted % p->lanes];
     const int slot = (int)(L.submitted % PLANNER_SLOTS);
@@ -1163,21 +1191,35 @@ extern "C" int bl_planner_submit(bl_planner* p, const bl_grid* map, const void* 
         BL_HIP(hipStreamSynchronize(L.side->stream));          // its zero-fill ran on the side stream
     }
     snap->frame = map->frame;
-    // SLAM stream: wait until the lane has finished with this slot, then snapshot map and pose
-    if (L.slot_used[slot]) BL_HIP(hipStreamWaitEvent(p->main->stream, L.slot_free[slot], 0));
-    {
-        const size_t n = (size_t)map->frame.width * map->frame.height;
-        int blocks = (int)((n / 16 + 255) / 256);
-        if (blocks < 1) blocks = 1;
-        if (blocks > 2048) blocks = 2048;
-        hipLaunchKernelGGL(k_planner_snapshot, dim3(blocks), dim3(256), 0, p->main->stream, map->cells, snap->cells, n,
-                           (const bl_pose_xyt_t*)d_start_pose, L.pose[slot]);
-        BL_HIP(hipGetLastError());
+    // the lane must have finished with this slot; in steady state it has, long ago -- only then is a stream wait enqueued
+    if (L.slot_used[slot] && hipEventQuery(L.slot_free[slot]) != hipSuccess)
+        BL_HIP(hipStreamWaitEvent(p->main->stream, L.slot_free[slot], 0));
+    out->cells = snap->cells;
+    out->pose = L.pose[slot];
+    out->flag = p->handoff_flag ? p->d_flag : nullptr;
+    out->seq = (unsigned long long)p->submitted + 1ull;
+    out->done_count = p->d_done;
+    p->reserved = true;
+    return BL_OK;
+}
+
+void bl_planner_cancel(bl_planner* p) { if (p) p->reserved = false; }
+
+// Second half: the lane stream waits for the published number, then runs setDistances + search_for_path on the snapshot.
+int bl_planner_commit(bl_planner* p, const bl_pose_xyt_t* goal, const bl_search_params_t* params)
+{
+    BL_CHECK_ARG(p != nullptr && goal != nullptr && params != nullptr);
+    if (!p->reserved) { bl_set_error("bl_planner_commit without bl_planner_reserve"); return BL_ERR_STATE; }
+    p->reserved = false;
+    planner_lane& L = p->lane[p->submitted % p->lanes];
+    const int slot = (int)(L.submitted % PLANNER_SLOTS);
+    if (p->handoff_flag) {
+        BL_HIP(hipStreamWaitValue64(L.side->stream, p->d_flag, (uint64_t)p->submitted + 1ull, hipStreamWaitValueGte, 0xffffffffffffffffull));
+    } else {
+        BL_HIP(hipEventRecord(L.snap_ready[slot], p->main->stream));
+        BL_HIP(hipStreamWaitEvent(L.side->stream, L.snap_ready[slot], 0));
     }
-    BL_HIP(hipEventRecord(L.snap_ready[slot], p->main->stream));
-    // lane stream: distance grid + search on the snapshot
-    BL_HIP(hipStreamWaitEvent(L.side->stream, L.snap_ready[slot], 0));
-    int rc = bl_dist_set_distances(L.dist, snap);
+    int rc = bl_dist_set_distances(L.dist, L.snap[slot]);
     if (rc) return rc;
     rc = astar_launch(L.side, L.dist, nullptr, L.pose[slot], goal, params);
     if (rc) return rc;
@@ -1186,6 +1228,23 @@ extern "C" int bl_planner_submit(bl_planner* p, const bl_grid* map, const void* 
     L.submitted += 1;
     p->submitted += 1;
     return BL_OK;
+}
+
+extern "C" int bl_planner_submit(bl_planner* p, const bl_grid* map, const void* d_start_pose, const bl_pose_xyt_t* goal,
+                                 const bl_search_params_t* params)
+{
+    BL_CHECK_ARG(p != nullptr && map != nullptr && d_start_pose != nullptr && goal != nullptr && params != nullptr);
+    bl_planner_snap sn;
+    int rc = bl_planner_reserve(p, map, &sn);
+    if (rc) return rc;
+    const size_t n = (size_t)map->frame.width * map->frame.height;
+    int blocks = (int)((n / 16 + 255) / 256);
+    if (blocks < 1) blocks = 1;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(k_planner_snapshot, dim3(blocks), dim3(256), 0, p->main->stream, map->cells, sn.cells, n,
+                       (const bl_pose_xyt_t*)d_start_pose, sn.pose, sn.done_count, sn.flag, sn.seq);
+    BL_HIP(hipGetLastError());
+    return bl_planner_commit(p, goal, params);
 }
 
 extern "C" int bl_planner_fetch(bl_planner* p, bl_pose_xyt_t* out_path, int cap, int* out_len, int64_t* stats)

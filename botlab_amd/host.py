@@ -508,6 +508,13 @@ class AsyncPlanner:
     def submit(self, grid, start_dev, goal):
         check(self.ctx.lib.bl_planner_submit(self.h, grid.h, start_dev, C.byref(goal), C.byref(self.searchParams_)))
 
+    def submit_with_map_update(self, mapping, scan, pose_dev, pose_utime, grid, goal):
+        """mapping.updateMapDevicePose(scan, pose_dev, pose_utime, grid) then submit(grid, pose_dev, goal) as one library call
+        (the map kernel leaves the snapshot behind on grids up to 256 K cells)."""
+        c = scan.as_c()
+        check(self.ctx.lib.bl_planner_submit_with_map_update(self.h, mapping.h, C.byref(c), pose_dev, int(pose_utime), grid.h,
+                                                             C.byref(goal), C.byref(self.searchParams_)))
+
     def fetch(self, return_stats=False):
         n = C.c_int()
         stats = (C.c_int64 * 2)()

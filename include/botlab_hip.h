@@ -195,6 +195,11 @@ int bl_planner_submit(bl_planner* p, const bl_grid* map, const void* d_start_pos
 int bl_planner_fetch(bl_planner* p, bl_pose_xyt_t* out_path, int cap, int* out_len, int64_t* stats);
 /* on: -1 = just read; 0/1 = disable/enable(+reset) HIP-event timing of the planner stream's kernels (totals in ms) */
 int bl_planner_timing(bl_planner* p, int on, double* dist_ms, double* astar_ms, int64_t* launches);
+/* bl_mapping_update_dev_pose followed by bl_planner_submit(p, map, d_pose, goal, params) as one call: on grids up to
+ * 256 K cells the map kernel itself leaves the snapshot behind (one dependent launch less on the SLAM stream). */
+int bl_planner_submit_with_map_update(bl_planner* p, bl_mapping* m, const bl_lidar_t* scan, const void* d_pose,
+                                      int64_t pose_utime, bl_grid* map, const bl_pose_xyt_t* goal,
+                                      const bl_search_params_t* params);
 
 /* ------------------------------------------------------------------ batched searches, frontiers  
  * n independent search_for_path calls (astar.hpp:58-61) from ONE start on one distance grid, run concurrently (one

@@ -27,5 +27,13 @@ def maps():
 
 @pytest.fixture(scope="session")
 def gpu_ctx():
+    # torch bundles its own ROCm runtime; whichever HIP runtime initialises first serves the whole process.  Let it be torch's,
+    # as in bench.py, so that tests which later bring up torch.distributed (nccl) in this process still see the GPU.
+    try:
+        import torch
+        if torch.cuda.is_available():
+            torch.cuda.init()
+    except ImportError:
+        pass
     import botlab_amd
     return botlab_amd.default_context()

@@ -326,9 +326,9 @@ def test_step_pipeline_with_device_pose_equals_host_pose_path(oracle, maps, gpu_
     scans = [synth.raycast_scan(truth, m["origin"], 0.05, poses[k - 1], poses[k], 1_000_000 + k * 100_000) for k in range(1, 9)]
     goal = bl.make_pose(-0.35, 0.2, 0.0)
     out = []
-    for dev in (False, True, "async"):
+    for dev in (False, True, "async", "fused"):
         g = _grid_from_map(m, gpu_ctx)
-        aplanner = bl.AsyncPlanner(ctx=gpu_ctx, lanes=3) if dev == "async" else None
+        aplanner = bl.AsyncPlanner(ctx=gpu_ctx, lanes=3) if dev in ("async", "fused") else None
         lagged = []
         pf = bl.ParticleFilter(2000, ctx=gpu_ctx)
         pf.initializeFilterAtPose(bl.make_pose(-0.75, 0.2, 0.0, utime=int(scans[0].times[0])), seed=5)
@@ -338,11 +338,14 @@ def test_step_pipeline_with_device_pose_equals_host_pose_path(oracle, maps, gpu_
         rec = []
         for k, sc in enumerate(scans):
             odo = bl.make_pose(*poses[k + 1], utime=sc.utime)
-            if dev == "async":
-                # replanner on its own stream against snapshots; results fetched one step late, in order
+            if dev in ("async", "fused"):
+                # replanner on its own stream against snapshots; results fetched three steps late, in order
                 pf.updateFilter(odo, sc, g, rand_value=1000 + k, want_pose=False)
-                mapper.updateMapDevicePose(sc, pf.poseDevicePtr(), sc.utime, g)
-                aplanner.submit(g, pf.poseDevicePtr(), goal)
+                if dev == "fused":                                   # map update + snapshot in one call (bench.py's form)
+                    aplanner.submit_with_map_update(mapper, sc, pf.poseDevicePtr(), sc.utime, g, goal)
+                else:
+                    mapper.updateMapDevicePose(sc, pf.poseDevicePtr(), sc.utime, g)
+                    aplanner.submit(g, pf.poseDevicePtr(), goal)
                 lagged.append(k)
                 if len(lagged) > 3:
                     lagged.pop(0)
@@ -368,8 +371,8 @@ def test_step_pipeline_with_device_pose_equals_host_pose_path(oracle, maps, gpu_
                 path = bl.search_for_path(pose, goal, planner.distances_, planner.searchParams_)
             rec.append(((pose.utime, pose.x, pose.y, pose.theta), [(p.x, p.y, p.theta) for p in path]))
         out.append((rec, g.cells().copy()))
-    assert out[0][0] == out[1][0] == out[2][0]
-    assert np.array_equal(out[0][1], out[1][1]) and np.array_equal(out[0][1], out[2][1])
+    assert out[0][0] == out[1][0] == out[2][0] == out[3][0]
+    assert np.array_equal(out[0][1], out[1][1]) and np.array_equal(out[0][1], out[2][1]) and np.array_equal(out[0][1], out[3][1])
     assert max(len(r[1]) for r in out[0][0]) > 3
 
 
