@@ -114,6 +114,7 @@ SIGNATURES = {
     "bl_frontiers_get": (C.c_int, [_vp, _vp, _vp]),
     "bl_frontiers_stats": (C.c_int, [_vp, _P(C.c_int), _P(C.c_int)]),
     "bl_frontiers_destroy": (None, [_vp]),
+    "bl_sim_cast_beams": (C.c_int, [_vp, _vp, C.c_double, C.c_double, C.c_double, _vp, _vp, _vp, C.c_int, C.c_double, _vp]),
     "bl_plan_path_to_frontier": (C.c_int, [_vp, _vp, _P(Pose), _vp, _P(MotionPlannerState), _vp, C.c_int, _P(C.c_int), _P(Pose),
                                            _vp]),
 }

@@ -225,6 +225,14 @@ int bl_frontiers_get(const bl_frontiers* f, int32_t* offsets /* count + 1 */, fl
 int bl_frontiers_stats(const bl_frontiers* f, int* bfs_cells, int* bfs_levels);   /* free-space flood size / depth (diagnostic) */
 void bl_frontiers_destroy(bl_frontiers* f);
 
+/* ------------------------------------------------------------------ simulator lidar  
+ * Lidar._beam_scan (src/sim/lidar.py:106-138) for n beams on a truth world (cells > 0 are occupied, Map.at_xy's index
+ * arithmetic without bounds checks included, src/sim/map.py:80-87): beam i starts at (x[i], y[i]) and points along
+ * angle[i] (the clamped pose.theta - theta); out_ranges[i] is the marched distance or max_distance.  World origin and
+ * resolution are doubles, as the simulator reads them from the .map header. */
+int bl_sim_cast_beams(bl_ctx* ctx, const bl_grid* world, double origin_x, double origin_y, double meters_per_cell,
+                      const double* x, const double* y, const double* angle, int n, double max_distance, double* out_ranges);
+
 /* The MotionPlanner members plan_path_to_frontier reads (motion_planner.hpp:153-165). */
 typedef struct {
     double robot_radius;               /* params_.robotRadius */
