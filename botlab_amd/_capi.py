@@ -114,6 +114,23 @@ SIGNATURES = {
     "bl_frontiers_get": (C.c_int, [_vp, _vp, _vp]),
     "bl_frontiers_stats": (C.c_int, [_vp, _P(C.c_int), _P(C.c_int)]),
     "bl_frontiers_destroy": (None, [_vp]),
+    "bl_lcm_fingerprint": (C.c_uint64, [C.c_int]),
+    "bl_lcm_encode_pose": (C.c_int64, [C.c_int, _P(Pose), _vp, C.c_int64]),
+    "bl_lcm_encode_lidar": (C.c_int64, [_P(Lidar), _vp, _vp, C.c_int64]),
+    "bl_lcm_encode_particles": (C.c_int64, [C.c_int64, _vp, C.c_int32, _vp, C.c_int64]),
+    "bl_lcm_encode_grid": (C.c_int64, [C.c_int64, C.c_float, C.c_float, C.c_float, C.c_int32, C.c_int32, _vp, _vp, C.c_int64]),
+    "bl_lcm_encode_path": (C.c_int64, [C.c_int64, _vp, C.c_int32, _vp, C.c_int64]),
+    "bl_lcm_decode_pose": (C.c_int, [C.c_int, _vp, C.c_int64, _P(Pose)]),
+    "bl_lcm_decode_lidar": (C.c_int, [_vp, C.c_int64, _P(C.c_int64), _P(C.c_int32), _vp, _vp, _vp, _vp, C.c_int32]),
+    "bl_lcm_decode_particles": (C.c_int, [_vp, C.c_int64, _P(C.c_int64), _P(C.c_int32), _vp, C.c_int32]),
+    "bl_lcm_decode_grid": (C.c_int, [_vp, C.c_int64, _P(C.c_int64), _vp, _vp, _vp, C.c_int64]),
+    "bl_lcm_decode_path": (C.c_int, [_vp, C.c_int64, _P(C.c_int64), _P(C.c_int32), _vp, C.c_int32]),
+    "bl_lcm_log_event_size": (C.c_int64, [C.c_int32, C.c_int32]),
+    "bl_lcm_log_write_event": (C.c_int64, [C.c_int64, C.c_int64, C.c_char_p, _vp, C.c_int32, _vp, C.c_int64]),
+    "bl_lcm_log_read_event": (C.c_int64, [_vp, C.c_int64, _P(C.c_int64), _P(C.c_int64), _P(C.c_int64), _P(C.c_int32), _P(C.c_int64),
+                                          _P(C.c_int32)]),
+    "bl_pf_encode_particles_lcm": (C.c_int64, [_vp, C.c_int64, _vp, C.c_int64]),
+    "bl_grid_encode_lcm": (C.c_int64, [_vp, C.c_int64, _vp, C.c_int64]),
     "bl_sim_cast_beams": (C.c_int, [_vp, _vp, C.c_double, C.c_double, C.c_double, _vp, _vp, _vp, C.c_int, C.c_double, _vp]),
     "bl_plan_path_to_frontier": (C.c_int, [_vp, _vp, _P(Pose), _vp, _P(MotionPlannerState), _vp, C.c_int, _P(C.c_int), _P(Pose),
                                            _vp]),

@@ -586,6 +586,34 @@ __global__ void k_pf_export(const float4* rec, const float4* parent, const pf_st
     out[j] = o;
 }
 
+__device__ __forceinline__ uint32_t bl_bswap32(uint32_t v) { return __builtin_bswap32(v); }
+
+// particles_t body on the LCM wire: 48 bytes = 12 big-endian dwords per particle (pose utime hi/lo, x, y, theta; parent
+// the same; weight as a double, high dword first), one thread per dword so that a wave writes 256 consecutive bytes.
+__global__ __launch_bounds__(256) void k_pf_encode_lcm(const float4* __restrict__ rec, const float4* __restrict__ parent,
+                                                       const pf_state* __restrict__ state, int lo, int n_local,
+                                                       int64_t pose_utime, int64_t parent_utime, uint32_t* __restrict__ out)
+{
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (long long)n_local * 12) return;
+    const int j = (int)(t / 12), d = (int)(t % 12);
+    uint32_t v;
+    if (d < 5) {
+        const float4 r = rec[lo + j];
+        v = d == 0 ? (uint32_t)((uint64_t)pose_utime >> 32) : d == 1 ? (uint32_t)pose_utime
+          : __float_as_uint(d == 2 ? r.x : (d == 3 ? r.y : r.z));
+    } else if (d < 10) {
+        const float4 p = parent[j];
+        v = d == 5 ? (uint32_t)((uint64_t)parent_utime >> 32) : d == 6 ? (uint32_t)parent_utime
+          : __float_as_uint(d == 7 ? p.x : (d == 8 ? p.y : p.z));
+    } else {
+        const double w = (double)__float_as_uint(rec[lo + j].w) / state->S;     // the weight k_pf_export hands out
+        const uint64_t b = (uint64_t)__double_as_longlong(w);
+        v = d == 10 ? (uint32_t)(b >> 32) : (uint32_t)b;
+    }
+    out[t] = bl_bswap32(v);
+}
+
 __global__ void k_pf_set_pose(pf_state* state, bl_pose_xyt_t pose, int only_utime)
 {
     if (only_utime) state->pose.utime = pose.utime;
@@ -749,6 +777,29 @@ extern "C" int bl_pf_get_particles(bl_pf* pf, bl_particle_t* out_local)
                           pf->ctx->stream));
     BL_HIP(hipStreamSynchronize(pf->ctx->stream));
     return BL_OK;
+}
+
+// particles() + particles_t::encode of slam.cpp:265-268 in one step: the wire bytes are produced on the device (48 B per
+// particle instead of the 56-byte host struct) and land in the caller's message buffer with one D2H.
+extern "C" int64_t bl_pf_encode_particles_lcm(bl_pf* pf, int64_t utime, uint8_t* buf, int64_t cap)
+{
+    if (!pf || !buf) { bl_set_error("bad argument"); return -(int64_t)BL_ERR_ARG; }
+    if (!pf->initialized || pf->pending_end) { bl_set_error("filter not initialised or update pending"); return -(int64_t)BL_ERR_STATE; }
+    const int64_t body = (int64_t)pf->n_local * 48, total = 20 + body;
+    if (total > cap) { bl_set_error("LCM encode: %lld bytes do not fit the %lld-byte buffer", (long long)total, (long long)cap); return -(int64_t)BL_ERR_CAPACITY; }
+    if (hipSetDevice(pf->ctx->device) != hipSuccess) return -(int64_t)BL_ERR_HIP;
+    if (!pf->d_export) { if (hipMalloc((void**)&pf->d_export, (size_t)pf->n_local * sizeof(bl_particle_t)) != hipSuccess) { bl_set_error("hipMalloc failed"); return -(int64_t)BL_ERR_HIP; } }
+    const long long dwords = (long long)pf->n_local * 12;
+    hipLaunchKernelGGL(k_pf_encode_lcm, dim3((unsigned)((dwords + 255) / 256)), dim3(256), 0, pf->ctx->stream, pf->rec[pf->cur], pf->parent,
+                       pf->state, pf->lo, pf->n_local, pf->pose_utime, pf->parent_utime, (uint32_t*)pf->d_export);
+    // header: fingerprint, utime, num_particles (big-endian)
+    const uint64_t fp = bl_lcm_fingerprint(BL_LCM_PARTICLES);
+    for (int i = 0; i < 8; ++i) buf[i] = (uint8_t)(fp >> (56 - 8 * i));
+    for (int i = 0; i < 8; ++i) buf[8 + i] = (uint8_t)((uint64_t)utime >> (56 - 8 * i));
+    for (int i = 0; i < 4; ++i) buf[16 + i] = (uint8_t)((uint32_t)pf->n_local >> (24 - 8 * i));
+    if (hipGetLastError() != hipSuccess || hipMemcpyAsync(buf + 20, pf->d_export, (size_t)body, hipMemcpyDeviceToHost, pf->ctx->stream) != hipSuccess ||
+        hipStreamSynchronize(pf->ctx->stream) != hipSuccess) { bl_set_error("bl_pf_encode_particles_lcm: HIP call failed"); return -(int64_t)BL_ERR_HIP; }
+    return total;
 }
 
 extern "C" int bl_pf_set_noise_seed(bl_pf* pf, uint64_t seed)

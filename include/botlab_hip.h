@@ -233,6 +233,45 @@ void bl_frontiers_destroy(bl_frontiers* f);
 int bl_sim_cast_beams(bl_ctx* ctx, const bl_grid* world, double origin_x, double origin_y, double meters_per_cell,
                       const double* x, const double* y, const double* angle, int n, double max_distance, double* out_ranges);
 
+/* ------------------------------------------------------------------ LCM wire codec  
+ * The seven message types on the hot path's boundary (the .lcm files under lcmtypes/), LCM 1.4.0 wire format: 8-byte fingerprint, then
+ * the members in declaration order, scalars big-endian.  Encoders return the encoded size (buf == NULL: size query) or a
+ * negative status; decoders fill caller-owned arrays (capacities in elements) and report the message's counts.  Host
+ * code (usable without a GPU) except bl_pf_encode_particles_lcm / bl_grid_encode_lcm, which produce the bytes from
+ * device state.  PARITY UNPINNED: no LCM build or LCM-encoded data exists in the reference checkout. */
+#define BL_LCM_POSE_XYT 0
+#define BL_LCM_ODOMETRY 1
+#define BL_LCM_LIDAR 2
+#define BL_LCM_PARTICLE 3
+#define BL_LCM_PARTICLES 4
+#define BL_LCM_OCCUPANCY_GRID 5
+#define BL_LCM_ROBOT_PATH 6
+#define BL_LCM_TYPE_COUNT 7
+uint64_t bl_lcm_fingerprint(int type);
+int64_t bl_lcm_encode_pose(int type /* BL_LCM_POSE_XYT or BL_LCM_ODOMETRY */, const bl_pose_xyt_t* pose, uint8_t* buf, int64_t cap);
+int64_t bl_lcm_encode_lidar(const bl_lidar_t* scan, const float* intensities /* NULL: zeros */, uint8_t* buf, int64_t cap);
+int64_t bl_lcm_encode_particles(int64_t utime, const bl_particle_t* particles, int32_t n, uint8_t* buf, int64_t cap);
+int64_t bl_lcm_encode_grid(int64_t utime, float origin_x, float origin_y, float meters_per_cell, int32_t width, int32_t height,
+                           const int8_t* cells, uint8_t* buf, int64_t cap);
+int64_t bl_lcm_encode_path(int64_t utime, const bl_pose_xyt_t* path, int32_t n, uint8_t* buf, int64_t cap);
+int bl_lcm_decode_pose(int type, const uint8_t* buf, int64_t len, bl_pose_xyt_t* out);
+int bl_lcm_decode_lidar(const uint8_t* buf, int64_t len, int64_t* utime, int32_t* n, float* ranges, float* thetas, int64_t* times,
+                        float* intensities, int32_t cap);
+int bl_lcm_decode_particles(const uint8_t* buf, int64_t len, int64_t* utime, int32_t* n, bl_particle_t* out, int32_t cap);
+int bl_lcm_decode_grid(const uint8_t* buf, int64_t len, int64_t* utime, float* origin_xy_mpc /* 3 */,
+                       int32_t* width_height_ncells /* 3 */, int8_t* cells, int64_t cap);
+int bl_lcm_decode_path(const uint8_t* buf, int64_t len, int64_t* utime, int32_t* n, bl_pose_xyt_t* path, int32_t cap);
+/* lcm-logger files: one event = sync 0xEDA1DA01, event number, timestamp (us), channel length, data length, channel, data */
+int64_t bl_lcm_log_event_size(int32_t channel_len, int32_t data_len);
+int64_t bl_lcm_log_write_event(int64_t event_number, int64_t timestamp_us, const char* channel, const uint8_t* data, int32_t data_len,
+                               uint8_t* buf, int64_t cap);
+/* returns the event's total size, 0 if buf[0..len) does not hold a whole event yet, < 0 if there is no event at buf */
+int64_t bl_lcm_log_read_event(const uint8_t* buf, int64_t len, int64_t* event_number, int64_t* timestamp_us, int64_t* channel_off,
+                              int32_t* channel_len, int64_t* data_off, int32_t* data_len);
+/* particles() + encode (slam.cpp:265-268) and toLCM() + encode (slam.cpp:285-289) from device state, one D2H into buf */
+int64_t bl_pf_encode_particles_lcm(bl_pf* pf, int64_t utime, uint8_t* buf, int64_t cap);
+int64_t bl_grid_encode_lcm(bl_grid* grid, int64_t utime, uint8_t* buf, int64_t cap);
+
 /* The MotionPlanner members plan_path_to_frontier reads (motion_planner.hpp:153-165). */
 typedef struct {
     double robot_radius;               /* params_.robotRadius */
