@@ -277,6 +277,7 @@ public:
         }
         return out;
     }
+    bl_pf* device() const { return h_; }                                        // for the device-side extras (bl_pf_encode_particles_lcm ...)
 private:
     bl_pf* h_;
     int n_;
