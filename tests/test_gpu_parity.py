@@ -118,6 +118,26 @@ def test_mapping_off_grid_and_empty_scan(oracle, gpu_ctx, maps):
     assert np.array_equal(g.cells(), ref)
 
 
+@pytest.mark.parametrize("rays,mpc,max_laser", [(1500, 0.05, 5.0),      # more rays than threads: the per-ray walk + direct hits path
+                                                 (290, 0.01, 8.0),       # 1 cm cells, 8 m: the counter window needs strips
+                                                 (700, 0.02, 6.0)])
+def test_mapping_unusual_shapes(oracle, maps, gpu_ctx, rays, mpc, max_laser):
+    m = maps["obstacle_slam_10mx10m_5cm"]
+    truth = np.where(m["cells"] > 0, 127, -127).astype(np.int8)
+    poses = synth.square_trajectory((-0.75, 0.2, 0.0), 6, step_len=0.03, turn=0.08, side=0.8)
+    g = bl.OccupancyGrid(10.0, 10.0, mpc, ctx=gpu_ctx)
+    mapper = bl.Mapping(max_laser, 4, 1, ctx=gpu_ctx)
+    om = oracle_lib.OracleMapping(oracle, max_laser, 4, 1)
+    ref = np.zeros((g.height, g.width), np.int8)
+    for k in range(1, len(poses)):
+        scan = synth.raycast_scan(truth, m["origin"], 0.05, poses[k - 1], poses[k], 1_000_000 + k * 100_000, rays=rays)
+        p = poses[k]
+        mapper.updateMap(scan, bl.make_pose(p[0], p[1], p[2], utime=scan.utime), g)
+        om.update(scan, oracle.pose(p[0], p[1], p[2], utime=scan.utime), ref, g.mpc, g.cpm, g.origin)
+        assert np.array_equal(g.cells(), ref), f"step {k}"
+    assert (ref != 0).sum() > 1000
+
+
 # ------------------------------------------------------------------ ParticleFilter
 def _mcl_sequence(oracle, maps, gpu_ctx, N, steps, name="obstacle_slam_10mx10m_5cm", seed=1):
     m, truth, poses, scans = _drive(maps, name, steps, seed)
