@@ -362,7 +362,7 @@ __global__ __launch_bounds__(BLOCK) void k_mcl_main(mcl_args a)
     }
 }
 
-// ---------------------------------------------------------------- weight-unit prefix scan over all N (3 launches)
+// ---------------------------------------------------------------- weight-unit prefix scan over all N from the record (2 launches)
 // Tile sums of the weight units and, when tile_pose != nullptr, of the estimatePosteriorPose terms
 // (particle_filter.cpp:144-160) units*(x, y, sinf(theta), cosf(theta)) in double.  The order of every addition is a
 // function of N alone (items in a thread, shuffle tree in a wave, waves in order), so the estimate does not depend on how
@@ -410,65 +410,29 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan_tile_sums(const float4* _
     }
 }
 
-// single workgroup: exclusive scan of the tile sums (in place), total -> state.S, and the pose estimate
-// (estimatePosteriorPose, particle_filter.cpp:144-160) from the per-tile sums, reduced in a fixed order.
-__global__ __launch_bounds__(1024) void k_scan_tiles_and_estimate(unsigned long long* __restrict__ tile_sums, int ntiles,
-                                                                  const double* __restrict__ tile_pose, pf_state* state,
-                                                                  int64_t utime, int write_pose)
-{
-    __shared__ unsigned long long s_wave[16];
-    __shared__ unsigned long long s_carry;
-    __shared__ double s_red[16][4];
-    if (threadIdx.x == 0) s_carry = 0;
-    if (write_pose) {
-        double v[4] = {0, 0, 0, 0};
-        for (int b = threadIdx.x; b < ntiles; b += 1024)
-            for (int k = 0; k < 4; ++k) v[k] += tile_pose[(size_t)b * 4 + k];
-        for (int k = 0; k < 4; ++k) v[k] = wave_sum(v[k]);
-        if ((threadIdx.x & 63) == 0) for (int k = 0; k < 4; ++k) s_red[threadIdx.x >> 6][k] = v[k];
-    }
-    __syncthreads();
-    for (int base = 0; base < ntiles; base += 1024) {
-        int idx = base + threadIdx.x;
-        unsigned long long v = idx < ntiles ? tile_sums[idx] : 0ull;
-        unsigned long long incl = v;
-        for (int off = 1; off < 64; off <<= 1) {
-            unsigned long long t = __shfl_up(incl, off, 64);
-            if ((threadIdx.x & 63) >= off) incl += t;
-        }
-        if ((threadIdx.x & 63) == 63) s_wave[threadIdx.x >> 6] = incl;
-        __syncthreads();
-        unsigned long long wave_off = 0;
-        for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) wave_off += s_wave[w];
-        unsigned long long carry = s_carry;
-        if (idx < ntiles) tile_sums[idx] = carry + wave_off + incl - v;      // exclusive
-        __syncthreads();
-        if (threadIdx.x == 1023) s_carry = carry + wave_off + incl;
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) {
-        state->S = (double)s_carry;
-        if (write_pose) {
-            double tot[4] = {0, 0, 0, 0};
-            for (int w = 0; w < 16; ++w) for (int k = 0; k < 4; ++k) tot[k] += s_red[w][k];
-            const double su = (double)s_carry;           // exact: the total of the integer units is below 2^53
-            bl_pose_xyt_t p;
-            p.utime = utime;
-            p.x = (float)(tot[0] / su);
-            p.y = (float)(tot[1] / su);
-            p.theta = (float)atan2(tot[2], tot[3]);
-            state->pose = p;
-            state->sums_used[0] = su;
-            for (int k = 0; k < 4; ++k) state->sums_used[k + 1] = tot[k];
-        }
-    }
-}
-
-__global__ __launch_bounds__(SCAN_THREADS) void k_scan_write_prefix(const float4* __restrict__ rec, int N,
-                                                                    const unsigned long long* __restrict__ tile_offsets,
-                                                                    unsigned long long* __restrict__ prefix)
+// Second (and last) launch of the record-based finish: workgroup b sums the unit totals of the tiles before it (exact
+// integers), scans its tile and writes the prefix; workgroup 0 also reduces the per-tile pose sums in a fixed order
+// (thread-strided, wave shuffles, waves in order) and forms the pose estimate (estimatePosteriorPose,
+// particle_filter.cpp:144-160).  The order of every floating-point addition depends on N alone.
+__global__ __launch_bounds__(SCAN_THREADS) void k_scan_finish_prefix(const float4* __restrict__ rec, int N,
+                                                                     const unsigned long long* __restrict__ tile_sums, int ntiles,
+                                                                     const double* __restrict__ tile_pose,
+                                                                     unsigned long long* __restrict__ prefix, pf_state* state,
+                                                                     int64_t utime, int write_pose)
 {
     __shared__ unsigned long long s_wave[SCAN_THREADS / 64];
+    __shared__ unsigned long long s_off[SCAN_THREADS / 64];
+    __shared__ unsigned long long s_tot[SCAN_THREADS / 64];
+    __shared__ double s_red[SCAN_THREADS / 64][4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    unsigned long long before = 0, all = 0;
+    for (int j = threadIdx.x; j < ntiles; j += SCAN_THREADS) {
+        const unsigned long long t = tile_sums[j];
+        if (j < (int)blockIdx.x) before += t;
+        all += t;
+    }
+    for (int off = 32; off > 0; off >>= 1) { before += __shfl_xor(before, off, 64); all += __shfl_xor(all, off, 64); }
+    if (lane == 0) { s_off[wave] = before; s_tot[wave] = all; }
     const int base = blockIdx.x * SCAN_TILE + threadIdx.x * SCAN_ITEMS;
     unsigned long long loc[SCAN_ITEMS];
     unsigned long long run = 0;
@@ -479,14 +443,37 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan_write_prefix(const float4
     unsigned long long incl = run;
     for (int off = 1; off < 64; off <<= 1) {
         unsigned long long t = __shfl_up(incl, off, 64);
-        if ((threadIdx.x & 63) >= off) incl += t;
+        if (lane >= off) incl += t;
     }
-    if ((threadIdx.x & 63) == 63) s_wave[threadIdx.x >> 6] = incl;
+    if (lane == 63) s_wave[wave] = incl;
+    if (blockIdx.x == 0 && write_pose) {
+        double v[4] = {0, 0, 0, 0};
+        for (int b = threadIdx.x; b < ntiles; b += SCAN_THREADS)
+            for (int k = 0; k < 4; ++k) v[k] += tile_pose[(size_t)b * 4 + k];
+        for (int k = 0; k < 4; ++k) v[k] = wave_sum(v[k]);
+        if (lane == 0) for (int k = 0; k < 4; ++k) s_red[wave][k] = v[k];
+    }
     __syncthreads();
-    unsigned long long off0 = tile_offsets[blockIdx.x] + incl - run;
-    for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) off0 += s_wave[w];
+    unsigned long long off0 = incl - run, total = 0;
+    for (int w = 0; w < SCAN_THREADS / 64; ++w) { off0 += s_off[w]; total += s_tot[w]; if (w < wave) off0 += s_wave[w]; }
     for (int k = 0; k < SCAN_ITEMS; ++k)
         if (base + k < N) prefix[base + k] = off0 + loc[k];
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        state->S = (double)total;
+        if (write_pose) {
+            double tot[4] = {0, 0, 0, 0};
+            for (int w = 0; w < SCAN_THREADS / 64; ++w) for (int k = 0; k < 4; ++k) tot[k] += s_red[w][k];
+            const double su = (double)total;             // exact: the total of the integer units is below 2^53
+            bl_pose_xyt_t p;
+            p.utime = utime;
+            p.x = (float)(tot[0] / su);
+            p.y = (float)(tot[1] / su);
+            p.theta = (float)atan2(tot[2], tot[3]);
+            state->pose = p;
+            state->sums_used[0] = su;
+            for (int k = 0; k < 4; ++k) state->sums_used[k + 1] = tot[k];
+        }
+    }
 }
 
 // Single-shard fast path (the whole particle set on this device): k_mcl_main's per-workgroup partials already hold the
@@ -702,10 +689,8 @@ static int pf_scan(bl_pf* pf, int which, int write_pose, int64_t utime)
     if (rc) return rc;
     hipLaunchKernelGGL(k_scan_tile_sums, dim3(pf->scan_blocks), dim3(SCAN_THREADS), 0, ctx->stream, pf->rec[which], pf->N,
                        pf->block_sums, write_pose ? pf->tile_pose : (double*)nullptr);
-    hipLaunchKernelGGL(k_scan_tiles_and_estimate, dim3(1), dim3(1024), 0, ctx->stream, pf->block_sums, pf->scan_blocks,
-                       pf->tile_pose, pf->state, utime, write_pose);
-    hipLaunchKernelGGL(k_scan_write_prefix, dim3(pf->scan_blocks), dim3(SCAN_THREADS), 0, ctx->stream, pf->rec[which], pf->N,
-                       pf->block_sums, pf->prefix);
+    hipLaunchKernelGGL(k_scan_finish_prefix, dim3(pf->scan_blocks), dim3(SCAN_THREADS), 0, ctx->stream, pf->rec[which], pf->N,
+                       pf->block_sums, pf->scan_blocks, pf->tile_pose, pf->prefix, pf->state, utime, write_pose);
     BL_HIP(hipGetLastError());
     return bl_timer_end(ctx, BL_K_MCL_SCAN, e0, e1);
 }
