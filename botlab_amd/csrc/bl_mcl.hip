@@ -28,6 +28,7 @@
 #define MCL_RAY_UNROLL 2
 #endif
 #define MCL_BLOCK 1024                        // largest workgroup of k_mcl_main
+#define MCL_LDS_RAYS 1024                     // rays whose (range, theta) table is staged in LDS (more: read from global memory)
 #define MCL_MIN_BLOCKS 512                    // split rays over lanes until the launch has at least this many workgroups (2 per CU)
 #define MCL_WIN_SMALL_BYTES (64 * 1024)       // whole-grid staging budget (200x200 int8 = 40 KB -> two workgroups per CU)
 #define MCL_WIN_BIG 384                       // window side for larger grids: 384^2 = 144 KB, one workgroup per CU
@@ -93,6 +94,14 @@ struct map_window { int x0, y0, w, h, stride; };
 
 typedef __attribute__((address_space(3))) signed char lds_i8_t;
 
+// min(max(x, -1), hi) for hi >= -1
+__device__ __forceinline__ int clamp_from_m1(int x, int hi)
+{
+    int r;
+    asm("v_med3_i32 %0, %1, -1, %2" : "=v"(r) : "v"(x), "s"(hi));
+    return r;
+}
+
 // MAP_MODE: 0 = gathers from HBM/L2 only; 1 = the whole grid is staged in LDS; 2 = LDS window + HBM/L2 fallback.
 // Branch-free in modes 0 and 1: an off-grid cell reads a dummy slot and is masked to 0 (OccupancyGrid::logOdds,
 // occupancy_grid.cpp:63-71).
@@ -103,8 +112,11 @@ __device__ __forceinline__ int grid_odds(const int8_t* __restrict__ cells, const
     if (MAP_MODE == 1) {
         // whole grid staged with a zero frame (one row above/below, four columns left, >= four right): clamping the cell
         // to the frame replaces the bounds test, the index select and the result mask
-        const int cx = min(max(x, -1), f.width), cy = min(max(y, -1), f.height);
-        return s_map[(cy + 1) * win.stride + cx + 4];
+        // to the frame replaces the bounds test; v_med3_i32 is the clamp in one instruction, and the row offset is a 24-bit
+        // multiply (v_mul_lo_u32 issues at quarter rate; rows and stride are far below 2^24)
+        // s_map points at cell (0, 0) of the framed image here, so row -1 / column -1 are plain negative offsets
+        const int cx = clamp_from_m1(x, f.width), cy = clamp_from_m1(y, f.height);
+        return s_map[__mul24(cy, win.stride) + cx];
     }
     const bool in = (unsigned int)x < (unsigned int)f.width && (unsigned int)y < (unsigned int)f.height;
     if (MAP_MODE == 0) {
@@ -199,8 +211,13 @@ __global__ __launch_bounds__(BLOCK) void k_mcl_main(mcl_args a)
     extern __shared__ __align__(16) signed char s_dyn[];
     __shared__ double s_part[BLOCK / 64][5];
     __shared__ map_window s_win;
+    __shared__ float2 s_ray[MCL_LDS_RAYS];                  // (range, theta) of the kept rays: one ds_read_b64 per ray
     const lds_i8_t* s_map = (const lds_i8_t*)s_dyn;
     map_window win = {0, 0, 0, 0, 0};
+    const bool rays_in_lds = a.R <= MCL_LDS_RAYS;
+    if (rays_in_lds)
+        for (int n = threadIdx.x; n < a.R; n += BLOCK) s_ray[n] = make_float2(a.ranges[n], a.thetas[n]);
+    if (MAP_MODE == 0) __syncthreads();                     // the staging paths below end with a barrier of their own
 
     if (MAP_MODE != 0) {
         // ---- stage the map window: centred on the cell the previous pose estimate moves to under the odometry action
@@ -232,6 +249,7 @@ __global__ __launch_bounds__(BLOCK) void k_mcl_main(mcl_args a)
             // framed image: rows -1..H, columns -4..stride-5 (zeros outside the grid)
             const int stride = ((a.frame.width + 3) & ~3) + 8;
             win.stride = stride;
+            s_map += stride + 4;                                  // cell (0, 0) of the framed image (grid_odds<1> indexes from it)
             const int wq = stride >> 2;
             const bool aligned = (a.frame.width & 3) == 0;
             for (int i = threadIdx.x; i < wq * (a.frame.height + 2); i += BLOCK) {
@@ -315,18 +333,19 @@ __global__ __launch_bounds__(BLOCK) void k_mcl_main(mcl_args a)
             const int isx0 = (int)sx0, isy0 = (int)sy0;
             // two rays per trip: their sincos polynomial chains (dependent FP64 fma) are independent, which is what the
             // scheduler needs to fill the issue slots a single chain leaves empty
-#pragma unroll MCL_RAY_UNROLL
             for (int n = sub; n < a.R; n += split) {        // the host uploads only rays with range > 0.15f (moving_laser_scan.cpp:24)
-                const float range = a.ranges[n];
+                float range, ray_theta;
+                if (rays_in_lds) { const float2 rt = s_ray[n]; range = rt.x; ray_theta = rt.y; }
+                else { range = a.ranges[n]; ray_theta = a.thetas[n]; }
                 float theta, sx, sy;
                 int isx, isy;
                 if (INTERP) {
                     bl_pose3 rp = bl_interpolate_pose(pb, pe, bl_interp_ratio(a.times[n], a.t_begin, a.t_den));
-                    theta = bl_wrap_to_pi(rp.theta - a.thetas[n]);
+                    theta = bl_wrap_to_pi(rp.theta - ray_theta);
                     bl_global_to_grid(rp.x, rp.y, a.frame, &sx, &sy);
                     isx = (int)sx; isy = (int)sy;
                 } else {
-                    theta = bl_wrap_to_pi(pth - a.thetas[n]);
+                    theta = bl_wrap_to_pi(pth - ray_theta);
                     sx = sx0; sy = sy0; isx = isx0; isy = isy0;
                 }
                 float sn, cs;
