@@ -241,8 +241,10 @@ int bl_scan_upload(bl_ctx* ctx, const bl_lidar_t* scan, int* num_rays)
     // MovingLaserScan keeps a ray only if its range exceeds 0.15f (moving_laser_scan.cpp:24); the kept rays are packed
     // in scan order, so no kernel branches on validity.
     int kept = 0;
+    float max_range = 0;
     for (int n = 0; n < R; ++n) {
         if (!(scan->ranges[n] > 0.15f)) continue;
+        if (scan->ranges[n] > max_range) max_range = scan->ranges[n];
         hrange[kept] = scan->ranges[n];
         htheta[kept] = scan->thetas[n];
         ht[kept] = scan->times[n];
@@ -265,6 +267,7 @@ int bl_scan_upload(bl_ctx* ctx, const bl_lidar_t* scan, int* num_rays)
     sl->last = s;
     sl->next = (s + 1) % kScanSlots;
     sd->kept = kept;
+    sd->max_range = max_range;
     return BL_OK;
 }
 

@@ -47,6 +47,7 @@ struct bl_scan_dev {
     void* staging = nullptr;    // pinned host slots: times | ranges | thetas
     size_t staging_bytes = 0;
     int kept = 0;               // rays in the block
+    float max_range = 0;        // largest kept range (bounds the cell offsets a ray can produce)
 };
 
 struct bl_astar_state;

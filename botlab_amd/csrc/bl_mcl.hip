@@ -154,6 +154,62 @@ __device__ __forceinline__ int score_ray_half_units(const int8_t* __restrict__ c
     return odds > 0 ? 2 * odds : (o1 > 0 ? o1 : (o2 > 0 ? o2 : 0));
 }
 
+// ---- packed 16-bit form of the scoring arithmetic (whole-grid LDS mode, no pose interpolation) ----------------------------
+// Cell coordinates travel as (x, y) int16 pairs, so one v_pk_* instruction serves both axes: the two Bresenham first steps,
+// the clamps to the zero frame and (v_dot2_i32_i16 with (1, stride)) the LDS offset.  Exactly the int32 arithmetic as long as
+// nothing leaves int16: the host enables it only for grids up to 8192 cells a side and scans whose longest ray spans at most
+// 4000 cells, and a lane uses it only if its start cell lies within +-8191 -- then |end| <= 12191, |2x-range point| <= 16191
+// and every doubled difference stays below 2^15.
+typedef short short2_t __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ short2_t pk_sign_fill(short2_t v)              // per half: -1 if negative else 0
+{
+    short2_t r;
+    // kept opaque: as plain C the compiler turns (v >> 15) & x into per-half compares and selects
+    asm("v_pk_ashrrev_i16 %0, 15, %1 op_sel_hi:[0,1]" : "=v"(r) : "v"(v));
+    return r;
+}
+
+// bl_bresenham_first_step on packed cells: step x iff 2dx - dy >= 0, step y iff 2dy - dx >= 0, toward the target
+__device__ __forceinline__ short2_t first_step_pk(short2_t e, short2_t target)
+{
+    const short2_t d = target - e;
+    const short2_t ad = __builtin_elementwise_max(d, -d);
+    const short2_t t = (ad << 1) - ad.yx;
+    const short2_t nostep = pk_sign_fill(t);
+    const short2_t sg = pk_sign_fill(d - (short)1) | (short)1;            // d > 0 ? 1 : -1
+    return e + (sg & ~nostep);
+}
+
+struct pk_map { int base; short2_t K; short2_t hi; };                     // LDS address of cell (0,0); (1, stride); (W, H)
+
+__device__ __forceinline__ int pk_odds(const pk_map& pm, short2_t c)
+{
+    const short2_t lo = {(short)-1, (short)-1};
+    const short2_t cc = __builtin_elementwise_min(__builtin_elementwise_max(c, lo), pm.hi);
+    const int addr = __builtin_amdgcn_sdot2(cc, pm.K, pm.base, false);
+    return *(const lds_i8_t*)(size_t)(unsigned int)addr;
+}
+
+// SensorModel::scoreRay in half-units (see score_ray_half_units), packed form.  The float endpoint arithmetic is written on
+// (x, y) pairs as well (v_pk_mul_f32 / v_pk_add_f32): each lane-wise operation is the reference's own IEEE operation
+// (2.0f * t == t + t exactly).
+typedef float float2_t __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ int score_ray_pk(const pk_map& pm, float2_t start, short2_t S, float cpm, float range, float cs, float sn)
+{
+    const float2_t dir = {cs, sn};
+    const float2_t t = (range * dir) * cpm;                               // (range * cos) * cpm, (range * sin) * cpm
+    const float2_t e = t + start;
+    const float2_t x = (t + t) + start;
+    const short2_t E = __builtin_amdgcn_cvt_pk_i16((int)e.x, (int)e.y);
+    const short2_t X = __builtin_amdgcn_cvt_pk_i16((int)x.x, (int)x.y);
+    const int odds = pk_odds(pm, E);
+    const int o1 = pk_odds(pm, first_step_pk(E, S));
+    const int o2 = pk_odds(pm, first_step_pk(E, X));
+    return odds > 0 ? 2 * odds : (o1 > 0 ? o1 : (o2 > 0 ? o2 : 0));
+}
+
 struct mcl_args {
     const float4* src;            // rec[cur]     (all N)
     float4* dst;                  // rec[cur ^ 1] (all N; this shard writes [lo, hi))
@@ -180,6 +236,7 @@ struct mcl_args {
     int resample;                 // 0: action-only (source = own index)
     int win_w, win_h;             // LDS map window size in cells (0: no staging); >= grid size means the whole grid
     int split_log2;               // each particle's rays are spread over 2^split_log2 adjacent lanes
+    int pk_ok;                    // grid and scan admit the packed 16-bit scoring path (see score_ray_pk)
 };
 
 __device__ __forceinline__ void philox_normals3(uint32_t m, uint32_t step, uint32_t k0, uint32_t k1, float z[3])
@@ -331,8 +388,22 @@ __global__ __launch_bounds__(BLOCK) void k_mcl_main(mcl_args a)
             float sx0, sy0;
             bl_global_to_grid(px, py, a.frame, &sx0, &sy0);
             const int isx0 = (int)sx0, isy0 = (int)sy0;
-            // two rays per trip: their sincos polynomial chains (dependent FP64 fma) are independent, which is what the
-            // scheduler needs to fill the issue slots a single chain leaves empty
+            if (MAP_MODE == 1 && !INTERP && a.pk_ok && isx0 >= -8191 && isx0 <= 8191 && isy0 >= -8191 && isy0 <= 8191) {
+                pk_map pm;
+                pm.base = (int)(unsigned int)(size_t)s_map;
+                pm.K = short2_t{(short)1, (short)win.stride};
+                pm.hi = short2_t{(short)a.frame.width, (short)a.frame.height};
+                const short2_t S = {(short)isx0, (short)isy0};
+                const float2_t start = {sx0, sy0};
+                for (int n = sub; n < a.R; n += split) {
+                    float range, ray_theta;
+                    if (rays_in_lds) { const float2 rt = s_ray[n]; range = rt.x; ray_theta = rt.y; }
+                    else { range = a.ranges[n]; ray_theta = a.thetas[n]; }
+                    float sn, cs;
+                    bl_sincosf(bl_wrap_to_pi(pth - ray_theta), &sn, &cs);
+                    acc += score_ray_pk(pm, start, S, a.frame.cpm, range, cs, sn);
+                }
+            } else
             for (int n = sub; n < a.R; n += split) {        // the host uploads only rays with range > 0.15f (moving_laser_scan.cpp:24)
                 float range, ray_theta;
                 if (rays_in_lds) { const float2 rt = s_ray[n]; range = rt.x; ray_theta = rt.y; }
@@ -894,6 +965,9 @@ static int pf_launch_main(bl_pf* pf, const bl_grid* map, int R, int rand_value, 
     // (40 KB: up to 3 per CU); 1024 threads with the 144 KB window (one workgroup per CU: as many waves as fit).
     int block = (mode == 2) ? 1024 : 512;        // measured at 100k and 1M particles, 200x200: 512 is within 3 % of the best
     if (pf->block_override > 0) block = pf->block_override;
+    // packed 16-bit scoring: grid up to 8192 a side, the longest kept ray spans at most 4000 cells (see score_ray_pk)
+    a.pk_ok = (map && a.frame.width <= 8192 && a.frame.height <= 8192 && ctx->scan.max_range * a.frame.cpm <= 4000.0f &&
+               getenv("BOTLAB_MCL_NO_PACKED") == nullptr) ? 1 : 0;
     a.split_log2 = 0;
     if (map && pf->split_log2_override >= 0) a.split_log2 = pf->split_log2_override;
     else if (map) {
