@@ -188,6 +188,37 @@ def test_mcl_parity_with_oracle_noise(oracle, maps, gpu_ctx, N):
     assert moved_updates >= 7
 
 
+@pytest.mark.parametrize("case", ["far_particles", "long_ray"])
+def test_mcl_packed_scoring_fallbacks(oracle, maps, gpu_ctx, case):
+    """The whole-grid LDS mode scores rays in packed int16 arithmetic only while every cell coordinate provably fits:
+    particles more than 8191 cells from the grid origin, or a scan with a ray longer than 4000 cells, must take the
+    int32 path -- per lane in the first case, for the whole launch in the second -- and still match the oracle exactly."""
+    N = 512
+    m, g, opf, pf, odo, scans, rands, cells = _mcl_sequence(oracle, maps, gpu_ctx, N, 4)
+    parts = opf.particles()
+    if case == "far_particles":                              # every 5th particle 450-600 m away (|cell| > 8191)
+        parts["x"][::5] += np.float32(450.0) * np.where(np.arange(len(parts["x"][::5])) % 2, 1, -1).astype(np.float32)
+        parts["y"][2::5] -= np.float32(600.0)
+        parts["p_x"][:] = parts["x"]; parts["p_y"][:] = parts["y"]
+        opf.set_particles(parts)
+        pf.setParticles(parts)
+    moved = 0
+    for k, scan in enumerate(scans):
+        if case == "long_ray":
+            scan.ranges[7] = np.float32(260.0)               # 5200 cells at 5 cm
+        o = odo[k + 1]
+        t = int(scan.times[-1])
+        res = opf.update(oracle.pose(o[0], o[1], o[2], utime=t), scan, cells, m["mpc"], helpers.CPM_DEFAULT, m["origin"], rands[k])
+        pf.updateFilter(bl.make_pose(o[0], o[1], o[2], utime=t), scan, g, rand_value=rands[k], noise=res["noise"])
+        if not res["moved"]:
+            continue
+        moved += 1
+        idx, like = pf.debugLast()
+        assert np.array_equal(idx, res["idx"]), k
+        assert np.array_equal(like.astype(np.float64) * 0.5, res["raw"]), k
+    assert moved >= 2
+
+
 @pytest.mark.parametrize("start,kidnap", [((3.3, -7.1, 0.4), False), ((-11.0, 6.0, 2.0), True)])
 def test_mcl_parity_large_grid_lds_window(oracle, maps, gpu_ctx, start, kidnap):
     """A 1000x1000 grid does not fit the whole-grid LDS staging: the kernel stages a 384x384 window around the predicted
