@@ -56,7 +56,7 @@ struct bl_pf {
     int partials_cap;
     bool use_lds;
     int last_blocks, last_tile;   // launch shape of the last k_mcl_main
-    bool fused_finish, no_fused_finish;
+    bool fused_finish, no_fused_finish, no_packed;
     int split_log2_override;  // -1: automatic
     int block_override;       // 0: automatic
     bool debug;               // record resample index / likelihood per particle (parity tests)
@@ -740,6 +740,7 @@ extern "C" int bl_pf_create(bl_ctx* ctx, int num_particles, int shard_lo, int sh
     pf->noise_seed = 0x243F6A8885A308D3ull;
     pf->use_lds = getenv("BOTLAB_MCL_NO_LDS") == nullptr;
     pf->no_fused_finish = getenv("BOTLAB_MCL_NO_FUSED_FINISH") != nullptr;
+    pf->no_packed = getenv("BOTLAB_MCL_NO_PACKED") != nullptr;
     pf->split_log2_override = getenv("BOTLAB_MCL_SPLIT_LOG2") ? atoi(getenv("BOTLAB_MCL_SPLIT_LOG2")) : -1;
     if (pf->split_log2_override > 6) pf->split_log2_override = 6;
     pf->block_override = getenv("BOTLAB_MCL_BLOCK") ? atoi(getenv("BOTLAB_MCL_BLOCK")) : 0;
@@ -967,7 +968,7 @@ static int pf_launch_main(bl_pf* pf, const bl_grid* map, int R, int rand_value, 
     if (pf->block_override > 0) block = pf->block_override;
     // packed 16-bit scoring: grid up to 8192 a side, the longest kept ray spans at most 4000 cells (see score_ray_pk)
     a.pk_ok = (map && a.frame.width <= 8192 && a.frame.height <= 8192 && ctx->scan.max_range * a.frame.cpm <= 4000.0f &&
-               getenv("BOTLAB_MCL_NO_PACKED") == nullptr) ? 1 : 0;
+               !pf->no_packed) ? 1 : 0;
     a.split_log2 = 0;
     if (map && pf->split_log2_override >= 0) a.split_log2 = pf->split_log2_override;
     else if (map) {
