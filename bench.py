@@ -121,7 +121,7 @@ def main():
                     help="replan goal in metres (default: a point on the driven loop, see build_inputs)")
     ap.add_argument("--goal-l1", type=int, default=40, help="without --goal on a non-default grid: max L1 distance (cells) "
                     "of the replan goal from the start")
-    ap.add_argument("--cpu-steps", type=int, default=10, help="steps of the CPU baseline sample (0 = skip)")
+    ap.add_argument("--cpu-steps", type=int, default=25, help="steps of the CPU baseline sample (0 = skip)")
     ap.add_argument("--depth", type=int, default=3, help="steps enqueued ahead of fetching a result (0 = synchronous steps)")
     ap.add_argument("--lanes", type=int, default=3, help="replanner streams: consecutive replans run concurrently (1..4)")
     args = ap.parse_args()

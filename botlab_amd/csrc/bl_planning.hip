@@ -554,7 +554,9 @@ __global__ __launch_bounds__(64) void k_astar(astar_args a)
         }
         // gCost of the popped node: fCost - hCost - oCost of its cell (the start node carries zeros, astar.cpp:66-69)
         const int ax = abs(a.gx - nx), ay = abs(a.gy - ny);                     // get_hCost (:170-179); lane 4: the cell itself
-        const int hc = (ax >= ay) ? 14 * ay + 10 * (ax - ay) : 14 * ax + 10 * (ay - ax);
+        // 14 * min + 10 * (max - min) = 10 * max + 4 * min, as shifts and adds (a 32-bit v_mul_lo issues at quarter rate)
+        const int hmx = max(ax, ay), hmn = min(ax, ay);
+        const int hc = (hmx << 3) + (hmx << 1) + (hmn << 2);
         const int c_cost = __builtin_amdgcn_readlane(my_cost, 4);
         const int c_h = __builtin_amdgcn_readlane(hc, 4);
         const int tg = (res.pops == 1) ? 0 : top.x - c_h - c_cost;
