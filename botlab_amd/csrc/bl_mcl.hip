@@ -56,7 +56,9 @@ struct bl_pf {
     int partials_cap;
     bool use_lds;
     int last_blocks, last_tile;   // launch shape of the last k_mcl_main
-    bool fused_finish, no_fused_finish, no_packed;
+    int last_main_blocks, last_main_particles, last_tail_tile;
+    bool fused_finish, no_fused_finish, no_packed, no_balance;
+    int cus;                      // compute units of the device
     int split_log2_override;  // -1: automatic
     int block_override;       // 0: automatic
     bool debug;               // record resample index / likelihood per particle (parity tests)
@@ -237,6 +239,7 @@ struct mcl_args {
     int win_w, win_h;             // LDS map window size in cells (0: no staging); >= grid size means the whole grid
     int split_log2;               // each particle's rays are spread over 2^split_log2 adjacent lanes
     int pk_ok;                    // grid and scan admit the packed 16-bit scoring path (see score_ray_pk)
+    int main_blocks, main_particles;   // region 1: main_blocks workgroups cover particles [0, main_particles) of the shard
 };
 
 __device__ __forceinline__ void philox_normals3(uint32_t m, uint32_t step, uint32_t k0, uint32_t k1, float z[3])
@@ -342,11 +345,16 @@ __global__ __launch_bounds__(BLOCK) void k_mcl_main(mcl_args a)
         __syncthreads();
     }
 
-    const int split = 1 << a.split_log2;
-    const int gtid = blockIdx.x * BLOCK + threadIdx.x;
-    const int j = gtid >> a.split_log2;
-    const int sub = gtid & (split - 1);
-    const bool active = j < a.n_local;
+    // Two regions in one launch (see "Whole rounds" in pf_launch_main): workgroups [0, main_blocks) take BLOCK >> split_log2
+    // particles each, 2^split_log2 lanes per particle; the workgroups after them take the remaining particles one per
+    // wave (64 lanes over the rays), so that the last partial round of the machine lasts a tenth of a full one.
+    const bool tail = (int)blockIdx.x >= a.main_blocks;
+    const int sl2 = tail ? 6 : a.split_log2;
+    const int split = 1 << sl2;
+    const int j = tail ? a.main_particles + ((((int)blockIdx.x - a.main_blocks) * BLOCK + (int)threadIdx.x) >> 6)
+                       : ((int)blockIdx.x * BLOCK + (int)threadIdx.x) >> sl2;
+    const int sub = (int)threadIdx.x & (split - 1);
+    const bool active = j < a.n_local && (tail || j < a.main_particles);
     double t_units = 0, t_x = 0, t_y = 0, t_s = 0, t_c = 0;
 
     if (active) {
@@ -574,8 +582,11 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan_finish_prefix(const float
 // reduces the five partial sums in a fixed order and forms the pose estimate (estimatePosteriorPose,
 // particle_filter.cpp:144-160).  No workgroup waits on another, so nothing separates this from k_mcl_main but one
 // kernel boundary (a dependent single-workgroup launch costs ~6 us here).
+// Tiles follow k_mcl_main's two regions: workgroups [0, main_blocks) own `tile` particles each from 0 on, the rest own
+// `tail_tile` particles each from main_particles on.
 __global__ __launch_bounds__(SCAN_THREADS) void k_mcl_finish_prefix(const double* __restrict__ partials, int nblocks,
                                                                     const float4* __restrict__ rec, int N, int tile,
+                                                                    int main_blocks, int main_particles, int tail_tile,
                                                                     unsigned long long* __restrict__ prefix, pf_state* state,
                                                                     int64_t utime)
 {
@@ -589,9 +600,11 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_mcl_finish_prefix(const double
     for (int off = 32; off > 0; off >>= 1) before += __shfl_xor(before, off, 64);
     if (lane == 0) s_off[wave] = before;
     // ---- local inclusive scan of the tile
-    const int ipt = (tile + SCAN_THREADS - 1) / SCAN_THREADS;                 // items per thread (<= 8)
-    const int tile_lo = blockIdx.x * tile;
-    const int tile_hi = min(N, tile_lo + tile);
+    const bool in_tail = (int)blockIdx.x >= main_blocks;
+    const int my_tile = in_tail ? tail_tile : tile;
+    const int ipt = (my_tile + SCAN_THREADS - 1) / SCAN_THREADS;              // items per thread (<= 8)
+    const int tile_lo = in_tail ? main_particles + ((int)blockIdx.x - main_blocks) * tail_tile : (int)blockIdx.x * tile;
+    const int tile_hi = in_tail ? min(N, tile_lo + tail_tile) : min(main_particles, tile_lo + tile);
     const int base = tile_lo + threadIdx.x * ipt;
     unsigned long long loc[SCAN_ITEMS];
     unsigned long long run = 0;
@@ -741,6 +754,8 @@ extern "C" int bl_pf_create(bl_ctx* ctx, int num_particles, int shard_lo, int sh
     pf->use_lds = getenv("BOTLAB_MCL_NO_LDS") == nullptr;
     pf->no_fused_finish = getenv("BOTLAB_MCL_NO_FUSED_FINISH") != nullptr;
     pf->no_packed = getenv("BOTLAB_MCL_NO_PACKED") != nullptr;
+    pf->no_balance = getenv("BOTLAB_MCL_NO_BALANCE") != nullptr;
+    { int cus = 0; if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device) == hipSuccess) pf->cus = cus; }
     pf->split_log2_override = getenv("BOTLAB_MCL_SPLIT_LOG2") ? atoi(getenv("BOTLAB_MCL_SPLIT_LOG2")) : -1;
     if (pf->split_log2_override > 6) pf->split_log2_override = 6;
     pf->block_override = getenv("BOTLAB_MCL_BLOCK") ? atoi(getenv("BOTLAB_MCL_BLOCK")) : 0;
@@ -975,7 +990,33 @@ static int pf_launch_main(bl_pf* pf, const bl_grid* map, int R, int rand_value, 
         while (a.split_log2 < 6 && ((int64_t)pf->n_local << a.split_log2) < (int64_t)MCL_MIN_BLOCKS * block) a.split_log2++;
     }
     while (a.split_log2 > 0 && (1 << a.split_log2) > R) a.split_log2--;
-    int blocks = (int)((((int64_t)pf->n_local << a.split_log2) + block - 1) / block);
+    // Whole rounds.  All workgroups of this VALU-bound kernel take about the same time T, so 782 workgroups on a machine
+    // that holds 768 at a time run for a full round plus a nearly empty one (measured: 98 304 particles 0.102 ms, 100 000
+    // particles 0.128 ms; the straggling round lasts T/4, the time one wave needs for its particles' rays on an idle CU).
+    // When the count exceeds whole rounds by less than ~60 % of a round, the excess particles therefore go to a second
+    // region of the same launch, dispatched last, in which every particle has a whole wave (5 rays per lane instead of
+    // 73): those workgroups last ~T/10.  One round is counted 1/32 short of what the device holds, because the
+    // replanner's kernels on the other streams occupy a few workgroup slots.
+    const int gpb = block >> a.split_log2;                  // particles per region-1 workgroup
+    int64_t main_blocks = ((int64_t)pf->n_local + gpb - 1) / gpb, tail_blocks = 0;
+    int64_t main_particles = pf->n_local;
+    const int tail_tile = block >> 6;                       // particles per region-2 workgroup
+    if (map && !pf->no_balance && gpb >= 1) {
+        const int cus = pf->cus > 0 ? pf->cus : 256;
+        int per_cu = 32 / (block >> 6);
+        const int lds_per_wg = lds_bytes + 9 * 1024;        // + static LDS (ray table, partial sums)
+        if ((160 * 1024) / lds_per_wg < per_cu) per_cu = (160 * 1024) / lds_per_wg;
+        if (per_cu < 1) per_cu = 1;
+        const int64_t round = (int64_t)cus * per_cu - (int64_t)cus * per_cu / 32;
+        const int64_t full = main_blocks / round, excess = main_blocks - full * round;
+        if (full >= 1 && excess > 0 && excess * 8 < round * 5) {
+            main_blocks = full * round;
+            main_particles = main_blocks * gpb;
+            tail_blocks = ((int64_t)pf->n_local - main_particles + tail_tile - 1) / tail_tile;
+        }
+    }
+    a.main_blocks = (int)main_blocks; a.main_particles = (int)main_particles;
+    int blocks = (int)(main_blocks + tail_blocks);
     if (blocks > pf->partials_cap) { bl_set_error("internal: partials buffer too small"); return BL_ERR_STATE; }
     hipEvent_t e0, e1;
     int rc = bl_timer_begin(ctx, BL_K_MCL_MAIN, &e0, &e1);
@@ -1000,7 +1041,8 @@ static int pf_launch_main(bl_pf* pf, const bl_grid* map, int R, int rand_value, 
     rc = bl_timer_end(ctx, BL_K_MCL_MAIN, e0, e1);
     if (rc) return rc;
     pf->last_blocks = blocks;
-    pf->last_tile = block >> a.split_log2;               // particles per k_mcl_main workgroup
+    pf->last_tile = gpb;                                  // particles per region-1 workgroup of k_mcl_main
+    pf->last_main_blocks = a.main_blocks; pf->last_main_particles = a.main_particles; pf->last_tail_tile = tail_tile;
     pf->fused_finish = (pf->n_local == pf->N) && pf->last_tile >= 1 && pf->last_tile <= SCAN_TILE && !pf->no_fused_finish;
     return BL_OK;
 }
@@ -1013,7 +1055,8 @@ static int pf_finish_fused(bl_pf* pf, int which, int64_t utime)
     int rc = bl_timer_begin(ctx, BL_K_MCL_SCAN, &e0, &e1);
     if (rc) return rc;
     hipLaunchKernelGGL(k_mcl_finish_prefix, dim3(pf->last_blocks), dim3(SCAN_THREADS), 0, ctx->stream, pf->partials, pf->last_blocks,
-                       pf->rec[which], pf->N, pf->last_tile, pf->prefix, pf->state, utime);
+                       pf->rec[which], pf->N, pf->last_tile, pf->last_main_blocks, pf->last_main_particles, pf->last_tail_tile,
+                       pf->prefix, pf->state, utime);
     BL_HIP(hipGetLastError());
     return bl_timer_end(ctx, BL_K_MCL_SCAN, e0, e1);
 }
