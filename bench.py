@@ -112,8 +112,8 @@ def cpu_baseline(args, m, odo, scans, rands, goal, n_steps):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=500)
+    ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--particles", type=int, default=100_000)
     ap.add_argument("--grid", type=int, default=200, help="grid side in cells (200 = shipped obstacle_slam map)")
     ap.add_argument("--no-astar", action="store_true", help="skip the replan (distance grid + A*) in the step")
