@@ -139,9 +139,17 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: botlab_amd has no CPU path")
+    # Test hook (tests/test_gpu_bench_two_ranks.py): exercise the N > 1 code path on a one-GPU box -- every rank on cuda:0 and
+    # the collectives over gloo (RCCL refuses two ranks on one device).  Never set by the driver.
+    one_device = bool(os.environ.get("BENCH_TEST_ONE_DEVICE"))
+    if one_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1 or os.environ.get("BOTLAB_FORCE_COLLECTIVES"):
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if one_device:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     total = args.steps + args.warmup + 34
     m, truth, poses, odo, scans, rands = build_inputs(args, total)
