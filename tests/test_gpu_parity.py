@@ -47,11 +47,17 @@ def test_distance_grid_reference_test_grid(oracle, gpu_ctx):
     assert np.all(got[cells == 0] == 0.0) and np.all(got[cells > 0] == 0.0)
 
 
-@pytest.mark.parametrize("shape", [(1, 1), (1, 37), (53, 1), (64, 64), (257, 129), (300, 1000)])
+@pytest.mark.parametrize("shape", [(1, 1), (1, 37), (53, 1), (64, 64), (257, 129), (300, 1000),
+                                   (40, 8192),        # wide rows: the row pass chains two 4096-cell chunks
+                                   (70, 12304),       # ... three chunks plus a ragged fourth (12304 = 3 * 4096 + 16)
+                                   (600, 1040),       # large-grid column pass, last macro strip partial (600 = 4 * 128 + 88)
+                                   (1029, 1024),      # ... one row into the ninth macro strip
+                                   (515, 1026)])      # W not a multiple of 16: wide rows off, large-grid column pass on
 def test_distance_grid_ragged_shapes(oracle, gpu_ctx, shape):
     rng = np.random.default_rng(shape[0] * 1000 + shape[1])
     h, w = shape
-    cells = np.where(rng.random(shape) < 0.02, rng.integers(0, 100, shape), -rng.integers(1, 100, shape)).astype(np.int8)
+    density = 0.02 if h * w < 100000 else 0.0003          # sparse sources on the big ones: long carries across chunks / strips
+    cells = np.where(rng.random(shape) < density, rng.integers(0, 100, shape), -rng.integers(1, 100, shape)).astype(np.int8)
     for variant in (cells, np.full(shape, -5, np.int8), np.zeros(shape, np.int8)):
         g = bl.OccupancyGrid.from_cells(variant, (-1.0, -2.0), 0.05, ctx=gpu_ctx)
         d = bl.ObstacleDistanceGrid(ctx=gpu_ctx)
