@@ -21,11 +21,16 @@ BL_HD float bl_wrap_to_pi(float angle)
 {
     // (double)angle < -M_PI  <=>  angle <= -(float)M_PI, because (float)M_PI = 3.14159274... is the float just ABOVE
     // M_PI and the next float toward zero (3.14159250...) is below it; likewise (double)angle > M_PI <=> angle >= (float)M_PI.
+    // The reference loops until the angle is in range and never returns for an angle so large that a float absorbs the
+    // 2*pi step (|angle| >= 2^26) or for NaN-free but absurd inputs that need billions of steps.  On a GPU that is a hung
+    // device, so the loop is cut after 2^16 steps (|angle| up to ~4e5 rad wraps exactly as in the reference; beyond that
+    // the result is whatever the last step left -- inputs no lidar or pose produces).
     const float PI_F = 0x1.921fb6p+1f;
+    int guard = 1 << 16;
     if (angle <= -PI_F) {
-        do { angle = (float)((double)angle + 2.0 * BL_PI); } while (angle <= -PI_F);
+        do { angle = (float)((double)angle + 2.0 * BL_PI); } while (angle <= -PI_F && --guard > 0);
     } else if (angle >= PI_F) {
-        do { angle = (float)((double)angle - 2.0 * BL_PI); } while (angle >= PI_F);
+        do { angle = (float)((double)angle - 2.0 * BL_PI); } while (angle >= PI_F && --guard > 0);
     }
     return angle;
 }
