@@ -200,13 +200,16 @@ def main():
             mapper.updateMapDevicePose(sc, pose_dev, sc.utime, grid)
         in_flight.append(k)
 
+    last_pose = [None]
+
     def fetch():
         # hands back the pose and the path of the oldest enqueued step (waits for that step only)
         in_flight.pop(0)
         if goal_pose is not None:
             path, st = aplanner.fetch(return_stats=True)
             pops_total[0] += st[0]
-            return path[0]                       # the start pose of the path is that step's pose estimate
+            last_pose[0] = path[0]               # the start pose of the path is that step's pose estimate
+            return path[0]
         return None
 
     host_t = [0.0, 0.0]
@@ -228,12 +231,11 @@ def main():
         return last
 
     def drain():
-        last = None
         while in_flight:
-            last = fetch()
-        if goal_pose is None:
-            last = engine.pf.poseEstimate()
-        return last
+            fetch()
+        if goal_pose is None or last_pose[0] is None:
+            return engine.pf.poseEstimate()
+        return last_pose[0]
 
     # The measured loop is a few hundred microseconds per step; a generational GC pass over the interpreter's (torch-sized)
     # heap is tens of milliseconds.  Collect once now and keep the collector out of the timed region.
@@ -299,7 +301,9 @@ def main():
     aplanner.timing(0)
     stage_ms["dist"] = (d_ms / pn if pn else 0.0, pn)
     stage_ms["astar"] = (a_ms / pn if pn else 0.0, pn)
-    stage_ms["mcl_main"] = (main_ms_total / main_n if main_n else 0.0, main_n)      # the timed-region figure
+    if main_n:
+        stage_ms["mcl_main"] = (main_ms_total / main_n, main_n)                      # the timed-region figure
+    # (a run too short for the event stride to catch a launch keeps the post-pass figure)
     pose, k = final_pose, final_k
     pops_total[0] = pops_timed
 
@@ -341,7 +345,7 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "k_mcl_main", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": main_ms,
-                         "launches_timed": int(main_n), "event_stride": EVENT_STRIDE,
+                         "launches_timed": int(stage_ms["mcl_main"][1]), "event_stride": EVENT_STRIDE,
                          "particle_rays_per_s": (n_local * R) / (main_ms * 1e-3) if main_ms > 0 else 0.0},
             "stage_ms": {k_: round(v[0], 5) for k_, v in stage_ms.items()},
             "astar_pops_per_step": pops_total[0] / args.steps,
