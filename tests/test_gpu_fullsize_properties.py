@@ -99,3 +99,27 @@ def test_astar_on_2000x2000_maze_path_is_valid(maps, gpu_ctx):
         for cx, cy in cells:
             assert dist[cy, cx] > 0.1 * 1.000001                             # every cell is valid (astar.cpp:141)
     assert found >= 1
+
+
+@pytest.mark.parametrize("size,radius", [(2000, 400), (4096, 1500)])
+def test_frontiers_full_size_match_oracle(oracle, gpu_ctx, size, radius):
+    """find_map_frontiers on a partially explored open hall (config 5's grid size): the oracle's bitmap flood finishes in
+    well under a second even at 4096^2, so the comparison is exact (same frontiers, same cell order)."""
+    cells = np.full((size, size), -100, np.int8)
+    for oy in range(20, size, 40):
+        for ox in range(20, size, 40):
+            cells[oy:oy + 4, ox:ox + 4] = 100
+    cells[0, :] = cells[-1, :] = 100
+    cells[:, 0] = cells[:, -1] = 100
+    yy, xx = np.mgrid[0:size, 0:size]
+    c = size // 2 + 6
+    cells[(xx - c) ** 2 + (yy - c) ** 2 > radius ** 2] = 0
+    half = size * 0.05 / 2
+    origin = (np.float32(-half), np.float32(-half))
+    robot = (-half + (c + radius - 40 + 0.5) * 0.05, -half + (c + 0.5) * 0.05, 0.0)
+    grid = bl.OccupancyGrid.from_cells(cells, origin, np.float32(0.05), cellsPerMeter=helpers.CPM_DEFAULT, ctx=gpu_ctx)
+    got = bl.find_map_frontiers(grid, bl.make_pose(*robot)).cells()
+    exp = oracle.find_frontiers(cells, np.float32(0.05), helpers.CPM_DEFAULT, origin, oracle.pose(*robot))
+    assert len(got) == len(exp) >= 3
+    for a, b in zip(got, exp):
+        assert a.tobytes() == b.tobytes()
