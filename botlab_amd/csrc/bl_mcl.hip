@@ -24,13 +24,9 @@
 
 #include "bl_internal.h"
 
-#ifndef MCL_RAY_UNROLL
-#define MCL_RAY_UNROLL 2
-#endif
-#define MCL_BLOCK 1024                        // largest workgroup of k_mcl_main
 #define MCL_LDS_RAYS 1024                     // rays whose (range, theta) table is staged in LDS (more: read from global memory)
 #define MCL_MIN_BLOCKS 512                    // split rays over lanes until the launch has at least this many workgroups (2 per CU)
-#define MCL_WIN_SMALL_BYTES (64 * 1024)       // whole-grid staging budget (200x200 int8 = 40 KB -> two workgroups per CU)
+#define MCL_WIN_SMALL_BYTES (64 * 1024)       // whole-grid staging budget (200x200 int8 framed = 41 KB -> three workgroups per CU)
 #define MCL_WIN_BIG 384                       // window side for larger grids: 384^2 = 144 KB, one workgroup per CU
 #define SCAN_THREADS 256
 #define SCAN_ITEMS 8
@@ -258,9 +254,10 @@ __device__ __forceinline__ void philox_normals3(uint32_t m, uint32_t step, uint3
     z[0] = ra * c2; z[1] = ra * s2; z[2] = rb * c4;
 }
 
-// One thread per output particle m of the shard: low-variance resample (gather), ActionModel::applyAction,
+// One lane group per output particle m of the shard: low-variance resample (gather), ActionModel::applyAction,
 // SensorModel::likelihood, weight units, and the block's partial sums for normalisation + pose estimate.
-// Launch shape: BLOCK = 1024 threads; a particle occupies `split` = 2^split_log2 adjacent lanes of one wave, lane
+// Launch shape: BLOCK threads (512 with the whole grid in LDS, 1024 with the LDS window); a particle occupies
+// `split` = 2^split_log2 adjacent lanes of one wave (a whole wave in the second region of the launch), lane
 // `sub` of them taking rays sub, sub + split, ...  (the host picks split so that the launch has >= ~512 workgroups:
 // at 100k particles a one-thread-per-particle launch is 6 waves per CU and latency-bound on its serial 290-ray loop).
 // Resampling and the action model are evaluated by every lane of the group (identical inputs, identical results);
