@@ -44,6 +44,7 @@
 #include <limits>
 #include <queue>
 #include <random>
+#include <set>
 #include <stack>
 #include <vector>
 
@@ -756,11 +757,17 @@ bool is_frontier_cell(int x, int y, const orc_grid_t& m)   // :217-246
 }
 // visitedCells (a std::set<Point<int>> in the reference) as a bitmap: every cell ever inserted is in the grid except,
 // possibly, the robot cell, which is kept beside it.
+// literal == true keeps the reference's std::set (same answers, its O(log n) cost per lookup: used for timing only).
 struct Visited {
-    const orc_grid_t& m; std::vector<uint8_t> bits; int rx, ry;
-    Visited(const orc_grid_t& g, int x, int y) : m(g), bits(static_cast<size_t>(g.width) * g.height, 0), rx(x), ry(y) {}
-    bool has(int x, int y) const { return (x == rx && y == ry) || (in_grid(m, x, y) && bits[static_cast<size_t>(y) * m.width + x]); }
-    void insert(int x, int y) { if (in_grid(m, x, y)) bits[static_cast<size_t>(y) * m.width + x] = 1; }
+    const orc_grid_t& m; std::vector<uint8_t> bits; int rx, ry; bool literal; std::set<std::pair<int, int>> cells;
+    Visited(const orc_grid_t& g, int x, int y, bool lit = false)
+        : m(g), bits(lit ? 0 : static_cast<size_t>(g.width) * g.height, 0), rx(x), ry(y), literal(lit) { if (lit) cells.insert({x, y}); }
+    bool has(int x, int y) const
+    {
+        if (literal) return cells.find({x, y}) != cells.end();
+        return (x == rx && y == ry) || (in_grid(m, x, y) && bits[static_cast<size_t>(y) * m.width + x]);
+    }
+    void insert(int x, int y) { if (literal) cells.insert({x, y}); else if (in_grid(m, x, y)) bits[static_cast<size_t>(y) * m.width + x] = 1; }
 };
 Frontier grow_frontier(int cx, int cy, const orc_grid_t& m, Visited& visited)   // :249-288
 {
@@ -782,13 +789,13 @@ Frontier grow_frontier(int cx, int cy, const orc_grid_t& m, Visited& visited)   
     }
     return f;
 }
-std::vector<Frontier> find_map_frontiers(const orc_grid_t& m, const orc_pose_t& robot, double minFrontierLength)   // :25-85
+std::vector<Frontier> find_map_frontiers(const orc_grid_t& m, const orc_pose_t& robot, double minFrontierLength, bool literal = false)   // :25-85
 {
     std::vector<Frontier> frontiers;
     // global_position_to_grid_cell(Point<float> -> Point<double>) (grid_utils.hpp:33-38)
     int rx = static_cast<int>((static_cast<double>(robot.x) - m.origin_x) * m.cells_per_meter);
     int ry = static_cast<int>((static_cast<double>(robot.y) - m.origin_y) * m.cells_per_meter);
-    Visited visited(m, rx, ry);
+    Visited visited(m, rx, ry, literal);
     std::queue<std::pair<int, int>> q;
     q.push({rx, ry});
     const int xDeltas[4] = {-1, 1, 0, 0};
@@ -1041,7 +1048,9 @@ int orc_is_valid_goal(const orc_pose_t* goal, const orc_dist_t* d, double robotR
 int orc_find_frontiers(const orc_grid_t* map, const orc_pose_t* robot, double minLen, int32_t* offsets, int cap_frontiers,
                        float* xy, int cap_cells, int* total_cells)
 {
-    std::vector<Frontier> fr = find_map_frontiers(*map, *robot, minLen);
+    const bool literal = cap_frontiers < 0;               // negative capacity: time the std::set form, return only the count
+    std::vector<Frontier> fr = find_map_frontiers(*map, *robot, minLen, literal);
+    if (literal) return static_cast<int>(fr.size());
     int total = 0;
     for (size_t k = 0; k < fr.size(); ++k) {
         int n = static_cast<int>(fr[k].xy.size() / 2);
