@@ -124,6 +124,8 @@ def main():
     ap.add_argument("--cpu-steps", type=int, default=25, help="steps of the CPU baseline sample (0 = skip)")
     ap.add_argument("--depth", type=int, default=3, help="steps enqueued ahead of fetching a result (0 = synchronous steps)")
     ap.add_argument("--lanes", type=int, default=3, help="replanner streams: consecutive replans run concurrently (1..4)")
+    ap.add_argument("--batch", type=int, default=1, help="replans a lane collects and searches in one launch (1..4): lanes x batch "
+                    "searches overlap; for grids where a search outlasts several steps (use with --depth >= lanes x batch)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -160,7 +162,7 @@ def main():
     # The replanner on its own stream(s) (the reference's planner process); consecutive replans overlap on `lanes` streams.
     # Created before anything touches the null stream: the HIP runtime multiplexes streams onto 4 hardware queues (raising
     # GPU_MAX_HW_QUEUES costs ~50 us of launch latency per kernel, measured), and two lanes sharing a queue serialise.
-    aplanner = bl.AsyncPlanner(ctx=ctx, lanes=args.lanes)
+    aplanner = bl.AsyncPlanner(ctx=ctx, lanes=args.lanes, batch=args.batch)
     spf = sharded.ShardedParticleFilter(engine)
     grid = bl.OccupancyGrid.from_cells(m["cells"], m["origin"], m["mpc"], cellsPerMeter=cpm, ctx=ctx)
     mapper = bl.Mapping(5.0, 4, 1, ctx=ctx)                 # slam.cpp:24, slam_main.cpp:22-23
@@ -340,7 +342,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"full SLAM step on {W}x{H} @5cm grid (shipped obstacle_slam map), {N} particles, "
                                    f"{R} rays, A* replan {'off' if goal is None else 'on'}",
-                       "particles": N, "grid": [W, H], "rays": R, "pipeline_depth": args.depth, "planner_lanes": args.lanes,
+                       "particles": N, "grid": [W, H], "rays": R, "pipeline_depth": args.depth, "planner_lanes": args.lanes, "planner_batch": args.batch,
                        "parallelism": f"particle-shard x{world}" if world > 1 else "single GPU"},
             "roofline": {"bound": "hbm", "kernel": "k_mcl_main", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,

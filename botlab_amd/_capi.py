@@ -100,6 +100,7 @@ SIGNATURES = {
     "bl_astar_search_async_dev_start": (C.c_int, [_vp, _vp, _vp, _P(Pose), _P(SearchParams)]),
     "bl_astar_search_result": (C.c_int, [_vp, _vp, C.c_int, _P(C.c_int), _P(C.c_int64)]),
     "bl_planner_create": (C.c_int, [_vp, C.c_int, _P(_vp)]),
+    "bl_planner_create_batched": (C.c_int, [_vp, C.c_int, C.c_int, _P(_vp)]),
     "bl_planner_destroy": (None, [_vp]),
     "bl_planner_submit": (C.c_int, [_vp, _vp, _vp, _P(Pose), _P(SearchParams)]),
     "bl_planner_fetch": (C.c_int, [_vp, _vp, C.c_int, _P(C.c_int), _P(C.c_int64)]),

@@ -64,6 +64,8 @@ struct bl_pf {
     int32_t* dbg_like;
     float* d_noise;           // 3 * n_local (parity mode)
     bl_particle_t* d_export;  // n_local
+    int8_t* framed;           // zero-framed copy of a grid too large for LDS (packed scoring gathers from it through L2)
+    size_t framed_cap;
     // uniform utimes of the particle set (every particle carries the same pair; DESIGN.md "Particle utimes")
     int64_t pose_utime, parent_utime;
     // ActionModel state (action_model.hpp:60-78)
@@ -180,13 +182,23 @@ __device__ __forceinline__ short2_t first_step_pk(short2_t e, short2_t target)
 }
 
 struct pk_map { int base; short2_t K; short2_t hi; };                     // LDS address of cell (0,0); (1, stride); (W, H)
+struct pk_map_global { const int8_t* base; short2_t K; short2_t hi; };    // the same over a zero-framed copy in device memory
+
+__device__ __forceinline__ short2_t pk_clamp_to_frame(short2_t c, short2_t hi)
+{
+    const short2_t lo = {(short)-1, (short)-1};
+    return __builtin_elementwise_min(__builtin_elementwise_max(c, lo), hi);
+}
 
 __device__ __forceinline__ int pk_odds(const pk_map& pm, short2_t c)
 {
-    const short2_t lo = {(short)-1, (short)-1};
-    const short2_t cc = __builtin_elementwise_min(__builtin_elementwise_max(c, lo), pm.hi);
-    const int addr = __builtin_amdgcn_sdot2(cc, pm.K, pm.base, false);
+    const int addr = __builtin_amdgcn_sdot2(pk_clamp_to_frame(c, pm.hi), pm.K, pm.base, false);
     return *(const lds_i8_t*)(size_t)(unsigned int)addr;
+}
+
+__device__ __forceinline__ int pk_odds(const pk_map_global& pm, short2_t c)
+{
+    return pm.base[__builtin_amdgcn_sdot2(pk_clamp_to_frame(c, pm.hi), pm.K, 0, false)];     // |offset| < 2^27
 }
 
 // SensorModel::scoreRay in half-units (see score_ray_half_units), packed form.  The float endpoint arithmetic is written on
@@ -194,7 +206,8 @@ __device__ __forceinline__ int pk_odds(const pk_map& pm, short2_t c)
 // (2.0f * t == t + t exactly).
 typedef float float2_t __attribute__((ext_vector_type(2)));
 
-__device__ __forceinline__ int score_ray_pk(const pk_map& pm, float2_t start, short2_t S, float cpm, float range, float cs, float sn)
+template <class PM>
+__device__ __forceinline__ int score_ray_pk(const PM& pm, float2_t start, short2_t S, float cpm, float range, float cs, float sn)
 {
     const float2_t dir = {cs, sn};
     const float2_t t = (range * dir) * cpm;                               // (range * cos) * cpm, (range * sin) * cpm
@@ -208,6 +221,26 @@ __device__ __forceinline__ int score_ray_pk(const pk_map& pm, float2_t start, sh
     return odds > 0 ? 2 * odds : (o1 > 0 ? o1 : (o2 > 0 ? o2 : 0));
 }
 
+// Zero-framed copy of the grid (rows -1..H, columns -4..stride-5), one dword per thread: the image k_mcl_main stages in LDS
+// for small grids, kept in device memory for grids that do not fit.
+__global__ __launch_bounds__(256) void k_mcl_frame(const int8_t* __restrict__ cells, int W, int H, int stride, int* __restrict__ framed)
+{
+    const int wq = stride >> 2;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= wq * (H + 2)) return;
+    const int ry = i / wq, q = i - ry * wq;
+    const int y = ry - 1, x = 4 * q - 4;
+    int v = 0;
+    if (y >= 0 && y < H && x >= 0 && x < W) {
+        const size_t g = (size_t)y * W + x;
+        if ((W & 3) == 0) v = *(const int*)(cells + g);
+        else
+            for (int b = 0; b < 4; ++b)
+                if (x + b < W) v |= ((int)(unsigned char)cells[g + b]) << (8 * b);
+    }
+    framed[i] = v;
+}
+
 struct mcl_args {
     const float4* src;            // rec[cur]     (all N)
     float4* dst;                  // rec[cur ^ 1] (all N; this shard writes [lo, hi))
@@ -218,6 +251,8 @@ struct mcl_args {
     int32_t* dbg_idx;
     int32_t* dbg_like;
     const int8_t* cells;
+    const int8_t* framed;         // cell (0, 0) of the zero-framed copy (MAP_MODE 0 with packed scoring) or null
+    int framed_stride;
     bl_frame frame;
     const float* ranges;
     const float* thetas;
@@ -393,13 +428,27 @@ __global__ __launch_bounds__(BLOCK) void k_mcl_main(mcl_args a)
             float sx0, sy0;
             bl_global_to_grid(px, py, a.frame, &sx0, &sy0);
             const int isx0 = (int)sx0, isy0 = (int)sy0;
-            if (MAP_MODE == 1 && !INTERP && a.pk_ok && isx0 >= -8191 && isx0 <= 8191 && isy0 >= -8191 && isy0 <= 8191) {
+            const bool pk_lane = !INTERP && a.pk_ok && isx0 >= -8191 && isx0 <= 8191 && isy0 >= -8191 && isy0 <= 8191;
+            const short2_t S = {(short)isx0, (short)isy0};
+            const float2_t start = {sx0, sy0};
+            if (MAP_MODE == 1 && pk_lane) {
                 pk_map pm;
                 pm.base = (int)(unsigned int)(size_t)s_map;
                 pm.K = short2_t{(short)1, (short)win.stride};
                 pm.hi = short2_t{(short)a.frame.width, (short)a.frame.height};
-                const short2_t S = {(short)isx0, (short)isy0};
-                const float2_t start = {sx0, sy0};
+                for (int n = sub; n < a.R; n += split) {
+                    float range, ray_theta;
+                    if (rays_in_lds) { const float2 rt = s_ray[n]; range = rt.x; ray_theta = rt.y; }
+                    else { range = a.ranges[n]; ray_theta = a.thetas[n]; }
+                    float sn, cs;
+                    bl_sincosf(bl_wrap_to_pi(pth - ray_theta), &sn, &cs);
+                    acc += score_ray_pk(pm, start, S, a.frame.cpm, range, cs, sn);
+                }
+            } else if (MAP_MODE == 0 && pk_lane && a.framed) {
+                pk_map_global pm;
+                pm.base = a.framed;
+                pm.K = short2_t{(short)1, (short)a.framed_stride};
+                pm.hi = short2_t{(short)a.frame.width, (short)a.frame.height};
                 for (int n = sub; n < a.R; n += split) {
                     float range, ray_theta;
                     if (rays_in_lds) { const float2 rt = s_ray[n]; range = rt.x; ray_theta = rt.y; }
@@ -767,7 +816,7 @@ extern "C" void bl_pf_destroy(bl_pf* pf)
     (void)hipStreamSynchronize(pf->ctx->stream);
     if (!pf->rec_external) { if (pf->rec[0]) (void)hipFree(pf->rec[0]); if (pf->rec[1]) (void)hipFree(pf->rec[1]); }
     void* ptrs[] = {pf->tile_pose, pf->prefix, pf->parent, pf->state, pf->partials, pf->block_sums, pf->dbg_idx, pf->dbg_like,
-                    pf->d_noise, pf->d_export};
+                    pf->d_noise, pf->d_export, pf->framed};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     delete pf;
 }
@@ -966,7 +1015,7 @@ static int pf_launch_main(bl_pf* pf, const bl_grid* map, int R, int rand_value, 
             a.win_w = map->frame.width; a.win_h = map->frame.height;
             lds_bytes = (int)whole;
             mode = 1;
-        } else {
+        } else if (getenv("BOTLAB_MCL_WINDOW")) {
             a.win_w = map->frame.width < MCL_WIN_BIG ? map->frame.width : MCL_WIN_BIG;
             a.win_h = map->frame.height < MCL_WIN_BIG ? map->frame.height : MCL_WIN_BIG;
             lds_bytes = ((a.win_w + 3) & ~3) * a.win_h;
@@ -981,6 +1030,22 @@ static int pf_launch_main(bl_pf* pf, const bl_grid* map, int R, int rand_value, 
     // packed 16-bit scoring: grid up to 8192 a side, the longest kept ray spans at most 4000 cells (see score_ray_pk)
     a.pk_ok = (map && a.frame.width <= 8192 && a.frame.height <= 8192 && ctx->scan.max_range * a.frame.cpm <= 4000.0f &&
                !pf->no_packed) ? 1 : 0;
+    // A grid too large for LDS is gathered through L2 (MAP_MODE 0); the packed path then reads a zero-framed copy made here
+    a.framed = nullptr; a.framed_stride = 0;
+    if (mode == 0 && a.pk_ok && !a.interp && !getenv("BOTLAB_MCL_NO_FRAMED")) {
+        const int W = map->frame.width, H = map->frame.height;
+        const int stride = ((W + 3) & ~3) + 8;
+        const size_t bytes = (size_t)stride * (H + 2);
+        if (bytes > pf->framed_cap) {
+            if (pf->framed) { BL_HIP(hipStreamSynchronize(ctx->stream)); BL_HIP(hipFree(pf->framed)); pf->framed = nullptr; pf->framed_cap = 0; }
+            BL_HIP(hipMalloc((void**)&pf->framed, bytes));
+            pf->framed_cap = bytes;
+        }
+        const int dwords = (stride >> 2) * (H + 2);
+        hipLaunchKernelGGL(k_mcl_frame, dim3((dwords + 255) / 256), dim3(256), 0, ctx->stream, map->cells, W, H, stride, (int*)pf->framed);
+        a.framed = pf->framed + stride + 4;
+        a.framed_stride = stride;
+    }
     a.split_log2 = 0;
     if (map && pf->split_log2_override >= 0) a.split_log2 = pf->split_log2_override;
     else if (map) {

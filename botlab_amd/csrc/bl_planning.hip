@@ -18,6 +18,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <cmath>
+#include <deque>
 #include <map>
 
 #include "bl_internal.h"
@@ -576,6 +577,7 @@ struct bl_astar_state {
     // result record and the head of the path.
     char* d_out; size_t path_cap;
     int32_t* cost_lut; int cost_lut_cap;
+    struct astar_unit* h_units;            // pinned [ASTAR_SLOTS][ASTAR_MAX_UNITS]: per-workgroup arguments of the unit form
     char* h_out[ASTAR_SLOTS];              // pinned result ring ([result][path head]): searches may be enqueued ahead of fetching
     hipEvent_t done[ASTAR_SLOTS];
     bl_frame slot_frame[ASTAR_SLOTS];
@@ -599,6 +601,12 @@ struct bl_astar_state {
 #define ASTAR_HDR 256
 static_assert(sizeof(astar_result) <= ASTAR_HDR, "result record must fit the header of the output buffer");
 
+#define ASTAR_MAX_UNITS 4
+struct astar_unit {
+    const uint16_t* l1; const int32_t* cost_lut; int2* heap; int32_t* closed; int32_t* path; astar_result* result;
+    const bl_pose_xyt_t* start_dev; bl_pose_xyt_t start_host; int sx, sy, gx, gy;
+};
+
 struct astar_args {
     const uint16_t* l1; int W, H;
     const int32_t* cost_lut; int cost_n;   // per L1 distance: obstacle cost, or ASTAR_INVALID_COST if the cell is not valid
@@ -616,6 +624,11 @@ struct astar_args {
     const int2* batch_goals;           // null: single search
     long long heap_stride, closed_stride, path_stride;
     int32_t* pool; unsigned long long* pool_cursor;
+    // unit form (the replanner's batches): workgroup b runs an unrelated search -- own distance grid, cost table, start
+    // pose, goal and scratch -- on grids of one size
+    // (an array in pinned host memory, read once per workgroup: indexing a by-value kernel argument with blockIdx moves the
+    // whole argument block out of scalar registers and slowed every search by a third)
+    const astar_unit* units;
 };
 
 // The LDS part of the heap is addressed through an address_space(3) pointer: a two-way select between an LDS and a
@@ -729,6 +742,11 @@ __device__ __forceinline__ void heap_adjust(int2* g_heap, int len, int2 value, i
 template <int LDSN, int COSTN>
 __global__ __launch_bounds__(64) void k_astar(astar_args a)
 {
+    if (a.units) {
+        const astar_unit u = a.units[blockIdx.x];
+        a.l1 = u.l1; a.cost_lut = u.cost_lut; a.heap = u.heap; a.closed = u.closed; a.path = u.path; a.result = u.result;
+        a.start_dev = u.start_dev; a.start_host = u.start_host; a.sx = u.sx; a.sy = u.sy; a.gx = u.gx; a.gy = u.gy;
+    }
     if (a.batch_goals) {
         const long long b = blockIdx.x;
         const int2 g = a.batch_goals[b];
@@ -907,6 +925,7 @@ void bl_astar_free(bl_ctx* ctx)
     if (s->heap) (void)hipFree(s->heap);
     if (s->d_out) (void)hipFree(s->d_out);
     if (s->cost_lut) (void)hipFree(s->cost_lut);
+    if (s->h_units) (void)hipHostFree(s->h_units);
     for (int i = 0; i < ASTAR_SLOTS; ++i) {
         if (s->h_out[i]) (void)hipHostFree(s->h_out[i]);
         if (s->done[i]) (void)hipEventDestroy(s->done[i]);
@@ -1006,8 +1025,9 @@ static int astar_prepare_lut(bl_ctx* ctx, const bl_dist* d, const bl_search_para
     return BL_OK;
 }
 
-static int astar_launch(bl_ctx* ctx, const bl_dist* d, const bl_pose_xyt_t* start, const void* d_start,
-                        const bl_pose_xyt_t* goal, const bl_search_params_t* params)
+// Everything of a search up to the launch: scratch, cost table, closed grid reset, and the kernel arguments.
+static int astar_fill(bl_ctx* ctx, const bl_dist* d, const bl_pose_xyt_t* start, const void* d_start,
+                      const bl_pose_xyt_t* goal, const bl_search_params_t* params, astar_args* out)
 {
     BL_CHECK_ARG(ctx != nullptr && d != nullptr && goal != nullptr && params != nullptr);
     BL_CHECK_ARG(start != nullptr || d_start != nullptr);
@@ -1024,7 +1044,7 @@ static int astar_launch(bl_ctx* ctx, const bl_dist* d, const bl_pose_xyt_t* star
     rc = astar_prepare_lut(ctx, d, params);
     if (rc) return rc;
     const int ln = d->frame.width + d->frame.height + 1;
-    astar_args a;
+    astar_args& a = *out;
     a.l1 = d->l1; a.W = d->frame.width; a.H = d->frame.height;
     a.cost_lut = s->cost_lut; a.cost_n = ln;
     a.heap = s->heap; a.heap_cap = (int)s->heap_cap;
@@ -1033,6 +1053,7 @@ static int astar_launch(bl_ctx* ctx, const bl_dist* d, const bl_pose_xyt_t* star
     a.result = (astar_result*)s->d_out;
     a.frame = d->frame;
     a.batch_goals = nullptr; a.heap_stride = a.closed_stride = a.path_stride = 0; a.pool = nullptr; a.pool_cursor = nullptr;
+    a.units = nullptr;
     bl_global_to_cell((double)goal->x, (double)goal->y, d->frame, &a.gx, &a.gy);     // astar.cpp:23-33
     a.sx = 0; a.sy = 0;
     a.start_dev = (const bl_pose_xyt_t*)d_start;
@@ -1043,28 +1064,85 @@ static int astar_launch(bl_ctx* ctx, const bl_dist* d, const bl_pose_xyt_t* star
         memset(&a.start_host, 0, sizeof(a.start_host));
     }
     a.max_pops = 1ll << 31;
-    hipEvent_t e0, e1;
-    rc = bl_timer_begin(ctx, BL_K_ASTAR, &e0, &e1);
-    if (rc) return rc;
     bl_dist* dm = const_cast<bl_dist*>(d);           // closed[] is search scratch that travels with the grid
     if (!dm->closed_clean) BL_HIP(hipMemsetAsync(dm->closed, 0xFF, (size_t)a.W * a.H * 4, ctx->stream));
     dm->closed_clean = false;
-    // The 40 KB heap is for searches that share CUs with the particle filter's whole-grid LDS image (grids up to 64 K
-    // cells: 3 x 40 KB + 40 KB fit one CU).  On larger grids the filter's 144 KB window leaves no room beside it either
-    // way, and an open list spilling past 4095 entries pays an HBM round trip per heap level: take the 147 KB heap.
-    if (ctx->astar_small_lds && (int64_t)a.W * a.H <= 65536)
-        hipLaunchKernelGGL((k_astar<AH_LDS_SMALL, AH_COST_LDS_SMALL>), dim3(1), dim3(64), AH_LDS_SMALL_BYTES, ctx->stream, a);
-    else
-        hipLaunchKernelGGL((k_astar<AH_LDS, AH_COST_LDS>), dim3(1), dim3(64), AH_LDS_BYTES, ctx->stream, a);
-    BL_HIP(hipGetLastError());
-    rc = bl_timer_end(ctx, BL_K_ASTAR, e0, e1);
-    if (rc) return rc;
+    return BL_OK;
+}
+
+// After the launch: the result record + path head go to the pinned ring, the event marks this search done.
+static int astar_after(bl_ctx* ctx, const bl_dist* d)
+{
+    bl_astar_state* s = ctx->astar;
     const int slot = (int)(s->launched % ASTAR_SLOTS);
     BL_HIP(hipMemcpyAsync(s->h_out[slot], s->d_out, ASTAR_HDR + ASTAR_PATH_HEAD * 4, hipMemcpyDeviceToHost, ctx->stream));
     BL_HIP(hipEventRecord(s->done[slot], ctx->stream));
     s->slot_frame[slot] = d->frame;
     s->launched += 1;
     s->pending = true;
+    return BL_OK;
+}
+
+static void astar_launch_kernel(bl_ctx* ctx, const astar_args& a, int workgroups)
+{
+    // The 40 KB heap is for searches that share CUs with the particle filter's whole-grid LDS image (grids up to 64 K
+    // cells: 3 x 40 KB + 40 KB fit one CU).  Larger grids are gathered through L2 by the filter, which leaves the LDS
+    // free, and an open list spilling past 4095 entries pays an HBM round trip per heap level: take the 147 KB heap.
+    if (ctx->astar_small_lds && (int64_t)a.W * a.H <= 65536)
+        hipLaunchKernelGGL((k_astar<AH_LDS_SMALL, AH_COST_LDS_SMALL>), dim3(workgroups), dim3(64), AH_LDS_SMALL_BYTES, ctx->stream, a);
+    else
+        hipLaunchKernelGGL((k_astar<AH_LDS, AH_COST_LDS>), dim3(workgroups), dim3(64), AH_LDS_BYTES, ctx->stream, a);
+}
+
+static int astar_launch(bl_ctx* ctx, const bl_dist* d, const bl_pose_xyt_t* start, const void* d_start,
+                        const bl_pose_xyt_t* goal, const bl_search_params_t* params)
+{
+    astar_args a;
+    int rc = astar_fill(ctx, d, start, d_start, goal, params, &a);
+    if (rc) return rc;
+    hipEvent_t e0, e1;
+    rc = bl_timer_begin(ctx, BL_K_ASTAR, &e0, &e1);
+    if (rc) return rc;
+    astar_launch_kernel(ctx, a, 1);
+    BL_HIP(hipGetLastError());
+    rc = bl_timer_end(ctx, BL_K_ASTAR, e0, e1);
+    if (rc) return rc;
+    return astar_after(ctx, d);
+}
+
+// n unrelated searches (own ctx state and distance grid each, all on the stream the ctxs share, grids of one size) as
+// ONE launch, a workgroup each: what a replanner lane does with the submissions it has collected.
+static int astar_launch_units(int n, bl_ctx* const* ctxs, bl_dist* const* dists, const void* const* d_starts,
+                              const bl_pose_xyt_t* goals, const bl_search_params_t* params)
+{
+    BL_CHECK_ARG(n >= 1 && n <= ASTAR_MAX_UNITS);
+    if (n == 1) return astar_launch(ctxs[0], dists[0], nullptr, d_starts[0], &goals[0], &params[0]);
+    astar_args a;
+    int rc0 = astar_prepare(ctxs[0], dists[0]);
+    if (rc0) return rc0;
+    bl_astar_state* s0 = ctxs[0]->astar;
+    if (!s0->h_units) BL_HIP(hipHostMalloc((void**)&s0->h_units, sizeof(astar_unit) * ASTAR_MAX_UNITS * ASTAR_SLOTS, hipHostMallocDefault));
+    // at most ASTAR_SLOTS launches of this ctx are pending, so the ring entry of the oldest is free again
+    astar_unit* units = s0->h_units + (size_t)(s0->launched % ASTAR_SLOTS) * ASTAR_MAX_UNITS;
+    for (int b = n - 1; b >= 0; --b) {               // unit 0 last: its arguments stay in `a` for the launch
+        BL_CHECK_ARG(ctxs[b]->stream == ctxs[0]->stream);
+        BL_CHECK_ARG(dists[b]->frame.width == dists[0]->frame.width && dists[b]->frame.height == dists[0]->frame.height);
+        int rc = astar_fill(ctxs[b], dists[b], nullptr, d_starts[b], &goals[b], &params[b], &a);
+        if (rc) return rc;
+        astar_unit& u = units[b];
+        u.l1 = a.l1; u.cost_lut = a.cost_lut; u.heap = a.heap; u.closed = a.closed; u.path = a.path; u.result = a.result;
+        u.start_dev = a.start_dev; u.start_host = a.start_host; u.sx = a.sx; u.sy = a.sy; u.gx = a.gx; u.gy = a.gy;
+    }
+    a.units = units;
+    bl_ctx* ctx = ctxs[0];
+    hipEvent_t e0, e1;
+    int rc = bl_timer_begin(ctx, BL_K_ASTAR, &e0, &e1);
+    if (rc) return rc;
+    astar_launch_kernel(ctx, a, n);
+    BL_HIP(hipGetLastError());
+    rc = bl_timer_end(ctx, BL_K_ASTAR, e0, e1);
+    if (rc) return rc;
+    for (int b = 0; b < n; ++b) { rc = astar_after(ctxs[b], dists[b]); if (rc) return rc; }
     return BL_OK;
 }
 
@@ -1237,6 +1315,7 @@ static int astar_batch_cells(bl_ctx* ctx, const bl_dist* d, const bl_pose_xyt_t*
         a.start_host = *start;
         bl_global_to_cell((double)start->x, (double)start->y, d->frame, &a.sx, &a.sy);
         a.max_pops = 1ll << 31;
+        a.units = nullptr;
         a.batch_goals = s->b_goals;
         a.heap_stride = s->b_heap_each; a.closed_stride = (long long)cells; a.path_stride = (long long)s->b_path_each;
         a.pool = s->b_pool; a.pool_cursor = s->b_cursor;
@@ -1340,40 +1419,60 @@ extern "C" int bl_dist_gather(bl_dist* d, const int32_t* xy_cells, int n, float*
 // them.  Two snapshot slots; every hand-off between the two streams is an event.
 #define PLANNER_SLOTS 2
 #define PLANNER_MAX_LANES 4
+#define PLANNER_MAX_BATCH ASTAR_MAX_UNITS
 
-// A lane = one side stream with its own distance grid, A* state and snapshot slots.  Consecutive submissions go to
-// consecutive lanes, so up to `lanes` replans (independent searches on independent snapshots) run concurrently, each
-// one wavefront on its own CU; results are fetched in submission order.
-struct planner_lane {
-    bl_ctx* side;                       // own ctx: stream, distance grid + A* state
+// A unit = what one replan needs: a ctx (A* scratch + result ring) on the lane's stream, a distance grid, snapshot slots.
+// A lane = one side stream with `batch` units.  Consecutive submissions fill the units of one lane; when the last one is
+// in, their searches go out as ONE k_astar launch, a workgroup each, and the next lane takes over.  So up to lanes x batch
+// replans (independent searches on independent snapshots) run concurrently, each one wavefront on its own CU, although
+// the runtime has only four hardware queues (a fifth stream would share one and serialise).  batch = 1 is a launch per
+// submission (lowest latency: the 200x200 case, where a search is shorter than a step); results always come back in
+// submission order.
+struct planner_unit {
+    bl_ctx* ctx;
     bl_dist* dist;
     bl_grid* snap[PLANNER_SLOTS];
     bl_pose_xyt_t* pose[PLANNER_SLOTS];
-    hipEvent_t snap_ready[PLANNER_SLOTS];   // recorded on main after the snapshot copies
-    hipEvent_t slot_free[PLANNER_SLOTS];    // recorded on side after the search that read the slot
-    bool slot_used[PLANNER_SLOTS];
-    int64_t submitted;
+    hipEvent_t snap_ready[PLANNER_SLOTS];   // recorded on main after the snapshot copy
+    bl_pose_xyt_t goal;
+    bl_search_params_t params;
 };
+
+struct planner_lane {
+    bl_ctx* side;                           // unit[0].ctx: owns the lane's stream
+    planner_unit unit[PLANNER_MAX_BATCH];
+    hipEvent_t slot_free[PLANNER_SLOTS];    // recorded on side after the searches that read the slot
+    bool slot_used[PLANNER_SLOTS];
+    int64_t batches;                        // batches launched on this lane
+    int filled;                             // units of the current batch whose snapshot + distance grid are enqueued
+};
+
+struct planner_ticket { int lane, unit; };
 
 struct bl_planner {
     bl_ctx* main;                       // the SLAM ctx (not owned)
-    int lanes;
+    int lanes, batch;
     planner_lane lane[PLANNER_MAX_LANES];
+    int cur_lane;                       // the lane collecting submissions
     int64_t submitted, fetched;
+    std::deque<planner_ticket>* tickets;    // outstanding submissions, oldest first
     unsigned long long* d_flag;         // number of the last submission whose snapshot is complete (written by the snapshot kernel)
     unsigned int* d_done;               // workgroup counter of the multi-workgroup snapshot kernel
     bool reserved;
     bool handoff_flag;                  // lane waits on the flag word (hipStreamWaitValue64) instead of an event
 };
 
-extern "C" int bl_planner_create(bl_ctx* ctx, int lanes, bl_planner** out)
+extern "C" int bl_planner_create_batched(bl_ctx* ctx, int lanes, int batch, bl_planner** out)
 {
     BL_CHECK_ARG(ctx != nullptr && out != nullptr && lanes >= 1 && lanes <= PLANNER_MAX_LANES);
+    BL_CHECK_ARG(batch >= 1 && batch <= PLANNER_MAX_BATCH);
     BL_HIP(hipSetDevice(ctx->device));
     bl_planner* p = new bl_planner();
     memset((void*)p, 0, sizeof(*p));
     p->main = ctx;
     p->lanes = lanes;
+    p->batch = batch;
+    p->tickets = new std::deque<planner_ticket>();
     p->handoff_flag = getenv("BOTLAB_PLANNER_HANDOFF_FLAG") != nullptr;
     BL_HIP(hipMalloc((void**)&p->d_flag, 8));
     BL_HIP(hipMalloc((void**)&p->d_done, 4));
@@ -1382,20 +1481,26 @@ extern "C" int bl_planner_create(bl_ctx* ctx, int lanes, bl_planner** out)
     BL_HIP(hipStreamSynchronize(ctx->stream));
     for (int l = 0; l < lanes; ++l) {
         planner_lane& L = p->lane[l];
-        int rc = bl_ctx_create(ctx->device, nullptr, &L.side);
-        if (rc) return rc;
-        L.side->astar_small_lds = true;      // co-runs with the SLAM stream's kernels
-        rc = bl_dist_create(L.side, &L.dist);
-        if (rc) return rc;
-        for (int i = 0; i < PLANNER_SLOTS; ++i) {
-            BL_HIP(hipMalloc((void**)&L.pose[i], sizeof(bl_pose_xyt_t)));
-            BL_HIP(hipEventCreateWithFlags(&L.snap_ready[i], hipEventDisableTiming));
-            BL_HIP(hipEventCreateWithFlags(&L.slot_free[i], hipEventDisableTiming));
+        for (int u = 0; u < batch; ++u) {
+            planner_unit& U = L.unit[u];
+            int rc = bl_ctx_create(ctx->device, u == 0 ? nullptr : (void*)L.side->stream, &U.ctx);
+            if (rc) return rc;
+            if (u == 0) L.side = U.ctx;
+            U.ctx->astar_small_lds = true;       // co-runs with the SLAM stream's kernels
+            rc = bl_dist_create(U.ctx, &U.dist);
+            if (rc) return rc;
+            for (int i = 0; i < PLANNER_SLOTS; ++i) {
+                BL_HIP(hipMalloc((void**)&U.pose[i], sizeof(bl_pose_xyt_t)));
+                BL_HIP(hipEventCreateWithFlags(&U.snap_ready[i], hipEventDisableTiming));
+            }
         }
+        for (int i = 0; i < PLANNER_SLOTS; ++i) BL_HIP(hipEventCreateWithFlags(&L.slot_free[i], hipEventDisableTiming));
     }
     *out = p;
     return BL_OK;
 }
+
+extern "C" int bl_planner_create(bl_ctx* ctx, int lanes, bl_planner** out) { return bl_planner_create_batched(ctx, lanes, 1, out); }
 
 extern "C" void bl_planner_destroy(bl_planner* p)
 {
@@ -1405,17 +1510,22 @@ extern "C" void bl_planner_destroy(bl_planner* p)
         planner_lane& L = p->lane[l];
         if (!L.side) continue;
         (void)hipStreamSynchronize(L.side->stream);
-        for (int i = 0; i < PLANNER_SLOTS; ++i) {
-            if (L.snap[i]) bl_grid_destroy(L.snap[i]);
-            if (L.pose[i]) (void)hipFree(L.pose[i]);
-            if (L.snap_ready[i]) (void)hipEventDestroy(L.snap_ready[i]);
-            if (L.slot_free[i]) (void)hipEventDestroy(L.slot_free[i]);
+        for (int u = p->batch - 1; u >= 0; --u) {            // unit 0 owns the stream: last
+            planner_unit& U = L.unit[u];
+            if (!U.ctx) continue;
+            for (int i = 0; i < PLANNER_SLOTS; ++i) {
+                if (U.snap[i]) bl_grid_destroy(U.snap[i]);
+                if (U.pose[i]) (void)hipFree(U.pose[i]);
+                if (U.snap_ready[i]) (void)hipEventDestroy(U.snap_ready[i]);
+            }
+            if (U.dist) bl_dist_destroy(U.dist);
+            bl_ctx_destroy(U.ctx);
         }
-        if (L.dist) bl_dist_destroy(L.dist);
-        bl_ctx_destroy(L.side);
+        for (int i = 0; i < PLANNER_SLOTS; ++i) if (L.slot_free[i]) (void)hipEventDestroy(L.slot_free[i]);
     }
     if (p->d_flag) (void)hipFree(p->d_flag);
     if (p->d_done) (void)hipFree(p->d_done);
+    delete p->tickets;
     delete p;
 }
 
@@ -1449,7 +1559,29 @@ __global__ __launch_bounds__(256) void k_planner_snapshot(const int8_t* __restri
     }
 }
 
-// First half of a submission: pick the lane and snapshot slot, make the SLAM stream safe to overwrite the slot, and
+// The searches of the lane's collected submissions as one launch; the next lane collects from here on.
+static int planner_launch_lane(bl_planner* p, int l)
+{
+    planner_lane& L = p->lane[l];
+    if (L.filled == 0) return BL_OK;
+    const int slot = (int)(L.batches % PLANNER_SLOTS);
+    bl_ctx* ctxs[PLANNER_MAX_BATCH]; bl_dist* dists[PLANNER_MAX_BATCH]; const void* starts[PLANNER_MAX_BATCH];
+    bl_pose_xyt_t goals[PLANNER_MAX_BATCH]; bl_search_params_t params[PLANNER_MAX_BATCH];
+    for (int u = 0; u < L.filled; ++u) {
+        planner_unit& U = L.unit[u];
+        ctxs[u] = U.ctx; dists[u] = U.dist; starts[u] = U.pose[slot]; goals[u] = U.goal; params[u] = U.params;
+    }
+    int rc = astar_launch_units(L.filled, ctxs, dists, starts, goals, params);
+    if (rc) return rc;
+    BL_HIP(hipEventRecord(L.slot_free[slot], L.side->stream));
+    L.slot_used[slot] = true;
+    L.batches += 1;
+    L.filled = 0;
+    if (l == p->cur_lane) p->cur_lane = (p->cur_lane + 1) % p->lanes;
+    return BL_OK;
+}
+
+// First half of a submission: pick the lane, unit and snapshot slot, make the SLAM stream safe to overwrite the slot, and
 // say where the snapshot goes and which number to publish when it is complete.
 int bl_planner_reserve(bl_planner* p, const bl_grid* map, bl_planner_snap* out)
 {
@@ -1457,17 +1589,27 @@ int bl_planner_reserve(bl_planner* p, const bl_grid* map, bl_planner_snap* out)
     BL_CHECK_ARG(map->ctx == p->main);
     if (p->reserved) { bl_set_error("a replanner submission is already reserved"); return BL_ERR_STATE; }
     BL_HIP(hipSetDevice(p->main->device));
-    planner_lane& L = p->lane[p->submitted % p->lanes];
-    const int slot = (int)(L.submitted % PLANNER_SLOTS);
-    bl_grid*& snap = L.snap[slot];
+    {   // a batch holds grids of one size: a map of another size starts a new one
+        planner_lane& C = p->lane[p->cur_lane];
+        if (C.filled > 0) {
+            const bl_frame& f0 = C.unit[0].dist->frame;
+            if (f0.width != map->frame.width || f0.height != map->frame.height) {
+                int rc = planner_launch_lane(p, p->cur_lane);
+                if (rc) return rc;
+            }
+        }
+    }
+    planner_lane& L = p->lane[p->cur_lane];
+    planner_unit& U = L.unit[L.filled];
+    const int slot = (int)(L.batches % PLANNER_SLOTS);
+    bl_grid*& snap = U.snap[slot];
     if (snap && (snap->frame.width != map->frame.width || snap->frame.height != map->frame.height)) {
         BL_HIP(hipStreamSynchronize(L.side->stream));
         bl_grid_destroy(snap);
         snap = nullptr;
-        L.slot_used[slot] = false;
     }
     if (!snap) {
-        int rc = bl_grid_create(L.side, map->frame.width, map->frame.height, map->frame.mpc, map->frame.cpm, map->frame.ox,
+        int rc = bl_grid_create(U.ctx, map->frame.width, map->frame.height, map->frame.mpc, map->frame.cpm, map->frame.ox,
                                 map->frame.oy, &snap);
         if (rc) return rc;
         BL_HIP(hipStreamSynchronize(L.side->stream));          // its zero-fill ran on the side stream
@@ -1477,7 +1619,7 @@ int bl_planner_reserve(bl_planner* p, const bl_grid* map, bl_planner_snap* out)
     if (L.slot_used[slot] && hipEventQuery(L.slot_free[slot]) != hipSuccess)
         BL_HIP(hipStreamWaitEvent(p->main->stream, L.slot_free[slot], 0));
     out->cells = snap->cells;
-    out->pose = L.pose[slot];
+    out->pose = U.pose[slot];
     out->flag = p->handoff_flag ? p->d_flag : nullptr;
     out->seq = (unsigned long long)p->submitted + 1ull;
     out->done_count = p->d_done;
@@ -1487,28 +1629,30 @@ int bl_planner_reserve(bl_planner* p, const bl_grid* map, bl_planner_snap* out)
 
 void bl_planner_cancel(bl_planner* p) { if (p) p->reserved = false; }
 
-// Second half: the lane stream waits for the published number, then runs setDistances + search_for_path on the snapshot.
+// Second half: the lane stream waits for the published number and runs setDistances on the snapshot; search_for_path goes
+// out with the lane's batch (at once when batch == 1).
 int bl_planner_commit(bl_planner* p, const bl_pose_xyt_t* goal, const bl_search_params_t* params)
 {
     BL_CHECK_ARG(p != nullptr && goal != nullptr && params != nullptr);
     if (!p->reserved) { bl_set_error("bl_planner_commit without bl_planner_reserve"); return BL_ERR_STATE; }
     p->reserved = false;
-    planner_lane& L = p->lane[p->submitted % p->lanes];
-    const int slot = (int)(L.submitted % PLANNER_SLOTS);
+    const int l = p->cur_lane;
+    planner_lane& L = p->lane[l];
+    planner_unit& U = L.unit[L.filled];
+    const int slot = (int)(L.batches % PLANNER_SLOTS);
     if (p->handoff_flag) {
         BL_HIP(hipStreamWaitValue64(L.side->stream, p->d_flag, (uint64_t)p->submitted + 1ull, hipStreamWaitValueGte, 0xffffffffffffffffull));
     } else {
-        BL_HIP(hipEventRecord(L.snap_ready[slot], p->main->stream));
-        BL_HIP(hipStreamWaitEvent(L.side->stream, L.snap_ready[slot], 0));
+        BL_HIP(hipEventRecord(U.snap_ready[slot], p->main->stream));
+        BL_HIP(hipStreamWaitEvent(L.side->stream, U.snap_ready[slot], 0));
     }
-    int rc = bl_dist_set_distances(L.dist, L.snap[slot]);
+    int rc = bl_dist_set_distances(U.dist, U.snap[slot]);
     if (rc) return rc;
-    rc = astar_launch(L.side, L.dist, nullptr, L.pose[slot], goal, params);
-    if (rc) return rc;
-    BL_HIP(hipEventRecord(L.slot_free[slot], L.side->stream));
-    L.slot_used[slot] = true;
-    L.submitted += 1;
+    U.goal = *goal; U.params = *params;
+    p->tickets->push_back(planner_ticket{l, L.filled});
+    L.filled += 1;
     p->submitted += 1;
+    if (L.filled == p->batch) return planner_launch_lane(p, l);
     return BL_OK;
 }
 
@@ -1533,8 +1677,20 @@ extern "C" int bl_planner_fetch(bl_planner* p, bl_pose_xyt_t* out_path, int cap,
 {
     BL_CHECK_ARG(p != nullptr);
     if (p->fetched == p->submitted) { bl_set_error("no replan pending"); return BL_ERR_STATE; }
-    planner_lane& L = p->lane[p->fetched % p->lanes];          // results come back in submission order
-    int rc = bl_astar_search_result(L.side, out_path, cap, out_len, stats);
+    const planner_ticket t = p->tickets->front();              // results come back in submission order
+    p->tickets->pop_front();
+    planner_lane& L = p->lane[t.lane];
+    // asked for before its batch is complete (the caller keeps fewer submissions in flight than a batch holds, or is
+    // draining): the batch goes out with what it has.  A lane's earlier batches are launched, so a ticket whose ctx has
+    // nothing pending can only belong to the batch being collected.
+    if (L.filled > 0 && t.unit < L.filled) {
+        bl_astar_state* st = L.unit[t.unit].ctx->astar;
+        if (!st || st->launched == st->fetched) {
+            int rc = planner_launch_lane(p, t.lane);
+            if (rc) return rc;
+        }
+    }
+    int rc = bl_astar_search_result(L.unit[t.unit].ctx, out_path, cap, out_len, stats);
     p->fetched += 1;
     return rc;
 }
@@ -1543,8 +1699,9 @@ extern "C" int bl_planner_timing(bl_planner* p, int on, double* dist_ms, double*
 {
     BL_CHECK_ARG(p != nullptr);
     double d = 0, a = 0; int64_t n = 0;
-    for (int l = 0; l < p->lanes; ++l) {
-        bl_ctx* c = p->lane[l].side;
+    for (int l = 0; l < p->lanes; ++l)
+    for (int u = 0; u < p->batch; ++u) {
+        bl_ctx* c = p->lane[l].unit[u].ctx;
         if (on >= 0) { int rc = bl_ctx_timing_enable(c, on); if (rc) return rc; if (on) { rc = bl_ctx_timing_reset(c); if (rc) return rc; } }
         double dl = 0, al = 0; int64_t nl = 0;
         int rc = bl_ctx_timing_get(c, BL_K_DIST, &dl, &nl); if (rc) return rc;

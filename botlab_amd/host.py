@@ -495,13 +495,15 @@ class AsyncPlanner:
     """bl_planner: MotionPlanner.setMap + planPath run on a second stream against a snapshot of the map and of the
     device-resident pose (the reference's planner process, src/planning/exploration.cpp:300-317)."""
 
-    def __init__(self, ctx=None, params=None, lanes=1):
+    def __init__(self, ctx=None, params=None, lanes=1, batch=1):
+        """lanes side streams; each collects `batch` submissions and searches them in one launch (bl_planner_create_batched)."""
         self.ctx = ctx or default_context()
         self.params_ = params or MotionPlannerParams()
         self.searchParams_ = SearchParams(self.params_.robotRadius, 10.0 * self.params_.robotRadius, 1.0)   # motion_planner.cpp:105-110
         self.lanes = int(lanes)
         h = C.c_void_p()
-        check(self.ctx.lib.bl_planner_create(self.ctx.h, self.lanes, C.byref(h)))
+        self.batch = int(batch)
+        check(self.ctx.lib.bl_planner_create_batched(self.ctx.h, self.lanes, self.batch, C.byref(h)))
         self.h = h
         self._buf = (Pose * 4097)()
 
