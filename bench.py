@@ -55,7 +55,7 @@ def build_inputs(args, total_steps):
     scans = []
     for k in range(1, len(poses)):
         scans.append(synth.raycast_scan(truth, m["origin"], float(m["mpc"]), poses[k - 1], poses[k], 1_000_000 + k * 100_000,
-                                        noise_sigma=0.005, rng=rng))
+                                        max_range=getattr(args, "max_range", synth.MAX_RANGE), noise_sigma=0.005, rng=rng))
     rands = np.random.default_rng(99).integers(0, 2**31 - 1, size=total_steps + 4)
     return m, truth, poses, odo, scans, rands
 
@@ -116,6 +116,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--particles", type=int, default=100_000)
     ap.add_argument("--grid", type=int, default=200, help="grid side in cells (200 = shipped obstacle_slam map)")
+    ap.add_argument("--max-range", type=float, default=8.0, help="range of the synthetic lidar in metres (rays that hit nothing "
+                    "report it)")
     ap.add_argument("--no-astar", action="store_true", help="skip the replan (distance grid + A*) in the step")
     ap.add_argument("--goal", type=float, nargs=2, default=None, metavar=("X", "Y"),
                     help="replan goal in metres (default: a point on the driven loop, see build_inputs)")

@@ -27,7 +27,8 @@
 #define MCL_LDS_RAYS 1024                     // rays whose (range, theta) table is staged in LDS (more: read from global memory)
 #define MCL_MIN_BLOCKS 512                    // split rays over lanes until the launch has at least this many workgroups (2 per CU)
 #define MCL_WIN_SMALL_BYTES (64 * 1024)       // whole-grid staging budget (200x200 int8 framed = 41 KB -> three workgroups per CU)
-#define MCL_WIN_BIG 384                       // window side for larger grids: 384^2 = 144 KB, one workgroup per CU
+#define MCL_WIN_MAX 208                       // window side: 208^2 = 42 KB, three workgroups per CU like the whole-grid image of a 200x200 map
+#define MCL_WIN_MARGIN 24                     // cells added to the scan's reach on every side of the window for the spread of the cloud
 #define SCAN_THREADS 256
 #define SCAN_ITEMS 8
 #define SCAN_TILE (SCAN_THREADS * SCAN_ITEMS)
@@ -53,7 +54,8 @@ struct bl_pf {
     bool use_lds;
     int last_blocks, last_tile;   // launch shape of the last k_mcl_main
     int last_main_blocks, last_main_particles, last_tail_tile;
-    bool fused_finish, no_fused_finish, no_packed, no_balance;
+    bool fused_finish, no_fused_finish, no_packed, no_balance, no_framed, no_window;
+    int window_override;          // window side in cells (0: from the scan's reach)
     int cus;                      // compute units of the device
     int split_log2_override;  // -1: automatic
     int block_override;       // 0: automatic
@@ -102,7 +104,8 @@ __device__ __forceinline__ int clamp_from_m1(int x, int hi)
     return r;
 }
 
-// MAP_MODE: 0 = gathers from HBM/L2 only; 1 = the whole grid is staged in LDS; 2 = LDS window + HBM/L2 fallback.
+// MAP_MODE: 0 = gathers from HBM/L2 only; 1 = the whole grid is staged in LDS; 2 = an LDS window of the zero-framed copy,
+// cells outside it gathered from that copy through L2 (packed scoring only).
 // Branch-free in modes 0 and 1: an off-grid cell reads a dummy slot and is masked to 0 (OccupancyGrid::logOdds,
 // occupancy_grid.cpp:63-71).
 template <int MAP_MODE>
@@ -118,15 +121,9 @@ __device__ __forceinline__ int grid_odds(const int8_t* __restrict__ cells, const
         const int cx = clamp_from_m1(x, f.width), cy = clamp_from_m1(y, f.height);
         return s_map[__mul24(cy, win.stride) + cx];
     }
+    // modes 0 and 2 (lanes of the window mode that cannot take the packed path): bounds test + gather through L2
     const bool in = (unsigned int)x < (unsigned int)f.width && (unsigned int)y < (unsigned int)f.height;
-    if (MAP_MODE == 0) {
-        const int v = cells[in ? (size_t)y * f.width + x : (size_t)0];
-        return in ? v : 0;
-    }
-    const unsigned int wx = (unsigned int)(x - win.x0), wy = (unsigned int)(y - win.y0);
-    const bool inw = in && wx < (unsigned int)win.w && wy < (unsigned int)win.h;
-    int v = s_map[inw ? wy * win.stride + wx : 0];
-    if (in && !inw) v = cells[(size_t)y * f.width + x];       // cloud wider than the window: rare
+    const int v = cells[in ? (size_t)y * f.width + x : (size_t)0];
     return in ? v : 0;
 }
 
@@ -206,18 +203,59 @@ __device__ __forceinline__ int pk_odds(const pk_map_global& pm, short2_t c)
 // (2.0f * t == t + t exactly).
 typedef float float2_t __attribute__((ext_vector_type(2)));
 
-template <class PM>
-__device__ __forceinline__ int score_ray_pk(const PM& pm, float2_t start, short2_t S, float cpm, float range, float cs, float sn)
+// the three cells scoreRay reads: the endpoint, its Bresenham neighbour toward the ray start and the one toward the point
+// at twice the range
+__device__ __forceinline__ void ray_cells_pk(float2_t start, short2_t S, float cpm, float range, float cs, float sn,
+                                             short2_t& E, short2_t& A, short2_t& B)
 {
     const float2_t dir = {cs, sn};
     const float2_t t = (range * dir) * cpm;                               // (range * cos) * cpm, (range * sin) * cpm
     const float2_t e = t + start;
     const float2_t x = (t + t) + start;
-    const short2_t E = __builtin_amdgcn_cvt_pk_i16((int)e.x, (int)e.y);
+    E = __builtin_amdgcn_cvt_pk_i16((int)e.x, (int)e.y);
     const short2_t X = __builtin_amdgcn_cvt_pk_i16((int)x.x, (int)x.y);
+    A = first_step_pk(E, S);
+    B = first_step_pk(E, X);
+}
+
+template <class PM>
+__device__ __forceinline__ int score_ray_pk(const PM& pm, float2_t start, short2_t S, float cpm, float range, float cs, float sn)
+{
+    short2_t E, A, B;
+    ray_cells_pk(start, S, cpm, range, cs, sn, E, A, B);
     const int odds = pk_odds(pm, E);
-    const int o1 = pk_odds(pm, first_step_pk(E, S));
-    const int o2 = pk_odds(pm, first_step_pk(E, X));
+    const int o1 = pk_odds(pm, A);
+    const int o2 = pk_odds(pm, B);
+    return odds > 0 ? 2 * odds : (o1 > 0 ? o1 : (o2 > 0 ? o2 : 0));
+}
+
+// Window form: an LDS copy of the rectangle [org, org + size) of the zero-framed image.  A cell outside the rectangle reads
+// a clamped (wrong) LDS slot and raises `miss`; the ray is then scored again from the framed image itself -- under a
+// wave-uniform branch, rare when the window covers the scan's reach around the particle cloud.
+struct pk_map_window { int base; short2_t K; short2_t org; short2_t hi; pk_map_global g; };   // hi = size - 1
+
+__device__ __forceinline__ int pk_odds_window(const pk_map_window& pm, short2_t c, int& miss)
+{
+    const short2_t zero = {(short)0, (short)0};
+    const short2_t cw = c - pm.org;
+    const short2_t cc = __builtin_elementwise_min(__builtin_elementwise_max(cw, zero), pm.hi);
+    miss |= __builtin_bit_cast(int, cc) ^ __builtin_bit_cast(int, cw);
+    const int addr = __builtin_amdgcn_sdot2(cc, pm.K, pm.base, false);
+    return *(const lds_i8_t*)(size_t)(unsigned int)addr;
+}
+
+__device__ __forceinline__ int score_ray_pk_window(const pk_map_window& pm, float2_t start, short2_t S, float cpm, float range,
+                                                   float cs, float sn)
+{
+    short2_t E, A, B;
+    ray_cells_pk(start, S, cpm, range, cs, sn, E, A, B);
+    int miss = 0;
+    int odds = pk_odds_window(pm, E, miss);
+    int o1 = pk_odds_window(pm, A, miss);
+    int o2 = pk_odds_window(pm, B, miss);
+    if (__builtin_amdgcn_ballot_w64(miss != 0)) {
+        if (miss) { odds = pk_odds(pm.g, E); o1 = pk_odds(pm.g, A); o2 = pk_odds(pm.g, B); }
+    }
     return odds > 0 ? 2 * odds : (o1 > 0 ? o1 : (o2 > 0 ? o2 : 0));
 }
 
@@ -311,68 +349,55 @@ __global__ __launch_bounds__(BLOCK) void k_mcl_main(mcl_args a)
         for (int n = threadIdx.x; n < a.R; n += BLOCK) s_ray[n] = make_float2(a.ranges[n], a.thetas[n]);
     if (MAP_MODE == 0) __syncthreads();                     // the staging paths below end with a barrier of their own
 
-    if (MAP_MODE != 0) {
-        // ---- stage the map window: centred on the cell the previous pose estimate moves to under the odometry action
+    if (MAP_MODE == 1) {
+        // ---- stage the whole grid as a framed image: rows -1..H, columns -4..stride-5 (zeros outside the grid)
+        int* s_map32 = (int*)s_dyn;
+        const int stride = ((a.frame.width + 3) & ~3) + 8;
+        win.stride = stride;
+        s_map += stride + 4;                                  // cell (0, 0) of the framed image (grid_odds<1> indexes from it)
+        const int wq = stride >> 2;
+        const bool aligned = (a.frame.width & 3) == 0;
+        for (int i = threadIdx.x; i < wq * (a.frame.height + 2); i += BLOCK) {
+            const int ry = i / wq, q = i - ry * wq;
+            const int y = ry - 1, x = 4 * q - 4;
+            int v = 0;
+            if (y >= 0 && y < a.frame.height && x >= 0 && x < a.frame.width) {
+                const size_t g = (size_t)y * a.frame.width + x;
+                if (aligned) v = *(const int*)(a.cells + g);
+                else
+                    for (int b = 0; b < 4; ++b)
+                        if (x + b < a.frame.width) v |= ((int)(unsigned char)a.cells[g + b]) << (8 * b);
+            }
+            s_map32[i] = v;
+        }
+        __syncthreads();
+    }
+    if (MAP_MODE == 2) {
+        // ---- stage a win_w x win_h window of the zero-framed copy, centred on the cell the previous pose estimate moves to
+        // under the odometry action (the host sizes it to the scan's reach; it may hang over the grid into the zero frame)
         if (threadIdx.x == 0) {
             map_window w;
-            if (a.win_w >= a.frame.width && a.win_h >= a.frame.height) {
-                w.x0 = 0; w.y0 = 0; w.w = a.frame.width; w.h = a.frame.height;
-            } else {
-                const bl_pose_xyt_t p = a.state->pose;
-                const float ex = (float)((double)p.x + a.trans * cos((double)p.theta + a.rot1));
-                const float ey = (float)((double)p.y + a.trans * sin((double)p.theta + a.rot1));
-                float gx, gy;
-                bl_global_to_grid(ex, ey, a.frame, &gx, &gy);
-                int cx = (gx > -1.0e9f && gx < 1.0e9f) ? (int)gx : 0, cy = (gy > -1.0e9f && gy < 1.0e9f) ? (int)gy : 0;
-                int x0 = max(0, min(cx - a.win_w / 2, a.frame.width - a.win_w));
-                int y0 = max(0, min(cy - a.win_h / 2, a.frame.height - a.win_h));
-                x0 &= ~3;                                     // dword-aligned window columns
-                w.x0 = x0; w.y0 = y0;
-                w.w = min(a.win_w, a.frame.width - x0);
-                w.h = min(a.win_h, a.frame.height - y0);
-            }
-            w.stride = (w.w + 3) & ~3;
+            const bl_pose_xyt_t p = a.state->pose;
+            const float ex = (float)((double)p.x + a.trans * cos((double)p.theta + a.rot1));
+            const float ey = (float)((double)p.y + a.trans * sin((double)p.theta + a.rot1));
+            float gx, gy;
+            bl_global_to_grid(ex, ey, a.frame, &gx, &gy);
+            const int cx = (gx > -1.0e6f && gx < 1.0e6f) ? (int)gx : 0, cy = (gy > -1.0e6f && gy < 1.0e6f) ? (int)gy : 0;
+            // framed image: columns [-4, framed_stride - 4), rows [-1, H + 1); window columns stay dword-aligned
+            w.x0 = max(-4, min(cx - a.win_w / 2, a.framed_stride - 4 - a.win_w)) & ~3;
+            w.y0 = max(-1, min(cy - a.win_h / 2, a.frame.height + 1 - a.win_h));
+            w.w = a.win_w; w.h = a.win_h; w.stride = a.win_w;
             s_win = w;
         }
         __syncthreads();
         win = s_win;
         int* s_map32 = (int*)s_dyn;
-        if (MAP_MODE == 1) {
-            // framed image: rows -1..H, columns -4..stride-5 (zeros outside the grid)
-            const int stride = ((a.frame.width + 3) & ~3) + 8;
-            win.stride = stride;
-            s_map += stride + 4;                                  // cell (0, 0) of the framed image (grid_odds<1> indexes from it)
-            const int wq = stride >> 2;
-            const bool aligned = (a.frame.width & 3) == 0;
-            for (int i = threadIdx.x; i < wq * (a.frame.height + 2); i += BLOCK) {
-                const int ry = i / wq, q = i - ry * wq;
-                const int y = ry - 1, x = 4 * q - 4;
-                int v = 0;
-                if (y >= 0 && y < a.frame.height && x >= 0 && x < a.frame.width) {
-                    const size_t g = (size_t)y * a.frame.width + x;
-                    if (aligned) v = *(const int*)(a.cells + g);
-                    else
-                        for (int b = 0; b < 4; ++b)
-                            if (x + b < a.frame.width) v |= ((int)(unsigned char)a.cells[g + b]) << (8 * b);
-                }
-                s_map32[i] = v;
-            }
-        } else {
-            const int wq = win.stride >> 2;                       // dwords per staged row
-            const bool aligned = ((a.frame.width & 3) == 0) && ((win.x0 & 3) == 0);
-            for (int i = threadIdx.x; i < wq * win.h; i += BLOCK) {
-                const int ry = i / wq, q = i - ry * wq;
-                const size_t g = (size_t)(win.y0 + ry) * a.frame.width + win.x0 + 4 * q;
-                int v;
-                if (aligned && win.x0 + 4 * q + 3 < a.frame.width) {
-                    v = *(const int*)(a.cells + g);
-                } else {
-                    v = 0;
-                    for (int b = 0; b < 4; ++b)
-                        if (win.x0 + 4 * q + b < a.frame.width) v |= ((int)(unsigned char)a.cells[g + b]) << (8 * b);
-                }
-                s_map32[i] = v;
-            }
+        const int wq = win.w >> 2, fq = a.framed_stride >> 2;
+        const int* f32 = (const int*)(a.framed - a.framed_stride - 4);       // row -1, column -4 of the framed image
+        const int q0 = (win.x0 + 4) >> 2;
+        for (int i = threadIdx.x; i < wq * win.h; i += BLOCK) {
+            const int ry = i / wq, q = i - ry * wq;
+            s_map32[i] = f32[(size_t)(win.y0 + 1 + ry) * fq + q0 + q];
         }
         __syncthreads();
     }
@@ -443,6 +468,23 @@ __global__ __launch_bounds__(BLOCK) void k_mcl_main(mcl_args a)
                     float sn, cs;
                     bl_sincosf(bl_wrap_to_pi(pth - ray_theta), &sn, &cs);
                     acc += score_ray_pk(pm, start, S, a.frame.cpm, range, cs, sn);
+                }
+            } else if (MAP_MODE == 2 && pk_lane) {
+                pk_map_window pm;
+                pm.base = (int)(unsigned int)(size_t)s_map;
+                pm.K = short2_t{(short)1, (short)win.stride};
+                pm.org = short2_t{(short)win.x0, (short)win.y0};
+                pm.hi = short2_t{(short)(win.w - 1), (short)(win.h - 1)};
+                pm.g.base = a.framed;
+                pm.g.K = short2_t{(short)1, (short)a.framed_stride};
+                pm.g.hi = short2_t{(short)a.frame.width, (short)a.frame.height};
+                for (int n = sub; n < a.R; n += split) {
+                    float range, ray_theta;
+                    if (rays_in_lds) { const float2 rt = s_ray[n]; range = rt.x; ray_theta = rt.y; }
+                    else { range = a.ranges[n]; ray_theta = a.thetas[n]; }
+                    float sn, cs;
+                    bl_sincosf(bl_wrap_to_pi(pth - ray_theta), &sn, &cs);
+                    acc += score_ray_pk_window(pm, start, S, a.frame.cpm, range, cs, sn);
                 }
             } else if (MAP_MODE == 0 && pk_lane && a.framed) {
                 pk_map_global pm;
@@ -772,9 +814,10 @@ static int pf_alloc(bl_pf* pf)
     pf->partials_cap = blocks;
     static bool attr_set = false;
     if (!attr_set) {
-        const int big = MCL_WIN_BIG * MCL_WIN_BIG;
+        const int big = 384 * 384;                     // BOTLAB_MCL_WINDOW may ask for up to 384 cells a side
+        BL_HIP(hipFuncSetAttribute((const void*)k_mcl_main<0, 256, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+        BL_HIP(hipFuncSetAttribute((const void*)k_mcl_main<0, 512, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
         BL_HIP(hipFuncSetAttribute((const void*)k_mcl_main<0, 1024, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
-        BL_HIP(hipFuncSetAttribute((const void*)k_mcl_main<1, 1024, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
         attr_set = true;
     }
     pf->scan_blocks = (int)((N + SCAN_TILE - 1) / SCAN_TILE);
@@ -801,6 +844,9 @@ extern "C" int bl_pf_create(bl_ctx* ctx, int num_particles, int shard_lo, int sh
     pf->no_fused_finish = getenv("BOTLAB_MCL_NO_FUSED_FINISH") != nullptr;
     pf->no_packed = getenv("BOTLAB_MCL_NO_PACKED") != nullptr;
     pf->no_balance = getenv("BOTLAB_MCL_NO_BALANCE") != nullptr;
+    pf->no_framed = getenv("BOTLAB_MCL_NO_FRAMED") != nullptr;
+    pf->no_window = getenv("BOTLAB_MCL_NO_WINDOW") != nullptr;
+    pf->window_override = getenv("BOTLAB_MCL_WINDOW") ? atoi(getenv("BOTLAB_MCL_WINDOW")) : 0;
     { int cus = 0; if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device) == hipSuccess) pf->cus = cus; }
     pf->split_log2_override = getenv("BOTLAB_MCL_SPLIT_LOG2") ? atoi(getenv("BOTLAB_MCL_SPLIT_LOG2")) : -1;
     if (pf->split_log2_override > 6) pf->split_log2_override = 6;
@@ -1005,47 +1051,56 @@ static int pf_launch_main(bl_pf* pf, const bl_grid* map, int R, int rand_value, 
     // MovingLaserScan(scan, parent_pose, pose): parent_pose.utime is the particle's previous pose utime, pose.utime is
     // ActionModel::utime_ == 0 (D3); they differ only on the first moved update after initialisation.
     a.interp = (map && pf->pose_utime != 0) ? 1 : 0;
-    // LDS map window: the whole grid when it fits the whole-grid budget, otherwise a MCL_WIN_BIG^2 window per workgroup;
-    // action-only updates read no map.
-    int lds_bytes = 0, mode = 0;
-    a.win_w = 0; a.win_h = 0;
-    if (map && pf->use_lds) {
-        const size_t whole = (size_t)(((map->frame.width + 3) & ~3) + 8) * (map->frame.height + 2);      // framed image
-        if (whole <= MCL_WIN_SMALL_BYTES) {
-            a.win_w = map->frame.width; a.win_h = map->frame.height;
-            lds_bytes = (int)whole;
-            mode = 1;
-        } else if (getenv("BOTLAB_MCL_WINDOW")) {
-            a.win_w = map->frame.width < MCL_WIN_BIG ? map->frame.width : MCL_WIN_BIG;
-            a.win_h = map->frame.height < MCL_WIN_BIG ? map->frame.height : MCL_WIN_BIG;
-            lds_bytes = ((a.win_w + 3) & ~3) * a.win_h;
-            mode = 2;
-        }
-    }
-    // Launch shape.  Rays of one particle go over 2^split_log2 adjacent lanes: the smallest split that gives
-    // >= MCL_MIN_BLOCKS workgroups (at most a wave).  512-thread workgroups when the whole grid is staged per workgroup
-    // (40 KB: up to 3 per CU); 1024 threads with the 144 KB window (one workgroup per CU: as many waves as fit).
-    int block = (mode == 2) ? 1024 : 512;        // measured at 100k and 1M particles, 200x200: 512 is within 3 % of the best
-    if (pf->block_override > 0) block = pf->block_override;
     // packed 16-bit scoring: grid up to 8192 a side, the longest kept ray spans at most 4000 cells (see score_ray_pk)
     a.pk_ok = (map && a.frame.width <= 8192 && a.frame.height <= 8192 && ctx->scan.max_range * a.frame.cpm <= 4000.0f &&
                !pf->no_packed) ? 1 : 0;
-    // A grid too large for LDS is gathered through L2 (MAP_MODE 0); the packed path then reads a zero-framed copy made here
+    // Where the gathers go.  Mode 1: the whole grid, zero-framed, staged in LDS by every workgroup (grids up to 64 KB).
+    // Larger grids: a zero-framed copy in device memory, made by k_mcl_frame in front of this launch, and
+    //   mode 2: an LDS window of it around the predicted pose, the scan's reach plus MCL_WIN_MARGIN cells for the spread of
+    //           the cloud on every side but at most MCL_WIN_MAX cells (cells outside it are gathered from the copy through L2), or
+    //   mode 0: every gather through L2 (window switched off).
+    // Without the packed path (longer rays, larger grids, the interpolating first update) mode 0 gathers from the grid itself.
+    int lds_bytes = 0, mode = 0;
+    a.win_w = 0; a.win_h = 0;
     a.framed = nullptr; a.framed_stride = 0;
-    if (mode == 0 && a.pk_ok && !a.interp && !getenv("BOTLAB_MCL_NO_FRAMED")) {
+    if (map) {
         const int W = map->frame.width, H = map->frame.height;
         const int stride = ((W + 3) & ~3) + 8;
-        const size_t bytes = (size_t)stride * (H + 2);
-        if (bytes > pf->framed_cap) {
-            if (pf->framed) { BL_HIP(hipStreamSynchronize(ctx->stream)); BL_HIP(hipFree(pf->framed)); pf->framed = nullptr; pf->framed_cap = 0; }
-            BL_HIP(hipMalloc((void**)&pf->framed, bytes));
-            pf->framed_cap = bytes;
+        const size_t whole = (size_t)stride * (H + 2);      // framed image
+        if (pf->use_lds && whole <= MCL_WIN_SMALL_BYTES) {
+            a.win_w = W; a.win_h = H;
+            lds_bytes = (int)whole;
+            mode = 1;
+        } else if (a.pk_ok && !a.interp && !pf->no_framed) {
+            if (whole > pf->framed_cap) {
+                if (pf->framed) { BL_HIP(hipStreamSynchronize(ctx->stream)); BL_HIP(hipFree(pf->framed)); pf->framed = nullptr; pf->framed_cap = 0; }
+                BL_HIP(hipMalloc((void**)&pf->framed, whole));
+                pf->framed_cap = whole;
+            }
+            const int dwords = (stride >> 2) * (H + 2);
+            hipLaunchKernelGGL(k_mcl_frame, dim3((dwords + 255) / 256), dim3(256), 0, ctx->stream, map->cells, W, H, stride, (int*)pf->framed);
+            a.framed = pf->framed + stride + 4;
+            a.framed_stride = stride;
+            // Measured at 100k-1M particles on 2000^2 / 4096^2 grids: with the rays inside it a 208-cell window is 8-22 %
+            // faster than gathering everything through L2, with nearly every ray leaving it (8 m rays) it is within
+            // -3 .. +6 %; larger windows lose more to occupancy (264: two workgroups per CU) than they gain in hits.
+            const int reach = (int)ceilf(ctx->scan.max_range * a.frame.cpm) + MCL_WIN_MARGIN;
+            int side = (2 * reach + 3) & ~3;
+            if (side > MCL_WIN_MAX) side = MCL_WIN_MAX;
+            if (pf->window_override > 0) side = (pf->window_override + 3) & ~3;
+            if (side > 384) side = 384;
+            if (pf->use_lds && !pf->no_window) {
+                a.win_w = side < stride ? side : stride;
+                a.win_h = side < H + 2 ? side : H + 2;
+                lds_bytes = a.win_w * a.win_h;
+                mode = 2;
+            }
         }
-        const int dwords = (stride >> 2) * (H + 2);
-        hipLaunchKernelGGL(k_mcl_frame, dim3((dwords + 255) / 256), dim3(256), 0, ctx->stream, map->cells, W, H, stride, (int*)pf->framed);
-        a.framed = pf->framed + stride + 4;
-        a.framed_stride = stride;
     }
+    // Launch shape.  Rays of one particle go over 2^split_log2 adjacent lanes: the smallest split that gives
+    // >= MCL_MIN_BLOCKS workgroups (at most a wave).  512-thread workgroups (whole grid staged: 40 KB, up to 3 per CU).
+    int block = 512;                             // measured at 100k and 1M particles, 200x200: 512 is within 3 % of the best
+    if (pf->block_override > 0) block = pf->block_override;
     a.split_log2 = 0;
     if (map && pf->split_log2_override >= 0) a.split_log2 = pf->split_log2_override;
     else if (map) {
@@ -1085,7 +1140,7 @@ static int pf_launch_main(bl_pf* pf, const bl_grid* map, int R, int rand_value, 
     if (rc) return rc;
 #define MCL_LAUNCH(B, M)                                                                                          \
     do {                                                                                                          \
-        if (a.interp) hipLaunchKernelGGL((k_mcl_main<1, B, M>), dim3(blocks), dim3(B), lds_bytes, ctx->stream, a); \
+        if (a.interp) hipLaunchKernelGGL((k_mcl_main<1, B, (M) == 2 ? 0 : (M)>), dim3(blocks), dim3(B), lds_bytes, ctx->stream, a); \
         else hipLaunchKernelGGL((k_mcl_main<0, B, M>), dim3(blocks), dim3(B), lds_bytes, ctx->stream, a);          \
     } while (0)
 #define MCL_LAUNCH_MODE(B)                                    \

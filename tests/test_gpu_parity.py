@@ -225,14 +225,28 @@ def test_mcl_packed_scoring_fallbacks(oracle, maps, gpu_ctx, case):
     assert moved >= 2
 
 
-@pytest.mark.parametrize("start,kidnap", [((3.3, -7.1, 0.4), False), ((-11.0, 6.0, 2.0), True)])
-def test_mcl_parity_large_grid_lds_window(oracle, maps, gpu_ctx, start, kidnap):
-    """A 1000x1000 grid does not fit the whole-grid LDS staging: the kernel stages a 384x384 window around the predicted
-    pose and falls back to global gathers outside it.  kidnap=True puts the particle cloud far from the pose the
-    window is centred on, so every gather takes the fallback path."""
+@pytest.mark.parametrize("start,kidnap,env", [
+    ((3.3, -7.1, 0.4), False, {}),
+    ((-11.0, 6.0, 2.0), True, {}),
+    ((3.3, -7.1, 0.4), False, {"BOTLAB_MCL_WINDOW": "40"}),          # a window far smaller than the scan's reach: most rays miss it
+    ("corner_lo", False, {}), ("corner_hi", False, {"BOTLAB_MCL_WINDOW": "120"}),   # window hanging over the grid's edges
+    ((3.3, -7.1, 0.4), False, {"BOTLAB_MCL_NO_WINDOW": "1"}),         # every gather through L2 from the zero-framed copy
+    ((3.3, -7.1, 0.4), False, {"BOTLAB_MCL_NO_FRAMED": "1"}),         # ... from the grid itself (unpacked scoring)
+])
+def test_mcl_parity_large_grid_lds_window(oracle, maps, gpu_ctx, start, kidnap, env, monkeypatch):
+    """A 1000x1000 grid does not fit the whole-grid LDS staging: the kernel stages a window of the zero-framed copy around
+    the predicted pose, sized to the scan's reach, and gathers from the copy through L2 outside it.  kidnap=True puts the
+    particle cloud far from the pose the window is centred on, so every gather takes the second path."""
     N = 3000
+    for k_, v_ in env.items():
+        monkeypatch.setenv(k_, v_)                      # read when the filter is created
     world = synth.tile_world(maps["astar_maze"]["cells"], 1000)
     origin, mpc, cpm = (np.float32(-25.0), np.float32(-25.0)), np.float32(0.05), helpers.CPM_DEFAULT
+    corner = isinstance(start, str)
+    if corner:                                          # a free cell next to the grid's first / last corner
+        free = np.argwhere(world[:40, :40] <= 0) if start == "corner_lo" else np.argwhere(world[-40:, -40:] <= 0) + 960
+        cy_, cx_ = free[len(free) // 2]
+        start = (-25.0 + (cx_ + 0.5) * 0.05, -25.0 + (cy_ + 0.5) * 0.05, 0.7)
     cells = np.where(world > 0, 100, -60).astype(np.int8)
     g = bl.OccupancyGrid.from_cells(cells, origin, mpc, cellsPerMeter=cpm, ctx=gpu_ctx)
     poses = synth.square_trajectory(start, 6, step_len=0.05, turn=0.1, side=0.2)
@@ -262,7 +276,7 @@ def test_mcl_parity_large_grid_lds_window(oracle, maps, gpu_ctx, start, kidnap):
         for f in ("x", "y", "theta"):
             assert np.allclose(got[f], exp[f], rtol=REL, atol=1e-7)
         assert np.allclose(got["weight"], exp["weight"], rtol=REL, atol=0)
-        assert (res["raw"] > 0).sum() > N // 2        # the scans really hit the map
+        assert corner or (res["raw"] > 0).sum() > N // 2        # the scans really hit the map
 
 
 def test_mcl_action_only(oracle, maps, gpu_ctx):
