@@ -76,7 +76,8 @@ BL_HD double bl_cos_poly(double x2, double c0, double c1c, double c2c, double c3
     return __builtin_fma(c2, x6, c);
 }
 
-BL_HD void bl_sincosf(float y, float* sn, float* cs)
+template <bool SIGNED_ZERO>
+BL_HD void bl_sincosf_t(float y, float* sn, float* cs)
 {
     const double C0 = 0x1p0, C1 = -0x1.ffffffd0c621cp-2, C2 = 0x1.55553e1068f19p-5, C3 = -0x1.6c087e89a359dp-10,
                  C4 = 0x1.99343027bf8c3p-16, S1 = -0x1.555545995a603p-3, S2 = 0x1.1107605230bc4p-7,
@@ -97,13 +98,24 @@ BL_HD void bl_sincosf(float y, float* sn, float* cs)
     float pc = (float)bl_cos_poly(x2, C0, C1, C2, C3, C4);
     union { float f; uint32_t u; } us, uc, uy;
     uy.f = y;
-    const bool tiny = ((uy.u >> 20) & 0x7ff) < 0x398;         // |y| < 2^-12: glibc returns y and 1.0f (keeps sin(-0) = -0)
-    us.f = tiny ? y : ps; uc.f = tiny ? 1.0f : pc;
+    if (SIGNED_ZERO) {
+        const bool tiny = ((uy.u >> 20) & 0x7ff) < 0x398;     // |y| < 2^-12: glibc returns y and 1.0f (keeps sin(-0) = -0)
+        us.f = tiny ? y : ps; uc.f = tiny ? 1.0f : pc;
+    } else {
+        us.f = ps; uc.f = pc;                                 // equal for every float but -0 (sin(-0) = +0 here)
+    }
     us.u ^= ((uint32_t)(n + 1) & 2u) << 30;                   // sign[n & 3] = {1, -1, -1, 1}
     uc.u ^= ((uint32_t)n & 2u) << 30;                         // table 1 (n & 2): cosine coefficients negated
     if (n & 1) { *sn = uc.f; *cs = us.f; }
     else       { *sn = us.f; *cs = uc.f; }
 }
+
+BL_HD void bl_sincosf(float y, float* sn, float* cs) { bl_sincosf_t<true>(y, sn, cs); }
+
+// For the ray scoring only: the one input on which it differs from bl_sincosf is y = -0 (sine +0 instead of -0; checked
+// over every float by tests/tools/sincosf_exhaustive.cpp), and a zero of either sign times range * cellsPerMeter added to
+// the start coordinate truncates to the same cell.  Saves the |y| < 2^-12 test and two selects per ray.
+BL_HD void bl_sincosf_cells(float y, float* sn, float* cs) { bl_sincosf_t<false>(y, sn, cs); }
 
 // ---------------------------------------------------------------- pose interpolation
 struct bl_pose3 { float x, y, theta; };

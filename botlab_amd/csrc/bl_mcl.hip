@@ -174,28 +174,43 @@ __device__ __forceinline__ short2_t first_step_pk(short2_t e, short2_t target)
     const short2_t ad = __builtin_elementwise_max(d, -d);
     const short2_t t = (ad << 1) - ad.yx;
     const short2_t nostep = pk_sign_fill(t);
-    const short2_t sg = pk_sign_fill(d - (short)1) | (short)1;            // d > 0 ? 1 : -1
-    return e + (sg & ~nostep);
+    const short2_t dneg = pk_sign_fill(d - (short)1);                     // d > 0 ? 0 : -1
+    // (dneg | 1) & ~nostep, i.e. (d > 0 ? 1 : -1) where the axis steps, in one v_bitop3 (truth table a=dneg, b=nostep, c=1)
+    const int sg = __builtin_amdgcn_bitop3_b32(__builtin_bit_cast(int, dneg), __builtin_bit_cast(int, nostep), 0x00010001, 0x32);
+    return e + __builtin_bit_cast(short2_t, sg);
 }
 
-struct pk_map { int base; short2_t K; short2_t hi; };                     // LDS address of cell (0,0); (1, stride); (W, H)
+// a.x * b.x + a.y * b.y + c: the three-address form (hipcc lowers __builtin_amdgcn_sdot2 to v_dot2c, which accumulates
+// into its destination and so needs a v_mov of c in front of it)
+__device__ __forceinline__ int pk_dot2(short2_t a, short2_t b, int c)
+{
+    int r;
+    asm("v_dot2_i32_i16 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+
+// The zero frame around a staged image is MCL_FRAME cells wide (rows; 4 or more columns).  Scoring clamps the ENDPOINT cell
+// to [-2, size + 1] once; its two Bresenham neighbours are then formed from the clamped cell and need no clamp of their
+// own: they stay within the frame, and whenever the clamp moved the endpoint all three true cells lie outside the grid
+// (the endpoint by >= 2 cells, so its neighbours by >= 1) and all three cells read are frame zeros.
+#define MCL_FRAME 3
+struct pk_map { int base; short2_t K; short2_t hi; };                     // LDS address of cell (0,0); (1, stride); (W + 1, H + 1)
 struct pk_map_global { const int8_t* base; short2_t K; short2_t hi; };    // the same over a zero-framed copy in device memory
 
-__device__ __forceinline__ short2_t pk_clamp_to_frame(short2_t c, short2_t hi)
+__device__ __forceinline__ short2_t pk_clamp_endpoint(short2_t c, short2_t hi)
 {
-    const short2_t lo = {(short)-1, (short)-1};
+    const short2_t lo = {(short)-2, (short)-2};
     return __builtin_elementwise_min(__builtin_elementwise_max(c, lo), hi);
 }
 
-__device__ __forceinline__ int pk_odds(const pk_map& pm, short2_t c)
+__device__ __forceinline__ int pk_read(const pk_map& pm, short2_t c)
 {
-    const int addr = __builtin_amdgcn_sdot2(pk_clamp_to_frame(c, pm.hi), pm.K, pm.base, false);
-    return *(const lds_i8_t*)(size_t)(unsigned int)addr;
+    return *(const lds_i8_t*)(size_t)(unsigned int)pk_dot2(c, pm.K, pm.base);
 }
 
-__device__ __forceinline__ int pk_odds(const pk_map_global& pm, short2_t c)
+__device__ __forceinline__ int pk_read(const pk_map_global& pm, short2_t c)
 {
-    return pm.base[__builtin_amdgcn_sdot2(pk_clamp_to_frame(c, pm.hi), pm.K, 0, false)];     // |offset| < 2^27
+    return pm.base[pk_dot2(c, pm.K, 0)];                                   // |offset| < 2^27
 }
 
 // SensorModel::scoreRay in half-units (see score_ray_half_units), packed form.  The float endpoint arithmetic is written on
@@ -203,71 +218,85 @@ __device__ __forceinline__ int pk_odds(const pk_map_global& pm, short2_t c)
 // (2.0f * t == t + t exactly).
 typedef float float2_t __attribute__((ext_vector_type(2)));
 
-// the three cells scoreRay reads: the endpoint, its Bresenham neighbour toward the ray start and the one toward the point
-// at twice the range
-__device__ __forceinline__ void ray_cells_pk(float2_t start, short2_t S, float cpm, float range, float cs, float sn,
-                                             short2_t& E, short2_t& A, short2_t& B)
+// bl_wrap_to_pi for the ray angles, without divergent loops: the first step of the reference's loop as a select (the same
+// IEEE operation: x - 2pi == x + (-2pi)), and the full function only for a wave in which some lane needs a second step
+// (never for a pose angle in [-pi, pi] less a scan angle in [0, 2pi]).  Differs from bl_wrap_to_pi in one respect: -0 comes
+// back as +0 ((double)x + 0.0), which bl_sincosf_cells does not distinguish either.
+__device__ __forceinline__ float wrap_to_pi_cells(float x)
+{
+    const float PI_F = 0x1.921fb6p+1f;
+    const bool lo = x <= -PI_F, hi = x >= PI_F;
+    const double step = lo ? 2.0 * BL_PI : (hi ? -2.0 * BL_PI : 0.0);
+    float w = (float)((double)x + step);
+    if (__builtin_amdgcn_ballot_w64(__builtin_fabsf(w) >= PI_F)) {
+        if (__builtin_fabsf(w) >= PI_F) w = bl_wrap_to_pi(x);
+    }
+    return w;
+}
+
+// the endpoint cell and the cell at twice the range (whose direction the second neighbour is taken in)
+__device__ __forceinline__ void ray_cells_pk(float2_t start, float cpm, float range, float cs, float sn, short2_t& E, short2_t& X)
 {
     const float2_t dir = {cs, sn};
     const float2_t t = (range * dir) * cpm;                               // (range * cos) * cpm, (range * sin) * cpm
     const float2_t e = t + start;
     const float2_t x = (t + t) + start;
     E = __builtin_amdgcn_cvt_pk_i16((int)e.x, (int)e.y);
-    const short2_t X = __builtin_amdgcn_cvt_pk_i16((int)x.x, (int)x.y);
-    A = first_step_pk(E, S);
-    B = first_step_pk(E, X);
+    X = __builtin_amdgcn_cvt_pk_i16((int)x.x, (int)x.y);
+}
+
+__device__ __forceinline__ int score_pick(int odds, int o1, int o2)
+{
+    return odds > 0 ? 2 * odds : (o1 > 0 ? o1 : (o2 > 0 ? o2 : 0));
 }
 
 template <class PM>
 __device__ __forceinline__ int score_ray_pk(const PM& pm, float2_t start, short2_t S, float cpm, float range, float cs, float sn)
 {
-    short2_t E, A, B;
-    ray_cells_pk(start, S, cpm, range, cs, sn, E, A, B);
-    const int odds = pk_odds(pm, E);
-    const int o1 = pk_odds(pm, A);
-    const int o2 = pk_odds(pm, B);
-    return odds > 0 ? 2 * odds : (o1 > 0 ? o1 : (o2 > 0 ? o2 : 0));
+    short2_t E, X;
+    ray_cells_pk(start, cpm, range, cs, sn, E, X);
+    const short2_t Ec = pk_clamp_endpoint(E, pm.hi);
+    return score_pick(pk_read(pm, Ec), pk_read(pm, first_step_pk(Ec, S)), pk_read(pm, first_step_pk(Ec, X)));
 }
 
-// Window form: an LDS copy of the rectangle [org, org + size) of the zero-framed image.  A cell outside the rectangle reads
-// a clamped (wrong) LDS slot and raises `miss`; the ray is then scored again from the framed image itself -- under a
-// wave-uniform branch, rare when the window covers the scan's reach around the particle cloud.
-struct pk_map_window { int base; short2_t K; short2_t org; short2_t hi; pk_map_global g; };   // hi = size - 1
-
-__device__ __forceinline__ int pk_odds_window(const pk_map_window& pm, short2_t c, int& miss)
-{
-    const short2_t zero = {(short)0, (short)0};
-    const short2_t cw = c - pm.org;
-    const short2_t cc = __builtin_elementwise_min(__builtin_elementwise_max(cw, zero), pm.hi);
-    miss |= __builtin_bit_cast(int, cc) ^ __builtin_bit_cast(int, cw);
-    const int addr = __builtin_amdgcn_sdot2(cc, pm.K, pm.base, false);
-    return *(const lds_i8_t*)(size_t)(unsigned int)addr;
-}
+// Window form: an LDS copy of the rectangle [org, org + size) of the zero-framed image.  The endpoint is clamped to the
+// rectangle less a one-cell rim, so the two neighbours formed from the clamped cell stay inside it; if the clamp moved the
+// endpoint the ray is scored again from the framed image itself -- under a wave-uniform branch, rare when the window covers
+// the scan's reach around the particle cloud.
+struct pk_map_window { int base; short2_t K; short2_t org; short2_t hi; pk_map_global g; };   // hi = size - 2
 
 __device__ __forceinline__ int score_ray_pk_window(const pk_map_window& pm, float2_t start, short2_t S, float cpm, float range,
                                                    float cs, float sn)
 {
-    short2_t E, A, B;
-    ray_cells_pk(start, S, cpm, range, cs, sn, E, A, B);
-    int miss = 0;
-    int odds = pk_odds_window(pm, E, miss);
-    int o1 = pk_odds_window(pm, A, miss);
-    int o2 = pk_odds_window(pm, B, miss);
-    if (__builtin_amdgcn_ballot_w64(miss != 0)) {
-        if (miss) { odds = pk_odds(pm.g, E); o1 = pk_odds(pm.g, A); o2 = pk_odds(pm.g, B); }
+    short2_t E, X;
+    ray_cells_pk(start, cpm, range, cs, sn, E, X);
+    const short2_t one = {(short)1, (short)1};
+    const short2_t Ew = E - pm.org;
+    const short2_t Ec = __builtin_elementwise_min(__builtin_elementwise_max(Ew, one), pm.hi);
+    const bool miss = __builtin_bit_cast(int, Ec) != __builtin_bit_cast(int, Ew);
+    // window coordinates throughout: the directions toward S and X are differences, so both move with the origin
+    const short2_t Sw = S - pm.org, Xw = X - pm.org;
+    int odds = *(const lds_i8_t*)(size_t)(unsigned int)pk_dot2(Ec, pm.K, pm.base);
+    int o1 = *(const lds_i8_t*)(size_t)(unsigned int)pk_dot2(first_step_pk(Ec, Sw), pm.K, pm.base);
+    int o2 = *(const lds_i8_t*)(size_t)(unsigned int)pk_dot2(first_step_pk(Ec, Xw), pm.K, pm.base);
+    if (__builtin_amdgcn_ballot_w64(miss)) {
+        if (miss) {
+            const short2_t Eg = pk_clamp_endpoint(E, pm.g.hi);
+            odds = pk_read(pm.g, Eg); o1 = pk_read(pm.g, first_step_pk(Eg, S)); o2 = pk_read(pm.g, first_step_pk(Eg, X));
+        }
     }
-    return odds > 0 ? 2 * odds : (o1 > 0 ? o1 : (o2 > 0 ? o2 : 0));
+    return score_pick(odds, o1, o2);
 }
 
-// Zero-framed copy of the grid (rows -1..H, columns -4..stride-5), one dword per thread: the image k_mcl_main stages in LDS
-// for small grids, kept in device memory for grids that do not fit.
+// Zero-framed copy of the grid (rows -MCL_FRAME..H+MCL_FRAME-1, columns -4..stride-5), one dword per thread: the image
+// k_mcl_main stages in LDS for small grids, kept in device memory for grids that do not fit.
 __global__ __launch_bounds__(256) void k_mcl_frame(const int8_t* __restrict__ cells, int W, int H, int stride, int* __restrict__ framed)
 {
     const int wq = stride >> 2;
     const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= wq * (H + 2)) return;
+    if (i >= wq * (H + 2 * MCL_FRAME)) return;
     const int ry = i / wq, q = i - ry * wq;
-    const int y = ry - 1, x = 4 * q - 4;
+    const int y = ry - MCL_FRAME, x = 4 * q - 4;
     int v = 0;
     if (y >= 0 && y < H && x >= 0 && x < W) {
         const size_t g = (size_t)y * W + x;
@@ -341,25 +370,28 @@ __global__ __launch_bounds__(BLOCK) void k_mcl_main(mcl_args a)
     extern __shared__ __align__(16) signed char s_dyn[];
     __shared__ double s_part[BLOCK / 64][5];
     __shared__ map_window s_win;
-    __shared__ float2 s_ray[MCL_LDS_RAYS];                  // (range, theta) of the kept rays: one ds_read_b64 per ray
+    // (range, theta) of the kept rays, MCL_LDS_RAYS at a time: one ds_read_b64 per ray.  (A table that is read from LDS or,
+    // past its size, from global memory makes every access a FLAT load behind two scalar branches.)
+    __shared__ float2 s_ray[MCL_LDS_RAYS];
     const lds_i8_t* s_map = (const lds_i8_t*)s_dyn;
     map_window win = {0, 0, 0, 0, 0};
-    const bool rays_in_lds = a.R <= MCL_LDS_RAYS;
-    if (rays_in_lds)
-        for (int n = threadIdx.x; n < a.R; n += BLOCK) s_ray[n] = make_float2(a.ranges[n], a.thetas[n]);
+    {
+        const int cnt = a.R < MCL_LDS_RAYS ? a.R : MCL_LDS_RAYS;
+        for (int n = threadIdx.x; n < cnt; n += BLOCK) s_ray[n] = make_float2(a.ranges[n], a.thetas[n]);
+    }
     if (MAP_MODE == 0) __syncthreads();                     // the staging paths below end with a barrier of their own
 
     if (MAP_MODE == 1) {
-        // ---- stage the whole grid as a framed image: rows -1..H, columns -4..stride-5 (zeros outside the grid)
+        // ---- stage the whole grid as a framed image: rows -MCL_FRAME..H+MCL_FRAME-1, columns -4..stride-5 (zeros outside)
         int* s_map32 = (int*)s_dyn;
         const int stride = ((a.frame.width + 3) & ~3) + 8;
         win.stride = stride;
-        s_map += stride + 4;                                  // cell (0, 0) of the framed image (grid_odds<1> indexes from it)
+        s_map += MCL_FRAME * stride + 4;                      // cell (0, 0) of the framed image (grid_odds<1> indexes from it)
         const int wq = stride >> 2;
         const bool aligned = (a.frame.width & 3) == 0;
-        for (int i = threadIdx.x; i < wq * (a.frame.height + 2); i += BLOCK) {
+        for (int i = threadIdx.x; i < wq * (a.frame.height + 2 * MCL_FRAME); i += BLOCK) {
             const int ry = i / wq, q = i - ry * wq;
-            const int y = ry - 1, x = 4 * q - 4;
+            const int y = ry - MCL_FRAME, x = 4 * q - 4;
             int v = 0;
             if (y >= 0 && y < a.frame.height && x >= 0 && x < a.frame.width) {
                 const size_t g = (size_t)y * a.frame.width + x;
@@ -374,7 +406,7 @@ __global__ __launch_bounds__(BLOCK) void k_mcl_main(mcl_args a)
     }
     if (MAP_MODE == 2) {
         // ---- stage a win_w x win_h window of the zero-framed copy, centred on the cell the previous pose estimate moves to
-        // under the odometry action (the host sizes it to the scan's reach; it may hang over the grid into the zero frame)
+        // under the odometry action (it may hang over the grid into the zero frame)
         if (threadIdx.x == 0) {
             map_window w;
             const bl_pose_xyt_t p = a.state->pose;
@@ -383,9 +415,9 @@ __global__ __launch_bounds__(BLOCK) void k_mcl_main(mcl_args a)
             float gx, gy;
             bl_global_to_grid(ex, ey, a.frame, &gx, &gy);
             const int cx = (gx > -1.0e6f && gx < 1.0e6f) ? (int)gx : 0, cy = (gy > -1.0e6f && gy < 1.0e6f) ? (int)gy : 0;
-            // framed image: columns [-4, framed_stride - 4), rows [-1, H + 1); window columns stay dword-aligned
+            // framed image: columns [-4, framed_stride - 4), rows [-MCL_FRAME, H + MCL_FRAME); window columns stay dword-aligned
             w.x0 = max(-4, min(cx - a.win_w / 2, a.framed_stride - 4 - a.win_w)) & ~3;
-            w.y0 = max(-1, min(cy - a.win_h / 2, a.frame.height + 1 - a.win_h));
+            w.y0 = max(-MCL_FRAME, min(cy - a.win_h / 2, a.frame.height + MCL_FRAME - a.win_h));
             w.w = a.win_w; w.h = a.win_h; w.stride = a.win_w;
             s_win = w;
         }
@@ -393,11 +425,11 @@ __global__ __launch_bounds__(BLOCK) void k_mcl_main(mcl_args a)
         win = s_win;
         int* s_map32 = (int*)s_dyn;
         const int wq = win.w >> 2, fq = a.framed_stride >> 2;
-        const int* f32 = (const int*)(a.framed - a.framed_stride - 4);       // row -1, column -4 of the framed image
+        const int* f32 = (const int*)(a.framed - MCL_FRAME * a.framed_stride - 4);       // first row, column -4 of the framed image
         const int q0 = (win.x0 + 4) >> 2;
         for (int i = threadIdx.x; i < wq * win.h; i += BLOCK) {
             const int ry = i / wq, q = i - ry * wq;
-            s_map32[i] = f32[(size_t)(win.y0 + 1 + ry) * fq + q0 + q];
+            s_map32[i] = f32[(size_t)(win.y0 + MCL_FRAME + ry) * fq + q0 + q];
         }
         __syncthreads();
     }
@@ -414,10 +446,13 @@ __global__ __launch_bounds__(BLOCK) void k_mcl_main(mcl_args a)
     const bool active = j < a.n_local && (tail || j < a.main_particles);
     double t_units = 0, t_x = 0, t_y = 0, t_s = 0, t_c = 0;
 
+    const int m = a.lo + j;
+    int i = m;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    float px = 0.f, py = 0.f, pth = 0.f, sx0 = 0.f, sy0 = 0.f;
+    int isx0 = 0, isy0 = 0;
     if (active) {
-        const int m = a.lo + j;
         // ---- resamplePosteriorDistribution (particle_filter.cpp:84-103)
-        int i = m;
         if (a.resample) {
             const double U = a.r + m * a.M_inv;
             const double T = U * a.state->S;
@@ -428,7 +463,7 @@ __global__ __launch_bounds__(BLOCK) void k_mcl_main(mcl_args a)
             }
             i = lo;
         }
-        const float4 s = a.src[i];
+        s = a.src[i];
         // ---- ActionModel::applyAction (action_model.cpp:78-103)
         float n1, n2, n3;
         if (a.noise) {
@@ -441,85 +476,90 @@ __global__ __launch_bounds__(BLOCK) void k_mcl_main(mcl_args a)
             n3 = (float)(a.rot2 + a.rot2Std * (double)z[2]);
         }
         const float head = s.z + n1;                        // float sum, then double libm cos/sin of it
-        const float px = (float)((double)s.x + (double)n2 * cos((double)head));
-        const float py = (float)((double)s.y + (double)n2 * sin((double)head));
-        const float pth = bl_wrap_to_pi(s.z + n1 + n3);
-
-        // ---- SensorModel::likelihood (sensor_model.cpp:14-25) over MovingLaserScan(scan, parent_pose, pose)
-        int acc = 0;                                        // half-units: likelihood = acc / 2 exactly
+        px = (float)((double)s.x + (double)n2 * cos((double)head));
+        py = (float)((double)s.y + (double)n2 * sin((double)head));
+        pth = bl_wrap_to_pi(s.z + n1 + n3);
         if (a.cells) {
-            const bl_pose3 pb = {s.x, s.y, s.z};
-            const bl_pose3 pe = {px, py, pth};
-            float sx0, sy0;
             bl_global_to_grid(px, py, a.frame, &sx0, &sy0);
-            const int isx0 = (int)sx0, isy0 = (int)sy0;
-            const bool pk_lane = !INTERP && a.pk_ok && isx0 >= -8191 && isx0 <= 8191 && isy0 >= -8191 && isy0 <= 8191;
-            const short2_t S = {(short)isx0, (short)isy0};
-            const float2_t start = {sx0, sy0};
+            isx0 = (int)sx0; isy0 = (int)sy0;
+        }
+    }
+
+    // ---- SensorModel::likelihood (sensor_model.cpp:14-25) over MovingLaserScan(scan, parent_pose, pose)
+    int acc = 0;                                            // half-units: likelihood = acc / 2 exactly
+    if (a.cells) {
+        const bool pk_lane = !INTERP && a.pk_ok && isx0 >= -8191 && isx0 <= 8191 && isy0 >= -8191 && isy0 <= 8191;
+        const short2_t S = {(short)isx0, (short)isy0};
+        const float2_t start = {sx0, sy0};
+        for (int base = 0; base < a.R; base += MCL_LDS_RAYS) {      // one pass for scans of up to MCL_LDS_RAYS kept rays
+            const int cnt = a.R - base < MCL_LDS_RAYS ? a.R - base : MCL_LDS_RAYS;
+            if (base > 0) {
+                __syncthreads();                                    // every lane is done with the previous chunk
+                for (int n = threadIdx.x; n < cnt; n += BLOCK) s_ray[n] = make_float2(a.ranges[base + n], a.thetas[base + n]);
+                __syncthreads();
+            }
+            if (!active) continue;
             if (MAP_MODE == 1 && pk_lane) {
                 pk_map pm;
                 pm.base = (int)(unsigned int)(size_t)s_map;
                 pm.K = short2_t{(short)1, (short)win.stride};
-                pm.hi = short2_t{(short)a.frame.width, (short)a.frame.height};
-                for (int n = sub; n < a.R; n += split) {
-                    float range, ray_theta;
-                    if (rays_in_lds) { const float2 rt = s_ray[n]; range = rt.x; ray_theta = rt.y; }
-                    else { range = a.ranges[n]; ray_theta = a.thetas[n]; }
+                pm.hi = short2_t{(short)(a.frame.width + 1), (short)(a.frame.height + 1)};
+                for (int n = sub; n < cnt; n += split) {
+                    const float2 rt = s_ray[n];
                     float sn, cs;
-                    bl_sincosf(bl_wrap_to_pi(pth - ray_theta), &sn, &cs);
-                    acc += score_ray_pk(pm, start, S, a.frame.cpm, range, cs, sn);
+                    bl_sincosf_cells(wrap_to_pi_cells(pth - rt.y), &sn, &cs);
+                    acc += score_ray_pk(pm, start, S, a.frame.cpm, rt.x, cs, sn);
                 }
             } else if (MAP_MODE == 2 && pk_lane) {
                 pk_map_window pm;
                 pm.base = (int)(unsigned int)(size_t)s_map;
                 pm.K = short2_t{(short)1, (short)win.stride};
                 pm.org = short2_t{(short)win.x0, (short)win.y0};
-                pm.hi = short2_t{(short)(win.w - 1), (short)(win.h - 1)};
+                pm.hi = short2_t{(short)(win.w - 2), (short)(win.h - 2)};
                 pm.g.base = a.framed;
                 pm.g.K = short2_t{(short)1, (short)a.framed_stride};
-                pm.g.hi = short2_t{(short)a.frame.width, (short)a.frame.height};
-                for (int n = sub; n < a.R; n += split) {
-                    float range, ray_theta;
-                    if (rays_in_lds) { const float2 rt = s_ray[n]; range = rt.x; ray_theta = rt.y; }
-                    else { range = a.ranges[n]; ray_theta = a.thetas[n]; }
+                pm.g.hi = short2_t{(short)(a.frame.width + 1), (short)(a.frame.height + 1)};
+                for (int n = sub; n < cnt; n += split) {
+                    const float2 rt = s_ray[n];
                     float sn, cs;
-                    bl_sincosf(bl_wrap_to_pi(pth - ray_theta), &sn, &cs);
-                    acc += score_ray_pk_window(pm, start, S, a.frame.cpm, range, cs, sn);
+                    bl_sincosf_cells(wrap_to_pi_cells(pth - rt.y), &sn, &cs);
+                    acc += score_ray_pk_window(pm, start, S, a.frame.cpm, rt.x, cs, sn);
                 }
             } else if (MAP_MODE == 0 && pk_lane && a.framed) {
                 pk_map_global pm;
                 pm.base = a.framed;
                 pm.K = short2_t{(short)1, (short)a.framed_stride};
-                pm.hi = short2_t{(short)a.frame.width, (short)a.frame.height};
-                for (int n = sub; n < a.R; n += split) {
-                    float range, ray_theta;
-                    if (rays_in_lds) { const float2 rt = s_ray[n]; range = rt.x; ray_theta = rt.y; }
-                    else { range = a.ranges[n]; ray_theta = a.thetas[n]; }
+                pm.hi = short2_t{(short)(a.frame.width + 1), (short)(a.frame.height + 1)};
+                for (int n = sub; n < cnt; n += split) {
+                    const float2 rt = s_ray[n];
                     float sn, cs;
-                    bl_sincosf(bl_wrap_to_pi(pth - ray_theta), &sn, &cs);
-                    acc += score_ray_pk(pm, start, S, a.frame.cpm, range, cs, sn);
+                    bl_sincosf_cells(wrap_to_pi_cells(pth - rt.y), &sn, &cs);
+                    acc += score_ray_pk(pm, start, S, a.frame.cpm, rt.x, cs, sn);
                 }
-            } else
-            for (int n = sub; n < a.R; n += split) {        // the host uploads only rays with range > 0.15f (moving_laser_scan.cpp:24)
-                float range, ray_theta;
-                if (rays_in_lds) { const float2 rt = s_ray[n]; range = rt.x; ray_theta = rt.y; }
-                else { range = a.ranges[n]; ray_theta = a.thetas[n]; }
-                float theta, sx, sy;
-                int isx, isy;
-                if (INTERP) {
-                    bl_pose3 rp = bl_interpolate_pose(pb, pe, bl_interp_ratio(a.times[n], a.t_begin, a.t_den));
-                    theta = bl_wrap_to_pi(rp.theta - ray_theta);
-                    bl_global_to_grid(rp.x, rp.y, a.frame, &sx, &sy);
-                    isx = (int)sx; isy = (int)sy;
-                } else {
-                    theta = bl_wrap_to_pi(pth - ray_theta);
-                    sx = sx0; sy = sy0; isx = isx0; isy = isy0;
+            } else {
+                const bl_pose3 pb = {s.x, s.y, s.z};
+                const bl_pose3 pe = {px, py, pth};
+                for (int n = sub; n < cnt; n += split) {    // the host uploads only rays with range > 0.15f (moving_laser_scan.cpp:24)
+                    const float2 rt = s_ray[n];
+                    float theta, sx, sy;
+                    int isx, isy;
+                    if (INTERP) {
+                        bl_pose3 rp = bl_interpolate_pose(pb, pe, bl_interp_ratio(a.times[base + n], a.t_begin, a.t_den));
+                        theta = bl_wrap_to_pi(rp.theta - rt.y);
+                        bl_global_to_grid(rp.x, rp.y, a.frame, &sx, &sy);
+                        isx = (int)sx; isy = (int)sy;
+                    } else {
+                        theta = bl_wrap_to_pi(pth - rt.y);
+                        sx = sx0; sy = sy0; isx = isx0; isy = isy0;
+                    }
+                    float sn, cs;
+                    bl_sincosf(theta, &sn, &cs);
+                    acc += score_ray_half_units<MAP_MODE>(a.cells, s_map, win, a.frame, sx, sy, isx, isy, rt.x, cs, sn);
                 }
-                float sn, cs;
-                bl_sincosf(theta, &sn, &cs);
-                acc += score_ray_half_units<MAP_MODE>(a.cells, s_map, win, a.frame, sx, sy, isx, isy, range, cs, sn);
             }
         }
+    }
+    if (active) {
         for (int off = split >> 1; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);     // exact integer sum over the group
         if (sub == 0) {
             // ---- computeNormalizedPosterior (particle_filter.cpp:116-141): w = max(likelihood, 0.001) in units of 0.0005
@@ -1048,6 +1088,7 @@ static int pf_launch_main(bl_pf* pf, const bl_grid* map, int R, int rand_value, 
     a.seed_lo = (uint32_t)pf->noise_seed; a.seed_hi = (uint32_t)(pf->noise_seed >> 32);
     a.step = pf->step;
     a.resample = resample;
+    if (getenv("BOTLAB_MCL_DIAG_NOSEARCH")) a.resample = 0;          // timing experiments only: WRONG results (no resampling)
     // MovingLaserScan(scan, parent_pose, pose): parent_pose.utime is the particle's previous pose utime, pose.utime is
     // ActionModel::utime_ == 0 (D3); they differ only on the first moved update after initialisation.
     a.interp = (map && pf->pose_utime != 0) ? 1 : 0;
@@ -1066,7 +1107,7 @@ static int pf_launch_main(bl_pf* pf, const bl_grid* map, int R, int rand_value, 
     if (map) {
         const int W = map->frame.width, H = map->frame.height;
         const int stride = ((W + 3) & ~3) + 8;
-        const size_t whole = (size_t)stride * (H + 2);      // framed image
+        const size_t whole = (size_t)stride * (H + 2 * MCL_FRAME);      // framed image
         if (pf->use_lds && whole <= MCL_WIN_SMALL_BYTES) {
             a.win_w = W; a.win_h = H;
             lds_bytes = (int)whole;
@@ -1077,9 +1118,9 @@ static int pf_launch_main(bl_pf* pf, const bl_grid* map, int R, int rand_value, 
                 BL_HIP(hipMalloc((void**)&pf->framed, whole));
                 pf->framed_cap = whole;
             }
-            const int dwords = (stride >> 2) * (H + 2);
+            const int dwords = (stride >> 2) * (H + 2 * MCL_FRAME);
             hipLaunchKernelGGL(k_mcl_frame, dim3((dwords + 255) / 256), dim3(256), 0, ctx->stream, map->cells, W, H, stride, (int*)pf->framed);
-            a.framed = pf->framed + stride + 4;
+            a.framed = pf->framed + MCL_FRAME * stride + 4;
             a.framed_stride = stride;
             // Measured at 100k-1M particles on 2000^2 / 4096^2 grids: with the rays inside it a 208-cell window is 8-22 %
             // faster than gathering everything through L2, with nearly every ray leaving it (8 m rays) it is within
@@ -1091,7 +1132,7 @@ static int pf_launch_main(bl_pf* pf, const bl_grid* map, int R, int rand_value, 
             if (side > 384) side = 384;
             if (pf->use_lds && !pf->no_window) {
                 a.win_w = side < stride ? side : stride;
-                a.win_h = side < H + 2 ? side : H + 2;
+                a.win_h = side < H + 2 * MCL_FRAME ? side : H + 2 * MCL_FRAME;
                 lds_bytes = a.win_w * a.win_h;
                 mode = 2;
             }
