@@ -58,10 +58,24 @@ BL_HD double bl_angle_sum(double a, double b)
 // only ever passes wrapped angles, |y| <= pi + ulp); larger arguments take the same reduction and are NOT bit-exact.
 struct bl_sincos_tab { double c0, c1, c2, c3, c4, s1, s2, s3; };
 
+// fma(a, k, c) with compile-time constants k and c.  On the device hipcc lowers __builtin_fma(a, k, c) to a v_mov_b64 of
+// c followed by v_fmac_f64; the three-address v_fma_f64 (k from a scalar pair, c from a vector pair kept outside the loop)
+// is the same IEEE operation in one instruction.
+BL_HD double bl_fma_kc(double a, double k, double c)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    double r;
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "v"(a), "s"(k), "v"(c));
+    return r;
+#else
+    return __builtin_fma(a, k, c);
+#endif
+}
+
 BL_HD double bl_sin_poly(double x, double x2, double s1c, double s2c, double s3c)
 {
     double x3 = x * x2;
-    double s1 = __builtin_fma(x2, s3c, s2c);
+    double s1 = bl_fma_kc(x2, s3c, s2c);
     double x7 = x3 * x2;
     double s = __builtin_fma(x3, s1c, x);
     return __builtin_fma(s1, x7, s);
@@ -70,7 +84,7 @@ BL_HD double bl_cos_poly(double x2, double c0, double c1c, double c2c, double c3
 {
     double x4 = x2 * x2;
     double c1 = __builtin_fma(x2, c1c, c0);
-    double c2 = __builtin_fma(x2, c4c, c3c);
+    double c2 = bl_fma_kc(x2, c4c, c3c);
     double x6 = x4 * x2;
     double c = __builtin_fma(x4, c2c, c1);
     return __builtin_fma(c2, x6, c);

@@ -29,6 +29,8 @@
 #define MCL_WIN_SMALL_BYTES (64 * 1024)       // whole-grid staging budget (200x200 int8 framed = 41 KB -> three workgroups per CU)
 #define MCL_WIN_MAX 208                       // window side: 208^2 = 42 KB, three workgroups per CU like the whole-grid image of a 200x200 map
 #define MCL_WIN_MARGIN 24                     // cells added to the scan's reach on every side of the window for the spread of the cloud
+#define MCL_STAGE_BATCH 7                     // map dwords a thread keeps in flight while staging the grid (200x200: 21 per thread)
+#define MCL_STAGE_SEARCH 6                    // resampling bisection steps issued behind each batch
 #define SCAN_THREADS 256
 #define SCAN_ITEMS 8
 #define SCAN_TILE (SCAN_THREADS * SCAN_ITEMS)
@@ -180,6 +182,15 @@ __device__ __forceinline__ short2_t first_step_pk(short2_t e, short2_t target)
     return e + __builtin_bit_cast(short2_t, sg);
 }
 
+// A wave-uniform value held in a vector register for the whole ray loop (an asm operand of pk_dot2 that the compiler only
+// knows as a scalar is re-materialised with a v_mov in front of every use)
+__device__ __forceinline__ int vgpr_of(int s)
+{
+    int v;
+    asm volatile("v_mov_b32 %0, %1" : "=v"(v) : "s"(s));
+    return v;
+}
+
 // a.x * b.x + a.y * b.y + c: the three-address form (hipcc lowers __builtin_amdgcn_sdot2 to v_dot2c, which accumulates
 // into its destination and so needs a v_mov of c in front of it)
 __device__ __forceinline__ int pk_dot2(short2_t a, short2_t b, int c)
@@ -218,16 +229,15 @@ __device__ __forceinline__ int pk_read(const pk_map_global& pm, short2_t c)
 // (2.0f * t == t + t exactly).
 typedef float float2_t __attribute__((ext_vector_type(2)));
 
-// bl_wrap_to_pi for the ray angles, without divergent loops: the first step of the reference's loop as a select (the same
-// IEEE operation: x - 2pi == x + (-2pi)), and the full function only for a wave in which some lane needs a second step
-// (never for a pose angle in [-pi, pi] less a scan angle in [0, 2pi]).  Differs from bl_wrap_to_pi in one respect: -0 comes
-// back as +0 ((double)x + 0.0), which bl_sincosf_cells does not distinguish either.
+// bl_wrap_to_pi for the ray angles, without divergent loops: the first upward step of the reference's loop as a select (the
+// same IEEE operation), and the full function only for a wave in which some lane needs anything else.
 __device__ __forceinline__ float wrap_to_pi_cells(float x)
 {
     const float PI_F = 0x1.921fb6p+1f;
-    const bool lo = x <= -PI_F, hi = x >= PI_F;
-    const double step = lo ? 2.0 * BL_PI : (hi ? -2.0 * BL_PI : 0.0);
-    float w = (float)((double)x + step);
+    // a pose angle in (-pi, pi) less a scan angle in [0, 2pi) only ever needs the upward step; anything else (x >= pi, or a
+    // second step) takes the full function under the wave-uniform branch
+    const float up = (float)((double)x + 2.0 * BL_PI);
+    float w = x <= -PI_F ? up : x;
     if (__builtin_amdgcn_ballot_w64(__builtin_fabsf(w) >= PI_F)) {
         if (__builtin_fabsf(w) >= PI_F) w = bl_wrap_to_pi(x);
     }
@@ -381,6 +391,32 @@ __global__ __launch_bounds__(BLOCK) void k_mcl_main(mcl_args a)
     }
     if (MAP_MODE == 0) __syncthreads();                     // the staging paths below end with a barrier of their own
 
+    // Two regions in one launch (see "Whole rounds" in pf_launch_main): workgroups [0, main_blocks) take BLOCK >> split_log2
+    // particles each, 2^split_log2 lanes per particle; the workgroups after them take the remaining particles one per
+    // wave (64 lanes over the rays), so that the last partial round of the machine lasts a tenth of a full one.
+    const bool tail = (int)blockIdx.x >= a.main_blocks;
+    const int sl2 = tail ? 6 : a.split_log2;
+    const int split = 1 << sl2;
+    const int j = tail ? a.main_particles + ((((int)blockIdx.x - a.main_blocks) * BLOCK + (int)threadIdx.x) >> 6)
+                       : ((int)blockIdx.x * BLOCK + (int)threadIdx.x) >> sl2;
+    const int sub = (int)threadIdx.x & (split - 1);
+    const bool active = j < a.n_local && (tail || j < a.main_particles);
+    const int m = a.lo + j;
+    // resamplePosteriorDistribution (particle_filter.cpp:84-103): first index with T <= prefix[i], clamped to N-1.  The
+    // bisection is a chain of ~17 dependent loads; its steps are issued between the loads of the map staging below, so the
+    // two latency chains overlap.
+    int rs_lo = 0, rs_hi = (active && a.resample) ? a.N - 1 : 0;
+    double rs_T = 0.0;
+    if (active && a.resample) rs_T = (a.r + m * a.M_inv) * a.state->S;
+#define MCL_RESAMPLE_STEP()                                                              \
+    do {                                                                                 \
+        if (rs_lo < rs_hi) {                                                             \
+            const int mid_ = (rs_lo + rs_hi) >> 1;                                       \
+            if (rs_T <= (double)a.prefix[mid_]) rs_hi = mid_; else rs_lo = mid_ + 1;     \
+        }                                                                                \
+    } while (0)
+
+
     if (MAP_MODE == 1) {
         // ---- stage the whole grid as a framed image: rows -MCL_FRAME..H+MCL_FRAME-1, columns -4..stride-5 (zeros outside)
         int* s_map32 = (int*)s_dyn;
@@ -389,18 +425,48 @@ __global__ __launch_bounds__(BLOCK) void k_mcl_main(mcl_args a)
         s_map += MCL_FRAME * stride + 4;                      // cell (0, 0) of the framed image (grid_odds<1> indexes from it)
         const int wq = stride >> 2;
         const bool aligned = (a.frame.width & 3) == 0;
-        for (int i = threadIdx.x; i < wq * (a.frame.height + 2 * MCL_FRAME); i += BLOCK) {
-            const int ry = i / wq, q = i - ry * wq;
-            const int y = ry - MCL_FRAME, x = 4 * q - 4;
-            int v = 0;
-            if (y >= 0 && y < a.frame.height && x >= 0 && x < a.frame.width) {
-                const size_t g = (size_t)y * a.frame.width + x;
-                if (aligned) v = *(const int*)(a.cells + g);
-                else
+        const int total = wq * (a.frame.height + 2 * MCL_FRAME);
+        if (aligned) {
+            // MCL_STAGE_BATCH dwords per thread and pass, loaded unconditionally from a clamped address so that all of them are
+            // in flight together (a load behind a bounds test is a branch, and the passes then run one L2 round trip each);
+            // (row, dword column) advance incrementally instead of a division per dword
+            const int wdw = a.frame.width >> 2;
+            const int* cells32 = (const int*)a.cells;
+            const int dr = BLOCK / wq, dq = BLOCK - dr * wq;
+            int ry = (int)threadIdx.x / wq, q = (int)threadIdx.x - ry * wq;
+            for (int i0 = threadIdx.x; i0 < total; i0 += MCL_STAGE_BATCH * BLOCK) {
+                int v[MCL_STAGE_BATCH];
+                bool in[MCL_STAGE_BATCH];
+#pragma unroll
+                for (int u = 0; u < MCL_STAGE_BATCH; ++u) {
+                    const int y = ry - MCL_FRAME, xq = q - 1;
+                    in[u] = y >= 0 && y < a.frame.height && xq >= 0 && xq < wdw;
+                    const int yc = min(max(y, 0), a.frame.height - 1), xc = min(max(xq, 0), wdw - 1);
+                    v[u] = cells32[yc * wdw + xc];
+                    q += dq; ry += dr;
+                    if (q >= wq) { q -= wq; ry += 1; }
+                }
+#pragma unroll
+                for (int u = 0; u < MCL_STAGE_SEARCH; ++u) MCL_RESAMPLE_STEP();
+#pragma unroll
+                for (int u = 0; u < MCL_STAGE_BATCH; ++u) {
+                    const int i = i0 + u * BLOCK;
+                    if (i < total) s_map32[i] = in[u] ? v[u] : 0;
+                }
+            }
+        } else {
+            for (int i = threadIdx.x; i < total; i += BLOCK) {
+                const int ry = i / wq, q = i - ry * wq;
+                const int y = ry - MCL_FRAME, x = 4 * q - 4;
+                int v = 0;
+                if (y >= 0 && y < a.frame.height && x >= 0 && x < a.frame.width) {
+                    const size_t g = (size_t)y * a.frame.width + x;
                     for (int b = 0; b < 4; ++b)
                         if (x + b < a.frame.width) v |= ((int)(unsigned char)a.cells[g + b]) << (8 * b);
+                }
+                MCL_RESAMPLE_STEP();
+                s_map32[i] = v;
             }
-            s_map32[i] = v;
         }
         __syncthreads();
     }
@@ -429,24 +495,14 @@ __global__ __launch_bounds__(BLOCK) void k_mcl_main(mcl_args a)
         const int q0 = (win.x0 + 4) >> 2;
         for (int i = threadIdx.x; i < wq * win.h; i += BLOCK) {
             const int ry = i / wq, q = i - ry * wq;
-            s_map32[i] = f32[(size_t)(win.y0 + MCL_FRAME + ry) * fq + q0 + q];
+            const int v = f32[(size_t)(win.y0 + MCL_FRAME + ry) * fq + q0 + q];
+            MCL_RESAMPLE_STEP();
+            s_map32[i] = v;
         }
         __syncthreads();
     }
 
-    // Two regions in one launch (see "Whole rounds" in pf_launch_main): workgroups [0, main_blocks) take BLOCK >> split_log2
-    // particles each, 2^split_log2 lanes per particle; the workgroups after them take the remaining particles one per
-    // wave (64 lanes over the rays), so that the last partial round of the machine lasts a tenth of a full one.
-    const bool tail = (int)blockIdx.x >= a.main_blocks;
-    const int sl2 = tail ? 6 : a.split_log2;
-    const int split = 1 << sl2;
-    const int j = tail ? a.main_particles + ((((int)blockIdx.x - a.main_blocks) * BLOCK + (int)threadIdx.x) >> 6)
-                       : ((int)blockIdx.x * BLOCK + (int)threadIdx.x) >> sl2;
-    const int sub = (int)threadIdx.x & (split - 1);
-    const bool active = j < a.n_local && (tail || j < a.main_particles);
     double t_units = 0, t_x = 0, t_y = 0, t_s = 0, t_c = 0;
-
-    const int m = a.lo + j;
     int i = m;
     float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
     float px = 0.f, py = 0.f, pth = 0.f, sx0 = 0.f, sy0 = 0.f;
@@ -454,14 +510,8 @@ __global__ __launch_bounds__(BLOCK) void k_mcl_main(mcl_args a)
     if (active) {
         // ---- resamplePosteriorDistribution (particle_filter.cpp:84-103)
         if (a.resample) {
-            const double U = a.r + m * a.M_inv;
-            const double T = U * a.state->S;
-            int lo = 0, hi = a.N - 1;                       // first index with T <= prefix[i], clamped to N-1
-            while (lo < hi) {
-                int mid = (lo + hi) >> 1;
-                if (T <= (double)a.prefix[mid]) hi = mid; else lo = mid + 1;
-            }
-            i = lo;
+            while (rs_lo < rs_hi) MCL_RESAMPLE_STEP();      // the steps the staging loop left over
+            i = rs_lo;
         }
         s = a.src[i];
         // ---- ActionModel::applyAction (action_model.cpp:78-103)
@@ -476,8 +526,10 @@ __global__ __launch_bounds__(BLOCK) void k_mcl_main(mcl_args a)
             n3 = (float)(a.rot2 + a.rot2Std * (double)z[2]);
         }
         const float head = s.z + n1;                        // float sum, then double libm cos/sin of it
-        px = (float)((double)s.x + (double)n2 * cos((double)head));
-        py = (float)((double)s.y + (double)n2 * sin((double)head));
+        double hs, hc;
+        sincos((double)head, &hs, &hc);                     // one argument reduction for both
+        px = (float)((double)s.x + (double)n2 * hc);
+        py = (float)((double)s.y + (double)n2 * hs);
         pth = bl_wrap_to_pi(s.z + n1 + n3);
         if (a.cells) {
             bl_global_to_grid(px, py, a.frame, &sx0, &sy0);
@@ -501,8 +553,8 @@ __global__ __launch_bounds__(BLOCK) void k_mcl_main(mcl_args a)
             if (!active) continue;
             if (MAP_MODE == 1 && pk_lane) {
                 pk_map pm;
-                pm.base = (int)(unsigned int)(size_t)s_map;
-                pm.K = short2_t{(short)1, (short)win.stride};
+                pm.base = vgpr_of((int)(unsigned int)(size_t)s_map);
+                pm.K = __builtin_bit_cast(short2_t, vgpr_of(1 | (win.stride << 16)));
                 pm.hi = short2_t{(short)(a.frame.width + 1), (short)(a.frame.height + 1)};
                 for (int n = sub; n < cnt; n += split) {
                     const float2 rt = s_ray[n];
@@ -512,8 +564,8 @@ __global__ __launch_bounds__(BLOCK) void k_mcl_main(mcl_args a)
                 }
             } else if (MAP_MODE == 2 && pk_lane) {
                 pk_map_window pm;
-                pm.base = (int)(unsigned int)(size_t)s_map;
-                pm.K = short2_t{(short)1, (short)win.stride};
+                pm.base = vgpr_of((int)(unsigned int)(size_t)s_map);
+                pm.K = __builtin_bit_cast(short2_t, vgpr_of(1 | (win.stride << 16)));
                 pm.org = short2_t{(short)win.x0, (short)win.y0};
                 pm.hi = short2_t{(short)(win.w - 2), (short)(win.h - 2)};
                 pm.g.base = a.framed;
@@ -1088,7 +1140,7 @@ static int pf_launch_main(bl_pf* pf, const bl_grid* map, int R, int rand_value, 
     a.seed_lo = (uint32_t)pf->noise_seed; a.seed_hi = (uint32_t)(pf->noise_seed >> 32);
     a.step = pf->step;
     a.resample = resample;
-    if (getenv("BOTLAB_MCL_DIAG_NOSEARCH")) a.resample = 0;          // timing experiments only: WRONG results (no resampling)
+    if (getenv("BOTLAB_MCL_DIAG_NOSEARCH")) a.resample = 0;
     // MovingLaserScan(scan, parent_pose, pose): parent_pose.utime is the particle's previous pose utime, pose.utime is
     // ActionModel::utime_ == 0 (D3); they differ only on the first moved update after initialisation.
     a.interp = (map && pf->pose_utime != 0) ? 1 : 0;
