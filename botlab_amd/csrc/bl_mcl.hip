@@ -251,8 +251,19 @@ __device__ __forceinline__ void ray_cells_pk(float2_t start, float cpm, float ra
     const float2_t t = (range * dir) * cpm;                               // (range * cos) * cpm, (range * sin) * cpm
     const float2_t e = t + start;
     const float2_t x = (t + t) + start;
-    E = __builtin_amdgcn_cvt_pk_i16((int)e.x, (int)e.y);
-    X = __builtin_amdgcn_cvt_pk_i16((int)x.x, (int)x.y);
+    // (int)e.x | (int)e.y << 16 in two instructions each: the float -> int conversion writes its low half-word straight into
+    // the selected half of the pair (SDWA destination select).  No saturation is needed: the packed path's preconditions keep
+    // every cell inside int16.  A half-word write must not be read by the very next instruction (gfx940 dst_sel forwarding
+    // hazard, invisible to the compiler inside inline asm), hence the interleaving and the closing s_nop.
+    int ei, xi;
+    asm("v_cvt_i32_f32_sdwa %0, %2 dst_sel:WORD_0 dst_unused:UNUSED_PAD src0_sel:DWORD\n\t"
+        "v_cvt_i32_f32_sdwa %1, %4 dst_sel:WORD_0 dst_unused:UNUSED_PAD src0_sel:DWORD\n\t"
+        "v_cvt_i32_f32_sdwa %0, %3 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD\n\t"
+        "v_cvt_i32_f32_sdwa %1, %5 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD\n\t"
+        "s_nop 0"
+        : "=&v"(ei), "=&v"(xi) : "v"(e.x), "v"(e.y), "v"(x.x), "v"(x.y));
+    E = __builtin_bit_cast(short2_t, ei);
+    X = __builtin_bit_cast(short2_t, xi);
 }
 
 __device__ __forceinline__ int score_pick(int odds, int o1, int o2)
@@ -365,6 +376,27 @@ __device__ __forceinline__ void philox_normals3(uint32_t m, uint32_t step, uint3
     c4 = cosf(6.2831853071795864769f * u4);
     z[0] = ra * c2; z[1] = ra * s2; z[2] = rb * c4;
 }
+
+// The packed ray loops: lane `sub` of a particle's group takes rays sub, sub + split, ...  All lanes of a wave run the same
+// number of whole rounds (a scalar loop counter; the ray index only lives on as the LDS address of the table entry), and the
+// lanes with one more ray take it in a masked round behind the loop.
+#define MCL_RAY_LOOP(SCORE_EXPR)                                                        \
+    do {                                                                                \
+        const int rounds_ = cnt >> sl2;                                                 \
+        int n_ = sub;                                                                   \
+        for (int k_ = 0; k_ < rounds_; ++k_, n_ += split) {                             \
+            const float2 rt = s_ray[n_];                                                \
+            float sn, cs;                                                               \
+            bl_sincosf_cells(wrap_to_pi_cells(pth - rt.y), &sn, &cs);                   \
+            acc += SCORE_EXPR;                                                          \
+        }                                                                               \
+        if (n_ < cnt) {                                                                 \
+            const float2 rt = s_ray[n_];                                                \
+            float sn, cs;                                                               \
+            bl_sincosf_cells(wrap_to_pi_cells(pth - rt.y), &sn, &cs);                   \
+            acc += SCORE_EXPR;                                                          \
+        }                                                                               \
+    } while (0)
 
 // One lane group per output particle m of the shard: low-variance resample (gather), ActionModel::applyAction,
 // SensorModel::likelihood, weight units, and the block's partial sums for normalisation + pose estimate.
@@ -556,12 +588,7 @@ __global__ __launch_bounds__(BLOCK) void k_mcl_main(mcl_args a)
                 pm.base = vgpr_of((int)(unsigned int)(size_t)s_map);
                 pm.K = __builtin_bit_cast(short2_t, vgpr_of(1 | (win.stride << 16)));
                 pm.hi = short2_t{(short)(a.frame.width + 1), (short)(a.frame.height + 1)};
-                for (int n = sub; n < cnt; n += split) {
-                    const float2 rt = s_ray[n];
-                    float sn, cs;
-                    bl_sincosf_cells(wrap_to_pi_cells(pth - rt.y), &sn, &cs);
-                    acc += score_ray_pk(pm, start, S, a.frame.cpm, rt.x, cs, sn);
-                }
+                MCL_RAY_LOOP(score_ray_pk(pm, start, S, a.frame.cpm, rt.x, cs, sn));
             } else if (MAP_MODE == 2 && pk_lane) {
                 pk_map_window pm;
                 pm.base = vgpr_of((int)(unsigned int)(size_t)s_map);
@@ -571,23 +598,13 @@ __global__ __launch_bounds__(BLOCK) void k_mcl_main(mcl_args a)
                 pm.g.base = a.framed;
                 pm.g.K = short2_t{(short)1, (short)a.framed_stride};
                 pm.g.hi = short2_t{(short)(a.frame.width + 1), (short)(a.frame.height + 1)};
-                for (int n = sub; n < cnt; n += split) {
-                    const float2 rt = s_ray[n];
-                    float sn, cs;
-                    bl_sincosf_cells(wrap_to_pi_cells(pth - rt.y), &sn, &cs);
-                    acc += score_ray_pk_window(pm, start, S, a.frame.cpm, rt.x, cs, sn);
-                }
+                MCL_RAY_LOOP(score_ray_pk_window(pm, start, S, a.frame.cpm, rt.x, cs, sn));
             } else if (MAP_MODE == 0 && pk_lane && a.framed) {
                 pk_map_global pm;
                 pm.base = a.framed;
                 pm.K = short2_t{(short)1, (short)a.framed_stride};
                 pm.hi = short2_t{(short)(a.frame.width + 1), (short)(a.frame.height + 1)};
-                for (int n = sub; n < cnt; n += split) {
-                    const float2 rt = s_ray[n];
-                    float sn, cs;
-                    bl_sincosf_cells(wrap_to_pi_cells(pth - rt.y), &sn, &cs);
-                    acc += score_ray_pk(pm, start, S, a.frame.cpm, rt.x, cs, sn);
-                }
+                MCL_RAY_LOOP(score_ray_pk(pm, start, S, a.frame.cpm, rt.x, cs, sn));
             } else {
                 const bl_pose3 pb = {s.x, s.y, s.z};
                 const bl_pose3 pe = {px, py, pth};
