@@ -124,7 +124,8 @@ def main():
     ap.add_argument("--goal-l1", type=int, default=40, help="without --goal on a non-default grid: max L1 distance (cells) "
                     "of the replan goal from the start")
     ap.add_argument("--cpu-steps", type=int, default=25, help="steps of the CPU baseline sample (0 = skip)")
-    ap.add_argument("--depth", type=int, default=3, help="steps enqueued ahead of fetching a result (0 = synchronous steps)")
+    ap.add_argument("--depth", type=int, default=6, help="steps enqueued ahead of fetching a result (0 = synchronous steps); a replan "
+                    "(distance grid + A*, ~0.4 ms) spans three steps, so fewer than ~6 leaves the SLAM stream waiting for the host")
     ap.add_argument("--lanes", type=int, default=3, help="replanner streams: consecutive replans run concurrently (1..4)")
     ap.add_argument("--batch", type=int, default=1, help="replans a lane collects and searches in one launch (1..4): lanes x batch "
                     "searches overlap; for grids where a search outlasts several steps (use with --depth >= lanes x batch)")

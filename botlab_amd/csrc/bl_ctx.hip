@@ -242,8 +242,10 @@ int bl_scan_upload(bl_ctx* ctx, const bl_lidar_t* scan, int* num_rays)
     // in scan order, so no kernel branches on validity.
     int kept = 0;
     float max_range = 0;
+    bool thetas_simple = true;
     for (int n = 0; n < R; ++n) {
         if (!(scan->ranges[n] > 0.15f)) continue;
+        if (!(scan->thetas[n] >= 0.0f && scan->thetas[n] <= 6.2831f)) thetas_simple = false;
         if (scan->ranges[n] > max_range) max_range = scan->ranges[n];
         hrange[kept] = scan->ranges[n];
         htheta[kept] = scan->thetas[n];
@@ -268,6 +270,7 @@ int bl_scan_upload(bl_ctx* ctx, const bl_lidar_t* scan, int* num_rays)
     sl->next = (s + 1) % kScanSlots;
     sd->kept = kept;
     sd->max_range = max_range;
+    sd->thetas_simple = thetas_simple;
     return BL_OK;
 }
 

@@ -48,6 +48,7 @@ struct bl_scan_dev {
     size_t staging_bytes = 0;
     int kept = 0;               // rays in the block
     float max_range = 0;        // largest kept range (bounds the cell offsets a ray can produce)
+    bool thetas_simple = false; // every kept theta lies in [0, 6.2831]: a wrapped pose angle less a theta needs at most one upward 2*pi step
 };
 
 struct bl_astar_state;

@@ -79,25 +79,45 @@ __device__ __forceinline__ bool cell_in_grid(const bl_frame& f, int x, int y)
 
 __device__ __forceinline__ unsigned int half_of(unsigned int pair, int ci) { return (ci & 1) ? (pair >> 16) : (pair & 0xffffu); }
 
-__device__ void map_update_body(const map_args& a);
+// snap != nullptr: every store to the grid is mirrored into the replanner snapshot, whose bulk copy (the grid as it was when
+// the kernel started) the caller holds in sv[] and map_update_body stores once its first loads are under way.
+#define MAP_EARLY_VEC 4                       // int4 per thread held for the early snapshot copy: grids up to 64 KB
+__device__ __forceinline__ void map_update_body(const map_args& a, int8_t* snap, const int4 (&sv)[MAP_EARLY_VEC]);
 
 __global__ __launch_bounds__(MAP_THREADS) void k_map_update(map_args a)
 {
-    map_update_body(a);                                         // every return inside is uniform over the workgroup
-    if (a.snap_cells) {
-        __syncthreads();                                        // the grid stores of this workgroup are visible to its own loads
-        const size_t n = (size_t)a.frame.width * a.frame.height;
-        const size_t n16 = n / 16;
-        const int4* s4 = (const int4*)a.cells;
-        int4* d4 = (int4*)a.snap_cells;
-        for (size_t base = 0; base < n16; base += 4 * MAP_THREADS) {       // four loads in flight per thread, then the stores
-            int4 v[4];
+    const size_t n = (size_t)a.frame.width * a.frame.height;
+    const size_t n16 = n / 16;
+    // Early snapshot (the usual case: a 200x200 grid, a 290-ray scan): the copy of the grid is loaded before anything else
+    // and stored while the ray geometry is computed; the cells this update changes are then written to both.  Otherwise
+    // the snapshot is a copy loop behind the update.
+    const bool early = a.snap_cells != nullptr && a.apply && a.R <= MAP_THREADS && (a.frame.width & 3) == 0 &&
+                       (n & 15) == 0 && n16 <= (size_t)MAP_EARLY_VEC * MAP_THREADS;
+    int4 sv[MAP_EARLY_VEC];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) { const size_t i = base + (size_t)u * MAP_THREADS + threadIdx.x; if (i < n16) v[u] = s4[i]; }
+    for (int u = 0; u < MAP_EARLY_VEC; ++u) sv[u] = make_int4(0, 0, 0, 0);
+    if (early) {
 #pragma unroll
-            for (int u = 0; u < 4; ++u) { const size_t i = base + (size_t)u * MAP_THREADS + threadIdx.x; if (i < n16) d4[i] = v[u]; }
+        for (int u = 0; u < MAP_EARLY_VEC; ++u) {
+            const size_t i = (size_t)u * MAP_THREADS + threadIdx.x;
+            if (i < n16) sv[u] = ((const int4*)a.cells)[i];
         }
-        for (size_t i = n16 * 16 + threadIdx.x; i < n; i += MAP_THREADS) a.snap_cells[i] = a.cells[i];
+    }
+    map_update_body(a, early ? a.snap_cells : nullptr, sv);    // every return inside is uniform over the workgroup
+    if (a.snap_cells) {
+        if (!early) {
+            __syncthreads();                                    // the grid stores of this workgroup are visible to its own loads
+            const int4* s4 = (const int4*)a.cells;
+            int4* d4 = (int4*)a.snap_cells;
+            for (size_t base = 0; base < n16; base += 4 * MAP_THREADS) {       // four loads in flight per thread, then the stores
+                int4 v[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { const size_t i = base + (size_t)u * MAP_THREADS + threadIdx.x; if (i < n16) v[u] = s4[i]; }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { const size_t i = base + (size_t)u * MAP_THREADS + threadIdx.x; if (i < n16) d4[i] = v[u]; }
+            }
+            for (size_t i = n16 * 16 + threadIdx.x; i < n; i += MAP_THREADS) a.snap_cells[i] = a.cells[i];
+        }
         if (threadIdx.x == 0) *a.snap_pose = *a.snap_pose_src;
         if (a.snap_flag) {                                              // flag hand-off only; an event hand-off needs nothing here
             __threadfence();
@@ -107,7 +127,7 @@ __global__ __launch_bounds__(MAP_THREADS) void k_map_update(map_args a)
     }
 }
 
-__device__ void map_update_body(const map_args& a)
+__device__ __forceinline__ void map_update_body(const map_args& a, int8_t* snap, const int4 (&sv)[MAP_EARLY_VEC])
 {
     extern __shared__ __align__(16) unsigned int s_cnt[];     // MAP_LDS_COUNTERS/2 dwords, two uint16 counters each
     __shared__ int s_box[4];                                   // xmin, ymin, xmax, ymax over all traced cells
@@ -128,6 +148,13 @@ __device__ void map_update_body(const map_args& a)
         rec.utime = a.cur_utime;
         *a.prev = rec;
     }
+    // the first ray of every thread is loaded before the barrier the pose arrives behind (the two round trips overlap)
+    float pre_range = 0.0f, pre_theta = 0.0f;
+    int64_t pre_time = 0;
+    if (a.apply && tid < a.R) {
+        pre_range = a.ranges[tid]; pre_theta = a.thetas[tid];
+        if (a.interp) pre_time = a.times[tid];
+    }
     __syncthreads();
     if (!a.apply) return;                                       // increase/decreaseCellOdds do nothing (mapping.cpp:74,88)
 
@@ -142,10 +169,11 @@ __device__ void map_update_body(const map_args& a)
     for (int r = tid; r < a.R; r += MAP_THREADS) {
         int4 ray = make_int4(0, 0, 0, 0);
         int valid = 0;
-        float range = a.ranges[r];
+        const bool first = r == tid;
+        const float range = first ? pre_range : a.ranges[r];
         if (range <= a.max_laser) {                             // rays with range <= 0.15f were dropped on the host
-            bl_pose3 rp = a.interp ? bl_interpolate_pose(pb, pe, bl_interp_ratio(a.times[r], a.t_begin, a.t_den)) : pe;
-            float theta = bl_wrap_to_pi(rp.theta - a.thetas[r]);
+            bl_pose3 rp = a.interp ? bl_interpolate_pose(pb, pe, bl_interp_ratio(first ? pre_time : a.times[r], a.t_begin, a.t_den)) : pe;
+            float theta = bl_wrap_to_pi(rp.theta - (first ? pre_theta : a.thetas[r]));
             float sn, cs, sx, sy;
             bl_sincosf(theta, &sn, &cs);
             bl_global_to_grid(rp.x, rp.y, a.frame, &sx, &sy);
@@ -194,12 +222,24 @@ __device__ void map_update_body(const map_args& a)
     }
     __syncthreads();
 
+    if (snap) {
+        const size_t n16 = ((size_t)a.frame.width * a.frame.height) / 16;
+#pragma unroll
+        for (int u = 0; u < MAP_EARLY_VEC; ++u) {
+            const size_t i = (size_t)u * MAP_THREADS + tid;
+            if (i < n16) ((int4*)snap)[i] = sv[u];
+        }
+        __syncthreads();                                        // bulk copy before the mirrored stores of changed cells below
+    }
     MSTAMP(2);
     // ---- the update runs through an LDS window of uint16 counters: the bounding box of all ray cells clipped to the grid,
     // in horizontal strips when it exceeds the LDS budget
     int bx0 = max(s_box[0], 0), by0 = max(s_box[1], 0);
     int bx1 = min(s_box[2], a.frame.width - 1), by1 = min(s_box[3], a.frame.height - 1);
     if (bx1 < bx0 || by1 < by0) return;                         // nothing inside the grid
+    // grid rows of whole dwords: the window takes whole dwords too, and the free-space pass below updates four cells per access
+    const bool dword_rows = (a.frame.width & 3) == 0 && seg_walk;
+    if (dword_rows) { bx0 &= ~3; bx1 |= 3; }
     const int ww = bx1 - bx0 + 1;
     const int wh = by1 - by0 + 1;
     int rows_per_strip = MAP_LDS_COUNTERS / ww;
@@ -282,6 +322,7 @@ __device__ void map_update_body(const map_args& a)
                 int v = a.cells[idx];
                 v = max(-128, min(127, v + a.hit * H) - a.miss * M);
                 a.cells[idx] = (int8_t)v;
+                if (snap) snap[idx] = (int8_t)v;
                 atomicAnd(&s_cnt[ci >> 1], (ci & 1) ? 0x0000ffffu : 0xffff0000u);
             }
             __syncthreads();
@@ -313,6 +354,42 @@ __device__ void map_update_body(const map_args& a)
         // of a batch are in flight together (a serial load -> store chain per cell cost ~1 us per cell per thread)
         const int tx = tid & 255, ty = tid >> 8;
         const int nrows = sy1 - sy0 + 1;
+        if (dword_rows) {
+            // four cells (one dword of the grid, two dwords of counters) per item, four items in flight per thread
+            const int wq = ww >> 2;
+            const int nitems = nrows * wq;
+            for (int it0 = tid; it0 < nitems; it0 += 4 * MAP_THREADS) {
+                unsigned long long c[4];
+                size_t gi[4];
+                int v[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int it = it0 + u * MAP_THREADS;
+                    c[u] = 0ull; gi[u] = 0; v[u] = 0;
+                    if (it < nitems) {
+                        const int ry = it / wq, dq = it - ry * wq;
+                        c[u] = *(const unsigned long long*)&s_cnt[(ry * ww + 4 * dq) >> 1];
+                        gi[u] = (size_t)(sy0 + ry) * a.frame.width + bx0 + 4 * dq;
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (c[u]) v[u] = *(const int*)(a.cells + gi[u]);
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (c[u]) {
+                        unsigned int nv = 0;
+#pragma unroll
+                        for (int b = 0; b < 4; ++b) {
+                            const int M = (int)((c[u] >> (16 * b)) & 0xffffull);
+                            const int val = (int)(int8_t)(v[u] >> (8 * b));
+                            nv |= ((unsigned int)max(-128, val - a.miss * M) & 0xffu) << (8 * b);
+                        }
+                        *(int*)(a.cells + gi[u]) = (int)nv;
+                        if (snap) *(int*)(snap + gi[u]) = (int)nv;
+                    }
+            }
+        } else
         for (int cx = tx; cx < ww; cx += 256) {
             for (int r0 = ty; r0 < nrows; r0 += 32) {
                 int M[8], v[8];

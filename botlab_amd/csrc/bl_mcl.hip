@@ -231,15 +231,19 @@ typedef float float2_t __attribute__((ext_vector_type(2)));
 
 // bl_wrap_to_pi for the ray angles, without divergent loops: the first upward step of the reference's loop as a select (the
 // same IEEE operation), and the full function only for a wave in which some lane needs anything else.
-__device__ __forceinline__ float wrap_to_pi_cells(float x)
+__device__ __forceinline__ float wrap_to_pi_cells(float x, bool simple)
 {
     const float PI_F = 0x1.921fb6p+1f;
     // a pose angle in (-pi, pi) less a scan angle in [0, 2pi) only ever needs the upward step; anything else (x >= pi, or a
-    // second step) takes the full function under the wave-uniform branch
+    // second step) takes the full function under the wave-uniform branch.  `simple` (wave-uniform): the host has checked
+    // that every theta of the scan lies in [0, 6.2831], and x = wrapped angle - theta: then x < pi and x + 2pi > -pi hold
+    // for every ray and the test is skipped.
     const float up = (float)((double)x + 2.0 * BL_PI);
     float w = x <= -PI_F ? up : x;
-    if (__builtin_amdgcn_ballot_w64(__builtin_fabsf(w) >= PI_F)) {
-        if (__builtin_fabsf(w) >= PI_F) w = bl_wrap_to_pi(x);
+    if (!simple) {
+        if (__builtin_amdgcn_ballot_w64(__builtin_fabsf(w) >= PI_F)) {
+            if (__builtin_fabsf(w) >= PI_F) w = bl_wrap_to_pi(x);
+        }
     }
     return w;
 }
@@ -358,6 +362,7 @@ struct mcl_args {
     int win_w, win_h;             // LDS map window size in cells (0: no staging); >= grid size means the whole grid
     int split_log2;               // each particle's rays are spread over 2^split_log2 adjacent lanes
     int pk_ok;                    // grid and scan admit the packed 16-bit scoring path (see score_ray_pk)
+    int theta_simple;             // every theta of the scan lies in [0, 6.2831] (see wrap_to_pi_cells)
     int main_blocks, main_particles;   // region 1: main_blocks workgroups cover particles [0, main_particles) of the shard
 };
 
@@ -383,17 +388,17 @@ __device__ __forceinline__ void philox_normals3(uint32_t m, uint32_t step, uint3
 #define MCL_RAY_LOOP(SCORE_EXPR)                                                        \
     do {                                                                                \
         const int rounds_ = cnt >> sl2;                                                 \
-        int n_ = sub;                                                                   \
-        for (int k_ = 0; k_ < rounds_; ++k_, n_ += split) {                             \
-            const float2 rt = s_ray[n_];                                                \
+        int off_ = sub * 8;                          /* byte offset of the table entry */ \
+        for (int k_ = 0; k_ < rounds_; ++k_, off_ += split * 8) {                       \
+            const float2 rt = *(const float2*)((const char*)s_ray + off_);              \
             float sn, cs;                                                               \
-            bl_sincosf_cells(wrap_to_pi_cells(pth - rt.y), &sn, &cs);                   \
+            bl_sincosf_cells(wrap_to_pi_cells(pth - rt.y, theta_simple), &sn, &cs);                   \
             acc += SCORE_EXPR;                                                          \
         }                                                                               \
-        if (n_ < cnt) {                                                                 \
-            const float2 rt = s_ray[n_];                                                \
+        if ((off_ >> 3) < cnt) {                                                        \
+            const float2 rt = *(const float2*)((const char*)s_ray + off_);              \
             float sn, cs;                                                               \
-            bl_sincosf_cells(wrap_to_pi_cells(pth - rt.y), &sn, &cs);                   \
+            bl_sincosf_cells(wrap_to_pi_cells(pth - rt.y, theta_simple), &sn, &cs);                   \
             acc += SCORE_EXPR;                                                          \
         }                                                                               \
     } while (0)
@@ -572,6 +577,7 @@ __global__ __launch_bounds__(BLOCK) void k_mcl_main(mcl_args a)
     // ---- SensorModel::likelihood (sensor_model.cpp:14-25) over MovingLaserScan(scan, parent_pose, pose)
     int acc = 0;                                            // half-units: likelihood = acc / 2 exactly
     if (a.cells) {
+        const bool theta_simple = a.theta_simple != 0;
         const bool pk_lane = !INTERP && a.pk_ok && isx0 >= -8191 && isx0 <= 8191 && isy0 >= -8191 && isy0 <= 8191;
         const short2_t S = {(short)isx0, (short)isy0};
         const float2_t start = {sx0, sy0};
@@ -1162,6 +1168,7 @@ static int pf_launch_main(bl_pf* pf, const bl_grid* map, int R, int rand_value, 
     // ActionModel::utime_ == 0 (D3); they differ only on the first moved update after initialisation.
     a.interp = (map && pf->pose_utime != 0) ? 1 : 0;
     // packed 16-bit scoring: grid up to 8192 a side, the longest kept ray spans at most 4000 cells (see score_ray_pk)
+    a.theta_simple = ctx->scan.thetas_simple ? 1 : 0;
     a.pk_ok = (map && a.frame.width <= 8192 && a.frame.height <= 8192 && ctx->scan.max_range * a.frame.cpm <= 4000.0f &&
                !pf->no_packed) ? 1 : 0;
     // Where the gathers go.  Mode 1: the whole grid, zero-framed, staged in LDS by every workgroup (grids up to 64 KB).

@@ -194,11 +194,13 @@ def test_mcl_parity_with_oracle_noise(oracle, maps, gpu_ctx, N):
     assert moved_updates >= 7
 
 
-@pytest.mark.parametrize("case", ["far_particles", "long_ray"])
+@pytest.mark.parametrize("case", ["far_particles", "long_ray", "thetas_negative", "thetas_many_turns"])
 def test_mcl_packed_scoring_fallbacks(oracle, maps, gpu_ctx, case):
     """The whole-grid LDS mode scores rays in packed int16 arithmetic only while every cell coordinate provably fits:
     particles more than 8191 cells from the grid origin, or a scan with a ray longer than 4000 cells, must take the
-    int32 path -- per lane in the first case, for the whole launch in the second -- and still match the oracle exactly."""
+    int32 path -- per lane in the first case, for the whole launch in the second -- and still match the oracle exactly.
+    The ray loop also skips the general wrap_to_pi when every theta of the scan lies in [0, 6.2831]: scans whose thetas
+    are negative or several turns away take the general form (downward and repeated 2*pi steps)."""
     N = 512
     m, g, opf, pf, odo, scans, rands, cells = _mcl_sequence(oracle, maps, gpu_ctx, N, 4)
     parts = opf.particles()
@@ -212,6 +214,11 @@ def test_mcl_packed_scoring_fallbacks(oracle, maps, gpu_ctx, case):
     for k, scan in enumerate(scans):
         if case == "long_ray":
             scan.ranges[7] = np.float32(260.0)               # 5200 cells at 5 cm
+        if case == "thetas_negative":
+            scan.thetas[:] = (scan.thetas - np.float32(6.0)).astype(np.float32)
+        if case == "thetas_many_turns":
+            scan.thetas[::3] = (scan.thetas[::3] + np.float32(4 * np.pi)).astype(np.float32)
+            scan.thetas[1::3] = (scan.thetas[1::3] - np.float32(6 * np.pi)).astype(np.float32)
         o = odo[k + 1]
         t = int(scan.times[-1])
         res = opf.update(oracle.pose(o[0], o[1], o[2], utime=t), scan, cells, m["mpc"], helpers.CPM_DEFAULT, m["origin"], rands[k])
