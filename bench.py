@@ -126,8 +126,8 @@ def main():
     ap.add_argument("--cpu-steps", type=int, default=25, help="steps of the CPU baseline sample (0 = skip)")
     ap.add_argument("--depth", type=int, default=6, help="steps enqueued ahead of fetching a result (0 = synchronous steps); a replan "
                     "(distance grid + A*, ~0.4 ms) spans three steps, so fewer than ~6 leaves the SLAM stream waiting for the host")
-    ap.add_argument("--lanes", type=int, default=3, help="replanner streams: consecutive replans run concurrently (1..4)")
-    ap.add_argument("--batch", type=int, default=1, help="replans a lane collects and searches in one launch (1..4): lanes x batch "
+    ap.add_argument("--lanes", type=int, default=2, help="replanner streams: consecutive replans run concurrently (1..4)")
+    ap.add_argument("--batch", type=int, default=2, help="replans a lane collects and searches in one launch (1..4): lanes x batch "
                     "searches overlap; for grids where a search outlasts several steps (use with --depth >= lanes x batch)")
     args = ap.parse_args()
 
@@ -189,6 +189,8 @@ def main():
     pops_total = [0]
 
     pose_dev = engine.pf.poseDevicePtr()
+    # with one rank and no collective the filter's end rides in the map kernel (bl_mapping_update_finishing_pf)
+    ride_finish = world == 1 and not spf.force_collectives and not os.environ.get("BENCH_NO_RIDE")
     in_flight = []                  # steps enqueued whose result has not been fetched yet
 
     def enqueue(k):
@@ -196,7 +198,17 @@ def main():
         # update and the A* start there.
         o = odo[k + 1]
         sc = scans[k]
-        spf.updateFilter(bl.make_pose(o[0], o[1], o[2], utime=sc.utime), sc, grid, int(rands[k]), want_pose=False)
+        odo_pose = bl.make_pose(o[0], o[1], o[2], utime=sc.utime)
+        if ride_finish:
+            # one rank: the end of the filter update (pose estimate + weight prefix) rides in the map kernel's launch
+            engine.begin(odo_pose, sc, grid, int(rands[k]))
+            if goal_pose is not None:
+                aplanner.submit_with_map_update_finishing(mapper, sc, engine.pf, sc.utime, grid, goal_pose)
+            else:
+                mapper.updateMapFinishingFilter(sc, engine.pf, sc.utime, grid)
+            in_flight.append(k)
+            return
+        spf.updateFilter(odo_pose, sc, grid, int(rands[k]), want_pose=False)
         if goal_pose is not None:
             # updateMap with the device-resident pose, then snapshot map + pose for the replanner (one library call);
             # setDistances + search_for_path overlap the next step on a replanner lane

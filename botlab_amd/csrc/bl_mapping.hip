@@ -17,6 +17,7 @@
 #include <stdio.h>
 
 #include "bl_internal.h"
+#include "bl_mcl_finish.h"
 
 #define MAP_THREADS 1024
 #define MAP_LDS_COUNTERS (72 * 1024)         // uint16 counters -> 144 KB of the 160 KB LDS
@@ -56,6 +57,9 @@ struct map_args {
     // (bl_planner_submit_with_map_update: saves a dependent launch on the SLAM stream)
     int8_t* snap_cells; bl_pose_xyt_t* snap_pose; const bl_pose_xyt_t* snap_pose_src;
     unsigned long long* snap_flag; unsigned long long snap_seq;
+    // optional: the end of the particle-filter update whose pose estimate this map update uses (bl_mcl_finish.h).
+    // Workgroup 0 forms the estimate before it reads the pose; workgroups 1.. write the weight prefix meanwhile.
+    int fin_on; mcl_finish_args fin;
 };
 
 #ifdef BL_MAP_STAMPS
@@ -86,6 +90,12 @@ __device__ __forceinline__ void map_update_body(const map_args& a, int8_t* snap,
 
 __global__ __launch_bounds__(MAP_THREADS) void k_map_update(map_args a)
 {
+    __shared__ unsigned long long s_fin[2 * MCLF_WG / 64];
+    __shared__ double s_fin_red[MCLF_POSE_THREADS / 64][5];
+    if (blockIdx.x > 0) {                                       // only launched when a.fin_on
+        mclf_prefix_group(a.fin, (int)blockIdx.x - 1, s_fin);
+        return;
+    }
     const size_t n = (size_t)a.frame.width * a.frame.height;
     const size_t n16 = n / 16;
     // Early snapshot (the usual case: a 200x200 grid, a 290-ray scan): the copy of the grid is loaded before anything else
@@ -102,6 +112,10 @@ __global__ __launch_bounds__(MAP_THREADS) void k_map_update(map_args a)
             const size_t i = (size_t)u * MAP_THREADS + threadIdx.x;
             if (i < n16) sv[u] = ((const int4*)a.cells)[i];
         }
+    }
+    if (a.fin_on) {
+        mclf_pose(a.fin, s_fin_red);                            // writes the pose a.cur_dev points at (thread 0)
+        __syncthreads();
     }
     map_update_body(a, early ? a.snap_cells : nullptr, sv);    // every return inside is uniform over the workgroup
     if (a.snap_cells) {
@@ -453,7 +467,8 @@ extern "C" void bl_mapping_destroy(bl_mapping* m)
 #define MAP_SNAPSHOT_IN_KERNEL_CELLS (256 * 1024)      // larger grids: one workgroup would copy for too long
 
 static int mapping_update_impl(bl_mapping* m, const bl_lidar_t* scan, const bl_pose_xyt_t* h_pose, const void* d_pose,
-                               int64_t pose_utime, bl_grid* map, const bl_planner_snap* snap = nullptr)
+                               int64_t pose_utime, bl_grid* map, const bl_planner_snap* snap = nullptr,
+                               const mcl_finish_args* fin = nullptr)
 {
     BL_CHECK_ARG(m != nullptr && scan != nullptr && map != nullptr);
     BL_CHECK_ARG(scan->num_ranges >= 0 && scan->num_ranges <= MAP_MAX_RAYS);
@@ -499,7 +514,10 @@ static int mapping_update_impl(bl_mapping* m, const bl_lidar_t* scan, const bl_p
     hipEvent_t e0, e1;
     rc = bl_timer_begin(ctx, BL_K_MAP, &e0, &e1);
     if (rc) return rc;
-    hipLaunchKernelGGL(k_map_update, dim3(1), dim3(MAP_THREADS), MAP_LDS_COUNTERS * 2, ctx->stream, a);
+    a.fin_on = fin ? 1 : 0;
+    if (fin) a.fin = *fin; else a.fin = mcl_finish_args{};
+    static_assert(MCLF_WG == MAP_THREADS, "the riding finish uses the map kernel's workgroup size");
+    hipLaunchKernelGGL(k_map_update, dim3(1 + (fin ? mclf_groups(*fin) : 0)), dim3(MAP_THREADS), MAP_LDS_COUNTERS * 2, ctx->stream, a);
     BL_HIP(hipGetLastError());
     rc = bl_timer_end(ctx, BL_K_MAP, e0, e1);
     if (rc) return rc;
@@ -545,6 +563,55 @@ extern "C" int bl_planner_submit_with_map_update(bl_planner* p, bl_mapping* m, c
     int rc = bl_planner_reserve(p, map, &sn);
     if (rc) return rc;
     rc = mapping_update_impl(m, scan, nullptr, d_pose, pose_utime, map, &sn);
+    if (rc) { bl_planner_cancel(p); return rc; }
+    return bl_planner_commit(p, goal, params);
+}
+
+// The same two calls with the END of the particle-filter update folded in: `pf` has an update begun (bl_pf_update_begin)
+// and this call is its bl_pf_update_end(pf, NULL) -- the pose estimate is formed by the map kernel's own workgroup right
+// before Mapping::updateMap uses it, the weight prefix is written by further workgroups of the same launch, and the SLAM
+// stream carries one kernel less per step.  A filter with nothing pending (the robot did not move) or whose finish cannot
+// ride (sharded particle set) is ended the ordinary way first; results are bit-identical either way.
+static int finishing_pf_prepare(bl_pf* pf, bl_mapping* m, mcl_finish_args* fin, bool* ride)
+{
+    *ride = false;
+    if (bl_pf_ctx(pf) != m->ctx) { bl_set_error("filter and mapping belong to different contexts"); return BL_ERR_ARG; }
+    const int t = bl_pf_take_finish(pf, fin);
+    if (t > 0) { *ride = true; return BL_OK; }
+    return bl_pf_update_end(pf, nullptr);                       // no-op when nothing is pending
+}
+
+extern "C" int bl_mapping_update_finishing_pf(bl_mapping* m, const bl_lidar_t* scan, bl_pf* pf, int64_t pose_utime, bl_grid* map)
+{
+    BL_CHECK_ARG(m != nullptr && pf != nullptr && map != nullptr);
+    mcl_finish_args fin; bool ride;
+    int rc = finishing_pf_prepare(pf, m, &fin, &ride);
+    if (rc) return rc;
+    return mapping_update_impl(m, scan, nullptr, bl_pf_pose_device_ptr(pf), pose_utime, map, nullptr, ride ? &fin : nullptr);
+}
+
+extern "C" int bl_planner_submit_with_map_update_finishing_pf(bl_planner* p, bl_mapping* m, const bl_lidar_t* scan, bl_pf* pf,
+                                                              int64_t pose_utime, bl_grid* map, const bl_pose_xyt_t* goal,
+                                                              const bl_search_params_t* params)
+{
+    BL_CHECK_ARG(p != nullptr && m != nullptr && pf != nullptr && map != nullptr && goal != nullptr && params != nullptr);
+    mcl_finish_args fin; bool ride;
+    int rc = finishing_pf_prepare(pf, m, &fin, &ride);
+    if (rc) return rc;
+    const void* d_pose = bl_pf_pose_device_ptr(pf);
+    if ((size_t)map->frame.width * map->frame.height > (size_t)MAP_SNAPSHOT_IN_KERNEL_CELLS) {
+        rc = mapping_update_impl(m, scan, nullptr, d_pose, pose_utime, map, nullptr, ride ? &fin : nullptr);
+        if (rc) return rc;
+        return bl_planner_submit(p, map, d_pose, goal, params);
+    }
+    bl_planner_snap sn;
+    rc = bl_planner_reserve(p, map, &sn);
+    if (rc) {
+        // the filter's bookkeeping is already done: its finish must still be launched
+        if (ride) (void)mapping_update_impl(m, scan, nullptr, d_pose, pose_utime, map, nullptr, &fin);
+        return rc;
+    }
+    rc = mapping_update_impl(m, scan, nullptr, d_pose, pose_utime, map, &sn, ride ? &fin : nullptr);
     if (rc) { bl_planner_cancel(p); return rc; }
     return bl_planner_commit(p, goal, params);
 }

@@ -23,6 +23,7 @@
 #include <new>
 
 #include "bl_internal.h"
+#include "bl_mcl_finish.h"
 
 #define MCL_LDS_RAYS 1024                     // rays whose (range, theta) table is staged in LDS (more: read from global memory)
 #define MCL_MIN_BLOCKS 512                    // split rays over lanes until the launch has at least this many workgroups (2 per CU)
@@ -35,11 +36,7 @@
 #define SCAN_ITEMS 8
 #define SCAN_TILE (SCAN_THREADS * SCAN_ITEMS)
 
-struct pf_state {
-    double S;                 // total weight units of rec[cur]
-    bl_pose_xyt_t pose;       // posteriorPose_
-    double sums_used[5];      // the sums the estimate was formed from (diagnostic)
-};
+// pf_state: bl_mcl_finish.h
 
 struct bl_pf {
     bl_ctx* ctx;
@@ -1339,6 +1336,28 @@ extern "C" int bl_pf_update_end(bl_pf* pf, bl_pose_xyt_t* out_pose)
     if (out_pose) return bl_pf_pose_estimate(pf, out_pose);
     return BL_OK;
 }
+
+// The end of a begun update handed to another launch (bl_mcl_finish.h)
+int bl_pf_take_finish(bl_pf* pf, mcl_finish_args* out)
+{
+    if (!pf || !pf->pending_end) return 0;
+    if (!pf->fused_finish) return -1;
+    const int which = pf->cur ^ 1;
+    out->partials = pf->partials; out->nblocks = pf->last_blocks;
+    out->rec = pf->rec[which]; out->N = pf->N;
+    out->tile = pf->last_tile; out->main_blocks = pf->last_main_blocks; out->main_particles = pf->last_main_particles;
+    out->tail_tile = pf->last_tail_tile > 0 ? pf->last_tail_tile : 1;
+    out->prefix = pf->prefix; out->state = pf->state; out->utime = pf->pending_utime;
+    if (out->tile <= 0 || out->tile > MCLF_CHUNK || (MCLF_CHUNK % out->tile) != 0 || (MCLF_CHUNK % out->tail_tile) != 0) return -1;
+    pf->cur ^= 1;
+    pf->parent_utime = pf->pose_utime;       // parent_pose = sample.pose (action_model.cpp:92)
+    pf->pose_utime = 0;                      // pose.utime = utime_ (D3)
+    pf->step += 1;
+    pf->pending_end = false;
+    return 1;
+}
+
+bl_ctx* bl_pf_ctx(bl_pf* pf) { return pf ? pf->ctx : nullptr; }
 
 extern "C" int bl_pf_update(bl_pf* pf, const bl_pose_xyt_t* odometry, const bl_lidar_t* scan, const bl_grid* map,
                             int rand_value, const float* noise, bl_pose_xyt_t* out_pose)

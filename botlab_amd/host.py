@@ -206,6 +206,12 @@ class Mapping:
         ls = scan.as_c()
         check(self.ctx.lib.bl_mapping_update_dev_pose(self.h, C.byref(ls), d_pose_ptr, int(pose_utime), grid.h))
 
+    def updateMapFinishingFilter(self, scan, pf, pose_utime, grid):
+        """pf.updateEnd(want_pose=False) + updateMapDevicePose(scan, pf.poseDevicePtr(), ...) in ONE launch: the end of the
+        filter update (pose estimate + weight prefix) rides in the map kernel (bl_mapping_update_finishing_pf)."""
+        ls = scan.as_c()
+        check(self.ctx.lib.bl_mapping_update_finishing_pf(self.h, C.byref(ls), pf.h, int(pose_utime), grid.h))
+
     def close(self):
         if self.h:
             self.ctx.lib.bl_mapping_destroy(self.h)
@@ -516,6 +522,12 @@ class AsyncPlanner:
         c = scan.as_c()
         check(self.ctx.lib.bl_planner_submit_with_map_update(self.h, mapping.h, C.byref(c), pose_dev, int(pose_utime), grid.h,
                                                              C.byref(goal), C.byref(self.searchParams_)))
+
+    def submit_with_map_update_finishing(self, mapping, scan, pf, pose_utime, grid, goal):
+        """submit_with_map_update whose map kernel also ends the filter update begun with pf.updateBegin()."""
+        c = scan.as_c()
+        check(self.ctx.lib.bl_planner_submit_with_map_update_finishing_pf(self.h, mapping.h, C.byref(c), pf.h, int(pose_utime),
+                                                                          grid.h, C.byref(goal), C.byref(self.searchParams_)))
 
     def fetch(self, return_stats=False):
         n = C.c_int()

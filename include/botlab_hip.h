@@ -205,6 +205,18 @@ int bl_planner_timing(bl_planner* p, int on, double* dist_ms, double* astar_ms, 
 int bl_planner_submit_with_map_update(bl_planner* p, bl_mapping* m, const bl_lidar_t* scan, const void* d_pose,
                                       int64_t pose_utime, bl_grid* map, const bl_pose_xyt_t* goal,
                                       const bl_search_params_t* params);
+/* updateLocalization + updateMap of one runSLAMIteration (src/slam/slam.cpp:191-207, 262, 279) with the END of the filter
+ * update folded into the map kernel: `pf` has an update begun with bl_pf_update_begin, and this call is its
+ * bl_pf_update_end(pf, NULL) followed by bl_mapping_update_dev_pose(m, scan, bl_pf_pose_device_ptr(pf), pose_utime, map)
+ * -- in ONE launch.  The map kernel's own workgroup forms the pose estimate right before Mapping::updateMap reads it and
+ * further workgroups of the launch write the weight prefix meanwhile, so the SLAM stream carries one kernel less per step.
+ * A filter with nothing pending (the robot did not move) or whose end cannot ride (sharded particle set) is ended the
+ * ordinary way first.  Results are bit-identical to the separate calls. */
+int bl_mapping_update_finishing_pf(bl_mapping* m, const bl_lidar_t* scan, bl_pf* pf, int64_t pose_utime, bl_grid* map);
+/* the same for bl_planner_submit_with_map_update */
+int bl_planner_submit_with_map_update_finishing_pf(bl_planner* p, bl_mapping* m, const bl_lidar_t* scan, bl_pf* pf,
+                                                   int64_t pose_utime, bl_grid* map, const bl_pose_xyt_t* goal,
+                                                   const bl_search_params_t* params);
 
 /* ------------------------------------------------------------------ batched searches, frontiers  
  * n independent search_for_path calls (astar.hpp:58-61) from ONE start on one distance grid, run concurrently (one

@@ -406,8 +406,9 @@ def test_step_pipeline_with_device_pose_equals_host_pose_path(oracle, maps, gpu_
     out = []
     # "batched*": a lane collects several submissions and searches them in one launch (lag 3 < batch x lanes: some batches
     # are sent off partly filled by the fetch; lag 6: every batch fills, the last one is flushed by the drain)
-    forms = {"async": (3, 1, 3), "fused": (3, 1, 3), "batched2": (3, 2, 3), "batched3": (2, 3, 6), "batched4": (1, 4, 2)}
-    for dev in (False, True, "async", "fused", "batched2", "batched3", "batched4"):
+    forms = {"async": (3, 1, 3), "fused": (3, 1, 3), "batched2": (3, 2, 3), "batched3": (2, 3, 6), "batched4": (1, 4, 2),
+             "riding": (3, 1, 3), "riding_deep": (3, 1, 6)}
+    for dev in (False, True, "async", "fused", "batched2", "batched3", "batched4", "riding", "riding_deep"):
         g = _grid_from_map(m, gpu_ctx)
         lanes, batch, lag = forms.get(dev, (0, 0, 0))
         aplanner = bl.AsyncPlanner(ctx=gpu_ctx, lanes=lanes, batch=batch) if dev in forms else None
@@ -422,8 +423,14 @@ def test_step_pipeline_with_device_pose_equals_host_pose_path(oracle, maps, gpu_
             odo = bl.make_pose(*poses[k + 1], utime=sc.utime)
             if dev in forms:
                 # replanner on its own stream against snapshots; results fetched three steps late, in order
-                pf.updateFilter(odo, sc, g, rand_value=1000 + k, want_pose=False)
-                if dev != "async":                                   # map update + snapshot in one call (bench.py's form)
+                if dev in ("riding", "riding_deep"):                 # the end of the filter update rides in the map kernel
+                    pf.updateBegin(odo, sc, g, 1000 + k)
+                    aplanner.submit_with_map_update_finishing(mapper, sc, pf, sc.utime, g, goal)
+                else:
+                    pf.updateFilter(odo, sc, g, rand_value=1000 + k, want_pose=False)
+                if dev in ("riding", "riding_deep"):
+                    pass
+                elif dev != "async":                                 # map update + snapshot in one call (bench.py's form)
                     aplanner.submit_with_map_update(mapper, sc, pf.poseDevicePtr(), sc.utime, g, goal)
                 else:
                     mapper.updateMapDevicePose(sc, pf.poseDevicePtr(), sc.utime, g)
@@ -457,6 +464,44 @@ def test_step_pipeline_with_device_pose_equals_host_pose_path(oracle, maps, gpu_
         assert o[0] == out[0][0]
         assert np.array_equal(o[1], out[0][1])
     assert max(len(r[1]) for r in out[0][0]) > 3
+
+
+@pytest.mark.parametrize("N", [1000, 100_000, 300_000])
+def test_filter_end_riding_in_map_kernel_equals_separate_calls(maps, gpu_ctx, N):
+    """bl_mapping_update_finishing_pf: updateFilter's end (weight prefix, unit total, pose estimate) computed inside the map
+    kernel's launch gives the same particles, weights, estimate, resampling and map, bit for bit, as bl_pf_update_end
+    followed by the map update -- for launch shapes with 64, 4 and 1 lanes per particle (tiles of 8, 128 and 512 particles,
+    with and without the second region)."""
+    m = maps["obstacle_slam_10mx10m_5cm"]
+    truth = np.where(m["cells"] > 0, 127, -127).astype(np.int8)
+    poses = synth.square_trajectory((-0.75, 0.2, 0.0), 5, step_len=0.02, turn=0.05, side=0.8)
+    scans = [synth.raycast_scan(truth, m["origin"], 0.05, poses[k - 1], poses[k], 1_000_000 + k * 100_000) for k in range(1, 6)]
+    res = []
+    for riding in (False, True):
+        g = _grid_from_map(m, gpu_ctx)
+        pf = bl.ParticleFilter(N, ctx=gpu_ctx)
+        pf.initializeFilterAtPose(bl.make_pose(-0.75, 0.2, 0.0, utime=int(scans[0].times[0])), seed=11)
+        pf.setNoiseSeed(4)
+        pf.debugEnable(True)
+        mapper = bl.Mapping(5.0, 4, 1, ctx=gpu_ctx)
+        rec = []
+        for k, sc in enumerate(scans):
+            odo = bl.make_pose(*poses[k + 1], utime=sc.utime) if k != 2 else bl.make_pose(*poses[k], utime=sc.utime)   # step 2: not moved
+            if riding:
+                pf.updateBegin(odo, sc, g, 77 + k)
+                mapper.updateMapFinishingFilter(sc, pf, sc.utime, g)
+            else:
+                pf.updateFilter(odo, sc, g, rand_value=77 + k, want_pose=False)
+                mapper.updateMapDevicePose(sc, pf.poseDevicePtr(), sc.utime, g)
+            p = pf.poseEstimate()
+            idx, like = pf.debugLast()
+            rec.append(((p.utime, p.x, p.y, p.theta), idx.copy(), like.copy(), pf.particles().copy(), g.cells().copy()))
+        res.append(rec)
+    for a, b in zip(*res):
+        assert a[0] == b[0]
+        assert np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
+        assert a[3].tobytes() == b[3].tobytes()
+        assert np.array_equal(a[4], b[4])
 
 
 def test_shard_engine_single_rank_with_nccl_collectives_matches_plain_filter(maps, gpu_ctx):
