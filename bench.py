@@ -342,6 +342,34 @@ def main():
         except (OSError, KeyError, ValueError):
             traffic = None
         achieved = alg_bytes / (main_ms * 1e-3) / 1e9 if main_ms > 0 else 0.0
+        # The other kernels of the step against the same roof, with SURVEY.md section 8d's algorithmic bytes:
+        # map 16 R + 2 C (C = traced cells), distance grid 5 W H per setDistances, A* 52 B per pop; and the whole step.
+        traced = float(np.mean([np.sum(np.minimum(sc.ranges[sc.ranges <= 5.0], 5.0)) * 20.0 for sc in scans[:64]]))
+        pops_step = pops_total[0] / max(args.steps, 1)
+        per_launch = max(args.batch, 1)
+        others = {}
+        map_bytes = 16.0 * R + 2.0 * traced + (24.0 * N if ride_finish else 0.0)     # riding finish: 16 N read + 8 N prefix written
+        for name, b in (("map", map_bytes), ("dist", 5.0 * W * H * per_launch), ("astar", 52.0 * pops_step * per_launch)):
+            ms = stage_ms[name][0]
+            if ms > 0 and (goal is not None or name == "map"):
+                gbs = b / (ms * 1e-3) / 1e9
+                others[name] = {"algorithmic_bytes_per_launch": round(b, 1), "avg_launch_ms": round(ms, 5), "achieved": round(gbs, 3),
+                                "frac": gbs / HBM_PEAK_GBS}
+        step_bytes = alg_bytes * world + 24.0 * N + 16.0 * R + 2.0 * traced + (5.0 * W * H + 52.0 * pops_step if goal is not None else 0.0)
+        step_gbs = step_bytes / (elapsed / args.steps) / 1e9
+        # secondary bound of k_mcl_main (it is VALU-bound, not HBM-bound): wave-level VALU instructions per launch from the
+        # committed SQ counter pass, against the 1024 SIMDs issuing one per 4 cycles at 2.4 GHz
+        valu = None
+        try:
+            import csv
+            if world == 1 and traffic is not None:
+                for row in csv.reader(open(os.path.join(ROOT, "profiles", "r01_mcl_main_pmc_sq.csv"))):
+                    if len(row) == 4 and row[0].startswith("void k_mcl_main<0") and row[1] == "SQ_INSTS_VALU":
+                        insts = float(row[3])
+                        valu = {"wave_valu_insts_per_launch": insts, "per_particle_ray": insts * 64.0 / (n_local * R),
+                                "valu_issue_frac": insts * 4.0 / (1024.0 * main_ms * 1e-3 * 2.4e9)}
+        except (OSError, ValueError):
+            valu = None
         out = {
             "metric": "SLAM steps/sec (map+MCL+A*)",
             "value": args.steps / elapsed,
@@ -363,7 +391,11 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": main_ms,
                          "launches_timed": int(stage_ms["mcl_main"][1]), "event_stride": EVENT_STRIDE,
-                         "particle_rays_per_s": (n_local * R) / (main_ms * 1e-3) if main_ms > 0 else 0.0},
+                         "particle_rays_per_s": (n_local * R) / (main_ms * 1e-3) if main_ms > 0 else 0.0,
+                         "valu": valu, "other_kernels": others,
+                         "step": {"algorithmic_bytes": round(step_bytes, 1), "achieved": round(step_gbs, 3), "frac": step_gbs / HBM_PEAK_GBS}},
+            "stage_note": ("map = k_map_update carrying the filter's end (pose estimate + weight prefix); mcl_scan is its stand-alone launch, "
+                           "unused here" if ride_finish else "mcl_scan = weight prefix + pose estimate launches"),
             "stage_ms": {k_: round(v[0], 5) for k_, v in stage_ms.items()},
             "astar_pops_per_step": pops_total[0] / args.steps,
             "host_ms_per_step": {"enqueue": round(host_ms[0], 4), "fetch_wait": round(host_ms[1], 4)},
