@@ -25,13 +25,11 @@
 #include "bl_internal.h"
 #include "bl_mcl_finish.h"
 
-#define MCL_LDS_RAYS 1024                     // rays whose (range, theta) table is staged in LDS (more: read from global memory)
+#define MCL_LDS_RAYS 768                      // rays whose (range, theta) table is staged in LDS (more: read from global memory)
 #define MCL_MIN_BLOCKS 512                    // split rays over lanes until the launch has at least this many workgroups (2 per CU)
 #define MCL_WIN_SMALL_BYTES (64 * 1024)       // whole-grid staging budget (200x200 int8 framed = 41 KB -> three workgroups per CU)
 #define MCL_WIN_MAX 208                       // window side: 208^2 = 42 KB, three workgroups per CU like the whole-grid image of a 200x200 map
 #define MCL_WIN_MARGIN 24                     // cells added to the scan's reach on every side of the window for the spread of the cloud
-#define MCL_STAGE_BATCH 7                     // map dwords a thread keeps in flight while staging the grid (200x200: 21 per thread)
-#define MCL_STAGE_SEARCH 6                    // resampling bisection steps issued behind each batch
 #define SCAN_THREADS 256
 #define SCAN_ITEMS 8
 #define SCAN_TILE (SCAN_THREADS * SCAN_ITEMS)
@@ -389,25 +387,61 @@ __device__ __forceinline__ void philox_normals3(uint32_t m, uint32_t step, uint3
         for (int k_ = 0; k_ < rounds_; ++k_, off_ += split * 8) {                       \
             const float2 rt = *(const float2*)((const char*)s_ray + off_);              \
             float sn, cs;                                                               \
-            bl_sincosf_cells(wrap_to_pi_cells(pth - rt.y, theta_simple), &sn, &cs);                   \
+            bl_sincosf_cells(wrap_to_pi_cells(pth_r - rt.y, theta_simple), &sn, &cs);                   \
             acc += SCORE_EXPR;                                                          \
         }                                                                               \
         if ((off_ >> 3) < cnt) {                                                        \
             const float2 rt = *(const float2*)((const char*)s_ray + off_);              \
             float sn, cs;                                                               \
-            bl_sincosf_cells(wrap_to_pi_cells(pth - rt.y, theta_simple), &sn, &cs);                   \
+            bl_sincosf_cells(wrap_to_pi_cells(pth_r - rt.y, theta_simple), &sn, &cs);                   \
             acc += SCORE_EXPR;                                                          \
         }                                                                               \
     } while (0)
 
+// Row-wise staging by `n_sw` whole waves (this one is number `sw` of them, wave-uniform): lane = dword column of the LDS row,
+// `MCL_STAGE_ROWS` rows in flight per wave.  The row index is scalar, so a load costs no address arithmetic beyond one add
+// and the frame rows are a scalar branch (the thread-strided form spent ~20 vector instructions per dword on indices and
+// clamps).  src_row(ry) returns the dword pointer of LDS row ry's source or nullptr for an all-zero row; column q of the row
+// holds source dword q - q_lo when q_lo <= q < q_hi and zero otherwise.
+#define MCL_STAGE_ROWS 6
+template <class SrcRow>
+__device__ __forceinline__ void stage_rows(int* s_map32, int rows, int wq, int q_lo, int q_hi, int sw, int n_sw, int lane, SrcRow src_row)
+{
+    for (int q0 = 0; q0 < wq; q0 += 64) {                       // one pass for rows of up to 64 dwords (256 cells)
+        const int q = q0 + lane;
+        const bool qin = q < wq, qdata = q >= q_lo && q < q_hi;
+        for (int r0 = sw; r0 < rows; r0 += n_sw * MCL_STAGE_ROWS) {
+            int v[MCL_STAGE_ROWS];
+#pragma unroll
+            for (int u = 0; u < MCL_STAGE_ROWS; ++u) {
+                const int ry = r0 + u * n_sw;
+                v[u] = 0;
+                if (ry < rows) {
+                    const int* src = src_row(ry);
+                    if (src != nullptr && qdata) v[u] = src[q - q_lo];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < MCL_STAGE_ROWS; ++u) {
+                const int ry = r0 + u * n_sw;
+                if (ry < rows && qin) s_map32[ry * wq + q] = v[u];
+            }
+        }
+    }
+}
+
 // One lane group per output particle m of the shard: low-variance resample (gather), ActionModel::applyAction,
 // SensorModel::likelihood, weight units, and the block's partial sums for normalisation + pose estimate.
-// Launch shape: BLOCK threads (512 with the whole grid in LDS, 1024 with the LDS window); a particle occupies
-// `split` = 2^split_log2 adjacent lanes of one wave (a whole wave in the second region of the launch), lane
-// `sub` of them taking rays sub, sub + split, ...  (the host picks split so that the launch has >= ~512 workgroups:
-// at 100k particles a one-thread-per-particle launch is 6 waves per CU and latency-bound on its serial 290-ray loop).
-// Resampling and the action model are evaluated by every lane of the group (identical inputs, identical results);
-// the integer half-unit score is summed across the group with xor-shuffles and lane sub == 0 writes the particle.
+// Launch shape: BLOCK threads; a particle occupies `split` = 2^split_log2 adjacent lanes of one wave (a whole wave in the
+// second region of the launch), lane `sub` of them taking rays sub, sub + split, ...  (the host picks split so that the
+// launch has >= ~512 workgroups: at 100k particles a one-thread-per-particle launch is 6 waves per CU and latency-bound on
+// its serial 290-ray loop).
+// Shared prologue (split >= 4, no pose interpolation): the per-particle work -- resampling bisection, gather, Philox noise,
+// action model -- is done ONCE per particle by the first P = BLOCK / split threads of the workgroup (one particle per lane)
+// while the other waves stage the ray table and the map; the result reaches the particle's lanes through a small LDS table,
+// and the same P threads write the particle and feed the partial sums after the ray loop.  (With every lane of a group
+// repeating the prologue, as the first form of this kernel did, a wave spent a quarter of its instructions outside the ray
+// loop; the kernel is VALU-bound.)
 template <int INTERP, int BLOCK, int MAP_MODE>
 __global__ __launch_bounds__(BLOCK) void k_mcl_main(mcl_args a)
 {
@@ -417,13 +451,13 @@ __global__ __launch_bounds__(BLOCK) void k_mcl_main(mcl_args a)
     // (range, theta) of the kept rays, MCL_LDS_RAYS at a time: one ds_read_b64 per ray.  (A table that is read from LDS or,
     // past its size, from global memory makes every access a FLAT load behind two scalar branches.)
     __shared__ float2 s_ray[MCL_LDS_RAYS];
+    __shared__ float4 s_pp[BLOCK / 4];                      // shared prologue: (theta, start x, start y, -) per particle
+    __shared__ int s_acc[BLOCK / 4];                        // shared prologue: half-unit score per particle
     const lds_i8_t* s_map = (const lds_i8_t*)s_dyn;
+    int* s_map32 = (int*)s_dyn;
     map_window win = {0, 0, 0, 0, 0};
-    {
-        const int cnt = a.R < MCL_LDS_RAYS ? a.R : MCL_LDS_RAYS;
-        for (int n = threadIdx.x; n < cnt; n += BLOCK) s_ray[n] = make_float2(a.ranges[n], a.thetas[n]);
-    }
-    if (MAP_MODE == 0) __syncthreads();                     // the staging paths below end with a barrier of their own
+    const int tid = (int)threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 
     // Two regions in one launch (see "Whole rounds" in pf_launch_main): workgroups [0, main_blocks) take BLOCK >> split_log2
     // particles each, 2^split_log2 lanes per particle; the workgroups after them take the remaining particles one per
@@ -431,83 +465,24 @@ __global__ __launch_bounds__(BLOCK) void k_mcl_main(mcl_args a)
     const bool tail = (int)blockIdx.x >= a.main_blocks;
     const int sl2 = tail ? 6 : a.split_log2;
     const int split = 1 << sl2;
-    const int j = tail ? a.main_particles + ((((int)blockIdx.x - a.main_blocks) * BLOCK + (int)threadIdx.x) >> 6)
-                       : ((int)blockIdx.x * BLOCK + (int)threadIdx.x) >> sl2;
-    const int sub = (int)threadIdx.x & (split - 1);
+    const int P = BLOCK >> sl2;                                                     // particles of this workgroup
+    const int jbase = tail ? a.main_particles + ((int)blockIdx.x - a.main_blocks) * (BLOCK >> 6) : (int)blockIdx.x * P;
+    const int jl = tid >> sl2;
+    const int j = jbase + jl;
+    const int sub = tid & (split - 1);
     const bool active = j < a.n_local && (tail || j < a.main_particles);
-    const int m = a.lo + j;
-    // resamplePosteriorDistribution (particle_filter.cpp:84-103): first index with T <= prefix[i], clamped to N-1.  The
-    // bisection is a chain of ~17 dependent loads; its steps are issued between the loads of the map staging below, so the
-    // two latency chains overlap.
-    int rs_lo = 0, rs_hi = (active && a.resample) ? a.N - 1 : 0;
-    double rs_T = 0.0;
-    if (active && a.resample) rs_T = (a.r + m * a.M_inv) * a.state->S;
-#define MCL_RESAMPLE_STEP()                                                              \
-    do {                                                                                 \
-        if (rs_lo < rs_hi) {                                                             \
-            const int mid_ = (rs_lo + rs_hi) >> 1;                                       \
-            if (rs_T <= (double)a.prefix[mid_]) rs_hi = mid_; else rs_lo = mid_ + 1;     \
-        }                                                                                \
-    } while (0)
+    const bool shared_pro = !INTERP && sl2 >= 2;                                    // workgroup-uniform
+    const int pw = shared_pro ? (P + 63) >> 6 : 0;                                  // waves that run the prologue only
+    const int n_sw = BLOCK / 64 - pw;                                               // waves that stage
+    // the particle whose prologue and epilogue this thread runs
+    const int jp = shared_pro ? jbase + tid : j;
+    const bool pro_active = shared_pro ? (tid < P && jp < a.n_local && (tail || jp < a.main_particles)) : active;
+    const int mp = a.lo + jp;
 
-
-    if (MAP_MODE == 1) {
-        // ---- stage the whole grid as a framed image: rows -MCL_FRAME..H+MCL_FRAME-1, columns -4..stride-5 (zeros outside)
-        int* s_map32 = (int*)s_dyn;
-        const int stride = ((a.frame.width + 3) & ~3) + 8;
-        win.stride = stride;
-        s_map += MCL_FRAME * stride + 4;                      // cell (0, 0) of the framed image (grid_odds<1> indexes from it)
-        const int wq = stride >> 2;
-        const bool aligned = (a.frame.width & 3) == 0;
-        const int total = wq * (a.frame.height + 2 * MCL_FRAME);
-        if (aligned) {
-            // MCL_STAGE_BATCH dwords per thread and pass, loaded unconditionally from a clamped address so that all of them are
-            // in flight together (a load behind a bounds test is a branch, and the passes then run one L2 round trip each);
-            // (row, dword column) advance incrementally instead of a division per dword
-            const int wdw = a.frame.width >> 2;
-            const int* cells32 = (const int*)a.cells;
-            const int dr = BLOCK / wq, dq = BLOCK - dr * wq;
-            int ry = (int)threadIdx.x / wq, q = (int)threadIdx.x - ry * wq;
-            for (int i0 = threadIdx.x; i0 < total; i0 += MCL_STAGE_BATCH * BLOCK) {
-                int v[MCL_STAGE_BATCH];
-                bool in[MCL_STAGE_BATCH];
-#pragma unroll
-                for (int u = 0; u < MCL_STAGE_BATCH; ++u) {
-                    const int y = ry - MCL_FRAME, xq = q - 1;
-                    in[u] = y >= 0 && y < a.frame.height && xq >= 0 && xq < wdw;
-                    const int yc = min(max(y, 0), a.frame.height - 1), xc = min(max(xq, 0), wdw - 1);
-                    v[u] = cells32[yc * wdw + xc];
-                    q += dq; ry += dr;
-                    if (q >= wq) { q -= wq; ry += 1; }
-                }
-#pragma unroll
-                for (int u = 0; u < MCL_STAGE_SEARCH; ++u) MCL_RESAMPLE_STEP();
-#pragma unroll
-                for (int u = 0; u < MCL_STAGE_BATCH; ++u) {
-                    const int i = i0 + u * BLOCK;
-                    if (i < total) s_map32[i] = in[u] ? v[u] : 0;
-                }
-            }
-        } else {
-            for (int i = threadIdx.x; i < total; i += BLOCK) {
-                const int ry = i / wq, q = i - ry * wq;
-                const int y = ry - MCL_FRAME, x = 4 * q - 4;
-                int v = 0;
-                if (y >= 0 && y < a.frame.height && x >= 0 && x < a.frame.width) {
-                    const size_t g = (size_t)y * a.frame.width + x;
-                    for (int b = 0; b < 4; ++b)
-                        if (x + b < a.frame.width) v |= ((int)(unsigned char)a.cells[g + b]) << (8 * b);
-                }
-                MCL_RESAMPLE_STEP();
-                s_map32[i] = v;
-            }
-        }
-        __syncthreads();
-    }
     if (MAP_MODE == 2) {
-        // ---- stage a win_w x win_h window of the zero-framed copy, centred on the cell the previous pose estimate moves to
-        // under the odometry action (it may hang over the grid into the zero frame)
-        if (threadIdx.x == 0) {
+        // ---- the window of the zero-framed copy to stage: win_w x win_h cells centred on the cell the previous pose estimate
+        // moves to under the odometry action (it may hang over the grid into the zero frame)
+        if (tid == 0) {
             map_window w;
             const bl_pose_xyt_t p = a.state->pose;
             const float ex = (float)((double)p.x + a.trans * cos((double)p.theta + a.rot1));
@@ -523,38 +498,76 @@ __global__ __launch_bounds__(BLOCK) void k_mcl_main(mcl_args a)
         }
         __syncthreads();
         win = s_win;
-        int* s_map32 = (int*)s_dyn;
-        const int wq = win.w >> 2, fq = a.framed_stride >> 2;
-        const int* f32 = (const int*)(a.framed - MCL_FRAME * a.framed_stride - 4);       // first row, column -4 of the framed image
-        const int q0 = (win.x0 + 4) >> 2;
-        for (int i = threadIdx.x; i < wq * win.h; i += BLOCK) {
-            const int ry = i / wq, q = i - ry * wq;
-            const int v = f32[(size_t)(win.y0 + MCL_FRAME + ry) * fq + q0 + q];
-            MCL_RESAMPLE_STEP();
-            s_map32[i] = v;
-        }
-        __syncthreads();
+    }
+    if (MAP_MODE == 1) {
+        win.stride = ((a.frame.width + 3) & ~3) + 8;
+        s_map += MCL_FRAME * win.stride + 4;                  // cell (0, 0) of the framed image (grid_odds<1> indexes from it)
     }
 
+    // ---- phase 1a: the staging waves (every wave when the prologue is not shared) bring the ray table and the map into LDS
+    if (wave >= pw) {
+        const int sw = wave - pw;
+        const int st = tid - pw * 64, n_st = n_sw * 64;
+        const int cnt0 = a.R < MCL_LDS_RAYS ? a.R : MCL_LDS_RAYS;
+        for (int n = st; n < cnt0; n += n_st) s_ray[n] = make_float2(a.ranges[n], a.thetas[n]);
+        if (MAP_MODE == 1) {
+            // the whole grid as a framed image: rows -MCL_FRAME..H+MCL_FRAME-1, columns -4..stride-5 (zeros outside)
+            const int wq = win.stride >> 2;
+            const int rows = a.frame.height + 2 * MCL_FRAME;
+            if ((a.frame.width & 3) == 0) {
+                const int wdw = a.frame.width >> 2;
+                const int* cells32 = (const int*)a.cells;
+                const int H = a.frame.height;
+                stage_rows(s_map32, rows, wq, 1, 1 + wdw, sw, n_sw, lane, [&](int ry) -> const int* {
+                    const int y = ry - MCL_FRAME;
+                    return (y >= 0 && y < H) ? cells32 + (size_t)y * wdw : nullptr;
+                });
+            } else {
+                for (int i = st; i < wq * rows; i += n_st) {    // rows that are not whole dwords: byte gathers
+                    const int ry = i / wq, q = i - ry * wq;
+                    const int y = ry - MCL_FRAME, x = 4 * q - 4;
+                    int v = 0;
+                    if (y >= 0 && y < a.frame.height && x >= 0 && x < a.frame.width) {
+                        const size_t g = (size_t)y * a.frame.width + x;
+                        for (int b = 0; b < 4; ++b)
+                            if (x + b < a.frame.width) v |= ((int)(unsigned char)a.cells[g + b]) << (8 * b);
+                    }
+                    s_map32[i] = v;
+                }
+            }
+        }
+        if (MAP_MODE == 2) {
+            const int wq = win.w >> 2, fq = a.framed_stride >> 2;
+            const int* f32 = (const int*)(a.framed - MCL_FRAME * a.framed_stride - 4);   // first row, column -4 of the framed image
+            const int* org = f32 + (size_t)(win.y0 + MCL_FRAME) * fq + ((win.x0 + 4) >> 2);
+            stage_rows(s_map32, win.h, wq, 0, wq, sw, n_sw, lane, [&](int ry) -> const int* { return org + (size_t)ry * fq; });
+        }
+    }
+
+    // ---- phase 1b: per-particle prologue
     double t_units = 0, t_x = 0, t_y = 0, t_s = 0, t_c = 0;
-    int i = m;
+    int i = mp;
     float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
     float px = 0.f, py = 0.f, pth = 0.f, sx0 = 0.f, sy0 = 0.f;
-    int isx0 = 0, isy0 = 0;
-    if (active) {
-        // ---- resamplePosteriorDistribution (particle_filter.cpp:84-103)
+    if (pro_active) {
+        // ---- resamplePosteriorDistribution (particle_filter.cpp:84-103): first index with T <= prefix[i], clamped to N-1
         if (a.resample) {
-            while (rs_lo < rs_hi) MCL_RESAMPLE_STEP();      // the steps the staging loop left over
-            i = rs_lo;
+            const double T = (a.r + mp * a.M_inv) * a.state->S;
+            int lo = 0, hi = a.N - 1;
+            while (lo < hi) {
+                const int mid = (lo + hi) >> 1;
+                if (T <= (double)a.prefix[mid]) hi = mid; else lo = mid + 1;
+            }
+            i = lo;
         }
         s = a.src[i];
         // ---- ActionModel::applyAction (action_model.cpp:78-103)
         float n1, n2, n3;
         if (a.noise) {
-            n1 = a.noise[3 * j]; n2 = a.noise[3 * j + 1]; n3 = a.noise[3 * j + 2];
+            n1 = a.noise[3 * jp]; n2 = a.noise[3 * jp + 1]; n3 = a.noise[3 * jp + 2];
         } else {
             float z[3];
-            philox_normals3((uint32_t)m, a.step, a.seed_lo, a.seed_hi, z);
+            philox_normals3((uint32_t)mp, a.step, a.seed_lo, a.seed_hi, z);
             n1 = (float)(a.rot1 + a.rot1Std * (double)z[0]);
             n2 = (float)(a.trans + a.transStd * (double)z[1]);
             n3 = (float)(a.rot2 + a.rot2Std * (double)z[2]);
@@ -565,11 +578,15 @@ __global__ __launch_bounds__(BLOCK) void k_mcl_main(mcl_args a)
         px = (float)((double)s.x + (double)n2 * hc);
         py = (float)((double)s.y + (double)n2 * hs);
         pth = bl_wrap_to_pi(s.z + n1 + n3);
-        if (a.cells) {
-            bl_global_to_grid(px, py, a.frame, &sx0, &sy0);
-            isx0 = (int)sx0; isy0 = (int)sy0;
-        }
+        if (a.cells) bl_global_to_grid(px, py, a.frame, &sx0, &sy0);
     }
+    if (shared_pro && tid < P) s_pp[tid] = make_float4(pth, sx0, sy0, 0.0f);
+    __syncthreads();                                            // map, ray table and particle table are in place
+
+    // what the ray loop needs of this lane's particle
+    float r_pth = pth, r_sx0 = sx0, r_sy0 = sy0;
+    if (shared_pro) { const float4 e = s_pp[jl]; r_pth = e.x; r_sx0 = e.y; r_sy0 = e.z; }
+    const int isx0 = (int)r_sx0, isy0 = (int)r_sy0;
 
     // ---- SensorModel::likelihood (sensor_model.cpp:14-25) over MovingLaserScan(scan, parent_pose, pose)
     int acc = 0;                                            // half-units: likelihood = acc / 2 exactly
@@ -577,12 +594,13 @@ __global__ __launch_bounds__(BLOCK) void k_mcl_main(mcl_args a)
         const bool theta_simple = a.theta_simple != 0;
         const bool pk_lane = !INTERP && a.pk_ok && isx0 >= -8191 && isx0 <= 8191 && isy0 >= -8191 && isy0 <= 8191;
         const short2_t S = {(short)isx0, (short)isy0};
-        const float2_t start = {sx0, sy0};
+        const float2_t start = {r_sx0, r_sy0};
+        const float pth_r = r_pth;
         for (int base = 0; base < a.R; base += MCL_LDS_RAYS) {      // one pass for scans of up to MCL_LDS_RAYS kept rays
             const int cnt = a.R - base < MCL_LDS_RAYS ? a.R - base : MCL_LDS_RAYS;
             if (base > 0) {
                 __syncthreads();                                    // every lane is done with the previous chunk
-                for (int n = threadIdx.x; n < cnt; n += BLOCK) s_ray[n] = make_float2(a.ranges[base + n], a.thetas[base + n]);
+                for (int n = tid; n < cnt; n += BLOCK) s_ray[n] = make_float2(a.ranges[base + n], a.thetas[base + n]);
                 __syncthreads();
             }
             if (!active) continue;
@@ -609,7 +627,7 @@ __global__ __launch_bounds__(BLOCK) void k_mcl_main(mcl_args a)
                 pm.hi = short2_t{(short)(a.frame.width + 1), (short)(a.frame.height + 1)};
                 MCL_RAY_LOOP(score_ray_pk(pm, start, S, a.frame.cpm, rt.x, cs, sn));
             } else {
-                const bl_pose3 pb = {s.x, s.y, s.z};
+                const bl_pose3 pb = {s.x, s.y, s.z};            // INTERP: the prologue is not shared, these are this lane's own
                 const bl_pose3 pe = {px, py, pth};
                 for (int n = sub; n < cnt; n += split) {    // the host uploads only rays with range > 0.15f (moving_laser_scan.cpp:24)
                     const float2 rt = s_ray[n];
@@ -621,8 +639,8 @@ __global__ __launch_bounds__(BLOCK) void k_mcl_main(mcl_args a)
                         bl_global_to_grid(rp.x, rp.y, a.frame, &sx, &sy);
                         isx = (int)sx; isy = (int)sy;
                     } else {
-                        theta = bl_wrap_to_pi(pth - rt.y);
-                        sx = sx0; sy = sy0; isx = isx0; isy = isy0;
+                        theta = bl_wrap_to_pi(pth_r - rt.y);
+                        sx = r_sx0; sy = r_sy0; isx = isx0; isy = isy0;
                     }
                     float sn, cs;
                     bl_sincosf(theta, &sn, &cs);
@@ -631,32 +649,39 @@ __global__ __launch_bounds__(BLOCK) void k_mcl_main(mcl_args a)
             }
         }
     }
-    if (active) {
+    if (active)
         for (int off = split >> 1; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);     // exact integer sum over the group
-        if (sub == 0) {
-            // ---- computeNormalizedPosterior (particle_filter.cpp:116-141): w = max(likelihood, 0.001) in units of 0.0005
-            const uint32_t units = a.cells ? (acc > 0 ? (uint32_t)acc * 1000u : 2u) : __float_as_uint(s.w);
-            a.dst[m] = make_float4(px, py, pth, __uint_as_float(units));
-            a.parent[j] = make_float4(s.x, s.y, s.z, 0.0f);
-            if (a.dbg_idx) { a.dbg_idx[j] = i; a.dbg_like[j] = acc; }
-            // ---- estimatePosteriorPose (particle_filter.cpp:144-160) partial sums
-            float sth, cth;
-            bl_sincosf(pth, &sth, &cth);
-            t_units = (double)units;
-            t_x = t_units * (double)px;
-            t_y = t_units * (double)py;
-            t_s = t_units * (double)sth;
-            t_c = t_units * (double)cth;
-        }
+    if (shared_pro) {
+        if (active && sub == 0) s_acc[jl] = acc;
+        __syncthreads();
+        if (pro_active) acc = s_acc[tid];
     }
-    t_units = wave_sum(t_units); t_x = wave_sum(t_x); t_y = wave_sum(t_y); t_s = wave_sum(t_s); t_c = wave_sum(t_c);
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    if (lane == 0) { s_part[wave][0] = t_units; s_part[wave][1] = t_x; s_part[wave][2] = t_y; s_part[wave][3] = t_s; s_part[wave][4] = t_c; }
+    if (shared_pro ? pro_active : (active && sub == 0)) {
+        // ---- computeNormalizedPosterior (particle_filter.cpp:116-141): w = max(likelihood, 0.001) in units of 0.0005
+        const uint32_t units = a.cells ? (acc > 0 ? (uint32_t)acc * 1000u : 2u) : __float_as_uint(s.w);
+        a.dst[mp] = make_float4(px, py, pth, __uint_as_float(units));
+        a.parent[jp] = make_float4(s.x, s.y, s.z, 0.0f);
+        if (a.dbg_idx) { a.dbg_idx[jp] = i; a.dbg_like[jp] = acc; }
+        // ---- estimatePosteriorPose (particle_filter.cpp:144-160) partial sums
+        float sth, cth;
+        bl_sincosf(pth, &sth, &cth);
+        t_units = (double)units;
+        t_x = t_units * (double)px;
+        t_y = t_units * (double)py;
+        t_s = t_units * (double)sth;
+        t_c = t_units * (double)cth;
+    }
+    // the workgroup's five sums: lanes in a wave by shuffles, then the waves that hold particles in order
+    const int nred = shared_pro ? pw : BLOCK / 64;
+    if (wave < nred) {
+        t_units = wave_sum(t_units); t_x = wave_sum(t_x); t_y = wave_sum(t_y); t_s = wave_sum(t_s); t_c = wave_sum(t_c);
+        if (lane == 0) { s_part[wave][0] = t_units; s_part[wave][1] = t_x; s_part[wave][2] = t_y; s_part[wave][3] = t_s; s_part[wave][4] = t_c; }
+    }
     __syncthreads();
-    if (threadIdx.x < 5) {
+    if (tid < 5) {
         double v = 0;
-        for (int w = 0; w < BLOCK / 64; ++w) v += s_part[w][threadIdx.x];
-        a.partials[(size_t)blockIdx.x * 5 + threadIdx.x] = v;
+        for (int w = 0; w < nred; ++w) v += s_part[w][tid];
+        a.partials[(size_t)blockIdx.x * 5 + tid] = v;
     }
 }
 
