@@ -112,8 +112,8 @@ def cpu_baseline(args, m, odo, scans, rands, goal, n_steps):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=500)
-    ap.add_argument("--warmup", type=int, default=50)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=100)
     ap.add_argument("--particles", type=int, default=100_000)
     ap.add_argument("--grid", type=int, default=200, help="grid side in cells (200 = shipped obstacle_slam map)")
     ap.add_argument("--max-range", type=float, default=8.0, help="range of the synthetic lidar in metres (rays that hit nothing "
@@ -244,7 +244,7 @@ def main():
         t2 = time.perf_counter()
         host_t[0] += t1 - t0
         host_t[1] += t2 - t1
-        step_wall.append((t2 - t0, k))
+        step_wall.append((t2 - t0, k, t1 - t0))
         return last
 
     def drain():
@@ -399,7 +399,7 @@ def main():
             "stage_ms": {k_: round(v[0], 5) for k_, v in stage_ms.items()},
             "astar_pops_per_step": pops_total[0] / args.steps,
             "host_ms_per_step": {"enqueue": round(host_ms[0], 4), "fetch_wait": round(host_ms[1], 4)},
-            "slowest_steps_ms": [[round(1e3 * t, 3), kk] for t, kk in slowest],
+            "slowest_steps_ms": [[round(1e3 * t, 3), kk, round(1e3 * te, 3)] for t, kk, te in slowest],   # wall, step, of which enqueue
             "final_pose": [pose.x, pose.y, pose.theta],
             "truth_pose": [float(v) for v in poses[k]],
         }

@@ -579,6 +579,7 @@ struct bl_astar_state {
     int32_t* cost_lut; int cost_lut_cap;
     struct astar_unit* h_units;            // pinned [ASTAR_SLOTS][ASTAR_MAX_UNITS]: per-workgroup arguments of the unit form
     char* h_out[ASTAR_SLOTS];              // pinned result ring ([result][path head]): searches may be enqueued ahead of fetching
+    char* h_out_dev[ASTAR_SLOTS];          // the same slots as the device sees them: k_astar writes its result there itself
     hipEvent_t done[ASTAR_SLOTS];
     bl_frame slot_frame[ASTAR_SLOTS];
     int64_t launched, fetched;
@@ -605,6 +606,7 @@ static_assert(sizeof(astar_result) <= ASTAR_HDR, "result record must fit the hea
 struct astar_unit {
     const uint16_t* l1; const int32_t* cost_lut; int2* heap; int32_t* closed; int32_t* path; astar_result* result;
     const bl_pose_xyt_t* start_dev; bl_pose_xyt_t start_host; int sx, sy, gx, gy;
+    char* host_out;
 };
 
 struct astar_args {
@@ -614,6 +616,9 @@ struct astar_args {
     int32_t* closed;
     int32_t* path; long long path_cap;
     astar_result* result;
+    // pinned host slot ([result][path head]) the search leaves its outcome in directly (no copy command behind the kernel:
+    // an asynchronous device-to-host copy blocked the enqueueing thread for ~7 ms once every few hundred calls), or null
+    char* host_out;
     int sx, sy, gx, gy;
     long long max_pops;
     const bl_pose_xyt_t* start_dev;    // when non-null the start cell is derived on the device from this pose
@@ -746,6 +751,7 @@ __global__ __launch_bounds__(64) void k_astar(astar_args a)
         const astar_unit u = a.units[blockIdx.x];
         a.l1 = u.l1; a.cost_lut = u.cost_lut; a.heap = u.heap; a.closed = u.closed; a.path = u.path; a.result = u.result;
         a.start_dev = u.start_dev; a.start_host = u.start_host; a.sx = u.sx; a.sy = u.sy; a.gx = u.gx; a.gy = u.gy;
+        a.host_out = u.host_out;
     }
     if (a.batch_goals) {
         const long long b = blockIdx.x;
@@ -753,6 +759,7 @@ __global__ __launch_bounds__(64) void k_astar(astar_args a)
         a.gx = g.x; a.gy = g.y;
         a.heap += b * a.heap_stride; a.closed += b * a.closed_stride; a.path += b * a.path_stride;
         a.result = (astar_result*)((char*)a.result + b * ASTAR_HDR);
+        a.host_out = nullptr;
     }
     int2* g_heap = a.heap;
     const int lane = threadIdx.x;
@@ -780,7 +787,7 @@ __global__ __launch_bounds__(64) void k_astar(astar_args a)
     const bool ok = cell_cost(a.gx, a.gy) != ASTAR_INVALID_COST       // astar.cpp:40-44
                     && cell_cost(a.sx, a.sy) != ASTAR_INVALID_COST    // :46-50
                     && !(a.sx == a.gx && a.sy == a.gy);               // :52-56
-    if (!ok) { if (lane == 0) *a.result = res; return; }
+    if (!ok) { if (lane == 0) { *a.result = res; if (a.host_out) *(astar_result*)a.host_out = res; } return; }
 
     // ---- per-lane constants of the sift-down rounds
     const int lk = 31 - __clz(lane + 1);                // level of this lane in a 6-level subtree (lane 63 unused)
@@ -882,6 +889,7 @@ __global__ __launch_bounds__(64) void k_astar(astar_args a)
                 int cell = gny * a.W + gnx, parent = cy * a.W + cx;
                 while (cell != start) {
                     if (n < a.path_cap) a.path[n] = cell;
+                    if (a.host_out && n < ASTAR_PATH_HEAD) ((int32_t*)(a.host_out + ASTAR_HDR))[n] = cell;
                     n += 1;
                     cell = parent;
                     int d = __hip_atomic_load(&a.closed[cell], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -915,7 +923,7 @@ __global__ __launch_bounds__(64) void k_astar(astar_args a)
             a.pool[off + i] = __hip_atomic_load(&a.path[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         res.path_off = (long long)off;
     }
-    if (lane == 0) *a.result = res;
+    if (lane == 0) { *a.result = res; if (a.host_out) *(astar_result*)a.host_out = res; }
 }
 
 void bl_astar_free(bl_ctx* ctx)
@@ -956,6 +964,7 @@ static int astar_prepare(bl_ctx* ctx, const bl_dist* d)
         memset((void*)ctx->astar, 0, sizeof(bl_astar_state));
         for (int i = 0; i < ASTAR_SLOTS; ++i) {
             BL_HIP(hipHostMalloc((void**)&ctx->astar->h_out[i], ASTAR_HDR + ASTAR_PATH_HEAD * 4, hipHostMallocDefault));
+            BL_HIP(hipHostGetDevicePointer((void**)&ctx->astar->h_out_dev[i], ctx->astar->h_out[i], 0));
             BL_HIP(hipEventCreateWithFlags(&ctx->astar->done[i], hipEventDisableTiming));
         }
     }
@@ -1051,6 +1060,7 @@ static int astar_fill(bl_ctx* ctx, const bl_dist* d, const bl_pose_xyt_t* start,
     a.closed = d->closed;
     a.path = (int32_t*)(s->d_out + ASTAR_HDR); a.path_cap = (long long)s->path_cap;
     a.result = (astar_result*)s->d_out;
+    a.host_out = s->h_out_dev[s->launched % ASTAR_SLOTS];
     a.frame = d->frame;
     a.batch_goals = nullptr; a.heap_stride = a.closed_stride = a.path_stride = 0; a.pool = nullptr; a.pool_cursor = nullptr;
     a.units = nullptr;
@@ -1075,7 +1085,7 @@ static int astar_after(bl_ctx* ctx, const bl_dist* d)
 {
     bl_astar_state* s = ctx->astar;
     const int slot = (int)(s->launched % ASTAR_SLOTS);
-    BL_HIP(hipMemcpyAsync(s->h_out[slot], s->d_out, ASTAR_HDR + ASTAR_PATH_HEAD * 4, hipMemcpyDeviceToHost, ctx->stream));
+    // the kernel has written [result][path head] into the pinned slot itself
     BL_HIP(hipEventRecord(s->done[slot], ctx->stream));
     s->slot_frame[slot] = d->frame;
     s->launched += 1;
@@ -1132,6 +1142,7 @@ static int astar_launch_units(int n, bl_ctx* const* ctxs, bl_dist* const* dists,
         astar_unit& u = units[b];
         u.l1 = a.l1; u.cost_lut = a.cost_lut; u.heap = a.heap; u.closed = a.closed; u.path = a.path; u.result = a.result;
         u.start_dev = a.start_dev; u.start_host = a.start_host; u.sx = a.sx; u.sy = a.sy; u.gx = a.gx; u.gy = a.gy;
+        u.host_out = a.host_out;
     }
     a.units = units;
     bl_ctx* ctx = ctxs[0];
