@@ -194,6 +194,42 @@ def test_mcl_parity_with_oracle_noise(oracle, maps, gpu_ctx, N):
     assert moved_updates >= 7
 
 
+def test_mcl_parity_at_the_headline_size(oracle, maps, gpu_ctx):
+    """BASELINE.json's configuration itself -- 100 000 particles, 290 rays, the shipped obstacle_slam map -- against the
+    oracle consuming the same noise: resampling indices and likelihoods exact, particle poses bit-equal, weights and pose
+    estimate within 1e-5 relative (the launch shape of this size: 4 lanes per particle, shared prologue, both regions)."""
+    N = 100_000
+    m = maps["obstacle_slam_10mx10m_5cm"]
+    truth = np.where(m["cells"] > 0, 127, -127).astype(np.int8)
+    g = _grid_from_map(m, gpu_ctx)
+    poses = synth.square_trajectory((-0.75, 0.2, 0.0), 3, step_len=0.02, turn=0.05, side=0.8)
+    scans = [synth.raycast_scan(truth, m["origin"], 0.05, poses[k - 1], poses[k], 1_000_000 + k * 100_000) for k in range(1, 4)]
+    opf = oracle_lib.OraclePF(oracle, N)
+    opf.init_at_pose(oracle.pose(-0.75, 0.2, 0.0, utime=int(scans[0].times[0])), 5)
+    pf = bl.ParticleFilter(N, ctx=gpu_ctx)
+    pf.setParticles(opf.particles())
+    pf.debugEnable(True)
+    moved = 0
+    for k, sc in enumerate(scans):
+        o = poses[k + 1]
+        res = opf.update(oracle.pose(*o, utime=sc.utime), sc, m["cells"], m["mpc"], helpers.CPM_DEFAULT, m["origin"], 1000 + k)
+        pose = pf.updateFilter(bl.make_pose(*o, utime=sc.utime), sc, g, rand_value=1000 + k, noise=res["noise"])
+        if not res["moved"]:
+            continue
+        moved += 1
+        idx, like = pf.debugLast()
+        assert np.array_equal(idx, res["idx"])
+        assert np.array_equal(like.astype(np.float64) * 0.5, res["raw"])
+        got, exp = pf.particles(), opf.particles()
+        for f in ("x", "y", "theta", "p_x", "p_y", "p_theta"):
+            assert np.array_equal(got[f], exp[f]), (k, f)
+        assert np.allclose(got["weight"], exp["weight"], rtol=REL, atol=0)
+        for f in ("x", "y", "theta"):
+            a, b = getattr(pose, f), getattr(res["pose"], f)
+            assert abs(a - b) <= REL * abs(b) + 2e-6, (k, f, a, b)
+    assert moved == 2
+
+
 @pytest.mark.parametrize("case", ["far_particles", "long_ray", "thetas_negative", "thetas_many_turns"])
 def test_mcl_packed_scoring_fallbacks(oracle, maps, gpu_ctx, case):
     """The whole-grid LDS mode scores rays in packed int16 arithmetic only while every cell coordinate provably fits:
