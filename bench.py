@@ -28,7 +28,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8 TB/s
-EVENT_STRIDE = 4                 # HIP-event pairs are recorded around every 4th k_mcl_main launch of the timed region
+EVENT_STRIDE = 8                 # HIP-event pairs are recorded around every 8th k_mcl_main launch of the timed region
 
 
 def load_map(name):
@@ -269,7 +269,7 @@ def main():
     ctx.timing_reset()
     if not os.environ.get("BENCH_NO_EVENTS"):
         # HIP events around the dominant kernel only (roofline leg), on every EVENT_STRIDE-th launch of the timed region:
-        # an event pair costs ~13 us of stream time per launch (measured), 5 % of this step
+        # an event pair costs ~13 us of stream time per launch (measured), more than a tenth of this step
         ctx.timing_stride(EVENT_STRIDE)
         ctx.timing_enable(True, kernels=[_capi.BL_K_MCL_MAIN])
     pops_total[0] = 0

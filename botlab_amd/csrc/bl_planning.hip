@@ -1576,6 +1576,15 @@ static int planner_launch_lane(bl_planner* p, int l)
     planner_lane& L = p->lane[l];
     if (L.filled == 0) return BL_OK;
     const int slot = (int)(L.batches % PLANNER_SLOTS);
+    if (p->batch > 1 && !p->handoff_flag) {
+        // the deferred hand-over of bl_planner_commit: one event behind the newest snapshot covers every snapshot of the batch
+        BL_HIP(hipEventRecord(L.unit[0].snap_ready[slot], p->main->stream));
+        BL_HIP(hipStreamWaitEvent(L.side->stream, L.unit[0].snap_ready[slot], 0));
+        for (int u = 0; u < L.filled; ++u) {
+            int rc = bl_dist_set_distances(L.unit[u].dist, L.unit[u].snap[slot]);
+            if (rc) return rc;
+        }
+    }
     bl_ctx* ctxs[PLANNER_MAX_BATCH]; bl_dist* dists[PLANNER_MAX_BATCH]; const void* starts[PLANNER_MAX_BATCH];
     bl_pose_xyt_t goals[PLANNER_MAX_BATCH]; bl_search_params_t params[PLANNER_MAX_BATCH];
     for (int u = 0; u < L.filled; ++u) {
@@ -1651,14 +1660,20 @@ int bl_planner_commit(bl_planner* p, const bl_pose_xyt_t* goal, const bl_search_
     planner_lane& L = p->lane[l];
     planner_unit& U = L.unit[L.filled];
     const int slot = (int)(L.batches % PLANNER_SLOTS);
-    if (p->handoff_flag) {
-        BL_HIP(hipStreamWaitValue64(L.side->stream, p->d_flag, (uint64_t)p->submitted + 1ull, hipStreamWaitValueGte, 0xffffffffffffffffull));
-    } else {
-        BL_HIP(hipEventRecord(U.snap_ready[slot], p->main->stream));
-        BL_HIP(hipStreamWaitEvent(L.side->stream, U.snap_ready[slot], 0));
+    // A lane that collects a batch hands over ONCE, when the batch goes out (planner_launch_lane): an event record costs
+    // the SLAM stream several microseconds, and the lane cannot start the batch's searches before its last snapshot anyway.
+    const bool deferred = p->batch > 1 && !p->handoff_flag;
+    int rc = BL_OK;
+    if (!deferred) {
+        if (p->handoff_flag) {
+            BL_HIP(hipStreamWaitValue64(L.side->stream, p->d_flag, (uint64_t)p->submitted + 1ull, hipStreamWaitValueGte, 0xffffffffffffffffull));
+        } else {
+            BL_HIP(hipEventRecord(U.snap_ready[slot], p->main->stream));
+            BL_HIP(hipStreamWaitEvent(L.side->stream, U.snap_ready[slot], 0));
+        }
+        rc = bl_dist_set_distances(U.dist, U.snap[slot]);
+        if (rc) return rc;
     }
-    int rc = bl_dist_set_distances(U.dist, U.snap[slot]);
-    if (rc) return rc;
     U.goal = *goal; U.params = *params;
     p->tickets->push_back(planner_ticket{l, L.filled});
     L.filled += 1;
