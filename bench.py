@@ -124,10 +124,11 @@ def main():
     ap.add_argument("--goal-l1", type=int, default=40, help="without --goal on a non-default grid: max L1 distance (cells) "
                     "of the replan goal from the start")
     ap.add_argument("--cpu-steps", type=int, default=25, help="steps of the CPU baseline sample (0 = skip)")
-    ap.add_argument("--depth", type=int, default=6, help="steps enqueued ahead of fetching a result (0 = synchronous steps); a replan "
-                    "(distance grid + A*, ~0.4 ms) spans three steps, so fewer than ~6 leaves the SLAM stream waiting for the host")
+    ap.add_argument("--depth", type=int, default=10, help="steps enqueued ahead of fetching a result (0 = synchronous steps); a replan "
+                    "(distance grid + A*, ~0.4 ms) spans several steps and a lane sends its batch off when it is full, so fewer than "
+                    "~lanes x batch + 2 leaves the SLAM stream waiting for the host")
     ap.add_argument("--lanes", type=int, default=2, help="replanner streams: consecutive replans run concurrently (1..4)")
-    ap.add_argument("--batch", type=int, default=2, help="replans a lane collects and searches in one launch (1..4): lanes x batch "
+    ap.add_argument("--batch", type=int, default=4, help="replans a lane collects and searches in one launch (1..4): lanes x batch "
                     "searches overlap; for grids where a search outlasts several steps (use with --depth >= lanes x batch)")
     args = ap.parse_args()
 
@@ -190,6 +191,7 @@ def main():
 
     pose_dev = engine.pf.poseDevicePtr()
     # with one rank and no collective the filter's end rides in the map kernel (bl_mapping_update_finishing_pf)
+    prefetch = not os.environ.get("BENCH_NO_PREFETCH")
     ride_finish = world == 1 and not spf.force_collectives and not os.environ.get("BENCH_NO_RIDE")
     in_flight = []                  # steps enqueued whose result has not been fetched yet
 
@@ -202,6 +204,8 @@ def main():
         if ride_finish:
             # one rank: the end of the filter update (pose estimate + weight prefix) rides in the map kernel's launch
             engine.begin(odo_pose, sc, grid, int(rands[k]))
+            if prefetch and k + 1 < len(scans):
+                ctx.scanPrefetch(scans[k + 1])       # the next scan is queued (slam.cpp:96-104): it rides in this step's map kernel
             if goal_pose is not None:
                 aplanner.submit_with_map_update_finishing(mapper, sc, engine.pf, sc.utime, grid, goal_pose)
             else:
@@ -209,6 +213,8 @@ def main():
             in_flight.append(k)
             return
         spf.updateFilter(odo_pose, sc, grid, int(rands[k]), want_pose=False)
+        if prefetch and k + 1 < len(scans):
+            ctx.scanPrefetch(scans[k + 1])
         if goal_pose is not None:
             # updateMap with the device-resident pose, then snapshot map + pose for the replanner (one library call);
             # setDistances + search_for_path overlap the next step on a replanner lane

@@ -107,6 +107,7 @@ SIGNATURES = {
     "bl_planner_timing": (C.c_int, [_vp, C.c_int, _P(C.c_double), _P(C.c_double), _P(C.c_int64)]),
     "bl_planner_submit_with_map_update": (C.c_int, [_vp, _vp, _P(Lidar), _vp, C.c_int64, _vp, _P(Pose), _P(SearchParams)]),
     "bl_mapping_update_finishing_pf": (C.c_int, [_vp, _P(Lidar), _vp, C.c_int64, _vp]),
+    "bl_scan_prefetch": (C.c_int, [_vp, _P(Lidar)]),
     "bl_planner_submit_with_map_update_finishing_pf": (C.c_int, [_vp, _vp, _P(Lidar), _vp, C.c_int64, _vp, _P(Pose), _P(SearchParams)]),
     "bl_astar_search_batch": (C.c_int, [_vp, _vp, _P(Pose), _vp, C.c_int, _P(SearchParams), _vp, C.c_int, _vp, _vp]),
     "bl_dist_gather": (C.c_int, [_vp, _vp, C.c_int, _vp]),

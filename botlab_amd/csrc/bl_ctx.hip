@@ -198,25 +198,28 @@ static int scan_wait_seq(bl_scan_slots* sl, unsigned long long seq)
     return BL_OK;
 }
 
-int bl_scan_upload(bl_ctx* ctx, const bl_lidar_t* scan, int* num_rays)
+// Packs the kept rays of `scan` into the next free pinned slot (not yet taken: the caller advances `next` when it uses it)
+// and says whether the device block already holds exactly this scan.
+static int scan_pack(bl_ctx* ctx, const bl_lidar_t* scan, int* kept_out, float* max_range_out, bool* simple_out, bool* resident)
 {
-    BL_CHECK_ARG(scan != nullptr && scan->num_ranges >= 0);
     bl_scan_dev* sd = &ctx->scan;
-    int R = scan->num_ranges;
-    *num_rays = 0;
-    if (R == 0) { sd->kept = 0; if (sd->staging) ((bl_scan_slots*)sd->staging)->last = -1; return BL_OK; }
-    BL_CHECK_ARG(scan->ranges && scan->thetas && scan->times);
+    const int R = scan->num_ranges;
     if (R > sd->capacity) {
         int cap = R < 512 ? 512 : R;
         BL_HIP(hipStreamSynchronize(ctx->stream));
         bl_scan_free(ctx);
         size_t bytes = (size_t)cap * (8 + 4 + 4);
         char* d = nullptr;
-        BL_HIP(hipMalloc((void**)&d, bytes));
+        BL_HIP(hipMalloc((void**)&d, 2 * bytes));                // two blocks: the current one and the prefetch target
         sd->capacity = cap;
+        sd->base = d;
         sd->times = (int64_t*)d;                                 // 8-byte aligned part first
         sd->ranges = (float*)(d + (size_t)cap * 8);
         sd->thetas = (float*)(d + (size_t)cap * 12);
+        sd->alt_times = (int64_t*)(d + bytes);
+        sd->alt_ranges = (float*)(d + bytes + (size_t)cap * 8);
+        sd->alt_thetas = (float*)(d + bytes + (size_t)cap * 12);
+        sd->pre_pending = false;
         bl_scan_slots* sl = new bl_scan_slots();
         memset(sl, 0, sizeof(*sl));
         sl->last = -1;
@@ -252,14 +255,34 @@ int bl_scan_upload(bl_ctx* ctx, const bl_lidar_t* scan, int* num_rays)
         ht[kept] = scan->times[n];
         ++kept;
     }
-    *num_rays = kept;
-    if (kept == 0) { sd->kept = 0; sl->last = -1; return BL_OK; }
-    if (sl->last >= 0 && sd->kept == kept) {                     // the same scan as the one in the device block?
+    *kept_out = kept; *max_range_out = max_range; *simple_out = thetas_simple;
+    *resident = false;
+    if (kept > 0 && sl->last >= 0 && sd->kept == kept) {          // the same scan as the one in the device block?
         const char* p = (const char*)sl->host[sl->last];
         if (memcmp(p, h, (size_t)kept * 8) == 0 && memcmp(p + cap * 8, hrange, (size_t)kept * 4) == 0 &&
             memcmp(p + cap * 12, htheta, (size_t)kept * 4) == 0)
-            return BL_OK;                                        // slot s stays free for the next scan
+            *resident = true;                                    // the slot stays free for the next scan
     }
+    return BL_OK;
+}
+
+int bl_scan_upload(bl_ctx* ctx, const bl_lidar_t* scan, int* num_rays)
+{
+    BL_CHECK_ARG(scan != nullptr && scan->num_ranges >= 0);
+    bl_scan_dev* sd = &ctx->scan;
+    *num_rays = 0;
+    if (scan->num_ranges == 0) { sd->kept = 0; if (sd->staging) ((bl_scan_slots*)sd->staging)->last = -1; return BL_OK; }
+    BL_CHECK_ARG(scan->ranges && scan->thetas && scan->times);
+    int kept = 0; float max_range = 0; bool thetas_simple = false, resident = false;
+    int prc = scan_pack(ctx, scan, &kept, &max_range, &thetas_simple, &resident);
+    if (prc) return prc;
+    bl_scan_slots* sl = (bl_scan_slots*)sd->staging;
+    const int s = sl->next;
+    const size_t cap = (size_t)sd->capacity;
+    *num_rays = kept;
+    if (kept == 0) { sd->kept = 0; sl->last = -1; return BL_OK; }
+    if (resident) return BL_OK;
+    sd->pre_pending = false;                                     // a packed scan nobody has carried over by now is dropped
     const char* hd = (const char*)sl->host_dev[s];
     hipLaunchKernelGGL(k_scan_fetch, dim3(1), dim3(256), 0, ctx->stream, (const int64_t*)hd, (const float*)(hd + cap * 8),
                        (const float*)(hd + cap * 12), kept, sd->times, sd->ranges, sd->thetas, sl->h_seq_dev, sl->seq + 1);
@@ -274,10 +297,57 @@ int bl_scan_upload(bl_ctx* ctx, const bl_lidar_t* scan, int* num_rays)
     return BL_OK;
 }
 
+// The NEXT scan, handed over early (a SLAM host has it queued: slam.cpp:96-104): packed into a pinned slot now, brought to
+// the second device block by the next map kernel of this ctx beside its own work (bl_scan_prefetch_take), so that the
+// bl_pf_update / bl_mapping_update call that brings the same scan finds it resident and launches no fetch kernel.
+// Handing over a scan that is not used next costs nothing but the packing.
+extern "C" int bl_scan_prefetch(bl_ctx* ctx, const bl_lidar_t* scan)
+{
+    BL_CHECK_ARG(ctx != nullptr && scan != nullptr && scan->num_ranges >= 0);
+    bl_scan_dev* sd = &ctx->scan;
+    sd->pre_pending = false;
+    if (scan->num_ranges == 0) return BL_OK;
+    BL_CHECK_ARG(scan->ranges && scan->thetas && scan->times);
+    BL_HIP(hipSetDevice(ctx->device));
+    int kept = 0; float max_range = 0; bool thetas_simple = false, resident = false;
+    int rc = scan_pack(ctx, scan, &kept, &max_range, &thetas_simple, &resident);
+    if (rc) return rc;
+    if (kept == 0 || resident) return BL_OK;
+    bl_scan_slots* sl = (bl_scan_slots*)sd->staging;
+    sd->pre_slot = sl->next;
+    sl->next = (sl->next + 1) % kScanSlots;                      // the slot is taken until the copy (if any) has read it
+    sd->pre_kept = kept; sd->pre_max_range = max_range; sd->pre_thetas_simple = thetas_simple;
+    sd->pre_pending = true;
+    return BL_OK;
+}
+
+int bl_scan_prefetch_take(bl_ctx* ctx, bl_scan_prefetch_args* out)
+{
+    bl_scan_dev* sd = &ctx->scan;
+    if (!sd->pre_pending || !sd->staging) return 0;
+    bl_scan_slots* sl = (bl_scan_slots*)sd->staging;
+    const size_t cap = (size_t)sd->capacity;
+    const char* hd = (const char*)sl->host_dev[sd->pre_slot];
+    out->h_times = (const int64_t*)hd; out->h_ranges = (const float*)(hd + cap * 8); out->h_thetas = (const float*)(hd + cap * 12);
+    out->kept = sd->pre_kept;
+    out->d_times = sd->alt_times; out->d_ranges = sd->alt_ranges; out->d_thetas = sd->alt_thetas;
+    out->h_seq = sl->h_seq_dev; out->seq = sl->seq + 1;
+    sl->seq += 1;
+    sl->slot_seq[sd->pre_slot] = sl->seq;
+    sl->last = sd->pre_slot;
+    // the blocks swap: everything launched from here on reads the prefetched scan
+    int64_t* t = sd->times; sd->times = sd->alt_times; sd->alt_times = t;
+    float* r = sd->ranges; sd->ranges = sd->alt_ranges; sd->alt_ranges = r;
+    float* th = sd->thetas; sd->thetas = sd->alt_thetas; sd->alt_thetas = th;
+    sd->kept = sd->pre_kept; sd->max_range = sd->pre_max_range; sd->thetas_simple = sd->pre_thetas_simple;
+    sd->pre_pending = false;
+    return 1;
+}
+
 void bl_scan_free(bl_ctx* ctx)
 {
     bl_scan_dev* sd = &ctx->scan;
-    if (sd->times) (void)hipFree(sd->times);
+    if (sd->base) (void)hipFree(sd->base);
     if (sd->staging) {
         bl_scan_slots* sl = (bl_scan_slots*)sd->staging;
         (void)scan_wait_seq(sl, sl->seq);                 // no fetch still reads a slot
@@ -288,6 +358,7 @@ void bl_scan_free(bl_ctx* ctx)
     }
     sd->capacity = 0; sd->kept = 0;
     sd->times = nullptr; sd->ranges = nullptr; sd->thetas = nullptr; sd->staging = nullptr;
+    sd->base = nullptr; sd->alt_times = nullptr; sd->alt_ranges = nullptr; sd->alt_thetas = nullptr; sd->pre_pending = false;
 }
 
 // ---------------------------------------------------------------- OccupancyGrid (src/slam/occupancy_grid.cpp)

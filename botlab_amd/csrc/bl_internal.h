@@ -49,7 +49,22 @@ struct bl_scan_dev {
     int kept = 0;               // rays in the block
     float max_range = 0;        // largest kept range (bounds the cell offsets a ray can produce)
     bool thetas_simple = false; // every kept theta lies in [0, 6.2831]: a wrapped pose angle less a theta needs at most one upward 2*pi step
+    // second device block + a packed scan waiting for it (bl_scan_prefetch): the next map kernel brings it over beside its own
+    // work, and the blocks swap
+    void* base = nullptr;       // the allocation both blocks live in
+    float* alt_ranges = nullptr; float* alt_thetas = nullptr; int64_t* alt_times = nullptr;
+    bool pre_pending = false; int pre_slot = 0, pre_kept = 0; float pre_max_range = 0; bool pre_thetas_simple = false;
 };
+
+struct bl_scan_prefetch_args {
+    const int64_t* h_times; const float* h_ranges; const float* h_thetas; int kept;
+    int64_t* d_times; float* d_ranges; float* d_thetas;
+    unsigned long long* h_seq; unsigned long long seq;
+};
+// bl_ctx.hip: 1 and `out` filled if a packed scan waits for a kernel to carry it (the bookkeeping is done: the caller MUST
+// launch the copy, behind everything that reads the current block); 0 otherwise.  Call it AFTER taking the current block's
+// pointers for the launch that carries the copy.
+int bl_scan_prefetch_take(struct bl_ctx* ctx, bl_scan_prefetch_args* out);
 
 struct bl_astar_state;
 struct bl_frontier_scratch;

@@ -60,6 +60,9 @@ struct map_args {
     // optional: the end of the particle-filter update whose pose estimate this map update uses (bl_mcl_finish.h).
     // Workgroup 0 forms the estimate before it reads the pose; workgroups 1.. write the weight prefix meanwhile.
     int fin_on; mcl_finish_args fin;
+    // optional: the next scan, packed in a pinned slot (bl_scan_prefetch), brought to the ctx's second device block by the last
+    // workgroup of this launch
+    int pre_on; bl_scan_prefetch_args pre;
 };
 
 #ifdef BL_MAP_STAMPS
@@ -92,8 +95,18 @@ __global__ __launch_bounds__(MAP_THREADS) void k_map_update(map_args a)
 {
     __shared__ unsigned long long s_fin[2 * MCLF_WG / 64];
     __shared__ double s_fin_red[MCLF_POSE_THREADS / 64][5];
-    if (blockIdx.x > 0) {                                       // only launched when a.fin_on
-        mclf_prefix_group(a.fin, (int)blockIdx.x - 1, s_fin);
+    if (blockIdx.x > 0) {                                       // riders: the filter's prefix groups, then the scan prefetch
+        if (a.pre_on && blockIdx.x == gridDim.x - 1) {
+            for (int i = threadIdx.x; i < a.pre.kept; i += MAP_THREADS) {
+                a.pre.d_times[i] = a.pre.h_times[i];
+                a.pre.d_ranges[i] = a.pre.h_ranges[i];
+                a.pre.d_thetas[i] = a.pre.h_thetas[i];
+            }
+            __syncthreads();                                    // every lane's loads from the slot have returned
+            if (threadIdx.x == 0) __hip_atomic_store(a.pre.h_seq, a.pre.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        } else {
+            mclf_prefix_group(a.fin, (int)blockIdx.x - 1, s_fin);
+        }
         return;
     }
     const size_t n = (size_t)a.frame.width * a.frame.height;
@@ -516,8 +529,11 @@ static int mapping_update_impl(bl_mapping* m, const bl_lidar_t* scan, const bl_p
     if (rc) return rc;
     a.fin_on = fin ? 1 : 0;
     if (fin) a.fin = *fin; else a.fin = mcl_finish_args{};
+    // the current scan block's pointers are in `a` already: a waiting prefetch may now take the other block
+    a.pre = bl_scan_prefetch_args{};
+    a.pre_on = bl_scan_prefetch_take(ctx, &a.pre);
     static_assert(MCLF_WG == MAP_THREADS, "the riding finish uses the map kernel's workgroup size");
-    hipLaunchKernelGGL(k_map_update, dim3(1 + (fin ? mclf_groups(*fin) : 0)), dim3(MAP_THREADS), MAP_LDS_COUNTERS * 2, ctx->stream, a);
+    hipLaunchKernelGGL(k_map_update, dim3(1 + (fin ? mclf_groups(*fin) : 0) + a.pre_on), dim3(MAP_THREADS), MAP_LDS_COUNTERS * 2, ctx->stream, a);
     BL_HIP(hipGetLastError());
     rc = bl_timer_end(ctx, BL_K_MAP, e0, e1);
     if (rc) return rc;

@@ -61,6 +61,12 @@ class Context:
         self.h = h
         self.device = device
 
+    def scanPrefetch(self, scan):
+        """Hands the NEXT lidar scan over early: the next map kernel of this context copies it to the device beside its own
+        work, and the update that later brings the same scan launches no fetch kernel (bl_scan_prefetch)."""
+        c = scan.as_c()
+        check(self.lib.bl_scan_prefetch(self.h, C.byref(c)))
+
     def sync(self):
         check(self.lib.bl_ctx_sync(self.h))
 

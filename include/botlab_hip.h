@@ -212,6 +212,11 @@ int bl_planner_submit_with_map_update(bl_planner* p, bl_mapping* m, const bl_lid
  * further workgroups of the launch write the weight prefix meanwhile, so the SLAM stream carries one kernel less per step.
  * A filter with nothing pending (the robot did not move) or whose end cannot ride (sharded particle set) is ended the
  * ordinary way first.  Results are bit-identical to the separate calls. */
+/* The NEXT lidar scan handed over early (a SLAM host has it queued, src/slam/slam.cpp:96-104): it is packed into pinned
+ * memory now and copied to the device by the next bl_mapping_update* / bl_planner_submit_with_map_update* launch of this
+ * ctx, beside that kernel's own work; the bl_pf_update* / bl_mapping_update* call that later brings the same scan then
+ * launches no fetch kernel.  Purely an optimisation: a scan that is not the next one used costs only its packing. */
+int bl_scan_prefetch(bl_ctx* ctx, const bl_lidar_t* scan);
 int bl_mapping_update_finishing_pf(bl_mapping* m, const bl_lidar_t* scan, bl_pf* pf, int64_t pose_utime, bl_grid* map);
 /* the same for bl_planner_submit_with_map_update */
 int bl_planner_submit_with_map_update_finishing_pf(bl_planner* p, bl_mapping* m, const bl_lidar_t* scan, bl_pf* pf,

@@ -443,8 +443,10 @@ def test_step_pipeline_with_device_pose_equals_host_pose_path(oracle, maps, gpu_
     # "batched*": a lane collects several submissions and searches them in one launch (lag 3 < batch x lanes: some batches
     # are sent off partly filled by the fetch; lag 6: every batch fills, the last one is flushed by the drain)
     forms = {"async": (3, 1, 3), "fused": (3, 1, 3), "batched2": (3, 2, 3), "batched3": (2, 3, 6), "batched4": (1, 4, 2),
-             "riding": (3, 1, 3), "riding_deep": (3, 1, 6)}
-    for dev in (False, True, "async", "fused", "batched2", "batched3", "batched4", "riding", "riding_deep"):
+             "riding": (3, 1, 3), "riding_deep": (3, 1, 6), "riding_prefetch": (2, 2, 6), "fused_prefetch": (3, 1, 3),
+             "riding_wrong_prefetch": (2, 2, 6)}
+    for dev in (False, True, "async", "fused", "batched2", "batched3", "batched4", "riding", "riding_deep", "riding_prefetch",
+                "fused_prefetch", "riding_wrong_prefetch"):
         g = _grid_from_map(m, gpu_ctx)
         lanes, batch, lag = forms.get(dev, (0, 0, 0))
         aplanner = bl.AsyncPlanner(ctx=gpu_ctx, lanes=lanes, batch=batch) if dev in forms else None
@@ -459,12 +461,20 @@ def test_step_pipeline_with_device_pose_equals_host_pose_path(oracle, maps, gpu_
             odo = bl.make_pose(*poses[k + 1], utime=sc.utime)
             if dev in forms:
                 # replanner on its own stream against snapshots; results fetched three steps late, in order
-                if dev in ("riding", "riding_deep"):                 # the end of the filter update rides in the map kernel
+                riding = dev in ("riding", "riding_deep", "riding_prefetch", "riding_wrong_prefetch")
+                if riding:                                           # the end of the filter update rides in the map kernel
                     pf.updateBegin(odo, sc, g, 1000 + k)
-                    aplanner.submit_with_map_update_finishing(mapper, sc, pf, sc.utime, g, goal)
                 else:
                     pf.updateFilter(odo, sc, g, rand_value=1000 + k, want_pose=False)
-                if dev in ("riding", "riding_deep"):
+                # the next scan handed over early rides in the map kernel too; handing over another scan than the one that
+                # comes next (here: the one after it, or the current one again) must change nothing
+                if dev in ("riding_prefetch", "fused_prefetch") and k + 1 < len(scans):
+                    gpu_ctx.scanPrefetch(scans[k + 1])
+                if dev == "riding_wrong_prefetch":
+                    gpu_ctx.scanPrefetch(scans[k + 2] if (k % 2 == 0 and k + 2 < len(scans)) else sc)
+                if riding:
+                    aplanner.submit_with_map_update_finishing(mapper, sc, pf, sc.utime, g, goal)
+                if riding:
                     pass
                 elif dev != "async":                                 # map update + snapshot in one call (bench.py's form)
                     aplanner.submit_with_map_update(mapper, sc, pf.poseDevicePtr(), sc.utime, g, goal)
