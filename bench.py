@@ -28,7 +28,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8 TB/s
-EVENT_STRIDE = 8                 # HIP-event pairs are recorded around every 8th k_mcl_main launch of the timed region
+EVENT_STRIDE = 8                 # every 8th k_mcl_main launch of the timed region carries start/stop events (a timed launch costs ~4 us of stream time)
 
 
 def load_map(name):
@@ -274,8 +274,9 @@ def main():
     drain()
     ctx.timing_reset()
     if not os.environ.get("BENCH_NO_EVENTS"):
-        # HIP events around the dominant kernel only (roofline leg), on every EVENT_STRIDE-th launch of the timed region:
-        # an event pair costs ~13 us of stream time per launch (measured), more than a tenth of this step
+        # HIP events of the dominant kernel only (roofline leg), on every EVENT_STRIDE-th launch of the timed region: the
+        # launch carries its own start / stop events (hipExtLaunchKernelGGL), which hold the kernel's begin and end time stamps
+        # -- a pair of hipEventRecord calls around it also measures the launch gap (~13 us here)
         ctx.timing_stride(EVENT_STRIDE)
         ctx.timing_enable(True, kernels=[_capi.BL_K_MCL_MAIN])
     pops_total[0] = 0

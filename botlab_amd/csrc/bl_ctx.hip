@@ -106,6 +106,32 @@ int bl_timer_begin(bl_ctx* ctx, int id, hipEvent_t* a, hipEvent_t* b)
     return BL_OK;
 }
 
+// The same bookkeeping for a launch that takes its own start/stop events (hipExtLaunchKernelGGL: the events carry the
+// kernel's begin and end time stamps themselves, with no barrier packets around it -- a pair of hipEventRecord calls measures
+// the launch gap as well, ~13 us here).  *a stays null when this launch is not to be timed.
+int bl_timer_pair(bl_ctx* ctx, int id, hipEvent_t* a, hipEvent_t* b)
+{
+    *a = nullptr; *b = nullptr;
+    if (!ctx->timing || !((ctx->timing_mask >> id) & 1u)) return BL_OK;
+    bl_timer& t = ctx->timers[id];
+    if (ctx->timing_stride > 1 && (t.seen++ % ctx->timing_stride) != 0) return BL_OK;
+    if (!t.pool.empty()) {
+        *a = t.pool.back().first; *b = t.pool.back().second;
+        t.pool.pop_back();
+    } else {
+        BL_HIP(hipEventCreate(a));
+        BL_HIP(hipEventCreate(b));
+    }
+    return BL_OK;
+}
+
+int bl_timer_commit(bl_ctx* ctx, int id, hipEvent_t a, hipEvent_t b)
+{
+    if (!a) return BL_OK;
+    ctx->timers[id].pending.emplace_back(a, b);
+    return BL_OK;
+}
+
 int bl_timer_end(bl_ctx* ctx, int id, hipEvent_t a, hipEvent_t b)
 {
     if (!ctx->timing || !a) return BL_OK;

@@ -110,6 +110,8 @@ void bl_planner_cancel(bl_planner* p);
 // RAII-less helpers
 int bl_timer_begin(bl_ctx* ctx, int id, hipEvent_t* a, hipEvent_t* b);
 int bl_timer_end(bl_ctx* ctx, int id, hipEvent_t a, hipEvent_t b);
+int bl_timer_pair(bl_ctx* ctx, int id, hipEvent_t* a, hipEvent_t* b);     // for launches that take start/stop events themselves
+int bl_timer_commit(bl_ctx* ctx, int id, hipEvent_t a, hipEvent_t b);
 int bl_scan_upload(bl_ctx* ctx, const bl_lidar_t* scan, int* num_rays);
 void bl_scan_free(bl_ctx* ctx);
 

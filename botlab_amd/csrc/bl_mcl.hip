@@ -22,6 +22,7 @@
 #include <string.h>
 #include <new>
 
+#include <hip/hip_ext.h>
 #include "bl_internal.h"
 #include "bl_mcl_finish.h"
 
@@ -1275,12 +1276,12 @@ static int pf_launch_main(bl_pf* pf, const bl_grid* map, int R, int rand_value, 
     int blocks = (int)(main_blocks + tail_blocks);
     if (blocks > pf->partials_cap) { bl_set_error("internal: partials buffer too small"); return BL_ERR_STATE; }
     hipEvent_t e0, e1;
-    int rc = bl_timer_begin(ctx, BL_K_MCL_MAIN, &e0, &e1);
+    int rc = bl_timer_pair(ctx, BL_K_MCL_MAIN, &e0, &e1);     // a timed launch carries its own start/stop events
     if (rc) return rc;
 #define MCL_LAUNCH(B, M)                                                                                          \
     do {                                                                                                          \
-        if (a.interp) hipLaunchKernelGGL((k_mcl_main<1, B, (M) == 2 ? 0 : (M)>), dim3(blocks), dim3(B), lds_bytes, ctx->stream, a); \
-        else hipLaunchKernelGGL((k_mcl_main<0, B, M>), dim3(blocks), dim3(B), lds_bytes, ctx->stream, a);          \
+        if (a.interp) hipExtLaunchKernelGGL((k_mcl_main<1, B, (M) == 2 ? 0 : (M)>), dim3(blocks), dim3(B), lds_bytes, ctx->stream, e0, e1, 0, a); \
+        else hipExtLaunchKernelGGL((k_mcl_main<0, B, M>), dim3(blocks), dim3(B), lds_bytes, ctx->stream, e0, e1, 0, a);          \
     } while (0)
 #define MCL_LAUNCH_MODE(B)                                    \
     do {                                                      \
@@ -1294,7 +1295,7 @@ static int pf_launch_main(bl_pf* pf, const bl_grid* map, int R, int rand_value, 
 #undef MCL_LAUNCH_MODE
 #undef MCL_LAUNCH
     BL_HIP(hipGetLastError());
-    rc = bl_timer_end(ctx, BL_K_MCL_MAIN, e0, e1);
+    rc = bl_timer_commit(ctx, BL_K_MCL_MAIN, e0, e1);
     if (rc) return rc;
     pf->last_blocks = blocks;
     pf->last_tile = gpb;                                  // particles per region-1 workgroup of k_mcl_main
