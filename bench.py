@@ -132,6 +132,12 @@ def main():
                     "searches overlap; for grids where a search outlasts several steps (use with --depth >= lanes x batch)")
     args = ap.parse_args()
 
+    # stdout carries ONE JSON line: anything native code prints there (RCCL writes a version banner to stdout when its first
+    # communicator comes up) goes to stderr instead
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -393,7 +399,10 @@ def main():
             "config": {"workload": f"full SLAM step on {W}x{H} @5cm grid (shipped obstacle_slam map), {N} particles, "
                                    f"{R} rays, A* replan {'off' if goal is None else 'on'}",
                        "particles": N, "grid": [W, H], "rays": R, "pipeline_depth": args.depth, "planner_lanes": args.lanes, "planner_batch": args.batch,
-                       "parallelism": f"particle-shard x{world}" if world > 1 else "single GPU"},
+                       "parallelism": f"particle-shard x{world}" if world > 1 else "single GPU",
+                       "collective": ("none" if not (world > 1 or spf.force_collectives) else
+                                      ("RCCL all-gather enqueued by the library on the filter's stream" if spf.comm is not None
+                                       else "torch.distributed all_gather_into_tensor"))},
             "roofline": {"bound": "hbm", "kernel": "k_mcl_main", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": main_ms,
@@ -412,9 +421,12 @@ def main():
         }
         if args.cpu_steps > 0 and world == 1:
             out["cpu_baseline"] = cpu_baseline(args, m, odo, scans, rands, goal, args.cpu_steps)
-        print(json.dumps(out))
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     if dist.is_initialized():
         dist.barrier()
+        torch.cuda.synchronize()
+        spf.close()
         dist.destroy_process_group()
 
 

@@ -108,6 +108,11 @@ SIGNATURES = {
     "bl_planner_submit_with_map_update": (C.c_int, [_vp, _vp, _P(Lidar), _vp, C.c_int64, _vp, _P(Pose), _P(SearchParams)]),
     "bl_mapping_update_finishing_pf": (C.c_int, [_vp, _P(Lidar), _vp, C.c_int64, _vp]),
     "bl_scan_prefetch": (C.c_int, [_vp, _P(Lidar)]),
+    "bl_comm_load": (C.c_int, [C.c_char_p]),
+    "bl_comm_unique_id": (C.c_int, [C.c_char_p, C.c_char_p]),
+    "bl_comm_create": (C.c_int, [_vp, C.c_char_p, C.c_char_p, C.c_int, C.c_int, _P(_vp)]),
+    "bl_comm_destroy": (None, [_vp]),
+    "bl_comm_all_gather_inplace": (C.c_int, [_vp, _vp, C.c_size_t]),
     "bl_planner_submit_with_map_update_finishing_pf": (C.c_int, [_vp, _vp, _P(Lidar), _vp, C.c_int64, _vp, _P(Pose), _P(SearchParams)]),
     "bl_astar_search_batch": (C.c_int, [_vp, _vp, _P(Pose), _vp, C.c_int, _P(SearchParams), _vp, C.c_int, _vp, _vp]),
     "bl_dist_gather": (C.c_int, [_vp, _vp, C.c_int, _vp]),

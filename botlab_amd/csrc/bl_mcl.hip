@@ -896,6 +896,7 @@ __global__ void k_pf_export(const float4* rec, const float4* parent, const pf_st
     float4 r = rec[lo + j];
     float4 p = parent[j];
     bl_particle_t o;
+    memset(&o, 0, sizeof(o));                                // the struct's padding bytes leave the device defined (zero)
     o.pose.utime = pose_utime; o.pose.x = r.x; o.pose.y = r.y; o.pose.theta = r.z;
     o.parent_pose.utime = parent_utime; o.parent_pose.x = p.x; o.parent_pose.y = p.y; o.parent_pose.theta = p.z;
     o.weight = (double)__float_as_uint(r.w) / state->S;

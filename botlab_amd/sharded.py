@@ -89,6 +89,51 @@ class ShardedParticleFilter:
         self.rank = engine.rank
         # exercise the collectives even with one rank (plumbing check on a 1-GPU box)
         self.force_collectives = bool(os.environ.get("BOTLAB_FORCE_COLLECTIVES")) and dist.is_initialized()
+        self._views = None
+        self._stream_current = False
+        self.comm = None
+        if (self.world > 1 or self.force_collectives) and dist.is_initialized() and hasattr(engine, "ctx") \
+                and dist.get_backend(self.group) == "nccl" and not os.environ.get("BOTLAB_TORCH_COLLECTIVES"):
+            self.comm = self._direct_comm()
+
+    def _direct_comm(self):
+        """The library's own RCCL communicator (csrc/bl_comm.hip): the all-gather is then ONE call that enqueues the collective
+        on the filter's stream.  torch.distributed is the rendezvous only (rank 0's unique id is broadcast).  Every rank ends
+        up with the same answer: if the communicator did not come up anywhere, all ranks keep torch's all_gather."""
+        lib = self.engine.ctx.lib
+        path = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so").encode()
+
+        def everyone(ok):
+            flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=self.engine.device)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.group)
+            return int(flag.item()) == 1
+
+        # 1. every rank can load the library (no RCCL call yet: a rank that could not would leave the others waiting inside
+        #    the collective initialisation below)
+        if not everyone(os.path.exists(path.decode()) and lib.bl_comm_load(path) == 0):
+            return None
+        # 2. rank 0's unique id reaches every rank
+        ident = [None]
+        if self.rank == 0:
+            buf = C.create_string_buffer(128)
+            if lib.bl_comm_unique_id(path, buf) == 0:
+                ident[0] = bytes(buf.raw)
+        dist.broadcast_object_list(ident, src=0, group=self.group)
+        if ident[0] is None:
+            return None
+        # 3. the communicator (collective), then agreement that it came up everywhere
+        h = C.c_void_p()
+        ok = lib.bl_comm_create(self.engine.ctx.h, path, ident[0], self.rank, self.world, C.byref(h)) == 0
+        if not everyone(ok):
+            if ok:
+                lib.bl_comm_destroy(h)
+            return None
+        return h
+
+    def close(self):
+        if self.comm is not None:
+            self.engine.ctx.lib.bl_comm_destroy(self.comm)
+            self.comm = None
 
     def initializeFilterAtPose(self, pose, seed=1):
         self.engine.init_at_pose(pose, seed)          # counter-based: every rank generates the identical full record
@@ -96,18 +141,35 @@ class ShardedParticleFilter:
     def setParticles(self, particles, units=None):
         self.engine.set_particles(particles, units)
 
+    def _exchange_views(self):
+        """(whole record, this rank's slice) per exchange buffer, made once: slicing a tensor costs microseconds per call."""
+        if self._views is None:
+            S = self.engine.S
+            self._views = {}
+            for t in getattr(self.engine, "rec", []):
+                self._views[t.data_ptr()] = (t, t[self.rank * S:(self.rank + 1) * S])
+        return self._views
+
     def updateFilter(self, odometry, scan, grid, rand_value, noise=None, want_pose=True):
         moved = self.engine.begin(odometry, scan, grid, rand_value, noise)
-        if moved and (self.world > 1 or self.force_collectives):
-            rec = self.engine.exchange_record()
-            S = self.engine.S
-            mine = rec[self.rank * S:(self.rank + 1) * S]
+        if moved and self.comm is not None:
+            lib = self.engine.ctx.lib
+            check(lib.bl_comm_all_gather_inplace(self.comm, lib.bl_pf_exchange_rec_ptr(self.engine.pf.h), self.engine.S * 4))
+        elif moved and (self.world > 1 or self.force_collectives):
             stream = getattr(self.engine, "stream", None)
             if stream is not None:
-                with torch.cuda.stream(stream):      # the collective is ordered on the engine's stream
-                    dist.all_gather_into_tensor(rec, mine, group=self.group)
-            else:
+                # the collective is ordered on the engine's stream: that stream is made torch's current stream of this thread
+                # once (entering a stream context per step costs ~10 us of host time)
+                if not self._stream_current:
+                    torch.cuda.set_stream(stream)
+                    self._stream_current = True
+                ptr = self.engine.ctx.lib.bl_pf_exchange_rec_ptr(self.engine.pf.h)
+                rec, mine = self._exchange_views()[ptr]
                 dist.all_gather_into_tensor(rec, mine, group=self.group)
+            else:
+                rec = self.engine.exchange_record()
+                S = self.engine.S
+                dist.all_gather_into_tensor(rec, rec[self.rank * S:(self.rank + 1) * S], group=self.group)
         return self.engine.end(want_pose)
 
     def particles(self):

@@ -212,6 +212,20 @@ int bl_planner_submit_with_map_update(bl_planner* p, bl_mapping* m, const bl_lid
  * further workgroups of the launch write the weight prefix meanwhile, so the SLAM stream carries one kernel less per step.
  * A filter with nothing pending (the robot did not move) or whose end cannot ride (sharded particle set) is ended the
  * ordinary way first.  Results are bit-identical to the separate calls. */
+/* ------------------------------------------------------------------ particle shards over RCCL  
+ * The shards' one collective -- the in-place all-gather of the 16-byte exchange record -- enqueued from this library on the
+ * ctx stream, between the two halves of bl_pf_update (bl_pf_update_begin / bl_pf_update_end).  RCCL is not linked: the
+ * caller names the librccl.so its process already uses (with PyTorch: torch/lib/librccl.so).  Rendezvous is the caller's:
+ * rank 0 makes the id with bl_comm_unique_id, every rank receives its 128 bytes by whatever transport the host has
+ * (torch.distributed in botlab_amd/sharded.py) and calls bl_comm_create (collective). */
+typedef struct bl_comm bl_comm;
+int bl_comm_load(const char* rccl_path);          /* dlopen + symbols only: 0 if the library is usable */
+int bl_comm_unique_id(const char* rccl_path, char* out_id128);
+int bl_comm_create(bl_ctx* ctx, const char* rccl_path, const char* id128, int rank, int world, bl_comm** out);
+void bl_comm_destroy(bl_comm* c);
+/* rec: world x per_rank_floats floats, this rank's slice already at its offset (bl_pf_exchange_rec_ptr) */
+int bl_comm_all_gather_inplace(bl_comm* c, void* rec, size_t per_rank_floats);
+
 /* The NEXT lidar scan handed over early (a SLAM host has it queued, src/slam/slam.cpp:96-104): it is packed into pinned
  * memory now and copied to the device by the next bl_mapping_update* / bl_planner_submit_with_map_update* launch of this
  * ctx, beside that kernel's own work; the bl_pf_update* / bl_mapping_update* call that later brings the same scan then
