@@ -8,9 +8,9 @@ from ._capi import BotlabHipError, Lidar, Particle, Pose, SearchParams, load  # 
 from .host import (AsyncPlanner, Context, LidarScan, Mapping, MotionPlanner, MotionPlannerParams, ObstacleDistanceGrid,  # noqa: F401
                    OccupancyGrid, ParticleFilter, PARTICLE_DTYPE, POSE_DTYPE, default_context, make_pose,
                    search_for_path, search_for_path_begin, search_for_path_end, search_for_path_batch, Frontiers,
-                   find_map_frontiers, plan_path_to_frontier)
+                   find_map_frontiers, plan_path_to_frontier, ExploringMap)
 
 __all__ = ["AsyncPlanner", "BotlabHipError", "Lidar", "Particle", "Pose", "SearchParams", "load", "Context", "LidarScan", "Mapping",
            "MotionPlanner", "MotionPlannerParams", "ObstacleDistanceGrid", "OccupancyGrid", "ParticleFilter",
            "PARTICLE_DTYPE", "POSE_DTYPE", "default_context", "make_pose", "search_for_path", "search_for_path_begin",
-           "search_for_path_end", "search_for_path_batch", "Frontiers", "find_map_frontiers", "plan_path_to_frontier"]
+           "search_for_path_end", "search_for_path_batch", "Frontiers", "find_map_frontiers", "plan_path_to_frontier", "ExploringMap"]

@@ -503,6 +503,52 @@ def plan_path_to_frontier(frontiers, robotPose, grid, planner, cap=1 << 16, retu
     return path
 
 
+# exploration_status_t (lcmtypes/exploration_status_t.lcm:3-11)
+STATE_INITIALIZING, STATE_EXPLORING_MAP, STATE_RETURNING_HOME, STATE_COMPLETED_EXPLORATION, STATE_FAILED_EXPLORATION = 0, 1, 2, 3, 4
+STATUS_IN_PROGRESS, STATUS_COMPLETE, STATUS_FAILED = 0, 1, 2
+
+
+class ExploringMap:
+    """Exploration::executeExploringMap (src/planning/exploration.cpp:277-369), the per-map step of the exploration loop,
+    without its LCM calls: setMap (distance transform), find_map_frontiers, and -- when the robot is within 0.5 m of the
+    current target or has none -- plan_path_to_frontier; then the status / next-state rule of :332-368.  The reference
+    leaves status.status unset when frontiers remain but no path was found (:344-347 is commented out) and so falls into the
+    default branch of :365-367: FAILED_EXPLORATION (definition D10; `status` then reports STATUS_FAILED)."""
+
+    def __init__(self, planner):
+        self.planner_ = planner
+        self.currentTarget_ = make_pose(0.0, 0.0, 0.0)
+        self.currentPath_ = []
+        self.frontiers_ = None
+        self.status = None
+
+    def execute(self, currentMap, currentPose):
+        self.planner_.setMap(currentMap)                                             # :299
+        self.frontiers_ = find_map_frontiers(currentMap, currentPose)                # :300
+        lists = self.frontiers_.cells()
+        self.planner_.setNumFrontiers(len(lists))                                    # :302
+        t = self.currentTarget_
+        if t.x != 0 or t.y != 0:                                                      # :307-311: double pow/sqrt, stored to a float
+            dx = float(np.float32(currentPose.x) - np.float32(t.x))
+            dy = float(np.float32(currentPose.y) - np.float32(t.y))
+            currDist = float(np.float32(np.sqrt(dx * dx + dy * dy)))
+        else:
+            currDist = 0.0
+        if currDist <= float(np.float32(0.5)) and len(lists) > 0:                     # :316-321
+            self.currentPath_ = plan_path_to_frontier(self.frontiers_, currentPose, currentMap, self.planner_)
+            if len(self.currentPath_) > 1:
+                p = self.currentPath_[-1]
+                self.currentTarget_ = Pose(p.utime, p.x, p.y, p.theta)
+        if len(lists) == 0:                                                           # :335-347
+            self.status = STATUS_COMPLETE
+        elif len(self.currentPath_) > 1:
+            self.status = STATUS_IN_PROGRESS
+        else:
+            self.status = STATUS_FAILED                                               # D10
+        return {STATUS_IN_PROGRESS: STATE_EXPLORING_MAP, STATUS_COMPLETE: STATE_RETURNING_HOME,
+                STATUS_FAILED: STATE_FAILED_EXPLORATION}[self.status]                # :352-368
+
+
 class AsyncPlanner:
     """bl_planner: MotionPlanner.setMap + planPath run on a second stream against a snapshot of the map and of the
     device-resident pose (the reference's planner process, src/planning/exploration.cpp:300-317)."""

@@ -58,3 +58,10 @@ static void check_planning_dropin(const botlab_hip::OccupancyGrid& map, const po
     robot_path_t p = botlab_hip::plan_path_to_frontier_t<robot_path_t>(fr, pose, map, planner);
     (void)planner.isPathSafe(p); (void)planner.isValidGoal(pose); (void)planner.planPath(pose, pose); (void)planner.obstacleDistances();
 }
+static void check_exploring_map(const botlab_hip::OccupancyGrid& map, const pose_xyt_t& pose)
+{
+    CheckMotionPlanner planner;
+    botlab_hip::ExploringMapT<pose_xyt_t, robot_path_t> ex(planner);
+    int8_t next = ex.execute(map, pose);
+    (void)next; (void)ex.status; (void)ex.currentPath_; (void)ex.currentTarget_;
+}

@@ -172,6 +172,55 @@ Path plan_path_to_frontier_t(const std::vector<frontier_t>& frontiers, const Pos
     path.path_length = static_cast<int32_t>(path.path.size());
     return path;
 }
+// Exploration::executeExploringMap (src/planning/exploration.cpp:277-369) without its LCM calls (the caller publishes the
+// status and the path): the per-map step of the exploration loop -- setMap, find_map_frontiers, plan_path_to_frontier when
+// the robot is within 0.5 m of the current target (or has none) -- and the status / next-state rule of :332-368.  The
+// reference leaves status.status unset when frontiers remain but no path was found (:344-347 is commented out) and so ends
+// in the default branch of :365-367: FAILED_EXPLORATION (definition D10; `status` then holds STATUS_FAILED).
+// States and statuses: lcmtypes/exploration_status_t.lcm:3-11.
+template <class Pose, class Path, class Planner = MotionPlannerT<Pose, Path> >
+class ExploringMapT {
+public:
+    enum { STATE_INITIALIZING = 0, STATE_EXPLORING_MAP = 1, STATE_RETURNING_HOME = 2, STATE_COMPLETED_EXPLORATION = 3, STATE_FAILED_EXPLORATION = 4 };
+    enum { STATUS_IN_PROGRESS = 0, STATUS_COMPLETE = 1, STATUS_FAILED = 2 };
+
+    explicit ExploringMapT(Planner& planner) : planner_(planner), status(STATUS_FAILED)
+    {
+        currentTarget_.utime = 0; currentTarget_.x = 0; currentTarget_.y = 0; currentTarget_.theta = 0;
+        currentPath_.utime = 0; currentPath_.path_length = 0;
+    }
+
+    int8_t execute(const OccupancyGrid& currentMap, const Pose& currentPose)
+    {
+        planner_.setMap(currentMap);                                                              // :299
+        frontiers_ = find_map_frontiers_t<Pose>(currentMap, currentPose);                        // :300
+        planner_.setNumFrontiers(frontiers_.size());                                              // :302
+        const float distThreshold = 0.5f;
+        float currDist;
+        if (currentTarget_.x != 0 || currentTarget_.y != 0)                                       // :307-311
+            currDist = std::sqrt(std::pow(currentPose.x - currentTarget_.x, 2) + std::pow(currentPose.y - currentTarget_.y, 2));
+        else
+            currDist = 0;
+        if (currDist <= distThreshold && !frontiers_.empty()) {                                   // :316-321
+            currentPath_ = plan_path_to_frontier_t<Path, Pose, Planner>(frontiers_, currentPose, currentMap, planner_);
+            if (currentPath_.path_length > 1) currentTarget_ = currentPath_.path[currentPath_.path_length - 1];
+        }
+        if (frontiers_.empty()) status = STATUS_COMPLETE;                                         // :335-347
+        else if (currentPath_.path.size() > 1) status = STATUS_IN_PROGRESS;
+        else status = STATUS_FAILED;                                                              // D10
+        switch (status) {                                                                         // :352-368
+        case STATUS_IN_PROGRESS: return STATE_EXPLORING_MAP;
+        case STATUS_COMPLETE: return STATE_RETURNING_HOME;
+        default: return STATE_FAILED_EXPLORATION;
+        }
+    }
+
+    Planner& planner_;
+    Pose currentTarget_;
+    Path currentPath_;
+    std::vector<frontier_t> frontiers_;
+    int8_t status;
+};
 
 }  // namespace botlab_hip
 

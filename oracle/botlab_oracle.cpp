@@ -32,6 +32,10 @@
 //       frontiers.hpp:41-43 is returned.
 //   D9  MotionPlanner::isPathSafe (motion_planner.cpp:77-96) reads distances_(x, y) unchecked; a pose that maps outside the
 //       grid makes the path unsafe.
+//   D10 Exploration::executeExploringMap (exploration.cpp:277-369) leaves status.status unset when frontiers remain but no
+//       path was found (:344-347 is commented out); the switch of :352-368 then ends in its default branch, so that case
+//       is FAILED (status STATUS_FAILED, next state FAILED_EXPLORATION).  Restated over this file's pieces in
+//       tests/oracle_lib.py (OracleExploringMap).
 
 #include <algorithm>
 #include <cmath>

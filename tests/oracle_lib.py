@@ -291,3 +291,41 @@ def load_ref_math():
     L.ref_angle_sum.argtypes = [C.c_double, C.c_double]
     L.ref_interpolate_pose.argtypes = [C.c_int64, C.POINTER(OPose), C.POINTER(OPose), C.POINTER(OPose)]
     return L
+
+
+class OracleExploringMap:
+    """Exploration::executeExploringMap (src/planning/exploration.cpp:277-369) over the oracle's own pieces (set_distances,
+    find_frontiers, plan_path_to_frontier): TEST INFRASTRUCTURE, the checker of botlab_amd.host.ExploringMap.
+    States / statuses are the constants of lcmtypes/exploration_status_t.lcm:3-11; the unset status of :344-347 is taken as
+    FAILED (definition D10: the switch of :352-368 ends in its default branch)."""
+
+    def __init__(self, orc, robot_radius=0.2, prev_goal=None):
+        self.orc = orc
+        self.r = float(robot_radius)
+        self.prev_goal = prev_goal if prev_goal is not None else orc.pose(1e9, 1e9, 0.0)
+        self.target = (np.float32(0.0), np.float32(0.0))
+        self.path = []
+        self.status = None
+
+    def execute(self, cells, mpc, cpm, origin, pose):
+        orc = self.orc
+        dist = orc.set_distances(cells, mpc, cpm, origin)                                   # :299
+        fr = orc.find_frontiers(cells, mpc, cpm, origin, pose)                              # :300
+        if self.target[0] != 0 or self.target[1] != 0:                                      # :307-311
+            dx = float(np.float32(pose.x) - self.target[0]); dy = float(np.float32(pose.y) - self.target[1])
+            cur = float(np.float32(np.sqrt(dx * dx + dy * dy)))
+        else:
+            cur = 0.0
+        if cur <= 0.5 and len(fr) > 0:                                                      # :316-321
+            path, goal, _ = orc.plan_path_to_frontier(fr, pose, dist, mpc, cpm, origin, self.r, self.r, 10.0 * self.r, 1.0,
+                                                      num_frontiers=len(fr), prev_goal=self.prev_goal)
+            self.path = path
+            if len(path) > 1:
+                self.target = (np.float32(path[-1]["x"]), np.float32(path[-1]["y"]))
+        if len(fr) == 0:                                                                    # :335-347
+            self.status = 1
+        elif len(self.path) > 1:
+            self.status = 0
+        else:
+            self.status = 2
+        return {0: 1, 1: 2, 2: 4}[self.status], fr                                          # :352-368

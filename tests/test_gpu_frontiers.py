@@ -243,3 +243,47 @@ def test_cpp_planning_dropin_matches_oracle(oracle, maps, tmp_path):
     for a, b in zip(path, epath):
         assert a[1:] == (b["x"], b["y"], b["theta"])
     assert path[0][0] == 42 and safe == 1 and valid == 1 and failed_len == 1
+
+
+def test_exploring_map_step_matches_oracle(oracle, maps, gpu_ctx):
+    """Exploration::executeExploringMap (exploration.cpp:277-369) as a sequence: the map is uncovered strip by strip while
+    the robot follows the planned paths -- next state, status, frontiers, path and target agree with the oracle at every
+    step; then the fully known map (no frontier: RETURNING_HOME) and a map whose frontiers cannot be reached (D10: FAILED)."""
+    import oracle_lib
+    m = maps["obstacle_slam_10mx10m_5cm"]
+    cpm = helpers.CPM_DEFAULT
+    pl = bl.MotionPlanner(bl.MotionPlannerParams(0.2), ctx=gpu_ctx)
+    ex = bl.ExploringMap(pl)
+    oex = oracle_lib.OracleExploringMap(oracle, 0.2)
+    robot = (-0.75, 0.2, 0.4)
+    states = []
+    for cut in (110, 110, 125, 140, 200):
+        cells = m["cells"].copy()
+        cells[:, cut:] = 0
+        grid = bl.OccupancyGrid.from_cells(cells, m["origin"], m["mpc"], cellsPerMeter=cpm, ctx=gpu_ctx)
+        nxt = ex.execute(grid, bl.make_pose(*robot))
+        enxt, efr = oex.execute(cells, m["mpc"], cpm, m["origin"], oracle.pose(*robot))
+        _same_frontiers(ex.frontiers_.cells(), efr)
+        assert (nxt, ex.status) == (enxt, oex.status), (cut, nxt, ex.status, enxt, oex.status)
+        assert len(ex.currentPath_) == len(oex.path)
+        for a, b in zip(ex.currentPath_, oex.path):
+            assert (a.utime, a.x, a.y, a.theta) == (int(b["utime"]), b["x"], b["y"], b["theta"])
+        assert (np.float32(ex.currentTarget_.x), np.float32(ex.currentTarget_.y)) == oex.target
+        states.append(nxt)
+        if len(ex.currentPath_) > 1:                       # drive most of the way along the path (inside / outside the 0.5 m rule)
+            p = ex.currentPath_[(3 * len(ex.currentPath_)) // 4] if cut != 125 else ex.currentPath_[1]
+            robot = (float(p.x), float(p.y), float(p.theta))
+    assert states[0] == bl.host.STATE_EXPLORING_MAP and states[-1] == bl.host.STATE_RETURNING_HOME
+    # frontiers that no goal can reach: a robot wider than every clearance
+    shape = (120, 120)
+    cells = np.zeros(shape, np.int8)
+    cells[50:70, 50:70] = -30
+    origin, mpc = _frame(shape)
+    pl2 = bl.MotionPlanner(bl.MotionPlannerParams(2.0), ctx=gpu_ctx)
+    ex2 = bl.ExploringMap(pl2)
+    oex2 = oracle_lib.OracleExploringMap(oracle, 2.0)
+    grid = bl.OccupancyGrid.from_cells(cells, origin, mpc, cellsPerMeter=cpm, ctx=gpu_ctx)
+    rp = (float(origin[0]) + 60.5 * 0.05, float(origin[1]) + 60.5 * 0.05, 0.0)
+    nxt = ex2.execute(grid, bl.make_pose(*rp))
+    enxt, _ = oex2.execute(cells, mpc, cpm, origin, oracle.pose(*rp))
+    assert nxt == enxt == bl.host.STATE_FAILED_EXPLORATION and ex2.status == oex2.status == bl.host.STATUS_FAILED
