@@ -89,7 +89,7 @@ __device__ __forceinline__ unsigned int half_of(unsigned int pair, int ci) { ret
 // snap != nullptr: every store to the grid is mirrored into the replanner snapshot, whose bulk copy (the grid as it was when
 // the kernel started) the caller holds in sv[] and map_update_body stores once its first loads are under way.
 #define MAP_EARLY_VEC 4                       // int4 per thread held for the early snapshot copy: grids up to 64 KB
-__device__ __forceinline__ void map_update_body(const map_args& a, int8_t* snap, const int4 (&sv)[MAP_EARLY_VEC]);
+__device__ __forceinline__ void map_update_body(const map_args& a, int8_t* snap, const int4 (&sv)[MAP_EARLY_VEC], const bl_pose_xyt_t* lds_pose);
 
 __global__ __launch_bounds__(MAP_THREADS) void k_map_update(map_args a)
 {
@@ -126,11 +126,13 @@ __global__ __launch_bounds__(MAP_THREADS) void k_map_update(map_args a)
             if (i < n16) sv[u] = ((const int4*)a.cells)[i];
         }
     }
+    __shared__ bl_pose_xyt_t s_fin_pose;
     if (a.fin_on) {
-        mclf_pose(a.fin, s_fin_red);                            // writes the pose a.cur_dev points at (thread 0)
+        mclf_pose(a.fin, s_fin_red, &s_fin_pose);               // writes the pose a.cur_dev points at, and a copy in LDS
         __syncthreads();
     }
-    map_update_body(a, early ? a.snap_cells : nullptr, sv);    // every return inside is uniform over the workgroup
+    // every return inside is uniform over the workgroup
+    map_update_body(a, early ? a.snap_cells : nullptr, sv, a.fin_on ? &s_fin_pose : nullptr);
     if (a.snap_cells) {
         if (!early) {
             __syncthreads();                                    // the grid stores of this workgroup are visible to its own loads
@@ -154,7 +156,7 @@ __global__ __launch_bounds__(MAP_THREADS) void k_map_update(map_args a)
     }
 }
 
-__device__ __forceinline__ void map_update_body(const map_args& a, int8_t* snap, const int4 (&sv)[MAP_EARLY_VEC])
+__device__ __forceinline__ void map_update_body(const map_args& a, int8_t* snap, const int4 (&sv)[MAP_EARLY_VEC], const bl_pose_xyt_t* lds_pose)
 {
     extern __shared__ __align__(16) unsigned int s_cnt[];     // MAP_LDS_COUNTERS/2 dwords, two uint16 counters each
     __shared__ int s_box[4];                                   // xmin, ymin, xmax, ymax over all traced cells
@@ -165,7 +167,7 @@ __device__ __forceinline__ void map_update_body(const map_args& a, int8_t* snap,
     const int tid = threadIdx.x;
     MSTAMP(0);
     if (tid == 0) {
-        bl_pose_xyt_t cur = a.cur_dev ? *a.cur_dev : a.cur_host;
+        bl_pose_xyt_t cur = lds_pose ? *lds_pose : (a.cur_dev ? *a.cur_dev : a.cur_host);   // lds_pose: formed by this very workgroup
         bl_pose_xyt_t prev = a.apply ? *a.prev : cur;          // mapping.cpp:19-21: first call uses pose for both
         s_pose[0] = prev.x; s_pose[1] = prev.y; s_pose[2] = prev.theta;
         s_pose[3] = cur.x; s_pose[4] = cur.y; s_pose[5] = cur.theta;

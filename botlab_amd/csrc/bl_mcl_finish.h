@@ -49,8 +49,8 @@ __device__ __forceinline__ double mclf_wave_sum(double v)
 
 // The five sums in a fixed order (thread-strided over the partials with a stride of 256, wave shuffles, waves in order) and
 // the estimate.  Called by EVERY thread of a workgroup of >= 256 threads (it contains a barrier); threads beyond the first
-// 256 only take part in the barrier.  s_red: shared double[4][5].
-__device__ __forceinline__ void mclf_pose(const mcl_finish_args& f, double (*s_red)[5])
+// 256 only take part in the barrier.  s_red: shared double[4][5].  s_pose_out (shared memory, optional) receives the estimate too.
+__device__ __forceinline__ void mclf_pose(const mcl_finish_args& f, double (*s_red)[5], bl_pose_xyt_t* s_pose_out = nullptr)
 {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (tid < MCLF_POSE_THREADS) {
@@ -71,6 +71,7 @@ __device__ __forceinline__ void mclf_pose(const mcl_finish_args& f, double (*s_r
         p.y = (float)(tot[2] / tot[0]);
         p.theta = (float)atan2(tot[3], tot[4]);
         f.state->pose = p;
+        if (s_pose_out) *s_pose_out = p;                     // shared memory: the caller's workgroup reads it behind its next barrier
         for (int k = 0; k < 5; ++k) f.state->sums_used[k] = tot[k];
     }
 }
