@@ -230,6 +230,35 @@ def test_mcl_parity_at_the_headline_size(oracle, maps, gpu_ctx):
     assert moved == 2
 
 
+@pytest.mark.parametrize("N,rays", [(300, 1700), (5000, 900), (40, 2400)])
+def test_mcl_scans_longer_than_the_lds_ray_table(oracle, maps, gpu_ctx, N, rays):
+    """The ray loop reads (range, theta) from an LDS table of 768 entries; longer scans go through it in chunks with the
+    table refilled behind barriers -- with 4, 64 and 1 lanes per particle here.  Likelihoods and indices stay exact."""
+    m = maps["obstacle_slam_10mx10m_5cm"]
+    truth = np.where(m["cells"] > 0, 127, -127).astype(np.int8)
+    g = _grid_from_map(m, gpu_ctx)
+    poses = synth.square_trajectory((-0.75, 0.2, 0.0), 4, step_len=0.02, turn=0.05, side=0.8)
+    scans = [synth.raycast_scan(truth, m["origin"], 0.05, poses[k - 1], poses[k], 1_000_000 + k * 100_000, rays=rays) for k in range(1, 5)]
+    assert scans[0].num_ranges == rays
+    opf = oracle_lib.OraclePF(oracle, N)
+    opf.init_at_pose(oracle.pose(-0.75, 0.2, 0.0, utime=int(scans[0].times[0])), 9)
+    pf = bl.ParticleFilter(N, ctx=gpu_ctx)
+    pf.setParticles(opf.particles())
+    pf.debugEnable(True)
+    moved = 0
+    for k, sc in enumerate(scans):
+        o = poses[k + 1]
+        res = opf.update(oracle.pose(*o, utime=sc.utime), sc, m["cells"], m["mpc"], helpers.CPM_DEFAULT, m["origin"], 31 + k)
+        pf.updateFilter(bl.make_pose(*o, utime=sc.utime), sc, g, rand_value=31 + k, noise=res["noise"])
+        if not res["moved"]:
+            continue
+        moved += 1
+        idx, like = pf.debugLast()
+        assert np.array_equal(idx, res["idx"]), k
+        assert np.array_equal(like.astype(np.float64) * 0.5, res["raw"]), k
+    assert moved >= 2
+
+
 @pytest.mark.parametrize("case", ["far_particles", "long_ray", "thetas_negative", "thetas_many_turns"])
 def test_mcl_packed_scoring_fallbacks(oracle, maps, gpu_ctx, case):
     """The whole-grid LDS mode scores rays in packed int16 arithmetic only while every cell coordinate provably fits:
