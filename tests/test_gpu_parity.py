@@ -194,11 +194,13 @@ def test_mcl_parity_with_oracle_noise(oracle, maps, gpu_ctx, N):
     assert moved_updates >= 7
 
 
-def test_mcl_parity_at_the_headline_size(oracle, maps, gpu_ctx):
+@pytest.mark.parametrize("N", [100_000, 300_000])
+def test_mcl_parity_at_the_headline_size(oracle, maps, gpu_ctx, N):
     """BASELINE.json's configuration itself -- 100 000 particles, 290 rays, the shipped obstacle_slam map -- against the
     oracle consuming the same noise: resampling indices and likelihoods exact, particle poses bit-equal, weights and pose
-    estimate within 1e-5 relative (the launch shape of this size: 4 lanes per particle, shared prologue, both regions)."""
-    N = 100_000
+    estimate within 1e-5 relative (the launch shape of this size: 4 lanes per particle, shared prologue, both regions);
+    and 300 000 particles, the one-lane-per-particle shape of the large configurations (estimate: 2e-5, the reference's own
+    float accumulation error grows with N)."""
     m = maps["obstacle_slam_10mx10m_5cm"]
     truth = np.where(m["cells"] > 0, 127, -127).astype(np.int8)
     g = _grid_from_map(m, gpu_ctx)
@@ -212,8 +214,12 @@ def test_mcl_parity_at_the_headline_size(oracle, maps, gpu_ctx):
     moved = 0
     for k, sc in enumerate(scans):
         o = poses[k + 1]
-        res = opf.update(oracle.pose(*o, utime=sc.utime), sc, m["cells"], m["mpc"], helpers.CPM_DEFAULT, m["origin"], 1000 + k)
-        pose = pf.updateFilter(bl.make_pose(*o, utime=sc.utime), sc, g, rand_value=1000 + k, noise=res["noise"])
+        # rand() values as glibc draws them (a value near 0 puts every U_m within rounding distance of a partial sum of the
+        # uniform initial weights, where the reference's sequentially rounded sum and the exact integer rule may part:
+        # DESIGN.md section 7, "Resampling rule")
+        rv = (1804289383, 846930886, 1681692777)[k]
+        res = opf.update(oracle.pose(*o, utime=sc.utime), sc, m["cells"], m["mpc"], helpers.CPM_DEFAULT, m["origin"], rv)
+        pose = pf.updateFilter(bl.make_pose(*o, utime=sc.utime), sc, g, rand_value=rv, noise=res["noise"])
         if not res["moved"]:
             continue
         moved += 1
@@ -224,9 +230,10 @@ def test_mcl_parity_at_the_headline_size(oracle, maps, gpu_ctx):
         for f in ("x", "y", "theta", "p_x", "p_y", "p_theta"):
             assert np.array_equal(got[f], exp[f]), (k, f)
         assert np.allclose(got["weight"], exp["weight"], rtol=REL, atol=0)
+        tol = REL if N <= 100_000 else 2 * REL
         for f in ("x", "y", "theta"):
             a, b = getattr(pose, f), getattr(res["pose"], f)
-            assert abs(a - b) <= REL * abs(b) + 2e-6, (k, f, a, b)
+            assert abs(a - b) <= tol * abs(b) + 2e-6, (k, f, a, b)
     assert moved == 2
 
 
