@@ -399,6 +399,42 @@ __device__ __forceinline__ void philox_normals3(uint32_t m, uint32_t step, uint3
         }                                                                               \
     } while (0)
 
+// ---- resampling search, first part: a wave narrows the range its lanes have to bisect -----------------------------------
+// The lanes of a wave resample consecutive particles, so their targets T ascend and every lane's source index lies
+// between the first and the last active lane's.  Those two are found by the whole wave at once -- 64 probes per round and
+// target, the range shrinking 64-fold: three dependent L2 round trips at 100k particles instead of the bisection's 17 --
+// and each lane then bisects only inside [first, last] (about as many entries as the wave has particles).
+// index(T) = first i with T <= prefix[i], or N - 1 (particle_filter.cpp:84-103 with D4's clamp).
+__device__ __forceinline__ double readlane_f64(double v, int lane)
+{
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane), hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+    return __hiloint2double(hi, lo);
+}
+
+__device__ __forceinline__ int kary_pos(int lo, int hi, int step, int k) { return min(lo + (k + 1) * step - 1, hi); }
+
+__device__ __forceinline__ void resample_bracket(const unsigned long long* __restrict__ prefix, int N, double T, bool active,
+                                                 int lane, int* out_lo, int* out_hi)
+{
+    *out_lo = 0; *out_hi = N - 1;
+    const unsigned long long act = __builtin_amdgcn_ballot_w64(active);
+    if (!act) return;
+    const double T0 = readlane_f64(T, __ffsll((long long)act) - 1), T1 = readlane_f64(T, 63 - __clzll((long long)act));
+    int lo0 = 0, hi0 = N - 1, lo1 = 0, hi1 = N - 1;
+    for (int round = 0; round < 8 && (lo0 < hi0 || lo1 < hi1); ++round) {     // 64^8 entries: the cap only bounds the loop
+        const int step0 = (hi0 - lo0 + 64) >> 6, step1 = (hi1 - lo1 + 64) >> 6;
+        const unsigned long long v0 = prefix[kary_pos(lo0, hi0, step0, lane)];
+        const unsigned long long v1 = prefix[kary_pos(lo1, hi1, step1, lane)];
+        const unsigned long long b0 = __builtin_amdgcn_ballot_w64(T0 <= (double)v0);
+        const unsigned long long b1 = __builtin_amdgcn_ballot_w64(T1 <= (double)v1);
+        if (b0 == 0) lo0 = hi0;                                                // nothing reaches T: the clamp
+        else { const int f = __ffsll((long long)b0) - 1; const int nl = f ? kary_pos(lo0, hi0, step0, f - 1) + 1 : lo0; hi0 = kary_pos(lo0, hi0, step0, f); lo0 = nl; }
+        if (b1 == 0) lo1 = hi1;
+        else { const int f = __ffsll((long long)b1) - 1; const int nl = f ? kary_pos(lo1, hi1, step1, f - 1) + 1 : lo1; hi1 = kary_pos(lo1, hi1, step1, f); lo1 = nl; }
+    }
+    if (lo0 == hi0 && lo1 == hi1) { *out_lo = lo0; *out_hi = lo1; }             // (else the full range stands)
+}
+
 // Row-wise staging by `n_sw` whole waves (this one is number `sw` of them, wave-uniform): lane = dword column of the LDS row,
 // `MCL_STAGE_ROWS` rows in flight per wave.  The row index is scalar, so a load costs no address arithmetic beyond one add
 // and the frame rows are a scalar branch (the thread-strided form spent ~20 vector instructions per dword on indices and
@@ -550,11 +586,17 @@ __global__ __launch_bounds__(BLOCK) void k_mcl_main(mcl_args a)
     int i = mp;
     float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
     float px = 0.f, py = 0.f, pth = 0.f, sx0 = 0.f, sy0 = 0.f;
+    // ---- resamplePosteriorDistribution (particle_filter.cpp:84-103): first index with T <= prefix[i], clamped to N-1
+    double rs_T = 0.0;
+    int rs_lo = 0, rs_hi = a.N - 1;
+    if (a.resample && (!shared_pro || wave < pw)) {                  // whole waves: the narrowing is cooperative
+        if (pro_active) rs_T = (a.r + mp * a.M_inv) * a.state->S;
+        resample_bracket(a.prefix, a.N, rs_T, pro_active, lane, &rs_lo, &rs_hi);
+    }
     if (pro_active) {
-        // ---- resamplePosteriorDistribution (particle_filter.cpp:84-103): first index with T <= prefix[i], clamped to N-1
         if (a.resample) {
-            const double T = (a.r + mp * a.M_inv) * a.state->S;
-            int lo = 0, hi = a.N - 1;
+            const double T = rs_T;
+            int lo = rs_lo, hi = rs_hi;
             while (lo < hi) {
                 const int mid = (lo + hi) >> 1;
                 if (T <= (double)a.prefix[mid]) hi = mid; else lo = mid + 1;
