@@ -406,7 +406,7 @@ def main():
             "vs_baseline": None,
             "dtype": "int8 grid / f32 poses with f64 intermediates / int64 weights",
             "data": "synthetic",
-            "config": {"workload": f"full SLAM step on {W}x{H} @5cm grid (shipped obstacle_slam map), {N} particles, "
+            "config": {"workload": f"full SLAM step on {W}x{H} @5cm grid ({'shipped obstacle_slam map' if args.grid == 200 else 'tiled astar/maze world'}), {N} particles, "
                                    f"{R} rays, A* replan {'off' if goal is None else 'on'}",
                        "particles": N, "grid": [W, H], "rays": R, "pipeline_depth": args.depth, "planner_lanes": args.lanes, "planner_batch": args.batch,
                        "parallelism": f"particle-shard x{world}" if world > 1 else "single GPU",
