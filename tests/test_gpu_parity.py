@@ -548,8 +548,8 @@ def test_step_pipeline_with_device_pose_equals_host_pose_path(oracle, maps, gpu_
     assert max(len(r[1]) for r in out[0][0]) > 3
 
 
-@pytest.mark.parametrize("N", [1000, 100_000, 300_000])
-def test_filter_end_riding_in_map_kernel_equals_separate_calls(maps, gpu_ctx, N):
+@pytest.mark.parametrize("N,rays", [(1000, 290), (100_000, 290), (300_000, 290), (3000, 1500)])
+def test_filter_end_riding_in_map_kernel_equals_separate_calls(maps, gpu_ctx, N, rays):
     """bl_mapping_update_finishing_pf: updateFilter's end (weight prefix, unit total, pose estimate) computed inside the map
     kernel's launch gives the same particles, weights, estimate, resampling and map, bit for bit, as bl_pf_update_end
     followed by the map update -- for launch shapes with 64, 4 and 1 lanes per particle (tiles of 8, 128 and 512 particles,
@@ -557,7 +557,9 @@ def test_filter_end_riding_in_map_kernel_equals_separate_calls(maps, gpu_ctx, N)
     m = maps["obstacle_slam_10mx10m_5cm"]
     truth = np.where(m["cells"] > 0, 127, -127).astype(np.int8)
     poses = synth.square_trajectory((-0.75, 0.2, 0.0), 5, step_len=0.02, turn=0.05, side=0.8)
-    scans = [synth.raycast_scan(truth, m["origin"], 0.05, poses[k - 1], poses[k], 1_000_000 + k * 100_000) for k in range(1, 6)]
+    # (1500 rays: more rays than the map kernel has threads -- its per-ray walk form and the copy-loop snapshot -- and a ray
+    # table that the particle filter reads in chunks)
+    scans = [synth.raycast_scan(truth, m["origin"], 0.05, poses[k - 1], poses[k], 1_000_000 + k * 100_000, rays=rays) for k in range(1, 6)]
     res = []
     for riding in (False, True):
         g = _grid_from_map(m, gpu_ctx)
@@ -571,6 +573,8 @@ def test_filter_end_riding_in_map_kernel_equals_separate_calls(maps, gpu_ctx, N)
             odo = bl.make_pose(*poses[k + 1], utime=sc.utime) if k != 2 else bl.make_pose(*poses[k], utime=sc.utime)   # step 2: not moved
             if riding:
                 pf.updateBegin(odo, sc, g, 77 + k)
+                if k + 1 < len(scans):
+                    gpu_ctx.scanPrefetch(scans[k + 1])               # the next scan rides along as well
                 mapper.updateMapFinishingFilter(sc, pf, sc.utime, g)
             else:
                 pf.updateFilter(odo, sc, g, rand_value=77 + k, want_pose=False)
