@@ -40,6 +40,15 @@ int main(int argc, char** argv)
     pose_xyt_t bad; bad.x = 1e6f; bad.y = 0;
     robot_path_t failed = planner.planPath(pose, bad);
     int32_t fl = failed.path_length; std::fwrite(&fl, 4, 1, out);
+    // Exploration::executeExploringMap (exploration.cpp:277-369) twice from the same pose: the second call has a target
+    // (the end of the first path) more than 0.5 m away, so it keeps the path and does not plan again
+    MotionPlanner planner2(params);
+    botlab_hip::ExploringMapT<pose_xyt_t, robot_path_t> ex(planner2);
+    int32_t ex_out[6];
+    ex_out[0] = ex.execute(map, pose); ex_out[1] = ex.status; ex_out[2] = ex.currentPath_.path_length;
+    ex_out[3] = ex.execute(map, pose); ex_out[4] = ex.status; ex_out[5] = ex.currentPath_.path_length;
+    std::fwrite(ex_out, 4, 6, out);
+    std::fwrite(&ex.currentTarget_.x, 4, 1, out); std::fwrite(&ex.currentTarget_.y, 4, 1, out);
     std::fclose(out);
     std::printf("planning_test ok: %d frontiers, path of %d poses\n", nf, path.path_length);
     return 0;

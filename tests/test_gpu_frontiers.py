@@ -232,7 +232,9 @@ def test_cpp_planning_dropin_matches_oracle(oracle, maps, tmp_path):
         got.append(np.frombuffer(raw, np.float32, 2 * n, off).reshape(n, 2)); off += 8 * n
     plen, safe, valid = struct.unpack_from("<iii", raw, off); off += 12
     path = [struct.unpack_from("<qfff", raw, off + 20 * i) for i in range(plen)]; off += 20 * plen
-    failed_len = struct.unpack_from("<i", raw, off)[0]
+    failed_len = struct.unpack_from("<i", raw, off)[0]; off += 4
+    ex_out = struct.unpack_from("<6i", raw, off); off += 24
+    ex_target = struct.unpack_from("<ff", raw, off)
     rp = oracle.pose(np.float32(robot[0]), np.float32(robot[1]), np.float32(robot[2]), utime=42)
     exp_fr = oracle.find_frontiers(cells, m["mpc"], helpers.CPM_DEFAULT, m["origin"], rp)
     _same_frontiers(got, exp_fr)
@@ -243,6 +245,12 @@ def test_cpp_planning_dropin_matches_oracle(oracle, maps, tmp_path):
     for a, b in zip(path, epath):
         assert a[1:] == (b["x"], b["y"], b["theta"])
     assert path[0][0] == 42 and safe == 1 and valid == 1 and failed_len == 1
+    # ExploringMapT: the same two calls on the oracle's composition
+    oex = oracle_lib.OracleExploringMap(oracle, 0.2)
+    n1, _ = oex.execute(cells, m["mpc"], helpers.CPM_DEFAULT, m["origin"], rp); s1, l1 = oex.status, len(oex.path)
+    n2, _ = oex.execute(cells, m["mpc"], helpers.CPM_DEFAULT, m["origin"], rp)
+    assert ex_out == (n1, s1, l1, n2, oex.status, len(oex.path))
+    assert (np.float32(ex_target[0]), np.float32(ex_target[1])) == oex.target
 
 
 def test_exploring_map_step_matches_oracle(oracle, maps, gpu_ctx):
