@@ -218,9 +218,28 @@ public:
         check(bl_mapping_update(h_, &v, &p, map.device()), "bl_mapping_update");
         map.markDeviceWritten();
     }
+    // updateMap with the END of a filter update begun by ParticleFilterT::updateFilterBegin folded in: one launch forms the pose
+    // estimate, updates the map with it and writes the filter's weight prefix (bl_mapping_update_finishing_pf).  The pose is
+    // the filter's poseEstimate() afterwards; poseUtime is the odometry utime of the update (posteriorPose_.utime).
+    template <class Filter>
+    void updateMapFinishingFilter(const Lidar& scan, Filter& filter, int64_t poseUtime, OccupancyGrid& map)
+    {
+        bl_lidar_t v = lidar_view(scan);
+        check(bl_mapping_update_finishing_pf(h_, &v, filter.device(), poseUtime, map.device()), "bl_mapping_update_finishing_pf");
+        map.markDeviceWritten();
+    }
 private:
     bl_mapping* h_;
 };
+
+// The NEXT scan handed over early (a SLAM host has it queued, slam.cpp:96-104): the next map kernel copies it to the device
+// beside its own work (bl_scan_prefetch).
+template <class Lidar>
+inline void prefetch_scan(const Lidar& scan)
+{
+    bl_lidar_t v = lidar_view(scan);
+    check(bl_scan_prefetch(default_ctx(), &v), "bl_scan_prefetch");
+}
 
 // ------------------------------------------------------------------------------------------------ ParticleFilter
 template <class Pose, class Lidar, class Particle, class Particles>
@@ -251,6 +270,23 @@ public:
         check(bl_pf_update(h_, &o, &v, map.device(), rand(), nullptr, &out), "bl_pf_update");
         return pose_out<Pose>(out);
     }
+    // First half of updateFilter: resampling, action and sensor model are launched; the update is ended by
+    // MappingT::updateMapFinishingFilter (one launch with the map update) -- or by updateFilterEnd().  Returns "moved".
+    bool updateFilterBegin(const Pose& odometry, const Lidar& laser, const OccupancyGrid& map)
+    {
+        bl_pose_xyt_t o = pose_in(odometry);
+        bl_lidar_t v = lidar_view(laser);
+        int moved = 0;
+        check(bl_pf_update_begin(h_, &o, &v, map.device(), rand(), nullptr, &moved), "bl_pf_update_begin");
+        return moved != 0;
+    }
+    Pose updateFilterEnd()
+    {
+        bl_pose_xyt_t out;
+        check(bl_pf_update_end(h_, &out), "bl_pf_update_end");
+        return pose_out<Pose>(out);
+    }
+
     Pose updateFilterActionOnly(const Pose& odometry)                           // particle_filter.cpp:54-65
     {
         bl_pose_xyt_t o = pose_in(odometry), out;

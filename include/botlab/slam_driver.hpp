@@ -186,6 +186,11 @@ public:
     void handlePose(const Pose& pose) { groundTruthPoses_.addPose(pose); }
     void handleOptitrack(const Pose& pose) { if (waitingForOptitrack_) { initialPose_ = pose; waitingForOptitrack_ = false; } }
 
+    // One launch for "end of updateFilter + updateMap + fetch of the next queued scan" (the default), or the reference's
+    // call-by-call order (false).  Results are bit-identical; with the fused step SLAM_POSE / SLAM_PARTICLES of an
+    // iteration are published after its map update has been enqueued instead of before.
+    void setFusedStep(bool on) { fusedStep_ = on; }
+
     bool isReadyToUpdate() const                                                                          // :163-188
     {
         bool haveData = false;
@@ -230,6 +235,8 @@ private:
     Mapper mapper_;
     Publisher pub_;
     int mapUpdateCount_;
+    bool fusedStep_ = true;      // updateFilter's end and the next scan's fetch ride in the map kernel (setFusedStep)
+    bool endRides_ = false;
 
     static Pose zeroPose() { Pose p; p.utime = 0; p.x = p.y = p.theta = 0.0f; return p; }
 
@@ -256,6 +263,14 @@ private:
         if (haveMap_ && (mode_ != kModeMappingOnly)) {
             previousPose_ = currentPose_;
             if (mode_ == kModeActionOnly) currentPose_ = filter_.updateFilterActionOnly(currentOdometry_);
+            else if (fusedStep_) {
+                // the filter's end rides in the map update's launch (updateMap below): the pose and the particles are read
+                // -- and published -- there, with the same values
+                filter_.updateFilterBegin(currentOdometry_, currentScan_, map_);
+                if (!incomingScans_.empty()) prefetch_scan(incomingScans_.front());   // the next scan is already queued
+                endRides_ = true;
+                return;
+            }
             else currentPose_ = filter_.updateFilter(currentOdometry_, currentScan_, map_);
             Particles particles = filter_.particles();
             if (pub_.slamPose) pub_.slamPose(currentPose_);                  // SLAM_POSE, then SLAM_PARTICLES (slam.cpp:267-268)
@@ -265,6 +280,14 @@ private:
     void updateMap()                                                                                      // :274-294
     {
         // the reference's guard `mode_ != localization_only || mode_ != action_only` is always true: the mapper runs in every mode
+        if (endRides_) {
+            mapper_.updateMapFinishingFilter(currentScan_, filter_, currentOdometry_.utime, map_);
+            endRides_ = false;
+            currentPose_ = filter_.poseEstimate();
+            Particles particles = filter_.particles();
+            if (pub_.slamPose) pub_.slamPose(currentPose_);                  // SLAM_POSE, then SLAM_PARTICLES (slam.cpp:267-268)
+            if (pub_.slamParticles) pub_.slamParticles(particles);
+        } else
         mapper_.updateMap(currentScan_, currentPose_, map_);
         haveMap_ = true;
         if (mapUpdateCount_ % 5 == 0 && pub_.slamMap) pub_.slamMap(map_.template toLCM<GridMsg>());
