@@ -135,8 +135,8 @@ def main():
                          "4: 2000x2000 maze with a replan per step; 5: 4096x4096, 256k particles); explicit flags still win")
     args = ap.parse_args()
     presets = {3: dict(particles=1_000_000, no_astar=True),
-               4: dict(grid=2000, lanes=3, batch=4, depth=14),
-               5: dict(grid=4096, particles=256_000, lanes=3, batch=4, depth=14)}
+               4: dict(grid=2000, lanes=3, batch=4, depth=18),
+               5: dict(grid=4096, particles=256_000, lanes=3, batch=4, depth=18)}
     for key, val in presets.get(args.config, {}).items():
         if getattr(args, key) == ap.get_default(key):
             setattr(args, key, val)
