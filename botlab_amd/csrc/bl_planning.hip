@@ -1095,10 +1095,12 @@ static int astar_after(bl_ctx* ctx, const bl_dist* d)
 
 static void astar_launch_kernel(bl_ctx* ctx, const astar_args& a, int workgroups)
 {
-    // The 40 KB heap is for searches that share CUs with the particle filter's whole-grid LDS image (grids up to 64 K
-    // cells: 3 x 40 KB + 40 KB fit one CU).  Larger grids are gathered through L2 by the filter, which leaves the LDS
-    // free, and an open list spilling past 4095 entries pays an HBM round trip per heap level: take the 147 KB heap.
-    if (ctx->astar_small_lds && (int64_t)a.W * a.H <= 65536)
+    // The 40 KB footprint is for searches that share CUs with the particle filter (the replanner's units): beside its
+    // whole-grid LDS image or its LDS window (3 x ~50 KB per CU) a 147 KB heap needs a CU of its own, and a dozen searches in
+    // flight then take a dozen CUs out of the filter's single round (4096 x 4096 / 256k particles: k_mcl_main 0.43 -> 0.37 ms
+    // with the small footprint, the searches themselves no slower).  A search that runs alone takes the 147 KB heap: an open
+    // list spilling past the LDS levels pays an HBM round trip per heap level.
+    if (ctx->astar_small_lds)
         hipLaunchKernelGGL((k_astar<AH_LDS_SMALL, AH_COST_LDS_SMALL>), dim3(workgroups), dim3(64), AH_LDS_SMALL_BYTES, ctx->stream, a);
     else
         hipLaunchKernelGGL((k_astar<AH_LDS, AH_COST_LDS>), dim3(workgroups), dim3(64), AH_LDS_BYTES, ctx->stream, a);
