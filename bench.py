@@ -109,6 +109,38 @@ def cpu_baseline(args, m, odo, scans, rands, goal, n_steps):
                        f"{os.cpu_count()} host cores visible")
 
 
+def self_launch(n):
+    """`python bench.py --gpus N` without a launcher: run N ranks under torch.distributed.run on this node (the same command the
+    contract quotes), pass rank 0's single JSON line through, return non-zero if any rank failed or no line came out."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env)
+    line = None
+    for raw in proc.stdout:
+        txt = raw.decode(errors="replace").strip()
+        if txt.startswith("{") and '"metric"' in txt:
+            line = txt
+        elif txt:
+            print(txt, file=sys.stderr)
+    rc = proc.wait()
+    if rc != 0:
+        print(f"bench.py: the {n}-rank launch failed (exit {rc})", file=sys.stderr)
+        return rc
+    if line is None:
+        print("bench.py: the ranks finished without a result line", file=sys.stderr)
+        return 1
+    print(line, flush=True)
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -147,11 +179,18 @@ def main():
     json_fd = os.dup(1)
     os.dup2(2, 1)
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # Started without a launcher: this process becomes the launcher.  It has not imported torch or touched HIP, starts
+        # one rank per GPU as a CHILD process group (never an exec), forwards rank 0's JSON line and exits with the group's status.
+        os.dup2(json_fd, 1)
+        os.close(json_fd)
+        raise SystemExit(self_launch(args.gpus))
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: start it as `python bench.py --gpus N` or under "
+                         f"torch.distributed.run with --nproc-per-node equal to --gpus")
 
     import torch
     import torch.distributed as dist
@@ -165,6 +204,9 @@ def main():
     one_device = bool(os.environ.get("BENCH_TEST_ONE_DEVICE"))
     if one_device:
         local_rank = 0
+    elif local_rank >= torch.cuda.device_count():
+        raise SystemExit(f"bench.py: rank {rank} of {world} has no GPU (this node shows {torch.cuda.device_count()}): --gpus {args.gpus} "
+                         f"cannot run here")
     torch.cuda.set_device(local_rank)
     if world > 1 or os.environ.get("BOTLAB_FORCE_COLLECTIVES"):
         if one_device:

@@ -1,0 +1,36 @@
+"""bench.py --gpus N without a launcher must start N ranks itself, from a parent that never imports torch or touches HIP, and
+must fail loudly (non-zero, no JSON line) when the ranks cannot run -- checked here without a GPU: every rank exits with
+"bench.py needs a GPU"."""
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_gpus_flag_launches_ranks_and_propagates_failure():
+    env = dict(os.environ, BENCH_TEST_ONE_DEVICE="1")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--cpu-steps", "0",
+                          "--particles", "500"], env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    err = out.stderr.decode()
+    import torch
+    if torch.cuda.is_available():
+        assert out.returncode == 0, err[-2000:]
+        return
+    assert out.returncode != 0
+    assert "bench.py needs a GPU" in err                      # the ranks ran (and said why they stopped)
+    assert '"metric"' not in out.stdout.decode()
+
+
+def test_mismatched_world_size_is_refused():
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "2"], env=env, cwd=ROOT,
+                         stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert out.returncode != 0 and b"WORLD_SIZE=1" in out.stderr
+
+
+def test_launcher_parent_does_not_import_torch():
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    head = src[:src.index("def self_launch")]
+    body = src[src.index("def self_launch"):src.index("def main()")]
+    assert "import torch" not in head and "import torch" not in body and "botlab_amd" not in body
