@@ -30,6 +30,15 @@ def test_pose_trace_matches_oracle(oracle):
         if k % 3 == 2:
             for q in (t, t - 1, t + 1, int(rng.integers(times[0] - 10, t + 10)), (times[-2] + t) // 2):
                 ev.append(("Q", q))
+        if k in (9, 30):                 # several samples with one time stamp: the bisection must pick the scan's first pair
+            ev.append(("P", (t, np.float32(rng.normal()), np.float32(rng.normal()), np.float32(rng.uniform(-3.14, 3.14)))))
+            ev.append(("P", (t, np.float32(rng.normal()), np.float32(rng.normal()), np.float32(rng.uniform(-3.14, 3.14)))))
+            for q in (t, t - 1, times[-2], times[-2] + 1):
+                ev.append(("Q", q))
+        if k == 36:                       # a late sample: the stamps no longer ascend, poseAt falls back to the scan
+            ev.append(("P", (t - 150_000, np.float32(0.5), np.float32(0.25), np.float32(-1.0))))
+            for q in (t, t - 1, t - 150_000, t - 150_001, t - 75_000, times[3] + 5):
+                ev.append(("Q", q))
         if k == 20:
             ev.append(("R", (0, np.float32(0.4), np.float32(-1.5), np.float32(2.2))))
         if k in (25, 33):
