@@ -93,8 +93,7 @@ __device__ __forceinline__ void map_update_body(const map_args& a, int8_t* snap,
 
 __global__ __launch_bounds__(MAP_THREADS) void k_map_update(map_args a)
 {
-    __shared__ unsigned long long s_fin[2 * MCLF_WG / 64];
-    __shared__ double s_fin_red[MCLF_POSE_THREADS / 64][5];
+    __shared__ mclf_smem s_fin;
     if (blockIdx.x > 0) {                                       // riders: the filter's prefix groups, then the scan prefetch
         if (a.pre_on && blockIdx.x == gridDim.x - 1) {
             for (int i = threadIdx.x; i < a.pre.kept; i += MAP_THREADS) {
@@ -128,7 +127,8 @@ __global__ __launch_bounds__(MAP_THREADS) void k_map_update(map_args a)
     }
     __shared__ bl_pose_xyt_t s_fin_pose;
     if (a.fin_on) {
-        mclf_pose(a.fin, s_fin_red, &s_fin_pose);               // writes the pose a.cur_dev points at, and a copy in LDS
+        extern __shared__ __align__(16) unsigned int s_dyn_fin[];             // the counter window of map_update_body, not yet in use
+        mclf_pose(a.fin, s_fin, (char*)s_dyn_fin, (size_t)MAP_LDS_COUNTERS * 2, &s_fin_pose);               // writes the pose a.cur_dev points at, and a copy in LDS
         __syncthreads();
     }
     // every return inside is uniform over the workgroup
@@ -535,7 +535,7 @@ static int mapping_update_impl(bl_mapping* m, const bl_lidar_t* scan, const bl_p
     a.pre = bl_scan_prefetch_args{};
     a.pre_on = bl_scan_prefetch_take(ctx, &a.pre);
     static_assert(MCLF_WG == MAP_THREADS, "the riding finish uses the map kernel's workgroup size");
-    hipLaunchKernelGGL(k_map_update, dim3(1 + (fin ? mclf_groups(*fin) : 0) + a.pre_on), dim3(MAP_THREADS), MAP_LDS_COUNTERS * 2, ctx->stream, a);
+    hipLaunchKernelGGL(k_map_update, dim3(1 + (fin ? fin->groups : 0) + a.pre_on), dim3(MAP_THREADS), MAP_LDS_COUNTERS * 2, ctx->stream, a);
     BL_HIP(hipGetLastError());
     rc = bl_timer_end(ctx, BL_K_MAP, e0, e1);
     if (rc) return rc;

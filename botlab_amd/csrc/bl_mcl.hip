@@ -18,6 +18,7 @@
 // exact integer), i clamped to N-1.  The reference accumulates c_i sequentially in double; the two rules can differ
 // only when U_m lies within rounding distance of a partial sum (DESIGN.md "Resampling").
 #include <math.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 #include <new>
@@ -32,7 +33,7 @@
 #define MCL_WIN_MAX 208                       // window side: 208^2 = 42 KB, three workgroups per CU like the whole-grid image of a 200x200 map
 #define MCL_WIN_MARGIN 24                     // cells added to the scan's reach on every side of the window for the spread of the cloud
 #define SCAN_THREADS 256
-#define SCAN_ITEMS 8
+#define SCAN_ITEMS 2                          // tiles of 512 particles: a whole number of them makes a finish group (bl_mcl_finish.h)
 #define SCAN_TILE (SCAN_THREADS * SCAN_ITEMS)
 
 // pf_state: bl_mcl_finish.h
@@ -43,7 +44,11 @@ struct bl_pf {
     float4* rec[2];
     bool rec_external;
     int cur;
-    double* tile_pose;        // [scan_blocks][4]: per-tile sums of units*(x, y, sin, cos) (non-fused finish)
+    double* tile_partials;    // [scan_blocks][5]: per-tile sums of units, units*(x, y, sin, cos) from the record (record-based finish)
+    ss_rec* fin_recs;         // [2][fin_subs_cap]: sub-tile records of the pose sums (bl_mcl_finish.h)
+    int fin_subs_cap;
+    mclf_tab_elem* fin_tabs;  // [2][MCLF_TSLOTS][MCLF_SUB]: tables of the risky sub-tiles
+    unsigned long long* fin_sync;     // the finish launches' sync word (zero between launches)
     unsigned long long* prefix;
     float4* parent;
     pf_state* state;
@@ -729,20 +734,21 @@ __global__ __launch_bounds__(BLOCK) void k_mcl_main(mcl_args a)
 }
 
 // ---------------------------------------------------------------- weight-unit prefix scan over all N from the record (2 launches)
-// Tile sums of the weight units and, when tile_pose != nullptr, of the estimatePosteriorPose terms
-// (particle_filter.cpp:144-160) units*(x, y, sinf(theta), cosf(theta)) in double.  The order of every addition is a
-// function of N alone (items in a thread, shuffle tree in a wave, waves in order), so the estimate does not depend on how
-// the particles were sharded: after the all-gather every rank derives it from the record itself, no all-reduce needed.
+// Tile sums of the weight units and, when tile_partials != nullptr, the block sums k_mcl_main would have left for tiles of
+// SCAN_TILE particles: units, units*(x, y, sinf(theta), cosf(theta)) in double (the finish takes the unit sums as exact integers,
+// theta from the sin / cos sums and the binade predictions of the x / y accumulators from the others).  The order of every
+// addition is a function of N alone (items in a thread, shuffle tree in a wave, waves in order), so the estimate does not
+// depend on how the particles were sharded: after the all-gather every rank derives it from the record itself.
 __global__ __launch_bounds__(SCAN_THREADS) void k_scan_tile_sums(const float4* __restrict__ rec, int N,
                                                                  unsigned long long* __restrict__ tile_sums,
-                                                                 double* __restrict__ tile_pose)
+                                                                 double* __restrict__ tile_partials)
 {
     __shared__ unsigned long long s[SCAN_THREADS / 64];
     __shared__ double s_pose[SCAN_THREADS / 64][4];
     const int base = blockIdx.x * SCAN_TILE + threadIdx.x * SCAN_ITEMS;
     unsigned long long v = 0;
     double e[4] = {0, 0, 0, 0};
-    if (tile_pose) {
+    if (tile_partials) {
         for (int k = 0; k < SCAN_ITEMS; ++k)
             if (base + k < N) {
                 const float4 r = rec[base + k];
@@ -768,28 +774,24 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan_tile_sums(const float4* _
         unsigned long long t = 0;
         for (int w = 0; w < SCAN_THREADS / 64; ++w) t += s[w];
         tile_sums[blockIdx.x] = t;
+        if (tile_partials) tile_partials[(size_t)blockIdx.x * 5] = (double)t;
     }
-    if (tile_pose && threadIdx.x < 4) {
+    if (tile_partials && threadIdx.x < 4) {
         double t = 0;
         for (int w = 0; w < SCAN_THREADS / 64; ++w) t += s_pose[w][threadIdx.x];
-        tile_pose[(size_t)blockIdx.x * 4 + threadIdx.x] = t;
+        tile_partials[(size_t)blockIdx.x * 5 + 1 + threadIdx.x] = t;
     }
 }
 
-// Second (and last) launch of the record-based finish: workgroup b sums the unit totals of the tiles before it (exact
-// integers), scans its tile and writes the prefix; workgroup 0 also reduces the per-tile pose sums in a fixed order
-// (thread-strided, wave shuffles, waves in order) and forms the pose estimate (estimatePosteriorPose,
-// particle_filter.cpp:144-160).  The order of every floating-point addition depends on N alone.
-__global__ __launch_bounds__(SCAN_THREADS) void k_scan_finish_prefix(const float4* __restrict__ rec, int N,
-                                                                     const unsigned long long* __restrict__ tile_sums, int ntiles,
-                                                                     const double* __restrict__ tile_pose,
-                                                                     unsigned long long* __restrict__ prefix, pf_state* state,
-                                                                     int64_t utime, int write_pose)
+// Prefix-only scan (particle uploads, initialisation, action-only updates: no estimate is formed): workgroup b sums the unit
+// totals of the tiles before it (exact integers), scans its tile and writes the prefix; workgroup 0 records the unit total.
+__global__ __launch_bounds__(SCAN_THREADS) void k_scan_write_prefix(const float4* __restrict__ rec, int N,
+                                                                    const unsigned long long* __restrict__ tile_sums, int ntiles,
+                                                                    unsigned long long* __restrict__ prefix, pf_state* state)
 {
     __shared__ unsigned long long s_wave[SCAN_THREADS / 64];
     __shared__ unsigned long long s_off[SCAN_THREADS / 64];
     __shared__ unsigned long long s_tot[SCAN_THREADS / 64];
-    __shared__ double s_red[SCAN_THREADS / 64][4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     unsigned long long before = 0, all = 0;
     for (int j = threadIdx.x; j < ntiles; j += SCAN_THREADS) {
@@ -812,105 +814,23 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan_finish_prefix(const float
         if (lane >= off) incl += t;
     }
     if (lane == 63) s_wave[wave] = incl;
-    if (blockIdx.x == 0 && write_pose) {
-        double v[4] = {0, 0, 0, 0};
-        for (int b = threadIdx.x; b < ntiles; b += SCAN_THREADS)
-            for (int k = 0; k < 4; ++k) v[k] += tile_pose[(size_t)b * 4 + k];
-        for (int k = 0; k < 4; ++k) v[k] = wave_sum(v[k]);
-        if (lane == 0) for (int k = 0; k < 4; ++k) s_red[wave][k] = v[k];
-    }
     __syncthreads();
     unsigned long long off0 = incl - run, total = 0;
     for (int w = 0; w < SCAN_THREADS / 64; ++w) { off0 += s_off[w]; total += s_tot[w]; if (w < wave) off0 += s_wave[w]; }
     for (int k = 0; k < SCAN_ITEMS; ++k)
         if (base + k < N) prefix[base + k] = off0 + loc[k];
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        state->S = (double)total;
-        if (write_pose) {
-            double tot[4] = {0, 0, 0, 0};
-            for (int w = 0; w < SCAN_THREADS / 64; ++w) for (int k = 0; k < 4; ++k) tot[k] += s_red[w][k];
-            const double su = (double)total;             // exact: the total of the integer units is below 2^53
-            bl_pose_xyt_t p;
-            p.utime = utime;
-            p.x = (float)(tot[0] / su);
-            p.y = (float)(tot[1] / su);
-            p.theta = (float)atan2(tot[2], tot[3]);
-            state->pose = p;
-            state->sums_used[0] = su;
-            for (int k = 0; k < 4; ++k) state->sums_used[k + 1] = tot[k];
-        }
-    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) state->S = (double)total;
 }
 
-// Single-shard fast path (the whole particle set on this device): k_mcl_main's per-workgroup partials already hold the
-// weight-unit sum of each workgroup's particles, i.e. the tile sums of a prefix scan whose tile is "particles per
-// k_mcl_main workgroup".
-// ONE launch: workgroup b (256 threads, tile b) forms its own tile offset as the exact integer sum of the unit sums of
-// the tiles before it (<= a few thousand L2-resident values), scans its tile and writes the prefix; workgroup 0 also
-// reduces the five partial sums in a fixed order and forms the pose estimate (estimatePosteriorPose,
-// particle_filter.cpp:144-160).  No workgroup waits on another, so nothing separates this from k_mcl_main but one
-// kernel boundary (a dependent single-workgroup launch costs ~6 us here).
-// Tiles follow k_mcl_main's two regions: workgroups [0, main_blocks) own `tile` particles each from 0 on, the rest own
-// `tail_tile` particles each from main_particles on.
-__global__ __launch_bounds__(SCAN_THREADS) void k_mcl_finish_prefix(const double* __restrict__ partials, int nblocks,
-                                                                    const float4* __restrict__ rec, int N, int tile,
-                                                                    int main_blocks, int main_particles, int tail_tile,
-                                                                    unsigned long long* __restrict__ prefix, pf_state* state,
-                                                                    int64_t utime)
+// Stand-alone launch of the end of an update (bl_mcl_finish.h): workgroup 0 is the finisher (estimatePosteriorPose,
+// particle_filter.cpp:144-160), workgroups 1.. are the groups (weight prefix + sub-tile records).  k_map_update carries the
+// same functions when the end rides in the map update's launch.
+__global__ __launch_bounds__(MCLF_WG) void k_mcl_finish(mcl_finish_args f)
 {
-    __shared__ unsigned long long s_wave[SCAN_THREADS / 64];
-    __shared__ unsigned long long s_off[SCAN_THREADS / 64];
-    __shared__ double s_red[SCAN_THREADS / 64][5];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    // ---- tile offset: sum of partials[j][0] (exact integers below 2^53) over the tiles j < blockIdx.x
-    unsigned long long before = 0;
-    for (int j = threadIdx.x; j < (int)blockIdx.x; j += SCAN_THREADS) before += (unsigned long long)partials[(size_t)j * 5];
-    for (int off = 32; off > 0; off >>= 1) before += __shfl_xor(before, off, 64);
-    if (lane == 0) s_off[wave] = before;
-    // ---- local inclusive scan of the tile
-    const bool in_tail = (int)blockIdx.x >= main_blocks;
-    const int my_tile = in_tail ? tail_tile : tile;
-    const int ipt = (my_tile + SCAN_THREADS - 1) / SCAN_THREADS;              // items per thread (<= 8)
-    const int tile_lo = in_tail ? main_particles + ((int)blockIdx.x - main_blocks) * tail_tile : (int)blockIdx.x * tile;
-    const int tile_hi = in_tail ? min(N, tile_lo + tail_tile) : min(main_particles, tile_lo + tile);
-    const int base = tile_lo + threadIdx.x * ipt;
-    unsigned long long loc[SCAN_ITEMS];
-    unsigned long long run = 0;
-    for (int k = 0; k < SCAN_ITEMS; ++k) {
-        if (k < ipt && base + k < tile_hi) run += __float_as_uint(rec[base + k].w);
-        loc[k] = run;
-    }
-    unsigned long long incl = run;
-    for (int off = 1; off < 64; off <<= 1) {
-        unsigned long long t = __shfl_up(incl, off, 64);
-        if (lane >= off) incl += t;
-    }
-    if (lane == 63) s_wave[wave] = incl;
-    // ---- workgroup 0: the five sums, fixed order (thread-strided, wave shuffles, waves in order)
-    if (blockIdx.x == 0) {
-        double v[5] = {0, 0, 0, 0, 0};
-        for (int b = threadIdx.x; b < nblocks; b += SCAN_THREADS)
-            for (int k = 0; k < 5; ++k) v[k] += partials[(size_t)b * 5 + k];
-        for (int k = 0; k < 5; ++k) v[k] = wave_sum(v[k]);
-        if (lane == 0) for (int k = 0; k < 5; ++k) s_red[wave][k] = v[k];
-    }
-    __syncthreads();
-    unsigned long long off0 = incl - run;
-    for (int w = 0; w < SCAN_THREADS / 64; ++w) { off0 += s_off[w]; if (w < wave) off0 += s_wave[w]; }
-    for (int k = 0; k < SCAN_ITEMS; ++k)
-        if (k < ipt && base + k < tile_hi) prefix[base + k] = off0 + loc[k];
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        double tot[5] = {0, 0, 0, 0, 0};
-        for (int w = 0; w < SCAN_THREADS / 64; ++w) for (int k = 0; k < 5; ++k) tot[k] += s_red[w][k];
-        state->S = tot[0];                                   // the unit total: an exact integer below 2^53, any order gives it
-        bl_pose_xyt_t p;
-        p.utime = utime;
-        p.x = (float)(tot[1] / tot[0]);
-        p.y = (float)(tot[2] / tot[0]);
-        p.theta = (float)atan2(tot[3], tot[4]);
-        state->pose = p;
-        for (int k = 0; k < 5; ++k) state->sums_used[k] = tot[k];
-    }
+    __shared__ mclf_smem sm;
+    extern __shared__ __align__(16) char s_fin_scratch[];                  // MCLF_LDS_BYTES (the groups do not touch it)
+    if (blockIdx.x == 0) mclf_pose(f, sm, s_fin_scratch, (size_t)MCLF_LDS_BYTES);
+    else mclf_prefix_group(f, (int)blockIdx.x - 1, sm);
 }
 
 // ---------------------------------------------------------------- init / export / small state kernels
@@ -999,11 +919,17 @@ static int pf_alloc(bl_pf* pf)
         BL_HIP(hipFuncSetAttribute((const void*)k_mcl_main<0, 256, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
         BL_HIP(hipFuncSetAttribute((const void*)k_mcl_main<0, 512, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
         BL_HIP(hipFuncSetAttribute((const void*)k_mcl_main<0, 1024, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+        BL_HIP(hipFuncSetAttribute((const void*)k_mcl_finish, hipFuncAttributeMaxDynamicSharedMemorySize, MCLF_LDS_BYTES));
         attr_set = true;
     }
     pf->scan_blocks = (int)((N + SCAN_TILE - 1) / SCAN_TILE);
     BL_HIP(hipMalloc((void**)&pf->block_sums, (size_t)pf->scan_blocks * sizeof(unsigned long long)));
-    BL_HIP(hipMalloc((void**)&pf->tile_pose, (size_t)pf->scan_blocks * 4 * sizeof(double)));
+    BL_HIP(hipMalloc((void**)&pf->tile_partials, (size_t)pf->scan_blocks * 5 * sizeof(double)));
+    pf->fin_subs_cap = (int)(N / MCLF_SUB) + 4 * (MCLF_WG / 64);      // main region + tail region, each rounded up to whole groups
+    BL_HIP(hipMalloc((void**)&pf->fin_recs, (size_t)2 * pf->fin_subs_cap * sizeof(ss_rec)));
+    BL_HIP(hipMalloc((void**)&pf->fin_tabs, (size_t)2 * MCLF_TSLOTS * MCLF_SUB * sizeof(mclf_tab_elem)));
+    BL_HIP(hipMalloc((void**)&pf->fin_sync, sizeof(unsigned long long)));
+    BL_HIP(hipMemsetAsync(pf->fin_sync, 0, sizeof(unsigned long long), pf->ctx->stream));
     BL_HIP(hipMalloc((void**)&pf->dbg_idx, n * sizeof(int32_t)));
     BL_HIP(hipMalloc((void**)&pf->dbg_like, n * sizeof(int32_t)));
     BL_HIP(hipMemsetAsync(pf->state, 0, sizeof(pf_state), pf->ctx->stream));
@@ -1042,7 +968,7 @@ extern "C" void bl_pf_destroy(bl_pf* pf)
     if (!pf) return;
     (void)hipStreamSynchronize(pf->ctx->stream);
     if (!pf->rec_external) { if (pf->rec[0]) (void)hipFree(pf->rec[0]); if (pf->rec[1]) (void)hipFree(pf->rec[1]); }
-    void* ptrs[] = {pf->tile_pose, pf->prefix, pf->parent, pf->state, pf->partials, pf->block_sums, pf->dbg_idx, pf->dbg_like,
+    void* ptrs[] = {pf->tile_partials, pf->fin_recs, pf->fin_tabs, pf->fin_sync, pf->prefix, pf->parent, pf->state, pf->partials, pf->block_sums, pf->dbg_idx, pf->dbg_like,
                     pf->d_noise, pf->d_export, pf->framed};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     delete pf;
@@ -1059,7 +985,28 @@ extern "C" int bl_pf_set_exchange_buffers(bl_pf* pf, void* d_rec0, void* d_rec1)
 extern "C" void* bl_pf_exchange_rec_ptr(bl_pf* pf) { return pf && pf->prefix ? (void*)pf->rec[pf->pending_end ? pf->cur ^ 1 : pf->cur] : nullptr; }
 extern "C" const void* bl_pf_pose_device_ptr(bl_pf* pf) { return pf && pf->state ? (const void*)&pf->state->pose : nullptr; }
 
-// prefix scan of rec[which] + (optionally) the pose estimate; timed as BL_K_MCL_SCAN
+// what a finish launch needs beyond the block sums: the group shape, record and table space, the sync word.  Returns the group
+// count or -1 when the blocks do not tile a group.
+static int pf_finish_fill(bl_pf* pf, mcl_finish_args* f)
+{
+    if (f->tile <= 0 || f->tail_tile <= 0) return -1;
+    f->gthreads = mclf_gthreads(pf->N);
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        const int chunk = mclf_chunk(f->gthreads);
+        if (f->tile <= chunk && (chunk % f->tile) == 0 && f->tail_tile <= chunk && (chunk % f->tail_tile) == 0) break;
+        if (attempt == 1 || f->gthreads == MCLF_GT_LARGE) return -1;
+        f->gthreads = MCLF_GT_LARGE;
+    }
+    const int groups = mclf_groups(*f);
+    if ((int64_t)groups * (f->gthreads >> 6) > pf->fin_subs_cap) return -1;
+    f->groups = groups;
+    f->recs = pf->fin_recs;
+    f->tabs = pf->fin_tabs;
+    f->sync = pf->fin_sync;
+    return groups;
+}
+
+// record-based end of an update, or a plain prefix scan of rec[which] (write_pose == 0); timed as BL_K_MCL_SCAN
 static int pf_scan(bl_pf* pf, int which, int write_pose, int64_t utime)
 {
     bl_ctx* ctx = pf->ctx;
@@ -1067,9 +1014,21 @@ static int pf_scan(bl_pf* pf, int which, int write_pose, int64_t utime)
     int rc = bl_timer_begin(ctx, BL_K_MCL_SCAN, &e0, &e1);
     if (rc) return rc;
     hipLaunchKernelGGL(k_scan_tile_sums, dim3(pf->scan_blocks), dim3(SCAN_THREADS), 0, ctx->stream, pf->rec[which], pf->N,
-                       pf->block_sums, write_pose ? pf->tile_pose : (double*)nullptr);
-    hipLaunchKernelGGL(k_scan_finish_prefix, dim3(pf->scan_blocks), dim3(SCAN_THREADS), 0, ctx->stream, pf->rec[which], pf->N,
-                       pf->block_sums, pf->scan_blocks, pf->tile_pose, pf->prefix, pf->state, utime, write_pose);
+                       pf->block_sums, write_pose ? pf->tile_partials : (double*)nullptr);
+    if (write_pose) {
+        // the tiles of k_scan_tile_sums stand where k_mcl_main's workgroups stand in the fused form
+        mcl_finish_args f;
+        f.partials = pf->tile_partials; f.nblocks = pf->scan_blocks;
+        f.rec = pf->rec[which]; f.N = pf->N;
+        f.tile = SCAN_TILE; f.main_blocks = pf->scan_blocks; f.main_particles = pf->N; f.tail_tile = 1;
+        f.prefix = pf->prefix; f.state = pf->state; f.utime = utime;
+        const int groups = pf_finish_fill(pf, &f);
+        if (groups < 0) { bl_set_error("internal: finish launch shape"); return BL_ERR_STATE; }
+        hipLaunchKernelGGL(k_mcl_finish, dim3(1 + groups), dim3(MCLF_WG), MCLF_LDS_BYTES, ctx->stream, f);
+    } else {
+        hipLaunchKernelGGL(k_scan_write_prefix, dim3(pf->scan_blocks), dim3(SCAN_THREADS), 0, ctx->stream, pf->rec[which], pf->N,
+                           pf->block_sums, pf->scan_blocks, pf->prefix, pf->state);
+    }
     BL_HIP(hipGetLastError());
     return bl_timer_end(ctx, BL_K_MCL_SCAN, e0, e1);
 }
@@ -1343,20 +1302,32 @@ static int pf_launch_main(bl_pf* pf, const bl_grid* map, int R, int rand_value, 
     pf->last_blocks = blocks;
     pf->last_tile = gpb;                                  // particles per region-1 workgroup of k_mcl_main
     pf->last_main_blocks = a.main_blocks; pf->last_main_particles = a.main_particles; pf->last_tail_tile = tail_tile;
-    pf->fused_finish = (pf->n_local == pf->N) && pf->last_tile >= 1 && pf->last_tile <= SCAN_TILE && !pf->no_fused_finish;
+    pf->fused_finish = (pf->n_local == pf->N) && pf->last_tile >= 1 && pf->last_tile <= mclf_chunk(MCLF_GT_LARGE) && !pf->no_fused_finish;
     return BL_OK;
 }
 
-// single-shard finish of an update: reduce + tile scan + estimate, then the prefix (timed as BL_K_MCL_SCAN)
+// the finish of the update k_mcl_main has begun, from that launch's per-workgroup sums
+static int pf_fused_args(bl_pf* pf, int which, int64_t utime, mcl_finish_args* f)
+{
+    f->partials = pf->partials; f->nblocks = pf->last_blocks;
+    f->rec = pf->rec[which]; f->N = pf->N;
+    f->tile = pf->last_tile; f->main_blocks = pf->last_main_blocks; f->main_particles = pf->last_main_particles;
+    f->tail_tile = pf->last_tail_tile > 0 ? pf->last_tail_tile : 1;
+    f->prefix = pf->prefix; f->state = pf->state; f->utime = utime;
+    return pf_finish_fill(pf, f);
+}
+
+// single-shard finish of an update as its own launch (timed as BL_K_MCL_SCAN)
 static int pf_finish_fused(bl_pf* pf, int which, int64_t utime)
 {
     bl_ctx* ctx = pf->ctx;
+    mcl_finish_args f;
+    const int groups = pf_fused_args(pf, which, utime, &f);
+    if (groups < 0) return pf_scan(pf, which, 1, utime);
     hipEvent_t e0, e1;
     int rc = bl_timer_begin(ctx, BL_K_MCL_SCAN, &e0, &e1);
     if (rc) return rc;
-    hipLaunchKernelGGL(k_mcl_finish_prefix, dim3(pf->last_blocks), dim3(SCAN_THREADS), 0, ctx->stream, pf->partials, pf->last_blocks,
-                       pf->rec[which], pf->N, pf->last_tile, pf->last_main_blocks, pf->last_main_particles, pf->last_tail_tile,
-                       pf->prefix, pf->state, utime);
+    hipLaunchKernelGGL(k_mcl_finish, dim3(1 + groups), dim3(MCLF_WG), MCLF_LDS_BYTES, ctx->stream, f);
     BL_HIP(hipGetLastError());
     return bl_timer_end(ctx, BL_K_MCL_SCAN, e0, e1);
 }
@@ -1411,13 +1382,7 @@ int bl_pf_take_finish(bl_pf* pf, mcl_finish_args* out)
 {
     if (!pf || !pf->pending_end) return 0;
     if (!pf->fused_finish) return -1;
-    const int which = pf->cur ^ 1;
-    out->partials = pf->partials; out->nblocks = pf->last_blocks;
-    out->rec = pf->rec[which]; out->N = pf->N;
-    out->tile = pf->last_tile; out->main_blocks = pf->last_main_blocks; out->main_particles = pf->last_main_particles;
-    out->tail_tile = pf->last_tail_tile > 0 ? pf->last_tail_tile : 1;
-    out->prefix = pf->prefix; out->state = pf->state; out->utime = pf->pending_utime;
-    if (out->tile <= 0 || out->tile > MCLF_CHUNK || (MCLF_CHUNK % out->tile) != 0 || (MCLF_CHUNK % out->tail_tile) != 0) return -1;
+    if (pf_fused_args(pf, pf->cur ^ 1, pf->pending_utime, out) < 0) return -1;
     pf->cur ^= 1;
     pf->parent_utime = pf->pose_utime;       // parent_pose = sample.pose (action_model.cpp:92)
     pf->pose_utime = 0;                      // pose.utime = utime_ (D3)
@@ -1467,6 +1432,42 @@ extern "C" int bl_pf_pose_estimate(bl_pf* pf, bl_pose_xyt_t* out_pose)
     BL_CHECK_ARG(pf != nullptr && out_pose != nullptr && pf->state != nullptr);
     BL_HIP(hipMemcpyAsync(out_pose, &pf->state->pose, sizeof(bl_pose_xyt_t), hipMemcpyDeviceToHost, pf->ctx->stream));
     BL_HIP(hipStreamSynchronize(pf->ctx->stream));
+    return BL_OK;
+}
+
+// estimatePosteriorPose(posterior_) on demand (particle_filter.cpp:144-160): the record-based finish on the current record
+extern "C" int bl_pf_estimate_posterior_pose(bl_pf* pf, bl_pose_xyt_t* out_pose)
+{
+    BL_CHECK_ARG(pf != nullptr);
+    if (!pf->initialized || pf->pending_end) { bl_set_error("filter not initialised or update pending"); return BL_ERR_STATE; }
+    BL_HIP(hipSetDevice(pf->ctx->device));
+    int rc = pf_scan(pf, pf->cur, 1, pf->pending_utime);
+    if (rc) return rc;
+    if (out_pose) return bl_pf_pose_estimate(pf, out_pose);
+    return BL_OK;
+}
+
+extern "C" int bl_pf_debug_estimate_stats(bl_pf* pf, uint32_t* out4)   /* eight values */
+{
+    BL_CHECK_ARG(pf != nullptr && out4 != nullptr && pf->state != nullptr);
+    BL_HIP(hipMemcpyAsync(out4, pf->state->chain_stats, 8 * sizeof(uint32_t), hipMemcpyDeviceToHost, pf->ctx->stream));
+    BL_HIP(hipStreamSynchronize(pf->ctx->stream));
+    if (getenv("BOTLAB_FINISH_STAMPS")) {
+        unsigned long long st[6];
+        BL_HIP(hipMemcpy(st, pf->state->stamps, sizeof(st), hipMemcpyDeviceToHost));
+        unsigned long long gs[8];
+        BL_HIP(hipMemcpy(gs, pf->state->gstamps, sizeof(gs), hipMemcpyDeviceToHost));
+        fprintf(stderr, "group timeline (us, from the finisher's entry): entry %+.2f", ((long long)gs[0] - (long long)st[0]) * 0.01);
+        for (int k = 1; k < 8; ++k) fprintf(stderr, " | +%.2f", (gs[k] - gs[k - 1]) * 0.01);
+        fprintf(stderr, "\n");
+        unsigned long long cs[16];
+        BL_HIP(hipMemcpy(cs, pf->state->cstamps, sizeof(cs), hipMemcpyDeviceToHost));
+        fprintf(stderr, "x chain entries (us):");
+        for (int k = 1; k < 16; ++k) fprintf(stderr, " %.2f", cs[k] > cs[k - 1] ? (cs[k] - cs[k - 1]) * 0.01 : -1.0);
+        fprintf(stderr, "\n");
+        fprintf(stderr, "finisher timeline (us): groups done +%.2f, staged a +%.2f, staged b +%.2f, chains +%.2f, exit +%.2f\n", (st[1] - st[0]) * 0.01,
+                (st[2] - st[1]) * 0.01, (st[3] - st[2]) * 0.01, (st[4] - st[3]) * 0.01, (st[5] - st[4]) * 0.01);
+    }
     return BL_OK;
 }
 

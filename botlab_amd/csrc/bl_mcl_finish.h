@@ -1,21 +1,47 @@
 // bl_mcl_finish.h -- the end of a particle-filter update (weight-unit prefix + estimatePosteriorPose, particle_filter.cpp:116-160)
 // as device functions, so that it can ride in another kernel's launch: k_map_update runs it beside Mapping::updateMap
-// (bl_mapping_update_finishing_pf), which needs the pose estimate and nothing else of it.  k_mcl_finish_prefix (bl_mcl.hip) is
-// the stand-alone launch of the same arithmetic; both give bit-identical prefix, unit total and pose.
+// (bl_mapping_update_finishing_pf), which needs the pose estimate and nothing else of it.  k_mcl_finish (bl_mcl.hip) is the
+// stand-alone launch of the same functions.
+//
+// One launch = the FINISHER (workgroup 0) + `groups` GROUP workgroups (the first `gthreads` threads of each work):
+//   group     exact integer prefix of its weight units (written out), and for each of its waves' 128 particles (a "sub-tile")
+//             one RECORD per axis of the serially rounded float sums pose.x / pose.y (bl_serial_sum.h), formed for the binade
+//             a double-precision running sum predicts.  A sub-tile in which that sum comes near a binade's end is RISKY: the
+//             finisher will have to step through it, and the group leaves a TABLE for that (the terms, and their integer
+//             prefix sums in the predicted binade and in the next one).  Then the group counts itself done.
+//   finisher  waits for the groups; all its waves bring records and tables into LDS and join the records BETWEEN risky
+//             sub-tiles into one composite per gap; then one wave per axis runs the chain with the TRUE accumulator: gap
+//             (one check, one add), risky sub-tile (first step that leaves the binade from the table, that step in real
+//             arithmetic, the rest of the sub-tile from the next binade's column), gap, ...  Whatever does not go by the book
+//             (a gap that does not fit, a tie, a sign change, a second crossing) is walked / replayed generically from the
+//             particle record: predictions and tables cost time when wrong, never correctness.
+//             x, y are bit for bit the reference's float accumulators; theta comes from double sums.
+//
+// Visibility inside the launch: the MI355X's eight XCDs have separate L2s, and an agent-scope release fence (__threadfence)
+// writes a whole L2 back -- 12 us measured with the prefix stores in it.  So everything a group hands to the finisher goes by
+// agent-scope relaxed atomic stores / loads (write-through, read-through: sc1), ordered by "wait for my stores, barrier, one
+// atomic add"; nothing else of the groups' output is read inside the launch.
 #ifndef BL_MCL_FINISH_H
 #define BL_MCL_FINISH_H
 
 #include "bl_internal.h"
+#include "bl_serial_sum.h"
 
 struct pf_state {
     double S;                 // total weight units of rec[cur]
     bl_pose_xyt_t pose;       // posteriorPose_
-    double sums_used[5];      // the sums the estimate was formed from (diagnostic)
+    double sums_used[5];      // units, -, -, units*sin, units*cos the estimate was formed from (diagnostic)
+    unsigned int chain_stats[8];   // x then y: generic replays, their phases, table replays, gaps walked the slow way (diagnostic)
+    unsigned long long cstamps[16]; // the x chain, entry by entry (diagnostic, -DMCLF_STAMPS)
+    unsigned long long gstamps[8]; // one group's timeline (diagnostic, -DMCLF_STAMPS)
+    unsigned long long stamps[6];  // finisher timeline in 10 ns ticks (diagnostic, -DMCLF_STAMPS)
 };
 
-// partials[b][5]: per k_mcl_main workgroup b the sums of units, units*x, units*y, units*sin(theta), units*cos(theta).
-// Workgroups [0, main_blocks) of that launch own `tile` particles each from 0 on (clipped to main_particles), the rest own
-// `tail_tile` particles each from main_particles on.
+struct mclf_tab_elem { double t; int se, se1; };       // term; (inclusive prefix << 1 | bad) in the predicted binade and in the next
+
+// partials[b][5]: per block b the sums of units, units*x, units*y, units*sin(theta), units*cos(theta) of its particles (units
+// exact; the others feed theta and the binade predictions only).  Blocks [0, main_blocks) own `tile` particles each from 0 on
+// (clipped to main_particles), the rest own `tail_tile` particles each from main_particles on.
 struct mcl_finish_args {
     const double* partials; int nblocks;
     const float4* rec; int N;
@@ -23,104 +49,786 @@ struct mcl_finish_args {
     unsigned long long* prefix;
     pf_state* state;
     int64_t utime;
+    ss_rec* recs;                          // [2][groups * subs]: x records, then y records
+    mclf_tab_elem* tabs;                   // [2][MCLF_TSLOTS][MCLF_SUB]
+    unsigned long long* sync;              // bits 32..: groups done; bits 0..15 / 16..31: x / y tables handed out.  Zero between launches.
+    int groups, gthreads;                  // group workgroups; threads of each that work (256 or 1024)
 };
 
-#define MCLF_POSE_THREADS 256                 // the estimate's addition order is that of a 256-thread workgroup, whoever runs it
-#define MCLF_WG 1024                          // prefix workgroups of the riding form
-#define MCLF_ITEMS 8
-#define MCLF_CHUNK (MCLF_WG * MCLF_ITEMS)     // particles per prefix workgroup: a whole number of k_mcl_main tiles (tiles are powers of two <= 1024)
+#define MCLF_POSE_THREADS 256                 // the theta sums' addition order is that of a 256-thread workgroup, whoever runs it
+#define MCLF_WG 1024                          // threads of every workgroup of the launch
+#define MCLF_ITEMS 2
+#define MCLF_SUB (64 * MCLF_ITEMS)            // particles per sub-tile
+#define MCLF_GT_SMALL 256                     // working threads of a group, small / large particle counts
+#define MCLF_GT_LARGE 1024
+#define MCLF_GT_SWITCH 160000                 // particle count from which the large groups are used
+#define MCLF_RISKY 0x1000                     // flag in a record's key
+#define MCLF_TSLOT_SHIFT 16                   // bits 16..23 of a record's key: 1 + the slot of its table
+#define MCLF_KEY_MASK 0xfff
+#define MCLF_MARGIN 4096                      // ulps of slack on the predicted start when deciding "risky"
+#define MCLF_TSLOTS 20                        // per axis: tables
+#define MCLF_MAXENT 32                        // per axis: risky sub-tiles the chain steps through by the list (more: the slow walk)
+#define MCLF_HEAD_STEPS 32                    // terms at the very start of a sum that are simply stepped (a binade change every few terms)
+#define MCLF_LDS_BYTES (112 * 1024)           // scratch the finisher wants (the map kernel's counter window serves)
 
-// prefix workgroups the riding form needs
+static inline int mclf_gthreads(int N) { return N >= MCLF_GT_SWITCH ? MCLF_GT_LARGE : MCLF_GT_SMALL; }
+#define mclf_chunk(gthreads) ((gthreads) * MCLF_ITEMS)
+
+// group workgroups a finish needs (tile and tail_tile must divide the chunk)
 static inline int mclf_groups(const mcl_finish_args& f)
 {
-    const int tpc_main = MCLF_CHUNK / f.tile;
+    const int chunk = mclf_chunk(f.gthreads);
+    const int tpc_main = chunk / f.tile;
     const int tail_blocks = f.nblocks - f.main_blocks;
     int g = (f.main_blocks + tpc_main - 1) / tpc_main;
-    if (tail_blocks > 0) { const int tpc_tail = MCLF_CHUNK / f.tail_tile; g += (tail_blocks + tpc_tail - 1) / tpc_tail; }
+    if (tail_blocks > 0) { const int tpc_tail = chunk / f.tail_tile; g += (tail_blocks + tpc_tail - 1) / tpc_tail; }
     return g;
 }
 
 #if defined(__HIPCC__)
+#define MCLF_MAXW (MCLF_WG / 64)
+struct mclf_smem {
+    unsigned long long off[MCLF_MAXW], wave[MCLF_MAXW], tot[MCLF_MAXW];
+    double bx[MCLF_MAXW], by[MCLF_MAXW];          // sums of the blocks before the group, per wave
+    double wx[MCLF_MAXW], wy[MCLF_MAXW];          // sums of the sub-tiles' terms
+    double red[MCLF_POSE_THREADS / 64][5];
+    unsigned long long word;                      // the sync word the finisher saw
+    float xy[2], first[2];                        // the sums; the sums behind sub-tile 0
+    unsigned int stats[8];
+};
+
+#ifdef MCLF_STAMPS
+#define MCLF_NOW() ((unsigned long long)wall_clock64())
+#else
+#define MCLF_NOW() 0ull
+#endif
+
 __device__ __forceinline__ double mclf_wave_sum(double v)
 {
     for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
     return v;
 }
-
-// The five sums in a fixed order (thread-strided over the partials with a stride of 256, wave shuffles, waves in order) and
-// the estimate.  Called by EVERY thread of a workgroup of >= 256 threads (it contains a barrier); threads beyond the first
-// 256 only take part in the barrier.  s_red: shared double[4][5].  s_pose_out (shared memory, optional) receives the estimate too.
-__device__ __forceinline__ void mclf_pose(const mcl_finish_args& f, double (*s_red)[5], bl_pose_xyt_t* s_pose_out = nullptr)
+__device__ __forceinline__ double mclf_wave_sum_all(double v)
 {
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (tid < MCLF_POSE_THREADS) {
-        double v[5] = {0, 0, 0, 0, 0};
-        for (int b = tid; b < f.nblocks; b += MCLF_POSE_THREADS)
-            for (int k = 0; k < 5; ++k) v[k] += f.partials[(size_t)b * 5 + k];
-        for (int k = 0; k < 5; ++k) v[k] = mclf_wave_sum(v[k]);
-        if (lane == 0) for (int k = 0; k < 5; ++k) s_red[wave][k] = v[k];
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+// ---- agent-scope relaxed accesses (sc1: through the L2 to memory, so that another XCD sees them without a cache writeback)
+__device__ __forceinline__ void mclf_store_u64(unsigned long long* p, unsigned long long v)
+{
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ unsigned long long mclf_load_u64(const unsigned long long* p)
+{
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void mclf_store_rec(ss_rec* p, const ss_rec& r)
+{
+    unsigned long long* q = (unsigned long long*)p;
+    mclf_store_u64(q, (unsigned long long)(unsigned int)r.key | ((unsigned long long)(unsigned int)r.D << 32));
+    mclf_store_u64(q + 1, (unsigned long long)(unsigned int)r.lo | ((unsigned long long)(unsigned int)r.hi << 32));
+}
+__device__ __forceinline__ ss_rec mclf_load_rec(const ss_rec* p)
+{
+    const unsigned long long* q = (const unsigned long long*)p;
+    const unsigned long long a = mclf_load_u64(q), b = mclf_load_u64(q + 1);
+    return ss_rec_make((int)(unsigned int)a, (int)(unsigned int)(a >> 32), (int)(unsigned int)b, (int)(unsigned int)(b >> 32));
+}
+__device__ __forceinline__ void mclf_store_tab(mclf_tab_elem* p, double t, int se, int se1)
+{
+    unsigned long long* q = (unsigned long long*)p;
+    mclf_store_u64(q, (unsigned long long)__double_as_longlong(t));
+    mclf_store_u64(q + 1, (unsigned long long)(unsigned int)se | ((unsigned long long)(unsigned int)se1 << 32));
+}
+__device__ __forceinline__ mclf_tab_elem mclf_load_tab(const mclf_tab_elem* p)
+{
+    const unsigned long long* q = (const unsigned long long*)p;
+    const unsigned long long a = mclf_load_u64(q), b = mclf_load_u64(q + 1);
+    mclf_tab_elem e;
+    e.t = __longlong_as_double((long long)a); e.se = (int)(unsigned int)b; e.se1 = (int)(unsigned int)(b >> 32);
+    return e;
+}
+
+// particles [lo, hi) of group g and the first block that belongs to it
+__device__ __forceinline__ void mclf_group_range(const mcl_finish_args& f, int g, int* first_block, int* lo, int* hi)
+{
+    const int chunk = mclf_chunk(f.gthreads);
+    const int tpc_main = chunk / f.tile;
+    const int main_groups = (f.main_blocks + tpc_main - 1) / tpc_main;
+    if (g < main_groups) {
+        *first_block = g * tpc_main;
+        *lo = *first_block * f.tile;
+        *hi = min(f.main_particles, *lo + chunk);
+    } else {
+        const int gt = g - main_groups;
+        *first_block = f.main_blocks + gt * (chunk / f.tail_tile);
+        *lo = f.main_particles + gt * chunk;
+        *hi = min(f.N, *lo + chunk);
     }
-    __syncthreads();
-    if (tid == 0) {
-        double tot[5] = {0, 0, 0, 0, 0};
-        for (int w = 0; w < MCLF_POSE_THREADS / 64; ++w) for (int k = 0; k < 5; ++k) tot[k] += s_red[w][k];
-        f.state->S = tot[0];                                 // the unit total: an exact integer below 2^53, any order gives it
-        bl_pose_xyt_t p;
-        p.utime = f.utime;
-        p.x = (float)(tot[1] / tot[0]);
-        p.y = (float)(tot[2] / tot[0]);
-        p.theta = (float)atan2(tot[3], tot[4]);
-        f.state->pose = p;
-        if (s_pose_out) *s_pose_out = p;                     // shared memory: the caller's workgroup reads it behind its next barrier
-        for (int k = 0; k < 5; ++k) f.state->sums_used[k] = tot[k];
+}
+// particles [lo, hi) of sub-tile s (global index: group * waves-per-group + wave)
+__device__ __forceinline__ void mclf_sub_range(const mcl_finish_args& f, int s, int* lo, int* hi)
+{
+    const int subs = f.gthreads >> 6;
+    int first_block, glo, ghi;
+    mclf_group_range(f, s / subs, &first_block, &glo, &ghi);
+    *lo = glo + (s % subs) * MCLF_SUB;
+    *hi = min(ghi, *lo + MCLF_SUB);
+    if (*hi < *lo) *hi = *lo;
+}
+
+// The term of particle r on an axis: t = fl64(w * x), w = fl64(units / S) (particle_filter.cpp:136-138, 151-152).  With the
+// units exact integers, units / S is the same real quotient as the reference's weight / wSum whenever no weight was floored to
+// 0.001 (then wSum itself is a rounded sum; DESIGN.md "Pose estimate").
+__device__ __forceinline__ double mclf_term(const float4& r, double S, int axis)
+{
+    const double w = (double)__float_as_uint(r.w) / S;
+    return w * (double)(axis ? r.y : r.x);
+}
+__device__ __forceinline__ void mclf_load_terms(const mcl_finish_args& f, int axis, double S, int lo, int hi, int lane, double (&t)[MCLF_ITEMS])
+{
+#pragma unroll
+    for (int k = 0; k < MCLF_ITEMS; ++k) {
+        const int i = lo + lane * MCLF_ITEMS + k;
+        t[k] = i < hi ? mclf_term(f.rec[i], S, axis) : 0.0;
     }
 }
 
-// Prefix workgroup g of the riding form: MCLF_WG threads, MCLF_CHUNK particles, exact integers throughout.
-// s_u64: shared unsigned long long[2 * MCLF_WG / 64].
-__device__ __forceinline__ void mclf_prefix_group(const mcl_finish_args& f, int g, unsigned long long* s_u64)
+// ---- wave-wide integer scans on DPP (row shifts inside the 16-lane rows, then the two row broadcasts of gfx9): six dependent
+// VALU operations instead of six LDS-crossbar round trips -- these sit on the serial path of the chain.
+// update_dpp(old, src, ctrl, row_mask, bank_mask, bound_ctrl = false): a lane without a source lane, or outside the row mask,
+// receives `old`, which is the operation's identity here.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ int mclf_dpp(int old, int v) { return __builtin_amdgcn_update_dpp(old, v, CTRL, ROW_MASK, 0xf, false); }
+#define MCLF_DPP_STEPS(STEP) \
+    STEP(0x111, 0xf) STEP(0x112, 0xf) STEP(0x114, 0xf) STEP(0x118, 0xf) STEP(0x142, 0xa) STEP(0x143, 0xc)
+// row_shr:1, 2, 4, 8; row_bcast:15 into rows 1 and 3; row_bcast:31 into rows 2 and 3
+
+__device__ __forceinline__ int mclf_scan_add(int v)
+{
+#define MCLF_STEP(C, R) v += mclf_dpp<C, R>(0, v);
+    MCLF_DPP_STEPS(MCLF_STEP)
+#undef MCLF_STEP
+    return v;
+}
+__device__ __forceinline__ int mclf_wave_min(int v)
+{
+#define MCLF_STEP(C, R) v = min(v, mclf_dpp<C, R>(0x7fffffff, v));
+    MCLF_DPP_STEPS(MCLF_STEP)
+#undef MCLF_STEP
+    return __builtin_amdgcn_readlane(v, 63);
+}
+__device__ __forceinline__ int mclf_wave_max(int v)
+{
+#define MCLF_STEP(C, R) v = max(v, mclf_dpp<C, R>((int)0x80000000, v));
+    MCLF_DPP_STEPS(MCLF_STEP)
+#undef MCLF_STEP
+    return __builtin_amdgcn_readlane(v, 63);
+}
+// inclusive scan of records by composition (lane l: records 0..l of the wave joined in order)
+__device__ __forceinline__ ss_rec mclf_scan_join(ss_rec r)
+{
+#define MCLF_STEP(C, R) { const ss_rec o = ss_rec_make(mclf_dpp<C, R>(SS_ID, r.key), mclf_dpp<C, R>(0, r.D), mclf_dpp<C, R>(0, r.lo), mclf_dpp<C, R>(0, r.hi)); \
+                          r = ss_rec_join(o, r); }
+    MCLF_DPP_STEPS(MCLF_STEP)
+#undef MCLF_STEP
+    return r;
+}
+// the same, restarting behind every lane whose `head` is set: lane l gets the join of the records from the last head <= l on
+__device__ __forceinline__ ss_rec mclf_scan_join_segmented(ss_rec r, int head)
+{
+#define MCLF_STEP(C, R) { const ss_rec o = ss_rec_make(mclf_dpp<C, R>(SS_ID, r.key), mclf_dpp<C, R>(0, r.D), mclf_dpp<C, R>(0, r.lo), mclf_dpp<C, R>(0, r.hi)); \
+                          const int oh = mclf_dpp<C, R>(0, head);                                                                                      \
+                          const ss_rec j = ss_rec_join(o, r);                                                                                          \
+                          r.key = head ? r.key : j.key; r.D = head ? r.D : j.D; r.lo = head ? r.lo : j.lo; r.hi = head ? r.hi : j.hi;                  \
+                          head |= oh; }
+    MCLF_DPP_STEPS(MCLF_STEP)
+#undef MCLF_STEP
+    return r;
+}
+
+// Quantized increments of this lane's terms in binade `key`, their inclusive prefix over the wave (p[k]), a bad flag per term.
+__device__ __forceinline__ void mclf_prefix_in(int key, const double (&t)[MCLF_ITEMS], int cnt, int (&p)[MCLF_ITEMS], int (&bad)[MCLF_ITEMS])
+{
+    const ss_bin b = ss_bin_of(key);
+    int run = 0;
+#pragma unroll
+    for (int k = 0; k < MCLF_ITEMS; ++k) {
+        int bk = 0;
+        const int d = ss_quantize(b, t[k], &bk);
+        run += k < cnt ? d : 0; bad[k] = k < cnt ? bk : 0;
+        p[k] = run;
+    }
+    const int excl = mclf_scan_add(run) - run;
+#pragma unroll
+    for (int k = 0; k < MCLF_ITEMS; ++k) p[k] += excl;
+}
+
+// Record of one sub-tile (this wave's particles, MCLF_ITEMS consecutive ones per lane, `cnt` of them valid in this lane) for the
+// binade of the predicted start value; a risky one also gets a table if a slot is left.
+__device__ __forceinline__ ss_rec mclf_make_record(const mcl_finish_args& f, int axis, const double (&t)[MCLF_ITEMS], int cnt,
+                                                   double predicted_start, bool very_first, int lane)
+{
+    // (the very first sub-tile starts from zero: the finisher steps through it itself, ahead of everything; it is listed as
+    // risky, without a table, so that no gap ever covers it)
+    if (very_first) return ss_rec_make(MCLF_RISKY, 0, 0, 0);
+    const int key = __builtin_amdgcn_readfirstlane(ss_key((float)predicted_start));
+    int p[MCLF_ITEMS] = {0, 0}, bad[MCLF_ITEMS] = {0, 0};
+    bool risky = true;
+    ss_rec rec = ss_rec_make(MCLF_RISKY, 0, 0, 0);
+    if (__builtin_amdgcn_ballot_w64(cnt > 0) == 0) return ss_rec_identity();                 // no particle in this sub-tile
+    if (key) {
+        mclf_prefix_in(key, t, cnt, p, bad);
+        int lo = SS_SAT, hi = -SS_SAT;
+#pragma unroll
+        for (int k = 0; k < MCLF_ITEMS; ++k)
+            if (k < cnt) { lo = min(lo, p[k]); hi = max(hi, p[k]); }
+        lo = mclf_wave_min(lo); hi = mclf_wave_max(hi);
+        const int D = __builtin_amdgcn_readlane(p[MCLF_ITEMS - 1], 63);
+        const bool anybad = __builtin_amdgcn_ballot_w64((bad[0] | bad[1]) != 0) != 0;
+        // "risky": with the predicted start magnitude and a margin for its error the run would not stay inside the binade
+        const int Mp = ss_mag((float)predicted_start);
+        risky = anybad || !(Mp + lo - MCLF_MARGIN > SS_MLO && Mp + hi + MCLF_MARGIN < SS_MHI);
+        rec = anybad ? ss_rec_make(MCLF_RISKY, 0, 0, 0) : ss_rec_make(key | (risky ? MCLF_RISKY : 0), D, lo, hi);
+    }
+    if (risky && f.tabs) {
+        // the table: terms, prefix in the predicted binade (if there is one), prefix in the next binade up
+        unsigned long long got = 0;
+        if (lane == 0) got = __hip_atomic_fetch_add(f.sync, axis ? (1ull << 16) : 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int slot = __builtin_amdgcn_readfirstlane((int)((got >> (axis ? 16 : 0)) & 0xffffull));
+        if (slot < MCLF_TSLOTS) {
+            int p1[MCLF_ITEMS] = {0, 0}, bad1[MCLF_ITEMS] = {1, 1};
+            const bool up = key != 0 && (key & 0xff) < 254;
+            if (up) mclf_prefix_in(key + 1, t, cnt, p1, bad1);
+            mclf_tab_elem* tab = f.tabs + ((size_t)axis * MCLF_TSLOTS + slot) * MCLF_SUB;
+#pragma unroll
+            for (int k = 0; k < MCLF_ITEMS; ++k) {
+                const int se = key ? ((p[k] << 1) | bad[k]) : 1, se1 = up ? ((p1[k] << 1) | bad1[k]) : 1;
+                mclf_store_tab(tab + lane * MCLF_ITEMS + k, t[k], se, se1);
+            }
+            rec.key |= (slot + 1) << MCLF_TSLOT_SHIFT;
+        }
+    }
+    return rec;
+}
+
+// Group g: the first f.gthreads threads of the workgroup work (the others leave at once); particles [lo, hi) of the group.
+__device__ __forceinline__ void mclf_prefix_group(const mcl_finish_args& f, int g, mclf_smem& sm)
 {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    unsigned long long* s_off = s_u64;
-    unsigned long long* s_wave = s_u64 + MCLF_WG / 64;
-    const int tpc_main = MCLF_CHUNK / f.tile;
-    const int main_groups = (f.main_blocks + tpc_main - 1) / tpc_main;
+    if (tid >= f.gthreads) return;
+    const int gt = f.gthreads, nw = gt >> 6;
+#ifdef MCLF_STAMPS
+    unsigned long long gs[8] = {MCLF_NOW(), 0, 0, 0, 0, 0, 0, 0};
+#define MCLF_GSTAMP(i) gs[i] = MCLF_NOW()
+#else
+#define MCLF_GSTAMP(i) do { } while (0)
+#endif
     int first_block, lo, hi;
-    if (g < main_groups) {
-        first_block = g * tpc_main;
-        lo = first_block * f.tile;
-        hi = min(f.main_particles, lo + MCLF_CHUNK);
-    } else {
-        const int gt = g - main_groups;
-        first_block = f.main_blocks + gt * (MCLF_CHUNK / f.tail_tile);
-        lo = f.main_particles + gt * MCLF_CHUNK;
-        hi = min(f.N, lo + MCLF_CHUNK);
+    mclf_group_range(f, g, &first_block, &lo, &hi);
+    // sums over the blocks: units before the group and in total (exact integers), x / y sums before the group (prediction)
+    unsigned long long before = 0, total = 0;
+    double bx = 0.0, by = 0.0;
+    for (int j = tid; j < f.nblocks; j += gt) {
+        const unsigned long long u = (unsigned long long)f.partials[(size_t)j * 5];
+        total += u;
+        if (j < first_block) { before += u; bx += f.partials[(size_t)j * 5 + 1]; by += f.partials[(size_t)j * 5 + 2]; }
     }
-    // units of everything before this chunk: the unit sums of the k_mcl_main workgroups before it
-    unsigned long long before = 0;
-    for (int j = tid; j < first_block; j += MCLF_WG) before += (unsigned long long)f.partials[(size_t)j * 5];
-    for (int off = 32; off > 0; off >>= 1) before += __shfl_xor(before, off, 64);
-    if (lane == 0) s_off[wave] = before;
     const int base = lo + tid * MCLF_ITEMS;
-    unsigned int u[MCLF_ITEMS];
+    float4 r[MCLF_ITEMS];
+    int cnt = 0;
 #pragma unroll
-    for (int k = 0; k < MCLF_ITEMS; ++k) u[k] = (base + k < hi) ? __float_as_uint(f.rec[base + k].w) : 0u;
+    for (int k = 0; k < MCLF_ITEMS; ++k) {
+        r[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (base + k < hi) { r[k] = f.rec[base + k]; cnt = k + 1; }
+    }
+    for (int off = 32; off > 0; off >>= 1) { before += __shfl_xor(before, off, 64); total += __shfl_xor(total, off, 64); }
+    bx = mclf_wave_sum_all(bx); by = mclf_wave_sum_all(by);
+    if (lane == 0) { sm.off[wave] = before; sm.tot[wave] = total; sm.bx[wave] = bx; sm.by[wave] = by; }
     unsigned long long loc[MCLF_ITEMS];
     unsigned long long run = 0;
 #pragma unroll
-    for (int k = 0; k < MCLF_ITEMS; ++k) { run += u[k]; loc[k] = run; }
+    for (int k = 0; k < MCLF_ITEMS; ++k) { run += __float_as_uint(r[k].w); loc[k] = run; }
     unsigned long long incl = run;
     for (int off = 1; off < 64; off <<= 1) {
         unsigned long long t = __shfl_up(incl, off, 64);
         if (lane >= off) incl += t;
     }
-    if (lane == 63) s_wave[wave] = incl;
+    if (lane == 63) sm.wave[wave] = incl;
+    MCLF_GSTAMP(1);
     __syncthreads();
-    unsigned long long off0 = incl - run;
-    for (int w = 0; w < MCLF_WG / 64; ++w) { off0 += s_off[w]; if (w < wave) off0 += s_wave[w]; }
+    MCLF_GSTAMP(2);
+    unsigned long long off0 = incl - run, S_u = 0;
+    double px = 0.0, py = 0.0;
+    for (int w = 0; w < nw; ++w) { off0 += sm.off[w]; S_u += sm.tot[w]; px += sm.bx[w]; py += sm.by[w]; if (w < wave) off0 += sm.wave[w]; }
 #pragma unroll
     for (int k = 0; k < MCLF_ITEMS; ++k)
         if (base + k < hi) f.prefix[base + k] = off0 + loc[k];
+    if (!f.recs) return;
+    MCLF_GSTAMP(3);
+    // ---- the sub-tile records of the two float accumulators
+    const double S = (double)S_u;
+    double tx[MCLF_ITEMS], ty[MCLF_ITEMS];
+    double sx = 0.0, sy = 0.0;
+#pragma unroll
+    for (int k = 0; k < MCLF_ITEMS; ++k) {
+        tx[k] = mclf_term(r[k], S, 0); ty[k] = mclf_term(r[k], S, 1);
+        sx += tx[k]; sy += ty[k];
+    }
+    sx = mclf_wave_sum_all(sx); sy = mclf_wave_sum_all(sy);
+    if (lane == 0) { sm.wx[wave] = sx; sm.wy[wave] = sy; }
+    MCLF_GSTAMP(4);
+    __syncthreads();
+    px /= S; py /= S;                                     // predicted accumulators where the group starts ...
+    for (int w = 0; w < wave; ++w) { px += sm.wx[w]; py += sm.wy[w]; }      // ... and where this wave's sub-tile starts
+    const bool very_first = g == 0 && wave == 0;
+    const ss_rec rx = mclf_make_record(f, 0, tx, cnt, px, very_first, lane);
+    const ss_rec ry = mclf_make_record(f, 1, ty, cnt, py, very_first, lane);
+    MCLF_GSTAMP(5);
+    if (lane == 0) {
+        const size_t nrec = (size_t)f.groups * nw, s = (size_t)g * nw + wave;
+        mclf_store_rec(f.recs + s, rx);
+        mclf_store_rec(f.recs + nrec + s, ry);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");      // this wave's write-through stores have left (no cache writeback)
+    __syncthreads();
+    MCLF_GSTAMP(6);
+    if (tid == 0) __hip_atomic_fetch_add(f.sync, 1ull << 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#ifdef MCLF_STAMPS
+    if (tid == 0 && g == f.groups / 2) { gs[7] = MCLF_NOW(); for (int k = 0; k < 8; ++k) f.state->gstamps[k] = gs[k]; }
+#endif
+}
+
+__device__ __forceinline__ double mclf_readlane_f64(double v, int lane)
+{
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane), hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+    return __hiloint2double(hi, lo);
+}
+
+// A sub-tile of n terms (lane l holds terms 2l, 2l+1) replayed from term `pos` on with the true accumulator by one wave (all 64
+// lanes call it; acc is wave-uniform): in-binade integer prefix sums up to the first step that leaves the binade, ties or is
+// too large, that step in real arithmetic, and on (bl_serial_sum.h).  Terms before `head` are simply stepped.
+__device__ __forceinline__ float mclf_replay(const double (&t)[MCLF_ITEMS], int n, int pos, int head, float acc, int lane, unsigned int* phases)
+{
+    static_assert(MCLF_ITEMS == 2, "the replay indexes two terms per lane");
+    n = __builtin_amdgcn_readfirstlane(n); pos = __builtin_amdgcn_readfirstlane(pos); head = __builtin_amdgcn_readfirstlane(head);
+    if (pos < head) {
+        // the first terms of a sum: the accumulator changes its binade every few terms, so they are stepped one by one (the
+        // term reads do not depend on the accumulator; the loop carries three dependent operations per term)
+        const int h = min(head, n);
+#pragma unroll 8
+        for (int i = pos; i < h; ++i) acc = ss_exact_step(acc, mclf_readlane_f64((i & 1) ? t[1] : t[0], i >> 1));
+        pos = h;
+    }
+    while (pos < n) {
+        const int key = __builtin_amdgcn_readfirstlane(ss_key(acc));
+        if (!key) {                                                   // no usable binade (zero, tiny, not finite): the step itself
+            const double tj = mclf_readlane_f64((pos & 1) ? t[1] : t[0], pos >> 1);
+            acc = ss_exact_step(acc, tj);
+            pos++;
+            continue;
+        }
+        *phases += 1;
+        const int M = ss_mag(acc);
+        const ss_bin b = ss_bin_of(key);
+        int bad[MCLF_ITEMS], p[MCLF_ITEMS];
+        int run = 0;
+#pragma unroll
+        for (int k = 0; k < MCLF_ITEMS; ++k) {
+            const int i = lane * MCLF_ITEMS + k;
+            int bk = 0;
+            const int d = ss_quantize(b, t[k], &bk);
+            const bool on = i >= pos && i < n;
+            run += on ? d : 0; bad[k] = on ? bk : 0;
+            p[k] = run;
+        }
+        const int excl = mclf_scan_add(run) - run;
+        int Mi[MCLF_ITEMS];
+        bool out[MCLF_ITEMS];
+#pragma unroll
+        for (int k = 0; k < MCLF_ITEMS; ++k) {
+            const int i = lane * MCLF_ITEMS + k;
+            Mi[k] = M + excl + p[k];
+            out[k] = i >= pos && i < n && (bad[k] || Mi[k] <= SS_MLO || Mi[k] >= SS_MHI);
+        }
+        const unsigned long long mask = __builtin_amdgcn_ballot_w64(out[0] || out[1]);
+        if (!mask) { acc = ss_from(key, __builtin_amdgcn_readlane(Mi[MCLF_ITEMS - 1], 63)); break; }
+        const int fl = __ffsll((long long)mask) - 1;
+        const int ek = __builtin_amdgcn_readlane(out[0] ? 1 : 0, fl) ? 0 : 1;
+        const int j = fl * MCLF_ITEMS + ek;
+        int Mb = M;
+        if (j > pos) Mb = ek ? __builtin_amdgcn_readlane(Mi[0], fl) : __builtin_amdgcn_readlane(Mi[1], fl - 1);
+        const double tj = mclf_readlane_f64(ek ? t[1] : t[0], fl);
+        acc = ss_exact_step(ss_from(key, Mb), tj);
+        pos = j + 1;
+    }
+    return acc;
+}
+
+// A risky sub-tile by its table (this lane's two rows e[0], e[1]; tkey = the binade the table was made for): the usual case is
+// ONE step that leaves the binade upwards.  Returns through the generic replay whenever the sub-tile does something else.
+__device__ __forceinline__ float mclf_replay_table(const mclf_tab_elem (&e)[MCLF_ITEMS], int tkey, int n, int head, float acc, int lane,
+                                                   unsigned int* phases, unsigned int* by_table)
+{
+    double t[MCLF_ITEMS] = {e[0].t, e[1].t};
+    const int key = __builtin_amdgcn_readfirstlane(ss_key(acc));
+    tkey = __builtin_amdgcn_readfirstlane(tkey); n = __builtin_amdgcn_readfirstlane(n); head = __builtin_amdgcn_readfirstlane(head);
+    if (key == 0 || key != tkey || head > 0) return mclf_replay(t, n, 0, head, acc, lane, phases);
+    const int M = ss_mag(acc);
+    int Mi[MCLF_ITEMS];
+    bool out[MCLF_ITEMS];
+#pragma unroll
+    for (int k = 0; k < MCLF_ITEMS; ++k) {
+        const int i = lane * MCLF_ITEMS + k;
+        Mi[k] = M + (e[k].se >> 1);
+        out[k] = i < n && ((e[k].se & 1) || Mi[k] <= SS_MLO || Mi[k] >= SS_MHI);
+    }
+    const unsigned long long mask = __builtin_amdgcn_ballot_w64(out[0] || out[1]);
+    *by_table += 1;
+    if (!mask) return ss_from(key, __builtin_amdgcn_readlane(Mi[MCLF_ITEMS - 1], 63));       // it stayed inside after all
+    const int fl = __ffsll((long long)mask) - 1;
+    const int ek = __builtin_amdgcn_readlane(out[0] ? 1 : 0, fl) ? 0 : 1;
+    const int j = fl * MCLF_ITEMS + ek;
+    int Mb = M;
+    if (j > 0) Mb = ek ? __builtin_amdgcn_readlane(Mi[0], fl) : __builtin_amdgcn_readlane(Mi[1], fl - 1);
+    const double tj = mclf_readlane_f64(ek ? t[1] : t[0], fl);
+    const float acc1 = ss_exact_step(ss_from(key, Mb), tj);
+    const int key1 = __builtin_amdgcn_readfirstlane(ss_key(acc1));
+    if (key1 != key + 1 || (key & 0xff) >= 254) return mclf_replay(t, n, j + 1, 0, acc1, lane, phases);
+    // the rest of the sub-tile in the next binade: prefix differences of the table's second column
+    const int M1 = ss_mag(acc1);
+    const int base1 = (ek ? __builtin_amdgcn_readlane(e[1].se1, fl) : __builtin_amdgcn_readlane(e[0].se1, fl)) >> 1;
+    bool out1 = false;
+    int last1 = 0;
+#pragma unroll
+    for (int k = 0; k < MCLF_ITEMS; ++k) {
+        const int i = lane * MCLF_ITEMS + k;
+        const int m = M1 + (e[k].se1 >> 1) - base1;
+        out1 |= i > j && i < n && ((e[k].se1 & 1) || m <= SS_MLO || m >= SS_MHI);
+        last1 = m;
+    }
+    if (__builtin_amdgcn_ballot_w64(out1)) return mclf_replay(t, n, j + 1, 0, acc1, lane, phases);
+    return ss_from(key1, __builtin_amdgcn_readlane(last1, 63));
+}
+
+__device__ __forceinline__ int mclf_plain_key(int key) { return key == SS_ID ? SS_ID : (key & MCLF_KEY_MASK); }
+
+// ---- LDS staging (per axis)
+struct mclf_ent { int s, tslot, tkey, lo_n; ss_rec head; };     // a risky sub-tile: index, table slot or -1, the table's binade, first particle << 8 | particle count - 1; join of the records between the previous risky one (or its batch's start) and it
+struct mclf_step { ss_rec gap; int s, tslot, tkey, lo_n; };     // what the chain reads per list entry, in sub-tile order: the gap in front of it, then the entry
+struct mclf_stage {
+    mclf_tab_elem* tab;           // [MCLF_TSLOTS][MCLF_SUB]
+    ss_rec* comp;                 // [nbatch]: join of a batch's records; key 0 for a batch with risky records in it
+    ss_rec* btail;                // [nbatch]: for such a batch, join of the records behind its last risky one
+    mclf_step* step;              // [MCLF_MAXENT + 1]: entry k in sub-tile order with the gap in front of it; [nent]: the gap behind the last
+    mclf_ent* ent;                // [MCLF_MAXENT], in arrival order
+    int* order;                   // [MCLF_MAXENT]: entries by sub-tile index
+    int* nent;                    // entries handed out (may exceed MCLF_MAXENT: the surplus is not listed)
+};
+__device__ __forceinline__ size_t mclf_stage_bytes(int nbatch)
+{
+    return (size_t)MCLF_TSLOTS * MCLF_SUB * sizeof(mclf_tab_elem) + 2 * (size_t)nbatch * sizeof(ss_rec) + (MCLF_MAXENT + 1) * sizeof(mclf_step) +
+           MCLF_MAXENT * sizeof(mclf_ent) + MCLF_MAXENT * sizeof(int) + 16;
+}
+__device__ __forceinline__ mclf_stage mclf_stage_at(char* base, int nbatch)
+{
+    mclf_stage st;
+    st.tab = (mclf_tab_elem*)base; base += (size_t)MCLF_TSLOTS * MCLF_SUB * sizeof(mclf_tab_elem);
+    st.comp = (ss_rec*)base; base += (size_t)nbatch * sizeof(ss_rec);
+    st.btail = (ss_rec*)base; base += (size_t)nbatch * sizeof(ss_rec);
+    st.step = (mclf_step*)base; base += (MCLF_MAXENT + 1) * sizeof(mclf_step);
+    st.ent = (mclf_ent*)base; base += MCLF_MAXENT * sizeof(mclf_ent);
+    st.order = (int*)base; base += MCLF_MAXENT * sizeof(int);
+    st.nent = (int*)base;
+    return st;
+}
+
+// One batch of 64 records of an axis, by one wave: composite, and the list entries of its risky records.
+__device__ __forceinline__ void mclf_stage_batch(const mcl_finish_args& f, const mclf_stage& st, ss_rec r, int b, int lane)
+{
+    const bool risky = r.key != SS_ID && (r.key & MCLF_RISKY) != 0;
+    const int tslot = r.key == SS_ID ? -1 : ((r.key >> MCLF_TSLOT_SHIFT) & 0xff) - 1;
+    const int pkey = mclf_plain_key(r.key);
+    const unsigned long long rmask = __builtin_amdgcn_ballot_w64(risky);
+    ss_rec v = r;
+    v.key = pkey;
+    if (risky) v = ss_rec_identity();
+    const int head = (lane == 0 || ((rmask >> (lane - 1)) & 1ull)) ? 1 : 0;        // a segment starts behind every risky record
+    const ss_rec seg = mclf_scan_join_segmented(v, head);
+    if (rmask == 0) {
+        if (lane == 63) st.comp[b] = seg;
+        return;
+    }
+    if (lane == 63) {
+        st.comp[b] = ss_rec_make(0, 0, 0, 0);
+        st.btail[b] = risky ? ss_rec_identity() : seg;
+    }
+    if (risky) {
+        const int e = atomicAdd(st.nent, 1);
+        if (e < MCLF_MAXENT) {
+            mclf_ent en;
+            int lo, hi;
+            mclf_sub_range(f, b * 64 + lane, &lo, &hi);
+            en.s = b * 64 + lane; en.tslot = tslot; en.tkey = pkey; en.lo_n = hi > lo ? ((lo << 8) | (hi - lo - 1)) : -1;
+            en.head = seg;                                     // (its own record counts as the identity in the scan)
+            st.ent[e] = en;
+        }
+    }
+}
+
+// join of comp[b0 .. b1] (inclusive; empty range: identity) by one wave; every lane returns the result
+__device__ __forceinline__ ss_rec mclf_join_batches(const mclf_stage& st, int b0, int b1, int lane)
+{
+    ss_rec acc = ss_rec_identity();
+    for (int b = b0; b <= b1; b += 64) {
+        ss_rec r = (b + lane <= b1) ? st.comp[b + lane] : ss_rec_identity();
+        r = mclf_scan_join(r);
+        const ss_rec all = ss_rec_make(__builtin_amdgcn_readlane(r.key, 63), __builtin_amdgcn_readlane(r.D, 63),
+                                       __builtin_amdgcn_readlane(r.lo, 63), __builtin_amdgcn_readlane(r.hi, 63));
+        acc = ss_rec_join(acc, all);
+    }
+    return acc;
+}
+
+// Records [ra, rb) of an axis walked with the true accumulator straight from global memory, replaying whatever does not fit
+// (the path for everything the staging did not foresee, and the whole chain when the scratch cannot hold the tables).
+__device__ __forceinline__ float mclf_walk(const mcl_finish_args& f, int axis, double S, int ra, int rb, float acc, int lane,
+                                           unsigned int* replays, unsigned int* phases)
+{
+    const int nrec = f.groups * (f.gthreads >> 6);
+    const ss_rec* recs = f.recs + (size_t)axis * nrec;
+    int r0 = ra;
+    while (r0 < rb) {
+        ss_rec r = (r0 + lane < rb) ? mclf_load_rec(recs + r0 + lane) : ss_rec_identity();
+        r.key = mclf_plain_key(r.key);
+        const ss_rec pre = mclf_scan_join(r);
+        const int key = __builtin_amdgcn_readfirstlane(ss_key(acc));
+        const int M = ss_mag(acc);
+        const bool fits = pre.key == SS_ID || (key != 0 && ss_rec_fits(pre, key, M));
+        const unsigned long long nofit = __builtin_amdgcn_ballot_w64(!fits);
+        const int nb = min(64, rb - r0);
+        int fb = nofit ? __ffsll((long long)nofit) - 1 : 64;
+        if (fb > nb) fb = nb;
+        if (fb > 0) {
+            const int pk = __builtin_amdgcn_readlane(pre.key, fb - 1), pD = __builtin_amdgcn_readlane(pre.D, fb - 1);
+            if (pk != SS_ID) acc = ss_from(key, M + pD);
+        }
+        if (fb < nb) {
+            const int s = r0 + fb;
+            int lo, hi;
+            mclf_sub_range(f, s, &lo, &hi);
+            if (lo < hi) {
+                double t[MCLF_ITEMS];
+                mclf_load_terms(f, axis, S, lo, hi, lane, t);
+                acc = mclf_replay(t, hi - lo, 0, 0, acc, lane, phases);
+                *replays += 1;
+            }
+            r0 = s + 1;
+        } else {
+            r0 += nb;
+        }
+    }
+    return acc;
+}
+
+// One axis' float accumulator over all particles, by one wave (all 64 lanes; the result is wave-uniform).
+// `first`: the accumulator behind sub-tile 0.
+__device__ __forceinline__ float mclf_chain(const mcl_finish_args& f, const mclf_stage* st, int ntab, int axis, double S, float first, int lane,
+                                            unsigned int* stats)
+{
+    const int nrec = f.groups * (f.gthreads >> 6);
+    // (a list that overflowed is no list: the gaps between listed entries would skip the unlisted risky records)
+    if (!st || *st->nent > MCLF_MAXENT) return mclf_walk(f, axis, S, 1, nrec, first, lane, &stats[0], &stats[1]);
+    const int nent = __builtin_amdgcn_readfirstlane(*st->nent);
+    float acc = first;                                           // sub-tile 0 is done (mclf_pose)
+    int prev = 0;                                                // last sub-tile done
+    for (int k = 0; k <= nent; ++k) {
+#ifdef MCLF_STAMPS
+        if (axis == 0 && k < 16 && lane == 0) f.state->cstamps[k] = MCLF_NOW();
+#endif
+        mclf_step sp = st->step[k];                              // wave-uniform LDS reads
+        sp.gap.key = __builtin_amdgcn_readfirstlane(sp.gap.key); sp.gap.D = __builtin_amdgcn_readfirstlane(sp.gap.D);
+        sp.gap.lo = __builtin_amdgcn_readfirstlane(sp.gap.lo); sp.gap.hi = __builtin_amdgcn_readfirstlane(sp.gap.hi);
+        sp.s = __builtin_amdgcn_readfirstlane(sp.s); sp.tslot = __builtin_amdgcn_readfirstlane(sp.tslot);
+        sp.tkey = __builtin_amdgcn_readfirstlane(sp.tkey); sp.lo_n = __builtin_amdgcn_readfirstlane(sp.lo_n);
+        // the gap in front of entry k (behind the last one for k == nent)
+        if (sp.gap.key != SS_ID) {
+            const int key = __builtin_amdgcn_readfirstlane(ss_key(acc));
+            const int M = ss_mag(acc);
+            if (key != 0 && ss_rec_fits(sp.gap, key, M)) acc = ss_from(key, M + sp.gap.D);
+            else { acc = mclf_walk(f, axis, S, prev + 1, sp.s, acc, lane, &stats[0], &stats[1]); stats[3] += 1; }
+        }
+        if (k == nent) break;
+        // the risky sub-tile itself (sub-tile 0, always the first of the list, is behind us)
+        if (sp.lo_n >= 0 && sp.s > 0) {
+            const int lo = sp.lo_n >> 8, n = (sp.lo_n & 0xff) + 1;
+            if (sp.tslot >= 0 && sp.tslot < ntab) {
+                const mclf_tab_elem* row = st->tab + sp.tslot * MCLF_SUB + 2 * lane;
+                mclf_tab_elem el[MCLF_ITEMS] = {row[0], row[1]};
+                acc = mclf_replay_table(el, sp.tkey, n, 0, acc, lane, &stats[1], &stats[2]);
+            } else {
+                double t[MCLF_ITEMS];
+                mclf_load_terms(f, axis, S, lo, lo + n, lane, t);
+                acc = mclf_replay(t, n, 0, 0, acc, lane, &stats[1]);
+                stats[0] += 1;
+            }
+        }
+        prev = sp.s;
+    }
+    return acc;
+}
+
+// The finisher: waits for the groups of this launch, forms estimatePosteriorPose.  Called by EVERY thread of a workgroup of
+// MCLF_WG threads (it contains barriers).  scratch / scratch_bytes: LDS the finisher may use until it returns (16-byte aligned).
+// s_pose_out (shared memory, optional) receives the estimate too.
+__device__ __forceinline__ void mclf_pose(const mcl_finish_args& f, mclf_smem& sm, char* scratch, size_t scratch_bytes,
+                                          bl_pose_xyt_t* s_pose_out = nullptr)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+#ifdef MCLF_STAMPS
+    unsigned long long stamp[6] = {MCLF_NOW(), 0, 0, 0, 0, 0};
+#define MCLF_STAMP(i) stamp[i] = MCLF_NOW()
+#else
+#define MCLF_STAMP(i) do { } while (0)
+#endif
+    // the sums of units, units*sin, units*cos in a fixed order (thread-strided with a stride of 256, wave shuffles, waves in order)
+    if (tid < MCLF_POSE_THREADS) {
+        double v[5] = {0, 0, 0, 0, 0};
+        for (int b = tid; b < f.nblocks; b += MCLF_POSE_THREADS)
+            for (int k = 0; k < 5; ++k) v[k] += f.partials[(size_t)b * 5 + k];
+        for (int k = 0; k < 5; ++k) v[k] = mclf_wave_sum(v[k]);
+        if (lane == 0) for (int k = 0; k < 5; ++k) sm.red[wave][k] = v[k];
+    }
+    const int nrec = f.groups * (f.gthreads >> 6), nbatch = (nrec + 63) >> 6;
+    const size_t per_axis = (mclf_stage_bytes(nbatch) + 15) & ~(size_t)15;
+    const bool staged = scratch != nullptr && 2 * per_axis <= scratch_bytes;
+#define MCLF_STAGE(axis) mclf_stage_at(scratch + (size_t)(axis) * per_axis, nbatch)
+    if (staged && tid < 2) *MCLF_STAGE(tid).nent = 0;
+    __syncthreads();
+    double S = 0.0;
+    for (int w = 0; w < MCLF_POSE_THREADS / 64; ++w) S += sm.red[w][0];          // exact integer below 2^53, any order gives it
+    if (tid == 0) {
+        // every group has counted itself once its records (and tables) were on their way through the L2
+        unsigned long long w;
+        while (((w = mclf_load_u64(f.sync)) >> 32) < (unsigned long long)f.groups) __builtin_amdgcn_s_sleep(1);
+        sm.word = w;
+    }
+    if (wave == 2 || wave == 3) {
+        // meanwhile: the sums start from zero, so sub-tile 0 needs nothing from the groups -- its first terms stepped one by
+        // one, the rest in-binade (waves 2 / 3: x / y)
+        int lo, hi;
+        mclf_sub_range(f, 0, &lo, &hi);
+        double t[MCLF_ITEMS];
+        mclf_load_terms(f, wave - 2, S, lo, hi, lane, t);
+        unsigned int ph = 0;
+        const float v = mclf_replay(t, hi - lo, 0, MCLF_HEAD_STEPS, 0.0f, lane, &ph);
+        if (lane == 0) sm.first[wave - 2] = v;
+    }
+    __syncthreads();
+    MCLF_STAMP(1);
+    const unsigned long long word = sm.word;
+    const int ntab[2] = {min((int)(word & 0xffffull), MCLF_TSLOTS), min((int)((word >> 16) & 0xffffull), MCLF_TSLOTS)};
+    if (staged) {
+        // ---- stage a: every wave takes batches of records and tables of both axes; the loads of four items are in flight together
+        const int nb2 = 2 * nbatch, items = nb2 + ntab[0] + ntab[1];
+        for (int base = wave; base < items; base += 4 * MCLF_MAXW) {
+            ss_rec rr[4];
+            mclf_tab_elem te[4][MCLF_ITEMS];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int it = base + u * MCLF_MAXW;
+                rr[u] = ss_rec_identity();
+                te[u][0].t = 0.0; te[u][0].se = 1; te[u][0].se1 = 1; te[u][1] = te[u][0];
+                if (it < nb2) {
+                    const int axis = it >= nbatch ? 1 : 0, b = it - axis * nbatch;
+                    if (b * 64 + lane < nrec) rr[u] = mclf_load_rec(f.recs + (size_t)axis * nrec + b * 64 + lane);
+                } else if (it < items) {
+                    const int q = it - nb2, axis = q >= ntab[0] ? 1 : 0, slot = q - axis * ntab[0];
+                    const mclf_tab_elem* src = f.tabs + ((size_t)axis * MCLF_TSLOTS + slot) * MCLF_SUB + lane * MCLF_ITEMS;
+                    te[u][0] = mclf_load_tab(src); te[u][1] = mclf_load_tab(src + 1);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int it = base + u * MCLF_MAXW;
+                if (it < nb2) {
+                    const int axis = it >= nbatch ? 1 : 0, b = it - axis * nbatch;
+                    mclf_stage_batch(f, MCLF_STAGE(axis), rr[u], b, lane);
+                } else if (it < items) {
+                    const int q = it - nb2, axis = q >= ntab[0] ? 1 : 0, slot = q - axis * ntab[0];
+                    mclf_tab_elem* dst = MCLF_STAGE(axis).tab + slot * MCLF_SUB + lane * MCLF_ITEMS;
+                    dst[0] = te[u][0];
+                    dst[1] = te[u][1];
+                }
+            }
+        }
+        __syncthreads();
+        MCLF_STAMP(2);
+        // ---- stage b: the list in sub-tile order (waves 0, 1), then one wave per gap
+        if (wave < 2) {
+            const mclf_stage a = MCLF_STAGE(wave);
+            const int n = min(*a.nent, MCLF_MAXENT);
+            const int mine = lane < n ? a.ent[lane].s : 0x7fffffff;
+            int rank = 0;
+            for (int j = 0; j < n; ++j) rank += (__builtin_amdgcn_readlane(mine, j) < mine) ? 1 : 0;
+            if (lane < n) a.order[rank] = lane;
+        }
+        __syncthreads();
+        {
+            const int n0 = min(*MCLF_STAGE(0).nent, MCLF_MAXENT), n1 = min(*MCLF_STAGE(1).nent, MCLF_MAXENT);
+            for (int it = wave; it < n0 + n1 + 2; it += MCLF_MAXW) {
+                const int axis = it > n0 ? 1 : 0, k = it - axis * (n0 + 1);
+                const mclf_stage a = MCLF_STAGE(axis);
+                const int n = axis ? n1 : n0;
+                const int pb = k > 0 ? (a.ent[a.order[k - 1]].s >> 6) : -1;
+                const int cb = k < n ? (a.ent[a.order[k]].s >> 6) : nbatch;
+                ss_rec g;
+                if (k > 0 && k < n && pb == cb) g = a.ent[a.order[k]].head;
+                else {
+                    g = k > 0 ? a.btail[pb] : ss_rec_identity();
+                    g = ss_rec_join(g, mclf_join_batches(a, pb + 1, cb - 1, lane));
+                    if (k < n) g = ss_rec_join(g, a.ent[a.order[k]].head);
+                }
+                if (lane == 0) {
+                    mclf_step sp;
+                    sp.gap = g;
+                    if (k < n) { const mclf_ent en = a.ent[a.order[k]]; sp.s = en.s; sp.tslot = en.tslot; sp.tkey = en.tkey; sp.lo_n = en.lo_n; }
+                    else { sp.s = nrec; sp.tslot = -1; sp.tkey = 0; sp.lo_n = -1; }
+                    a.step[k] = sp;
+                }
+            }
+        }
+        __syncthreads();
+    }
+    MCLF_STAMP(3);
+    if (wave < 2) {                                                                // wave 0: pose.x, wave 1: pose.y
+        unsigned int stats[4] = {0, 0, 0, 0};
+        const mclf_stage mine = MCLF_STAGE(wave);
+        const float v = mclf_chain(f, staged ? &mine : nullptr, wave ? ntab[1] : ntab[0], wave, S, sm.first[wave], lane, stats);
+        if (lane == 0) { sm.xy[wave] = v; for (int k = 0; k < 4; ++k) sm.stats[4 * wave + k] = stats[k]; }
+    }
+    __syncthreads();
+    MCLF_STAMP(4);
+    if (tid == 0) {
+        mclf_store_u64(f.sync, 0ull);                        // the next launch on this stream counts from zero again
+        double tot[5] = {0, 0, 0, 0, 0};
+        for (int w = 0; w < MCLF_POSE_THREADS / 64; ++w) for (int k = 0; k < 5; ++k) tot[k] += sm.red[w][k];
+        f.state->S = tot[0];
+        bl_pose_xyt_t p;
+        p.utime = f.utime;
+        p.x = sm.xy[0];
+        p.y = sm.xy[1];
+        p.theta = (float)atan2(tot[3], tot[4]);
+        f.state->pose = p;
+        if (s_pose_out) *s_pose_out = p;                     // shared memory: the caller's workgroup reads it behind its next barrier
+        for (int k = 0; k < 5; ++k) f.state->sums_used[k] = tot[k];
+        for (int k = 0; k < 8; ++k) f.state->chain_stats[k] = sm.stats[k];
+#ifdef MCLF_STAMPS
+        stamp[5] = MCLF_NOW();
+        for (int k = 0; k < 6; ++k) f.state->stamps[k] = stamp[k];
+#endif
+    }
 }
 #endif  // __HIPCC__
 

@@ -1,0 +1,127 @@
+// bl_serial_sum.h -- the reference's SERIALLY ROUNDED float accumulator, reproduced bit for bit by parallel code.
+//
+// estimatePosteriorPose (src/slam/particle_filter.cpp:144-160, lines 151-152) forms
+//       pose.x += p.weight * p.pose.x;          float += double * float
+// i.e.  acc <- fl32( fl64( (double)acc + t_i ) ),  t_i = fl64(w_i * x_i),  over the particles in order, from acc = 0.
+// Every step rounds, so the result depends on the order and no reduction tree reproduces it.  What makes it parallel:
+//
+//   While acc stays inside one binade, |acc| in [2^e, 2^(e+1)), write acc = s * M * u with u = 2^(e-23) (acc's ulp),
+//   M an integer in [2^23, 2^24), s = +-1.  A term with |t| < 2^(e-1) then advances M by an INTEGER that does not depend on M:
+//       fl64(acc + t) = acc + t',   t' = t rounded to a multiple of v = 2^(e-52)      (acc is a multiple of v; the tie rule
+//                                                                                      sees an even acc / v)
+//       fl32(acc + t') = s * (M + d) * u,   d = round(s * t' / u)                     (unless s*t'/u ends in exactly .5)
+//   as long as the result stays strictly inside the binade (2^23 < M + d < 2^24).  So inside a binade the accumulator is an
+//   integer prefix sum of the d_i; ss_quantize() forms d_i (and says "bad" for a tie or an oversized term, which must be
+//   stepped exactly).
+//
+//   A run of terms is summarised for a PREDICTED binade by ss_rec = (key, D, lo, hi): D = sum of the d_i, lo / hi = the
+//   smallest / largest inclusive prefix.  If the accumulator really arrives in that binade with magnitude M and
+//   2^23 < M + lo, M + hi < 2^24, every step of the run was an in-binade step and the run leaves M + D: a record is a
+//   function that is only ever APPLIED after this check (ss_rec_fits), so a wrong prediction costs time, never correctness.
+//   Records of consecutive runs compose associatively (ss_rec_join).  Wherever a record does not fit -- the accumulator
+//   crosses a binade (about log2 N times per sum), a tie, a change of sign, a term as large as the sum -- the run is replayed
+//   from the true accumulator (ss_replay): in-binade prefix sums up to the first step that leaves, that one step in real
+//   arithmetic (ss_exact_step), and on.
+//
+// The scalar core below is shared by the kernels (bl_mcl_finish.h) and by a CPU model of the whole scheme
+// (tests/cpp/serial_sum_model.cpp), which checks it against the plain loop on adversarial sequences without a GPU.
+#ifndef BL_SERIAL_SUM_H
+#define BL_SERIAL_SUM_H
+
+#include <math.h>
+#include <stdint.h>
+#include <string.h>
+
+#if defined(__HIPCC__)
+#define SS_HD __host__ __device__ __forceinline__
+#else
+#define SS_HD inline
+#endif
+
+#define SS_MLO (1 << 23)
+#define SS_MHI (1 << 24)
+#define SS_SAT (1 << 29)                          // |D|, |lo|, |hi| saturate here: sums of two stay inside int, and anything
+                                                  // this large is out of every binade's range anyway
+
+#define SS_ID 0x7fffffff                          // key of the empty run's record: fits everything, joins to the other side
+struct ss_rec { int key, D, lo, hi; };            // key 0: never fits
+
+SS_HD uint32_t ss_f2u(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
+SS_HD float ss_u2f(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
+
+// one step of the reference's loop
+SS_HD float ss_exact_step(float acc, double t) { return (float)((double)acc + t); }
+
+// Binade key of an accumulator: 0 if it has none that the integer form can use (zero, subnormal or tiny, inf, nan),
+// else 0x400 | sign << 9 | biased exponent.  Magnitude M = the 24-bit significand.
+SS_HD int ss_key(float acc)
+{
+    const uint32_t b = ss_f2u(acc);
+    const int ex = (int)((b >> 23) & 0xff);
+    if (ex < 16 || ex == 255) return 0;
+    return 0x400 | (int)((b >> 31) << 9) | ex;
+}
+SS_HD int ss_mag(float acc) { return (int)((ss_f2u(acc) & 0x7fffffu) | 0x800000u); }
+SS_HD float ss_from(int key, int M)                // 2^23 <= M <= 2^24 (M = 2^24 is the next binade's first value)
+{
+    const int ex = key & 0xff;
+    const float mag = ldexpf((float)M, ex - 127 - 23);            // exact: M has at most 25 significant bits only when it is 2^24
+    return (key & 0x200) ? -mag : mag;
+}
+
+// What the in-binade step needs of the binade: computed once per key.
+struct ss_bin { double lim, C; int down; int neg; };
+SS_HD ss_bin ss_bin_of(int key)
+{
+    const int e = (key & 0xff) - 127;
+    ss_bin b;
+    b.lim = ldexp(1.0, e - 1);          // terms must be smaller than a quarter of the binade's upper end
+    b.C = ldexp(1.5, e);                // middle of the binade: C + t keeps the binade's double ulp, C / v is even like acc / v
+    b.down = 23 - e;                    // scaling to units of u
+    b.neg = (key & 0x200) ? 1 : 0;
+    return b;
+}
+
+// d and bad for a term t while the accumulator is in binade b.  Branch-free: an oversized (or nan) term is quantized as 0
+// and flagged.
+SS_HD int ss_quantize(const ss_bin& b, double t, int* bad)
+{
+    const double ta = b.neg ? -t : t;
+    const bool big = !(fabs(ta) < b.lim);                       // also catches nan
+    const double tm = big ? 0.0 : ta;
+    const double tp = (tm + b.C) - b.C;                         // tm rounded to a multiple of 2^(e-52), ties to even
+    const double q = ldexp(tp, b.down);                         // exact, |q| < 2^22, a multiple of 2^-29
+    const double f = floor(q);
+    const double r = q - f;                                     // exact
+    *bad |= (big || r == 0.5) ? 1 : 0;
+    return (int)f + (r > 0.5 ? 1 : 0);
+}
+SS_HD int ss_quantize(int key, double t, int* bad) { return ss_quantize(ss_bin_of(key), t, bad); }
+
+SS_HD int ss_sat(long long v) { return v > SS_SAT ? SS_SAT : (v < -SS_SAT ? -SS_SAT : (int)v); }
+SS_HD int ss_sat_i(int v) { return v > SS_SAT ? SS_SAT : (v < -SS_SAT ? -SS_SAT : v); }
+
+SS_HD ss_rec ss_rec_make(int key, int D, int lo, int hi) { ss_rec r; r.key = key; r.D = D; r.lo = lo; r.hi = hi; return r; }
+SS_HD ss_rec ss_rec_identity() { return ss_rec_make(SS_ID, 0, 0, 0); }
+
+// a, then b (branch-free)
+SS_HD ss_rec ss_rec_join(const ss_rec& a, const ss_rec& b)
+{
+    const bool ida = a.key == SS_ID, idb = b.key == SS_ID;
+    const int D = ss_sat_i(a.D + b.D), blo = ss_sat_i(a.D + b.lo), bhi = ss_sat_i(a.D + b.hi);
+    ss_rec r;
+    r.key = ida ? b.key : (idb ? a.key : (a.key == b.key ? a.key : 0));
+    r.D = ida ? b.D : (idb ? a.D : D);
+    r.lo = ida ? b.lo : (idb ? a.lo : (a.lo < blo ? a.lo : blo));
+    r.hi = ida ? b.hi : (idb ? a.hi : (a.hi > bhi ? a.hi : bhi));
+    return r;
+}
+
+// may the record be applied to an accumulator with this key and magnitude?
+SS_HD bool ss_rec_fits(const ss_rec& r, int key, int M)
+{
+    const bool in = r.key != 0 && r.key == key && M + r.lo > SS_MLO && M + r.hi < SS_MHI;
+    return r.key == SS_ID || in;
+}
+
+#endif  // BL_SERIAL_SUM_H

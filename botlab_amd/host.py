@@ -302,6 +302,18 @@ class ParticleFilter:
     def poseDevicePtr(self):
         return self.ctx.lib.bl_pf_pose_device_ptr(self.h)
 
+    def estimatePosteriorPose(self):
+        """estimatePosteriorPose(posterior_) of the particles as they stand (particle_filter.cpp:144-160)."""
+        out = Pose()
+        check(self.ctx.lib.bl_pf_estimate_posterior_pose(self.h, C.byref(out)))
+        return out
+
+    def debugEstimateStats(self):
+        """Per axis (x, then y): generic replays, their phases, table replays, gaps walked the slow way."""
+        out = np.zeros(8, np.uint32)
+        check(self.ctx.lib.bl_pf_debug_estimate_stats(self.h, out.ctypes.data))
+        return [int(v) for v in out]
+
     def particles(self):
         """particles_t.particles of the local shard as a structured array."""
         out = np.zeros(self.hi - self.lo, dtype=PARTICLE_DTYPE)

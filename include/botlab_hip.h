@@ -147,6 +147,12 @@ int bl_pf_update_end(bl_pf* pf, bl_pose_xyt_t* out_pose);
 int bl_pf_update_action_only(bl_pf* pf, const bl_pose_xyt_t* odometry, const float* noise, bl_pose_xyt_t* out_pose);
 int bl_pf_pose_estimate(bl_pf* pf, bl_pose_xyt_t* out_pose);              /* poseEstimate() (synchronises) */
 const void* bl_pf_pose_device_ptr(bl_pf* pf);                             /* bl_pose_xyt_t in HBM */
+/* estimatePosteriorPose(posterior_) (particle_filter.cpp:144-160) of the particles as they stand (all N on this device or
+ * replicated): x / y the reference's serially rounded float sums, bit for bit; becomes poseEstimate().  out_pose may be NULL. */
+int bl_pf_estimate_posterior_pose(bl_pf* pf, bl_pose_xyt_t* out_pose);
+/* diagnostics of the last estimate, eight values: for the x sum, then for the y sum -- sub-tiles replayed generically, phases
+ * of those replays, sub-tiles stepped through by their table, gaps walked the slow way (bl_serial_sum.h, bl_mcl_finish.h) */
+int bl_pf_debug_estimate_stats(bl_pf* pf, uint32_t* out8);
 /* diagnostics for the parity tests: resample source index and raw likelihood (half-units) of the local shard of the last
  * update; recorded only while enabled (8 B per particle of extra stores) */
 int bl_pf_debug_enable(bl_pf* pf, int on);

@@ -1,0 +1,157 @@
+// CPU model of the serially-rounded-accumulator scheme of botlab_amd/csrc/bl_serial_sum.h, lane for lane as the kernels run it
+// (sub-tiles of 64 lanes x SS_ITEMS terms, records for a predicted binade, batches of 64 records scanned by composition, replay
+// of what does not fit), checked against the plain loop of estimatePosteriorPose (particle_filter.cpp:151-152) on random and
+// adversarial sequences.  Test infrastructure: built and run by tests/test_serial_sum_model.py, no GPU.
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <random>
+#include <vector>
+
+#include "../../botlab_amd/csrc/bl_serial_sum.h"
+
+static const int ITEMS = 2, LANES = 64, SUB = ITEMS * LANES;
+
+static float plain_loop(const std::vector<double>& t)
+{
+    float acc = 0.0f;
+    for (double v : t) acc = (float)((double)acc + v);
+    return acc;
+}
+
+struct Stats { long records = 0, fitted = 0, replays = 0, phases = 0, exact_steps = 0, batches = 0; };
+
+// ---- stage A: the record of sub-tile s for a predicted start value
+static ss_rec make_record(const std::vector<double>& t, int s, double predicted_start)
+{
+    const int key = ss_key((float)predicted_start);
+    ss_rec r = ss_rec_make(key, 0, 0, 0);
+    if (!key) return r;
+    int bad = 0;
+    long long run = 0, lo = (1ll << 40), hi = -(1ll << 40);
+    for (int i = s * SUB; i < (s + 1) * SUB && i < (int)t.size(); ++i) {
+        run += ss_quantize(key, t[i], &bad);
+        if (run < lo) lo = run;
+        if (run > hi) hi = run;
+    }
+    if (bad) { r.key = 0; return r; }
+    r.D = ss_sat(run); r.lo = ss_sat(lo); r.hi = ss_sat(hi);
+    return r;
+}
+
+// ---- replay of sub-tile s from the true accumulator: the wave's phase loop
+static float replay(const std::vector<double>& t, int s, float acc, Stats& st)
+{
+    const int base = s * SUB, n = std::min(SUB, (int)t.size() - base);
+    int pos = 0;
+    st.replays++;
+    while (pos < n) {
+        const int key = ss_key(acc);
+        if (!key) { acc = ss_exact_step(acc, t[base + pos]); pos++; st.exact_steps++; continue; }
+        st.phases++;
+        const int M = ss_mag(acc);
+        // every lane: its terms from pos on, inclusive prefix, exit test
+        int d[SUB], bad[SUB];
+        for (int i = 0; i < n; ++i) { bad[i] = 0; d[i] = i >= pos ? ss_quantize(key, t[base + i], &bad[i]) : 0; }
+        long long run = 0;
+        int first_exit = -1;
+        long long Mi[SUB];
+        for (int i = 0; i < n; ++i) {
+            run += d[i];
+            Mi[i] = M + run;
+            if (i >= pos && first_exit < 0 && (bad[i] || Mi[i] <= SS_MLO || Mi[i] >= SS_MHI)) first_exit = i;
+        }
+        if (first_exit < 0) { acc = ss_from(key, (int)Mi[n - 1]); pos = n; break; }
+        const long long Mb = first_exit == pos ? M : Mi[first_exit - 1];
+        acc = ss_exact_step(ss_from(key, (int)Mb), t[base + first_exit]);
+        st.exact_steps++;
+        pos = first_exit + 1;
+    }
+    return acc;
+}
+
+// ---- the chain: batches of 64 records; inside a batch the inclusive composition scan finds the first record that does not fit
+static float chain(const std::vector<double>& t, const std::vector<ss_rec>& recs, Stats& st)
+{
+    float acc = 0.0f;
+    const int nrec = (int)recs.size();
+    int r0 = 0;
+    while (r0 < nrec) {
+        st.batches++;
+        const int nb = std::min(LANES, nrec - r0);
+        const int key = ss_key(acc), M = key ? ss_mag(acc) : 0;
+        ss_rec pre[LANES];
+        int first_bad = nb;
+        for (int l = 0; l < nb; ++l) {
+            pre[l] = l ? ss_rec_join(pre[l - 1], recs[r0 + l]) : recs[r0 + l];
+            if (first_bad == nb && !(key && ss_rec_fits(pre[l], key, M))) first_bad = l;
+        }
+        if (first_bad > 0 && pre[first_bad - 1].key != SS_ID) acc = ss_from(key, M + pre[first_bad - 1].D);
+        st.fitted += first_bad;
+        if (first_bad < nb) acc = replay(t, r0 + first_bad, acc, st);
+        r0 += first_bad + (first_bad < nb ? 1 : 0);
+    }
+    return acc;
+}
+
+static float scheme(const std::vector<double>& t, int predict_mode, std::mt19937_64& rng, Stats& st)
+{
+    const int nrec = ((int)t.size() + SUB - 1) / SUB;
+    std::vector<ss_rec> recs(nrec);
+    double P = 0.0;                                    // the prediction: a double-precision running sum
+    for (int s = 0; s < nrec; ++s) {
+        double start = P;
+        if (predict_mode == 1) start = P * (1.0 + 1e-3 * ((double)(rng() % 2001) - 1000.0) / 1000.0);      // sloppy
+        if (predict_mode == 2) start = ldexp(1.0 + (double)(rng() % 1000) / 1000.0, (int)(rng() % 60) - 40) * ((rng() & 1) ? 1 : -1);  // nonsense
+        recs[s] = make_record(t, s, start);
+        for (int i = s * SUB; i < (s + 1) * SUB && i < (int)t.size(); ++i) P += t[i];
+    }
+    st.records += nrec;
+    return chain(t, recs, st);
+}
+
+int main(int argc, char** argv)
+{
+    const int rounds = argc > 1 ? atoi(argv[1]) : 60;
+    std::mt19937_64 rng(12345);
+    std::normal_distribution<double> nd(0.0, 1.0);
+    long cases = 0, failures = 0;
+    Stats st;
+    for (int round = 0; round < rounds; ++round) {
+        for (int kind = 0; kind < 10; ++kind) {
+            int n = 1 + (int)(rng() % (round % 7 == 0 ? 300000 : 5000));
+            if (kind == 9) n = 1 + (int)(rng() % 400);
+            std::vector<double> t(n);
+            const double centre = (kind & 1) ? 0.0 : ldexp(1.0, (int)(rng() % 12) - 6) * ((rng() & 2) ? 1 : -1);
+            const double spread = ldexp(1.0, (int)(rng() % 10) - 8);
+            const double w = 1.0 / n;
+            for (int i = 0; i < n; ++i) {
+                const float x = (float)(centre + spread * nd(rng));
+                switch (kind) {
+                case 0: case 1: t[i] = (w * (1.0 + 0.5 * nd(rng))) * (double)x; break;            // weights x poses: the real thing
+                case 2: t[i] = w * (double)(float)centre; break;                                   // all terms equal
+                case 3: t[i] = ldexp((double)((int)(rng() % 33) - 16), -20 - (int)(rng() % 4)); break;          // few significant bits: ties galore
+                case 4: t[i] = ldexp(nd(rng), (int)(rng() % 80) - 60); break;                      // wild dynamic range
+                case 5: t[i] = (i % 97 == 0) ? -0.9 * (double)i * w : w * (double)x; break;          // big negative jolts: falls through binades and zero
+                case 6: t[i] = (rng() % 5 == 0) ? 0.0 : w * (double)x; break;
+                case 7: t[i] = ldexp(1.0, -24) * (double)((rng() % 3) + 1) * ((rng() & 1) ? 0.5 : 1.0); break; // halves of an ulp near 1.0 once summed
+                case 8: t[i] = (i & 1) ? w * (double)x : -w * (double)x * (1.0 - 1e-7); break;    // cancelling pairs around zero
+                default: t[i] = w * (double)x; break;
+                }
+            }
+            const float want = plain_loop(t);
+            for (int mode = 0; mode < 3; ++mode) {
+                const float got = scheme(t, mode, rng, st);
+                cases++;
+                if (ss_f2u(got) != ss_f2u(want) && !(got != got && want != want)) {
+                    if (failures < 10) fprintf(stderr, "MISMATCH kind %d n %d mode %d: got %.9g want %.9g\n", kind, n, mode, got, want);
+                    failures++;
+                }
+            }
+        }
+    }
+    printf("cases %ld failures %ld records %ld fitted %ld replays %ld phases %ld exact_steps %ld batches %ld\n", cases, failures, st.records,
+           st.fitted, st.replays, st.phases, st.exact_steps, st.batches);
+    return failures ? 1 : 0;
+}

@@ -145,6 +145,14 @@ def test_mapping_unusual_shapes(oracle, maps, gpu_ctx, rays, mpc, max_laser):
 
 
 # ------------------------------------------------------------------ ParticleFilter
+def _assert_estimate_bit_equal(pose, want, where):
+    """estimatePosteriorPose (particle_filter.cpp:144-160): pose.x / pose.y are the reference's serially rounded FLOAT
+    accumulators, reproduced bit for bit (bl_serial_sum.h); theta = (float)atan2 of two double sums."""
+    got = np.array([pose.x, pose.y, pose.theta], np.float32).view(np.uint32)
+    exp = np.array([want.x, want.y, want.theta], np.float32).view(np.uint32)
+    assert np.array_equal(got, exp), (where, (pose.x, pose.y, pose.theta), (want.x, want.y, want.theta))
+
+
 def _mcl_sequence(oracle, maps, gpu_ctx, N, steps, name="obstacle_slam_10mx10m_5cm", seed=1):
     m, truth, poses, scans = _drive(maps, name, steps, seed)
     rng = np.random.default_rng(seed + 100)
@@ -186,21 +194,16 @@ def test_mcl_parity_with_oracle_noise(oracle, maps, gpu_ctx, N):
             assert np.array_equal(got[f], exp[f]), (k, f)      # in practice bit-equal; a failure here is informational
         assert np.array_equal(got["utime"], exp["utime"]) and np.array_equal(got["p_utime"], exp["p_utime"])
         assert np.allclose(got["weight"], exp["weight"], rtol=REL, atol=0)
-        # pose estimate: the reference accumulates x, y in a float (order-dependent rounding up to ~N * 2^-24 relative);
-        # the kernel reduces in double.  Tolerance 1e-5 relative + float epsilon absolute.
-        for f in ("x", "y", "theta"):
-            a, b = getattr(pose, f), getattr(res["pose"], f)
-            assert abs(a - b) <= REL * abs(b) + 2e-6, (k, f, a, b)
+        _assert_estimate_bit_equal(pose, res["pose"], (N, k))
     assert moved_updates >= 7
 
 
 @pytest.mark.parametrize("N", [100_000, 300_000])
 def test_mcl_parity_at_the_headline_size(oracle, maps, gpu_ctx, N):
     """BASELINE.json's configuration itself -- 100 000 particles, 290 rays, the shipped obstacle_slam map -- against the
-    oracle consuming the same noise: resampling indices and likelihoods exact, particle poses bit-equal, weights and pose
-    estimate within 1e-5 relative (the launch shape of this size: 4 lanes per particle, shared prologue, both regions);
-    and 300 000 particles, the one-lane-per-particle shape of the large configurations (estimate: 2e-5, the reference's own
-    float accumulation error grows with N)."""
+    oracle consuming the same noise: resampling indices and likelihoods exact, particle poses bit-equal, weights within 1e-5
+    relative, pose estimate bit-equal (the launch shape of this size: 4 lanes per particle, shared prologue, both regions);
+    and 300 000 particles, the one-lane-per-particle shape of the large configurations."""
     m = maps["obstacle_slam_10mx10m_5cm"]
     truth = np.where(m["cells"] > 0, 127, -127).astype(np.int8)
     g = _grid_from_map(m, gpu_ctx)
@@ -230,10 +233,7 @@ def test_mcl_parity_at_the_headline_size(oracle, maps, gpu_ctx, N):
         for f in ("x", "y", "theta", "p_x", "p_y", "p_theta"):
             assert np.array_equal(got[f], exp[f]), (k, f)
         assert np.allclose(got["weight"], exp["weight"], rtol=REL, atol=0)
-        tol = REL if N <= 100_000 else 2 * REL
-        for f in ("x", "y", "theta"):
-            a, b = getattr(pose, f), getattr(res["pose"], f)
-            assert abs(a - b) <= tol * abs(b) + 2e-6, (k, f, a, b)
+        _assert_estimate_bit_equal(pose, res["pose"], (N, k))
     assert moved == 2
 
 
