@@ -440,6 +440,16 @@ __device__ __forceinline__ void resample_bracket(const unsigned long long* __res
     if (lo0 == hi0 && lo1 == hi1) { *out_lo = lo0; *out_hi = lo1; }             // (else the full range stands)
 }
 
+// second part: the lane's own bisection inside the bracket.  index(T) = first i with T <= prefix[i] (clamped by the bracket).
+__device__ __forceinline__ int resample_bisect(const unsigned long long* __restrict__ prefix, double T, int lo, int hi)
+{
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (T <= (double)prefix[mid]) hi = mid; else lo = mid + 1;
+    }
+    return lo;
+}
+
 // Row-wise staging by `n_sw` whole waves (this one is number `sw` of them, wave-uniform): lane = dword column of the LDS row,
 // `MCL_STAGE_ROWS` rows in flight per wave.  The row index is scalar, so a load costs no address arithmetic beyond one add
 // and the frame rows are a scalar branch (the thread-strided form spent ~20 vector instructions per dword on indices and
@@ -599,15 +609,7 @@ __global__ __launch_bounds__(BLOCK) void k_mcl_main(mcl_args a)
         resample_bracket(a.prefix, a.N, rs_T, pro_active, lane, &rs_lo, &rs_hi);
     }
     if (pro_active) {
-        if (a.resample) {
-            const double T = rs_T;
-            int lo = rs_lo, hi = rs_hi;
-            while (lo < hi) {
-                const int mid = (lo + hi) >> 1;
-                if (T <= (double)a.prefix[mid]) hi = mid; else lo = mid + 1;
-            }
-            i = lo;
-        }
+        if (a.resample) i = resample_bisect(a.prefix, rs_T, rs_lo, rs_hi);
         s = a.src[i];
         // ---- ActionModel::applyAction (action_model.cpp:78-103)
         float n1, n2, n3;
@@ -831,6 +833,19 @@ __global__ __launch_bounds__(MCLF_WG) void k_mcl_finish(mcl_finish_args f)
     extern __shared__ __align__(16) char s_fin_scratch[];                  // MCLF_LDS_BYTES (the groups do not touch it)
     if (blockIdx.x == 0) mclf_pose(f, sm, s_fin_scratch, (size_t)MCLF_LDS_BYTES);
     else mclf_prefix_group(f, (int)blockIdx.x - 1, sm);
+}
+
+// resamplePosteriorDistribution alone (particle_filter.cpp:84-103): the source index of every output particle, by exactly the
+// search k_mcl_main runs (diagnostic entry bl_pf_debug_resample)
+__global__ __launch_bounds__(256) void k_pf_resample_only(const unsigned long long* __restrict__ prefix, const pf_state* __restrict__ state,
+                                                          int N, double r, double M_inv, int32_t* __restrict__ out)
+{
+    const int m = blockIdx.x * blockDim.x + threadIdx.x, lane = threadIdx.x & 63;
+    const bool on = m < N;
+    const double T = on ? (r + m * M_inv) * state->S : 0.0;
+    int lo, hi;
+    resample_bracket(prefix, N, T, on, lane, &lo, &hi);
+    if (on) out[m] = resample_bisect(prefix, T, lo, hi);
 }
 
 // ---------------------------------------------------------------- init / export / small state kernels
@@ -1468,6 +1483,22 @@ extern "C" int bl_pf_debug_estimate_stats(bl_pf* pf, uint32_t* out4)   /* eight 
         fprintf(stderr, "finisher timeline (us): groups done +%.2f, staged a +%.2f, staged b +%.2f, chains +%.2f, exit +%.2f\n", (st[1] - st[0]) * 0.01,
                 (st[2] - st[1]) * 0.01, (st[3] - st[2]) * 0.01, (st[4] - st[3]) * 0.01, (st[5] - st[4]) * 0.01);
     }
+    return BL_OK;
+}
+
+extern "C" int bl_pf_debug_resample(bl_pf* pf, int rand_value, int32_t* out_idx)
+{
+    BL_CHECK_ARG(pf != nullptr && out_idx != nullptr);
+    if (!pf->initialized || pf->pending_end) { bl_set_error("filter not initialised or update pending"); return BL_ERR_STATE; }
+    if (pf->n_local != pf->N) { bl_set_error("bl_pf_debug_resample needs the whole particle set on one device"); return BL_ERR_ARG; }
+    BL_HIP(hipSetDevice(pf->ctx->device));
+    const double M_inv = 1.0 / pf->N;                                              // particle_filter.cpp:89
+    const double r = (((double)rand_value) / (double)RAND_MAX) * M_inv;            // particle_filter.cpp:92
+    hipLaunchKernelGGL(k_pf_resample_only, dim3((pf->N + 255) / 256), dim3(256), 0, pf->ctx->stream, pf->prefix, pf->state, pf->N, r, M_inv,
+                       pf->dbg_idx);
+    BL_HIP(hipGetLastError());
+    BL_HIP(hipMemcpyAsync(out_idx, pf->dbg_idx, (size_t)pf->N * 4, hipMemcpyDeviceToHost, pf->ctx->stream));
+    BL_HIP(hipStreamSynchronize(pf->ctx->stream));
     return BL_OK;
 }
 

@@ -308,6 +308,12 @@ class ParticleFilter:
         check(self.ctx.lib.bl_pf_estimate_posterior_pose(self.h, C.byref(out)))
         return out
 
+    def debugResample(self, rand_value):
+        """Source index of every output particle of resamplePosteriorDistribution for this rand() value (particle_filter.cpp:84-103)."""
+        idx = np.empty(self.N, np.int32)
+        check(self.ctx.lib.bl_pf_debug_resample(self.h, int(rand_value), idx.ctypes.data))
+        return idx
+
     def debugEstimateStats(self):
         """Per axis (x, then y): generic replays, their phases, table replays, gaps walked the slow way."""
         out = np.zeros(8, np.uint32)

@@ -153,6 +153,9 @@ int bl_pf_estimate_posterior_pose(bl_pf* pf, bl_pose_xyt_t* out_pose);
 /* diagnostics of the last estimate, eight values: for the x sum, then for the y sum -- sub-tiles replayed generically, phases
  * of those replays, sub-tiles stepped through by their table, gaps walked the slow way (bl_serial_sum.h, bl_mcl_finish.h) */
 int bl_pf_debug_estimate_stats(bl_pf* pf, uint32_t* out8);
+/* resamplePosteriorDistribution alone (particle_filter.cpp:84-103): the source index each output particle would take for this
+ * rand() value, by the very search the update kernel runs; num_particles entries (whole set on this device; synchronises) */
+int bl_pf_debug_resample(bl_pf* pf, int rand_value, int32_t* out_idx);
 /* diagnostics for the parity tests: resample source index and raw likelihood (half-units) of the local shard of the last
  * update; recorded only while enabled (8 B per particle of extra stores) */
 int bl_pf_debug_enable(bl_pf* pf, int on);

@@ -1003,6 +1003,13 @@ void orc_likelihood(const orc_particle_t* p, int n, const orc_lidar_t* scan, con
 {
     for (int i = 0; i < n; ++i) out[i] = likelihood(p[i], *scan, *map);
 }
+// resamplePosteriorDistribution alone (particle_filter.cpp:84-103 with D4): source index per output particle
+void orc_resample_indices(const orc_particle_t* p, int n, int rand_value, int32_t* idx)
+{
+    ParticleFilter pf(n);
+    pf.posterior.assign(p, p + n);
+    pf.resample(rand_value, idx);
+}
 void orc_estimate_pose(const orc_particle_t* p, int n, orc_pose_t* out)
 {
     std::vector<orc_particle_t> v(p, p + n);

@@ -79,6 +79,7 @@ class Oracle:
         L.orc_pf_action_state.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_int)]
         L.orc_likelihood.argtypes = [C.c_void_p, C.c_int, C.POINTER(OLidar), C.POINTER(OGrid), C.c_void_p]
         L.orc_estimate_pose.argtypes = [C.c_void_p, C.c_int, C.POINTER(OPose)]
+        L.orc_resample_indices.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
         L.orc_set_distances.argtypes = [C.POINTER(OGrid), C.POINTER(OGrid)]
         L.orc_search_for_path.restype = C.c_int
         L.orc_search_for_path.argtypes = [C.POINTER(OPose), C.POINTER(OPose), C.POINTER(OGrid), C.POINTER(OSearchParams),

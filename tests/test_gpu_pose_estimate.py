@@ -1,0 +1,83 @@
+"""estimatePosteriorPose (particle_filter.cpp:144-160) on its own: bl_pf_estimate_posterior_pose against the oracle's plain
+loop (a float accumulator stepped over the particles in order) on particle sets chosen to exercise every path of
+bl_serial_sum.h / bl_mcl_finish.h -- sums that cross binades, hover around zero, change sign, tie, sets of every awkward size,
+weights spanning five decades.  x and y must be BIT-EQUAL; theta is (float)atan2 of two double sums."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import botlab_amd as bl
+import oracle_lib
+from botlab_amd.host import PARTICLE_DTYPE
+
+pytestmark = pytest.mark.gpu
+
+
+def _check(oracle, ctx, x, y, theta, units, tag):
+    N = len(x)
+    p = np.zeros(N, PARTICLE_DTYPE)
+    p["x"], p["y"], p["theta"] = x.astype(np.float32), y.astype(np.float32), theta.astype(np.float32)
+    pf = bl.ParticleFilter(N, ctx=ctx)
+    try:
+        pf.setParticles(p, units.astype(np.uint32))
+        est = pf.estimatePosteriorPose()
+        got = pf.particles()                                # carries the weights units / S as the library hands them out
+        assert np.array_equal(got["x"], p["x"]) and np.array_equal(got["y"], p["y"])
+        want = oracle_lib.OPose()
+        oracle.lib.orc_estimate_pose(np.ascontiguousarray(got).ctypes.data, N, C.byref(want))
+        a = np.array([est.x, est.y], np.float32).view(np.uint32)
+        b = np.array([want.x, want.y], np.float32).view(np.uint32)
+        assert np.array_equal(a, b), (tag, N, (est.x, est.y), (want.x, want.y), pf.debugEstimateStats())
+        assert abs(est.theta - want.theta) <= 1e-6, (tag, est.theta, want.theta)
+        return pf.debugEstimateStats()
+    finally:
+        pf.close()
+
+
+@pytest.mark.parametrize("N", [2, 3, 63, 64, 65, 127, 128, 129, 255, 257, 511, 512, 513, 1000, 2047, 2049, 4097, 12345, 100_001])
+def test_estimate_sizes(oracle, gpu_ctx, N):
+    rng = np.random.default_rng(N)
+    x = -0.75 + 0.02 * rng.standard_normal(N)
+    y = 0.2 + 0.02 * rng.standard_normal(N)
+    _check(oracle, gpu_ctx, x, y, 0.1 * rng.standard_normal(N), 1000 * rng.integers(1, 400, N), "sizes")
+
+
+CASES = {
+    "near_zero": lambda r, n: (0.001 + 0.02 * r.standard_normal(n), -0.0005 + 0.02 * r.standard_normal(n)),
+    "zero_mean": lambda r, n: (0.05 * r.standard_normal(n), 0.05 * r.standard_normal(n)),
+    "all_equal": lambda r, n: (np.full(n, 0.3), np.full(n, -7.25)),
+    "far_away": lambda r, n: (97.5 + 0.3 * r.standard_normal(n), -51.0 + 0.3 * r.standard_normal(n)),
+    "sign_flips": lambda r, n: (np.where(np.arange(n) % 97 == 0, -30.0, 0.4) + 0.01 * r.standard_normal(n), np.where(np.arange(n) < n // 2, 1.0, -1.0) * (1 + 0.01 * r.standard_normal(n))),
+    "few_bits": lambda r, n: (r.integers(-8, 9, n) / 16.0, r.integers(0, 5, n) / 4.0),          # ties: terms with few significant bits
+    "zeros_mixed": lambda r, n: (np.where(r.random(n) < 0.3, 0.0, 0.5), np.where(r.random(n) < 0.9, 0.0, -2.0)),
+}
+
+
+@pytest.mark.parametrize("case", sorted(CASES))
+@pytest.mark.parametrize("N", [4096, 30_000])
+def test_estimate_adversarial_clouds(oracle, gpu_ctx, case, N):
+    rng = np.random.default_rng(abs(hash(case)) % 1000 + N)
+    x, y = CASES[case](rng, N)
+    units = 1000 * rng.integers(1, 400, N)
+    if case == "few_bits":
+        units = np.full(N, 1 << 10)               # weights 1 / N with N a power of two times ...: products with few bits
+    _check(oracle, gpu_ctx, np.asarray(x, np.float64), np.asarray(y, np.float64), rng.uniform(-3, 3, N), units, case)
+
+
+def test_estimate_weights_over_five_decades_and_floors(oracle, gpu_ctx):
+    N = 50_000
+    rng = np.random.default_rng(5)
+    units = np.where(rng.random(N) < 0.4, 2, 1000 * rng.integers(1, 580, N))        # 2 = the 0.001 floor (particle_filter.cpp:128-130)
+    units[::1000] = 1000 * 36_830                                                     # 290 rays x 127: the largest likelihood there is
+    _check(oracle, gpu_ctx, 1.5 + 0.1 * rng.standard_normal(N), -2.5 + 0.1 * rng.standard_normal(N), rng.uniform(-3, 3, N), units, "decades")
+
+
+def test_estimate_large_set_uses_the_fast_paths(oracle, gpu_ctx):
+    """300 000 particles (the large-group launch shape): bit-equal, and the chain went by tables and gaps -- a handful of
+    generic replays at most, no gap walked the slow way."""
+    N = 300_000
+    rng = np.random.default_rng(8)
+    st = _check(oracle, gpu_ctx, -0.75 + 0.02 * rng.standard_normal(N), 0.2 + 0.02 * rng.standard_normal(N), 0.1 * rng.standard_normal(N),
+                1000 * rng.integers(20, 400, N), "large")
+    assert st[2] >= 8 and st[6] >= 8 and st[0] <= 4 and st[4] <= 4 and st[3] == 0 and st[7] == 0, st

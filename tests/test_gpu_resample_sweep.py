@@ -1,0 +1,80 @@
+"""How often does the resampler pick another source particle than the reference?
+
+resamplePosteriorDistribution (particle_filter.cpp:84-103) compares U_m = r + m / N with a cumulative weight c_i that is a
+SEQUENTIALLY ROUNDED double sum; the kernels compare U_m * S with an exact integer prefix of the weight units.  The two rules can
+part only where U_m lies within the rounding error of c_i of a partial sum.  This sweep counts the output particles whose
+source index differs from the oracle's, over rand() values {0, 1, 1000, 2^30, RAND_MAX, glibc's first sixteen} and N in {4096,
+100k, 300k}, for three kinds of weights, and asserts the bounds DESIGN.md quotes:
+  * weights as an update leaves them (integer likelihoods, a few floored to 0.001): no difference at all;
+  * weights of a fresh filter (all equal -- D2): every U_m sits ON a partial sum when r is 0, nearly 0 or exactly 1 / N
+    (rand() <= ~1000 or == RAND_MAX: a 5e-7 chance on the ONE update that follows initialisation), so there the choice is
+    decided by rounding on both sides; the differences are counted (half to three quarters of the particles, each off by
+    one index) and bounded; for every other r: none."""
+import ctypes as C
+import json
+import os
+
+import numpy as np
+import pytest
+
+import botlab_amd as bl
+from botlab_amd.host import PARTICLE_DTYPE
+
+pytestmark = pytest.mark.gpu
+
+RAND_MAX = 2147483647
+GLIBC = [1804289383, 846930886, 1681692777, 1714636915, 1957747793, 424238335, 719885386, 1649760492, 596516649, 1189641421,
+         1025202362, 1350490027, 783368690, 1102520059, 2044897763, 1967513926]
+EDGE = [0, 1, 1000, 1 << 30, RAND_MAX]
+
+
+def _sweep(oracle, ctx, N, units):
+    p = np.zeros(N, PARTICLE_DTYPE)
+    rng = np.random.default_rng(N)
+    p["x"] = rng.standard_normal(N).astype(np.float32)
+    pf = bl.ParticleFilter(N, ctx=ctx)
+    out = {}
+    try:
+        pf.setParticles(p, units)
+        host = np.ascontiguousarray(pf.particles())          # the weights units / S as doubles: what the reference would hold
+        want = np.empty(N, np.int32)
+        for rv in EDGE + GLIBC:
+            got = pf.debugResample(rv)
+            oracle.lib.orc_resample_indices(host.ctypes.data, N, rv, want.ctypes.data)
+            d = np.nonzero(got != want)[0]
+            assert np.all(np.abs(got[d].astype(np.int64) - want[d]) <= 1), (N, rv)        # never farther than the neighbour
+            out[rv] = int(d.size)
+    finally:
+        pf.close()
+    return out
+
+
+@pytest.mark.parametrize("N", [4096, 100_000, 300_000])
+def test_resample_index_disagreements_are_counted_and_bounded(oracle, gpu_ctx, N):
+    rng = np.random.default_rng(7 * N)
+    report = {}
+    # (a) weights as updateFilter leaves them: likelihood sums of 290 rays in half-units (x1000), some particles at the floor (2)
+    units = (1000 * rng.integers(40, 36000, N)).astype(np.uint32)
+    units[rng.random(N) < 0.02] = 2
+    report["after_update"] = _sweep(oracle, gpu_ctx, N, units)
+    assert sum(report["after_update"].values()) == 0, report
+    # (b) a narrower spread (a converged filter: nearly equal likelihoods)
+    units = (1000 * rng.integers(30000, 30400, N)).astype(np.uint32)
+    report["converged"] = _sweep(oracle, gpu_ctx, N, units)
+    assert sum(report["converged"].values()) == 0, report
+    # (c) a fresh filter: all weights 1 / N
+    report["uniform"] = _sweep(oracle, gpu_ctx, N, np.ones(N, np.uint32))
+    # r = 0, r ~ 0 and r = 1 / N (rand() == RAND_MAX) put EVERY U_m on a partial sum m / N of the equal weights: which side the
+    # reference's rounded cumulative falls on is rounding noise, and about half of the particles take the neighbouring source
+    # (index + 1 or - 1, never farther -- checked in _sweep).  Everything else is clear of the partial sums.
+    # (at 300k particles the rounded cumulative is off by up to i * 2^-54 ~ 1.6e-11 at the end, more than the r = 1.5e-12 of
+    # rand() == 1000: that value is "nearly 0" there as well)
+    degenerate = [0, 1, 1000, RAND_MAX]
+    ordinary = [rv for rv in EDGE + GLIBC if rv not in degenerate]
+    assert all(report["uniform"][rv] == 0 for rv in ordinary), report["uniform"]
+    assert all(report["uniform"][rv] <= N for rv in degenerate), report["uniform"]
+    if N <= 100_000:
+        assert report["uniform"][1000] == 0
+    os.makedirs("gpurun_out", exist_ok=True)
+    with open(os.path.join("gpurun_out", f"resample_sweep_{N}.json"), "w") as fh:
+        json.dump({k: {str(r): c for r, c in v.items()} for k, v in report.items()}, fh)
