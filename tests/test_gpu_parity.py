@@ -355,7 +355,55 @@ def test_mcl_parity_large_grid_lds_window(oracle, maps, gpu_ctx, start, kidnap, 
         for f in ("x", "y", "theta"):
             assert np.allclose(got[f], exp[f], rtol=REL, atol=1e-7)
         assert np.allclose(got["weight"], exp["weight"], rtol=REL, atol=0)
+        _assert_estimate_bit_equal(pose, res["pose"], (start, kidnap, k))
         assert corner or (res["raw"] > 0).sum() > N // 2        # the scans really hit the map
+
+
+@pytest.mark.parametrize("where", ["centre", "corner"])
+def test_mcl_parity_at_config5_shape(oracle, maps, gpu_ctx, where):
+    """BASELINE.json configs[4]'s shape: a 4096x4096 grid (16 MiB: LDS window mode at full stride, zero-framed copy) and
+    256 000 particles (one lane per particle, the large finish groups), two moved updates against the oracle consuming the same
+    noise: resampling indices, likelihoods, particle poses and the pose estimate exact.  "corner": the cloud sits in the grid's
+    last corner, so the window hangs over two edges of the grid at that stride and most rays leave the map."""
+    N, size = 256_000, 4096
+    world = synth.tile_world(maps["astar_maze"]["cells"], size)
+    half = size * 0.05 / 2.0
+    origin, mpc, cpm = (np.float32(-half), np.float32(-half)), np.float32(0.05), helpers.CPM_DEFAULT
+    if where == "corner":
+        free = np.argwhere(world[-40:, -40:] <= 0) + (size - 40)
+        cy_, cx_ = free[len(free) // 2]
+        start = (-half + (cx_ + 0.5) * 0.05, -half + (cy_ + 0.5) * 0.05, 0.7)
+    else:
+        start = (0.3, 0.3, 0.0)
+    cells = np.where(world > 0, 100, -60).astype(np.int8)
+    g = bl.OccupancyGrid.from_cells(cells, origin, mpc, cellsPerMeter=cpm, ctx=gpu_ctx)
+    poses = synth.square_trajectory(start, 3, step_len=0.05, turn=0.1, side=0.2)
+    odo = synth.odometry_from_truth(poses, np.random.default_rng(15))
+    opf = oracle_lib.OraclePF(oracle, N)
+    opf.init_at_pose(oracle.pose(*start, utime=1000), 21)
+    pf = bl.ParticleFilter(N, ctx=gpu_ctx)
+    pf.setParticles(opf.particles())
+    pf.debugEnable(True)
+    moved = 0
+    for k in range(1, len(poses)):
+        scan = synth.raycast_scan(world, origin, 0.05, poses[k - 1], poses[k], 1000 + 100000 * k)
+        o = odo[k]
+        rv = (1804289383, 846930886, 1681692777)[k - 1]
+        res = opf.update(oracle.pose(*o, utime=scan.utime), scan, cells, mpc, cpm, origin, rv)
+        pose = pf.updateFilter(bl.make_pose(*o, utime=scan.utime), scan, g, rand_value=rv, noise=res["noise"])
+        if not res["moved"]:
+            continue
+        moved += 1
+        idx, like = pf.debugLast()
+        assert np.array_equal(idx, res["idx"]), (where, k)
+        assert np.array_equal(like.astype(np.float64) * 0.5, res["raw"]), (where, k)
+        got, exp = pf.particles(), opf.particles()
+        for f in ("x", "y", "theta", "p_x", "p_y", "p_theta"):
+            assert np.array_equal(got[f], exp[f]), (where, k, f)
+        assert np.allclose(got["weight"], exp["weight"], rtol=REL, atol=0)
+        _assert_estimate_bit_equal(pose, res["pose"], (where, k))
+        assert (res["raw"] > 0).sum() > N // 2                 # the scans really hit the map
+    assert moved == 2
 
 
 def test_mcl_action_only(oracle, maps, gpu_ctx):
