@@ -576,6 +576,10 @@ struct bl_astar_state {
     // closed entry; 4 start.  d_out = [astar_result, padded to ASTAR_HDR bytes][path cells]: one D2H brings back the
     // result record and the head of the path.
     char* d_out; size_t path_cap;
+    // every pending search also leaves its path in a buffer of its result slot (8 * (W + H) cells, at least the head): a path
+    // longer than the pinned head is fetched from there under the slot's event, whatever was launched behind it
+    int32_t* d_slot_path[ASTAR_SLOTS]; size_t slot_path_cap; int64_t slot_search[ASTAR_SLOTS];
+    int path_head;                         // cells of the path that travel with the result record (BOTLAB_ASTAR_PATH_HEAD: tests)
     int32_t* cost_lut; int cost_lut_cap;
     struct astar_unit* h_units;            // pinned [ASTAR_SLOTS][ASTAR_MAX_UNITS]: per-workgroup arguments of the unit form
     char* h_out[ASTAR_SLOTS];              // pinned result ring ([result][path head]): searches may be enqueued ahead of fetching
@@ -606,7 +610,7 @@ static_assert(sizeof(astar_result) <= ASTAR_HDR, "result record must fit the hea
 struct astar_unit {
     const uint16_t* l1; const int32_t* cost_lut; int2* heap; int32_t* closed; int32_t* path; astar_result* result;
     const bl_pose_xyt_t* start_dev; bl_pose_xyt_t start_host; int sx, sy, gx, gy;
-    char* host_out;
+    char* host_out; int32_t* slot_path;
 };
 
 struct astar_args {
@@ -615,6 +619,7 @@ struct astar_args {
     int2* heap; int heap_cap;
     int32_t* closed;
     int32_t* path; long long path_cap;
+    int32_t* slot_path; long long slot_path_cap; int path_head;      // per-result-slot copy of the path; cells that go to host_out
     astar_result* result;
     // pinned host slot ([result][path head]) the search leaves its outcome in directly (no copy command behind the kernel:
     // an asynchronous device-to-host copy blocked the enqueueing thread for ~7 ms once every few hundred calls), or null
@@ -751,7 +756,7 @@ __global__ __launch_bounds__(64) void k_astar(astar_args a)
         const astar_unit u = a.units[blockIdx.x];
         a.l1 = u.l1; a.cost_lut = u.cost_lut; a.heap = u.heap; a.closed = u.closed; a.path = u.path; a.result = u.result;
         a.start_dev = u.start_dev; a.start_host = u.start_host; a.sx = u.sx; a.sy = u.sy; a.gx = u.gx; a.gy = u.gy;
-        a.host_out = u.host_out;
+        a.host_out = u.host_out; a.slot_path = u.slot_path;
     }
     if (a.batch_goals) {
         const long long b = blockIdx.x;
@@ -759,7 +764,7 @@ __global__ __launch_bounds__(64) void k_astar(astar_args a)
         a.gx = g.x; a.gy = g.y;
         a.heap += b * a.heap_stride; a.closed += b * a.closed_stride; a.path += b * a.path_stride;
         a.result = (astar_result*)((char*)a.result + b * ASTAR_HDR);
-        a.host_out = nullptr;
+        a.host_out = nullptr; a.slot_path = nullptr; a.slot_path_cap = 0;
     }
     int2* g_heap = a.heap;
     const int lane = threadIdx.x;
@@ -889,7 +894,8 @@ __global__ __launch_bounds__(64) void k_astar(astar_args a)
                 int cell = gny * a.W + gnx, parent = cy * a.W + cx;
                 while (cell != start) {
                     if (n < a.path_cap) a.path[n] = cell;
-                    if (a.host_out && n < ASTAR_PATH_HEAD) ((int32_t*)(a.host_out + ASTAR_HDR))[n] = cell;
+                    if (n < a.slot_path_cap) a.slot_path[n] = cell;
+                    if (a.host_out && n < a.path_head) ((int32_t*)(a.host_out + ASTAR_HDR))[n] = cell;
                     n += 1;
                     cell = parent;
                     int d = __hip_atomic_load(&a.closed[cell], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -932,6 +938,7 @@ void bl_astar_free(bl_ctx* ctx)
     if (!s) return;
     if (s->heap) (void)hipFree(s->heap);
     if (s->d_out) (void)hipFree(s->d_out);
+    for (int i = 0; i < ASTAR_SLOTS; ++i) if (s->d_slot_path[i]) (void)hipFree(s->d_slot_path[i]);
     if (s->cost_lut) (void)hipFree(s->cost_lut);
     if (s->h_units) (void)hipHostFree(s->h_units);
     for (int i = 0; i < ASTAR_SLOTS; ++i) {
@@ -962,6 +969,8 @@ static int astar_prepare(bl_ctx* ctx, const bl_dist* d)
     if (!ctx->astar) {
         ctx->astar = new bl_astar_state();
         memset((void*)ctx->astar, 0, sizeof(bl_astar_state));
+        ctx->astar->path_head = ASTAR_PATH_HEAD;
+        if (const char* e = getenv("BOTLAB_ASTAR_PATH_HEAD")) { const int v = atoi(e); if (v >= 1 && v <= ASTAR_PATH_HEAD) ctx->astar->path_head = v; }
         for (int i = 0; i < ASTAR_SLOTS; ++i) {
             BL_HIP(hipHostMalloc((void**)&ctx->astar->h_out[i], ASTAR_HDR + ASTAR_PATH_HEAD * 4, hipHostMallocDefault));
             BL_HIP(hipHostGetDevicePointer((void**)&ctx->astar->h_out_dev[i], ctx->astar->h_out[i], 0));
@@ -988,6 +997,17 @@ static int astar_prepare(bl_ctx* ctx, const bl_dist* d)
         s->d_out = nullptr;
         BL_HIP(hipMalloc((void**)&s->d_out, ASTAR_HDR + n * 4));
         s->path_cap = n;
+    }
+    size_t sp = (size_t)8 * ((size_t)d->frame.width + d->frame.height);
+    if (sp < ASTAR_PATH_HEAD) sp = ASTAR_PATH_HEAD;
+    if (sp > s->slot_path_cap) {
+        BL_HIP(hipStreamSynchronize(ctx->stream));
+        for (int i = 0; i < ASTAR_SLOTS; ++i) {
+            if (s->d_slot_path[i]) BL_HIP(hipFree(s->d_slot_path[i]));
+            s->d_slot_path[i] = nullptr;
+            BL_HIP(hipMalloc((void**)&s->d_slot_path[i], sp * 4));
+        }
+        s->slot_path_cap = sp;
     }
     int ln = d->frame.width + d->frame.height + 1;
     if (ln > s->cost_lut_cap) {
@@ -1061,6 +1081,7 @@ static int astar_fill(bl_ctx* ctx, const bl_dist* d, const bl_pose_xyt_t* start,
     a.path = (int32_t*)(s->d_out + ASTAR_HDR); a.path_cap = (long long)s->path_cap;
     a.result = (astar_result*)s->d_out;
     a.host_out = s->h_out_dev[s->launched % ASTAR_SLOTS];
+    a.slot_path = s->d_slot_path[s->launched % ASTAR_SLOTS]; a.slot_path_cap = (long long)s->slot_path_cap; a.path_head = s->path_head;
     a.frame = d->frame;
     a.batch_goals = nullptr; a.heap_stride = a.closed_stride = a.path_stride = 0; a.pool = nullptr; a.pool_cursor = nullptr;
     a.units = nullptr;
@@ -1088,6 +1109,7 @@ static int astar_after(bl_ctx* ctx, const bl_dist* d)
     // the kernel has written [result][path head] into the pinned slot itself
     BL_HIP(hipEventRecord(s->done[slot], ctx->stream));
     s->slot_frame[slot] = d->frame;
+    s->slot_search[slot] = s->launched;
     s->launched += 1;
     s->pending = true;
     return BL_OK;
@@ -1144,7 +1166,7 @@ static int astar_launch_units(int n, bl_ctx* const* ctxs, bl_dist* const* dists,
         astar_unit& u = units[b];
         u.l1 = a.l1; u.cost_lut = a.cost_lut; u.heap = a.heap; u.closed = a.closed; u.path = a.path; u.result = a.result;
         u.start_dev = a.start_dev; u.start_host = a.start_host; u.sx = a.sx; u.sy = a.sy; u.gx = a.gx; u.gy = a.gy;
-        u.host_out = a.host_out;
+        u.host_out = a.host_out; u.slot_path = a.slot_path;
     }
     a.units = units;
     bl_ctx* ctx = ctxs[0];
@@ -1203,10 +1225,14 @@ extern "C" int bl_astar_search_result(bl_ctx* ctx, bl_pose_xyt_t* out_path, int 
     if (r.status != ASTAR_ST_FOUND) return BL_OK;
     // makePath (astar.cpp:235-274): cells come goal-first; poses are emitted start-side first
     std::vector<int32_t> cells((size_t)r.path_len);
-    if (r.path_len <= ASTAR_PATH_HEAD) memcpy(cells.data(), s->h_out[slot] + ASTAR_HDR, (size_t)r.path_len * 4);
-    else {
-        // longer than the head copied with the result: only valid if no later search has overwritten the device path
-        if (s->pending) { bl_set_error("A* path of %d cells exceeds the pipelined result head (%d)", r.path_len, ASTAR_PATH_HEAD); return BL_ERR_CAPACITY; }
+    if (r.path_len <= s->path_head) memcpy(cells.data(), s->h_out[slot] + ASTAR_HDR, (size_t)r.path_len * 4);
+    else if ((size_t)r.path_len <= s->slot_path_cap) {
+        // longer than the head that came with the result record: the slot's own copy of the path is complete (the event has
+        // fired) and stays untouched until ASTAR_SLOTS further searches have been launched, which cannot happen before this fetch
+        BL_HIP(hipMemcpy(cells.data(), s->d_slot_path[slot], (size_t)r.path_len * 4, hipMemcpyDeviceToHost));
+    } else {
+        // longer even than 8 * (W + H) cells: only the search scratch holds all of it, and a later search reuses that
+        if (s->pending) { bl_set_error("A* path of %d cells exceeds the per-result path buffer (%zu) while later searches are pending", r.path_len, s->slot_path_cap); return BL_ERR_CAPACITY; }
         BL_HIP(hipStreamSynchronize(ctx->stream));
         BL_HIP(hipMemcpy(cells.data(), s->d_out + ASTAR_HDR, (size_t)r.path_len * 4, hipMemcpyDeviceToHost));
     }
@@ -1321,6 +1347,7 @@ static int astar_batch_cells(bl_ctx* ctx, const bl_dist* d, const bl_pose_xyt_t*
         a.heap = s->b_heap; a.heap_cap = (int)s->b_heap_each;
         a.closed = s->b_closed;
         a.path = s->b_path; a.path_cap = (long long)s->b_path_each;
+        a.slot_path = nullptr; a.slot_path_cap = 0; a.path_head = 0; a.host_out = nullptr;
         a.result = (astar_result*)s->b_results;
         a.frame = d->frame;
         a.gx = a.gy = 0;

@@ -498,6 +498,33 @@ def test_astar_long_cases(oracle, maps, gpu_ctx, name, case, counts):
     assert got.tobytes() == exp.tobytes()
 
 
+def test_astar_pipelined_results_longer_than_the_pinned_head(oracle, maps, monkeypatch):
+    """Searches enqueued ahead of fetching (the replanner's pattern): a path longer than the head that travels with the result
+    record must come back whole although later searches on the same ctx have run meanwhile -- every result slot keeps its own
+    copy of the path.  The head is shrunk to 8 cells (BOTLAB_ASTAR_PATH_HEAD) so that the shipped maze's 60-76-cell paths take
+    that route; under the reference's own fCost < 32767 rule a path can barely exceed the real head of 4096 cells."""
+    monkeypatch.setenv("BOTLAB_ASTAR_PATH_HEAD", "8")
+    ctx = bl.Context()
+    try:
+        m = maps["astar_maze"]
+        g = bl.OccupancyGrid.from_cells(m["cells"], m["origin"], m["mpc"], cellsPerMeter=helpers.CPM_DEFAULT, ctx=ctx)
+        planner = bl.MotionPlanner(bl.MotionPlannerParams(0.1), ctx=ctx)
+        planner.setMap(g)
+        dist = oracle.set_distances(m["cells"], m["mpc"], helpers.CPM_DEFAULT, m["origin"])
+        rows = [helpers.load_astar_cases()["maze"][i] for i in (0, 2, 3, 0)]
+        for row in rows:                                       # four searches in flight
+            bl.search_for_path_begin(bl.make_pose(*row["goal"], 0.0), planner.distances_, planner.searchParams_, start=bl.make_pose(*row["start"], 0.0))
+        for row in rows:
+            path, stats = bl.search_for_path_end(planner.distances_, return_stats=True)
+            exp, est = oracle.search(oracle.pose(*row["start"], 0.0), oracle.pose(*row["goal"], 0.0), dist, m["mpc"], helpers.CPM_DEFAULT,
+                                     m["origin"], 0.1, 1.0)
+            assert stats == est and len(path) == len(exp) > 9
+            got = np.array([(p.utime, p.x, p.y, p.theta) for p in path], dtype=exp.dtype)
+            assert got.tobytes() == exp.tobytes()
+    finally:
+        ctx.close()
+
+
 def test_astar_on_slam_map_with_default_radius(oracle, maps, gpu_ctx):
     """MotionPlanner() default robotRadius 0.2 (motion_planner.hpp:31) on a SLAM-built map, several goals."""
     m = maps["obstacle_slam_10mx10m_5cm"]
