@@ -36,7 +36,7 @@ def load_map(name):
     return dict(cells=z[name + "__cells"], origin=tuple(z[name + "__origin"]), mpc=z[name + "__mpc"][0])
 
 
-def build_inputs(args, total_steps):
+def build_inputs(args, total_steps, ctx=None):
     from botlab_amd import synth
     m = load_map("obstacle_slam_10mx10m_5cm")
     if args.grid != 200:
@@ -52,10 +52,17 @@ def build_inputs(args, total_steps):
     rng = np.random.default_rng(1234)
     poses = synth.square_trajectory(start, total_steps, step_len=0.02, turn=0.05, side=side)
     odo = synth.odometry_from_truth(poses, rng)
-    scans = []
-    for k in range(1, len(poses)):
-        scans.append(synth.raycast_scan(truth, m["origin"], float(m["mpc"]), poses[k - 1], poses[k], 1_000_000 + k * 100_000,
-                                        max_range=getattr(args, "max_range", synth.MAX_RANGE), noise_sigma=0.005, rng=rng))
+    max_range = getattr(args, "max_range", synth.MAX_RANGE)
+    if args.grid != 200 and ctx is not None:
+        # large worlds: every beam of every scan marched in ONE launch of the simulator's lidar kernel (bl_sim_cast_beams,
+        # SURVEY.md section 8 row f4) -- the numpy ray caster needs minutes for a few hundred scans of a 4096 x 4096 world
+        scans = synth.raycast_scans_gpu(truth, m["origin"], float(m["mpc"]), poses, 1_000_000, 100_000, ctx, max_range=max_range,
+                                        noise_sigma=0.005, rng=rng)
+    else:
+        scans = []
+        for k in range(1, len(poses)):
+            scans.append(synth.raycast_scan(truth, m["origin"], float(m["mpc"]), poses[k - 1], poses[k], 1_000_000 + k * 100_000,
+                                            max_range=max_range, noise_sigma=0.005, rng=rng))
     rands = np.random.default_rng(99).integers(0, 2**31 - 1, size=total_steps + 4)
     return m, truth, poses, odo, scans, rands
 
@@ -141,6 +148,77 @@ def self_launch(n):
     return 0
 
 
+OTHER_CONFIGS = [                                      # (preset, goal_l1 in cells): short runs printed beside the headline
+    (4, 40), (4, 400), (5, 40), (5, 200),
+]
+
+
+def run_other_configs(steps, warmup):
+    """BASELINE.json configs[3] / configs[4] (2000 x 2000 with 100k particles, 4096 x 4096 with 256k) as short child runs of
+    this script, each with the replan goal 40 and 400 cells (2 m, 20 m) from the start.  SURVEY.md section 8d asks for the
+    farthest free cell; with the reference's cost function and its open list without de-duplication a goal 1600 cells away in
+    this world exhausts 64 GB of host memory in the CPU oracle before it returns (measured), and 400 cells away on the 4096 x 4096
+    SLAM-built map overflows a 16 M-entry open list after 1.9e7 pops here; so the sweep stops where the reference's own
+    algorithm still terminates, and says how many pops each goal costs (an entry with "error" is a search that did not).  Started BEFORE this process
+    initialises HIP (a child is a fork + exec)."""
+    import subprocess
+    out = []
+    for cfg, l1 in OTHER_CONFIGS:
+        cmd = [sys.executable, os.path.abspath(__file__), "--config", str(cfg), "--goal-l1", str(l1), "--steps", str(steps), "--warmup", str(warmup),
+               "--cpu-steps", "0", "--sub"]
+        t0 = time.perf_counter()
+        try:
+            r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=420)
+            line = [l for l in r.stdout.decode(errors="replace").splitlines() if l.startswith("{")]
+            if r.returncode != 0 or not line:
+                err = [l for l in r.stderr.decode(errors="replace").splitlines() if l.strip()]
+                out.append({"config": cfg, "goal_l1_cells": l1, "error": err[-1][-300:] if err else f"exit {r.returncode}"})
+                continue
+            d = json.loads(line[-1])
+            out.append({"config": cfg, "goal_l1_cells": l1, "workload": d["config"]["workload"], "value": d["value"], "unit": d["unit"],
+                        "steps": d["steps"], "warmup": d["warmup"], "ms_per_step": d["ms_per_step"], "astar_pops_per_step": d["astar_pops_per_step"],
+                        "stage_ms": d["stage_ms"], "planner": [d["config"]["planner_lanes"], d["config"]["planner_batch"], d["config"]["pipeline_depth"]],
+                        "streaming_kernels": d.get("streaming_kernels"), "wall_s": round(time.perf_counter() - t0, 1)})
+        except subprocess.TimeoutExpired:
+            out.append({"config": cfg, "goal_l1_cells": l1, "error": "timed out after 420 s"})
+    return out
+
+
+def streaming_kernels(ctx, grid, planner, aplanner, pose_dev, goal_pose, W, H):
+    """The HBM-bound kernels of the path at this grid size, each timed by its own HIP events in this run (alone on the device,
+    after the timed region): bytes the kernel must read + write / its average duration, against the 8 TB/s peak."""
+    import torch
+    from botlab_amd import _capi
+    ids = [_capi.BL_K_DIST_ROWS, _capi.BL_K_DIST_COLS_SUMMARY, _capi.BL_K_DIST_COLS_APPLY, _capi.BL_K_SNAPSHOT]
+    ctx.timing_reset()
+    ctx.timing_stride(1)
+    ctx.timing_enable(True, kernels=ids)
+    reps = 12
+    for _ in range(reps):
+        planner.setMap(grid)                               # ObstacleDistanceGrid::setDistances on the live map
+    if goal_pose is not None:
+        for _ in range(reps):                              # the stand-alone snapshot copy (the bench's own rides in the map kernel)
+            aplanner.submit(grid, pose_dev, goal_pose)
+            aplanner.fetch()
+    torch.cuda.synchronize()
+    ctx.timing_enable(False)
+    cells = float(W) * H
+    wide = W >= 1024 and W % 16 == 0
+    tall = H >= 512 and W >= 256 and W % 2 == 0
+    spec = [("k_dist_rows_wide" if wide else "k_dist_rows", _capi.BL_K_DIST_ROWS, 3.0 * cells),             # int8 in, uint16 out
+            ("k_dist_cols_summary", _capi.BL_K_DIST_COLS_SUMMARY, 2.0 * cells),                           # uint16 in
+            ("k_dist_cols_apply" if tall else "k_dist_cols", _capi.BL_K_DIST_COLS_APPLY, 12.0 * cells),  # uint16 in; uint16 + float + int32 out
+            ("k_planner_snapshot", _capi.BL_K_SNAPSHOT, 2.0 * cells)]                                     # int8 in, int8 out
+    out = {}
+    for name, kid, nbytes in spec:
+        ms, n = ctx.timing_get(kid)
+        if n:
+            gbs = nbytes / (ms / n * 1e-3) / 1e9
+            out[name] = {"bytes_per_launch": nbytes, "avg_launch_ms": round(ms / n, 5), "launches": int(n), "achieved_GBps": round(gbs, 1),
+                         "frac_of_hbm_peak": round(gbs / HBM_PEAK_GBS, 4)}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -165,6 +243,9 @@ def main():
     ap.add_argument("--config", type=int, default=0, choices=[0, 2, 3, 4, 5],
                     help="BASELINE.json configs[i - 1] as a preset (0/2: the default, configs[1]; 3: 1M-particle MCL, no replan; "
                          "4: 2000x2000 maze with a replan per step; 5: 4096x4096, 256k particles); explicit flags still win")
+    ap.add_argument("--sub", action="store_true", help="a child run of the default invocation (other_configs): no children of its own")
+    ap.add_argument("--no-other-configs", action="store_true", help="default run: skip the short runs of configs 4 and 5")
+    ap.add_argument("--other-steps", type=int, default=300, help="timed steps of each other_configs run")
     args = ap.parse_args()
     presets = {3: dict(particles=1_000_000, no_astar=True),
                4: dict(grid=2000, lanes=3, batch=4, depth=18),
@@ -185,6 +266,9 @@ def main():
         os.dup2(json_fd, 1)
         os.close(json_fd)
         raise SystemExit(self_launch(args.gpus))
+    other = None
+    if args.config == 0 and args.gpus == 1 and args.grid == 200 and not args.sub and not args.no_other_configs and "WORLD_SIZE" not in os.environ:
+        other = run_other_configs(args.other_steps, 40)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -215,7 +299,6 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     total = args.steps + args.warmup + 34
-    m, truth, poses, odo, scans, rands = build_inputs(args, total)
     cpm = np.float32(1.0 / np.float64(np.float32(0.05)))
 
     engine = sharded.HipShardEngine(args.particles, rank, world, local_rank)
@@ -224,6 +307,7 @@ def main():
     # Created before anything touches the null stream: the HIP runtime multiplexes streams onto 4 hardware queues (raising
     # GPU_MAX_HW_QUEUES costs ~50 us of launch latency per kernel, measured), and two lanes sharing a queue serialise.
     aplanner = bl.AsyncPlanner(ctx=ctx, lanes=args.lanes, batch=args.batch)
+    m, truth, poses, odo, scans, rands = build_inputs(args, total, ctx)
     spf = sharded.ShardedParticleFilter(engine)
     grid = bl.OccupancyGrid.from_cells(m["cells"], m["origin"], m["mpc"], cellsPerMeter=cpm, ctx=ctx)
     mapper = bl.Mapping(5.0, 4, 1, ctx=ctx)                 # slam.cpp:24, slam_main.cpp:22-23
@@ -397,6 +481,9 @@ def main():
     # (a run too short for the event stride to catch a launch keeps the post-pass figure)
     pose, k = final_pose, final_k
     pops_total[0] = pops_timed
+    stream_k = None
+    if world == 1 and (args.sub or args.grid != 200):
+        stream_k = streaming_kernels(ctx, grid, planner, aplanner, pose_dev, goal_pose, m["cells"].shape[1], m["cells"].shape[0])
 
     if rank == 0:
         N, R = args.particles, scans[0].num_ranges
@@ -409,12 +496,16 @@ def main():
         # HBM bytes per launch from the rocprofv3 PMC passes committed under profiles/ (FETCH_SIZE / WRITE_SIZE, separate
         # passes, gfx950 correction applied); only valid for the configuration they were collected on
         traffic = None
-        try:
-            tj = json.load(open(os.path.join(ROOT, "profiles", "r01_mcl_main_traffic.json")))
-            if world == 1 and tj["config"] == {"particles": N, "grid": [W, H], "rays": R}:
-                traffic = tj["traffic_bytes_per_launch"]
-        except (OSError, KeyError, ValueError):
-            traffic = None
+        traffic_src = None
+        for prof in ("r02_mcl_main_traffic.json", "r01_mcl_main_traffic.json"):
+            try:
+                tj = json.load(open(os.path.join(ROOT, "profiles", prof)))
+                if world == 1 and tj["config"] == {"particles": N, "grid": [W, H], "rays": R}:
+                    traffic = tj["traffic_bytes_per_launch"]
+                    traffic_src = "profiles/" + prof + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, not measured in this run)"
+                    break
+            except (OSError, KeyError, ValueError):
+                continue
         achieved = alg_bytes / (main_ms * 1e-3) / 1e9 if main_ms > 0 else 0.0
         # The other kernels of the step against the same roof, with SURVEY.md section 8d's algorithmic bytes:
         # map 16 R + 2 C (C = traced cells), distance grid 5 W H per setDistances, A* 52 B per pop; and the whole step.
@@ -434,16 +525,18 @@ def main():
         # secondary bound of k_mcl_main (it is VALU-bound, not HBM-bound): wave-level VALU instructions per launch from the
         # committed SQ counter pass, against the 1024 SIMDs issuing one per 4 cycles at 2.4 GHz
         valu = None
-        try:
-            import csv
-            if world == 1 and traffic is not None:
-                for row in csv.reader(open(os.path.join(ROOT, "profiles", "r01_mcl_main_pmc_sq.csv"))):
-                    if len(row) == 4 and row[0].startswith("void k_mcl_main<0") and row[1] == "SQ_INSTS_VALU":
-                        insts = float(row[3])
-                        valu = {"wave_valu_insts_per_launch": insts, "per_particle_ray": insts * 64.0 / (n_local * R),
-                                "valu_issue_frac": insts * 4.0 / (1024.0 * main_ms * 1e-3 * 2.4e9)}
-        except (OSError, ValueError):
-            valu = None
+        import csv
+        for prof in ("r02_mcl_main_pmc_sq.csv", "r01_mcl_main_pmc_sq.csv"):
+            try:
+                if world == 1 and traffic is not None and valu is None:
+                    for row in csv.reader(open(os.path.join(ROOT, "profiles", prof))):
+                        if len(row) == 4 and row[0].startswith("void k_mcl_main<0") and row[1] == "SQ_INSTS_VALU":
+                            insts = float(row[3])
+                            valu = {"wave_valu_insts_per_launch": insts, "per_particle_ray": insts * 64.0 / (n_local * R),
+                                    "valu_issue_frac_at_4_cycles": insts * 4.0 / (1024.0 * main_ms * 1e-3 * 2.4e9),
+                                    "source": "profiles/" + prof + " (rocprofv3 --pmc SQ_INSTS_VALU pass of this command, not measured in this run)"}
+            except (OSError, ValueError):
+                continue
         out = {
             "metric": "SLAM steps/sec (map+MCL+A*)",
             "value": args.steps / elapsed,
@@ -465,7 +558,7 @@ def main():
                                       ("RCCL all-gather enqueued by the library on the filter's stream" if spf.comm is not None
                                        else "torch.distributed all_gather_into_tensor"))},
             "roofline": {"bound": "hbm", "kernel": "k_mcl_main", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": main_ms,
                          "launches_timed": int(stage_ms["mcl_main"][1]), "event_stride": EVENT_STRIDE,
                          "particle_rays_per_s": (n_local * R) / (main_ms * 1e-3) if main_ms > 0 else 0.0,
@@ -480,6 +573,10 @@ def main():
             "final_pose": [pose.x, pose.y, pose.theta],
             "truth_pose": [float(v) for v in poses[k]],
         }
+        if world == 1 and stream_k is not None:
+            out["streaming_kernels"] = stream_k
+        if other is not None:
+            out["other_configs"] = other
         if args.cpu_steps > 0 and world == 1:
             out["cpu_baseline"] = cpu_baseline(args, m, odo, scans, rands, goal, args.cpu_steps)
         sys.stdout.flush()

@@ -78,7 +78,7 @@ extern "C" int bl_ctx_timing_enable(bl_ctx* ctx, int on)
 {
     BL_CHECK_ARG(ctx != nullptr);
     ctx->timing = on != 0;
-    ctx->timing_mask = (on == 1) ? 0xffffffffu : (unsigned int)on;      // 1: every kernel; otherwise bit i = BL_K_* id i
+    ctx->timing_mask = (on == 1) ? 0x3fu : (unsigned int)on;            // 1: every kernel (ids 0..5); otherwise bit i = BL_K_* id i
     return BL_OK;
 }
 

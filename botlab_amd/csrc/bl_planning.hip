@@ -486,17 +486,34 @@ extern "C" int bl_dist_set_distances(bl_dist* d, const bl_grid* map)
     hipEvent_t e0, e1;
     int rc = bl_timer_begin(ctx, BL_K_DIST, &e0, &e1);
     if (rc) return rc;
+    hipEvent_t f0, f1;
+    rc = bl_timer_begin(ctx, BL_K_DIST_ROWS, &f0, &f1);
+    if (rc) return rc;
     if (W >= 1024 && (W & 15) == 0) hipLaunchKernelGGL(k_dist_rows_wide, dim3(H), dim3(256), 0, ctx->stream, map->cells, W, d->row);
     else hipLaunchKernelGGL(k_dist_rows, dim3(H), dim3(256), 0, ctx->stream, map->cells, W, d->row);
+    rc = bl_timer_end(ctx, BL_K_DIST_ROWS, f0, f1);
+    if (rc) return rc;
     if (H >= 4 * DC2_ROWS && W >= 4 * DC2_TX && (W & 1) == 0) {
         const int nmacro = (H + DC2_ROWS - 1) / DC2_ROWS;
         const dim3 grid2((W + 2 * DC2_TX - 1) / (2 * DC2_TX), nmacro);
+        rc = bl_timer_begin(ctx, BL_K_DIST_COLS_SUMMARY, &f0, &f1);
+        if (rc) return rc;
         hipLaunchKernelGGL(k_dist_cols_summary, grid2, dim3(DC2_TX, DC2_TY), 0, ctx->stream, d->row, W, H, d->sum_f, d->sum_b);
+        rc = bl_timer_end(ctx, BL_K_DIST_COLS_SUMMARY, f0, f1);
+        if (rc) return rc;
+        rc = bl_timer_begin(ctx, BL_K_DIST_COLS_APPLY, &f0, &f1);
+        if (rc) return rc;
         hipLaunchKernelGGL(k_dist_cols_apply, grid2, dim3(DC2_TX, DC2_TY), 0, ctx->stream, d->row, W, H, d->sum_f, d->sum_b,
                            d->l1, d->cells, d->lut, d->closed);
+        rc = bl_timer_end(ctx, BL_K_DIST_COLS_APPLY, f0, f1);
+        if (rc) return rc;
     } else {
+        rc = bl_timer_begin(ctx, BL_K_DIST_COLS_APPLY, &f0, &f1);
+        if (rc) return rc;
         hipLaunchKernelGGL(k_dist_cols, dim3((W + DCOL_TX - 1) / DCOL_TX), dim3(DCOL_TX, DCOL_TY), 0, ctx->stream, d->row, W, H,
                            d->l1, d->cells, d->lut, d->closed);
+        rc = bl_timer_end(ctx, BL_K_DIST_COLS_APPLY, f0, f1);
+        if (rc) return rc;
     }
     BL_HIP(hipGetLastError());
     rc = bl_timer_end(ctx, BL_K_DIST, e0, e1);
@@ -1722,9 +1739,14 @@ extern "C" int bl_planner_submit(bl_planner* p, const bl_grid* map, const void* 
     int blocks = (int)((n / 16 + 255) / 256);
     if (blocks < 1) blocks = 1;
     if (blocks > 2048) blocks = 2048;
+    hipEvent_t f0, f1;
+    rc = bl_timer_begin(p->main, BL_K_SNAPSHOT, &f0, &f1);
+    if (rc) return rc;
     hipLaunchKernelGGL(k_planner_snapshot, dim3(blocks), dim3(256), 0, p->main->stream, map->cells, sn.cells, n,
                        (const bl_pose_xyt_t*)d_start_pose, sn.pose, sn.done_count, sn.flag, sn.seq);
     BL_HIP(hipGetLastError());
+    rc = bl_timer_end(p->main, BL_K_SNAPSHOT, f0, f1);
+    if (rc) return rc;
     return bl_planner_commit(p, goal, params);
 }
 

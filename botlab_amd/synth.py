@@ -101,3 +101,32 @@ def odometry_from_truth(poses, rng, sigma_trans=1e-3, sigma_rot=3e-3):
         nth = np.arctan2(np.sin(p[2] + dth_n), np.cos(p[2] + dth_n))
         odo.append(np.array([nx, ny, nth]))
     return odo
+
+
+def raycast_scans_gpu(truth, origin, mpc, poses, t0_us, dt_us, ctx, rays=RAYS, max_range=MAX_RANGE, noise_sigma=0.0, rng=None):
+    """raycast_scan for every consecutive pose pair of `poses` at once: the beams of all scans are marched by the simulator's
+    lidar kernel (botlab_amd.sim.SimLidar.cast, half-cell steps as src/sim/lidar.py:106-138) in one launch.  Scan k ends at
+    t0_us + k * dt_us.  Inputs to the hot path only."""
+    from .sim import SimLidar, _clamp
+    n = len(poses) - 1
+    i = np.arange(rays)
+    frac = (i + 1) / rays
+    pb = np.array(poses[:-1], dtype=np.float64)
+    pe = np.array(poses[1:], dtype=np.float64)
+    px = pb[:, None, 0] + (pe[:, None, 0] - pb[:, None, 0]) * frac[None, :]
+    py = pb[:, None, 1] + (pe[:, None, 1] - pb[:, None, 1]) * frac[None, :]
+    dth = np.arctan2(np.sin(pe[:, 2] - pb[:, 2]), np.cos(pe[:, 2] - pb[:, 2]))
+    pth = pb[:, None, 2] + dth[:, None] * frac[None, :]
+    thetas = (2.0 * np.pi * i / rays).astype(np.float32)
+    ang = pth - thetas[None, :]
+    lidar = SimLidar(truth, float(origin[0]), float(origin[1]), float(mpc), ctx=ctx, num_ranges=rays, max_distance=max_range)
+    ranges = lidar.cast(px.ravel(), py.ravel(), _clamp(ang.ravel())).reshape(n, rays)
+    ranges = np.minimum(ranges, max_range)
+    if noise_sigma > 0.0:
+        ranges = ranges + rng.normal(0.0, noise_sigma, size=ranges.shape)
+    scans = []
+    for k in range(n):
+        t_end = t0_us + (k + 1) * dt_us
+        times = (t_end - (rays - 1 - i) * RAY_DT_US).astype(np.int64)
+        scans.append(LidarScan(ranges[k].astype(np.float32), thetas, times, utime=int(t_end)))
+    return scans

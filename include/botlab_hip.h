@@ -79,7 +79,13 @@ int bl_ctx_timing_reset(bl_ctx* ctx);
 #define BL_K_DIST 3          /* ObstacleDistanceGrid::setDistances (2 launches, timed together) */
 #define BL_K_ASTAR 4         /* search_for_path */
 #define BL_K_FRONTIERS 5     /* find_map_frontiers */
-#define BL_K_COUNT 6
+/* the launches inside setDistances and the replanner's snapshot copy one by one (timed only when asked for by id: "every
+ * kernel" means ids 0..5; an event pair between two kernels costs a few microseconds of stream time) */
+#define BL_K_DIST_ROWS 6
+#define BL_K_DIST_COLS_SUMMARY 7
+#define BL_K_DIST_COLS_APPLY 8
+#define BL_K_SNAPSHOT 9
+#define BL_K_COUNT 10
 
 /* ------------------------------------------------------------------ OccupancyGrid  (src/slam/occupancy_grid.hpp:51-209)
  * Device-resident int8 log-odds cells, row-major y*width+x.  meters_per_cell and cells_per_meter are both carried

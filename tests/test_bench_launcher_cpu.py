@@ -30,7 +30,26 @@ def test_mismatched_world_size_is_refused():
 
 
 def test_launcher_parent_does_not_import_torch():
+    """What runs before a child is started -- the module level, self_launch and run_other_configs -- must not import torch or the
+    library (either would initialise HIP in the parent)."""
+    import ast
     src = open(os.path.join(ROOT, "bench.py")).read()
-    head = src[:src.index("def self_launch")]
-    body = src[src.index("def self_launch"):src.index("def main()")]
-    assert "import torch" not in head and "import torch" not in body and "botlab_amd" not in body
+    tree = ast.parse(src)
+
+    def imports(node):
+        names = []
+        for n in ast.walk(node):
+            if isinstance(n, ast.Import):
+                names += [a.name for a in n.names]
+            elif isinstance(n, ast.ImportFrom):
+                names.append(n.module or "")
+        return names
+
+    top = [n for n in tree.body if not isinstance(n, (ast.FunctionDef, ast.ClassDef))]
+    for node in top:
+        assert not any(m.startswith(("torch", "botlab_amd")) for m in imports(node)), ast.dump(node)[:200]
+    funcs = {n.name: n for n in tree.body if isinstance(n, ast.FunctionDef)}
+    for name in ("self_launch", "run_other_configs"):
+        assert not any(m.startswith(("torch", "botlab_amd")) for m in imports(funcs[name])), name
+    main_src = ast.get_source_segment(src, funcs["main"])
+    assert main_src.index("run_other_configs(") < main_src.index("import torch") and main_src.index("self_launch(") < main_src.index("import torch")
