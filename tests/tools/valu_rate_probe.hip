@@ -1,9 +1,10 @@
 // valu_rate_probe.hip -- issue cost of the vector instructions k_mcl_main's ray loop is made of, relative to v_fma_f32.
-// Every kernel runs ITER x 8 independent copies of one instruction per lane, 4 waves per SIMD on every CU; the figure
+// Every kernel runs ITER x 8 independent copies of one instruction per lane, `wps` (argv[1], default 4) waves per SIMD on every CU; the figure
 // printed is SIMD cycles per wave-instruction (time x clock x SIMDs / wave-instructions), 4.0 = full rate.
 //   hipcc --offload-arch=gfx950 -O2 -o valu_rate_probe valu_rate_probe.hip && ./valu_rate_probe
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <cstdlib>
 #include <vector>
 #define ITER 2048
 #define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at line %d\n", hipGetErrorString(e_), __LINE__); return 1; } } while (0)
@@ -103,15 +104,16 @@ KERNEL_64_FROM_32(k_cvt_f64_i32, "v_cvt_f64_i32 %0, %1")
 
 struct entry { const char* name; void (*fn)(int*, int); };
 
-int main()
+int main(int argc, char** argv)
 {
+    const int wps = argc > 1 ? atoi(argv[1]) : 4;    // waves per SIMD: workgroups of 4 waves, `wps` of them per CU
     int dev = 0; CHECK(hipSetDevice(dev));
     hipDeviceProp_t prop; CHECK(hipGetDeviceProperties(&prop, dev));
     const int cus = prop.multiProcessorCount;
     const double ghz = prop.clockRate * 1e-6;
     int* out; CHECK(hipMalloc((void**)&out, 64));
     hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
-    const int blocks = cus * 4;                      // 4 workgroups x 4 waves per CU = 4 waves per SIMD
+    const int blocks = cus * wps;                    // wps workgroups x 4 waves per CU = wps waves per SIMD
     std::vector<entry> es = {
         {"v_fma_f32 (cold)", k_fma_f32}, {"v_fma_f32", k_fma_f32}, {"v_add_u32", k_add_u32}, {"v_mul_lo_u32", k_mul_lo_u32}, {"v_mul_i32_i24", k_mul_i24},
         {"v_med3_i32", k_med3_i32}, {"v_cndmask_b32", k_cndmask}, {"v_cmp_lt_i32", k_cmp}, {"v_cvt_i32_f32", k_cvt_i32_f32},
@@ -120,7 +122,7 @@ int main()
         {"v_fma_f64", k_fma_f64}, {"v_mul_f64", k_mul_f64}, {"v_add_f64", k_add_f64}, {"v_trunc_f64", k_trunc_f64},
         {"v_floor_f64", k_floor_f64}, {"v_pk_mul_f32", k_pk_mul_f32}, {"v_pk_add_f32", k_pk_add_f32}, {"v_pk_fma_f32", k_pk_fma_f32},
         {"v_cvt_f32_f64", k_cvt_f32_f64}, {"v_cvt_i32_f64", k_cvt_i32_f64}, {"v_cvt_f64_f32", k_cvt_f64_f32}, {"v_cvt_f64_i32", k_cvt_f64_i32}};
-    printf("device: %s, %d CUs, clockRate %.2f GHz\n", prop.name, cus, ghz);
+    printf("device: %s, %d CUs, clockRate %.2f GHz, %d waves per SIMD\n", prop.name, cus, ghz, wps);
     for (auto& e : es) {
         hipLaunchKernelGGL(e.fn, dim3(blocks), dim3(256), 0, 0, out, 0);          // warm
         CHECK(hipDeviceSynchronize());
@@ -129,7 +131,7 @@ int main()
         CHECK(hipEventRecord(e1, 0));
         CHECK(hipEventSynchronize(e1));
         float ms = 0; CHECK(hipEventElapsedTime(&ms, e0, e1));
-        const double wave_instr_per_simd = 5.0 * 4.0 * ITER * 8.0;      // launches x waves per SIMD x iterations x copies
+        const double wave_instr_per_simd = 5.0 * (double)wps * ITER * 8.0;      // launches x waves per SIMD x iterations x copies
         const double cyc = (ms * 1e-3) * ghz * 1e9 / wave_instr_per_simd;
         printf("%-18s %6.2f cycles per wave-instruction (%.3f ms)\n", e.name, cyc, ms / 5);
     }
