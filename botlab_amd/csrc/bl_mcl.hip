@@ -63,6 +63,7 @@ struct bl_pf {
     int split_log2_override;  // -1: automatic
     int block_override;       // 0: automatic
     bool debug;               // record resample index / likelihood per particle (parity tests)
+    bool strict;              // strict resampling: prefix[] is overwritten with the reference's rounded double cumulative after every finish
     unsigned long long* block_sums;   // scan scratch
     int scan_blocks;
     int32_t* dbg_idx;
@@ -360,6 +361,7 @@ struct mcl_args {
     uint32_t seed_lo, seed_hi, step;
     int interp;                   // parent utime != pose utime (first moved update)
     int resample;                 // 0: action-only (source = own index)
+    int strict;                   // prefix[] holds the reference's rounded double cumulative (bl_pf_set_strict_resampling)
     int win_w, win_h;             // LDS map window size in cells (0: no staging); >= grid size means the whole grid
     int split_log2;               // each particle's rays are spread over 2^split_log2 adjacent lanes
     int pk_ok;                    // grid and scan admit the packed 16-bit scoring path (see score_ray_pk)
@@ -418,8 +420,15 @@ __device__ __forceinline__ double readlane_f64(double v, int lane)
 
 __device__ __forceinline__ int kary_pos(int lo, int hi, int step, int k) { return min(lo + (k + 1) * step - 1, hi); }
 
+// The cumulative the search runs on: the exact integer prefix of the weight units (compared with T = U * S), or -- strict
+// mode -- the reference's own sequentially rounded double cumulative c_i (k_pf_cumulative_strict; compared with T = U).
+__device__ __forceinline__ bool resample_reaches(double T, unsigned long long v, bool strict)
+{
+    return strict ? T <= __longlong_as_double((long long)v) : T <= (double)v;
+}
+
 __device__ __forceinline__ void resample_bracket(const unsigned long long* __restrict__ prefix, int N, double T, bool active,
-                                                 int lane, int* out_lo, int* out_hi)
+                                                 int lane, int* out_lo, int* out_hi, bool strict = false)
 {
     *out_lo = 0; *out_hi = N - 1;
     const unsigned long long act = __builtin_amdgcn_ballot_w64(active);
@@ -430,8 +439,8 @@ __device__ __forceinline__ void resample_bracket(const unsigned long long* __res
         const int step0 = (hi0 - lo0 + 64) >> 6, step1 = (hi1 - lo1 + 64) >> 6;
         const unsigned long long v0 = prefix[kary_pos(lo0, hi0, step0, lane)];
         const unsigned long long v1 = prefix[kary_pos(lo1, hi1, step1, lane)];
-        const unsigned long long b0 = __builtin_amdgcn_ballot_w64(T0 <= (double)v0);
-        const unsigned long long b1 = __builtin_amdgcn_ballot_w64(T1 <= (double)v1);
+        const unsigned long long b0 = __builtin_amdgcn_ballot_w64(resample_reaches(T0, v0, strict));
+        const unsigned long long b1 = __builtin_amdgcn_ballot_w64(resample_reaches(T1, v1, strict));
         if (b0 == 0) lo0 = hi0;                                                // nothing reaches T: the clamp
         else { const int f = __ffsll((long long)b0) - 1; const int nl = f ? kary_pos(lo0, hi0, step0, f - 1) + 1 : lo0; hi0 = kary_pos(lo0, hi0, step0, f); lo0 = nl; }
         if (b1 == 0) lo1 = hi1;
@@ -441,11 +450,11 @@ __device__ __forceinline__ void resample_bracket(const unsigned long long* __res
 }
 
 // second part: the lane's own bisection inside the bracket.  index(T) = first i with T <= prefix[i] (clamped by the bracket).
-__device__ __forceinline__ int resample_bisect(const unsigned long long* __restrict__ prefix, double T, int lo, int hi)
+__device__ __forceinline__ int resample_bisect(const unsigned long long* __restrict__ prefix, double T, int lo, int hi, bool strict = false)
 {
     while (lo < hi) {
         const int mid = (lo + hi) >> 1;
-        if (T <= (double)prefix[mid]) hi = mid; else lo = mid + 1;
+        if (resample_reaches(T, prefix[mid], strict)) hi = mid; else lo = mid + 1;
     }
     return lo;
 }
@@ -605,11 +614,11 @@ __global__ __launch_bounds__(BLOCK) void k_mcl_main(mcl_args a)
     double rs_T = 0.0;
     int rs_lo = 0, rs_hi = a.N - 1;
     if (a.resample && (!shared_pro || wave < pw)) {                  // whole waves: the narrowing is cooperative
-        if (pro_active) rs_T = (a.r + mp * a.M_inv) * a.state->S;
-        resample_bracket(a.prefix, a.N, rs_T, pro_active, lane, &rs_lo, &rs_hi);
+        if (pro_active) { rs_T = a.r + mp * a.M_inv; if (!a.strict) rs_T *= a.state->S; }      // U (particle_filter.cpp:95), or U * S
+        resample_bracket(a.prefix, a.N, rs_T, pro_active, lane, &rs_lo, &rs_hi, a.strict != 0);
     }
     if (pro_active) {
-        if (a.resample) i = resample_bisect(a.prefix, rs_T, rs_lo, rs_hi);
+        if (a.resample) i = resample_bisect(a.prefix, rs_T, rs_lo, rs_hi, a.strict != 0);
         s = a.src[i];
         // ---- ActionModel::applyAction (action_model.cpp:78-103)
         float n1, n2, n3;
@@ -838,14 +847,106 @@ __global__ __launch_bounds__(MCLF_WG) void k_mcl_finish(mcl_finish_args f)
 // resamplePosteriorDistribution alone (particle_filter.cpp:84-103): the source index of every output particle, by exactly the
 // search k_mcl_main runs (diagnostic entry bl_pf_debug_resample)
 __global__ __launch_bounds__(256) void k_pf_resample_only(const unsigned long long* __restrict__ prefix, const pf_state* __restrict__ state,
-                                                          int N, double r, double M_inv, int32_t* __restrict__ out)
+                                                          int N, double r, double M_inv, int strict, int32_t* __restrict__ out)
 {
     const int m = blockIdx.x * blockDim.x + threadIdx.x, lane = threadIdx.x & 63;
     const bool on = m < N;
-    const double T = on ? (r + m * M_inv) * state->S : 0.0;
+    double T = on ? r + m * M_inv : 0.0;
+    if (!strict) T *= state->S;
     int lo, hi;
-    resample_bracket(prefix, N, T, on, lane, &lo, &hi);
-    if (on) out[m] = resample_bisect(prefix, T, lo, hi);
+    resample_bracket(prefix, N, T, on, lane, &lo, &hi, strict != 0);
+    if (on) out[m] = resample_bisect(prefix, T, lo, hi, strict != 0);
+}
+
+// ---- strict resampling: the reference's cumulative weight, bit for bit.
+// resamplePosteriorDistribution (particle_filter.cpp:84-103) compares U with c, c = w_0, then c += w_i: a SEQUENTIALLY ROUNDED
+// double sum of the normalised weights w_i = fl64(units_i / S).  One wave reproduces every c_i: inside a binade the sum is an
+// integer prefix of quantized terms (bl_serial_sum.h, double form), a step that leaves the binade or ties is taken in real
+// arithmetic.  128 particles per round, the next round's weights loaded ahead.  Strict mode only (bl_pf_set_strict_resampling):
+// it costs a launch of its own per update, ~0.6 ms at 100k particles.
+__device__ __forceinline__ long long mclf_scan_add_i64(long long v)
+{
+#define MCLF_STEP(C, R) { const int lo_ = mclf_dpp<C, R>(0, (int)(unsigned int)(unsigned long long)v);                       \
+                          const int hi_ = mclf_dpp<C, R>(0, (int)(unsigned int)((unsigned long long)v >> 32));                 \
+                          v += (long long)(((unsigned long long)(unsigned int)hi_ << 32) | (unsigned long long)(unsigned int)lo_); }
+    MCLF_DPP_STEPS(MCLF_STEP)
+#undef MCLF_STEP
+    return v;
+}
+__device__ __forceinline__ long long mclf_readlane_i64(long long v, int lane)
+{
+    const int lo = __builtin_amdgcn_readlane((int)(unsigned int)(unsigned long long)v, lane);
+    const int hi = __builtin_amdgcn_readlane((int)(unsigned int)((unsigned long long)v >> 32), lane);
+    return (long long)(((unsigned long long)(unsigned int)hi << 32) | (unsigned long long)(unsigned int)lo);
+}
+
+__global__ __launch_bounds__(64) void k_pf_cumulative_strict(const float4* __restrict__ rec, int N, const pf_state* __restrict__ state,
+                                                             double* __restrict__ out)
+{
+    const int lane = threadIdx.x;
+    const double S = state->S;
+    double acc = 0.0;                                              // wave-uniform
+    unsigned int un[2] = {0u, 0u};
+    if (2 * lane < N) un[0] = __float_as_uint(rec[2 * lane].w);
+    if (2 * lane + 1 < N) un[1] = __float_as_uint(rec[2 * lane + 1].w);
+    for (int base = 0; base < N; base += 128) {
+        const int n = min(128, N - base);
+        const double w[2] = {(double)un[0] / S, (double)un[1] / S};
+        {   // the next round's units, in flight during this round
+            const int nb = base + 128 + 2 * lane;
+            un[0] = nb < N ? __float_as_uint(rec[nb].w) : 0u;
+            un[1] = nb + 1 < N ? __float_as_uint(rec[nb + 1].w) : 0u;
+        }
+        int pos = 0;
+        while (pos < n) {
+            const int key = __builtin_amdgcn_readfirstlane(ssd_key(acc));
+            if (!key) {                                            // the very first term (c = w_0), or nothing usable
+                acc = ssd_exact_step(acc, mclf_readlane_f64((pos & 1) ? w[1] : w[0], pos >> 1));
+                if (lane == (pos >> 1)) out[base + pos] = acc;
+                pos++;
+                continue;
+            }
+            const long long M = ssd_mag(acc);
+            const ssd_bin b = ssd_bin_of(key);
+            long long p[2], run = 0;
+            int bad[2];
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const int i = 2 * lane + k;
+                int bk = 0;
+                const long long d = ssd_quantize(b, w[k], &bk);
+                const bool on = i >= pos && i < n;
+                run += on ? d : 0; bad[k] = on ? bk : 0;
+                p[k] = run;
+            }
+            const long long excl = mclf_scan_add_i64(run) - run;
+            long long Mi[2];
+            bool ex[2];
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const int i = 2 * lane + k;
+                Mi[k] = M + excl + p[k];
+                ex[k] = i >= pos && i < n && (bad[k] || Mi[k] <= SSD_MLO || Mi[k] >= SSD_MHI);
+            }
+            const unsigned long long mask = __builtin_amdgcn_ballot_w64(ex[0] || ex[1]);
+            int j = n;
+            if (mask) {
+                const int fl = __ffsll((long long)mask) - 1;
+                j = 2 * fl + (__builtin_amdgcn_readlane(ex[0] ? 1 : 0, fl) ? 0 : 1);
+            }
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const int i = 2 * lane + k;
+                if (i >= pos && i < j) out[base + i] = ssd_from(key, Mi[k]);
+            }
+            if (j == n) { acc = ssd_from(key, mclf_readlane_i64((n - 1) & 1 ? Mi[1] : Mi[0], (n - 1) >> 1)); break; }
+            double before = acc;
+            if (j > pos) before = ssd_from(key, mclf_readlane_i64((j - 1) & 1 ? Mi[1] : Mi[0], (j - 1) >> 1));
+            acc = ssd_exact_step(before, mclf_readlane_f64((j & 1) ? w[1] : w[0], j >> 1));
+            if (lane == (j >> 1)) out[base + j] = acc;
+            pos = j + 1;
+        }
+    }
 }
 
 // ---------------------------------------------------------------- init / export / small state kernels
@@ -1000,6 +1101,13 @@ extern "C" int bl_pf_set_exchange_buffers(bl_pf* pf, void* d_rec0, void* d_rec1)
 extern "C" void* bl_pf_exchange_rec_ptr(bl_pf* pf) { return pf && pf->prefix ? (void*)pf->rec[pf->pending_end ? pf->cur ^ 1 : pf->cur] : nullptr; }
 extern "C" const void* bl_pf_pose_device_ptr(bl_pf* pf) { return pf && pf->state ? (const void*)&pf->state->pose : nullptr; }
 
+// strict resampling: the integer prefix just written gives way to the reference's own cumulative (same buffer, as doubles)
+static void pf_strict_cumulative(bl_pf* pf, int which)
+{
+    if (!pf->strict) return;
+    hipLaunchKernelGGL(k_pf_cumulative_strict, dim3(1), dim3(64), 0, pf->ctx->stream, pf->rec[which], pf->N, pf->state, (double*)pf->prefix);
+}
+
 // what a finish launch needs beyond the block sums: the group shape, record and table space, the sync word.  Returns the group
 // count or -1 when the blocks do not tile a group.
 static int pf_finish_fill(bl_pf* pf, mcl_finish_args* f)
@@ -1045,6 +1153,7 @@ static int pf_scan(bl_pf* pf, int which, int write_pose, int64_t utime)
                            pf->block_sums, pf->scan_blocks, pf->prefix, pf->state);
     }
     BL_HIP(hipGetLastError());
+    pf_strict_cumulative(pf, which);
     return bl_timer_end(ctx, BL_K_MCL_SCAN, e0, e1);
 }
 
@@ -1203,6 +1312,7 @@ static int pf_launch_main(bl_pf* pf, const bl_grid* map, int R, int rand_value, 
     a.seed_lo = (uint32_t)pf->noise_seed; a.seed_hi = (uint32_t)(pf->noise_seed >> 32);
     a.step = pf->step;
     a.resample = resample;
+    a.strict = pf->strict ? 1 : 0;
     if (getenv("BOTLAB_MCL_DIAG_NOSEARCH")) a.resample = 0;
     // MovingLaserScan(scan, parent_pose, pose): parent_pose.utime is the particle's previous pose utime, pose.utime is
     // ActionModel::utime_ == 0 (D3); they differ only on the first moved update after initialisation.
@@ -1344,6 +1454,7 @@ static int pf_finish_fused(bl_pf* pf, int which, int64_t utime)
     if (rc) return rc;
     hipLaunchKernelGGL(k_mcl_finish, dim3(1 + groups), dim3(MCLF_WG), MCLF_LDS_BYTES, ctx->stream, f);
     BL_HIP(hipGetLastError());
+    pf_strict_cumulative(pf, which);
     return bl_timer_end(ctx, BL_K_MCL_SCAN, e0, e1);
 }
 
@@ -1396,7 +1507,7 @@ extern "C" int bl_pf_update_end(bl_pf* pf, bl_pose_xyt_t* out_pose)
 int bl_pf_take_finish(bl_pf* pf, mcl_finish_args* out)
 {
     if (!pf || !pf->pending_end) return 0;
-    if (!pf->fused_finish) return -1;
+    if (!pf->fused_finish || pf->strict) return -1;          // (strict resampling appends a launch of its own to the finish)
     if (pf_fused_args(pf, pf->cur ^ 1, pf->pending_utime, out) < 0) return -1;
     pf->cur ^= 1;
     pf->parent_utime = pf->pose_utime;       // parent_pose = sample.pose (action_model.cpp:92)
@@ -1486,6 +1597,18 @@ extern "C" int bl_pf_debug_estimate_stats(bl_pf* pf, uint32_t* out4)   /* eight 
     return BL_OK;
 }
 
+// Strict resampling on / off.  Takes effect with the next prefix the filter forms (an update's end, an upload of particles,
+// initializeFilterAtPose); switching it on for a filter that already holds particles re-forms the prefix at once.
+extern "C" int bl_pf_set_strict_resampling(bl_pf* pf, int on)
+{
+    BL_CHECK_ARG(pf != nullptr);
+    if (pf->pending_end) { bl_set_error("update pending"); return BL_ERR_STATE; }
+    const bool was = pf->strict;
+    pf->strict = on != 0;
+    if (pf->initialized && was != pf->strict) { BL_HIP(hipSetDevice(pf->ctx->device)); return pf_scan(pf, pf->cur, 0, 0); }
+    return BL_OK;
+}
+
 extern "C" int bl_pf_debug_resample(bl_pf* pf, int rand_value, int32_t* out_idx)
 {
     BL_CHECK_ARG(pf != nullptr && out_idx != nullptr);
@@ -1495,7 +1618,7 @@ extern "C" int bl_pf_debug_resample(bl_pf* pf, int rand_value, int32_t* out_idx)
     const double M_inv = 1.0 / pf->N;                                              // particle_filter.cpp:89
     const double r = (((double)rand_value) / (double)RAND_MAX) * M_inv;            // particle_filter.cpp:92
     hipLaunchKernelGGL(k_pf_resample_only, dim3((pf->N + 255) / 256), dim3(256), 0, pf->ctx->stream, pf->prefix, pf->state, pf->N, r, M_inv,
-                       pf->dbg_idx);
+                       pf->strict ? 1 : 0, pf->dbg_idx);
     BL_HIP(hipGetLastError());
     BL_HIP(hipMemcpyAsync(out_idx, pf->dbg_idx, (size_t)pf->N * 4, hipMemcpyDeviceToHost, pf->ctx->stream));
     BL_HIP(hipStreamSynchronize(pf->ctx->stream));

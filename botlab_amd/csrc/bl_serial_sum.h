@@ -124,4 +124,48 @@ SS_HD bool ss_rec_fits(const ss_rec& r, int key, int M)
     return r.key == SS_ID || in;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// The same for a DOUBLE accumulator stepped by doubles, c <- fl64(c + w): resamplePosteriorDistribution's cumulative weight
+// (src/slam/particle_filter.cpp:94-99).  One rounding per step (no float stage), 53-bit magnitudes in 64-bit integers.
+#define SSD_MLO (1ll << 52)
+#define SSD_MHI (1ll << 53)
+
+SS_HD uint64_t ssd_bits(double d) { uint64_t u; memcpy(&u, &d, 8); return u; }
+SS_HD double ssd_exact_step(double c, double w) { return c + w; }
+// 0: no usable binade (zero, subnormal or tiny, inf, nan); else 0x1000 | sign << 11 | biased exponent
+SS_HD int ssd_key(double c)
+{
+    const uint64_t b = ssd_bits(c);
+    const int ex = (int)((b >> 52) & 0x7ff);
+    if (ex < 128 || ex == 2047) return 0;
+    return 0x1000 | (int)((b >> 63) << 11) | ex;
+}
+SS_HD long long ssd_mag(double c) { return (long long)((ssd_bits(c) & 0xfffffffffffffull) | 0x10000000000000ull); }
+SS_HD double ssd_from(int key, long long M)        // 2^52 <= M <= 2^53
+{
+    const double mag = ldexp((double)M, (key & 0x7ff) - 1023 - 52);
+    return (key & 0x800) ? -mag : mag;
+}
+struct ssd_bin { double lim; int down; int neg; };
+SS_HD ssd_bin ssd_bin_of(int key)
+{
+    const int e = (key & 0x7ff) - 1023;
+    ssd_bin b;
+    b.lim = ldexp(1.0, e - 1);          // |t| < 2^(e-1): the scaled term stays below 2^51, where doubles still carry quarters
+    b.down = 52 - e;
+    b.neg = (key & 0x800) ? 1 : 0;
+    return b;
+}
+// integer the magnitude advances by for a term t, bad for a tie or an oversized term (branch-free)
+SS_HD long long ssd_quantize(const ssd_bin& b, double t, int* bad)
+{
+    const double ta = b.neg ? -t : t;
+    const bool big = !(fabs(ta) < b.lim);
+    const double q = ldexp(big ? 0.0 : ta, b.down);             // exact
+    const double f = floor(q);
+    const double r = q - f;                                     // exact: |q| < 2^51
+    *bad |= (big || r == 0.5) ? 1 : 0;
+    return (long long)f + (r > 0.5 ? 1 : 0);
+}
+
 #endif  // BL_SERIAL_SUM_H

@@ -308,6 +308,10 @@ class ParticleFilter:
         check(self.ctx.lib.bl_pf_estimate_posterior_pose(self.h, C.byref(out)))
         return out
 
+    def setStrictResampling(self, on=True):
+        """Resample against the reference's own sequentially rounded cumulative weight (bl_pf_set_strict_resampling)."""
+        check(self.ctx.lib.bl_pf_set_strict_resampling(self.h, 1 if on else 0))
+
     def debugResample(self, rand_value):
         """Source index of every output particle of resamplePosteriorDistribution for this rand() value (particle_filter.cpp:84-103)."""
         idx = np.empty(self.N, np.int32)

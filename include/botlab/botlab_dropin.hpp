@@ -313,6 +313,9 @@ public:
         }
         return out;
     }
+    // (extension) resample against the reference's own sequentially rounded cumulative weight: identical source indices for
+    // every rand() value, at the price of an extra launch per update (botlab_hip.h, bl_pf_set_strict_resampling)
+    void setStrictResampling(bool on) { check(bl_pf_set_strict_resampling(h_, on ? 1 : 0), "bl_pf_set_strict_resampling"); }
     bl_pf* device() const { return h_; }                                        // for the device-side extras (bl_pf_encode_particles_lcm ...)
 private:
     bl_pf* h_;

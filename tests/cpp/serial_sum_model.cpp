@@ -111,6 +111,65 @@ static float scheme(const std::vector<double>& t, int predict_mode, std::mt19937
     return chain(t, recs, st);
 }
 
+// ---- the double accumulator (resampling cumulative): every prefix value, by the phase loop alone
+static long check_double_scheme(std::mt19937_64& rng, long* cases)
+{
+    long failures = 0;
+    for (int kind = 0; kind < 6; ++kind) {
+        const int n = 1 + (int)(rng() % 3000);
+        std::vector<double> w(n), want(n), got(n);
+        double S = 0;
+        std::vector<double> u(n);
+        for (int i = 0; i < n; ++i) {
+            switch (kind) {
+            case 0: u[i] = 1.0; break;                                              // a fresh filter: all equal
+            case 1: u[i] = 1000.0 * (double)(40 + rng() % 36000); break;               // an update's likelihood units
+            case 2: u[i] = (rng() % 50 == 0) ? 2.0 : 1000.0 * (double)(1 + rng() % 500); break;   // with floored weights
+            case 3: u[i] = (double)(1ull << (rng() % 40)); break;                      // powers of two: ties
+            case 4: u[i] = (i % 7 == 0) ? 1e12 : 1.0; break;                           // a few dominant weights
+            default: u[i] = (double)(1 + rng() % 3); break;
+            }
+            S += u[i];
+        }
+        for (int i = 0; i < n; ++i) w[i] = u[i] / S;
+        double c = w[0];
+        want[0] = c;
+        for (int i = 1; i < n; ++i) { c = c + w[i]; want[i] = c; }
+        // the scheme: sub-tiles of SUB terms, phases inside
+        double acc = 0.0;
+        for (int base = 0; base < n; base += SUB) {
+            const int m = std::min(SUB, n - base);
+            int pos = 0;
+            while (pos < m) {
+                const int key = ssd_key(acc);
+                if (!key) { acc = ssd_exact_step(acc, w[base + pos]); got[base + pos] = acc; pos++; continue; }
+                const long long M = ssd_mag(acc);
+                const ssd_bin b = ssd_bin_of(key);
+                long long run = 0;
+                int exit_at = -1;
+                long long Mi[SUB];
+                for (int i = pos; i < m; ++i) {
+                    int bad = 0;
+                    run += ssd_quantize(b, w[base + i], &bad);
+                    Mi[i] = M + run;
+                    if (bad || Mi[i] <= SSD_MLO || Mi[i] >= SSD_MHI) { exit_at = i; break; }
+                }
+                const int upto = exit_at < 0 ? m : exit_at;
+                for (int i = pos; i < upto; ++i) got[base + i] = ssd_from(key, Mi[i]);
+                if (exit_at < 0) { acc = got[base + m - 1]; pos = m; break; }
+                const double before = exit_at == pos ? acc : got[base + exit_at - 1];
+                acc = ssd_exact_step(before, w[base + exit_at]);
+                got[base + exit_at] = acc;
+                pos = exit_at + 1;
+            }
+        }
+        (*cases)++;
+        for (int i = 0; i < n; ++i)
+            if (ssd_bits(got[i]) != ssd_bits(want[i])) { if (failures < 5) fprintf(stderr, "DOUBLE MISMATCH kind %d n %d i %d\n", kind, n, i); failures++; break; }
+    }
+    return failures;
+}
+
 int main(int argc, char** argv)
 {
     const int rounds = argc > 1 ? atoi(argv[1]) : 60;
@@ -151,6 +210,7 @@ int main(int argc, char** argv)
             }
         }
     }
+    for (int round = 0; round < rounds; ++round) failures += check_double_scheme(rng, &cases);
     printf("cases %ld failures %ld records %ld fitted %ld replays %ld phases %ld exact_steps %ld batches %ld\n", cases, failures, st.records,
            st.fitted, st.replays, st.phases, st.exact_steps, st.batches);
     return failures ? 1 : 0;

@@ -28,13 +28,14 @@ GLIBC = [1804289383, 846930886, 1681692777, 1714636915, 1957747793, 424238335, 7
 EDGE = [0, 1, 1000, 1 << 30, RAND_MAX]
 
 
-def _sweep(oracle, ctx, N, units):
+def _sweep(oracle, ctx, N, units, strict=False):
     p = np.zeros(N, PARTICLE_DTYPE)
     rng = np.random.default_rng(N)
     p["x"] = rng.standard_normal(N).astype(np.float32)
     pf = bl.ParticleFilter(N, ctx=ctx)
     out = {}
     try:
+        pf.setStrictResampling(strict)
         pf.setParticles(p, units)
         host = np.ascontiguousarray(pf.particles())          # the weights units / S as doubles: what the reference would hold
         want = np.empty(N, np.int32)
@@ -78,3 +79,56 @@ def test_resample_index_disagreements_are_counted_and_bounded(oracle, gpu_ctx, N
     os.makedirs("gpurun_out", exist_ok=True)
     with open(os.path.join("gpurun_out", f"resample_sweep_{N}.json"), "w") as fh:
         json.dump({k: {str(r): c for r, c in v.items()} for k, v in report.items()}, fh)
+
+
+@pytest.mark.parametrize("N", [4096, 100_000, 300_000])
+def test_strict_resampling_has_no_disagreements(oracle, gpu_ctx, N):
+    """bl_pf_set_strict_resampling: the resampler searches the reference's own sequentially rounded cumulative (formed bit for
+    bit by k_pf_cumulative_strict) -- identical source indices for EVERY rand() value of the sweep and all three kinds of
+    weights, the degenerate ones included."""
+    rng = np.random.default_rng(11 * N)
+    kinds = {"after_update": (1000 * rng.integers(40, 36000, N)).astype(np.uint32), "uniform": np.ones(N, np.uint32),
+             "few_dominant": np.where(np.arange(N) % 997 == 0, 1000 * 36830, 2).astype(np.uint32)}
+    kinds["after_update"][rng.random(N) < 0.02] = 2
+    for name, units in kinds.items():
+        rep = _sweep(oracle, gpu_ctx, N, units, strict=True)
+        assert sum(rep.values()) == 0, (name, rep)
+
+
+def test_strict_mode_updates_match_the_oracle(oracle, maps, gpu_ctx):
+    """Whole updates in strict mode (the stand-alone finish + the cumulative kernel in front of every k_mcl_main): indices,
+    likelihoods, particles and estimate as in the default mode's parity tests -- with rand() values the default mode cannot
+    take on a fresh filter (0, RAND_MAX)."""
+    import helpers
+    import oracle_lib
+    from botlab_amd import synth
+    N = 20_000
+    m = maps["obstacle_slam_10mx10m_5cm"]
+    truth = np.where(m["cells"] > 0, 127, -127).astype(np.int8)
+    g = bl.OccupancyGrid.from_cells(m["cells"], m["origin"], m["mpc"], cellsPerMeter=helpers.CPM_DEFAULT, ctx=gpu_ctx)
+    poses = synth.square_trajectory((-0.75, 0.2, 0.0), 4, step_len=0.02, turn=0.05, side=0.8)
+    scans = [synth.raycast_scan(truth, m["origin"], 0.05, poses[k - 1], poses[k], 1_000_000 + k * 100_000) for k in range(1, 5)]
+    opf = oracle_lib.OraclePF(oracle, N)
+    opf.init_at_pose(oracle.pose(-0.75, 0.2, 0.0, utime=int(scans[0].times[0])), 5)
+    pf = bl.ParticleFilter(N, ctx=gpu_ctx)
+    pf.setStrictResampling(True)
+    pf.setParticles(opf.particles())
+    pf.debugEnable(True)
+    moved = 0
+    for k, sc in enumerate(scans):
+        o = poses[k + 1]
+        rv = (0, 0, RAND_MAX, 1)[k]
+        res = opf.update(oracle.pose(*o, utime=sc.utime), sc, m["cells"], m["mpc"], helpers.CPM_DEFAULT, m["origin"], rv)
+        pose = pf.updateFilter(bl.make_pose(*o, utime=sc.utime), sc, g, rand_value=rv, noise=res["noise"])
+        if not res["moved"]:
+            continue
+        moved += 1
+        idx, like = pf.debugLast()
+        assert np.array_equal(idx, res["idx"]), k
+        assert np.array_equal(like.astype(np.float64) * 0.5, res["raw"]), k
+        got, exp = pf.particles(), opf.particles()
+        for f in ("x", "y", "theta", "p_x", "p_y", "p_theta"):
+            assert np.array_equal(got[f], exp[f]), (k, f)
+        assert (np.float32(pose.x), np.float32(pose.y), np.float32(pose.theta)) == (np.float32(res["pose"].x), np.float32(res["pose"].y), np.float32(res["pose"].theta))
+    assert moved == 3
+    pf.close()
