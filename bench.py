@@ -149,7 +149,7 @@ def self_launch(n):
 
 
 OTHER_CONFIGS = [                                      # (preset, goal_l1 in cells): short runs printed beside the headline
-    (4, 40), (4, 400), (5, 40), (5, 200),
+    (4, 40), (4, 400), (5, 40),
 ]
 
 
@@ -245,7 +245,7 @@ def main():
                          "4: 2000x2000 maze with a replan per step; 5: 4096x4096, 256k particles); explicit flags still win")
     ap.add_argument("--sub", action="store_true", help="a child run of the default invocation (other_configs): no children of its own")
     ap.add_argument("--no-other-configs", action="store_true", help="default run: skip the short runs of configs 4 and 5")
-    ap.add_argument("--other-steps", type=int, default=300, help="timed steps of each other_configs run")
+    ap.add_argument("--other-steps", type=int, default=200, help="timed steps of each other_configs run")
     args = ap.parse_args()
     presets = {3: dict(particles=1_000_000, no_astar=True),
                4: dict(grid=2000, lanes=3, batch=4, depth=18),
