@@ -68,7 +68,8 @@ struct mcl_finish_args {
 #define MCLF_MARGIN 4096                      // ulps of slack on the predicted start when deciding "risky"
 #define MCLF_TSLOTS 20                        // per axis: tables
 #define MCLF_MAXENT 32                        // per axis: risky sub-tiles the chain steps through by the list (more: the slow walk)
-#define MCLF_HEAD_STEPS 32                    // terms at the very start of a sum that are simply stepped (a binade change every few terms)
+#define MCLF_PRE_SUBS 5                       // sub-tiles at the start of the sums that the finisher's idle waves do while the groups run
+#define MCLF_PRE_STEPPED 2                    // ... the first of them term by term (a binade change every few terms), the others in-binade
 #define MCLF_LDS_BYTES (112 * 1024)           // scratch the finisher wants (the map kernel's counter window serves)
 
 static inline int mclf_gthreads(int N) { return N >= MCLF_GT_SWITCH ? MCLF_GT_LARGE : MCLF_GT_SMALL; }
@@ -93,8 +94,9 @@ struct mclf_smem {
     double wx[MCLF_MAXW], wy[MCLF_MAXW];          // sums of the sub-tiles' terms
     double red[MCLF_POSE_THREADS / 64][5];
     unsigned long long word;                      // the sync word the finisher saw
-    float xy[2], first[2];                        // the sums; the sums behind sub-tile 0
+    float xy[2], first[2];                        // the sums; the sums behind the finisher's own sub-tiles
     unsigned int stats[8];
+    double pre[2][MCLF_PRE_STEPPED * MCLF_SUB];   // the terms the finisher steps one by one, per axis
 };
 
 #ifdef MCLF_STAMPS
@@ -270,9 +272,10 @@ __device__ __forceinline__ void mclf_prefix_in(int key, const double (&t)[MCLF_I
 __device__ __forceinline__ ss_rec mclf_make_record(const mcl_finish_args& f, int axis, const double (&t)[MCLF_ITEMS], int cnt,
                                                    double predicted_start, bool very_first, int lane)
 {
-    // (the very first sub-tile starts from zero: the finisher steps through it itself, ahead of everything; it is listed as
-    // risky, without a table, so that no gap ever covers it)
-    if (very_first) return ss_rec_make(MCLF_RISKY, 0, 0, 0);
+    // (the first sub-tiles of the sums are the finisher's own work, done while the groups run: the sums start from zero, so
+    // nothing is needed from the groups there, and the binade changes every few terms.  Their records are empty runs: no gap
+    // and no list entry ever covers them)
+    if (very_first) return ss_rec_identity();
     const int key = __builtin_amdgcn_readfirstlane(ss_key((float)predicted_start));
     int p[MCLF_ITEMS] = {0, 0}, bad[MCLF_ITEMS] = {0, 0};
     bool risky = true;
@@ -382,7 +385,7 @@ __device__ __forceinline__ void mclf_prefix_group(const mcl_finish_args& f, int 
     __syncthreads();
     px /= S; py /= S;                                     // predicted accumulators where the group starts ...
     for (int w = 0; w < wave; ++w) { px += sm.wx[w]; py += sm.wy[w]; }      // ... and where this wave's sub-tile starts
-    const bool very_first = g == 0 && wave == 0;
+    const bool very_first = g * nw + wave < MCLF_PRE_SUBS;
     const ss_rec rx = mclf_make_record(f, 0, tx, cnt, px, very_first, lane);
     const ss_rec ry = mclf_make_record(f, 1, ty, cnt, py, very_first, lane);
     MCLF_GSTAMP(5);
@@ -633,16 +636,17 @@ __device__ __forceinline__ float mclf_walk(const mcl_finish_args& f, int axis, d
 }
 
 // One axis' float accumulator over all particles, by one wave (all 64 lanes; the result is wave-uniform).
-// `first`: the accumulator behind sub-tile 0.
+// `first`: the accumulator behind the first MCLF_PRE_SUBS sub-tiles (mclf_pose).
 __device__ __forceinline__ float mclf_chain(const mcl_finish_args& f, const mclf_stage* st, int ntab, int axis, double S, float first, int lane,
                                             unsigned int* stats)
 {
     const int nrec = f.groups * (f.gthreads >> 6);
     // (a list that overflowed is no list: the gaps between listed entries would skip the unlisted risky records)
-    if (!st || *st->nent > MCLF_MAXENT) return mclf_walk(f, axis, S, 1, nrec, first, lane, &stats[0], &stats[1]);
+    const int done = min(MCLF_PRE_SUBS, nrec);
+    if (!st || *st->nent > MCLF_MAXENT) return mclf_walk(f, axis, S, done, nrec, first, lane, &stats[0], &stats[1]);
     const int nent = __builtin_amdgcn_readfirstlane(*st->nent);
-    float acc = first;                                           // sub-tile 0 is done (mclf_pose)
-    int prev = 0;                                                // last sub-tile done
+    float acc = first;                                           // the first sub-tiles are done (mclf_pose)
+    int prev = done - 1;                                         // last sub-tile done
     for (int k = 0; k <= nent; ++k) {
 #ifdef MCLF_STAMPS
         if (axis == 0 && k < 16 && lane == 0) f.state->cstamps[k] = MCLF_NOW();
@@ -660,8 +664,8 @@ __device__ __forceinline__ float mclf_chain(const mcl_finish_args& f, const mclf
             else { acc = mclf_walk(f, axis, S, prev + 1, sp.s, acc, lane, &stats[0], &stats[1]); stats[3] += 1; }
         }
         if (k == nent) break;
-        // the risky sub-tile itself (sub-tile 0, always the first of the list, is behind us)
-        if (sp.lo_n >= 0 && sp.s > 0) {
+        // the risky sub-tile itself
+        if (sp.lo_n >= 0) {
             const int lo = sp.lo_n >> 8, n = (sp.lo_n & 0xff) + 1;
             if (sp.tslot >= 0 && sp.tslot < ntab) {
                 const mclf_tab_elem* row = st->tab + sp.tslot * MCLF_SUB + 2 * lane;
@@ -692,6 +696,25 @@ __device__ __forceinline__ void mclf_pose(const mcl_finish_args& f, mclf_smem& s
 #else
 #define MCLF_STAMP(i) do { } while (0)
 #endif
+    const int nrec = f.groups * (f.gthreads >> 6), nbatch = (nrec + 63) >> 6;
+    // waves 2 / 3 will do the first sub-tiles of the x / y sums themselves (below): their particles are requested now, so that
+    // the loads are under way while the block sums are reduced
+    float4 pre_r[MCLF_PRE_SUBS][MCLF_ITEMS];
+    int pre_cnt[MCLF_PRE_SUBS];
+    const int npre = min(MCLF_PRE_SUBS, nrec);
+    if (wave == 2 || wave == 3) {
+#pragma unroll
+        for (int q = 0; q < MCLF_PRE_SUBS; ++q) {
+            int lo = 0, hi = 0;
+            if (q < npre) mclf_sub_range(f, q, &lo, &hi);
+            pre_cnt[q] = hi - lo;
+#pragma unroll
+            for (int k = 0; k < MCLF_ITEMS; ++k) {
+                const int i = lo + lane * MCLF_ITEMS + k;
+                pre_r[q][k] = i < hi ? f.rec[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+    }
     // the sums of units, units*sin, units*cos in a fixed order (thread-strided with a stride of 256, wave shuffles, waves in order)
     if (tid < MCLF_POSE_THREADS) {
         double v[5] = {0, 0, 0, 0, 0};
@@ -700,7 +723,6 @@ __device__ __forceinline__ void mclf_pose(const mcl_finish_args& f, mclf_smem& s
         for (int k = 0; k < 5; ++k) v[k] = mclf_wave_sum(v[k]);
         if (lane == 0) for (int k = 0; k < 5; ++k) sm.red[wave][k] = v[k];
     }
-    const int nrec = f.groups * (f.gthreads >> 6), nbatch = (nrec + 63) >> 6;
     const size_t per_axis = (mclf_stage_bytes(nbatch) + 15) & ~(size_t)15;
     const bool staged = scratch != nullptr && 2 * per_axis <= scratch_bytes;
 #define MCLF_STAGE(axis) mclf_stage_at(scratch + (size_t)(axis) * per_axis, nbatch)
@@ -715,14 +737,47 @@ __device__ __forceinline__ void mclf_pose(const mcl_finish_args& f, mclf_smem& s
         sm.word = w;
     }
     if (wave == 2 || wave == 3) {
-        // meanwhile: the sums start from zero, so sub-tile 0 needs nothing from the groups -- its first terms stepped one by
-        // one, the rest in-binade (waves 2 / 3: x / y)
-        int lo, hi;
-        mclf_sub_range(f, 0, &lo, &hi);
-        double t[MCLF_ITEMS];
-        mclf_load_terms(f, wave - 2, S, lo, hi, lane, t);
+        // meanwhile: the sums start from zero, so their first MCLF_PRE_SUBS sub-tiles need nothing from the groups -- the first
+        // two stepped term by term (three dependent operations per term), the others by the in-binade replay (waves 2 / 3: x / y)
+        double t[MCLF_PRE_SUBS][MCLF_ITEMS];
+        int cnt[MCLF_PRE_SUBS];
+#pragma unroll
+        for (int q = 0; q < MCLF_PRE_SUBS; ++q) {
+            cnt[q] = pre_cnt[q];
+#pragma unroll
+            for (int k = 0; k < MCLF_ITEMS; ++k)
+                t[q][k] = (lane * MCLF_ITEMS + k < pre_cnt[q]) ? mclf_term(pre_r[q][k], S, wave - 2) : 0.0;
+        }
         unsigned int ph = 0;
-        const float v = mclf_replay(t, hi - lo, 0, MCLF_HEAD_STEPS, 0.0f, lane, &ph);
+        float v = 0.0f;
+        // the stepped sub-tiles: terms to LDS (lane order = term order), then one wave-uniform loop of three dependent
+        // operations per term; the LDS reads run ahead of the sum
+        double* pre = sm.pre[wave - 2];
+        int nstep = 0;
+#pragma unroll
+        for (int q = 0; q < MCLF_PRE_STEPPED; ++q) {
+            if (q < npre) {
+                pre[q * MCLF_SUB + 2 * lane] = t[q][0];
+                pre[q * MCLF_SUB + 2 * lane + 1] = t[q][1];
+                nstep = q * MCLF_SUB + cnt[q];                    // (a short sub-tile can only be the last one)
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        nstep = __builtin_amdgcn_readfirstlane(nstep);
+        {
+            int i = 0;
+            for (; i + 8 <= nstep; i += 8) {
+                double w8[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) w8[u] = pre[i + u];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v = ss_exact_step(v, w8[u]);
+            }
+            for (; i < nstep; ++i) v = ss_exact_step(v, pre[i]);
+        }
+#pragma unroll
+        for (int q = MCLF_PRE_STEPPED; q < MCLF_PRE_SUBS; ++q)
+            if (q < npre && cnt[q] > 0) v = mclf_replay(t[q], cnt[q], 0, 0, v, lane, &ph);
         if (lane == 0) sm.first[wave - 2] = v;
     }
     __syncthreads();
