@@ -104,7 +104,8 @@ __global__ __launch_bounds__(MAP_THREADS) void k_map_update(map_args a)
             __syncthreads();                                    // every lane's loads from the slot have returned
             if (threadIdx.x == 0) __hip_atomic_store(a.pre.h_seq, a.pre.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         } else {
-            mclf_prefix_group(a.fin, (int)blockIdx.x - 1, s_fin);
+            if (blockIdx.x == 1) mclf_pre_chain(a.fin, s_fin);
+            else mclf_prefix_group(a.fin, (int)blockIdx.x - MCLF_EXTRA_WGS, s_fin);
         }
         return;
     }
@@ -535,7 +536,7 @@ static int mapping_update_impl(bl_mapping* m, const bl_lidar_t* scan, const bl_p
     a.pre = bl_scan_prefetch_args{};
     a.pre_on = bl_scan_prefetch_take(ctx, &a.pre);
     static_assert(MCLF_WG == MAP_THREADS, "the riding finish uses the map kernel's workgroup size");
-    hipLaunchKernelGGL(k_map_update, dim3(1 + (fin ? fin->groups : 0) + a.pre_on), dim3(MAP_THREADS), MAP_LDS_COUNTERS * 2, ctx->stream, a);
+    hipLaunchKernelGGL(k_map_update, dim3(1 + (fin ? fin->groups + MCLF_EXTRA_WGS - 1 : 0) + a.pre_on), dim3(MAP_THREADS), MAP_LDS_COUNTERS * 2, ctx->stream, a);
     BL_HIP(hipGetLastError());
     rc = bl_timer_end(ctx, BL_K_MAP, e0, e1);
     if (rc) return rc;

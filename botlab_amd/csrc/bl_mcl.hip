@@ -841,7 +841,8 @@ __global__ __launch_bounds__(MCLF_WG) void k_mcl_finish(mcl_finish_args f)
     __shared__ mclf_smem sm;
     extern __shared__ __align__(16) char s_fin_scratch[];                  // MCLF_LDS_BYTES (the groups do not touch it)
     if (blockIdx.x == 0) mclf_pose(f, sm, s_fin_scratch, (size_t)MCLF_LDS_BYTES);
-    else mclf_prefix_group(f, (int)blockIdx.x - 1, sm);
+    else if (blockIdx.x == 1) mclf_pre_chain(f, sm);
+    else mclf_prefix_group(f, (int)blockIdx.x - MCLF_EXTRA_WGS, sm);
 }
 
 // resamplePosteriorDistribution alone (particle_filter.cpp:84-103): the source index of every output particle, by exactly the
@@ -1044,8 +1045,8 @@ static int pf_alloc(bl_pf* pf)
     pf->fin_subs_cap = (int)(N / MCLF_SUB) + 4 * (MCLF_WG / 64);      // main region + tail region, each rounded up to whole groups
     BL_HIP(hipMalloc((void**)&pf->fin_recs, (size_t)2 * pf->fin_subs_cap * sizeof(ss_rec)));
     BL_HIP(hipMalloc((void**)&pf->fin_tabs, (size_t)2 * MCLF_TSLOTS * MCLF_SUB * sizeof(mclf_tab_elem)));
-    BL_HIP(hipMalloc((void**)&pf->fin_sync, sizeof(unsigned long long)));
-    BL_HIP(hipMemsetAsync(pf->fin_sync, 0, sizeof(unsigned long long), pf->ctx->stream));
+    BL_HIP(hipMalloc((void**)&pf->fin_sync, 4 * sizeof(unsigned long long)));
+    BL_HIP(hipMemsetAsync(pf->fin_sync, 0, 4 * sizeof(unsigned long long), pf->ctx->stream));
     BL_HIP(hipMalloc((void**)&pf->dbg_idx, n * sizeof(int32_t)));
     BL_HIP(hipMalloc((void**)&pf->dbg_like, n * sizeof(int32_t)));
     BL_HIP(hipMemsetAsync(pf->state, 0, sizeof(pf_state), pf->ctx->stream));
@@ -1147,7 +1148,7 @@ static int pf_scan(bl_pf* pf, int which, int write_pose, int64_t utime)
         f.prefix = pf->prefix; f.state = pf->state; f.utime = utime;
         const int groups = pf_finish_fill(pf, &f);
         if (groups < 0) { bl_set_error("internal: finish launch shape"); return BL_ERR_STATE; }
-        hipLaunchKernelGGL(k_mcl_finish, dim3(1 + groups), dim3(MCLF_WG), MCLF_LDS_BYTES, ctx->stream, f);
+        hipLaunchKernelGGL(k_mcl_finish, dim3(MCLF_EXTRA_WGS + groups), dim3(MCLF_WG), MCLF_LDS_BYTES, ctx->stream, f);
     } else {
         hipLaunchKernelGGL(k_scan_write_prefix, dim3(pf->scan_blocks), dim3(SCAN_THREADS), 0, ctx->stream, pf->rec[which], pf->N,
                            pf->block_sums, pf->scan_blocks, pf->prefix, pf->state);
@@ -1452,7 +1453,7 @@ static int pf_finish_fused(bl_pf* pf, int which, int64_t utime)
     hipEvent_t e0, e1;
     int rc = bl_timer_begin(ctx, BL_K_MCL_SCAN, &e0, &e1);
     if (rc) return rc;
-    hipLaunchKernelGGL(k_mcl_finish, dim3(1 + groups), dim3(MCLF_WG), MCLF_LDS_BYTES, ctx->stream, f);
+    hipLaunchKernelGGL(k_mcl_finish, dim3(MCLF_EXTRA_WGS + groups), dim3(MCLF_WG), MCLF_LDS_BYTES, ctx->stream, f);
     BL_HIP(hipGetLastError());
     pf_strict_cumulative(pf, which);
     return bl_timer_end(ctx, BL_K_MCL_SCAN, e0, e1);

@@ -51,7 +51,8 @@ struct mcl_finish_args {
     int64_t utime;
     ss_rec* recs;                          // [2][groups * subs]: x records, then y records
     mclf_tab_elem* tabs;                   // [2][MCLF_TSLOTS][MCLF_SUB]
-    unsigned long long* sync;              // bits 32..: groups done; bits 0..15 / 16..31: x / y tables handed out.  Zero between launches.
+    unsigned long long* sync;              // [0] bits 32..: groups done; bits 0..15 / 16..31: x / y tables handed out.  [1] the sums
+                                           // behind the first MCLF_PRE_SUBS sub-tiles (x, y float bits), [2] "they are there".  Zero between launches.
     int groups, gthreads;                  // group workgroups; threads of each that work (256 or 1024)
 };
 
@@ -68,7 +69,8 @@ struct mcl_finish_args {
 #define MCLF_MARGIN 4096                      // ulps of slack on the predicted start when deciding "risky"
 #define MCLF_TSLOTS 20                        // per axis: tables
 #define MCLF_MAXENT 32                        // per axis: risky sub-tiles the chain steps through by the list (more: the slow walk)
-#define MCLF_PRE_SUBS 5                       // sub-tiles at the start of the sums that the finisher's idle waves do while the groups run
+#define MCLF_PRE_SUBS 9                       // sub-tiles at the start of the sums that a workgroup of its own does while the groups run
+#define MCLF_EXTRA_WGS 2                      // workgroups of the launch in front of the groups: finisher, pre-chain
 #define MCLF_PRE_STEPPED 2                    // ... the first of them term by term (a binade change every few terms), the others in-binade
 #define MCLF_LDS_BYTES (112 * 1024)           // scratch the finisher wants (the map kernel's counter window serves)
 
@@ -683,6 +685,85 @@ __device__ __forceinline__ float mclf_chain(const mcl_finish_args& f, const mclf
     return acc;
 }
 
+// The pre-chain workgroup: the float sums over the first MCLF_PRE_SUBS sub-tiles.  The sums start from zero, so nothing is
+// needed from the groups there, and that is where the accumulator changes its binade every few terms: the first sub-tiles are
+// stepped term by term (terms through LDS, one wave-uniform loop of three dependent operations per term), the others by the
+// in-binade replay.  Waves 0 / 1: x / y; the result goes to the finisher through f.sync[1..2].  Called by every thread of the
+// workgroup (barriers).
+__device__ __forceinline__ void mclf_pre_chain(const mcl_finish_args& f, mclf_smem& sm)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid >= MCLF_POSE_THREADS) return;
+    const int nrec = f.groups * (f.gthreads >> 6);
+    const int npre = min(MCLF_PRE_SUBS, nrec);
+    // the particles are requested before the block sums are reduced
+    float4 pre_r[MCLF_PRE_SUBS][MCLF_ITEMS];
+    int cnt[MCLF_PRE_SUBS];
+    if (wave < 2) {
+#pragma unroll
+        for (int q = 0; q < MCLF_PRE_SUBS; ++q) {
+            int lo = 0, hi = 0;
+            if (q < npre) mclf_sub_range(f, q, &lo, &hi);
+            cnt[q] = hi - lo;
+#pragma unroll
+            for (int k = 0; k < MCLF_ITEMS; ++k) {
+                const int i = lo + lane * MCLF_ITEMS + k;
+                pre_r[q][k] = i < hi ? f.rec[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+    }
+    double su = 0.0;
+    for (int b = tid; b < f.nblocks; b += MCLF_POSE_THREADS) su += f.partials[(size_t)b * 5];
+    su = mclf_wave_sum_all(su);
+    if (lane == 0) sm.red[wave][0] = su;
+    __syncthreads();
+    if (wave >= 2) return;
+    double S = 0.0;
+    for (int w = 0; w < MCLF_POSE_THREADS / 64; ++w) S += sm.red[w][0];          // exact integer below 2^53, any order gives it
+    unsigned int ph = 0;
+    float v = 0.0f;
+    double* pre = sm.pre[wave];
+    int nstep = 0;
+#pragma unroll
+    for (int q = 0; q < MCLF_PRE_STEPPED; ++q) {
+        if (q < npre) {
+#pragma unroll
+            for (int k = 0; k < MCLF_ITEMS; ++k)
+                pre[q * MCLF_SUB + 2 * lane + k] = (lane * MCLF_ITEMS + k < cnt[q]) ? mclf_term(pre_r[q][k], S, wave) : 0.0;
+            nstep = q * MCLF_SUB + cnt[q];                    // (a short sub-tile can only be the last one)
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    nstep = __builtin_amdgcn_readfirstlane(nstep);
+    {
+        int i = 0;
+        for (; i + 8 <= nstep; i += 8) {
+            double w8[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) w8[u] = pre[i + u];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v = ss_exact_step(v, w8[u]);
+        }
+        for (; i < nstep; ++i) v = ss_exact_step(v, pre[i]);
+    }
+#pragma unroll
+    for (int q = MCLF_PRE_STEPPED; q < MCLF_PRE_SUBS; ++q) {
+        if (q < npre && cnt[q] > 0) {
+            double t[MCLF_ITEMS];
+#pragma unroll
+            for (int k = 0; k < MCLF_ITEMS; ++k) t[k] = (lane * MCLF_ITEMS + k < cnt[q]) ? mclf_term(pre_r[q][k], S, wave) : 0.0;
+            v = mclf_replay(t, cnt[q], 0, 0, v, lane, &ph);
+        }
+    }
+    if (lane == 0) sm.first[wave] = v;
+    __syncthreads();                                           // (waves 0 and 1 only: the others have left)
+    if (tid == 0) {
+        mclf_store_u64(f.sync + 1, (unsigned long long)__float_as_uint(sm.first[0]) | ((unsigned long long)__float_as_uint(sm.first[1]) << 32));
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        mclf_store_u64(f.sync + 2, 1ull);
+    }
+}
+
 // The finisher: waits for the groups of this launch, forms estimatePosteriorPose.  Called by EVERY thread of a workgroup of
 // MCLF_WG threads (it contains barriers).  scratch / scratch_bytes: LDS the finisher may use until it returns (16-byte aligned).
 // s_pose_out (shared memory, optional) receives the estimate too.
@@ -697,24 +778,6 @@ __device__ __forceinline__ void mclf_pose(const mcl_finish_args& f, mclf_smem& s
 #define MCLF_STAMP(i) do { } while (0)
 #endif
     const int nrec = f.groups * (f.gthreads >> 6), nbatch = (nrec + 63) >> 6;
-    // waves 2 / 3 will do the first sub-tiles of the x / y sums themselves (below): their particles are requested now, so that
-    // the loads are under way while the block sums are reduced
-    float4 pre_r[MCLF_PRE_SUBS][MCLF_ITEMS];
-    int pre_cnt[MCLF_PRE_SUBS];
-    const int npre = min(MCLF_PRE_SUBS, nrec);
-    if (wave == 2 || wave == 3) {
-#pragma unroll
-        for (int q = 0; q < MCLF_PRE_SUBS; ++q) {
-            int lo = 0, hi = 0;
-            if (q < npre) mclf_sub_range(f, q, &lo, &hi);
-            pre_cnt[q] = hi - lo;
-#pragma unroll
-            for (int k = 0; k < MCLF_ITEMS; ++k) {
-                const int i = lo + lane * MCLF_ITEMS + k;
-                pre_r[q][k] = i < hi ? f.rec[i] : make_float4(0.f, 0.f, 0.f, 0.f);
-            }
-        }
-    }
     // the sums of units, units*sin, units*cos in a fixed order (thread-strided with a stride of 256, wave shuffles, waves in order)
     if (tid < MCLF_POSE_THREADS) {
         double v[5] = {0, 0, 0, 0, 0};
@@ -735,50 +798,6 @@ __device__ __forceinline__ void mclf_pose(const mcl_finish_args& f, mclf_smem& s
         unsigned long long w;
         while (((w = mclf_load_u64(f.sync)) >> 32) < (unsigned long long)f.groups) __builtin_amdgcn_s_sleep(1);
         sm.word = w;
-    }
-    if (wave == 2 || wave == 3) {
-        // meanwhile: the sums start from zero, so their first MCLF_PRE_SUBS sub-tiles need nothing from the groups -- the first
-        // two stepped term by term (three dependent operations per term), the others by the in-binade replay (waves 2 / 3: x / y)
-        double t[MCLF_PRE_SUBS][MCLF_ITEMS];
-        int cnt[MCLF_PRE_SUBS];
-#pragma unroll
-        for (int q = 0; q < MCLF_PRE_SUBS; ++q) {
-            cnt[q] = pre_cnt[q];
-#pragma unroll
-            for (int k = 0; k < MCLF_ITEMS; ++k)
-                t[q][k] = (lane * MCLF_ITEMS + k < pre_cnt[q]) ? mclf_term(pre_r[q][k], S, wave - 2) : 0.0;
-        }
-        unsigned int ph = 0;
-        float v = 0.0f;
-        // the stepped sub-tiles: terms to LDS (lane order = term order), then one wave-uniform loop of three dependent
-        // operations per term; the LDS reads run ahead of the sum
-        double* pre = sm.pre[wave - 2];
-        int nstep = 0;
-#pragma unroll
-        for (int q = 0; q < MCLF_PRE_STEPPED; ++q) {
-            if (q < npre) {
-                pre[q * MCLF_SUB + 2 * lane] = t[q][0];
-                pre[q * MCLF_SUB + 2 * lane + 1] = t[q][1];
-                nstep = q * MCLF_SUB + cnt[q];                    // (a short sub-tile can only be the last one)
-            }
-        }
-        __builtin_amdgcn_wave_barrier();
-        nstep = __builtin_amdgcn_readfirstlane(nstep);
-        {
-            int i = 0;
-            for (; i + 8 <= nstep; i += 8) {
-                double w8[8];
-#pragma unroll
-                for (int u = 0; u < 8; ++u) w8[u] = pre[i + u];
-#pragma unroll
-                for (int u = 0; u < 8; ++u) v = ss_exact_step(v, w8[u]);
-            }
-            for (; i < nstep; ++i) v = ss_exact_step(v, pre[i]);
-        }
-#pragma unroll
-        for (int q = MCLF_PRE_STEPPED; q < MCLF_PRE_SUBS; ++q)
-            if (q < npre && cnt[q] > 0) v = mclf_replay(t[q], cnt[q], 0, 0, v, lane, &ph);
-        if (lane == 0) sm.first[wave - 2] = v;
     }
     __syncthreads();
     MCLF_STAMP(1);
@@ -859,14 +878,20 @@ __device__ __forceinline__ void mclf_pose(const mcl_finish_args& f, mclf_smem& s
     MCLF_STAMP(3);
     if (wave < 2) {                                                                // wave 0: pose.x, wave 1: pose.y
         unsigned int stats[4] = {0, 0, 0, 0};
+        // the sums behind the first sub-tiles, from the pre-chain workgroup (long done by now, as a rule)
+        while (mclf_load_u64(f.sync + 2) == 0ull) __builtin_amdgcn_s_sleep(1);
+        const unsigned long long fw = mclf_load_u64(f.sync + 1);
+        const float first = __uint_as_float((unsigned int)(wave ? fw >> 32 : fw));
         const mclf_stage mine = MCLF_STAGE(wave);
-        const float v = mclf_chain(f, staged ? &mine : nullptr, wave ? ntab[1] : ntab[0], wave, S, sm.first[wave], lane, stats);
+        const float v = mclf_chain(f, staged ? &mine : nullptr, wave ? ntab[1] : ntab[0], wave, S, first, lane, stats);
         if (lane == 0) { sm.xy[wave] = v; for (int k = 0; k < 4; ++k) sm.stats[4 * wave + k] = stats[k]; }
     }
     __syncthreads();
     MCLF_STAMP(4);
     if (tid == 0) {
         mclf_store_u64(f.sync, 0ull);                        // the next launch on this stream counts from zero again
+        mclf_store_u64(f.sync + 1, 0ull);
+        mclf_store_u64(f.sync + 2, 0ull);
         double tot[5] = {0, 0, 0, 0, 0};
         for (int w = 0; w < MCLF_POSE_THREADS / 64; ++w) for (int k = 0; k < 5; ++k) tot[k] += sm.red[w][k];
         f.state->S = tot[0];
