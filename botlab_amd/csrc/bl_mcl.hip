@@ -57,7 +57,7 @@ struct bl_pf {
     bool use_lds;
     int last_blocks, last_tile;   // launch shape of the last k_mcl_main
     int last_main_blocks, last_main_particles, last_tail_tile;
-    bool fused_finish, no_fused_finish, no_packed, no_balance, no_framed, no_window;
+    bool fused_finish, no_fused_finish, no_packed, no_balance, no_framed, no_window, no_fast_trig;
     int window_override;          // window side in cells (0: from the scan's reach)
     int cus;                      // compute units of the device
     int split_log2_override;  // -1: automatic
@@ -250,17 +250,20 @@ __device__ __forceinline__ float wrap_to_pi_cells(float x, bool simple)
     return w;
 }
 
-// the endpoint cell and the cell at twice the range (whose direction the second neighbour is taken in)
-__device__ __forceinline__ void ray_cells_pk(float2_t start, float cpm, float range, float cs, float sn, short2_t& E, short2_t& X)
+// the endpoint and the point at twice the range (whose direction the second neighbour is taken in), in float cells
+__device__ __forceinline__ void ray_points_pk(float2_t start, float cpm, float range, float cs, float sn, float2_t& e, float2_t& x)
 {
     const float2_t dir = {cs, sn};
     const float2_t t = (range * dir) * cpm;                               // (range * cos) * cpm, (range * sin) * cpm
-    const float2_t e = t + start;
-    const float2_t x = (t + t) + start;
-    // (int)e.x | (int)e.y << 16 in two instructions each: the float -> int conversion writes its low half-word straight into
-    // the selected half of the pair (SDWA destination select).  No saturation is needed: the packed path's preconditions keep
-    // every cell inside int16.  A half-word write must not be read by the very next instruction (gfx940 dst_sel forwarding
-    // hazard, invisible to the compiler inside inline asm), hence the interleaving and the closing s_nop.
+    e = t + start;
+    x = (t + t) + start;
+}
+// (int)e.x | (int)e.y << 16 in two instructions each: the float -> int conversion writes its low half-word straight into
+// the selected half of the pair (SDWA destination select).  No saturation is needed: the packed path's preconditions keep
+// every cell inside int16.  A half-word write must not be read by the very next instruction (gfx940 dst_sel forwarding
+// hazard, invisible to the compiler inside inline asm), hence the interleaving and the closing s_nop.
+__device__ __forceinline__ void ray_points_to_cells(float2_t e, float2_t x, short2_t& E, short2_t& X)
+{
     int ei, xi;
     asm("v_cvt_i32_f32_sdwa %0, %2 dst_sel:WORD_0 dst_unused:UNUSED_PAD src0_sel:DWORD\n\t"
         "v_cvt_i32_f32_sdwa %1, %4 dst_sel:WORD_0 dst_unused:UNUSED_PAD src0_sel:DWORD\n\t"
@@ -271,6 +274,51 @@ __device__ __forceinline__ void ray_cells_pk(float2_t start, float cpm, float ra
     E = __builtin_bit_cast(short2_t, ei);
     X = __builtin_bit_cast(short2_t, xi);
 }
+// the endpoint cell and the cell at twice the range
+__device__ __forceinline__ void ray_cells_pk(float2_t start, float cpm, float range, float cs, float sn, short2_t& E, short2_t& X)
+{
+    float2_t e, x;
+    ray_points_pk(start, cpm, range, cs, sn, e, x);
+    ray_points_to_cells(e, x, E, X);
+}
+
+// ---- the same two cells WITHOUT the exact sinf / cosf for almost every ray.
+// The reference takes sinf / cosf of theta' = wrap_to_pi(d), d = pose.theta - ray theta.  v_sin_f32 / v_cos_f32 of d / 2pi differ
+// from those values by at most MCL_TRIG_EPS for EVERY float d in [-3pi - 0.01, pi + 0.01] -- the wrap's own rounding and the
+// scaling included (tests/tools/sincos_hw_probe.hip: exhaustive over the 2 170 595 470 floats of that range, 8.81e-7 for the
+// sine, 7.75e-7 for the cosine) -- which is the range of d when every theta of the scan lies in [0, 6.2831] (theta_simple).
+// With dir' = dir + eta, |eta| <= eps, and u = 2^-24 the relative error of one float operation:
+//     |fl(range * dir') - fl(range * dir)|      <= range * (eps + 2u)
+//     |t' - t|, t = fl(fl(range * dir) * cpm)   <= range * cpm * (eps + 4u) (1 + 2u)
+//     |e' - e|, e = fl(t + start)                <= range * cpm * (eps + 4u) (1 + 2u) + 2u * max(|e|, |e'|)
+//     |x' - x|, x = fl(fl(t + t) + start)        <= 2 * range * cpm * (eps + 4u) (1 + 2u) + 2u * max(|x|, |x'|)
+// so the truncated cells agree whenever e' (x') is farther than B1 (B2) from every integer, B1 = range * k1 + k2, B2 = range * 2 k1
+// + k2 with k1 = 1.02 * cpm * (eps + 4u) and k2 = 2.04u * (a bound on the particle's cell coordinates: |start| + 2 * longest
+// ray + 8).  A ray inside a band (1-4 in a thousand) makes its whole wave take the exact path for that round and keeps the exact
+// cells; everything downstream is integer.  (The guard costs ~15 instructions, the exact sinf / cosf with the wrap 36.)
+#define MCL_TRIG_EPS 9.0e-7f
+__device__ __forceinline__ void ray_cells_fast(float2_t start, float cpm, float range, float d, float k1, float k2, short2_t& E, short2_t& X)
+{
+    const float rev = d * 0.15915494309189535f;
+    float sn, cs;
+    asm("v_sin_f32 %0, %1" : "=v"(sn) : "v"(rev));
+    asm("v_cos_f32 %0, %1" : "=v"(cs) : "v"(rev));
+    float2_t e, x;
+    ray_points_pk(start, cpm, range, cs, sn, e, x);
+    const float B1 = __builtin_fmaf(range, k1, k2), B2 = __builtin_fmaf(range, k1 + k1, k2);
+    const float ge = __builtin_fminf(__builtin_fabsf(e.x - __builtin_rintf(e.x)), __builtin_fabsf(e.y - __builtin_rintf(e.y)));
+    const float gx = __builtin_fminf(__builtin_fabsf(x.x - __builtin_rintf(x.x)), __builtin_fabsf(x.y - __builtin_rintf(x.y)));
+    const bool near = !(ge > B1) || !(gx > B2);                          // (a nan lands here too)
+    ray_points_to_cells(e, x, E, X);
+    if (__builtin_amdgcn_ballot_w64(near)) {
+        float sn2, cs2;
+        bl_sincosf_cells(wrap_to_pi_cells(d, true), &sn2, &cs2);
+        short2_t E2, X2;
+        ray_cells_pk(start, cpm, range, cs2, sn2, E2, X2);
+        E = near ? E2 : E;
+        X = near ? X2 : X;
+    }
+}
 
 __device__ __forceinline__ int score_pick(int odds, int o1, int o2)
 {
@@ -278,12 +326,17 @@ __device__ __forceinline__ int score_pick(int odds, int o1, int o2)
 }
 
 template <class PM>
+__device__ __forceinline__ int score_cells_pk(const PM& pm, short2_t S, short2_t E, short2_t X)
+{
+    const short2_t Ec = pk_clamp_endpoint(E, pm.hi);
+    return score_pick(pk_read(pm, Ec), pk_read(pm, first_step_pk(Ec, S)), pk_read(pm, first_step_pk(Ec, X)));
+}
+template <class PM>
 __device__ __forceinline__ int score_ray_pk(const PM& pm, float2_t start, short2_t S, float cpm, float range, float cs, float sn)
 {
     short2_t E, X;
     ray_cells_pk(start, cpm, range, cs, sn, E, X);
-    const short2_t Ec = pk_clamp_endpoint(E, pm.hi);
-    return score_pick(pk_read(pm, Ec), pk_read(pm, first_step_pk(Ec, S)), pk_read(pm, first_step_pk(Ec, X)));
+    return score_cells_pk(pm, S, E, X);
 }
 
 // Window form: an LDS copy of the rectangle [org, org + size) of the zero-framed image.  The endpoint is clamped to the
@@ -292,11 +345,8 @@ __device__ __forceinline__ int score_ray_pk(const PM& pm, float2_t start, short2
 // the scan's reach around the particle cloud.
 struct pk_map_window { int base; short2_t K; short2_t org; short2_t hi; pk_map_global g; };   // hi = size - 2
 
-__device__ __forceinline__ int score_ray_pk_window(const pk_map_window& pm, float2_t start, short2_t S, float cpm, float range,
-                                                   float cs, float sn)
+__device__ __forceinline__ int score_cells_pk(const pk_map_window& pm, short2_t S, short2_t E, short2_t X)
 {
-    short2_t E, X;
-    ray_cells_pk(start, cpm, range, cs, sn, E, X);
     const short2_t one = {(short)1, (short)1};
     const short2_t Ew = E - pm.org;
     const short2_t Ec = __builtin_elementwise_min(__builtin_elementwise_max(Ew, one), pm.hi);
@@ -313,6 +363,13 @@ __device__ __forceinline__ int score_ray_pk_window(const pk_map_window& pm, floa
         }
     }
     return score_pick(odds, o1, o2);
+}
+__device__ __forceinline__ int score_ray_pk_window(const pk_map_window& pm, float2_t start, short2_t S, float cpm, float range,
+                                                   float cs, float sn)
+{
+    short2_t E, X;
+    ray_cells_pk(start, cpm, range, cs, sn, E, X);
+    return score_cells_pk(pm, S, E, X);
 }
 
 // Zero-framed copy of the grid (rows -MCL_FRAME..H+MCL_FRAME-1, columns -4..stride-5), one dword per thread: the image
@@ -366,6 +423,8 @@ struct mcl_args {
     int split_log2;               // each particle's rays are spread over 2^split_log2 adjacent lanes
     int pk_ok;                    // grid and scan admit the packed 16-bit scoring path (see score_ray_pk)
     int theta_simple;             // every theta of the scan lies in [0, 6.2831] (see wrap_to_pi_cells)
+    int fast_trig;                // hardware sine / cosine with a guard band and the exact path behind it (ray_cells_fast)
+    float max_range_cells;        // longest kept ray in cells
     int main_blocks, main_particles;   // region 1: main_blocks workgroups cover particles [0, main_particles) of the shard
 };
 
@@ -403,6 +462,25 @@ __device__ __forceinline__ void philox_normals3(uint32_t m, uint32_t step, uint3
             float sn, cs;                                                               \
             bl_sincosf_cells(wrap_to_pi_cells(pth_r - rt.y, theta_simple), &sn, &cs);                   \
             acc += SCORE_EXPR;                                                          \
+        }                                                                               \
+    } while (0)
+
+// The same loops with the two cells from ray_cells_fast (theta_simple scans only)
+#define MCL_RAY_LOOP_FAST(PM)                                                           \
+    do {                                                                                \
+        const int rounds_ = cnt >> sl2;                                                 \
+        int off_ = sub * 8;                                                             \
+        for (int k_ = 0; k_ < rounds_; ++k_, off_ += split * 8) {                       \
+            const float2 rt = *(const float2*)((const char*)s_ray + off_);              \
+            short2_t E_, X_;                                                            \
+            ray_cells_fast(start, a.frame.cpm, rt.x, pth_r - rt.y, trig_k1, trig_k2, E_, X_);   \
+            acc += score_cells_pk(PM, S, E_, X_);                                       \
+        }                                                                               \
+        if ((off_ >> 3) < cnt) {                                                        \
+            const float2 rt = *(const float2*)((const char*)s_ray + off_);              \
+            short2_t E_, X_;                                                            \
+            ray_cells_fast(start, a.frame.cpm, rt.x, pth_r - rt.y, trig_k1, trig_k2, E_, X_);   \
+            acc += score_cells_pk(PM, S, E_, X_);                                       \
         }                                                                               \
     } while (0)
 
@@ -639,12 +717,17 @@ __global__ __launch_bounds__(BLOCK) void k_mcl_main(mcl_args a)
         pth = bl_wrap_to_pi(s.z + n1 + n3);
         if (a.cells) bl_global_to_grid(px, py, a.frame, &sx0, &sy0);
     }
-    if (shared_pro && tid < P) s_pp[tid] = make_float4(pth, sx0, sy0, 0.0f);
+    // guard-band offset of the fast trig path for this particle: 2.04 u times a bound on its cell coordinates (ray_cells_fast)
+    const float trig_reach = 2.0f * a.max_range_cells + 8.0f;
+    const float k2_own = 1.2159e-7f * (__builtin_fmaxf(__builtin_fabsf(sx0), __builtin_fabsf(sy0)) + trig_reach);
+    if (shared_pro && tid < P) s_pp[tid] = make_float4(pth, sx0, sy0, k2_own);
     __syncthreads();                                            // map, ray table and particle table are in place
 
     // what the ray loop needs of this lane's particle
-    float r_pth = pth, r_sx0 = sx0, r_sy0 = sy0;
-    if (shared_pro) { const float4 e = s_pp[jl]; r_pth = e.x; r_sx0 = e.y; r_sy0 = e.z; }
+    float r_pth = pth, r_sx0 = sx0, r_sy0 = sy0, trig_k2 = k2_own;
+    if (shared_pro) { const float4 e = s_pp[jl]; r_pth = e.x; r_sx0 = e.y; r_sy0 = e.z; trig_k2 = e.w; }
+    const float trig_k1 = 1.02f * a.frame.cpm * (MCL_TRIG_EPS + 2.3842e-7f);      // 4u = 2^-22
+    const bool fast_trig = a.fast_trig != 0;                                       // wave-uniform
     const int isx0 = (int)r_sx0, isy0 = (int)r_sy0;
 
     // ---- SensorModel::likelihood (sensor_model.cpp:14-25) over MovingLaserScan(scan, parent_pose, pose)
@@ -668,6 +751,7 @@ __global__ __launch_bounds__(BLOCK) void k_mcl_main(mcl_args a)
                 pm.base = vgpr_of((int)(unsigned int)(size_t)s_map);
                 pm.K = __builtin_bit_cast(short2_t, vgpr_of(1 | (win.stride << 16)));
                 pm.hi = short2_t{(short)(a.frame.width + 1), (short)(a.frame.height + 1)};
+                if (fast_trig) MCL_RAY_LOOP_FAST(pm); else
                 MCL_RAY_LOOP(score_ray_pk(pm, start, S, a.frame.cpm, rt.x, cs, sn));
             } else if (MAP_MODE == 2 && pk_lane) {
                 pk_map_window pm;
@@ -678,12 +762,14 @@ __global__ __launch_bounds__(BLOCK) void k_mcl_main(mcl_args a)
                 pm.g.base = a.framed;
                 pm.g.K = short2_t{(short)1, (short)a.framed_stride};
                 pm.g.hi = short2_t{(short)(a.frame.width + 1), (short)(a.frame.height + 1)};
+                if (fast_trig) MCL_RAY_LOOP_FAST(pm); else
                 MCL_RAY_LOOP(score_ray_pk_window(pm, start, S, a.frame.cpm, rt.x, cs, sn));
             } else if (MAP_MODE == 0 && pk_lane && a.framed) {
                 pk_map_global pm;
                 pm.base = a.framed;
                 pm.K = short2_t{(short)1, (short)a.framed_stride};
                 pm.hi = short2_t{(short)(a.frame.width + 1), (short)(a.frame.height + 1)};
+                if (fast_trig) MCL_RAY_LOOP_FAST(pm); else
                 MCL_RAY_LOOP(score_ray_pk(pm, start, S, a.frame.cpm, rt.x, cs, sn));
             } else {
                 const bl_pose3 pb = {s.x, s.y, s.z};            // INTERP: the prologue is not shared, these are this lane's own
@@ -1070,6 +1156,7 @@ extern "C" int bl_pf_create(bl_ctx* ctx, int num_particles, int shard_lo, int sh
     pf->no_balance = getenv("BOTLAB_MCL_NO_BALANCE") != nullptr;
     pf->no_framed = getenv("BOTLAB_MCL_NO_FRAMED") != nullptr;
     pf->no_window = getenv("BOTLAB_MCL_NO_WINDOW") != nullptr;
+    pf->no_fast_trig = getenv("BOTLAB_MCL_NO_FAST_TRIG") != nullptr;
     pf->window_override = getenv("BOTLAB_MCL_WINDOW") ? atoi(getenv("BOTLAB_MCL_WINDOW")) : 0;
     { int cus = 0; if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device) == hipSuccess) pf->cus = cus; }
     pf->split_log2_override = getenv("BOTLAB_MCL_SPLIT_LOG2") ? atoi(getenv("BOTLAB_MCL_SPLIT_LOG2")) : -1;
@@ -1320,6 +1407,8 @@ static int pf_launch_main(bl_pf* pf, const bl_grid* map, int R, int rand_value, 
     a.interp = (map && pf->pose_utime != 0) ? 1 : 0;
     // packed 16-bit scoring: grid up to 8192 a side, the longest kept ray spans at most 4000 cells (see score_ray_pk)
     a.theta_simple = ctx->scan.thetas_simple ? 1 : 0;
+    a.max_range_cells = map ? ctx->scan.max_range * a.frame.cpm : 0.0f;
+    a.fast_trig = (a.theta_simple && !pf->no_fast_trig) ? 1 : 0;
     a.pk_ok = (map && a.frame.width <= 8192 && a.frame.height <= 8192 && ctx->scan.max_range * a.frame.cpm <= 4000.0f &&
                !pf->no_packed) ? 1 : 0;
     // Where the gathers go.  Mode 1: the whole grid, zero-framed, staged in LDS by every workgroup (grids up to 64 KB).
