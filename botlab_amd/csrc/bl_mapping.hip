@@ -89,12 +89,18 @@ __device__ __forceinline__ unsigned int half_of(unsigned int pair, int ci) { ret
 // snap != nullptr: every store to the grid is mirrored into the replanner snapshot, whose bulk copy (the grid as it was when
 // the kernel started) the caller holds in sv[] and map_update_body stores once its first loads are under way.
 #define MAP_EARLY_VEC 4                       // int4 per thread held for the early snapshot copy: grids up to 64 KB
-__device__ __forceinline__ void map_update_body(const map_args& a, int8_t* snap, const int4 (&sv)[MAP_EARLY_VEC], const bl_pose_xyt_t* lds_pose);
+__device__ __forceinline__ void map_update_body(const map_args& a, int8_t* snap, const int4 (&sv)[MAP_EARLY_VEC], bl_pose_xyt_t* lds_pose, bool provisional);
 
+// Workgroups of a launch that carries a filter's end: 0 the map update, 1 the pre-chain, 2 the finisher, 3.. the groups, last
+// (optional) the scan prefetch.  The map update does not wait idle for the finisher's exact x, y: it forms the estimate's double
+// reduction itself (same theta, x / y within a few 1e-6), runs everything up to the first grid store with that pose -- ray geometry,
+// hit and miss counts in LDS: integer results of the pose -- and, when the exact x, y arrive, recomputes the rays' integer cells
+// with them: equal (9 scans in 10 at 100k particles) means the counts are the reference's, otherwise the phases run again.
+#define MAP_RIDER_WGS 3
 __global__ __launch_bounds__(MAP_THREADS) void k_map_update(map_args a)
 {
     __shared__ mclf_smem s_fin;
-    if (blockIdx.x > 0) {                                       // riders: the filter's prefix groups, then the scan prefetch
+    if (blockIdx.x > 0) {                                       // riders
         if (a.pre_on && blockIdx.x == gridDim.x - 1) {
             for (int i = threadIdx.x; i < a.pre.kept; i += MAP_THREADS) {
                 a.pre.d_times[i] = a.pre.h_times[i];
@@ -103,9 +109,13 @@ __global__ __launch_bounds__(MAP_THREADS) void k_map_update(map_args a)
             }
             __syncthreads();                                    // every lane's loads from the slot have returned
             if (threadIdx.x == 0) __hip_atomic_store(a.pre.h_seq, a.pre.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        } else if (blockIdx.x == 1) {
+            mclf_pre_chain(a.fin, s_fin);
+        } else if (blockIdx.x == 2) {
+            extern __shared__ __align__(16) unsigned int s_dyn_fin[];         // this workgroup's own dynamic LDS
+            mclf_pose(a.fin, s_fin, (char*)s_dyn_fin, (size_t)MAP_LDS_COUNTERS * 2, true);
         } else {
-            if (blockIdx.x == 1) mclf_pre_chain(a.fin, s_fin);
-            else mclf_prefix_group(a.fin, (int)blockIdx.x - MCLF_EXTRA_WGS, s_fin);
+            mclf_prefix_group(a.fin, (int)blockIdx.x - MAP_RIDER_WGS, s_fin);
         }
         return;
     }
@@ -128,12 +138,17 @@ __global__ __launch_bounds__(MAP_THREADS) void k_map_update(map_args a)
     }
     __shared__ bl_pose_xyt_t s_fin_pose;
     if (a.fin_on) {
-        extern __shared__ __align__(16) unsigned int s_dyn_fin[];             // the counter window of map_update_body, not yet in use
-        mclf_pose(a.fin, s_fin, (char*)s_dyn_fin, (size_t)MAP_LDS_COUNTERS * 2, &s_fin_pose);               // writes the pose a.cur_dev points at, and a copy in LDS
+        mclf_reduce_partials(a.fin, s_fin);
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double tot[5];
+            mclf_block_totals(s_fin, tot);
+            s_fin_pose = mclf_approx_pose(tot, a.fin.utime);    // theta final, x / y provisional
+        }
         __syncthreads();
     }
     // every return inside is uniform over the workgroup
-    map_update_body(a, early ? a.snap_cells : nullptr, sv, a.fin_on ? &s_fin_pose : nullptr);
+    map_update_body(a, early ? a.snap_cells : nullptr, sv, a.fin_on ? &s_fin_pose : nullptr, a.fin_on != 0);
     if (a.snap_cells) {
         if (!early) {
             __syncthreads();                                    // the grid stores of this workgroup are visible to its own loads
@@ -148,7 +163,8 @@ __global__ __launch_bounds__(MAP_THREADS) void k_map_update(map_args a)
             }
             for (size_t i = n16 * 16 + threadIdx.x; i < n; i += MAP_THREADS) a.snap_cells[i] = a.cells[i];
         }
-        if (threadIdx.x == 0) *a.snap_pose = *a.snap_pose_src;
+        // (a riding finish: the estimate was written by another workgroup of this launch -- take it from this one's LDS copy)
+        if (threadIdx.x == 0) *a.snap_pose = a.fin_on ? s_fin_pose : *a.snap_pose_src;
         if (a.snap_flag) {                                              // flag hand-off only; an event hand-off needs nothing here
             __threadfence();
             __syncthreads();
@@ -157,27 +173,39 @@ __global__ __launch_bounds__(MAP_THREADS) void k_map_update(map_args a)
     }
 }
 
-__device__ __forceinline__ void map_update_body(const map_args& a, int8_t* snap, const int4 (&sv)[MAP_EARLY_VEC], const bl_pose_xyt_t* lds_pose)
+// start cell and end cell of one ray (moving_laser_scan.cpp:22-37, mapping.cpp:45-49); x == 0x7fffffff: the ray takes no part
+__device__ __forceinline__ int4 map_ray_cells(const map_args& a, const bl_pose3& pb, const bl_pose3& pe, float range, float ray_theta, int64_t ray_time)
+{
+    int4 ray = make_int4(0x7fffffff, 0, 0, 0);
+    if (range <= a.max_laser) {                                 // rays with range <= 0.15f were dropped on the host
+        bl_pose3 rp = a.interp ? bl_interpolate_pose(pb, pe, bl_interp_ratio(ray_time, a.t_begin, a.t_den)) : pe;
+        float theta = bl_wrap_to_pi(rp.theta - ray_theta);
+        float sn, cs, sx, sy;
+        bl_sincosf(theta, &sn, &cs);
+        bl_global_to_grid(rp.x, rp.y, a.frame, &sx, &sy);
+        float fx = (range * cs * a.frame.cpm) + sx;
+        float fy = (range * sn * a.frame.cpm) + sy;
+        const float lim = (float)MAP_CELL_LIMIT;
+        if (fx > -lim && fx < lim && fy > -lim && fy < lim && sx > -lim && sx < lim && sy > -lim && sy < lim)
+            ray = make_int4((int)sx, (int)sy, (int)fx, (int)fy);        // float -> int truncation at the bresenham() call
+    }
+    return ray;
+}
+
+// lds_pose: the pose of this update in shared memory (or null: a.cur_dev / a.cur_host).  provisional: its x, y are the map
+// workgroup's own double reduction; the reference's x, y come from the finisher (mclf_wait_pose) -- everything up to the first
+// grid store runs with the provisional pose, then the rays' integer cells are recomputed with the exact one and compared.
+__device__ __forceinline__ void map_update_body(const map_args& a, int8_t* snap, const int4 (&sv)[MAP_EARLY_VEC], bl_pose_xyt_t* lds_pose, bool provisional)
 {
     extern __shared__ __align__(16) unsigned int s_cnt[];     // MAP_LDS_COUNTERS/2 dwords, two uint16 counters each
     __shared__ int s_box[4];                                   // xmin, ymin, xmax, ymax over all traced cells
     __shared__ float s_pose[6];                                // prev x,y,theta ; cur x,y,theta
     __shared__ int s_segp[MAP_SEG_RAYS + 1];                   // exclusive prefix of the rays' segment counts
     __shared__ int s_wsum[MAP_THREADS / 64];
+    __shared__ int s_redo;
 
     const int tid = threadIdx.x;
     MSTAMP(0);
-    if (tid == 0) {
-        bl_pose_xyt_t cur = lds_pose ? *lds_pose : (a.cur_dev ? *a.cur_dev : a.cur_host);   // lds_pose: formed by this very workgroup
-        bl_pose_xyt_t prev = a.apply ? *a.prev : cur;          // mapping.cpp:19-21: first call uses pose for both
-        s_pose[0] = prev.x; s_pose[1] = prev.y; s_pose[2] = prev.theta;
-        s_pose[3] = cur.x; s_pose[4] = cur.y; s_pose[5] = cur.theta;
-        s_box[0] = 0x7fffffff; s_box[1] = 0x7fffffff; s_box[2] = -0x7fffffff; s_box[3] = -0x7fffffff;
-        // previousPose_ = pose (mapping.cpp:38)
-        bl_pose_xyt_t rec = cur;
-        rec.utime = a.cur_utime;
-        *a.prev = rec;
-    }
     // the first ray of every thread is loaded before the barrier the pose arrives behind (the two round trips overlap)
     float pre_range = 0.0f, pre_theta = 0.0f;
     int64_t pre_time = 0;
@@ -185,8 +213,25 @@ __device__ __forceinline__ void map_update_body(const map_args& a, int8_t* snap,
         pre_range = a.ranges[tid]; pre_theta = a.thetas[tid];
         if (a.interp) pre_time = a.times[tid];
     }
+    // the exact pose into *lds_pose (one thread waits for the finisher), visible to the workgroup behind the barrier
+    auto take_exact_pose = [&]() {
+        if (tid == 0) { float x, y; mclf_wait_pose(a.fin, &x, &y); lds_pose->x = x; lds_pose->y = y; }
+        __syncthreads();
+    };
+    bool snap_stored = false;
+    // One pass over everything.  Returns 1 when it ran with the provisional pose and must run again with the exact one (which
+    // is in *lds_pose by then), 0 when the update is complete.
+    auto run = [&](bool prov) -> int {
+    if (tid == 0) {
+        bl_pose_xyt_t cur = lds_pose ? *lds_pose : (a.cur_dev ? *a.cur_dev : a.cur_host);
+        bl_pose_xyt_t prev = a.apply ? *a.prev : cur;          // mapping.cpp:19-21: first call uses pose for both
+        s_pose[0] = prev.x; s_pose[1] = prev.y; s_pose[2] = prev.theta;
+        s_pose[3] = cur.x; s_pose[4] = cur.y; s_pose[5] = cur.theta;
+        s_box[0] = 0x7fffffff; s_box[1] = 0x7fffffff; s_box[2] = -0x7fffffff; s_box[3] = -0x7fffffff;
+        s_redo = 0;
+    }
     __syncthreads();
-    if (!a.apply) return;                                       // increase/decreaseCellOdds do nothing (mapping.cpp:74,88)
+    if (!a.apply) { if (prov) take_exact_pose(); return 0; }    // increase/decreaseCellOdds do nothing (mapping.cpp:74,88)
 
     const bl_pose3 pb = {s_pose[0], s_pose[1], s_pose[2]};
     const bl_pose3 pe = {s_pose[3], s_pose[4], s_pose[5]};
@@ -197,28 +242,13 @@ __device__ __forceinline__ void map_update_body(const map_args& a, int8_t* snap,
     int bx_lo = 0x7fffffff, by_lo = 0x7fffffff, bx_hi = -0x7fffffff, by_hi = -0x7fffffff;
     int4 my_ray = make_int4(0x7fffffff, 0, 0, 0);
     for (int r = tid; r < a.R; r += MAP_THREADS) {
-        int4 ray = make_int4(0, 0, 0, 0);
-        int valid = 0;
         const bool first = r == tid;
-        const float range = first ? pre_range : a.ranges[r];
-        if (range <= a.max_laser) {                             // rays with range <= 0.15f were dropped on the host
-            bl_pose3 rp = a.interp ? bl_interpolate_pose(pb, pe, bl_interp_ratio(first ? pre_time : a.times[r], a.t_begin, a.t_den)) : pe;
-            float theta = bl_wrap_to_pi(rp.theta - (first ? pre_theta : a.thetas[r]));
-            float sn, cs, sx, sy;
-            bl_sincosf(theta, &sn, &cs);
-            bl_global_to_grid(rp.x, rp.y, a.frame, &sx, &sy);
-            float fx = (range * cs * a.frame.cpm) + sx;
-            float fy = (range * sn * a.frame.cpm) + sy;
-            const float lim = (float)MAP_CELL_LIMIT;
-            if (fx > -lim && fx < lim && fy > -lim && fy < lim && sx > -lim && sx < lim && sy > -lim && sy < lim) {
-                ray.x = (int)sx; ray.y = (int)sy;               // float -> int truncation at the bresenham() call
-                ray.z = (int)fx; ray.w = (int)fy;
-                valid = 1;
-                bx_lo = min(bx_lo, min(ray.x, ray.z)); by_lo = min(by_lo, min(ray.y, ray.w));
-                bx_hi = max(bx_hi, max(ray.x, ray.z)); by_hi = max(by_hi, max(ray.y, ray.w));
-            }
+        const int4 ray = map_ray_cells(a, pb, pe, first ? pre_range : a.ranges[r], first ? pre_theta : a.thetas[r],
+                                       a.interp ? (first ? pre_time : a.times[r]) : 0);
+        if (ray.x != 0x7fffffff) {
+            bx_lo = min(bx_lo, min(ray.x, ray.z)); by_lo = min(by_lo, min(ray.y, ray.w));
+            bx_hi = max(bx_hi, max(ray.x, ray.z)); by_hi = max(by_hi, max(ray.y, ray.w));
         }
-        if (!valid) ray.x = 0x7fffffff;
         a.rays[r] = ray;
         my_ray = ray;
     }
@@ -252,7 +282,7 @@ __device__ __forceinline__ void map_update_body(const map_args& a, int8_t* snap,
     }
     __syncthreads();
 
-    if (snap) {
+    if (snap && !snap_stored) {
         const size_t n16 = ((size_t)a.frame.width * a.frame.height) / 16;
 #pragma unroll
         for (int u = 0; u < MAP_EARLY_VEC; ++u) {
@@ -260,13 +290,17 @@ __device__ __forceinline__ void map_update_body(const map_args& a, int8_t* snap,
             if (i < n16) ((int4*)snap)[i] = sv[u];
         }
         __syncthreads();                                        // bulk copy before the mirrored stores of changed cells below
+        snap_stored = true;
     }
     MSTAMP(2);
     // ---- the update runs through an LDS window of uint16 counters: the bounding box of all ray cells clipped to the grid,
     // in horizontal strips when it exceeds the LDS budget
     int bx0 = max(s_box[0], 0), by0 = max(s_box[1], 0);
     int bx1 = min(s_box[2], a.frame.width - 1), by1 = min(s_box[3], a.frame.height - 1);
-    if (bx1 < bx0 || by1 < by0) return;                         // nothing inside the grid
+    if (bx1 < bx0 || by1 < by0) {                               // nothing inside the grid (with this pose)
+        if (prov) { take_exact_pose(); return 1; }
+        return 0;
+    }
     // grid rows of whole dwords: the window takes whole dwords too, and the free-space pass below updates four cells per access
     const bool dword_rows = (a.frame.width & 3) == 0 && seg_walk;
     if (dword_rows) { bx0 &= ~3; bx1 |= 3; }
@@ -276,7 +310,9 @@ __device__ __forceinline__ void map_update_body(const map_args& a, int8_t* snap,
     if (rows_per_strip < 1) rows_per_strip = 1;                 // ww > 73728 cannot happen for int32 grids < 2^31 cells with sane width
     if (rows_per_strip > wh) rows_per_strip = wh;
     const int strip_cells_max = rows_per_strip * ww;
-    if (strip_cells_max > MAP_LDS_COUNTERS) return;             // defensive: never index past the LDS window
+    if (strip_cells_max > MAP_LDS_COUNTERS) { if (prov) take_exact_pose(); return 0; }      // defensive: never index past the LDS window
+    // the look-ahead covers the usual shape only: one strip, a thread per ray
+    if (prov && (rows_per_strip < wh || a.R > MAP_THREADS)) { take_exact_pose(); return 1; }
 
     for (int sy0 = by0; sy0 <= by1; sy0 += rows_per_strip) {
         const int sy1 = min(sy0 + rows_per_strip - 1, by1);
@@ -346,6 +382,18 @@ __device__ __forceinline__ void map_update_body(const map_args& a, int8_t* snap,
             }
             __syncthreads();
             MSTAMP(5);
+            if (prov) {
+                // hit and miss counts stand in LDS, nothing has been stored to the grid yet: now the reference's x, y
+                take_exact_pose();
+                const bl_pose3 pe2 = {lds_pose->x, lds_pose->y, pe.theta};
+                if (tid < a.R) {
+                    const int4 ray2 = map_ray_cells(a, pb, pe2, pre_range, pre_theta, pre_time);
+                    if (ray2.x != my_ray.x || ray2.y != my_ray.y || ray2.z != my_ray.z || ray2.w != my_ray.w) atomicOr(&s_redo, 1);
+                }
+                __syncthreads();
+                if (s_redo) return 1;                                 // some ray's cells moved: count again with the exact pose
+                prov = false;                                         // every ray has the reference's cells: the counts are the reference's
+            }
             // leaders finish their end cell: v' = max(-128, min(127, v + hit*H) - miss*M), then hide it from the window pass
             if (leader) {
                 const int M = (int)half_of(s_cnt[ci >> 1], ci);
@@ -443,6 +491,16 @@ __device__ __forceinline__ void map_update_body(const map_args& a, int8_t* snap,
         __syncthreads();
         MSTAMP(6);
     }
+    return 0;
+    };   // run
+
+    if (run(provisional && lds_pose != nullptr) == 1) (void)run(false);
+    // previousPose_ = pose (mapping.cpp:38) -- the exact one
+    if (tid == 0) {
+        bl_pose_xyt_t rec = lds_pose ? *lds_pose : (a.cur_dev ? *a.cur_dev : a.cur_host);
+        rec.utime = a.cur_utime;
+        *a.prev = rec;
+    }
 }
 
 // ---------------------------------------------------------------- host side
@@ -536,7 +594,7 @@ static int mapping_update_impl(bl_mapping* m, const bl_lidar_t* scan, const bl_p
     a.pre = bl_scan_prefetch_args{};
     a.pre_on = bl_scan_prefetch_take(ctx, &a.pre);
     static_assert(MCLF_WG == MAP_THREADS, "the riding finish uses the map kernel's workgroup size");
-    hipLaunchKernelGGL(k_map_update, dim3(1 + (fin ? fin->groups + MCLF_EXTRA_WGS - 1 : 0) + a.pre_on), dim3(MAP_THREADS), MAP_LDS_COUNTERS * 2, ctx->stream, a);
+    hipLaunchKernelGGL(k_map_update, dim3(1 + (fin ? fin->groups + MAP_RIDER_WGS - 1 : 0) + a.pre_on), dim3(MAP_THREADS), MAP_LDS_COUNTERS * 2, ctx->stream, a);
     BL_HIP(hipGetLastError());
     rc = bl_timer_end(ctx, BL_K_MAP, e0, e1);
     if (rc) return rc;

@@ -685,6 +685,46 @@ __device__ __forceinline__ float mclf_chain(const mcl_finish_args& f, const mclf
     return acc;
 }
 
+// The block sums in the fixed order of a 256-thread workgroup (thread-strided with a stride of 256, wave shuffles, waves in order)
+// into sm.red; the caller puts a barrier behind it and adds the four rows up (mclf_block_totals).
+__device__ __forceinline__ void mclf_reduce_partials(const mcl_finish_args& f, mclf_smem& sm)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid < MCLF_POSE_THREADS) {
+        double v[5] = {0, 0, 0, 0, 0};
+        for (int b = tid; b < f.nblocks; b += MCLF_POSE_THREADS)
+            for (int k = 0; k < 5; ++k) v[k] += f.partials[(size_t)b * 5 + k];
+        for (int k = 0; k < 5; ++k) v[k] = mclf_wave_sum(v[k]);
+        if (lane == 0) for (int k = 0; k < 5; ++k) sm.red[wave][k] = v[k];
+    }
+}
+__device__ __forceinline__ void mclf_block_totals(const mclf_smem& sm, double (&tot)[5])
+{
+    for (int k = 0; k < 5; ++k) tot[k] = 0.0;
+    for (int w = 0; w < MCLF_POSE_THREADS / 64; ++w) for (int k = 0; k < 5; ++k) tot[k] += sm.red[w][k];
+}
+// theta of the estimate (final: the finisher forms it from the same sums in the same order) and the weighted means of x, y in
+// double -- NOT the reference's x, y (those are the serially rounded float sums), but within a few 1e-6 of them at 100k particles
+__device__ __forceinline__ bl_pose_xyt_t mclf_approx_pose(const double (&tot)[5], int64_t utime)
+{
+    bl_pose_xyt_t p;
+    p.utime = utime;
+    p.x = (float)(tot[1] / tot[0]);
+    p.y = (float)(tot[2] / tot[0]);
+    p.theta = (float)atan2(tot[3], tot[4]);
+    return p;
+}
+// one thread: wait for the finisher's x, y (mclf_pose with publish), clear the mailbox for the next launch
+__device__ __forceinline__ void mclf_wait_pose(const mcl_finish_args& f, float* x, float* y)
+{
+    while (mclf_load_u64(f.sync + 4) == 0ull) __builtin_amdgcn_s_sleep(1);
+    const unsigned long long w = mclf_load_u64(f.sync + 3);
+    *x = __uint_as_float((unsigned int)w);
+    *y = __uint_as_float((unsigned int)(w >> 32));
+    mclf_store_u64(f.sync + 4, 0ull);
+    mclf_store_u64(f.sync + 3, 0ull);
+}
+
 // The pre-chain workgroup: the float sums over the first MCLF_PRE_SUBS sub-tiles.  The sums start from zero, so nothing is
 // needed from the groups there, and that is where the accumulator changes its binade every few terms: the first sub-tiles are
 // stepped term by term (terms through LDS, one wave-uniform loop of three dependent operations per term), the others by the
@@ -766,9 +806,9 @@ __device__ __forceinline__ void mclf_pre_chain(const mcl_finish_args& f, mclf_sm
 
 // The finisher: waits for the groups of this launch, forms estimatePosteriorPose.  Called by EVERY thread of a workgroup of
 // MCLF_WG threads (it contains barriers).  scratch / scratch_bytes: LDS the finisher may use until it returns (16-byte aligned).
-// s_pose_out (shared memory, optional) receives the estimate too.
+// publish: x and y also go to f.sync[3..4] for another workgroup of the same launch (mclf_wait_pose).
 __device__ __forceinline__ void mclf_pose(const mcl_finish_args& f, mclf_smem& sm, char* scratch, size_t scratch_bytes,
-                                          bl_pose_xyt_t* s_pose_out = nullptr)
+                                          bool publish = false)
 {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 #ifdef MCLF_STAMPS
@@ -778,14 +818,7 @@ __device__ __forceinline__ void mclf_pose(const mcl_finish_args& f, mclf_smem& s
 #define MCLF_STAMP(i) do { } while (0)
 #endif
     const int nrec = f.groups * (f.gthreads >> 6), nbatch = (nrec + 63) >> 6;
-    // the sums of units, units*sin, units*cos in a fixed order (thread-strided with a stride of 256, wave shuffles, waves in order)
-    if (tid < MCLF_POSE_THREADS) {
-        double v[5] = {0, 0, 0, 0, 0};
-        for (int b = tid; b < f.nblocks; b += MCLF_POSE_THREADS)
-            for (int k = 0; k < 5; ++k) v[k] += f.partials[(size_t)b * 5 + k];
-        for (int k = 0; k < 5; ++k) v[k] = mclf_wave_sum(v[k]);
-        if (lane == 0) for (int k = 0; k < 5; ++k) sm.red[wave][k] = v[k];
-    }
+    mclf_reduce_partials(f, sm);
     const size_t per_axis = (mclf_stage_bytes(nbatch) + 15) & ~(size_t)15;
     const bool staged = scratch != nullptr && 2 * per_axis <= scratch_bytes;
 #define MCLF_STAGE(axis) mclf_stage_at(scratch + (size_t)(axis) * per_axis, nbatch)
@@ -901,7 +934,12 @@ __device__ __forceinline__ void mclf_pose(const mcl_finish_args& f, mclf_smem& s
         p.y = sm.xy[1];
         p.theta = (float)atan2(tot[3], tot[4]);
         f.state->pose = p;
-        if (s_pose_out) *s_pose_out = p;                     // shared memory: the caller's workgroup reads it behind its next barrier
+        if (publish) {
+            // another workgroup of this launch (the map update) is waiting for x and y: f.sync[3] / [4], which that workgroup clears
+            mclf_store_u64(f.sync + 3, (unsigned long long)__float_as_uint(p.x) | ((unsigned long long)__float_as_uint(p.y) << 32));
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            mclf_store_u64(f.sync + 4, 1ull);
+        }
         for (int k = 0; k < 5; ++k) f.state->sums_used[k] = tot[k];
         for (int k = 0; k < 8; ++k) f.state->chain_stats[k] = sm.stats[k];
 #ifdef MCLF_STAMPS
