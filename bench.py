@@ -485,6 +485,8 @@ def main():
     if world == 1 and (args.sub or args.grid != 200):
         stream_k = streaming_kernels(ctx, grid, planner, aplanner, pose_dev, goal_pose, m["cells"].shape[1], m["cells"].shape[0])
 
+    if os.environ.get("BOTLAB_FINISH_LOOKAHEAD") and world == 1:
+        engine.pf.debugEstimateStats()          # the library prints the map update's look-ahead counters to stderr
     if rank == 0:
         N, R = args.particles, scans[0].num_ranges
         W, H = m["cells"].shape[1], m["cells"].shape[0]

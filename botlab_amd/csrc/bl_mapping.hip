@@ -494,7 +494,10 @@ __device__ __forceinline__ void map_update_body(const map_args& a, int8_t* snap,
     return 0;
     };   // run
 
-    if (run(provisional && lds_pose != nullptr) == 1) (void)run(false);
+    const bool ahead = provisional && lds_pose != nullptr;
+    const int again = run(ahead);
+    if (again == 1) (void)run(false);
+    if (ahead && tid == 0) { a.fin.state->lookahead[0] += 1; a.fin.state->lookahead[1] += again; }
     // previousPose_ = pose (mapping.cpp:38) -- the exact one
     if (tid == 0) {
         bl_pose_xyt_t rec = lds_pose ? *lds_pose : (a.cur_dev ? *a.cur_dev : a.cur_host);

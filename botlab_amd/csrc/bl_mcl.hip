@@ -1668,6 +1668,11 @@ extern "C" int bl_pf_debug_estimate_stats(bl_pf* pf, uint32_t* out4)   /* eight 
     BL_CHECK_ARG(pf != nullptr && out4 != nullptr && pf->state != nullptr);
     BL_HIP(hipMemcpyAsync(out4, pf->state->chain_stats, 8 * sizeof(uint32_t), hipMemcpyDeviceToHost, pf->ctx->stream));
     BL_HIP(hipStreamSynchronize(pf->ctx->stream));
+    if (getenv("BOTLAB_FINISH_LOOKAHEAD")) {
+        unsigned int la[2];
+        BL_HIP(hipMemcpy(la, pf->state->lookahead, sizeof(la), hipMemcpyDeviceToHost));
+        fprintf(stderr, "map updates ahead of the exact pose: %u, run again: %u\n", la[0], la[1]);
+    }
     if (getenv("BOTLAB_FINISH_STAMPS")) {
         unsigned long long st[6];
         BL_HIP(hipMemcpy(st, pf->state->stamps, sizeof(st), hipMemcpyDeviceToHost));

@@ -32,6 +32,7 @@ struct pf_state {
     bl_pose_xyt_t pose;       // posteriorPose_
     double sums_used[5];      // units, -, -, units*sin, units*cos the estimate was formed from (diagnostic)
     unsigned int chain_stats[8];   // x then y: generic replays, their phases, table replays, gaps walked the slow way (diagnostic)
+    unsigned int lookahead[2];     // map updates that ran ahead of the exact pose; of those, the ones that had to run again (diagnostic)
     unsigned long long cstamps[16]; // the x chain, entry by entry (diagnostic, -DMCLF_STAMPS)
     unsigned long long gstamps[8]; // one group's timeline (diagnostic, -DMCLF_STAMPS)
     unsigned long long stamps[6];  // finisher timeline in 10 ns ticks (diagnostic, -DMCLF_STAMPS)
