@@ -415,6 +415,7 @@ extern "C" void bl_grid_destroy(bl_grid* g)
     if (!g) return;
     (void)hipStreamSynchronize(g->ctx->stream);
     (void)hipFree(g->cells);
+    if (g->mirror) (void)hipFree(g->mirror);
     delete g;
 }
 
@@ -422,6 +423,7 @@ extern "C" int bl_grid_upload(bl_grid* g, const int8_t* cells)
 {
     BL_CHECK_ARG(g != nullptr && cells != nullptr);
     size_t n = (size_t)g->frame.width * g->frame.height;
+    g->mirror_valid = false;
     BL_HIP(hipMemcpyAsync(g->cells, cells, n, hipMemcpyHostToDevice, g->ctx->stream));
     BL_HIP(hipStreamSynchronize(g->ctx->stream));    // the host buffer is caller-owned and may be reused at once
     return BL_OK;
@@ -439,6 +441,7 @@ extern "C" int bl_grid_download(bl_grid* g, int8_t* cells)
 extern "C" int bl_grid_reset(bl_grid* g)
 {
     BL_CHECK_ARG(g != nullptr);
+    g->mirror_valid = false;
     BL_HIP(hipMemsetAsync(g->cells, 0, (size_t)g->frame.width * g->frame.height, g->ctx->stream));
     return BL_OK;
 }
@@ -456,12 +459,19 @@ extern "C" int bl_grid_copy(bl_grid* dst, const bl_grid* src)
     BL_CHECK_ARG(dst != nullptr && src != nullptr);
     BL_CHECK_ARG(dst->frame.width == src->frame.width && dst->frame.height == src->frame.height);
     dst->frame = src->frame;
+    dst->mirror_valid = false;
     BL_HIP(hipMemcpyAsync(dst->cells, src->cells, (size_t)src->frame.width * src->frame.height,
                           hipMemcpyDeviceToDevice, dst->ctx->stream));
     return BL_OK;
 }
 
-extern "C" void* bl_grid_device_ptr(bl_grid* g) { return g ? (void*)g->cells : nullptr; }
+extern "C" void* bl_grid_device_ptr(bl_grid* g)
+{
+    if (!g) return nullptr;
+    g->mirror_external = true;          // the caller may write the cells without the library seeing it
+    g->mirror_valid = false;
+    return (void*)g->cells;
+}
 
 extern "C" int bl_grid_shape(const bl_grid* g, int* width, int* height)
 {

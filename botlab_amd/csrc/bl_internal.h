@@ -91,10 +91,22 @@ struct bl_frontiers {
     int bfs_cells = 0, bfs_levels = 0;
 };
 
+// Zero-framed mirror of a grid too large to stage whole in LDS (rows -BL_MIRROR_FRAME..H+BL_MIRROR_FRAME-1, columns
+// -4..stride-5, stride = ((W + 3) & ~3) + 8; zeros outside the grid): the image k_mcl_main gathers from and cuts its LDS window
+// out of.  The particle filter builds it (k_mcl_frame) when it is not current; k_map_update then stores every cell it changes
+// into both images, so that a SLAM loop pays for the copy once, not once per step.  Anything else that writes the cells
+// (upload, reset, copy, a replanner snapshot) marks it stale, and a caller that has taken the raw device pointer may write
+// behind the library's back: from then on the mirror is rebuilt before every use.
+#define BL_MIRROR_FRAME 3
 struct bl_grid {
     bl_ctx* ctx;
     bl_frame frame;
     int8_t* cells;      // device
+    mutable int8_t* mirror;           // device, first byte of the framed image (or null)
+    mutable size_t mirror_cap;
+    mutable int mirror_stride;
+    mutable bool mirror_valid;        // the mirror equals the cells as of the work enqueued so far
+    bool mirror_external;             // bl_grid_device_ptr has been handed out
 };
 
 // where a replanner submission wants its map + pose snapshot, and the number to publish in *flag when it is complete

@@ -53,6 +53,7 @@ struct map_args {
     int hit, miss;
     int4* rays;
     long long* stamps;              // diagnostic build only (-DBL_MAP_STAMPS)
+    int8_t* mirror; int mirror_stride;   // cell (0, 0) of the grid's zero-framed mirror when it is current (bl_internal.h), or null
     // optional tail: copy the updated grid and the pose to a replanner snapshot and publish its submission number
     // (bl_planner_submit_with_map_update: saves a dependent launch on the SLAM stream)
     int8_t* snap_cells; bl_pose_xyt_t* snap_pose; const bl_pose_xyt_t* snap_pose_src;
@@ -70,6 +71,12 @@ struct map_args {
 #else
 #define MSTAMP(i) do { } while (0)
 #endif
+
+// where cell number idx (row-major in the grid, row y) lies in the zero-framed mirror, relative to the mirror's cell (0, 0)
+__device__ __forceinline__ size_t mirror_at(const map_args& a, size_t idx, int y)
+{
+    return idx + (size_t)y * (size_t)(a.mirror_stride - a.frame.width);
+}
 
 __device__ __forceinline__ bool cell_in_grid(const bl_frame& f, int x, int y)
 {
@@ -335,18 +342,23 @@ __device__ __forceinline__ void map_update_body(const map_args& a, int8_t* snap,
                 }
             }
             __syncthreads();
-            int H = 0;
+            int H = 0, idx_y = 0;
             size_t idx = 0;
             if (leader) {
                 H = (int)half_of(s_cnt[ci >> 1], ci);
                 const int4 me = seg_walk ? my_ray : a.rays[r];
                 idx = (size_t)me.w * a.frame.width + me.z;
+                idx_y = me.w;
             }
             __syncthreads();
             if (a.R > MAP_THREADS) {
                 // more rays than threads (never the case for a 290-ray lidar): hits of this round go straight to the grid;
                 // the free-space pass of an end cell then sees the already saturated value, as in the reference
-                if (leader) { int v = a.cells[idx]; a.cells[idx] = (int8_t)min(127, v + a.hit * H); }
+                if (leader) {
+                    int v = a.cells[idx];
+                    a.cells[idx] = (int8_t)min(127, v + a.hit * H);
+                    if (a.mirror) a.mirror[mirror_at(a, idx, idx_y)] = a.cells[idx];
+                }
                 if (ci >= 0) atomicAnd(&s_cnt[ci >> 1], (ci & 1) ? 0x0000ffffu : 0xffff0000u);
                 __syncthreads();
                 continue;
@@ -401,6 +413,7 @@ __device__ __forceinline__ void map_update_body(const map_args& a, int8_t* snap,
                 v = max(-128, min(127, v + a.hit * H) - a.miss * M);
                 a.cells[idx] = (int8_t)v;
                 if (snap) snap[idx] = (int8_t)v;
+                if (a.mirror) a.mirror[mirror_at(a, idx, idx_y)] = (int8_t)v;
                 atomicAnd(&s_cnt[ci >> 1], (ci & 1) ? 0x0000ffffu : 0xffff0000u);
             }
             __syncthreads();
@@ -439,15 +452,16 @@ __device__ __forceinline__ void map_update_body(const map_args& a, int8_t* snap,
             for (int it0 = tid; it0 < nitems; it0 += 4 * MAP_THREADS) {
                 unsigned long long c[4];
                 size_t gi[4];
-                int v[4];
+                int v[4], gy[4];
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                     const int it = it0 + u * MAP_THREADS;
-                    c[u] = 0ull; gi[u] = 0; v[u] = 0;
+                    c[u] = 0ull; gi[u] = 0; v[u] = 0; gy[u] = 0;
                     if (it < nitems) {
                         const int ry = it / wq, dq = it - ry * wq;
                         c[u] = *(const unsigned long long*)&s_cnt[(ry * ww + 4 * dq) >> 1];
                         gi[u] = (size_t)(sy0 + ry) * a.frame.width + bx0 + 4 * dq;
+                        gy[u] = sy0 + ry;
                     }
                 }
 #pragma unroll
@@ -465,6 +479,7 @@ __device__ __forceinline__ void map_update_body(const map_args& a, int8_t* snap,
                         }
                         *(int*)(a.cells + gi[u]) = (int)nv;
                         if (snap) *(int*)(snap + gi[u]) = (int)nv;
+                        if (a.mirror) *(int*)(a.mirror + mirror_at(a, gi[u], gy[u])) = (int)nv;
                     }
             }
         } else
@@ -485,7 +500,11 @@ __device__ __forceinline__ void map_update_body(const map_args& a, int8_t* snap,
                     if (M[u] > 0) v[u] = a.cells[(size_t)(sy0 + r0 + 4 * u) * a.frame.width + bx0 + cx];
 #pragma unroll
                 for (int u = 0; u < 8; ++u)
-                    if (M[u] > 0) a.cells[(size_t)(sy0 + r0 + 4 * u) * a.frame.width + bx0 + cx] = (int8_t)max(-128, v[u] - a.miss * M[u]);
+                    if (M[u] > 0) {
+                        const size_t at = (size_t)(sy0 + r0 + 4 * u) * a.frame.width + bx0 + cx;
+                        a.cells[at] = (int8_t)max(-128, v[u] - a.miss * M[u]);
+                        if (a.mirror) a.mirror[mirror_at(a, at, sy0 + r0 + 4 * u)] = a.cells[at];
+                    }
             }
         }
         __syncthreads();
@@ -578,6 +597,12 @@ static int mapping_update_impl(bl_mapping* m, const bl_lidar_t* scan, const bl_p
     a.hit = m->hit; a.miss = m->miss;
     a.rays = m->d_rays;
     a.stamps = nullptr;
+    // the zero-framed mirror the particle filter gathers from, kept current while this update's stream is the one it was built on
+    a.mirror = nullptr; a.mirror_stride = 0;
+    if (map->mirror && map->mirror_valid && !map->mirror_external && map->ctx == ctx) {
+        a.mirror = map->mirror + BL_MIRROR_FRAME * map->mirror_stride + 4;
+        a.mirror_stride = map->mirror_stride;
+    } else map->mirror_valid = false;
     a.snap_cells = nullptr; a.snap_pose = nullptr; a.snap_pose_src = nullptr; a.snap_flag = nullptr; a.snap_seq = 0;
     if (snap) {
         a.snap_cells = snap->cells; a.snap_pose = snap->pose; a.snap_pose_src = (const bl_pose_xyt_t*)d_pose;

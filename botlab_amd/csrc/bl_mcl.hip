@@ -57,7 +57,7 @@ struct bl_pf {
     bool use_lds;
     int last_blocks, last_tile;   // launch shape of the last k_mcl_main
     int last_main_blocks, last_main_particles, last_tail_tile;
-    bool fused_finish, no_fused_finish, no_packed, no_balance, no_framed, no_window, no_fast_trig;
+    bool fused_finish, no_fused_finish, no_packed, no_balance, no_framed, no_window, no_fast_trig, no_mirror_reuse;
     int window_override;          // window side in cells (0: from the scan's reach)
     int cus;                      // compute units of the device
     int split_log2_override;  // -1: automatic
@@ -70,8 +70,6 @@ struct bl_pf {
     int32_t* dbg_like;
     float* d_noise;           // 3 * n_local (parity mode)
     bl_particle_t* d_export;  // n_local
-    int8_t* framed;           // zero-framed copy of a grid too large for LDS (packed scoring gathers from it through L2)
-    size_t framed_cap;
     // uniform utimes of the particle set (every particle carries the same pair; DESIGN.md "Particle utimes")
     int64_t pose_utime, parent_utime;
     // ActionModel state (action_model.hpp:60-78)
@@ -206,7 +204,7 @@ __device__ __forceinline__ int pk_dot2(short2_t a, short2_t b, int c)
 // to [-2, size + 1] once; its two Bresenham neighbours are then formed from the clamped cell and need no clamp of their
 // own: they stay within the frame, and whenever the clamp moved the endpoint all three true cells lie outside the grid
 // (the endpoint by >= 2 cells, so its neighbours by >= 1) and all three cells read are frame zeros.
-#define MCL_FRAME 3
+#define MCL_FRAME BL_MIRROR_FRAME
 struct pk_map { int base; short2_t K; short2_t hi; };                     // LDS address of cell (0,0); (1, stride); (W + 1, H + 1)
 struct pk_map_global { const int8_t* base; short2_t K; short2_t hi; };    // the same over a zero-framed copy in device memory
 
@@ -1155,6 +1153,7 @@ extern "C" int bl_pf_create(bl_ctx* ctx, int num_particles, int shard_lo, int sh
     pf->no_packed = getenv("BOTLAB_MCL_NO_PACKED") != nullptr;
     pf->no_balance = getenv("BOTLAB_MCL_NO_BALANCE") != nullptr;
     pf->no_framed = getenv("BOTLAB_MCL_NO_FRAMED") != nullptr;
+    pf->no_mirror_reuse = getenv("BOTLAB_MCL_NO_MIRROR_REUSE") != nullptr;
     pf->no_window = getenv("BOTLAB_MCL_NO_WINDOW") != nullptr;
     pf->no_fast_trig = getenv("BOTLAB_MCL_NO_FAST_TRIG") != nullptr;
     pf->window_override = getenv("BOTLAB_MCL_WINDOW") ? atoi(getenv("BOTLAB_MCL_WINDOW")) : 0;
@@ -1173,7 +1172,7 @@ extern "C" void bl_pf_destroy(bl_pf* pf)
     (void)hipStreamSynchronize(pf->ctx->stream);
     if (!pf->rec_external) { if (pf->rec[0]) (void)hipFree(pf->rec[0]); if (pf->rec[1]) (void)hipFree(pf->rec[1]); }
     void* ptrs[] = {pf->tile_partials, pf->fin_recs, pf->fin_tabs, pf->fin_sync, pf->prefix, pf->parent, pf->state, pf->partials, pf->block_sums, pf->dbg_idx, pf->dbg_like,
-                    pf->d_noise, pf->d_export, pf->framed};
+                    pf->d_noise, pf->d_export};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     delete pf;
 }
@@ -1429,14 +1428,19 @@ static int pf_launch_main(bl_pf* pf, const bl_grid* map, int R, int rand_value, 
             lds_bytes = (int)whole;
             mode = 1;
         } else if (a.pk_ok && !a.interp && !pf->no_framed) {
-            if (whole > pf->framed_cap) {
-                if (pf->framed) { BL_HIP(hipStreamSynchronize(ctx->stream)); BL_HIP(hipFree(pf->framed)); pf->framed = nullptr; pf->framed_cap = 0; }
-                BL_HIP(hipMalloc((void**)&pf->framed, whole));
-                pf->framed_cap = whole;
+            if (whole > map->mirror_cap) {
+                if (map->mirror) { BL_HIP(hipStreamSynchronize(ctx->stream)); BL_HIP(hipFree(map->mirror)); map->mirror = nullptr; map->mirror_cap = 0; }
+                BL_HIP(hipMalloc((void**)&map->mirror, whole));
+                map->mirror_cap = whole;
+                map->mirror_valid = false;
             }
-            const int dwords = (stride >> 2) * (H + 2 * MCL_FRAME);
-            hipLaunchKernelGGL(k_mcl_frame, dim3((dwords + 255) / 256), dim3(256), 0, ctx->stream, map->cells, W, H, stride, (int*)pf->framed);
-            a.framed = pf->framed + MCL_FRAME * stride + 4;
+            if (!map->mirror_valid || map->mirror_stride != stride || map->mirror_external || pf->no_mirror_reuse) {
+                const int dwords = (stride >> 2) * (H + 2 * MCL_FRAME);
+                hipLaunchKernelGGL(k_mcl_frame, dim3((dwords + 255) / 256), dim3(256), 0, ctx->stream, map->cells, W, H, stride, (int*)map->mirror);
+                map->mirror_stride = stride;
+                map->mirror_valid = map->ctx == ctx;          // k_map_update keeps it current from here on (same stream only)
+            }
+            a.framed = map->mirror + MCL_FRAME * stride + 4;
             a.framed_stride = stride;
             // Measured at 100k-1M particles on 2000^2 / 4096^2 grids: with the rays inside it a 208-cell window is 8-22 %
             // faster than gathering everything through L2, with nearly every ray leaving it (8 m rays) it is within

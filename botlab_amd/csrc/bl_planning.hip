@@ -1685,6 +1685,7 @@ int bl_planner_reserve(bl_planner* p, const bl_grid* map, bl_planner_snap* out)
     if (L.slot_used[slot] && hipEventQuery(L.slot_free[slot]) != hipSuccess)
         BL_HIP(hipStreamWaitEvent(p->main->stream, L.slot_free[slot], 0));
     out->cells = snap->cells;
+    snap->mirror_valid = false;                              // (nobody localises on a snapshot, but its cells are about to change)
     out->pose = U.pose[slot];
     out->flag = p->handoff_flag ? p->d_flag : nullptr;
     out->seq = (unsigned long long)p->submitted + 1ull;

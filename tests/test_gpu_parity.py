@@ -711,3 +711,57 @@ def test_shard_engine_single_rank_with_nccl_collectives_matches_plain_filter(map
         os.environ.pop("BOTLAB_FORCE_COLLECTIVES", None)
         if created:
             dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("side,form", [(1000, "riding"), (1000, "host_pose"), (1001, "host_pose")])
+def test_large_grid_mirror_kept_current_by_map_updates(maps, gpu_ctx, side, form, monkeypatch):
+    """Grids that do not fit LDS are scored from a zero-framed mirror of the grid.  The filter builds it once; every map update
+    then stores the cells it changes into both images (the endpoints it changes are exactly the cells the next scan scores).
+    A SLAM loop on such a grid must give the same particles, poses and map whether the mirror is reused, rebuilt before every
+    update (BOTLAB_MCL_NO_MIRROR_REUSE) or not used at all (BOTLAB_MCL_NO_FRAMED: gathers from the grid itself) -- including
+    across an upload that replaces the cells mid-run and, side 1001, rows that are not whole dwords."""
+    N = 4000
+    world = synth.tile_world(maps["astar_maze"]["cells"], side)
+    half = side * 0.05 / 2.0
+    origin, mpc, cpm = (np.float32(-half), np.float32(-half)), np.float32(0.05), helpers.CPM_DEFAULT
+    start = (3.3, -7.1, 0.4)
+    truth = np.where(world > 0, 127, -127).astype(np.int8)
+    first = np.where(world > 0, 30, -20).astype(np.int8)
+    first[:, : side // 2] = 0                                           # half the map still unknown: the updates matter
+    poses = synth.square_trajectory(start, 10, step_len=0.05, turn=0.1, side=0.2)
+    scans = [synth.raycast_scan(truth, origin, 0.05, poses[k - 1], poses[k], 1_000_000 + k * 100_000) for k in range(1, len(poses))]
+    out = []
+    for env in ({}, {"BOTLAB_MCL_NO_MIRROR_REUSE": "1"}, {"BOTLAB_MCL_NO_FRAMED": "1"}):
+        with monkeypatch.context() as mp:
+            for k_, v_ in env.items():
+                mp.setenv(k_, v_)                                       # read when the filter is created
+            g = bl.OccupancyGrid.from_cells(first, origin, mpc, cellsPerMeter=cpm, ctx=gpu_ctx)
+            pf = bl.ParticleFilter(N, ctx=gpu_ctx)
+            pf.initializeFilterAtPose(bl.make_pose(*start, utime=int(scans[0].times[0])), seed=5)
+            pf.setNoiseSeed(9)
+            mapper = bl.Mapping(5.0, 4, 1, ctx=gpu_ctx)
+            aplanner = bl.AsyncPlanner(ctx=gpu_ctx, lanes=1, batch=1) if form == "riding" else None
+            rec = []
+            for k, sc in enumerate(scans):
+                odo = bl.make_pose(*poses[k + 1], utime=sc.utime)
+                if k == 5:                                              # the cells are replaced behind the mirror's back
+                    g.upload(np.where(world > 0, 10, -5).astype(np.int8))
+                if form == "riding":
+                    pf.updateBegin(odo, sc, g, 1000 + k)
+                    aplanner.submit_with_map_update_finishing(mapper, sc, pf, sc.utime, g, bl.make_pose(start[0] + 0.5, start[1], 0.0))
+                    aplanner.fetch()
+                    pose = pf.poseEstimate()
+                else:
+                    pose = pf.updateFilter(odo, sc, g, rand_value=1000 + k)
+                    mapper.updateMap(sc, pose, g)
+                parts = pf.particles()
+                rec.append((None if pose is None else (pose.x, pose.y, pose.theta), parts["x"].copy(), parts["y"].copy(),
+                            parts["theta"].copy(), parts["weight"].copy()))
+            out.append((rec, g.cells().copy()))
+    for o in out[1:]:
+        assert np.array_equal(o[1], out[0][1])
+        for a_, b_ in zip(o[0], out[0][0]):
+            assert a_[0] == b_[0]
+            for u_, v_ in zip(a_[1:], b_[1:]):
+                assert np.array_equal(u_, v_)
+    assert (out[0][1] != first).sum() > 1000                           # the map really changed
