@@ -610,6 +610,7 @@ struct bl_astar_state {
     bl_frame frame;
     // cost table cache key
     bool lut_valid; bl_search_params_t lut_params; int lut_n; const void* lut_owner;
+    int lut_eff;                       // entries [lut_eff - 1, lut_n) of the cost table are all equal: the kernel clamps the index to lut_eff - 1
     // batch form
     int b_cap; size_t b_cells; int64_t b_heap_each; size_t b_path_each;
     int2* b_heap; int32_t* b_closed; int32_t* b_path; int32_t* b_pool; char* b_results; int2* b_goals;
@@ -623,16 +624,17 @@ struct bl_astar_state {
 #define ASTAR_HDR 256
 static_assert(sizeof(astar_result) <= ASTAR_HDR, "result record must fit the header of the output buffer");
 
-#define ASTAR_MAX_UNITS 4
+#define ASTAR_MAX_UNITS 8
 struct astar_unit {
     const uint16_t* l1; const int32_t* cost_lut; int2* heap; int32_t* closed; int32_t* path; astar_result* result;
     const bl_pose_xyt_t* start_dev; bl_pose_xyt_t start_host; int sx, sy, gx, gy;
     char* host_out; int32_t* slot_path;
+    int cost_n;
 };
 
 struct astar_args {
     const uint16_t* l1; int W, H;
-    const int32_t* cost_lut; int cost_n;   // per L1 distance: obstacle cost, or ASTAR_INVALID_COST if the cell is not valid
+    const int32_t* cost_lut; int cost_n;   // per L1 distance min(n, cost_n - 1): obstacle cost, or ASTAR_INVALID_COST if the cell is not valid
     int2* heap; int heap_cap;
     int32_t* closed;
     int32_t* path; long long path_cap;
@@ -773,7 +775,7 @@ __global__ __launch_bounds__(64) void k_astar(astar_args a)
         const astar_unit u = a.units[blockIdx.x];
         a.l1 = u.l1; a.cost_lut = u.cost_lut; a.heap = u.heap; a.closed = u.closed; a.path = u.path; a.result = u.result;
         a.start_dev = u.start_dev; a.start_host = u.start_host; a.sx = u.sx; a.sy = u.sy; a.gx = u.gx; a.gy = u.gy;
-        a.host_out = u.host_out; a.slot_path = u.slot_path;
+        a.host_out = u.host_out; a.slot_path = u.slot_path; a.cost_n = u.cost_n;
     }
     if (a.batch_goals) {
         const long long b = blockIdx.x;
@@ -804,7 +806,7 @@ __global__ __launch_bounds__(64) void k_astar(astar_args a)
         if (x < 0 || y < 0 || x >= a.W || y >= a.H) return ASTAR_INVALID_COST;
         int n = a.l1[(size_t)y * a.W + x];
         if (n == 0xFFFF) return ASTAR_INVALID_COST;                 // distance -1: never > minDist
-        return a.cost_lut[n];
+        return a.cost_lut[min(n, a.cost_n - 1)];
     };
     const bool ok = cell_cost(a.gx, a.gy) != ASTAR_INVALID_COST       // astar.cpp:40-44
                     && cell_cost(a.sx, a.sy) != ASTAR_INVALID_COST    // :46-50
@@ -873,7 +875,8 @@ __global__ __launch_bounds__(64) void k_astar(astar_args a)
         // ---- the four neighbours, one per lane (expand_node order is the lane order, astar.cpp:213-233)
         int my_cost = ASTAR_INVALID_COST;
         if (inb && my_l1 != 0xFFFF) {
-            if (cost_in_lds) my_cost = s_cost[my_l1]; else my_cost = a.cost_lut[my_l1];
+            const int ci = min(my_l1, a.cost_n - 1);
+            if (cost_in_lds) my_cost = s_cost[ci]; else my_cost = a.cost_lut[ci];
         }
         // gCost of the popped node: fCost - hCost - oCost of its cell (the start node carries zeros, astar.cpp:66-69)
         const int ax = abs(a.gx - nx), ay = abs(a.gy - ny);                     // get_hCost (:170-179); lane 4: the cell itself
@@ -1067,6 +1070,11 @@ static int astar_prepare_lut(bl_ctx* ctx, const bl_dist* d, const bl_search_para
         s->h_cost[n] = c;
     }
     BL_HIP(hipMemcpyAsync(s->cost_lut, s->h_cost, (size_t)ln * 4, hipMemcpyHostToDevice, ctx->stream));
+    // the cost is 0 from maxDistanceWithCost on: the table's constant tail is not worth LDS (or a gather per expansion on grids
+    // whose W + H + 1 entries do not fit it)
+    int eff = ln;
+    while (eff > 1 && s->h_cost[eff - 2] == s->h_cost[ln - 1]) eff--;
+    s->lut_eff = eff;
     s->lut_valid = true; s->lut_n = ln; s->lut_owner = (const void*)d; s->lut_params = *params;
     return BL_OK;
 }
@@ -1092,7 +1100,7 @@ static int astar_fill(bl_ctx* ctx, const bl_dist* d, const bl_pose_xyt_t* start,
     const int ln = d->frame.width + d->frame.height + 1;
     astar_args& a = *out;
     a.l1 = d->l1; a.W = d->frame.width; a.H = d->frame.height;
-    a.cost_lut = s->cost_lut; a.cost_n = ln;
+    a.cost_lut = s->cost_lut; a.cost_n = s->lut_eff;
     a.heap = s->heap; a.heap_cap = (int)s->heap_cap;
     a.closed = d->closed;
     a.path = (int32_t*)(s->d_out + ASTAR_HDR); a.path_cap = (long long)s->path_cap;
@@ -1139,7 +1147,8 @@ static void astar_launch_kernel(bl_ctx* ctx, const astar_args& a, int workgroups
     // flight then take a dozen CUs out of the filter's single round (4096 x 4096 / 256k particles: k_mcl_main 0.43 -> 0.37 ms
     // with the small footprint, the searches themselves no slower).  A search that runs alone takes the 147 KB heap: an open
     // list spilling past the LDS levels pays an HBM round trip per heap level.
-    if (ctx->astar_small_lds)
+    static const bool force_small = getenv("BOTLAB_ASTAR_SMALL_LDS") != nullptr;     // probes: the replanner's footprint on a lone search
+    if (ctx->astar_small_lds || force_small)
         hipLaunchKernelGGL((k_astar<AH_LDS_SMALL, AH_COST_LDS_SMALL>), dim3(workgroups), dim3(64), AH_LDS_SMALL_BYTES, ctx->stream, a);
     else
         hipLaunchKernelGGL((k_astar<AH_LDS, AH_COST_LDS>), dim3(workgroups), dim3(64), AH_LDS_BYTES, ctx->stream, a);
@@ -1183,7 +1192,7 @@ static int astar_launch_units(int n, bl_ctx* const* ctxs, bl_dist* const* dists,
         astar_unit& u = units[b];
         u.l1 = a.l1; u.cost_lut = a.cost_lut; u.heap = a.heap; u.closed = a.closed; u.path = a.path; u.result = a.result;
         u.start_dev = a.start_dev; u.start_host = a.start_host; u.sx = a.sx; u.sy = a.sy; u.gx = a.gx; u.gy = a.gy;
-        u.host_out = a.host_out; u.slot_path = a.slot_path;
+        u.host_out = a.host_out; u.slot_path = a.slot_path; u.cost_n = a.cost_n;
     }
     a.units = units;
     bl_ctx* ctx = ctxs[0];
@@ -1360,7 +1369,7 @@ static int astar_batch_cells(bl_ctx* ctx, const bl_dist* d, const bl_pose_xyt_t*
         BL_HIP(hipMemsetAsync(s->b_cursor, 0, 8, ctx->stream));
         astar_args a;
         a.l1 = d->l1; a.W = d->frame.width; a.H = d->frame.height;
-        a.cost_lut = s->cost_lut; a.cost_n = d->frame.width + d->frame.height + 1;
+        a.cost_lut = s->cost_lut; a.cost_n = s->lut_eff;
         a.heap = s->b_heap; a.heap_cap = (int)s->b_heap_each;
         a.closed = s->b_closed;
         a.path = s->b_path; a.path_cap = (long long)s->b_path_each;

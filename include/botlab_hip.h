@@ -212,7 +212,7 @@ typedef struct bl_planner bl_planner;
 /* lanes (1..4): consecutive submissions go to consecutive side streams, so up to `lanes` replans run concurrently (each
  * is one wavefront on its own CU and latency-bound; independent searches are what the GPU can overlap). */
 int bl_planner_create(bl_ctx* ctx, int lanes, bl_planner** out);
-/* batch (1..4): a lane collects `batch` consecutive submissions and issues their searches as ONE launch, a workgroup each,
+/* batch (1..8): a lane collects `batch` consecutive submissions and issues their searches as ONE launch, a workgroup each,
  * so lanes x batch replans overlap although the runtime multiplexes streams onto four hardware queues.  For grids where a
  * search outlasts a step (2000x2000: ~1.5 ms against 0.2 ms); a result is then available `batch` - 1 submissions later
  * (a fetch that cannot wait for the batch to fill sends it off as it is).  bl_planner_create is batch = 1. */

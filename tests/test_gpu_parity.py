@@ -563,8 +563,8 @@ def test_step_pipeline_with_device_pose_equals_host_pose_path(oracle, maps, gpu_
     # are sent off partly filled by the fetch; lag 6: every batch fills, the last one is flushed by the drain)
     forms = {"async": (3, 1, 3), "fused": (3, 1, 3), "batched2": (3, 2, 3), "batched3": (2, 3, 6), "batched4": (1, 4, 2),
              "riding": (3, 1, 3), "riding_deep": (3, 1, 6), "riding_prefetch": (2, 2, 6), "fused_prefetch": (3, 1, 3),
-             "riding_wrong_prefetch": (2, 2, 6)}
-    for dev in (False, True, "async", "fused", "batched2", "batched3", "batched4", "riding", "riding_deep", "riding_prefetch",
+             "riding_wrong_prefetch": (2, 2, 6), "batched8": (1, 8, 7)}
+    for dev in (False, True, "async", "fused", "batched2", "batched3", "batched4", "batched8", "riding", "riding_deep", "riding_prefetch",
                 "fused_prefetch", "riding_wrong_prefetch"):
         g = _grid_from_map(m, gpu_ctx)
         lanes, batch, lag = forms.get(dev, (0, 0, 0))
