@@ -341,9 +341,9 @@ def main():
     pops_total = [0]
 
     pose_dev = engine.pf.poseDevicePtr()
-    # with one rank and no collective the filter's end rides in the map kernel (bl_mapping_update_finishing_pf)
+    # the filter's end rides in the map kernel (bl_mapping_update_finishing_pf), behind the record exchange when sharded
     prefetch = not os.environ.get("BENCH_NO_PREFETCH")
-    ride_finish = world == 1 and not spf.force_collectives and not os.environ.get("BENCH_NO_RIDE")
+    ride_finish = not os.environ.get("BENCH_NO_RIDE")
     in_flight = []                  # steps enqueued whose result has not been fetched yet
 
     def enqueue(k):
@@ -353,8 +353,9 @@ def main():
         sc = scans[k]
         odo_pose = bl.make_pose(o[0], o[1], o[2], utime=sc.utime)
         if ride_finish:
-            # one rank: the end of the filter update (pose estimate + weight prefix) rides in the map kernel's launch
-            engine.begin(odo_pose, sc, grid, int(rands[k]))
+            # the end of the filter update (pose estimate + weight prefix) rides in the map kernel's launch; on shards the
+            # record exchange comes first and every rank ends the update the same way
+            spf.updateBegin(odo_pose, sc, grid, int(rands[k]))
             if prefetch and k + 1 < len(scans):
                 ctx.scanPrefetch(scans[k + 1])       # the next scan is queued (slam.cpp:96-104): it rides in this step's map kernel
             if goal_pose is not None:

@@ -1601,8 +1601,27 @@ extern "C" int bl_pf_update_end(bl_pf* pf, bl_pose_xyt_t* out_pose)
 int bl_pf_take_finish(bl_pf* pf, mcl_finish_args* out)
 {
     if (!pf || !pf->pending_end) return 0;
-    if (!pf->fused_finish || pf->strict) return -1;          // (strict resampling appends a launch of its own to the finish)
-    if (pf_fused_args(pf, pf->cur ^ 1, pf->pending_utime, out) < 0) return -1;
+    if (pf->strict) return -1;                               // (strict resampling appends a launch of its own to the finish)
+    if (pf->fused_finish) {
+        if (pf_fused_args(pf, pf->cur ^ 1, pf->pending_utime, out) < 0) return -1;
+    } else {
+        // a shard (the record has just been gathered from every rank) or a launch shape the groups do not tile: the tile sums
+        // come from the record itself, in an order that depends on N alone (k_scan_tile_sums, launched here), and the rest of
+        // the finish -- groups, pre-chain, finisher -- rides in the caller's kernel exactly as in the fused form
+        if (pf->no_fused_finish) return -1;
+        const int which = pf->cur ^ 1;
+        mcl_finish_args& f = *out;
+        f.partials = pf->tile_partials; f.nblocks = pf->scan_blocks;
+        f.rec = pf->rec[which]; f.N = pf->N;
+        f.tile = SCAN_TILE; f.main_blocks = pf->scan_blocks; f.main_particles = pf->N; f.tail_tile = 1;
+        f.prefix = pf->prefix; f.state = pf->state; f.utime = pf->pending_utime;
+        if (pf_finish_fill(pf, &f) < 0) return -1;
+        hipEvent_t e0, e1;
+        if (bl_timer_begin(pf->ctx, BL_K_MCL_SCAN, &e0, &e1)) return -1;
+        hipLaunchKernelGGL(k_scan_tile_sums, dim3(pf->scan_blocks), dim3(SCAN_THREADS), 0, pf->ctx->stream, pf->rec[which], pf->N,
+                           pf->block_sums, pf->tile_partials);
+        if (bl_timer_end(pf->ctx, BL_K_MCL_SCAN, e0, e1)) return -1;
+    }
     pf->cur ^= 1;
     pf->parent_utime = pf->pose_utime;       // parent_pose = sample.pose (action_model.cpp:92)
     pf->pose_utime = 0;                      // pose.utime = utime_ (D3)

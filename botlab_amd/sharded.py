@@ -6,8 +6,10 @@ Exchange per moved update:
      slice of the 16-byte exchange record (x, y, theta, weight-units);
   2. ONE all-gather of the record (in place: each rank's slice already sits at its offset) -- the only collective;
   3. every rank scans the integer weight units of all N particles (exact, so every rank derives the same cumulative
-     and the same total) and forms the pose estimate from the gathered record in an addition order fixed by N alone,
-     so the estimate is bit-identical on every rank and for every shard count.
+     and the same total) and forms the pose estimate from the gathered record -- the reference's own serially rounded
+     float sums over all N particles in order -- so the estimate is bit-identical on every rank, for every shard count,
+     and equal to one GPU's.  That end of the update is either `updateFilter` (own launches) or, after `updateBegin`,
+     rides in the map kernel as on one GPU.
 The map update, distance grid and A* are replicated (every rank applies the identical integer update; no traffic).
 
 The engine behind a shard is pluggable so the orchestration is testable without a GPU: the product engine is
@@ -151,6 +153,13 @@ class ShardedParticleFilter:
         return self._views
 
     def updateFilter(self, odometry, scan, grid, rand_value, noise=None, want_pose=True):
+        self.updateBegin(odometry, scan, grid, rand_value, noise)
+        return self.engine.end(want_pose)
+
+    def updateBegin(self, odometry, scan, grid, rand_value, noise=None):
+        """The update up to and including the exchange.  Its end -- weight prefix and pose estimate, identical on every rank -- is
+        either `engine.end()` or rides in the map kernel (Mapping.updateMapFinishingFilter / AsyncPlanner.
+        submit_with_map_update_finishing with `engine.pf`), as on a single GPU."""
         moved = self.engine.begin(odometry, scan, grid, rand_value, noise)
         if moved and self.comm is not None:
             lib = self.engine.ctx.lib
@@ -170,7 +179,7 @@ class ShardedParticleFilter:
                 rec = self.engine.exchange_record()
                 S = self.engine.S
                 dist.all_gather_into_tensor(rec, rec[self.rank * S:(self.rank + 1) * S], group=self.group)
-        return self.engine.end(want_pose)
+        return moved
 
     def particles(self):
         return self.engine.particles()

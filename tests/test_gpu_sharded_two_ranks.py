@@ -13,7 +13,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 N, STEPS = 30001, 6           # odd N: last shard shorter than the padded block
 
 
-def _run(rank, world, port, out_dir):
+def _run(rank, world, port, out_dir, riding=False):
     sys.path.insert(0, HERE)
     sys.path.insert(0, os.path.dirname(HERE))
     import torch
@@ -31,16 +31,29 @@ def _run(rank, world, port, out_dir):
     scans = [synth.raycast_scan(truth, m["origin"], 0.05, poses[k - 1], poses[k], 1_000_000 + k * 100_000) for k in range(1, STEPS + 1)]
     # one rank would take the fused single-shard finish (sums from k_mcl_main's workgroup partials, another addition
     # order); the scan-based finish is the one every shard count shares, so the comparison below can be bit-exact
-    os.environ["BOTLAB_MCL_NO_FUSED_FINISH"] = "1"
+    # (riding=True with two ranks: the shards' own default -- the tile sums from the record, the rest of the finish riding in the
+    # map kernel -- against the same record-based finish as separate launches on one rank)
+    if not (riding and world > 1):
+        os.environ["BOTLAB_MCL_NO_FUSED_FINISH"] = "1"
     eng = sharded.HipShardEngine(N, rank, world, 0)            # both ranks on device 0
     spf = sharded.ShardedParticleFilter(eng)
     grid = bl.OccupancyGrid.from_cells(m["cells"], m["origin"], m["mpc"], cellsPerMeter=helpers.CPM_DEFAULT, ctx=eng.ctx)
+    mapper = bl.Mapping(5.0, 4, 1, ctx=eng.ctx)
     spf.initializeFilterAtPose(bl.make_pose(-0.75, 0.2, 0.0, utime=int(scans[0].times[0])), seed=21)
     est = []
     for k, sc in enumerate(scans):
-        p = spf.updateFilter(bl.make_pose(*poses[k + 1], utime=sc.utime), sc, grid, 900 + k)
+        odo = bl.make_pose(*poses[k + 1], utime=sc.utime)
+        if riding and world > 1:
+            spf.updateBegin(odo, sc, grid, 900 + k)
+            mapper.updateMapFinishingFilter(sc, eng.pf, sc.utime, grid)
+            p = eng.pf.poseEstimate()
+        else:
+            p = spf.updateFilter(odo, sc, grid, 900 + k)
+            if riding:
+                mapper.updateMapDevicePose(sc, eng.pf.poseDevicePtr(), sc.utime, grid)
         est.append((p.utime, p.x, p.y, p.theta))
     parts = spf.particles()
+    np.save(os.path.join(out_dir, f"grid_w{world}_r{rank}.npy"), grid.cells())
     np.save(os.path.join(out_dir, f"parts_w{world}_r{rank}.npy"), parts)
     np.save(os.path.join(out_dir, f"est_w{world}_r{rank}.npy"), np.array(est, dtype=np.float64))
     with open(os.path.join(out_dir, f"shard_w{world}_r{rank}.txt"), "w") as f:
@@ -50,11 +63,12 @@ def _run(rank, world, port, out_dir):
         dist.destroy_process_group()
 
 
-def test_two_ranks_one_device_match_single_rank(tmp_path):
+@pytest.mark.parametrize("riding", [False, True])
+def test_two_ranks_one_device_match_single_rank(tmp_path, riding):
     import torch.multiprocessing as mp
     out = str(tmp_path)
-    mp.spawn(_run, args=(1, 0, out), nprocs=1, join=True)
-    mp.spawn(_run, args=(2, 29600 + os.getpid() % 300, out), nprocs=2, join=True)
+    mp.spawn(_run, args=(1, 0, out, riding), nprocs=1, join=True)
+    mp.spawn(_run, args=(2, 29600 + os.getpid() % 300 + (300 if riding else 0), out, riding), nprocs=2, join=True)
     one = np.load(os.path.join(out, "parts_w1_r0.npy"))
     got = []
     for r in range(2):
@@ -66,3 +80,6 @@ def test_two_ranks_one_device_match_single_rank(tmp_path):
         assert e1.tobytes() == e2.tobytes()      # pose estimates bit-identical: formed from the gathered record in an order fixed by N
     two = np.concatenate(got)
     assert two.tobytes() == one.tobytes()
+    g1 = np.load(os.path.join(out, "grid_w1_r0.npy"))
+    for r in range(2):
+        assert np.array_equal(g1, np.load(os.path.join(out, f"grid_w2_r{r}.npy")))      # the replicated map stays identical
