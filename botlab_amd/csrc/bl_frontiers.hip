@@ -13,6 +13,8 @@
 //     queue visits the touches in key order and grows every component not grown yet from its seed.
 // The depth of the computation is the number of BFS levels (inherent to the FIFO order); each level is a few barriers
 // of one 1024-thread workgroup, with all per-cell state in L2-resident arrays.
+#include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "bl_internal.h"
@@ -29,7 +31,10 @@ struct frontier_args {
     int32_t* queue;             // free-space queue, position 0 = the robot cell (coordinates in rx, ry)
     int32_t* out_cells;         // frontier cells, frontier after frontier, each in growth-queue order
     int32_t* out_offsets; int cap_frontiers;
-    int32_t* counts;            // [0] frontiers, [1] frontier cells, [2] free cells reached (+1), [3] levels, [4] overflow flag
+    int32_t* counts;            // [0] frontiers, [1] frontier cells, [2] free cells reached (+1), [3] levels, [4] overflow flag,
+                                // [5], [6] time stamps, [7] touches found (k_frontier_touches), [8] "take the one-workgroup sweep" flag
+    int phase;                  // k_frontiers: 0 flood + sweep (small grids), 1 flood only, 2 sweep only (and only if counts[8] is set)
+    uint2* touch;               // (key, cell) of every frontier cell the flood touched, in no order; FR_TOUCH_MAX entries
 };
 
 __device__ __forceinline__ unsigned int ld_claim(const unsigned int* p)
@@ -78,9 +83,34 @@ __device__ __forceinline__ int fr_log_odds(const frontier_args& a, int x, int y)
 #define FR_CLS_LDS (96 * 1024)
 #define FR_LQ 2048                // next-level queue entries mirrored in LDS (wider levels are re-read from the global queue)
 
+// Classification of every cell -- is_frontier_cell (frontiers.cpp:217-246) / free (:77) -- and the reset of the claim words.
+// Independent per cell: for grids whose classes do not fit LDS this runs as its own launch over the whole device in front of
+// the flood (one workgroup walking 16 M cells with five dependent loads each cost more than the flood itself).
+__device__ __forceinline__ void fr_classify(const frontier_args& a, uint8_t* cls, long long c)
+{
+    const int x = (int)(c % a.W), y = (int)(c / a.W);
+    const int v = a.cells[c];
+    int k = 0;
+    if (!(v > 0 || v < -5)) {                          // (map(x,y) > .1 || map(x,y) < -5) on an int8
+        if (fr_log_odds(a, x - 1, y) < 0 || fr_log_odds(a, x + 1, y) < 0 || fr_log_odds(a, x, y + 1) < 0 || fr_log_odds(a, x, y - 1) < 0) k = 2;
+    }
+    if (k == 0 && v < 0) k = 1;
+    if (x == a.rx && y == a.ry) k = 3;                  // visitedCells.insert(robotCell) before anything else (:42)
+    cls[c] = (uint8_t)k;
+    a.claim[c] = FR_INF;
+    a.fclaim[c] = FR_INF;
+}
+
+__global__ __launch_bounds__(256) void k_frontier_classify(frontier_args a)
+{
+    const long long ncell = (long long)a.W * a.H;
+    for (long long c = (long long)blockIdx.x * 256 + threadIdx.x; c < ncell; c += (long long)gridDim.x * 256) fr_classify(a, a.cls, c);
+}
+
 template <bool CLS_LDS>
 __global__ __launch_bounds__(FR_T) void k_frontiers(frontier_args a)
 {
+    const long long t_begin = wall_clock64();
     extern __shared__ uint8_t s_cls[];
     __shared__ int s_wave[FR_T / 64];
     __shared__ unsigned int s_umin[FR_T / 64];
@@ -88,24 +118,17 @@ __global__ __launch_bounds__(FR_T) void k_frontiers(frontier_args a)
     const int tid = threadIdx.x;
     const long long ncell = (long long)a.W * a.H;
     uint8_t* cls = CLS_LDS ? s_cls : a.cls;
-    // ---- classification: is_frontier_cell (frontiers.cpp:217-246) / free (:77)
-    for (long long c = tid; c < ncell; c += FR_T) {
-        const int x = (int)(c % a.W), y = (int)(c / a.W);
-        const int v = a.cells[c];
-        int k = 0;
-        if (!(v > 0 || v < -5)) {                          // (map(x,y) > .1 || map(x,y) < -5) on an int8
-            if (fr_log_odds(a, x - 1, y) < 0 || fr_log_odds(a, x + 1, y) < 0 || fr_log_odds(a, x, y + 1) < 0 || fr_log_odds(a, x, y - 1) < 0) k = 2;
-        }
-        if (k == 0 && v < 0) k = 1;
-        if (x == a.rx && y == a.ry) k = 3;                  // visitedCells.insert(robotCell) before anything else (:42)
-        cls[c] = (uint8_t)k;
-        a.claim[c] = FR_INF;
-        a.fclaim[c] = FR_INF;
-    }
+    // ---- classification (large grids: done by k_frontier_classify in front of this launch)
+    if (CLS_LDS)
+        for (long long c = tid; c < ncell; c += FR_T) fr_classify(a, cls, c);
     __threadfence();
     __syncthreads();
     // ---- free-space flood (:47-82), xDeltas {-1,1,0,0}, yDeltas {0,0,1,-1}
     int lo = 0, hi = 1, levels = 0, cur = 0;
+    if (a.phase == 2) {                                     // the flood has run (phase 1): only the sweep, and only when asked for
+        if (a.counts[8] == 0) return;
+        lo = hi = a.counts[2]; levels = a.counts[3];
+    }
     while (lo < hi) {
         const bool one_pass = hi - lo <= FR_T;              // the common case: this thread's neighbours stay in registers
         const bool from_lds = hi - lo <= FR_LQ && lo > 0;
@@ -160,6 +183,11 @@ __global__ __launch_bounds__(FR_T) void k_frontiers(frontier_args a)
         lo = hi; hi = newhi; levels += 1; cur ^= 1;
     }
     const int qn = hi;
+    const long long t_flood = wall_clock64();
+    if (a.phase == 1) {
+        if (tid == 0) { a.counts[2] = qn; a.counts[3] = levels; a.counts[5] = (int)(t_flood - t_begin); a.counts[7] = 0; a.counts[8] = 0; }
+        return;
+    }
     // ---- frontiers in discovery order (:66-75): touches in key order; a touched frontier cell that is not part of a grown
     // frontier yet is the seed of the next one (grow_frontier, :249-288; xDeltas {-1,-1,-1,1,1,1,0,0}, yDeltas {0,1,-1,0,1,-1,1,-1})
     int nf = 0, total_cells = 0, overflow = 0;
@@ -260,6 +288,146 @@ __global__ __launch_bounds__(FR_T) void k_frontiers(frontier_args a)
     if (tid == 0) {
         if (nf <= a.cap_frontiers) a.out_offsets[nf] = total_cells;
         a.counts[0] = nf; a.counts[1] = total_cells; a.counts[2] = qn; a.counts[3] = levels; a.counts[4] = overflow;
+        if (a.phase == 0) a.counts[5] = (int)(t_flood - t_begin);
+        a.counts[6] = (int)(wall_clock64() - t_flood);     // 100 MHz ticks: flood, frontier sweep
+    }
+}
+
+// ---- large grids: the frontier sweep as two launches ------------------------------------------------------------------------
+// The one-workgroup sweep walks the whole free-space queue again (7 M positions at 4096^2) to find the touches in key order, and
+// grows each frontier level by level with three global round trips per level -- frontiers are thin curves, so a level holds two
+// cells (measured: 6.7 of 12.9 ms at 2000^2, 42 of 133 ms at 4096^2).  Instead:
+//   k_frontier_touches  every frontier cell the flood touched carries its first-touch key in claim[]: all workgroups collect
+//                       (key, cell) pairs, in no order (a few thousand on a real map);
+//   k_frontier_grow     one workgroup: the live touch with the smallest key is the next seed (a touch is dead once its cell is
+//                       part of a grown frontier); ONE WAVE then runs the reference's FIFO growth serially, eight lanes looking
+//                       at the eight neighbours of up to eight queued cells per global round trip, the visited set an LDS hash.
+// A map with more touches than FR_TOUCH_MAX or a frontier larger than the hash holds takes the one-workgroup sweep instead
+// (k_frontiers phase 2, launched behind this one: it returns at once unless counts[8] is set).
+#define FR_TOUCH_MAX 16384
+#define FR_TOUCH_PER_THREAD (FR_TOUCH_MAX / FR_T)
+#define FR_HASH 16384                       // slots of the visited set (a power of two); a frontier may fill half of them
+#define FR_RING 1024                        // growth queue entries mirrored in LDS
+
+__global__ __launch_bounds__(256) void k_frontier_touches(frontier_args a)
+{
+    const long long ncell = (long long)a.W * a.H;
+    for (long long c = (long long)blockIdx.x * 256 + threadIdx.x; c < ncell; c += (long long)gridDim.x * 256) {
+        if (a.cls[c] != 2) continue;
+        const unsigned int key = a.claim[c];
+        if (key == FR_INF) continue;
+        const int at = atomicAdd(&a.counts[7], 1);
+        if (at < FR_TOUCH_MAX) a.touch[at] = make_uint2(key, (unsigned int)c);
+    }
+}
+
+// wave-uniform: is x in the set, and if not, put it there.  Returns 1 (was there), 0 (inserted), -1 (no room within 64 slots)
+__device__ __forceinline__ int fr_hash_test_and_set(int* s_hash, int x, int lane)
+{
+    const unsigned int h = ((unsigned int)x * 2654435761u) >> (32 - 14);          // FR_HASH = 2^14
+    const int slot = (int)((h + (unsigned int)lane) & (FR_HASH - 1));
+    const int v = s_hash[slot];
+    const unsigned long long hit = __ballot(v == x), empty = __ballot(v == -1);
+    const int first_empty = empty ? __ffsll((long long)empty) - 1 : 64;
+    if (hit && (__ffsll((long long)hit) - 1) < first_empty) return 1;
+    if (first_empty == 64) return -1;
+    if (lane == first_empty) s_hash[slot] = x;
+    __builtin_amdgcn_wave_barrier();
+    return 0;
+}
+
+__global__ __launch_bounds__(FR_T) void k_frontier_grow(frontier_args a)
+{
+    __shared__ int s_hash[FR_HASH];
+    __shared__ int s_ring[FR_RING];
+    __shared__ unsigned int s_umin[FR_T / 64];
+    __shared__ int s_seed, s_cnt, s_fail;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const long long t_begin = wall_clock64();
+    const int T = a.counts[7];
+    if (T > FR_TOUCH_MAX) { if (tid == 0) a.counts[8] = 1; return; }
+    unsigned int tk[FR_TOUCH_PER_THREAD]; int tc[FR_TOUCH_PER_THREAD];
+#pragma unroll
+    for (int j = 0; j < FR_TOUCH_PER_THREAD; ++j) {
+        const int i = j * FR_T + tid;
+        tk[j] = FR_INF; tc[j] = 0;
+        if (i < T) { const uint2 t = a.touch[i]; tk[j] = t.x; tc[j] = (int)t.y; }
+    }
+    int nf = 0, total = 0, overflow = 0;
+    while (true) {
+        // ---- the next seed: the live touch with the smallest key (frontiers.cpp:66-75 meets them in that order)
+        unsigned int mine = FR_INF; int mine_c = 0;
+#pragma unroll
+        for (int j = 0; j < FR_TOUCH_PER_THREAD; ++j) {
+            if (tk[j] == FR_INF) continue;
+            if (a.cls[tc[j]] != 2) { tk[j] = FR_INF; continue; }                 // its frontier has been grown
+            if (tk[j] < mine) { mine = tk[j]; mine_c = tc[j]; }
+        }
+        const unsigned int best = block_min(mine, s_umin);
+        if (best == FR_INF) break;
+        if (mine == best) s_seed = mine_c;                                      // keys are unique
+        for (int i = tid; i < FR_HASH; i += FR_T) s_hash[i] = -1;
+        if (tid == 0) { s_cnt = 0; s_fail = 0; }
+        __syncthreads();
+        int32_t* fq = a.out_cells + total;
+        if (wave == 0) {
+            // ---- grow_frontier (:249-288) by one wave, serially in queue order; xDeltas {-1,-1,-1,1,1,1,0,0}, yDeltas {0,1,-1,0,1,-1,1,-1}
+            const int seed = s_seed;
+            int head = 0, tail = 1, fail = 0;
+            if (lane == 0) { fq[0] = seed; s_ring[0] = seed; }
+            (void)fr_hash_test_and_set(s_hash, seed, lane);
+            const int n = lane & 7, qi = lane >> 3;
+            const int dx = n < 3 ? -1 : (n < 6 ? 1 : 0);
+            const int dy = (n == 1 || n == 4 || n == 6) ? 1 : ((n == 2 || n == 5 || n == 7) ? -1 : 0);
+            while (head < tail && !fail) {
+                const int nb = min(tail - head, 8);
+                int nc = -1;
+                if (qi < nb) {
+                    const int q = head + qi;
+                    int c;
+                    if (tail - q <= FR_RING) c = s_ring[q & (FR_RING - 1)];
+                    else c = __hip_atomic_load(&fq[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const int x = c % a.W + dx, y = c / a.W + dy;
+                    if (x >= 0 && y >= 0 && x < a.W && y < a.H) nc = y * a.W + x;
+                }
+                const bool isf = nc >= 0 && a.cls[nc] == 2;                     // class 2 does not change while a frontier grows
+                unsigned long long m = __ballot(isf);
+                m &= nb >= 8 ? ~0ull : ((1ull << (8 * nb)) - 1ull);
+                while (m) {
+                    const int l = __ffsll((long long)m) - 1;                     // ascending lane = queue order, then neighbour order
+                    m &= m - 1ull;
+                    const int x = __builtin_amdgcn_readlane(nc, l);
+                    const int r = fr_hash_test_and_set(s_hash, x, lane);
+                    if (r < 0 || tail >= FR_HASH / 2) { fail = 1; break; }
+                    if (r == 0) {
+                        if (lane == 0) { __hip_atomic_store(&fq[tail], x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); s_ring[tail & (FR_RING - 1)] = x; }
+                        tail += 1;
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
+                head += nb;
+            }
+            if (lane == 0) { s_cnt = tail; s_fail = fail; }
+        }
+        __syncthreads();
+        if (s_fail) {
+            // a frontier too large for the visited set: undo the marks and hand the whole sweep to the one-workgroup form
+            for (int i = tid; i < total; i += FR_T) a.cls[a.out_cells[i]] = 2;
+            if (tid == 0) a.counts[8] = 1;
+            return;
+        }
+        const int cnt = s_cnt;
+        for (int i = tid; i < cnt; i += FR_T) a.cls[__hip_atomic_load(&fq[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)] = 5;
+        __threadfence();
+        __syncthreads();
+        if (nf < a.cap_frontiers) { if (tid == 0) a.out_offsets[nf] = total; } else overflow = 1;
+        nf += 1;
+        total += cnt;
+    }
+    if (tid == 0) {
+        if (nf <= a.cap_frontiers) a.out_offsets[nf] = total;
+        a.counts[0] = nf; a.counts[1] = total; a.counts[4] = overflow;
+        a.counts[6] = (int)(wall_clock64() - t_begin);
     }
 }
 
@@ -269,13 +437,14 @@ struct bl_frontier_scratch {
     int32_t* queue = nullptr; int32_t* out_cells = nullptr; int32_t* out_offsets = nullptr; int32_t* counts = nullptr;
     int cap_frontiers = 0;
     int32_t* h_counts = nullptr;
+    uint2* touch = nullptr;
 };
 
 void bl_frontier_scratch_free(bl_ctx* ctx)
 {
     bl_frontier_scratch* s = ctx->frontier;
     if (!s) return;
-    void* dev[] = {s->cls, s->claim, s->fclaim, s->queue, s->out_cells, s->out_offsets, s->counts};
+    void* dev[] = {s->cls, s->claim, s->fclaim, s->queue, s->out_cells, s->out_offsets, s->counts, s->touch};
     for (void* q : dev) if (q) (void)hipFree(q);
     if (s->h_counts) (void)hipHostFree(s->h_counts);
     delete s;
@@ -306,8 +475,9 @@ extern "C" int bl_frontiers_find(bl_ctx* ctx, const bl_grid* map, const bl_pose_
         BL_HIP(hipMalloc((void**)&s->queue, (n + 1) * 4));
         BL_HIP(hipMalloc((void**)&s->out_cells, n * 4));
         BL_HIP(hipMalloc((void**)&s->out_offsets, ((size_t)s->cap_frontiers + 1) * 4));
-        if (!s->counts) BL_HIP(hipMalloc((void**)&s->counts, 8 * 4));
-        if (!s->h_counts) BL_HIP(hipHostMalloc((void**)&s->h_counts, 8 * 4, hipHostMallocDefault));
+        if (!s->counts) BL_HIP(hipMalloc((void**)&s->counts, 16 * 4));
+        if (!s->h_counts) BL_HIP(hipHostMalloc((void**)&s->h_counts, 16 * 4, hipHostMallocDefault));
+        if (!s->touch) BL_HIP(hipMalloc((void**)&s->touch, (size_t)FR_TOUCH_MAX * sizeof(uint2)));
         s->cells = n;
     }
     frontier_args a;
@@ -315,6 +485,7 @@ extern "C" int bl_frontiers_find(bl_ctx* ctx, const bl_grid* map, const bl_pose_
     bl_global_to_cell((double)robot_pose->x, (double)robot_pose->y, map->frame, &a.rx, &a.ry);      // :39
     a.cls = s->cls; a.claim = s->claim; a.fclaim = s->fclaim; a.queue = s->queue;
     a.out_cells = s->out_cells; a.out_offsets = s->out_offsets; a.cap_frontiers = s->cap_frontiers; a.counts = s->counts;
+    a.phase = 0; a.touch = s->touch;
     hipEvent_t e0, e1;
     int rc = bl_timer_begin(ctx, BL_K_FRONTIERS, &e0, &e1);
     if (rc) return rc;
@@ -326,14 +497,31 @@ extern "C" int bl_frontiers_find(bl_ctx* ctx, const bl_grid* map, const bl_pose_
         }
         hipLaunchKernelGGL(k_frontiers<true>, dim3(1), dim3(FR_T), (n + 15) & ~(size_t)15, ctx->stream, a);
     } else {
-        hipLaunchKernelGGL(k_frontiers<false>, dim3(1), dim3(FR_T), 0, ctx->stream, a);
+        long long cblocks = ((long long)n + 255) / 256;
+        if (cblocks > 8192) cblocks = 8192;
+        hipLaunchKernelGGL(k_frontier_classify, dim3((unsigned int)cblocks), dim3(256), 0, ctx->stream, a);
+        static const bool one_wg_sweep = getenv("BOTLAB_FRONTIER_ONE_WG_SWEEP") != nullptr;       // A/B runs and tests of the fallback
+        if (one_wg_sweep) {
+            hipLaunchKernelGGL(k_frontiers<false>, dim3(1), dim3(FR_T), 0, ctx->stream, a);
+        } else {
+            a.phase = 1;
+            hipLaunchKernelGGL(k_frontiers<false>, dim3(1), dim3(FR_T), 0, ctx->stream, a);
+            hipLaunchKernelGGL(k_frontier_touches, dim3((unsigned int)cblocks), dim3(256), 0, ctx->stream, a);
+            hipLaunchKernelGGL(k_frontier_grow, dim3(1), dim3(FR_T), 0, ctx->stream, a);
+            a.phase = 2;
+            hipLaunchKernelGGL(k_frontiers<false>, dim3(1), dim3(FR_T), 0, ctx->stream, a);
+        }
     }
     BL_HIP(hipGetLastError());
     rc = bl_timer_end(ctx, BL_K_FRONTIERS, e0, e1);
     if (rc) return rc;
-    BL_HIP(hipMemcpyAsync(s->h_counts, s->counts, 8 * 4, hipMemcpyDeviceToHost, ctx->stream));
+    BL_HIP(hipMemcpyAsync(s->h_counts, s->counts, 16 * 4, hipMemcpyDeviceToHost, ctx->stream));
     BL_HIP(hipStreamSynchronize(ctx->stream));
     const int nf = s->h_counts[0], total = s->h_counts[1];
+    if (getenv("BOTLAB_FRONTIER_STAMPS"))
+        fprintf(stderr, "[frontiers] flood %.3f ms (%d cells, %d levels), frontier sweep %.3f ms (%d frontiers, %d cells; %d touches%s)\n",
+                s->h_counts[5] * 1e-5, s->h_counts[2], s->h_counts[3], s->h_counts[6] * 1e-5, nf, total, s->h_counts[7],
+                s->h_counts[8] ? ", one-workgroup sweep" : "");
     if (s->h_counts[4] || nf > s->cap_frontiers) { bl_set_error("internal: frontier table overflow (%d frontiers)", nf); return BL_ERR_CAPACITY; }
     std::vector<int32_t> offs((size_t)nf + 1), cells((size_t)total);
     BL_HIP(hipMemcpy(offs.data(), s->out_offsets, ((size_t)nf + 1) * 4, hipMemcpyDeviceToHost));

@@ -67,6 +67,43 @@ def test_find_map_frontiers_random_maps(oracle, gpu_ctx, seed):
     assert total > 10
 
 
+@pytest.mark.parametrize("seed,shape", [(11, (400, 420)), (12, (700, 333)), (13, (1000, 1000))])
+def test_find_map_frontiers_random_maps_beyond_lds(oracle, gpu_ctx, seed, shape):
+    """Grids whose class bytes do not fit LDS take the multi-launch form: classification over the whole device, the flood by one
+    workgroup, the touches collected by all workgroups, the frontiers grown by one wave with an LDS visited set.  Random blob maps
+    have dozens to hundreds of small frontiers (the fallbacks of that form: the next test)."""
+    cells = _blob_map(seed, shape)
+    origin, mpc = _frame(shape)
+    grid = bl.OccupancyGrid.from_cells(cells, origin, mpc, cellsPerMeter=helpers.CPM_DEFAULT, ctx=gpu_ctx)
+    rng = np.random.default_rng(300 + seed)
+    ys, xs = np.nonzero(cells < -5)
+    total = 0
+    for _ in range(3):
+        k = rng.integers(len(xs))
+        rx, ry = float(origin[0]) + (xs[k] + 0.5) * 0.05, float(origin[1]) + (ys[k] + 0.5) * 0.05
+        exp = oracle.find_frontiers(cells, mpc, helpers.CPM_DEFAULT, origin, oracle.pose(rx, ry, 0.0), 0.1)
+        got = bl.find_map_frontiers(grid, bl.make_pose(rx, ry, 0.0), 0.1).cells()
+        _same_frontiers(got, exp)
+        total += len(exp)
+    assert total > 3
+
+
+@pytest.mark.parametrize("S,free", [(2600, 2400), (4400, 4200)])
+def test_find_map_frontiers_one_frontier_larger_than_the_visited_set(oracle, gpu_ctx, S, free):
+    """A free square in unknown space: ONE frontier of 4 x `free` cells.  2400: more cells than the grow kernel's LDS visited set
+    holds (half of 16 384 slots) -- it undoes its marks and the one-workgroup sweep takes over.  4200: more touches (16 800) than
+    the grow kernel keeps -- the one-workgroup sweep from the start.  Same list as the oracle's either way."""
+    cells = np.zeros((S, S), np.int8)
+    cells[100:100 + free, 100:100 + free] = -50
+    origin, mpc = _frame((S, S))
+    grid = bl.OccupancyGrid.from_cells(cells, origin, mpc, cellsPerMeter=helpers.CPM_DEFAULT, ctx=gpu_ctx)
+    rx, ry = float(origin[0]) + 300.5 * 0.05, float(origin[1]) + 1200.5 * 0.05
+    exp = oracle.find_frontiers(cells, mpc, helpers.CPM_DEFAULT, origin, oracle.pose(rx, ry, 0.0), 0.1)
+    got = bl.find_map_frontiers(grid, bl.make_pose(rx, ry, 0.0), 0.1).cells()
+    assert len(exp) == 1 and len(exp[0]) > 8192
+    _same_frontiers(got, exp)
+
+
 def test_find_map_frontiers_cut_reference_map(oracle, maps, gpu_ctx):
     m = maps["obstacle_slam_10mx10m_5cm"]
     cells = m["cells"].copy()
