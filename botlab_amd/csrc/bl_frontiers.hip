@@ -81,7 +81,10 @@ __device__ __forceinline__ int fr_log_odds(const frontier_args& a, int x, int y)
 // All communication is inside ONE workgroup (one CU, one vector L1): __syncthreads() orders plain stores/loads and makes
 // the claim atomics (performed at L2) complete; claim words are read back with L2-scope loads only.
 #define FR_CLS_LDS (96 * 1024)
-#define FR_LQ 2048                // next-level queue entries mirrored in LDS (wider levels are re-read from the global queue)
+#define FR_LQ 4096                // next-level queue entries mirrored in LDS (wider levels are re-read from the global queue)
+#define FR_B 4                    // queue positions per thread in a batched level
+#define FR_CH 8192                // slots of the LDS claim table of a level
+#define FR_CH_PROBES 128           // linear probes after which the table counts as full
 
 // Classification of every cell -- is_frontier_cell (frontiers.cpp:217-246) / free (:77) -- and the reset of the claim words.
 // Independent per cell: for grids whose classes do not fit LDS this runs as its own launch over the whole device in front of
@@ -107,6 +110,89 @@ __global__ __launch_bounds__(256) void k_frontier_classify(frontier_args a)
     for (long long c = (long long)blockIdx.x * 256 + threadIdx.x; c < ncell; c += (long long)gridDim.x * 256) fr_classify(a, a.cls, c);
 }
 
+// One flood level of up to B x 1024 cells on a large grid, with the claims on free cells settled in an LDS table (cell -> smallest
+// key) instead of atomicMin + read-back through L2: one global round trip (the class bytes, every load of the level in flight
+// together) and the closing stores per level instead of three round trips.  Thread t owns the B consecutive queue positions
+// lo + B t ...: thread order = queue order, so one scan places the winners.  A free cell that is still class 1 at the start of a
+// level has never been claimed (every claimed free cell has a winner, and winners become class 4 before the next level starts),
+// so claim[] is only needed for frontier cells -- their first-touch keys, read after the flood.  The table holds one entry per
+// distinct claimed cell (about the size of the next level); returns the size of the next level, or -1 with nothing stored if the
+// table got too crowded (the caller empties it).
+template <int B>
+__device__ __forceinline__ int fr_level_lds(const frontier_args& a, uint8_t* cls, const int* s_cur, int* s_next, int* s_hc, unsigned int* s_hk,
+                                            int* s_wave, int* s_full, int lo, int hi)
+{
+    const int tid = threadIdx.x;
+    int nc[B][4], kk[B][4], slot[B][4];
+#pragma unroll
+    for (int j = 0; j < B; ++j) {
+        const int p = lo + B * tid + j;
+#pragma unroll
+        for (int n = 0; n < 4; ++n) { nc[j][n] = -1; slot[j][n] = -1; }
+        if (p < hi) {
+            int x, y;
+            if (p == 0) { x = a.rx; y = a.ry; } else { const int c = lo > 0 ? s_cur[p - lo] : a.queue[p]; x = c % a.W; y = c / a.W; }
+#pragma unroll
+            for (int n = 0; n < 4; ++n) {
+                const int nx = x + (n == 0 ? -1 : (n == 1 ? 1 : 0)), ny = y + (n == 2 ? 1 : (n == 3 ? -1 : 0));
+                if (nx >= 0 && ny >= 0 && nx < a.W && ny < a.H) nc[j][n] = ny * a.W + nx;
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < B; ++j)
+#pragma unroll
+        for (int n = 0; n < 4; ++n) kk[j][n] = nc[j][n] >= 0 ? (int)cls[nc[j][n]] : 0;
+    bool full = false;
+#pragma unroll
+    for (int j = 0; j < B; ++j)
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+            const unsigned int key = ((unsigned int)(lo + B * tid + j) << 2) | (unsigned int)n;
+            if (kk[j][n] == 2) atomicMin(&a.claim[nc[j][n]], key);                // (harmless if the level is taken again)
+            if (kk[j][n] == 1 && !full) {
+                int sl = (int)(((unsigned int)nc[j][n] * 2654435761u) >> (32 - 13));             // FR_CH = 2^13
+                int probes = 0;
+                while (true) {
+                    const int old_tag = atomicCAS(&s_hc[sl], -1, nc[j][n]);
+                    if (old_tag == nc[j][n] || old_tag == -1) break;
+                    if (B > 1 && ++probes > FR_CH_PROBES) { full = true; break; }    // a table this crowded: give the level up (B = 1: at most half full)
+                    sl = (sl + 1) & (FR_CH - 1);
+                }
+                if (!full) { atomicMin(&s_hk[sl], key); slot[j][n] = sl; }
+            }
+        }
+    if (B > 1 && full) *s_full = 1;
+    __syncthreads();
+    if (B > 1 && *s_full) { __syncthreads(); if (tid == 0) *s_full = 0; return -1; }
+    int wins = 0;
+    unsigned int winmask = 0;
+#pragma unroll
+    for (int j = 0; j < B; ++j)
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+            const bool w = slot[j][n] >= 0 && s_hk[slot[j][n]] == ((((unsigned int)(lo + B * tid + j)) << 2) | (unsigned int)n);
+            winmask |= (w ? 1u : 0u) << (4 * j + n);
+            wins += w ? 1 : 0;
+        }
+    int total;
+    int at = hi + block_excl_scan(wins, s_wave, &total);                            // (its barriers: every thread has read its slots)
+#pragma unroll
+    for (int j = 0; j < B; ++j)
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+            if (slot[j][n] >= 0) { s_hc[slot[j][n]] = -1; s_hk[slot[j][n]] = FR_INF; }       // the table is empty again for the next level
+            if ((winmask >> (4 * j + n)) & 1u) {
+                a.queue[at] = nc[j][n];
+                cls[nc[j][n]] = 4;                                                  // visited
+                if (at - hi < FR_LQ) s_next[at - hi] = nc[j][n];
+                at += 1;
+            }
+        }
+    __syncthreads();
+    return total;
+}
+
 template <bool CLS_LDS>
 __global__ __launch_bounds__(FR_T) void k_frontiers(frontier_args a)
 {
@@ -115,6 +201,10 @@ __global__ __launch_bounds__(FR_T) void k_frontiers(frontier_args a)
     __shared__ int s_wave[FR_T / 64];
     __shared__ unsigned int s_umin[FR_T / 64];
     __shared__ int s_q[2][FR_LQ];
+    // claims of a narrow level (large grids only: the small-grid form spends its LDS on the class bytes)
+    __shared__ int s_hc[CLS_LDS ? 1 : FR_CH];
+    __shared__ unsigned int s_hk[CLS_LDS ? 1 : FR_CH];
+    __shared__ int s_full;
     const int tid = threadIdx.x;
     const long long ncell = (long long)a.W * a.H;
     uint8_t* cls = CLS_LDS ? s_cls : a.cls;
@@ -125,13 +215,85 @@ __global__ __launch_bounds__(FR_T) void k_frontiers(frontier_args a)
     __syncthreads();
     // ---- free-space flood (:47-82), xDeltas {-1,1,0,0}, yDeltas {0,0,1,-1}
     int lo = 0, hi = 1, levels = 0, cur = 0;
+    if (!CLS_LDS) {
+        for (int i = tid; i < FR_CH; i += FR_T) { s_hc[i] = -1; s_hk[i] = FR_INF; }
+        if (tid == 0) s_full = 0;
+        __syncthreads();
+    }
     if (a.phase == 2) {                                     // the flood has run (phase 1): only the sweep, and only when asked for
         if (a.counts[8] == 0) return;
         lo = hi = a.counts[2]; levels = a.counts[3];
     }
     while (lo < hi) {
-        const bool one_pass = hi - lo <= FR_T;              // the common case: this thread's neighbours stay in registers
-        const bool from_lds = hi - lo <= FR_LQ && lo > 0;
+        if (!CLS_LDS && hi - lo <= FR_B * FR_T) {
+            // ---- large grids, levels of up to FR_B x 1024 cells: claims on free cells settled in LDS (fr_level_lds)
+            const int total = hi - lo <= FR_T ? fr_level_lds<1>(a, cls, s_q[cur], s_q[cur ^ 1], s_hc, s_hk, s_wave, &s_full, lo, hi)
+                                              : fr_level_lds<FR_B>(a, cls, s_q[cur], s_q[cur ^ 1], s_hc, s_hk, s_wave, &s_full, lo, hi);
+            if (total >= 0) { lo = hi; hi += total; levels += 1; cur ^= 1; continue; }
+            // the table filled up (a level that claims several times its own size): empty it, take the level through claim[]
+            for (int i = tid; i < FR_CH; i += FR_T) { s_hc[i] = -1; s_hk[i] = FR_INF; }
+            __syncthreads();
+        }
+        if (hi - lo > FR_T && hi - lo <= FR_B * FR_T) {
+            // ---- a level of 1025 .. FR_B x 1024 cells in one batch: thread t owns the FR_B consecutive queue positions lo + FR_B t ...
+            // (thread order = queue order, so one scan places the winners), everything in registers, every load of a phase in
+            // flight together: three global round trips per level whatever its width (the per-position loop below pays them
+            // once per 1024 positions and reads the queue back from memory)
+            const bool from_lds = hi - lo <= FR_LQ && lo > 0;
+            int nc[FR_B][4], kk[FR_B][4];
+#pragma unroll
+            for (int j = 0; j < FR_B; ++j) {
+                const int p = lo + FR_B * tid + j;
+#pragma unroll
+                for (int n = 0; n < 4; ++n) nc[j][n] = -1;
+                if (p < hi) {
+                    int x, y;
+                    if (p == 0) { x = a.rx; y = a.ry; } else { const int c = from_lds ? s_q[cur][p - lo] : a.queue[p]; x = c % a.W; y = c / a.W; }
+#pragma unroll
+                    for (int n = 0; n < 4; ++n) {
+                        const int nx = x + (n == 0 ? -1 : (n == 1 ? 1 : 0)), ny = y + (n == 2 ? 1 : (n == 3 ? -1 : 0));
+                        if (nx >= 0 && ny >= 0 && nx < a.W && ny < a.H) nc[j][n] = ny * a.W + nx;
+                    }
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < FR_B; ++j)
+#pragma unroll
+                for (int n = 0; n < 4; ++n) kk[j][n] = nc[j][n] >= 0 ? (int)cls[nc[j][n]] : 0;
+#pragma unroll
+            for (int j = 0; j < FR_B; ++j)
+#pragma unroll
+                for (int n = 0; n < 4; ++n)
+                    if (kk[j][n] == 1 || kk[j][n] == 2) atomicMin(&a.claim[nc[j][n]], ((unsigned int)(lo + FR_B * tid + j) << 2) | (unsigned int)n);
+            __syncthreads();
+            unsigned int got[FR_B][4];
+#pragma unroll
+            for (int j = 0; j < FR_B; ++j)
+#pragma unroll
+                for (int n = 0; n < 4; ++n) got[j][n] = kk[j][n] == 1 ? ld_claim(&a.claim[nc[j][n]]) : FR_INF;
+            int wins = 0;
+#pragma unroll
+            for (int j = 0; j < FR_B; ++j)
+#pragma unroll
+                for (int n = 0; n < 4; ++n) wins += got[j][n] == ((((unsigned int)(lo + FR_B * tid + j)) << 2) | (unsigned int)n) ? 1 : 0;
+            int total;
+            int at = hi + block_excl_scan(wins, s_wave, &total);
+#pragma unroll
+            for (int j = 0; j < FR_B; ++j)
+#pragma unroll
+                for (int n = 0; n < 4; ++n)
+                    if (got[j][n] == ((((unsigned int)(lo + FR_B * tid + j)) << 2) | (unsigned int)n)) {
+                        a.queue[at] = nc[j][n];
+                        cls[nc[j][n]] = 4;                  // visited: never claimed again (its claim key stays the smallest anyway)
+                        if (at - hi < FR_LQ) s_q[cur ^ 1][at - hi] = nc[j][n];
+                        at += 1;
+                    }
+            __syncthreads();
+            lo = hi; hi += total; levels += 1; cur ^= 1;
+            continue;
+        }
+        const bool one_pass = hi - lo <= FR_T;              // the common case on small maps: this thread's neighbours stay in registers
+        const bool from_lds = hi - lo <= FR_LQ && lo > 0;   // (levels wider than FR_B x 1024: 1024 positions at a time)
         int rc[4], rn = 0; unsigned int rk[4];
         for (int p = lo + tid; p < hi; p += FR_T) {
             int x, y;
