@@ -747,7 +747,8 @@ __device__ __forceinline__ void heap_sift_up(int2* g_heap, int hole, int2 value,
     const int anc = (int)(hp >> (lane + 1)) - 1;
     const int below = (int)(hp >> lane) - 1;            // where this ancestor lands if it drops one level
     int2 e = make_int2(0, 0);
-    if (v) e = IN_LDS ? lds_entry(anc) : heap_read<LDSN>(g_heap, anc);
+    if (IN_LDS) e = lds_entry(v ? anc : 0);               // (unconditional: a clamped index costs less than a branch around the read)
+    else if (v) e = heap_read<LDSN>(g_heap, anc);
     const unsigned long long m = __ballot(v && (e.x > value.x));
     const int t = __ffsll((long long)~m) - 1;           // length of the leading run
     if (IN_LDS) {
@@ -782,14 +783,14 @@ __device__ __forceinline__ void heap_adjust(int2* g_heap, int len, int2 value, i
         const bool two = lane < 31 && cl + 1 < len;     // both children exist
         int2 e = make_int2(0, 0);
         int fl = 0, fr = 0;
-        if (valid) {
-            if (IN_LDS) {
-                e = lds_entry(node);
-                if (two) { fl = lds_entry(cl).x; fr = lds_entry(cl + 1).x; }
-            } else {
-                e = heap_read<LDSN>(g_heap, node);
-                if (two) { fl = heap_read<LDSN>(g_heap, cl).x; fr = heap_read<LDSN>(g_heap, cl + 1).x; }
-            }
+        if (IN_LDS) {
+            // unconditional reads at clamped indices (entry 0 always exists here): no branches around the three loads
+            e = lds_entry(valid ? node : 0);
+            fl = lds_entry(two && valid ? cl : 0).x;
+            fr = lds_entry(two && valid ? cl + 1 : 0).x;
+        } else if (valid) {
+            e = heap_read<LDSN>(g_heap, node);
+            if (two) { fl = heap_read<LDSN>(g_heap, cl).x; fr = heap_read<LDSN>(g_heap, cl + 1).x; }
         }
         // right child preferred unless comp(right, left), i.e. right.fCost > left.fCost; a lone left child -> left
         const unsigned long long M = __ballot(valid && two && !(fr > fl));
