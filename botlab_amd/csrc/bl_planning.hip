@@ -30,7 +30,8 @@ struct bl_dist {
     size_t capacity;          // cells allocated
     uint16_t* row;            // per-row nearest-source distance (0xFFFF: none in row)
     uint16_t* l1;             // L1 distance (0xFFFF: no source anywhere)
-    float* cells;             // float distances handed to callers
+    float* cells;             // float distances handed to callers: f[l1], formed when a caller first asks (floats_valid)
+    bool floats_valid;
     float* lut;               // device f[n]
     int32_t* closed;          // A* closed-cell scratch of this grid (-1 = not closed); cleared by setDistances
     bool closed_clean;        // no search has written closed[] since it was last cleared
@@ -285,7 +286,7 @@ __global__ __launch_bounds__(DCOL_TX * DCOL_TY) void k_dist_cols(dist_batch db, 
         int v = min(f, b);
         bool none = v >= 0xFFFF;
         l1[(size_t)y * W + x] = none ? (uint16_t)0xFFFF : (uint16_t)v;
-        out[(size_t)y * W + x] = none ? -1.0f : lut[v];
+        if (out) out[(size_t)y * W + x] = none ? -1.0f : lut[v];
         closed[(size_t)y * W + x] = -1;                     // the first search on this grid needs no separate clear
     }
 }
@@ -427,7 +428,7 @@ __global__ __launch_bounds__(DC2_TX * DC2_TY) void k_dist_cols_apply(dist_batch 
         const bool n0 = v[0] >= 0xFFFF, n1 = v[1] >= 0xFFFF;
         const size_t at = (size_t)(y0 + i) * W + x;
         *(unsigned int*)(l1 + at) = (n0 ? 0xFFFFu : (unsigned int)v[0]) | ((n1 ? 0xFFFFu : (unsigned int)v[1]) << 16);
-        *(float2*)(out + at) = make_float2(n0 ? -1.0f : lut[v[0]], n1 ? -1.0f : lut[v[1]]);
+        if (out) *(float2*)(out + at) = make_float2(n0 ? -1.0f : lut[v[0]], n1 ? -1.0f : lut[v[1]]);
         *(int2*)(closed + at) = make_int2(-1, -1);           // the first search on this grid needs no separate clear
     }
 }
@@ -457,6 +458,29 @@ extern "C" void bl_dist_destroy(bl_dist* d)
     if (d->lut) (void)hipFree(d->lut);
     delete d->lut_host;
     delete d;
+}
+
+// The float grid the reference's callers see: f[L1 distance], -1 where no source exists.  k_astar reads the integer distances,
+// so a replan never needs it: it is formed when a caller first asks (bl_dist_download, bl_dist_device_ptr, bl_dist_gather) --
+// 4 of the 12 bytes per cell the column pass used to move.
+__global__ __launch_bounds__(256) void k_dist_floats(const uint16_t* __restrict__ l1, const float* __restrict__ lut, float* __restrict__ out, size_t n)
+{
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const int v = l1[i];
+        out[i] = v == 0xFFFF ? -1.0f : lut[v];
+    }
+}
+
+static int dist_floats(bl_dist* d)
+{
+    if (d->floats_valid) return BL_OK;
+    const size_t n = (size_t)d->frame.width * d->frame.height;
+    size_t blocks = (n + 255) / 256;
+    if (blocks > 16384) blocks = 16384;
+    hipLaunchKernelGGL(k_dist_floats, dim3((unsigned int)blocks), dim3(256), 0, d->ctx->stream, d->l1, d->lut, d->cells, n);
+    BL_HIP(hipGetLastError());
+    d->floats_valid = true;
+    return BL_OK;
 }
 
 // resetGrid (obstacle_distance_grid.cpp:100-118) and the scratch a transform of `map` needs; no launch
@@ -521,7 +545,8 @@ static int dist_set_distances_batch(int n, bl_dist* const* ds, const bl_grid* co
         BL_CHECK_ARG(maps[u]->frame.width == W && maps[u]->frame.height == H);
         int rc = dist_prepare(ds[u], maps[u]);
         if (rc) return rc;
-        b.cells[u] = maps[u]->cells; b.row[u] = ds[u]->row; b.l1[u] = ds[u]->l1; b.out[u] = ds[u]->cells; b.lut[u] = ds[u]->lut;
+        b.cells[u] = maps[u]->cells; b.row[u] = ds[u]->row; b.l1[u] = ds[u]->l1; b.out[u] = nullptr; b.lut[u] = ds[u]->lut;
+        ds[u]->floats_valid = false;
         b.closed[u] = ds[u]->closed; b.sum_f[u] = ds[u]->sum_f; b.sum_b[u] = ds[u]->sum_b;
     }
     hipEvent_t e0, e1;
@@ -570,6 +595,7 @@ extern "C" int bl_dist_set_distances(bl_dist* d, const bl_grid* map)
 extern "C" int bl_dist_download(bl_dist* d, float* cells)
 {
     BL_CHECK_ARG(d != nullptr && cells != nullptr && d->valid);
+    { int rc = dist_floats(d); if (rc) return rc; }
     BL_HIP(hipMemcpyAsync(cells, d->cells, (size_t)d->frame.width * d->frame.height * 4, hipMemcpyDeviceToHost, d->ctx->stream));
     BL_HIP(hipStreamSynchronize(d->ctx->stream));
     return BL_OK;
@@ -593,7 +619,12 @@ extern "C" int bl_dist_frame(const bl_dist* d, float* mpc, float* cpm, float* ox
     return BL_OK;
 }
 
-extern "C" void* bl_dist_device_ptr(bl_dist* d) { return d ? (void*)d->cells : nullptr; }
+extern "C" void* bl_dist_device_ptr(bl_dist* d)
+{
+    if (!d || !d->valid) return d ? (void*)d->cells : nullptr;
+    if (dist_floats(d) != BL_OK) return nullptr;
+    return (void*)d->cells;
+}
 
 // =============================================================================================== A*
 #define ASTAR_INVALID_COST INT32_MIN
@@ -1495,6 +1526,8 @@ extern "C" int bl_dist_gather(bl_dist* d, const int32_t* xy_cells, int n, float*
     bl_ctx* ctx = d->ctx;
     BL_HIP(hipSetDevice(ctx->device));
     int rc = astar_prepare(ctx, d);
+    if (rc) return rc;
+    rc = dist_floats(d);
     if (rc) return rc;
     bl_astar_state* s = ctx->astar;
     if (s->g_cap < n) {

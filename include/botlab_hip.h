@@ -183,7 +183,7 @@ int bl_dist_set_distances(bl_dist* d, const bl_grid* map);                /* set
 int bl_dist_download(bl_dist* d, float* cells);                           /* width*height floats (synchronises) */
 int bl_dist_shape(const bl_dist* d, int* width, int* height);
 int bl_dist_frame(const bl_dist* d, float* meters_per_cell, float* cells_per_meter, float* origin_x, float* origin_y);
-void* bl_dist_device_ptr(bl_dist* d);                                     /* float* in HBM */
+void* bl_dist_device_ptr(bl_dist* d);                                     /* float* in HBM (the float grid is formed on the first request after a setDistances) */
 
 /* ------------------------------------------------------------------ search_for_path  (src/planning/astar.hpp:58-61, astar.cpp:9-274)
  * out_path[0] is always the start pose; *out_len == 1 means "no path" (lcmtypes/robot_path_t.lcm:7).  If the path is
