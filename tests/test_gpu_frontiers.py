@@ -88,6 +88,35 @@ def test_find_map_frontiers_random_maps_beyond_lds(oracle, gpu_ctx, seed, shape)
     assert total > 3
 
 
+@pytest.mark.parametrize("case", ["all_free", "all_unknown", "robot_outside", "robot_on_unknown", "robot_on_frontier_value", "walls_only"])
+def test_find_map_frontiers_degenerate_maps_beyond_lds(oracle, gpu_ctx, case):
+    """The multi-launch form on maps that have no frontier at all, no free space at all, or a robot that does not stand in free
+    space (the flood then starts from a cell it may not enter): same lists (mostly empty) as the oracle's."""
+    shape = (700, 1000)
+    origin, mpc = _frame(shape)
+    cells = np.zeros(shape, np.int8)
+    rx, ry = 0.0, 0.0
+    if case == "all_free":
+        cells[:] = -60
+    elif case == "walls_only":
+        cells[:] = 80
+    elif case == "robot_outside":
+        cells[100:600, 100:900] = -60
+        rx, ry = float(origin[0]) - 3.0, 0.0
+    elif case == "robot_on_unknown":
+        cells[100:600, 100:900] = -60
+        rx, ry = float(origin[0]) + 50.5 * 0.05, float(origin[1]) + 350.5 * 0.05          # in the unknown margin, next to nothing
+    elif case == "robot_on_frontier_value":
+        cells[100:600, 100:900] = -60
+        cells[350, 99] = -3                                                                  # a weak cell on the rim: class "frontier"
+        rx, ry = float(origin[0]) + 99.5 * 0.05, float(origin[1]) + 350.5 * 0.05
+    grid = bl.OccupancyGrid.from_cells(cells, origin, mpc, cellsPerMeter=helpers.CPM_DEFAULT, ctx=gpu_ctx)
+    for min_len in (0.1, 0.35):
+        exp = oracle.find_frontiers(cells, mpc, helpers.CPM_DEFAULT, origin, oracle.pose(rx, ry, 0.0), min_len)
+        got = bl.find_map_frontiers(grid, bl.make_pose(rx, ry, 0.0), min_len).cells()
+        _same_frontiers(got, exp)
+
+
 @pytest.mark.parametrize("S,free", [(2600, 2400), (4400, 4200)])
 def test_find_map_frontiers_one_frontier_larger_than_the_visited_set(oracle, gpu_ctx, S, free):
     """A free square in unknown space: ONE frontier of 4 x `free` cells.  2400: more cells than the grow kernel's LDS visited set
