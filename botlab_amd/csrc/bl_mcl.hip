@@ -57,7 +57,7 @@ struct bl_pf {
     bool use_lds;
     int last_blocks, last_tile;   // launch shape of the last k_mcl_main
     int last_main_blocks, last_main_particles, last_tail_tile;
-    bool fused_finish, no_fused_finish, no_packed, no_balance, no_framed, no_window, no_fast_trig, no_mirror_reuse;
+    bool fused_finish, no_fused_finish, no_packed, no_balance, no_framed, no_window, no_fast_trig, no_mirror_reuse, no_stage_dma;
     int window_override;          // window side in cells (0: from the scan's reach)
     int cus;                      // compute units of the device
     int split_log2_override;  // -1: automatic
@@ -422,6 +422,7 @@ struct mcl_args {
     int pk_ok;                    // grid and scan admit the packed 16-bit scoring path (see score_ray_pk)
     int theta_simple;             // every theta of the scan lies in [0, 6.2831] (see wrap_to_pi_cells)
     int fast_trig;                // hardware sine / cosine with a guard band and the exact path behind it (ray_cells_fast)
+    int stage_dma;                // whole-grid staging by LDS-DMA (rows of whole dwords, at most 64 of them)
     float max_range_cells;        // longest kept ray in cells
     int main_blocks, main_particles;   // region 1: main_blocks workgroups cover particles [0, main_particles) of the shard
 };
@@ -579,6 +580,20 @@ __device__ __forceinline__ void stage_rows(int* s_map32, int rows, int wq, int q
 // and the same P threads write the particle and feed the partial sums after the ray loop.  (With every lane of a group
 // repeating the prologue, as the first form of this kernel did, a wave spent a quarter of its instructions outside the ray
 // loop; the kernel is VALU-bound.)
+#ifdef MCL_STAMPS
+// diagnostic build: per workgroup, the 100 MHz clock at entry, behind the first barrier, behind the ray loop and at the end
+__device__ unsigned long long g_mcl_stamps[4096 * 8];
+#define MCL_STAMP(k) do { if (threadIdx.x == 0 && blockIdx.x < 4096) g_mcl_stamps[blockIdx.x * 8 + (k)] = wall_clock64(); } while (0)
+#define MCL_STAMP_T(k, T) do { if ((int)threadIdx.x == (T) && blockIdx.x < 4096) g_mcl_stamps[blockIdx.x * 8 + (k)] = wall_clock64(); } while (0)
+extern "C" int bl_debug_mcl_stamps(unsigned long long* out, int n)
+{
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_mcl_stamps), (size_t)n * 8 * 8) == hipSuccess ? 0 : 1;
+}
+#else
+#define MCL_STAMP(k) do { } while (0)
+#define MCL_STAMP_T(k, T) do { } while (0)
+#endif
+
 template <int INTERP, int BLOCK, int MAP_MODE>
 __global__ __launch_bounds__(BLOCK) void k_mcl_main(mcl_args a)
 {
@@ -595,6 +610,7 @@ __global__ __launch_bounds__(BLOCK) void k_mcl_main(mcl_args a)
     map_window win = {0, 0, 0, 0, 0};
     const int tid = (int)threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    MCL_STAMP(0);
 
     // Two regions in one launch (see "Whole rounds" in pf_launch_main): workgroups [0, main_blocks) take BLOCK >> split_log2
     // particles each, 2^split_log2 lanes per particle; the workgroups after them take the remaining particles one per
@@ -651,7 +667,28 @@ __global__ __launch_bounds__(BLOCK) void k_mcl_main(mcl_args a)
             // the whole grid as a framed image: rows -MCL_FRAME..H+MCL_FRAME-1, columns -4..stride-5 (zeros outside)
             const int wq = win.stride >> 2;
             const int rows = a.frame.height + 2 * MCL_FRAME;
-            if ((a.frame.width & 3) == 0) {
+            if ((a.frame.width & 3) == 0 && (a.frame.width >> 2) <= 64 && a.stage_dma) {
+                // Rows of up to 64 dwords by LDS-DMA: one global_load_lds_dword per row (lane = dword column; the wave-uniform
+                // destination is the row's first data dword), no register between the load and LDS, so EVERY row of a wave
+                // is in flight at once -- the register-staged form below keeps six rows per wave in flight and took 8 us of a
+                // workgroup's first 11 (tests/tools/mcl_timeline_probe.py); more rows in flight there cost registers the
+                // ray loop needs.  Frame rows and the two frame columns are plain zero stores.  The barrier behind the
+                // prologue waits for the DMAs (hipcc drains vmcnt in front of it).
+                const int wdw = a.frame.width >> 2;
+                const int H = a.frame.height;
+                for (int ry = sw; ry < rows; ry += n_sw) {
+                    const int y = ry - MCL_FRAME;
+                    int* row = s_map32 + ry * wq;
+                    if (y < 0 || y >= H) {
+                        for (int q = lane; q < wq; q += 64) row[q] = 0;
+                    } else {
+                        if (lane == 0) { row[0] = 0; row[wdw + 1] = 0; }
+                        if (lane < wdw)
+                            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)((const int*)a.cells + (size_t)y * wdw + lane),
+                                                             (__attribute__((address_space(3))) void*)(row + 1), 4, 0, 0);
+                    }
+                }
+            } else if ((a.frame.width & 3) == 0) {
                 const int wdw = a.frame.width >> 2;
                 const int* cells32 = (const int*)a.cells;
                 const int H = a.frame.height;
@@ -677,10 +714,17 @@ __global__ __launch_bounds__(BLOCK) void k_mcl_main(mcl_args a)
             const int wq = win.w >> 2, fq = a.framed_stride >> 2;
             const int* f32 = (const int*)(a.framed - MCL_FRAME * a.framed_stride - 4);   // first row, column -4 of the framed image
             const int* org = f32 + (size_t)(win.y0 + MCL_FRAME) * fq + ((win.x0 + 4) >> 2);
+            if (wq <= 64 && a.stage_dma) {                          // the window lies inside the mirror: every row by LDS-DMA (see mode 1)
+                if (lane < wq)
+                    for (int ry = sw; ry < win.h; ry += n_sw)
+                        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(org + (size_t)ry * fq + lane),
+                                                         (__attribute__((address_space(3))) void*)(s_map32 + ry * wq), 4, 0, 0);
+            } else
             stage_rows(s_map32, win.h, wq, 0, wq, sw, n_sw, lane, [&](int ry) -> const int* { return org + (size_t)ry * fq; });
         }
     }
 
+    MCL_STAMP_T(4, pw * 64);                                     // a staging wave is through
     // ---- phase 1b: per-particle prologue
     double t_units = 0, t_x = 0, t_y = 0, t_s = 0, t_c = 0;
     int i = mp;
@@ -693,8 +737,10 @@ __global__ __launch_bounds__(BLOCK) void k_mcl_main(mcl_args a)
         if (pro_active) { rs_T = a.r + mp * a.M_inv; if (!a.strict) rs_T *= a.state->S; }      // U (particle_filter.cpp:95), or U * S
         resample_bracket(a.prefix, a.N, rs_T, pro_active, lane, &rs_lo, &rs_hi, a.strict != 0);
     }
+    MCL_STAMP(5);                                                // the bracket is known
     if (pro_active) {
         if (a.resample) i = resample_bisect(a.prefix, rs_T, rs_lo, rs_hi, a.strict != 0);
+        MCL_STAMP(6);
         s = a.src[i];
         // ---- ActionModel::applyAction (action_model.cpp:78-103)
         float n1, n2, n3;
@@ -718,8 +764,10 @@ __global__ __launch_bounds__(BLOCK) void k_mcl_main(mcl_args a)
     // guard-band offset of the fast trig path for this particle: 2.04 u times a bound on its cell coordinates (ray_cells_fast)
     const float trig_reach = 2.0f * a.max_range_cells + 8.0f;
     const float k2_own = 1.2159e-7f * (__builtin_fmaxf(__builtin_fabsf(sx0), __builtin_fabsf(sy0)) + trig_reach);
+    MCL_STAMP(7);                                                // prologue arithmetic done
     if (shared_pro && tid < P) s_pp[tid] = make_float4(pth, sx0, sy0, k2_own);
     __syncthreads();                                            // map, ray table and particle table are in place
+    MCL_STAMP(1);
 
     // what the ray loop needs of this lane's particle
     float r_pth = pth, r_sx0 = sx0, r_sy0 = sy0, trig_k2 = k2_own;
@@ -792,6 +840,7 @@ __global__ __launch_bounds__(BLOCK) void k_mcl_main(mcl_args a)
             }
         }
     }
+    MCL_STAMP(2);
     if (active)
         for (int off = split >> 1; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);     // exact integer sum over the group
     if (shared_pro) {
@@ -826,6 +875,7 @@ __global__ __launch_bounds__(BLOCK) void k_mcl_main(mcl_args a)
         for (int w = 0; w < nred; ++w) v += s_part[w][tid];
         a.partials[(size_t)blockIdx.x * 5 + tid] = v;
     }
+    MCL_STAMP(3);
 }
 
 // ---------------------------------------------------------------- weight-unit prefix scan over all N from the record (2 launches)
@@ -1154,6 +1204,7 @@ extern "C" int bl_pf_create(bl_ctx* ctx, int num_particles, int shard_lo, int sh
     pf->no_balance = getenv("BOTLAB_MCL_NO_BALANCE") != nullptr;
     pf->no_framed = getenv("BOTLAB_MCL_NO_FRAMED") != nullptr;
     pf->no_mirror_reuse = getenv("BOTLAB_MCL_NO_MIRROR_REUSE") != nullptr;
+    pf->no_stage_dma = getenv("BOTLAB_MCL_NO_STAGE_DMA") != nullptr;
     pf->no_window = getenv("BOTLAB_MCL_NO_WINDOW") != nullptr;
     pf->no_fast_trig = getenv("BOTLAB_MCL_NO_FAST_TRIG") != nullptr;
     pf->window_override = getenv("BOTLAB_MCL_WINDOW") ? atoi(getenv("BOTLAB_MCL_WINDOW")) : 0;
@@ -1408,6 +1459,7 @@ static int pf_launch_main(bl_pf* pf, const bl_grid* map, int R, int rand_value, 
     a.theta_simple = ctx->scan.thetas_simple ? 1 : 0;
     a.max_range_cells = map ? ctx->scan.max_range * a.frame.cpm : 0.0f;
     a.fast_trig = (a.theta_simple && !pf->no_fast_trig) ? 1 : 0;
+    a.stage_dma = pf->no_stage_dma ? 0 : 1;
     a.pk_ok = (map && a.frame.width <= 8192 && a.frame.height <= 8192 && ctx->scan.max_range * a.frame.cpm <= 4000.0f &&
                !pf->no_packed) ? 1 : 0;
     // Where the gathers go.  Mode 1: the whole grid, zero-framed, staged in LDS by every workgroup (grids up to 64 KB).
