@@ -840,6 +840,65 @@ __device__ __forceinline__ void heap_adjust(int2* g_heap, int len, int2 value, i
     heap_sift_up<IN_LDS, LDSN>(g_heap, hole, value, lane);
 }
 
+// std::__adjust_heap as ONE pass for heaps with levels outside LDS.  heap_adjust above moves every entry on the walk up one
+// level and then lets heap_sift_up pull the lowest t of them down again -- two rounds of stores, a fence between them (the
+// sift-up re-reads what the walk has just written, from memory that is not coherent within the wave without it) and a second
+// read of the same entries: four global round trips per pop once the walk leaves the LDS levels.  Here the walk stores nothing:
+// every round notes the entries it passes in a small LDS array indexed by heap level (s_path[j] = the old entry of the walk's
+// node at level j); the climb is decided on that array (the ancestors' "new" entries are exactly s_path[k], s_path[k-1], ...),
+// and only the net result is written: the walk's nodes above the landing level take their child's old entry, the landing node
+// takes `value`, the nodes below keep theirs.  Same final heap, entry for entry; two global round trips (the last round's loads,
+// the closing stores' fence).
+template <int LDSN>
+__device__ __forceinline__ void heap_adjust_fused(int2* g_heap, int len, int2 value, int lane, int lk, int ljm1,
+                                                  unsigned long long amask, unsigned long long areq, volatile lds_ll_t* s_path)
+{
+    int hole = 0;
+    while (true) {
+        const int hp = hole + 1;
+        const int node = (hp << lk) + ljm1;
+        const bool valid = lane < 63 && node < len;
+        const int cl = 2 * node + 1;
+        const bool two = lane < 31 && cl + 1 < len;     // both children exist
+        // the three reads of a lane, issued together: LDS at clamped indices, and for nodes past the LDS levels the global
+        // loads back to back (one heap_read after the other waits for each load before it issues the next)
+        const bool vt = valid && two;
+        int2 e = lds_entry(valid && node < LDSN ? node : LDSN);
+        int fl = lds_entry(vt && cl < LDSN ? cl : LDSN).x, fr = lds_entry(vt && cl + 1 < LDSN ? cl + 1 : LDSN).x;
+        int2 eg = make_int2(0, 0), flg = make_int2(0, 0), frg = make_int2(0, 0);
+        if (valid && node >= LDSN) eg = g_heap[node];
+        if (vt && cl >= LDSN) flg = g_heap[cl];
+        if (vt && cl + 1 >= LDSN) frg = g_heap[cl + 1];
+        if (valid && node >= LDSN) e = eg;
+        if (vt && cl >= LDSN) fl = flg.x;
+        if (vt && cl + 1 >= LDSN) fr = frg.x;
+        const unsigned long long M = __ballot(valid && two && !(fr > fl));
+        const bool on_path = valid && (((M ^ areq) & amask) == 0ull);
+        const unsigned long long P = __ballot(on_path);
+        const int cur = 63 - __clzll((long long)P);     // deepest on-path lane
+        if (on_path) s_path[31 - __clz(node + 1)] = ((long long)(unsigned int)e.x) | ((long long)e.y << 32);
+        hole = __builtin_amdgcn_readlane(node, cur);
+        if (!(cur >= 31 && 2 * hole + 1 < len)) break;
+    }
+    __builtin_amdgcn_wave_barrier();
+    // the climb (std::__push_heap from the leaf): lane a looks at the ancestor a + 1 levels above the hole, whose entry after
+    // the walk would be the old entry of the walk's node one level below it
+    const unsigned int hpf = (unsigned int)hole + 1u;
+    const int k = 31 - __clz(hpf);                      // level of the leaf = number of ancestors
+    const bool v = lane < k;
+    long long raw = 0;
+    if (v) raw = s_path[k - lane];
+    const int ex = (int)(raw & 0xffffffffll);
+    const unsigned long long m = __ballot(v && (ex > value.x));
+    const int t = __ffsll((long long)~m) - 1;           // ancestors that end up where they were
+    // net stores: the walk's node at level j < k - t takes s_path[j + 1] (lane a holds s_path[k - a], whose new home is the
+    // node a + 1 levels above the leaf); the node at level k - t takes `value`; the t nodes below keep their entries
+    if (v && lane >= t) heap_write<LDSN>(g_heap, (int)(hpf >> (lane + 1)) - 1, make_int2(ex, (int)(raw >> 32)));
+    if (lane == 0) heap_write<LDSN>(g_heap, (int)(hpf >> t) - 1, value);
+    __threadfence_block();
+    __builtin_amdgcn_wave_barrier();
+}
+
 // One wavefront runs the reference's search loop (astar.cpp:75-135) with libstdc++'s heap operations executed
 // cooperatively; lanes 0..3 evaluate the four neighbours of the popped node, lane 4 re-derives its gCost.
 // Closed cells: closed[] is written with a no-return atomic compare-and-swap (first closing wins) and read with
@@ -862,6 +921,7 @@ __global__ __launch_bounds__(64) void k_astar(astar_args a)
         a.host_out = nullptr; a.slot_path = nullptr; a.slot_path_cap = 0;
     }
     int2* g_heap = a.heap;
+    __shared__ long long s_path[40];                    // heap_adjust_fused: the entries a walk passes, by heap level
     const int lane = threadIdx.x;
     __builtin_amdgcn_s_setprio(3);          // a lone latency-bound wave: win issue arbitration against co-resident kernels
     astar_result res; res.status = ASTAR_ST_NOPATH; res.path_len = 0; res.pops = 0; res.pushes = 0;
@@ -939,7 +999,7 @@ __global__ __launch_bounds__(64) void k_astar(astar_args a)
                 heap_adjust<true, LDSN>(g_heap, len, value, lane, lk, lj - 1, amask, areq);
             } else {
                 const int2 value = heap_read<LDSN>(g_heap, len);
-                heap_adjust<false, LDSN>(g_heap, len, value, lane, lk, lj - 1, amask, areq);
+                heap_adjust_fused<LDSN>(g_heap, len, value, lane, lk, lj - 1, amask, areq, (volatile lds_ll_t*)s_path);
             }
         }
         STAMP(ta);
