@@ -391,6 +391,7 @@ def main():
 
     host_t = [0.0, 0.0]
     step_wall = []
+    trace_every = int(os.environ.get("BENCH_TRACE_RATE", "0"))
 
     def step(k):
         # software pipeline of depth args.depth: step k is enqueued before the result of step k - depth is fetched, so the
@@ -405,6 +406,8 @@ def main():
         host_t[0] += t1 - t0
         host_t[1] += t2 - t1
         step_wall.append((t2 - t0, k, t1 - t0))
+        if trace_every and k % trace_every == 0:            # BENCH_TRACE_RATE=<steps>: where a long run spends its time
+            sys.stderr.write(f"[bench] step {k}: enqueue {host_t[0]:.3f} s, fetch {host_t[1]:.3f} s so far\n")
         return last
 
     def drain():
