@@ -33,8 +33,9 @@ struct bl_dist {
     float* cells;             // float distances handed to callers: f[l1], formed when a caller first asks (floats_valid)
     bool floats_valid;
     float* lut;               // device f[n]
-    int32_t* closed;          // A* closed-cell scratch of this grid (-1 = not closed); cleared by setDistances
-    bool closed_clean;        // no search has written closed[] since it was last cleared
+    int32_t* closed;          // A* closed-cell scratch of this grid: (generation << 3) | move code; an entry of another generation
+                              // than the running search's is "not closed" -- no clearing between searches (k_astar)
+    uint32_t closed_gen;      // generation of the last search launched on this grid (0: none yet; the array starts zeroed)
     int* sum_f; int* sum_b; size_t sum_cap;   // per macro strip and column: chain summaries of the large-grid column pass
     int lut_n;
     std::vector<float>* lut_host;
@@ -237,7 +238,6 @@ __global__ __launch_bounds__(DCOL_TX * DCOL_TY) void k_dist_cols(dist_batch db, 
     uint16_t* __restrict__ l1 = db.l1[blockIdx.z];
     float* __restrict__ out = db.out[blockIdx.z];
     const float* __restrict__ lut = db.lut[blockIdx.z];
-    int32_t* __restrict__ closed = db.closed[blockIdx.z];
     __shared__ int s_fwd[DCOL_TY][DCOL_TX];
     __shared__ int s_bwd[DCOL_TY][DCOL_TX];
     const int tx = threadIdx.x, ty = threadIdx.y;
@@ -287,7 +287,6 @@ __global__ __launch_bounds__(DCOL_TX * DCOL_TY) void k_dist_cols(dist_batch db, 
         bool none = v >= 0xFFFF;
         l1[(size_t)y * W + x] = none ? (uint16_t)0xFFFF : (uint16_t)v;
         if (out) out[(size_t)y * W + x] = none ? -1.0f : lut[v];
-        closed[(size_t)y * W + x] = -1;                     // the first search on this grid needs no separate clear
     }
 }
 
@@ -368,7 +367,6 @@ __global__ __launch_bounds__(DC2_TX * DC2_TY) void k_dist_cols_apply(dist_batch 
     uint16_t* __restrict__ l1 = db.l1[blockIdx.z];
     float* __restrict__ out = db.out[blockIdx.z];
     const float* __restrict__ lut = db.lut[blockIdx.z];
-    int32_t* __restrict__ closed = db.closed[blockIdx.z];
     __shared__ int s_f[DC2_TY][2 * DC2_TX];
     __shared__ int s_b[DC2_TY][2 * DC2_TX];
     const int tx = threadIdx.x, ty = threadIdx.y;
@@ -429,7 +427,6 @@ __global__ __launch_bounds__(DC2_TX * DC2_TY) void k_dist_cols_apply(dist_batch 
         const size_t at = (size_t)(y0 + i) * W + x;
         *(unsigned int*)(l1 + at) = (n0 ? 0xFFFFu : (unsigned int)v[0]) | ((n1 ? 0xFFFFu : (unsigned int)v[1]) << 16);
         if (out) *(float2*)(out + at) = make_float2(n0 ? -1.0f : lut[v[0]], n1 ? -1.0f : lut[v[1]]);
-        *(int2*)(closed + at) = make_int2(-1, -1);           // the first search on this grid needs no separate clear
     }
 }
 
@@ -501,6 +498,8 @@ static int dist_prepare(bl_dist* d, const bl_grid* map)
         BL_HIP(hipMalloc((void**)&d->l1, n * 2));
         BL_HIP(hipMalloc((void**)&d->cells, n * 4));
         BL_HIP(hipMalloc((void**)&d->closed, n * 4));
+        BL_HIP(hipMemsetAsync(d->closed, 0, n * 4, ctx->stream));           // generation 0: nothing closed
+        d->closed_gen = 0;
         d->capacity = n;
     }
     d->frame = map->frame;
@@ -582,7 +581,7 @@ static int dist_set_distances_batch(int n, bl_dist* const* ds, const bl_grid* co
     BL_HIP(hipGetLastError());
     rc = bl_timer_end(ctx, BL_K_DIST, e0, e1);
     if (rc) return rc;
-    for (int u = 0; u < n; ++u) { ds[u]->closed_clean = true; ds[u]->valid = true; }
+    for (int u = 0; u < n; ++u) ds[u]->valid = true;
     return BL_OK;
 }
 
@@ -705,13 +704,14 @@ struct astar_unit {
     const bl_pose_xyt_t* start_dev; bl_pose_xyt_t start_host; int sx, sy, gx, gy;
     char* host_out; int32_t* slot_path;
     int cost_n;
+    unsigned int closed_gen;
 };
 
 struct astar_args {
     const uint16_t* l1; int W, H;
     const int32_t* cost_lut; int cost_n;   // per L1 distance min(n, cost_n - 1): obstacle cost, or ASTAR_INVALID_COST if the cell is not valid
     int2* heap; int heap_cap;
-    int32_t* closed;
+    int32_t* closed; unsigned int closed_gen;     // closed cells: entries of generation closed_gen, (closed_gen << 3) | move
     int32_t* path; long long path_cap;
     int32_t* slot_path; long long slot_path_cap; int path_head;      // per-result-slot copy of the path; cells that go to host_out
     astar_result* result;
@@ -901,7 +901,8 @@ __device__ __forceinline__ void heap_adjust_fused(int2* g_heap, int len, int2 va
 
 // One wavefront runs the reference's search loop (astar.cpp:75-135) with libstdc++'s heap operations executed
 // cooperatively; lanes 0..3 evaluate the four neighbours of the popped node, lane 4 re-derives its gCost.
-// Closed cells: closed[] is written with a no-return atomic compare-and-swap (first closing wins) and read with
+// Closed cells: closed[] holds (generation << 3) | move; an entry of this search's generation is written once (first closing wins:
+// lane 4 loads the popped cell's own entry with the neighbours') and read with
 // L1-bypassing loads, so no lane ever waits on the closing store of the popped cell.
 template <int LDSN, int COSTN>
 __global__ __launch_bounds__(64) void k_astar(astar_args a)
@@ -910,7 +911,7 @@ __global__ __launch_bounds__(64) void k_astar(astar_args a)
         const astar_unit u = a.units[blockIdx.x];
         a.l1 = u.l1; a.cost_lut = u.cost_lut; a.heap = u.heap; a.closed = u.closed; a.path = u.path; a.result = u.result;
         a.start_dev = u.start_dev; a.start_host = u.start_host; a.sx = u.sx; a.sy = u.sy; a.gx = u.gx; a.gy = u.gy;
-        a.host_out = u.host_out; a.slot_path = u.slot_path; a.cost_n = u.cost_n;
+        a.host_out = u.host_out; a.slot_path = u.slot_path; a.cost_n = u.cost_n; a.closed_gen = u.closed_gen;
     }
     if (a.batch_goals) {
         const long long b = blockIdx.x;
@@ -988,8 +989,6 @@ __global__ __launch_bounds__(64) void k_astar(astar_args a)
         int my_l1, my_closed;
         asm volatile("global_load_ushort %0, %2, off\n\tglobal_load_dword %1, %3, off sc1"
                      : "=&v"(my_l1), "=&v"(my_closed) : "v"(l1_addr), "v"(cl_addr) : "memory");
-        // closedList.push_back(nNode): only the first entry per cell is ever observed (is_member / get_member)
-        if (lane == 0) atomicCAS(&a.closed[cy * a.W + cx], -1, res.pops == 0 ? 4 : tdir);
         // ---- openList.pop(): std::pop_heap + pop_back
         STAMP(t1);
         len -= 1;
@@ -1004,8 +1003,12 @@ __global__ __launch_bounds__(64) void k_astar(astar_args a)
         }
         STAMP(ta);
         asm volatile("s_waitcnt vmcnt(0)" : "+v"(my_l1), "+v"(my_closed) :: "memory");
-        if (!inb) { my_l1 = 0xFFFF; my_closed = -1; }
-        if (lane >= 4) my_closed = -1;
+        // closedList.push_back(nNode): only the first entry per cell is ever observed (is_member / get_member).  Lane 4 has
+        // loaded the popped cell's own entry: it is closed now unless an earlier pop of this search closed it
+        if (lane == 4 && inb && ((unsigned int)my_closed >> 3) != a.closed_gen)
+            a.closed[cy * a.W + cx] = (int)((a.closed_gen << 3) | (unsigned int)(res.pops == 0 ? 4 : tdir));
+        const bool nclosed = inb && lane < 4 && ((unsigned int)my_closed >> 3) == a.closed_gen;
+        if (!inb) my_l1 = 0xFFFF;
         STAMP(t2);
         res.pops += 1;
         // ---- the four neighbours, one per lane (expand_node order is the lane order, astar.cpp:213-233)
@@ -1026,7 +1029,7 @@ __global__ __launch_bounds__(64) void k_astar(astar_args a)
         const int f = tg + 10 + hc + (nvalid ? my_cost : 0);                    // get_gCost: 4-connected step
         const unsigned int goal_m = (unsigned int)__ballot(nvalid && nx == a.gx && ny == a.gy);
         // a valid neighbour is pushed unless it is closed (:123) or fNew >= INT16_MAX (:103,124)
-        unsigned int push_m = (unsigned int)__ballot(nvalid && my_closed < 0 && 32767 > f);
+        unsigned int push_m = (unsigned int)__ballot(nvalid && !nclosed && 32767 > f);
         const int ey = (ny << 17) | (nx << 2) | lane;
         if (goal_m) push_m &= (goal_m & (0u - goal_m)) - 1u;                    // neighbours before the goal neighbour only
         STAMP(tb);
@@ -1054,8 +1057,9 @@ __global__ __launch_bounds__(64) void k_astar(astar_args a)
                     if (a.host_out && n < a.path_head) ((int32_t*)(a.host_out + ASTAR_HDR))[n] = cell;
                     n += 1;
                     cell = parent;
-                    int d = __hip_atomic_load(&a.closed[cell], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if (d < 0 || d >= 4) break;                                 // reached the start entry
+                    const unsigned int cw = (unsigned int)__hip_atomic_load(&a.closed[cell], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const int d = (cw >> 3) == a.closed_gen ? (int)(cw & 7u) : 4;
+                    if (d >= 4) break;                                          // reached the start entry
                     parent = cell - (d == 0 ? 1 : (d == 1 ? -1 : (d == 2 ? a.W : -a.W)));
                 }
                 res.path_len = (int)n;
@@ -1233,7 +1237,6 @@ static int astar_fill(bl_ctx* ctx, const bl_dist* d, const bl_pose_xyt_t* start,
     }
     rc = astar_prepare_lut(ctx, d, params);
     if (rc) return rc;
-    const int ln = d->frame.width + d->frame.height + 1;
     astar_args& a = *out;
     a.l1 = d->l1; a.W = d->frame.width; a.H = d->frame.height;
     a.cost_lut = s->cost_lut; a.cost_n = s->lut_eff;
@@ -1257,8 +1260,11 @@ static int astar_fill(bl_ctx* ctx, const bl_dist* d, const bl_pose_xyt_t* start,
     }
     a.max_pops = 1ll << 31;
     bl_dist* dm = const_cast<bl_dist*>(d);           // closed[] is search scratch that travels with the grid
-    if (!dm->closed_clean) BL_HIP(hipMemsetAsync(dm->closed, 0xFF, (size_t)a.W * a.H * 4, ctx->stream));
-    dm->closed_clean = false;
+    if (++dm->closed_gen >= (1u << 28)) {            // (a wrap every 2.7e8 searches: start over from a zeroed array)
+        BL_HIP(hipMemsetAsync(dm->closed, 0, (size_t)a.W * a.H * 4, ctx->stream));
+        dm->closed_gen = 1;
+    }
+    a.closed_gen = dm->closed_gen;
     return BL_OK;
 }
 
@@ -1328,7 +1334,7 @@ static int astar_launch_units(int n, bl_ctx* const* ctxs, bl_dist* const* dists,
         astar_unit& u = units[b];
         u.l1 = a.l1; u.cost_lut = a.cost_lut; u.heap = a.heap; u.closed = a.closed; u.path = a.path; u.result = a.result;
         u.start_dev = a.start_dev; u.start_host = a.start_host; u.sx = a.sx; u.sy = a.sy; u.gx = a.gx; u.gy = a.gy;
-        u.host_out = a.host_out; u.slot_path = a.slot_path; u.cost_n = a.cost_n;
+        u.host_out = a.host_out; u.slot_path = a.slot_path; u.cost_n = a.cost_n; u.closed_gen = a.closed_gen;
     }
     a.units = units;
     bl_ctx* ctx = ctxs[0];
@@ -1501,13 +1507,13 @@ static int astar_batch_cells(bl_ctx* ctx, const bl_dist* d, const bl_pose_xyt_t*
         const int m = (n - base) < s->b_cap ? (n - base) : s->b_cap;
         memcpy(s->hb_goals, goals + base, (size_t)m * sizeof(int2));
         BL_HIP(hipMemcpyAsync(s->b_goals, s->hb_goals, (size_t)m * sizeof(int2), hipMemcpyHostToDevice, ctx->stream));
-        BL_HIP(hipMemsetAsync(s->b_closed, 0xFF, (size_t)m * cells * 4, ctx->stream));
+        BL_HIP(hipMemsetAsync(s->b_closed, 0, (size_t)m * cells * 4, ctx->stream));
         BL_HIP(hipMemsetAsync(s->b_cursor, 0, 8, ctx->stream));
         astar_args a;
         a.l1 = d->l1; a.W = d->frame.width; a.H = d->frame.height;
         a.cost_lut = s->cost_lut; a.cost_n = s->lut_eff;
         a.heap = s->b_heap; a.heap_cap = (int)s->b_heap_each;
-        a.closed = s->b_closed;
+        a.closed = s->b_closed; a.closed_gen = 1;
         a.path = s->b_path; a.path_cap = (long long)s->b_path_each;
         a.slot_path = nullptr; a.slot_path_cap = 0; a.path_head = 0; a.host_out = nullptr;
         a.result = (astar_result*)s->b_results;
