@@ -40,13 +40,16 @@ def load_map(name):
 
 def build_inputs(args, total_steps, ctx=None):
     from botlab_amd import synth
-    m = load_map("obstacle_slam_10mx10m_5cm")
+    m = load_map(args.map)
     if args.grid != 200:
         cells = synth.tile_world(load_map("astar_maze")["cells"], args.grid)
         half = args.grid * 0.05 / 2.0
         m = dict(cells=np.where(cells > 0, 127, -100).astype(np.int8), origin=(np.float32(-half), np.float32(-half)),
                  mpc=np.float32(0.05))
         start, side = (0.3, 0.3, 0.0), 0.5
+    elif args.map == "convex_10mx10m_5cm":
+        # BASELINE.json configs[2]: localization on the shipped convex room (3.5 m across, centred on the origin)
+        start, side = (-0.4, -0.4, 0.0), 0.8
     else:
         # a 0.8 m square loop that keeps >= 0.2 m clearance inside the mapped arena of obstacle_slam (searched offline)
         start, side = (-0.75, 0.2, 0.0), 0.8
@@ -227,7 +230,9 @@ def main():
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--warmup", type=int, default=100)
     ap.add_argument("--particles", type=int, default=100_000)
-    ap.add_argument("--grid", type=int, default=200, help="grid side in cells (200 = shipped obstacle_slam map)")
+    ap.add_argument("--grid", type=int, default=200, help="grid side in cells (200 = a shipped map, see --map)")
+    ap.add_argument("--map", default="obstacle_slam_10mx10m_5cm", choices=["obstacle_slam_10mx10m_5cm", "convex_10mx10m_5cm"],
+                    help="the shipped 200x200 map (tests/golden/reference_maps.npz) scans are cast on and the filter localises in")
     ap.add_argument("--max-range", type=float, default=8.0, help="range of the synthetic lidar in metres (rays that hit nothing "
                     "report it)")
     ap.add_argument("--no-astar", action="store_true", help="skip the replan (distance grid + A*) in the step")
@@ -249,7 +254,7 @@ def main():
     ap.add_argument("--no-other-configs", action="store_true", help="default run: skip the short runs of configs 4 and 5")
     ap.add_argument("--other-steps", type=int, default=200, help="timed steps of each other_configs run")
     args = ap.parse_args()
-    presets = {3: dict(particles=1_000_000, no_astar=True),
+    presets = {3: dict(particles=1_000_000, no_astar=True, map="convex_10mx10m_5cm"),     # slam.cpp:36-45: --localization-only <map>
                4: dict(grid=2000, lanes=3, batch=8, depth=32),
                5: dict(grid=4096, particles=256_000, lanes=3, batch=4, depth=18)}
     for key, val in presets.get(args.config, {}).items():
@@ -558,7 +563,7 @@ def main():
             "vs_baseline": None,
             "dtype": "int8 grid / f32 poses with f64 intermediates / int64 weights",
             "data": "synthetic",
-            "config": {"workload": f"full SLAM step on {W}x{H} @5cm grid ({'shipped obstacle_slam map' if args.grid == 200 else 'tiled astar/maze world'}), {N} particles, "
+            "config": {"workload": f"full SLAM step on {W}x{H} @5cm grid ({('shipped ' + args.map + ' map') if args.grid == 200 else 'tiled astar/maze world'}), {N} particles, "
                                    f"{R} rays, A* replan {'off' if goal is None else 'on'}",
                        "particles": N, "grid": [W, H], "rays": R, "pipeline_depth": args.depth, "planner_lanes": args.lanes, "planner_batch": args.batch,
                        "parallelism": f"particle-shard x{world}" if world > 1 else "single GPU",

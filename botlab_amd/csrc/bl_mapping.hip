@@ -562,13 +562,21 @@ extern "C" void bl_mapping_destroy(bl_mapping* m)
 
 #define MAP_SNAPSHOT_IN_KERNEL_CELLS (256 * 1024)      // larger grids: one workgroup would copy for too long
 
-static int mapping_update_impl(bl_mapping* m, const bl_lidar_t* scan, const bl_pose_xyt_t* h_pose, const void* d_pose,
-                               int64_t pose_utime, bl_grid* map, const bl_planner_snap* snap = nullptr,
-                               const mcl_finish_args* fin = nullptr)
+// what mapping_update_impl checks of its arguments, ahead of taking a filter's finish (a finish that has been taken MUST be
+// launched: the filter's end-of-update bookkeeping is done by then)
+static int mapping_check_args(const bl_mapping* m, const bl_lidar_t* scan, const bl_grid* map)
 {
     BL_CHECK_ARG(m != nullptr && scan != nullptr && map != nullptr);
     BL_CHECK_ARG(scan->num_ranges >= 0 && scan->num_ranges <= MAP_MAX_RAYS);
     BL_CHECK_ARG(map->frame.width <= 65535 && map->frame.height <= 65535);       // end cells are packed 16+16 bits in LDS
+    return BL_OK;
+}
+
+static int mapping_update_impl(bl_mapping* m, const bl_lidar_t* scan, const bl_pose_xyt_t* h_pose, const void* d_pose,
+                               int64_t pose_utime, bl_grid* map, const bl_planner_snap* snap = nullptr,
+                               const mcl_finish_args* fin = nullptr)
+{
+    { const int rc0 = mapping_check_args(m, scan, map); if (rc0) return rc0; }
     bl_ctx* ctx = m->ctx;
     BL_HIP(hipSetDevice(ctx->device));
     int64_t begin = m->initialized ? m->prev_utime : pose_utime;
@@ -677,22 +685,32 @@ extern "C" int bl_planner_submit_with_map_update(bl_planner* p, bl_mapping* m, c
 // before Mapping::updateMap uses it, the weight prefix is written by further workgroups of the same launch, and the SLAM
 // stream carries one kernel less per step.  A filter with nothing pending (the robot did not move) or whose finish cannot
 // ride (sharded particle set) is ended the ordinary way first; results are bit-identical either way.
-static int finishing_pf_prepare(bl_pf* pf, bl_mapping* m, mcl_finish_args* fin, bool* ride)
+static int finishing_pf_prepare(bl_pf* pf, bl_mapping* m, const bl_lidar_t* scan, const bl_grid* map, mcl_finish_args* fin, bool* ride)
 {
     *ride = false;
     if (bl_pf_ctx(pf) != m->ctx) { bl_set_error("filter and mapping belong to different contexts"); return BL_ERR_ARG; }
+    int rc = mapping_check_args(m, scan, map);                  // before the filter's bookkeeping: a refused call leaves it pending
+    if (rc) return rc;
     const int t = bl_pf_take_finish(pf, fin);
     if (t > 0) { *ride = true; return BL_OK; }
     return bl_pf_update_end(pf, nullptr);                       // no-op when nothing is pending
+}
+
+// the map update that carries a taken finish failed before its launch (scan upload, allocation): the finish goes out on its own
+static int finish_after_failure(bl_pf* pf, const mcl_finish_args* fin, bool ride, int rc)
+{
+    if (rc && ride) (void)bl_pf_launch_taken_finish(pf, fin);
+    return rc;
 }
 
 extern "C" int bl_mapping_update_finishing_pf(bl_mapping* m, const bl_lidar_t* scan, bl_pf* pf, int64_t pose_utime, bl_grid* map)
 {
     BL_CHECK_ARG(m != nullptr && pf != nullptr && map != nullptr);
     mcl_finish_args fin; bool ride;
-    int rc = finishing_pf_prepare(pf, m, &fin, &ride);
+    int rc = finishing_pf_prepare(pf, m, scan, map, &fin, &ride);
     if (rc) return rc;
-    return mapping_update_impl(m, scan, nullptr, bl_pf_pose_device_ptr(pf), pose_utime, map, nullptr, ride ? &fin : nullptr);
+    rc = mapping_update_impl(m, scan, nullptr, bl_pf_pose_device_ptr(pf), pose_utime, map, nullptr, ride ? &fin : nullptr);
+    return finish_after_failure(pf, &fin, ride, rc);
 }
 
 extern "C" int bl_planner_submit_with_map_update_finishing_pf(bl_planner* p, bl_mapping* m, const bl_lidar_t* scan, bl_pf* pf,
@@ -701,22 +719,22 @@ extern "C" int bl_planner_submit_with_map_update_finishing_pf(bl_planner* p, bl_
 {
     BL_CHECK_ARG(p != nullptr && m != nullptr && pf != nullptr && map != nullptr && goal != nullptr && params != nullptr);
     mcl_finish_args fin; bool ride;
-    int rc = finishing_pf_prepare(pf, m, &fin, &ride);
+    int rc = finishing_pf_prepare(pf, m, scan, map, &fin, &ride);
     if (rc) return rc;
     const void* d_pose = bl_pf_pose_device_ptr(pf);
     if ((size_t)map->frame.width * map->frame.height > (size_t)MAP_SNAPSHOT_IN_KERNEL_CELLS) {
         rc = mapping_update_impl(m, scan, nullptr, d_pose, pose_utime, map, nullptr, ride ? &fin : nullptr);
-        if (rc) return rc;
+        if (rc) return finish_after_failure(pf, &fin, ride, rc);
         return bl_planner_submit(p, map, d_pose, goal, params);
     }
     bl_planner_snap sn;
     rc = bl_planner_reserve(p, map, &sn);
     if (rc) {
-        // the filter's bookkeeping is already done: its finish must still be launched
-        if (ride) (void)mapping_update_impl(m, scan, nullptr, d_pose, pose_utime, map, nullptr, &fin);
+        // the filter's bookkeeping is already done: its finish must still be launched (with the map update, which is this step's)
+        if (ride) { const int rc2 = mapping_update_impl(m, scan, nullptr, d_pose, pose_utime, map, nullptr, &fin); (void)finish_after_failure(pf, &fin, true, rc2); }
         return rc;
     }
     rc = mapping_update_impl(m, scan, nullptr, d_pose, pose_utime, map, &sn, ride ? &fin : nullptr);
-    if (rc) { bl_planner_cancel(p); return rc; }
+    if (rc) { bl_planner_cancel(p); return finish_after_failure(pf, &fin, ride, rc); }
     return bl_planner_commit(p, goal, params);
 }

@@ -294,13 +294,19 @@ __device__ __forceinline__ void ray_cells_pk(float2_t start, float cpm, float ra
 // + k2 with k1 = 1.02 * cpm * (eps + 4u) and k2 = 2.04u * (a bound on the particle's cell coordinates: |start| + 2 * longest
 // ray + 8).  A ray inside a band (1-4 in a thousand) makes its whole wave take the exact path for that round and keeps the exact
 // cells; everything downstream is integer.  (The guard costs ~15 instructions, the exact sinf / cosf with the wrap 36.)
-#define MCL_TRIG_EPS 9.0e-7f
-__device__ __forceinline__ void ray_cells_fast(float2_t start, float cpm, float range, float d, float k1, float k2, short2_t& E, short2_t& X)
+// MCL_TRIG_EPS: 5.5 % above the larger measured maximum.  bl_debug_trig_probe repeats the exhaustive measurement with the very
+// function the ray loop calls (hw_sincos_unwrapped), and tests/test_gpu_trig_guard.py asserts both maxima stay 5 % below it.
+#define MCL_TRIG_EPS 9.3e-7f
+__device__ __forceinline__ void hw_sincos_unwrapped(float d, float* sn, float* cs)
 {
     const float rev = d * 0.15915494309189535f;
+    asm("v_sin_f32 %0, %1" : "=v"(*sn) : "v"(rev));
+    asm("v_cos_f32 %0, %1" : "=v"(*cs) : "v"(rev));
+}
+__device__ __forceinline__ void ray_cells_fast(float2_t start, float cpm, float range, float d, float k1, float k2, short2_t& E, short2_t& X)
+{
     float sn, cs;
-    asm("v_sin_f32 %0, %1" : "=v"(sn) : "v"(rev));
-    asm("v_cos_f32 %0, %1" : "=v"(cs) : "v"(rev));
+    hw_sincos_unwrapped(d, &sn, &cs);
     float2_t e, x;
     ray_points_pk(start, cpm, range, cs, sn, e, x);
     const float B1 = __builtin_fmaf(range, k1, k2), B2 = __builtin_fmaf(range, k1 + k1, k2);
@@ -1179,8 +1185,8 @@ static int pf_alloc(bl_pf* pf)
     pf->fin_subs_cap = (int)(N / MCLF_SUB) + 4 * (MCLF_WG / 64);      // main region + tail region, each rounded up to whole groups
     BL_HIP(hipMalloc((void**)&pf->fin_recs, (size_t)2 * pf->fin_subs_cap * sizeof(ss_rec)));
     BL_HIP(hipMalloc((void**)&pf->fin_tabs, (size_t)2 * MCLF_TSLOTS * MCLF_SUB * sizeof(mclf_tab_elem)));
-    BL_HIP(hipMalloc((void**)&pf->fin_sync, 4 * sizeof(unsigned long long)));
-    BL_HIP(hipMemsetAsync(pf->fin_sync, 0, 4 * sizeof(unsigned long long), pf->ctx->stream));
+    BL_HIP(hipMalloc((void**)&pf->fin_sync, MCLF_SYNC_WORDS * sizeof(unsigned long long)));
+    BL_HIP(hipMemsetAsync(pf->fin_sync, 0, MCLF_SYNC_WORDS * sizeof(unsigned long long), pf->ctx->stream));
     BL_HIP(hipMalloc((void**)&pf->dbg_idx, n * sizeof(int32_t)));
     BL_HIP(hipMalloc((void**)&pf->dbg_like, n * sizeof(int32_t)));
     BL_HIP(hipMemsetAsync(pf->state, 0, sizeof(pf_state), pf->ctx->stream));
@@ -1684,6 +1690,14 @@ int bl_pf_take_finish(bl_pf* pf, mcl_finish_args* out)
 
 bl_ctx* bl_pf_ctx(bl_pf* pf) { return pf ? pf->ctx : nullptr; }
 
+int bl_pf_launch_taken_finish(bl_pf* pf, const mcl_finish_args* fin)
+{
+    if (!pf || !fin) return BL_ERR_ARG;
+    hipLaunchKernelGGL(k_mcl_finish, dim3(MCLF_EXTRA_WGS + fin->groups), dim3(MCLF_WG), MCLF_LDS_BYTES, pf->ctx->stream, *fin);
+    BL_HIP(hipGetLastError());
+    return BL_OK;
+}
+
 extern "C" int bl_pf_update(bl_pf* pf, const bl_pose_xyt_t* odometry, const bl_lidar_t* scan, const bl_grid* map,
                             int rand_value, const float* noise, bl_pose_xyt_t* out_pose)
 {
@@ -1792,6 +1806,52 @@ extern "C" int bl_pf_debug_resample(bl_pf* pf, int rand_value, int32_t* out_idx)
     BL_HIP(hipGetLastError());
     BL_HIP(hipMemcpyAsync(out_idx, pf->dbg_idx, (size_t)pf->N * 4, hipMemcpyDeviceToHost, pf->ctx->stream));
     BL_HIP(hipStreamSynchronize(pf->ctx->stream));
+    return BL_OK;
+}
+
+// ---- the measurement MCL_TRIG_EPS rests on, as a call (tests/test_gpu_trig_guard.py runs it on every driver run): the largest
+// |hw_sincos_unwrapped(d) - (sinf, cosf)(wrap_to_pi(d))| over EVERY float d in [-3 pi - 0.01, pi + 0.01], the range of a wrapped
+// pose angle less a scan angle in [0, 6.2831] (sensor_model.cpp:34-37 through moving_laser_scan.cpp:33).  ~0.7 s on the device.
+__global__ __launch_bounds__(256) void k_trig_probe(uint32_t lo_bits, uint32_t count, unsigned int* out_max)
+{
+    float ms = 0.f, mc = 0.f;
+    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < count; i += (uint64_t)gridDim.x * blockDim.x) {
+        const float d = __uint_as_float(lo_bits + (uint32_t)i);
+        float sn, cs, hs, hc;
+        bl_sincosf_cells(bl_wrap_to_pi(d), &sn, &cs);
+        hw_sincos_unwrapped(d, &hs, &hc);
+        ms = fmaxf(ms, fabsf(hs - sn)); mc = fmaxf(mc, fabsf(hc - cs));
+        if (!(fabsf(hs - sn) <= 1.0f)) ms = 2.0f;               // a nan difference must not hide in fmaxf
+        if (!(fabsf(hc - cs) <= 1.0f)) mc = 2.0f;
+    }
+    for (int off = 32; off > 0; off >>= 1) { ms = fmaxf(ms, __shfl_xor(ms, off, 64)); mc = fmaxf(mc, __shfl_xor(mc, off, 64)); }
+    if ((threadIdx.x & 63) == 0) {                              // non-negative floats order like their bit patterns
+        atomicMax(&out_max[0], __float_as_uint(ms));
+        atomicMax(&out_max[1], __float_as_uint(mc));
+    }
+}
+
+extern "C" int bl_debug_trig_probe(bl_ctx* ctx, float* max_sin_err, float* max_cos_err, float* eps_used, uint64_t* floats_checked)
+{
+    BL_CHECK_ARG(ctx != nullptr && max_sin_err != nullptr && max_cos_err != nullptr);
+    BL_HIP(hipSetDevice(ctx->device));
+    unsigned int* d_max = nullptr;
+    BL_HIP(hipMalloc((void**)&d_max, 8));
+    BL_HIP(hipMemsetAsync(d_max, 0, 8, ctx->stream));
+    const float hi_pos = 3.1515927f, hi_neg = 9.4347780f;       // pi + 0.01, 3 pi + 0.01
+    uint32_t bp, bn;
+    memcpy(&bp, &hi_pos, 4); memcpy(&bn, &hi_neg, 4);
+    // positive floats 0 .. hi_pos: bit patterns 0 .. bp; negative floats -0 .. -hi_neg: 0x80000000 .. 0x80000000 + bn
+    hipLaunchKernelGGL(k_trig_probe, dim3(4096), dim3(256), 0, ctx->stream, 0u, bp + 1u, d_max);
+    hipLaunchKernelGGL(k_trig_probe, dim3(4096), dim3(256), 0, ctx->stream, 0x80000000u, bn + 1u, d_max);
+    BL_HIP(hipGetLastError());
+    float h[2];
+    BL_HIP(hipMemcpyAsync(h, d_max, 8, hipMemcpyDeviceToHost, ctx->stream));
+    BL_HIP(hipStreamSynchronize(ctx->stream));
+    BL_HIP(hipFree(d_max));
+    *max_sin_err = h[0]; *max_cos_err = h[1];
+    if (eps_used) *eps_used = MCL_TRIG_EPS;
+    if (floats_checked) *floats_checked = (uint64_t)bp + 1ull + (uint64_t)bn + 1ull;
     return BL_OK;
 }
 

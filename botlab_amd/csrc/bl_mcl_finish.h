@@ -52,8 +52,11 @@ struct mcl_finish_args {
     int64_t utime;
     ss_rec* recs;                          // [2][groups * subs]: x records, then y records
     mclf_tab_elem* tabs;                   // [2][MCLF_TSLOTS][MCLF_SUB]
-    unsigned long long* sync;              // [0] bits 32..: groups done; bits 0..15 / 16..31: x / y tables handed out.  [1] the sums
-                                           // behind the first MCLF_PRE_SUBS sub-tiles (x, y float bits), [2] "they are there".  Zero between launches.
+    unsigned long long* sync;              // MCLF_SYNC_WORDS words, zero between launches:
+                                           // [0] bits 32..: groups done; bits 0..15 / 16..31: x / y tables handed out
+                                           // [1] the sums behind the first MCLF_PRE_SUBS sub-tiles (x, y float bits), [2] "they are there"
+                                           // [3] the finisher's exact x, y (float bits) for the map workgroup of the same launch, [4] "they are there"
+                                           //     (mclf_pose with publish writes them, mclf_wait_pose reads and clears them)
     int groups, gthreads;                  // group workgroups; threads of each that work (256 or 1024)
 };
 
@@ -73,6 +76,7 @@ struct mcl_finish_args {
 #define MCLF_PRE_SUBS 9                       // sub-tiles at the start of the sums that a workgroup of its own does while the groups run
 #define MCLF_EXTRA_WGS 2                      // workgroups of the launch in front of the groups: finisher, pre-chain
 #define MCLF_PRE_STEPPED 2                    // ... the first of them term by term (a binade change every few terms), the others in-binade
+#define MCLF_SYNC_WORDS 8                     // words of the sync block (one 64-byte line; five in use)
 #define MCLF_LDS_BYTES (112 * 1024)           // scratch the finisher wants (the map kernel's counter window serves)
 
 static inline int mclf_gthreads(int N) { return N >= MCLF_GT_SWITCH ? MCLF_GT_LARGE : MCLF_GT_SMALL; }
@@ -127,6 +131,13 @@ __device__ __forceinline__ void mclf_store_u64(unsigned long long* p, unsigned l
 __device__ __forceinline__ unsigned long long mclf_load_u64(const unsigned long long* p)
 {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// "my write-through stores have left": the sc1 stores above are ordered against a LATER flag store / counter add only if the
+// wave really waits for them -- a workgroup-scope release fence emits no s_waitcnt vmcnt(0) on gfx950 outside tgsplit mode, and
+// records and flag travel to different L2 channels.  No cache writeback is involved (the stores are write-through).
+__device__ __forceinline__ void mclf_drain_stores()
+{
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 __device__ __forceinline__ void mclf_store_rec(ss_rec* p, const ss_rec& r)
 {
@@ -397,7 +408,7 @@ __device__ __forceinline__ void mclf_prefix_group(const mcl_finish_args& f, int 
         mclf_store_rec(f.recs + s, rx);
         mclf_store_rec(f.recs + nrec + s, ry);
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");      // this wave's write-through stores have left (no cache writeback)
+    mclf_drain_stores();                                        // this wave's records and table rows have left (no cache writeback)
     __syncthreads();
     MCLF_GSTAMP(6);
     if (tid == 0) __hip_atomic_fetch_add(f.sync, 1ull << 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -800,7 +811,7 @@ __device__ __forceinline__ void mclf_pre_chain(const mcl_finish_args& f, mclf_sm
     __syncthreads();                                           // (waves 0 and 1 only: the others have left)
     if (tid == 0) {
         mclf_store_u64(f.sync + 1, (unsigned long long)__float_as_uint(sm.first[0]) | ((unsigned long long)__float_as_uint(sm.first[1]) << 32));
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        mclf_drain_stores();
         mclf_store_u64(f.sync + 2, 1ull);
     }
 }
@@ -938,7 +949,7 @@ __device__ __forceinline__ void mclf_pose(const mcl_finish_args& f, mclf_smem& s
         if (publish) {
             // another workgroup of this launch (the map update) is waiting for x and y: f.sync[3] / [4], which that workgroup clears
             mclf_store_u64(f.sync + 3, (unsigned long long)__float_as_uint(p.x) | ((unsigned long long)__float_as_uint(p.y) << 32));
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            mclf_drain_stores();
             mclf_store_u64(f.sync + 4, 1ull);
         }
         for (int k = 0; k < 5; ++k) f.state->sums_used[k] = tot[k];
@@ -957,5 +968,7 @@ __device__ __forceinline__ void mclf_pose(const mcl_finish_args& f, mclf_smem& s
 // and a negative status when the pending update cannot ride (the caller falls back to bl_pf_update_end).
 int bl_pf_take_finish(bl_pf* pf, mcl_finish_args* out);
 bl_ctx* bl_pf_ctx(bl_pf* pf);
+// a finish that was taken and could not ride after all (its carrier failed before the launch): k_mcl_finish on its own
+int bl_pf_launch_taken_finish(bl_pf* pf, const mcl_finish_args* fin);
 
 #endif

@@ -173,6 +173,11 @@ int bl_pf_debug_resample(bl_pf* pf, int rand_value, int32_t* out_idx);
 /* diagnostics for the parity tests: resample source index and raw likelihood (half-units) of the local shard of the last
  * update; recorded only while enabled (8 B per particle of extra stores) */
 int bl_pf_debug_enable(bl_pf* pf, int on);
+/* The hardware measurement behind the sensor model's fast trigonometry (SensorModel::scoreRay's endpoint cells,
+ * sensor_model.cpp:34-38): the largest difference between v_sin_f32 / v_cos_f32 of the unwrapped ray angle and the
+ * reference's sinf / cosf(wrap_to_pi(angle)), exhaustively over every float of the angle's range; *eps_used is the bound
+ * the kernel's guard band is built on (both maxima must stay below it). */
+int bl_debug_trig_probe(bl_ctx* ctx, float* max_sin_err, float* max_cos_err, float* eps_used, uint64_t* floats_checked);
 int bl_pf_debug_last(bl_pf* pf, int32_t* resample_idx, int32_t* likelihood_half_units);
 
 /* ------------------------------------------------------------------ ObstacleDistanceGrid  (src/planning/obstacle_distance_grid.hpp:28-96) */
@@ -183,7 +188,11 @@ int bl_dist_set_distances(bl_dist* d, const bl_grid* map);                /* set
 int bl_dist_download(bl_dist* d, float* cells);                           /* width*height floats (synchronises) */
 int bl_dist_shape(const bl_dist* d, int* width, int* height);
 int bl_dist_frame(const bl_dist* d, float* meters_per_cell, float* cells_per_meter, float* origin_x, float* origin_y);
-void* bl_dist_device_ptr(bl_dist* d);                                     /* float* in HBM (the float grid is formed on the first request after a setDistances) */
+/* float* in HBM.  The float grid is formed on the first request after a setDistances, on the ctx stream at the time of THIS
+ * call: the contents are valid for work ordered behind this call on that stream and only until the next
+ * bl_dist_set_distances on `d` -- a caller that keeps the pointer across setDistances calls must request it again (the
+ * address stays the same while the shape does; the floats behind it would be the previous transform's). */
+void* bl_dist_device_ptr(bl_dist* d);
 
 /* ------------------------------------------------------------------ search_for_path  (src/planning/astar.hpp:58-61, astar.cpp:9-274)
  * out_path[0] is always the start pose; *out_len == 1 means "no path" (lcmtypes/robot_path_t.lcm:7).  If the path is

@@ -18,7 +18,9 @@ int main(int argc, char** argv)
     FILE* in = std::fopen(argv[1], "rb");
     FILE* out = std::fopen(argv[2], "wb");
     if (!in || !out) return 2;
-    int32_t mode, nparticles, nevents, wait_opti;       // mode 0 = mapping-only, 3 = full SLAM, -1 = PoseTrace only (no GPU touched)
+    // mode 0 = mapping-only, 1 = localization-only, 2 = action-only (both on the .map file named by argv[3]: slam.cpp:36-45),
+    // 3 = full SLAM, -1 = PoseTrace only (no GPU touched)
+    int32_t mode, nparticles, nevents, wait_opti;
     rd(in, &mode, 4); rd(in, &nparticles, 4); rd(in, &nevents, 4); rd(in, &wait_opti, 4);
     int published_pose = 0, published_map = 0, published_particles = 0;
     SLAM::Publisher pub;
@@ -26,7 +28,9 @@ int main(int argc, char** argv)
     pub.slamParticles = [&](const particles_t& p) { published_particles += p.num_particles > 0; };
     pub.slamMap = [&](const occupancy_grid_t&) { ++published_map; };
     std::unique_ptr<SLAM> slamp;
-    if (mode >= 0) slamp.reset(new SLAM(nparticles, 4, 1, pub, wait_opti != 0, mode == 0, false, ""));
+    const std::string loc_map = (mode == 1 || mode == 2) && argc > 3 ? argv[3] : "";
+    if ((mode == 1 || mode == 2) && loc_map.empty()) { std::fprintf(stderr, "mode %d needs a map file\n", mode); return 2; }
+    if (mode >= 0) slamp.reset(new SLAM(nparticles, 4, 1, pub, wait_opti != 0, mode == 0, mode == 2, loc_map));
     // PoseTrace checks ride along: a private trace fed with the same 'P' events, queried by 'Q' events
     botlab_hip::PoseTraceT<pose_xyt_t> trace;
     for (int e = 0; e < nevents; ++e) {

@@ -28,12 +28,12 @@ def _build():
     return exe
 
 
-def _events(maps, mode, steps=14):
+def _events(maps, mode, steps=14, name="obstacle_slam_10mx10m_5cm", start=(-0.75, 0.2, 0.0)):
     """An event list with the hazards the reference's handlers deal with: scans before any pose/odometry (ignored), a
     scan whose pose has not arrived yet (queued, not ready), a short scan (< 100 ranges: skipped with an error)."""
-    m = maps["obstacle_slam_10mx10m_5cm"]
+    m = maps[name]
     truth = np.where(m["cells"] > 0, 127, -127).astype(np.int8)
-    poses = synth.square_trajectory((-0.75, 0.2, 0.0), steps, step_len=0.03, turn=0.05, side=0.8)
+    poses = synth.square_trajectory(start, steps, step_len=0.03, turn=0.05, side=0.8)
     ev = []
     t0 = 1_000_000
     sc0 = synth.raycast_scan(truth, m["origin"], 0.05, poses[0], poses[0], t0 - 150_000)
@@ -173,3 +173,91 @@ def test_full_slam_driver_control_flow_and_tracking(oracle, maps):
     assert abs(last[0] - cp.x) < 0.02 and abs(last[1] - cp.y) < 0.02
     assert abs(last[0] - truth[0]) < 0.10 and abs(last[1] - truth[1]) < 0.10
     L.orc_slam_destroy(d)
+
+
+def _write_map_file(path, m):
+    """The reference's ASCII .map format (occupancy_grid.cpp:111-136), as the shipped data/*.map files are written."""
+    c = m["cells"]
+    with open(path, "w") as f:
+        f.write(f"{float(m['origin'][0]):g} {float(m['origin'][1]):g} {c.shape[1]} {c.shape[0]} {float(m['mpc']):g}\n")
+        for row in c:
+            f.write(" ".join(str(int(v)) for v in row) + " \n")
+
+
+def _oracle_run(oracle, m, ev, n, action_only, rand_value=12345):
+    L = oracle.lib
+    g = oracle.grid(m["cells"].copy(), m["mpc"], helpers.CPM_DEFAULT, m["origin"])
+    d = L.orc_slam_create(n, 4, 1, 0, 0, 1 if action_only else 0, C.byref(g), 1)
+    its = []
+    for kind, x in ev:
+        if kind == "O":
+            p = oracle.pose(x[1], x[2], x[3], utime=x[0]); L.orc_slam_handle_odometry(d, C.byref(p))
+        elif kind == "L":
+            l = oracle.lidar(x); L.orc_slam_handle_laser(d, C.byref(l))
+        while L.orc_slam_ready(d):
+            L.orc_slam_iterate(d, rand_value)
+            st = (C.c_int * 6)(); cp = oracle_lib.OPose()
+            L.orc_slam_state(d, st, C.byref(cp), None)
+            its.append(((cp.utime, cp.x, cp.y, cp.theta), (st[0], st[1], st[2])))
+    st = (C.c_int * 6)()
+    cells = np.zeros((200, 200), np.int8)
+    L.orc_slam_state(d, st, None, cells.ctypes.data)
+    L.orc_slam_destroy(d)
+    return its, tuple(st), cells
+
+
+def _driver_run(exe, mode, nparticles, ev, mapfile):
+    with tempfile.TemporaryDirectory() as td:
+        script, outp = os.path.join(td, "s.bin"), os.path.join(td, "o.bin")
+        _write_script(script, mode, nparticles, ev)
+        out = subprocess.check_output([exe, script, outp, mapfile], stderr=subprocess.DEVNULL).decode()
+        assert "slam_driver_test ok" in out
+        raw = open(outp, "rb").read()
+    off, its = 0, []
+    while raw[off:off + 1] == b"I":
+        t, x, y, th, a, b, c = struct.unpack_from("<qfffiii", raw, off + 1)
+        its.append(((t, x, y, th), (a, b, c)))
+        off += 33
+    assert raw[off:off + 1] == b"E"
+    fin = struct.unpack_from("<iiiii", raw, off + 1)
+    cells = np.frombuffer(raw, np.int8, 40000, off + 21).reshape(200, 200)
+    return its, fin, cells
+
+
+def test_action_only_driver_matches_oracle(oracle, maps, tmp_path):
+    """--action-only on a loaded map (slam.cpp:36-45, 253-262): updateFilterActionOnly returns the odometry itself
+    (particle_filter.cpp:54-65), so every iteration's pose, the queue bookkeeping, the publish counts and the map the
+    (always-on, slam.cpp:276) map update leaves are deterministic: all identical to the oracle driver's."""
+    exe = _build()
+    m, poses, ev = _events(maps, mode=2, steps=16, name="convex_10mx10m_5cm", start=(0.0, 0.0, 0.0))
+    mapfile = str(tmp_path / "convex.map")
+    _write_map_file(mapfile, m)
+    got_its, fin, cells = _driver_run(exe, 2, 500, ev, mapfile)
+    exp_its, st, exp_cells = _oracle_run(oracle, m, ev, 500, action_only=True)
+    assert len(got_its) == len(exp_its) >= 12
+    assert got_its == exp_its
+    assert fin[:3] == st[:3] and fin[3] == st[3] and fin[4] == st[4]
+    assert np.array_equal(cells, exp_cells)
+    assert (cells != m["cells"]).sum() > 300                  # the loaded map was extended: the mode test of slam.cpp:276 is always true
+
+
+def test_localization_only_driver_control_flow_and_tracking(oracle, maps, tmp_path):
+    """--localization-only on data/convex_10mx10m_5cm.map (BASELINE.json configs[2]'s mode, slam.cpp:36-45): updateFilter runs
+    from the first iteration on (haveMap_ from the file), the map is still extended every iteration.  Different random
+    streams on the two sides (reference: random_device / mt19937), so control flow and publish counts are compared exactly
+    and the estimates statistically."""
+    exe = _build()
+    m, poses, ev = _events(maps, mode=1, steps=24, name="convex_10mx10m_5cm", start=(0.0, 0.0, 0.0))    # the reference's own start: the map frame's origin
+    mapfile = str(tmp_path / "convex.map")
+    _write_map_file(mapfile, m)
+    got_its, fin, cells = _driver_run(exe, 1, 3000, ev, mapfile)
+    exp_its, st, exp_cells = _oracle_run(oracle, m, ev, 300, action_only=False)
+    assert [(g[0][0], g[1]) for g in got_its] == [(e[0][0], e[1]) for e in exp_its]      # same iterations, stamps, queue state
+    assert len(got_its) >= 20
+    assert fin[3] == st[3] > 0                                                             # a SLAM_POSE per localised iteration
+    assert fin[4] == st[4]
+    last, ol = got_its[-1][0], exp_its[-1][0]
+    truth = (poses[-1][0] - poses[0][0], poses[-1][1] - poses[0][1])
+    assert abs(last[1] - ol[1]) < 0.03 and abs(last[2] - ol[2]) < 0.03
+    assert abs(last[1] - truth[0]) < 0.10 and abs(last[2] - truth[1]) < 0.10
+    assert (cells != m["cells"]).sum() > 300                  # localization-only still maps (slam.cpp:276)
