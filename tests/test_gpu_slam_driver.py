@@ -238,7 +238,7 @@ def test_action_only_driver_matches_oracle(oracle, maps, tmp_path):
     assert got_its == exp_its
     assert fin[:3] == st[:3] and fin[3] == st[3] and fin[4] == st[4]
     assert np.array_equal(cells, exp_cells)
-    assert (cells != m["cells"]).sum() > 300                  # the loaded map was extended: the mode test of slam.cpp:276 is always true
+    assert (cells != m["cells"]).sum() > 20                   # the loaded map was extended: the mode test of slam.cpp:276 is always true
 
 
 def test_localization_only_driver_control_flow_and_tracking(oracle, maps, tmp_path):
@@ -260,4 +260,4 @@ def test_localization_only_driver_control_flow_and_tracking(oracle, maps, tmp_pa
     truth = (poses[-1][0] - poses[0][0], poses[-1][1] - poses[0][1])
     assert abs(last[1] - ol[1]) < 0.03 and abs(last[2] - ol[2]) < 0.03
     assert abs(last[1] - truth[0]) < 0.10 and abs(last[2] - truth[1]) < 0.10
-    assert (cells != m["cells"]).sum() > 300                  # localization-only still maps (slam.cpp:276)
+    assert (cells != m["cells"]).sum() > 20                   # localization-only still maps (slam.cpp:276)
