@@ -406,6 +406,64 @@ void bl_scan_free(bl_ctx* ctx)
     sd->base = nullptr; sd->alt_times = nullptr; sd->alt_ranges = nullptr; sd->alt_thetas = nullptr; sd->pre_pending = false;
 }
 
+// ---------------------------------------------------------------- grid lineage + dirty log (bl_internal.h)
+#include <atomic>
+static std::atomic<uint64_t> g_next_lineage{1};
+
+static void log_release(bl_dirty_log* l)
+{
+    if (l && --l->refs == 0) { if (l->dev) (void)hipFree(l->dev); delete l; }
+}
+
+uint64_t bl_grid_new_lineage(bl_grid* g)
+{
+    g->id = g_next_lineage.fetch_add(1);
+    g->version = 0;
+    log_release(g->log);
+    g->log = nullptr;
+    return g->id;
+}
+
+uint64_t bl_grid_lineage_id(const bl_grid* g)
+{
+    if (g->id == 0) const_cast<bl_grid*>(g)->id = g_next_lineage.fetch_add(1);
+    return g->id;
+}
+
+void bl_grid_adopt_lineage(bl_grid* snap, const bl_grid* src)
+{
+    (void)bl_grid_lineage_id(src);
+    snap->id = src->id;
+    snap->version = src->version;
+    if (snap->log != src->log) {
+        log_release(snap->log);
+        snap->log = src->log;
+        if (snap->log) snap->log->refs += 1;
+    }
+}
+
+int4* bl_grid_log_next(bl_grid* g, uint64_t* version)
+{
+    if (g->id == 0) g->id = g_next_lineage.fetch_add(1);
+    if (!g->log) {
+        bl_dirty_log* l = new bl_dirty_log();
+        l->refs = 1; l->dev = nullptr;
+        if (hipMalloc((void**)&l->dev, sizeof(int4) * BL_DIRTY_LOG) != hipSuccess ||
+            hipMemsetAsync(l->dev, 0xff, sizeof(int4) * BL_DIRTY_LOG, g->ctx->stream) != hipSuccess) {
+            // no log: every consumer of this lineage takes the full transform (a version without an entry never matches its tag)
+            if (l->dev) (void)hipFree(l->dev);
+            delete l;
+            (void)bl_grid_new_lineage(g);
+            *version = 0;
+            return nullptr;
+        }
+        g->log = l;
+    }
+    g->version += 1;
+    *version = g->version;
+    return g->log->dev + (g->version % BL_DIRTY_LOG);
+}
+
 // ---------------------------------------------------------------- OccupancyGrid (src/slam/occupancy_grid.cpp)
 extern "C" int bl_grid_create(bl_ctx* ctx, int width, int height, float meters_per_cell, float cells_per_meter,
                               float origin_x, float origin_y, bl_grid** out)
@@ -435,6 +493,7 @@ extern "C" void bl_grid_destroy(bl_grid* g)
     (void)hipStreamSynchronize(g->ctx->stream);
     (void)hipFree(g->cells);
     if (g->mirror) (void)hipFree(g->mirror);
+    log_release(g->log);
     delete g;
 }
 
@@ -443,6 +502,7 @@ extern "C" int bl_grid_upload(bl_grid* g, const int8_t* cells)
     BL_CHECK_ARG(g != nullptr && cells != nullptr);
     size_t n = (size_t)g->frame.width * g->frame.height;
     g->mirror_valid = false;
+    (void)bl_grid_new_lineage(g);
     BL_HIP(hipMemcpyAsync(g->cells, cells, n, hipMemcpyHostToDevice, g->ctx->stream));
     BL_HIP(hipStreamSynchronize(g->ctx->stream));    // the host buffer is caller-owned and may be reused at once
     return BL_OK;
@@ -461,6 +521,7 @@ extern "C" int bl_grid_reset(bl_grid* g)
 {
     BL_CHECK_ARG(g != nullptr);
     g->mirror_valid = false;
+    (void)bl_grid_new_lineage(g);
     BL_HIP(hipMemsetAsync(g->cells, 0, (size_t)g->frame.width * g->frame.height, g->ctx->stream));
     return BL_OK;
 }
@@ -479,6 +540,7 @@ extern "C" int bl_grid_copy(bl_grid* dst, const bl_grid* src)
     BL_CHECK_ARG(dst->frame.width == src->frame.width && dst->frame.height == src->frame.height);
     dst->frame = src->frame;
     dst->mirror_valid = false;
+    (void)bl_grid_new_lineage(dst);               // (a plain copy runs on dst's stream, unordered against src's later updates: no shared log)
     BL_HIP(hipMemcpyAsync(dst->cells, src->cells, (size_t)src->frame.width * src->frame.height,
                           hipMemcpyDeviceToDevice, dst->ctx->stream));
     return BL_OK;
@@ -489,6 +551,7 @@ extern "C" void* bl_grid_device_ptr(bl_grid* g)
     if (!g) return nullptr;
     g->mirror_external = true;          // the caller may write the cells without the library seeing it
     g->mirror_valid = false;
+    (void)bl_grid_new_lineage(g);
     return (void*)g->cells;
 }
 

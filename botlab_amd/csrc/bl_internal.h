@@ -98,6 +98,16 @@ struct bl_frontiers {
 // (upload, reset, copy, a replanner snapshot) marks it stale, and a caller that has taken the raw device pointer may write
 // behind the library's back: from then on the mirror is rebuilt before every use.
 #define BL_MIRROR_FRAME 3
+
+// Which cells the map updates of a grid's LINEAGE have touched, kept on the device so that nothing on the host has to wait for a
+// kernel: Mapping::updateMap number v (1-based) of the lineage leaves the bounding box of the cells it may have changed in entry
+// v % BL_DIRTY_LOG -- (x0 | y0 << 16, x1 | y1 << 16, v low, v high), x1 < x0 for an update that changed nothing.  A lineage is a
+// sequence of cell states each of which comes from the one before by a map update; an upload, a reset or a copy from elsewhere
+// starts a new one (new id).  The replanner's snapshots carry the id and version of the map they were copied from and share its
+// log, and a distance grid remembers which (id, version) it last transformed: when the next map it is given is a later version
+// of the same lineage, only the window those boxes can influence is transformed again (bl_planning.hip, "incremental").
+#define BL_DIRTY_LOG 1024
+struct bl_dirty_log { int refs; int4* dev; };
 struct bl_grid {
     bl_ctx* ctx;
     bl_frame frame;
@@ -107,10 +117,19 @@ struct bl_grid {
     mutable int mirror_stride;
     mutable bool mirror_valid;        // the mirror equals the cells as of the work enqueued so far
     bool mirror_external;             // bl_grid_device_ptr has been handed out
+    uint64_t id;                      // lineage of the cells (0: none yet -- assigned on first need)
+    uint64_t version;                 // map updates logged in this lineage
+    bl_dirty_log* log;                // the lineage's log (shared with snapshots), or null before the first logged update
 };
+uint64_t bl_grid_new_lineage(bl_grid* g);                  // bl_ctx.hip: the cells were rewritten wholesale
+uint64_t bl_grid_lineage_id(const bl_grid* g);             // the grid's lineage (assigned now if it has none yet)
+void bl_grid_adopt_lineage(bl_grid* snap, const bl_grid* src);   // snap's cells are (about to be) a copy of src's
+// a map update is about to be enqueued on g: its log entry (null when the log cannot be had) and the version it will carry
+int4* bl_grid_log_next(bl_grid* g, uint64_t* version);
 
 // where a replanner submission wants its map + pose snapshot, and the number to publish in *flag when it is complete
 struct bl_planner_snap {
+    bl_grid* grid;                    // the snapshot grid itself (its lineage is set once the copy is enqueued)
     int8_t* cells; bl_pose_xyt_t* pose;
     unsigned long long* flag; unsigned long long seq;
     unsigned int* done_count;

@@ -54,6 +54,7 @@ struct map_args {
     int4* rays;
     long long* stamps;              // diagnostic build only (-DBL_MAP_STAMPS)
     int8_t* mirror; int mirror_stride;   // cell (0, 0) of the grid's zero-framed mirror when it is current (bl_internal.h), or null
+    int4* dirty_entry; unsigned long long dirty_version;   // the lineage's log entry of this update (bl_internal.h), or null
     // optional tail: copy the updated grid and the pose to a replanner snapshot and publish its submission number
     // (bl_planner_submit_with_map_update: saves a dependent launch on the SLAM stream)
     int8_t* snap_cells; bl_pose_xyt_t* snap_pose; const bl_pose_xyt_t* snap_pose_src;
@@ -210,6 +211,7 @@ __device__ __forceinline__ void map_update_body(const map_args& a, int8_t* snap,
     __shared__ int s_segp[MAP_SEG_RAYS + 1];                   // exclusive prefix of the rays' segment counts
     __shared__ int s_wsum[MAP_THREADS / 64];
     __shared__ int s_redo;
+    __shared__ int s_dirty[4];                                 // the box of cells this update may change (the last pass's)
 
     const int tid = threadIdx.x;
     MSTAMP(0);
@@ -236,6 +238,7 @@ __device__ __forceinline__ void map_update_body(const map_args& a, int8_t* snap,
         s_pose[3] = cur.x; s_pose[4] = cur.y; s_pose[5] = cur.theta;
         s_box[0] = 0x7fffffff; s_box[1] = 0x7fffffff; s_box[2] = -0x7fffffff; s_box[3] = -0x7fffffff;
         s_redo = 0;
+        s_dirty[0] = 1; s_dirty[1] = 1; s_dirty[2] = 0; s_dirty[3] = 0;      // empty
     }
     __syncthreads();
     if (!a.apply) { if (prov) take_exact_pose(); return 0; }    // increase/decreaseCellOdds do nothing (mapping.cpp:74,88)
@@ -311,6 +314,7 @@ __device__ __forceinline__ void map_update_body(const map_args& a, int8_t* snap,
     // grid rows of whole dwords: the window takes whole dwords too, and the free-space pass below updates four cells per access
     const bool dword_rows = (a.frame.width & 3) == 0 && seg_walk;
     if (dword_rows) { bx0 &= ~3; bx1 |= 3; }
+    if (tid == 0) { s_dirty[0] = bx0; s_dirty[1] = by0; s_dirty[2] = bx1; s_dirty[3] = by1; }     // every store below lies inside
     const int ww = bx1 - bx0 + 1;
     const int wh = by1 - by0 + 1;
     int rows_per_strip = MAP_LDS_COUNTERS / ww;
@@ -522,6 +526,9 @@ __device__ __forceinline__ void map_update_body(const map_args& a, int8_t* snap,
         bl_pose_xyt_t rec = lds_pose ? *lds_pose : (a.cur_dev ? *a.cur_dev : a.cur_host);
         rec.utime = a.cur_utime;
         *a.prev = rec;
+        if (a.dirty_entry)                                     // one 16-byte store: box and the version it belongs to
+            *a.dirty_entry = make_int4(s_dirty[0] | (s_dirty[1] << 16), s_dirty[2] | (s_dirty[3] << 16), (int)(unsigned int)a.dirty_version,
+                                       (int)(unsigned int)(a.dirty_version >> 32));
     }
 }
 
@@ -611,6 +618,8 @@ static int mapping_update_impl(bl_mapping* m, const bl_lidar_t* scan, const bl_p
         a.mirror = map->mirror + BL_MIRROR_FRAME * map->mirror_stride + 4;
         a.mirror_stride = map->mirror_stride;
     } else map->mirror_valid = false;
+    // the cells this update may change go to the lineage's log (grids up to 65535 a side: checked above)
+    a.dirty_entry = bl_grid_log_next(map, (uint64_t*)&a.dirty_version);
     a.snap_cells = nullptr; a.snap_pose = nullptr; a.snap_pose_src = nullptr; a.snap_flag = nullptr; a.snap_seq = 0;
     if (snap) {
         a.snap_cells = snap->cells; a.snap_pose = snap->pose; a.snap_pose_src = (const bl_pose_xyt_t*)d_pose;
@@ -677,6 +686,7 @@ extern "C" int bl_planner_submit_with_map_update(bl_planner* p, bl_mapping* m, c
     if (rc) return rc;
     rc = mapping_update_impl(m, scan, nullptr, d_pose, pose_utime, map, &sn);
     if (rc) { bl_planner_cancel(p); return rc; }
+    bl_grid_adopt_lineage(sn.grid, map);                        // the snapshot holds the map as this update leaves it
     return bl_planner_commit(p, goal, params);
 }
 
@@ -736,5 +746,6 @@ extern "C" int bl_planner_submit_with_map_update_finishing_pf(bl_planner* p, bl_
     }
     rc = mapping_update_impl(m, scan, nullptr, d_pose, pose_utime, map, &sn, ride ? &fin : nullptr);
     if (rc) { bl_planner_cancel(p); return finish_after_failure(pf, &fin, ride, rc); }
+    bl_grid_adopt_lineage(sn.grid, map);
     return bl_planner_commit(p, goal, params);
 }

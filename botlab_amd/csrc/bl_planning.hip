@@ -30,7 +30,7 @@ struct bl_dist {
     size_t capacity;          // cells allocated
     uint16_t* row;            // per-row nearest-source distance (0xFFFF: none in row)
     uint16_t* l1;             // L1 distance (0xFFFF: no source anywhere)
-    float* cells;             // float distances handed to callers: f[l1], formed when a caller first asks (floats_valid)
+    float* cells;             // float distances handed to callers: f[l1], allocated and formed when a caller first asks (floats_valid)
     bool floats_valid;
     float* lut;               // device f[n]
     int32_t* closed;          // A* closed-cell scratch of this grid: (generation << 3) | move code; an entry of another generation
@@ -40,18 +40,73 @@ struct bl_dist {
     int lut_n;
     std::vector<float>* lut_host;
     bool valid;
+    // incremental transforms (see "incremental" below): what l1 is the transform of, and the device / pinned words of the scheme
+    uint64_t src_id, src_version;
+    unsigned int* state;      // device: DST_* words
+    unsigned int* h_status;   // pinned: the plan the last incremental launch settled on (DST_MODE_*), written by the device
+    unsigned int* h_status_dev;
+    int inc_holdoff;          // incremental launches to skip (the device kept falling back to the whole grid)
+    int64_t n_inc, n_full, n_same;   // transforms by kind (diagnostic)
 };
 
 #define DIST_INF (1 << 28)
 
-// The grids of one launch: blockIdx.z picks the unit.  A replanner lane transforms the snapshots of a whole batch in three
-// launches instead of three per snapshot (eight 200 x 200 grids: 0.17 ms of back-to-back small kernels on the lane -> 0.03);
+// The grids of one launch: blockIdx.z picks the unit.  A replanner lane transforms the snapshots of a whole batch in one set of
+// launches instead of one set per snapshot (eight 200 x 200 grids: 0.17 ms of back-to-back small kernels on the lane -> 0.03);
 // a single setDistances is a batch of one.
-#define DIST_MAX_BATCH 8
+#define DIST_MAX_BATCH 32
 struct dist_batch {
-    const int8_t* cells[DIST_MAX_BATCH]; uint16_t* row[DIST_MAX_BATCH]; uint16_t* l1[DIST_MAX_BATCH]; float* out[DIST_MAX_BATCH];
-    const float* lut[DIST_MAX_BATCH]; int32_t* closed[DIST_MAX_BATCH]; int* sum_f[DIST_MAX_BATCH]; int* sum_b[DIST_MAX_BATCH];
+    const int8_t* cells[DIST_MAX_BATCH]; uint16_t* row[DIST_MAX_BATCH]; uint16_t* l1[DIST_MAX_BATCH];
+    int* sum_f[DIST_MAX_BATCH]; int* sum_b[DIST_MAX_BATCH];
+    unsigned int* state[DIST_MAX_BATCH]; unsigned int* hstat[DIST_MAX_BATCH];
+    const int4* log[DIST_MAX_BATCH]; unsigned int from[DIST_MAX_BATCH], to[DIST_MAX_BATCH];   // incremental: map updates from + 1 .. to of the log
 };
+
+// ---- incremental transform: the words of bl_dist::state
+// A map update changes cells inside a box B (the lineage's dirty log, bl_internal.h).  With D an upper bound of every finite
+// distance before AND after, a cell farther than D from B keeps its distance: its nearest source is nearer than any changed cell
+// (removed sources do not matter) and no new source is nearer than that.  So only the window W = B dilated by D + 1 is
+// transformed again, with the OLD distances of the ring of cells around W as seeds (an L1 path from a cell of W to a source
+// outside W crosses the ring at a cell q with d(q) + |p - q| = d(p), and d(q) is unchanged) -- exact, bit for bit the full
+// transform (tests/test_gpu_dist_incremental.py).  The window is decided ON THE DEVICE from the log (the host has not seen the
+// poses the boxes depend on): a window wider than DINC_MAX cells, a log entry that is not there any more, or no bound D make the
+// same launch transform the whole grid instead (slower than the dedicated kernels; the host then stays away from the
+// incremental form for a while, h_status).
+#define DST_DUB 0            // D: upper bound of the finite distances of l1 (0xFFFF: unknown / a cell without any source)
+#define DST_MODE 1           // plan of the running transform: DST_MODE_*
+#define DST_X0 2             // ... its region, inclusive (x0 a multiple of 16, x1 + 1 a multiple of 16)
+#define DST_Y0 3
+#define DST_X1 4
+#define DST_Y1 5
+#define DST_TICKET 6         // work items handed out by the merged column pass
+#define DST_ERROR 7          // a wait that did not end (never seen; the transform is then flagged invalid to the host)
+#define DST_GROUPS 8         // [DST_MAX_GROUPS] per column group: strips whose summaries are published
+#define DST_MAX_GROUPS 64    // grids up to 8192 columns / rows in the merged pass
+#define DST_STATS (DST_GROUPS + DST_MAX_GROUPS)   // [3] incremental launches that ended as: nothing to do, a window, the whole grid (diagnostic)
+#define DST_WORDS (DST_STATS + 3)
+#define DST_MODE_NONE 0      // nothing changed
+#define DST_MODE_WINDOW 1
+#define DST_MODE_FULL 2
+#define DINC_MAX 1024        // widest / tallest window
+
+// ---- plans ------------------------------------------------------------------------------------------------------------
+// agent-scope relaxed accesses through the L2 (sc1): what one workgroup hands to another inside a launch (the XCDs have separate
+// L2s; a release fence would write a whole L2 back)
+__device__ __forceinline__ void dst_store(int* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ int dst_load(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ unsigned int dst_load_u(const unsigned int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// The whole grid as the plan of the transform the column pass behind this kernel runs (one thread of the launch's first
+// workgroup per unit); the bound D starts again from the values that pass writes.
+__device__ __forceinline__ void dist_plan_full(unsigned int* state, int W, int H)
+{
+    if (!state) return;
+    state[DST_DUB] = 0u;
+    state[DST_MODE] = DST_MODE_FULL;
+    state[DST_X0] = 0u; state[DST_Y0] = 0u; state[DST_X1] = (unsigned int)(W - 1); state[DST_Y1] = (unsigned int)(H - 1);
+    state[DST_TICKET] = 0u; state[DST_ERROR] = 0u;
+    for (int i = 0; i < DST_MAX_GROUPS; ++i) state[DST_GROUPS + i] = 0u;
+}
 
 // Row pass: one workgroup per row; d_row[x] = min over sources x' in the row of |x - x'|.
 __global__ __launch_bounds__(256) void k_dist_rows(dist_batch db, int W)
@@ -60,6 +115,7 @@ __global__ __launch_bounds__(256) void k_dist_rows(dist_batch db, int W)
     uint16_t* __restrict__ row = db.row[blockIdx.z];
     __shared__ int s_wave[4];
     __shared__ int s_carry;
+    if (blockIdx.x == 0 && threadIdx.x == 0) dist_plan_full(db.state[blockIdx.z], W, (int)gridDim.x);
     const int y = blockIdx.x;
     const int8_t* c = cells + (size_t)y * W;
     uint16_t* out = row + (size_t)y * W;
@@ -123,6 +179,7 @@ __global__ __launch_bounds__(256) void k_dist_rows_wide(dist_batch db, int W)
     uint16_t* __restrict__ row = db.row[blockIdx.z];
     __shared__ int s_wl[4], s_wr[4];
     __shared__ int s_carry_l, s_carry_r;
+    if (blockIdx.x == 0 && threadIdx.x == 0) dist_plan_full(db.state[blockIdx.z], W, (int)gridDim.x);
     const int y = blockIdx.x;
     const int8_t* c = cells + (size_t)y * W;
     uint16_t* out = row + (size_t)y * W;
@@ -236,8 +293,6 @@ __global__ __launch_bounds__(DCOL_TX * DCOL_TY) void k_dist_cols(dist_batch db, 
 {
     const uint16_t* __restrict__ row = db.row[blockIdx.z];
     uint16_t* __restrict__ l1 = db.l1[blockIdx.z];
-    float* __restrict__ out = db.out[blockIdx.z];
-    const float* __restrict__ lut = db.lut[blockIdx.z];
     __shared__ int s_fwd[DCOL_TY][DCOL_TX];
     __shared__ int s_bwd[DCOL_TY][DCOL_TX];
     const int tx = threadIdx.x, ty = threadIdx.y;
@@ -286,7 +341,6 @@ __global__ __launch_bounds__(DCOL_TX * DCOL_TY) void k_dist_cols(dist_batch db, 
         int v = min(f, b);
         bool none = v >= 0xFFFF;
         l1[(size_t)y * W + x] = none ? (uint16_t)0xFFFF : (uint16_t)v;
-        if (out) out[(size_t)y * W + x] = none ? -1.0f : lut[v];
     }
 }
 
@@ -366,8 +420,6 @@ __global__ __launch_bounds__(DC2_TX * DC2_TY) void k_dist_cols_apply(dist_batch 
     const int* __restrict__ sum_f = db.sum_f[blockIdx.z];
     const int* __restrict__ sum_b = db.sum_b[blockIdx.z];
     uint16_t* __restrict__ l1 = db.l1[blockIdx.z];
-    float* __restrict__ out = db.out[blockIdx.z];
-    const float* __restrict__ lut = db.lut[blockIdx.z];
     __shared__ int s_f[DC2_TY][2 * DC2_TX];
     __shared__ int s_b[DC2_TY][2 * DC2_TX];
     const int tx = threadIdx.x, ty = threadIdx.y;
@@ -440,7 +492,266 @@ __global__ __launch_bounds__(DC2_TX * DC2_TY) void k_dist_cols_apply(dist_batch 
         const bool n0 = v[0] >= 0xFFFF, n1 = v[1] >= 0xFFFF;
         const size_t at = (size_t)(y0 + i) * W + x;
         *(unsigned int*)(l1 + at) = (n0 ? 0xFFFFu : (unsigned int)v[0]) | ((n1 ? 0xFFFFu : (unsigned int)v[1]) << 16);
-        if (out) *(float2*)(out + at) = make_float2(n0 ? -1.0f : lut[v[0]], n1 ? -1.0f : lut[v[1]]);
+    }
+}
+
+// The plan of an incremental transform, by the first wave of a workgroup (every workgroup of k_dist_rows_inc forms the same one
+// from the same inputs: the log entries from + 1 .. to and the bound D as the previous transform left it).  plan[0..4] = mode,
+// x0, y0, x1, y1.  W is a multiple of 16.
+__device__ __forceinline__ void dist_plan_inc(const dist_batch& db, int z, int W, int H, int lane, int* plan)
+{
+    const unsigned int from = db.from[z], to = db.to[z];
+    const int4* log = db.log[z];
+    int bx0 = 0x7fffffff, by0 = 0x7fffffff, bx1 = -1, by1 = -1;
+    bool lost = log == nullptr || to - from > (unsigned int)(BL_DIRTY_LOG - 32);
+    if (!lost)
+        for (unsigned int v = from + 1u + (unsigned int)lane; v <= to; v += 64u) {
+            const int4 e = log[v % BL_DIRTY_LOG];
+            if ((unsigned int)e.z != v) { lost = true; continue; }            // overwritten, or never written: no knowledge
+            const int x0 = e.x & 0xffff, y0 = (int)((unsigned int)e.x >> 16), x1 = e.y & 0xffff, y1 = (int)((unsigned int)e.y >> 16);
+            if (x1 < x0 || y1 < y0) continue;                                 // that update changed nothing
+            bx0 = min(bx0, x0); by0 = min(by0, y0); bx1 = max(bx1, x1); by1 = max(by1, y1);
+        }
+    for (int off = 32; off > 0; off >>= 1) {
+        bx0 = min(bx0, __shfl_xor(bx0, off, 64)); by0 = min(by0, __shfl_xor(by0, off, 64));
+        bx1 = max(bx1, __shfl_xor(bx1, off, 64)); by1 = max(by1, __shfl_xor(by1, off, 64));
+    }
+    lost = __builtin_amdgcn_ballot_w64(lost) != 0ull;
+    if (lane != 0) return;
+    const unsigned int dub = db.state[z][DST_DUB];
+    int mode = DST_MODE_WINDOW, x0 = 0, y0 = 0, x1 = W - 1, y1 = H - 1;
+    if (lost || dub >= 0xFFFFu) mode = DST_MODE_FULL;
+    else if (bx1 < bx0) mode = DST_MODE_NONE;
+    else {
+        const int R = (int)dub + 1;
+        x0 = max(0, bx0 - R) & ~15; x1 = min(W - 1, bx1 + R) | 15;
+        y0 = max(0, by0 - R); y1 = min(H - 1, by1 + R);
+        if (x1 > W - 1) x1 = W - 1;
+        if (x1 - x0 + 1 > DINC_MAX || y1 - y0 + 1 > DINC_MAX) { mode = DST_MODE_FULL; x0 = 0; y0 = 0; x1 = W - 1; y1 = H - 1; }
+    }
+    plan[0] = mode; plan[1] = x0; plan[2] = y0; plan[3] = x1; plan[4] = y1;
+}
+
+// Row pass of an incremental transform: row[y][x] for the plan's region = min over the sources x' of the region's row of |x - x'|
+// and over the two ring cells of the row (just left / right of the region) of their OLD distance + the way to them -- one wave
+// per row, a lane per 16 cells, regions wider than 1024 cells in chunks chained through a carry.  Min-plus prefix scans: a value
+// v at position p reaches x > p with (v - p) + x and x < p with (v + p) - x.  The first workgroup of a unit publishes the plan.
+#define DRI_WAVES 4
+__global__ __launch_bounds__(64 * DRI_WAVES) void k_dist_rows_inc(dist_batch db, int W, int H)
+{
+    const int z = blockIdx.z;
+    __shared__ int s_plan[5];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (wave == 0) dist_plan_inc(db, z, W, H, lane, s_plan);
+    __syncthreads();
+    const int mode = s_plan[0], x0 = s_plan[1], y0 = s_plan[2], x1 = s_plan[3], y1 = s_plan[4];
+    unsigned int* state = db.state[z];
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        state[DST_MODE] = (unsigned int)mode;
+        state[DST_X0] = (unsigned int)x0; state[DST_Y0] = (unsigned int)y0; state[DST_X1] = (unsigned int)x1; state[DST_Y1] = (unsigned int)y1;
+        state[DST_TICKET] = 0u; state[DST_ERROR] = 0u;
+        if (mode == DST_MODE_FULL) state[DST_DUB] = 0u;                       // the column pass forms the bound anew
+        for (int i = 0; i < DST_MAX_GROUPS; ++i) state[DST_GROUPS + i] = 0u;
+        state[DST_STATS + mode] += 1u;
+        if (db.hstat[z]) __hip_atomic_store(db.hstat[z], (unsigned int)mode, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    if (mode == DST_MODE_NONE) return;
+    const int8_t* __restrict__ cells = db.cells[z];
+    uint16_t* __restrict__ row = db.row[z];
+    const uint16_t* __restrict__ old = db.l1[z];
+    const int nrows = y1 - y0 + 1, w = x1 - x0 + 1;
+    const int nchunk = (w + 1023) >> 10;
+    for (int r = blockIdx.x * DRI_WAVES + wave; r < nrows; r += gridDim.x * DRI_WAVES) {
+        const int y = y0 + r;
+        const int8_t* c = cells + (size_t)y * W;
+        uint16_t* out = row + (size_t)y * W;
+        int carry_f = DIST_INF, carry_b = DIST_INF;                           // (v - p) of the left ring cell, (v + p) of the right one
+        if (mode == DST_MODE_WINDOW) {
+            if (x0 > 0) { const int v = old[(size_t)y * W + x0 - 1]; if (v != 0xFFFF) carry_f = v - (x0 - 1); }
+            if (x1 < W - 1) { const int v = old[(size_t)y * W + x1 + 1]; if (v != 0xFFFF) carry_b = v + (x1 + 1); }
+        }
+        // ---- left to right: nearest seed at or left of every cell, kept as a distance in `out` (or in registers: one chunk)
+        int4 raw = make_int4(-1, -1, -1, -1);
+        uint16_t o[16];
+        for (int ch = 0; ch < nchunk; ++ch) {
+            const int xb = x0 + (ch << 10) + lane * 16;
+            raw = make_int4(-1, -1, -1, -1);                                  // 0xFF bytes: free cells, no source
+            if (xb <= x1) raw = *(const int4*)(c + xb);
+            const int8_t* b = (const int8_t*)&raw;
+            int la = DIST_INF;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) if (b[i] >= 0) la = -(xb + i);       // is_cell_occupied: logOdds >= 0; the rightmost one wins
+            int incl = la;
+            for (int off = 1; off < 64; off <<= 1) { const int t = __shfl_up(incl, off, 64); if (lane >= off) incl = min(incl, t); }
+            int run = __shfl_up(incl, 1, 64);
+            if (lane == 0) run = DIST_INF;
+            run = min(run, carry_f);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { if (b[i] >= 0) run = -(xb + i); o[i] = (uint16_t)min(run + xb + i, 0xFFFF); }
+            carry_f = min(carry_f, __builtin_amdgcn_readlane(incl, 63));
+            if (nchunk > 1 && xb <= x1) { *(int4*)(out + xb) = *(const int4*)&o[0]; *(int4*)(out + xb + 8) = *(const int4*)&o[8]; }
+        }
+        // ---- right to left, merged with the first sweep
+        for (int ch = nchunk - 1; ch >= 0; --ch) {
+            const int xb = x0 + (ch << 10) + lane * 16;
+            if (nchunk > 1) {
+                raw = make_int4(-1, -1, -1, -1);
+                if (xb <= x1) { raw = *(const int4*)(c + xb); *(int4*)&o[0] = *(const int4*)(out + xb); *(int4*)&o[8] = *(const int4*)(out + xb + 8); }
+            }
+            const int8_t* b = (const int8_t*)&raw;
+            int lb = DIST_INF;
+#pragma unroll
+            for (int i = 15; i >= 0; --i) if (b[i] >= 0) lb = xb + i;         // the leftmost one wins
+            int incl = lb;
+            for (int off = 1; off < 64; off <<= 1) { const int t = __shfl_down(incl, off, 64); if (lane + off < 64) incl = min(incl, t); }
+            int run = __shfl_down(incl, 1, 64);
+            if (lane == 63) run = DIST_INF;
+            run = min(run, carry_b);
+#pragma unroll
+            for (int i = 15; i >= 0; --i) { if (b[i] >= 0) run = xb + i; o[i] = (uint16_t)min((int)o[i], min(run - (xb + i), 0xFFFF)); }
+            carry_b = min(carry_b, __builtin_amdgcn_readlane(incl, 0));
+            if (xb <= x1) { *(int4*)(out + xb) = *(const int4*)&o[0]; *(int4*)(out + xb + 8) = *(const int4*)&o[8]; }
+        }
+    }
+}
+
+// Column pass, summaries and application in ONE launch: a workgroup takes work items (column group of 128 columns, macro strip of
+// 128 rows) of the plan's region by ticket, keeps its tile of `row` in registers, publishes its strip's summaries (distance to the
+// nearest seed inside the strip as seen from its last and from its first row), counts itself in, waits until every strip of its
+// column group is in, chains the others' summaries into the carries entering its strip from above and below, and writes l1:
+// 2 B read + 2 B written per cell (k_dist_cols_summary + k_dist_cols_apply: 4 + 2 and two launches).  In a window plan the rows
+// just above / below the region seed the chains with their OLD distances.
+// Tickets are handed out in arrival order, column group by column group, so the strips a workgroup waits for are held by
+// workgroups that are already running or will get the next free slots: everything below the lowest unfinished group is complete
+// and drains.  A launch with fewer workgroups than items (the incremental form: the region is decided on the device) loops; it
+// needs more workgroups than a column group has strips (DST_MAX_GROUPS), which the host guarantees.
+__global__ __launch_bounds__(DC2_TX * DC2_TY) void k_dist_cols_merged(dist_batch db, int W, int H)
+{
+    const int z = blockIdx.z;
+    unsigned int* state = db.state[z];
+    const int mode = (int)state[DST_MODE];
+    if (mode == DST_MODE_NONE) return;
+    const int x0 = (int)state[DST_X0], y0 = (int)state[DST_Y0], x1 = (int)state[DST_X1], y1 = (int)state[DST_Y1];
+    const uint16_t* __restrict__ row = db.row[z];
+    uint16_t* __restrict__ l1 = db.l1[z];
+    int* __restrict__ sum_f = db.sum_f[z];
+    int* __restrict__ sum_b = db.sum_b[z];
+    __shared__ int s_f[DC2_TY][2 * DC2_TX];
+    __shared__ int s_b[DC2_TY][2 * DC2_TX];
+    extern __shared__ int s_dcm_sum[];                               // [2][strips of the grid][128]: the launch sizes it
+    const int strips_cap = (H + DC2_ROWS - 1) / DC2_ROWS;
+    int (*s_sf)[2 * DC2_TX] = (int (*)[2 * DC2_TX])s_dcm_sum;
+    int (*s_sb)[2 * DC2_TX] = (int (*)[2 * DC2_TX])(s_dcm_sum + (size_t)strips_cap * 2 * DC2_TX);
+    __shared__ int s_item, s_dub;
+    const int tx = threadIdx.x, ty = threadIdx.y, t = ty * DC2_TX + tx;
+    const int w = x1 - x0 + 1, h = y1 - y0 + 1;
+    const int ngroups = (w + 2 * DC2_TX - 1) / (2 * DC2_TX), nstrips = (h + DC2_ROWS - 1) / DC2_ROWS;
+    const int nitems = ngroups * nstrips;
+    const bool ring = mode == DST_MODE_WINDOW;
+    while (true) {
+        if (t == 0) { s_item = (int)atomicAdd(&state[DST_TICKET], 1u); s_dub = 0; }
+        __syncthreads();
+        const int item = s_item;
+        if (item >= nitems) break;
+        const int cg = item / nstrips, st = item - cg * nstrips;
+        const int x = x0 + cg * 2 * DC2_TX + 2 * tx;
+        const int Y0 = y0 + st * DC2_ROWS;
+        const int ya = Y0 + ty * DC2_SUB;
+        const bool live = x <= x1;                                   // (x0 even, x1 odd: a live pair lies inside)
+        int g[DC2_SUB][2];
+        int a_f[2] = {DIST_INF, DIST_INF}, a_b[2] = {DIST_INF, DIST_INF};
+#pragma unroll
+        for (int i = 0; i < DC2_SUB; ++i) {
+            unsigned int v = 0xFFFFFFFFu;
+            if (live && ya + i <= y1) v = *(const unsigned int*)(row + (size_t)(ya + i) * W + x);
+            const int a = (int)(v & 0xFFFFu), b = (int)(v >> 16);
+            g[i][0] = a == 0xFFFF ? DIST_INF : a;
+            g[i][1] = b == 0xFFFF ? DIST_INF : b;
+        }
+        const int yend = min(y1 + 1, ya + DC2_SUB);                  // one past this thread row's last row
+#pragma unroll
+        for (int i = 0; i < DC2_SUB; ++i)
+            if (ya + i <= y1)
+                for (int c = 0; c < 2; ++c) {
+                    a_f[c] = min(a_f[c], g[i][c] + (yend - 1 - (ya + i)));
+                    a_b[c] = min(a_b[c], g[i][c] + i);
+                }
+        for (int c = 0; c < 2; ++c) { s_f[ty][2 * tx + c] = a_f[c]; s_b[ty][2 * tx + c] = a_b[c]; }
+        __syncthreads();
+        if (ty == 0 && live) {
+            for (int c = 0; c < 2; ++c) {
+                int F = DIST_INF, B = DIST_INF;
+                for (int s2 = 0; s2 < DC2_TY; ++s2) {
+                    const int sy0 = Y0 + s2 * DC2_SUB, len = max(0, min(y1 + 1, sy0 + DC2_SUB) - sy0);
+                    if (len > 0) F = min(s_f[s2][2 * tx + c], F + len);
+                }
+                for (int s2 = DC2_TY - 1; s2 >= 0; --s2) {
+                    const int sy0 = Y0 + s2 * DC2_SUB, len = max(0, min(y1 + 1, sy0 + DC2_SUB) - sy0);
+                    if (len > 0) B = min(s_b[s2][2 * tx + c], B + len);
+                }
+                dst_store(&sum_f[(size_t)st * W + x + c], min(F, DIST_INF));
+                dst_store(&sum_b[(size_t)st * W + x + c], min(B, DIST_INF));
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // the summaries have left before the strip counts itself in
+        }
+        __syncthreads();
+        if (t == 0) {
+            __hip_atomic_fetch_add(&state[DST_GROUPS + cg], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            // every strip of the column group (held by running workgroups, see above).  The cap only bounds a wait that cannot
+            // happen by construction (~2 s): the transform is then flagged.
+            long long spins = 0;
+            while (dst_load_u(&state[DST_GROUPS + cg]) < (unsigned int)nstrips) {
+                __builtin_amdgcn_s_sleep(2);
+                if (++spins > (1ll << 24)) { state[DST_ERROR] = 1u; break; }
+            }
+        }
+        __syncthreads();
+        // the other strips' summaries of this column group
+        for (int i = t; i < nstrips * 2 * DC2_TX; i += DC2_TX * DC2_TY) {
+            const int m = i / (2 * DC2_TX), cx = i - m * (2 * DC2_TX);
+            const int xg = x0 + cg * 2 * DC2_TX + cx;
+            s_sf[m][cx] = xg <= x1 ? dst_load(&sum_f[(size_t)m * W + xg]) : DIST_INF;
+            s_sb[m][cx] = xg <= x1 ? dst_load(&sum_b[(size_t)m * W + xg]) : DIST_INF;
+        }
+        __syncthreads();
+        int dmax = 0;
+        if (live && ya <= y1) {
+            int E[2], B[2];
+            for (int c = 0; c < 2; ++c) {
+                // carries entering the strip: the distance at the row just above it / just below it
+                int e = DIST_INF, b = DIST_INF;
+                if (ring && y0 > 0) { const int v = l1[(size_t)(y0 - 1) * W + x + c]; if (v != 0xFFFF) e = v; }
+                if (ring && y1 < H - 1) { const int v = l1[(size_t)(y1 + 1) * W + x + c]; if (v != 0xFFFF) b = v; }
+                for (int m = 0; m < st; ++m) e = min(s_sf[m][2 * tx + c], e + DC2_ROWS);
+                for (int m = nstrips - 1; m > st; --m) {
+                    const int len = min(h, (m + 1) * DC2_ROWS) - m * DC2_ROWS;
+                    b = min(s_sb[m][2 * tx + c], b + len);
+                }
+                for (int s2 = 0; s2 < ty; ++s2) e = min(s_f[s2][2 * tx + c], e + DC2_SUB);
+                for (int s2 = DC2_TY - 1; s2 > ty; --s2) {
+                    const int sy0 = Y0 + s2 * DC2_SUB, len = max(0, min(y1 + 1, sy0 + DC2_SUB) - sy0);
+                    if (len > 0) b = min(s_b[s2][2 * tx + c], b + len);
+                }
+                E[c] = min(e, DIST_INF); B[c] = min(b, DIST_INF);
+            }
+            int f[DC2_SUB][2];
+#pragma unroll
+            for (int i = 0; i < DC2_SUB; ++i)
+                for (int c = 0; c < 2; ++c) { E[c] = min(g[i][c], E[c] + 1); f[i][c] = E[c]; }
+#pragma unroll
+            for (int i = DC2_SUB - 1; i >= 0; --i) {
+                if (ya + i > y1) continue;
+                int v[2];
+                for (int c = 0; c < 2; ++c) { B[c] = min(g[i][c], B[c] + 1); v[c] = min(min(f[i][c], B[c]), 0xFFFF); }
+                dmax = max(dmax, max(v[0], v[1]));
+                *(unsigned int*)(l1 + (size_t)(ya + i) * W + x) = (unsigned int)v[0] | ((unsigned int)v[1] << 16);
+            }
+        }
+        // the bound D: largest value written (0xFFFF where no seed reaches)
+        for (int off = 32; off > 0; off >>= 1) dmax = max(dmax, __shfl_xor(dmax, off, 64));
+        if (tx == 0 && dmax > 0) atomicMax(&s_dub, dmax);
+        __syncthreads();
+        if (t == 0 && s_dub > 0) atomicMax(&state[DST_DUB], (unsigned int)s_dub);
     }
 }
 
@@ -467,6 +778,8 @@ extern "C" void bl_dist_destroy(bl_dist* d)
     if (d->sum_f) (void)hipFree(d->sum_f);
     if (d->sum_b) (void)hipFree(d->sum_b);
     if (d->lut) (void)hipFree(d->lut);
+    if (d->state) (void)hipFree(d->state);
+    if (d->h_status) (void)hipHostFree(d->h_status);
     delete d->lut_host;
     delete d;
 }
@@ -486,6 +799,7 @@ static int dist_floats(bl_dist* d)
 {
     if (d->floats_valid) return BL_OK;
     const size_t n = (size_t)d->frame.width * d->frame.height;
+    if (!d->cells) BL_HIP(hipMalloc((void**)&d->cells, d->capacity * 4));      // a replan never needs the floats: allocated on first request
     size_t blocks = (n + 255) / 256;
     if (blocks > 16384) blocks = 16384;
     hipLaunchKernelGGL(k_dist_floats, dim3((unsigned int)blocks), dim3(256), 0, d->ctx->stream, d->l1, d->lut, d->cells, n);
@@ -510,11 +824,19 @@ static int dist_prepare(bl_dist* d, const bl_grid* map)
         d->row = nullptr; d->l1 = nullptr; d->cells = nullptr; d->closed = nullptr;
         BL_HIP(hipMalloc((void**)&d->row, n * 2));
         BL_HIP(hipMalloc((void**)&d->l1, n * 2));
-        BL_HIP(hipMalloc((void**)&d->cells, n * 4));
         BL_HIP(hipMalloc((void**)&d->closed, n * 4));
         BL_HIP(hipMemsetAsync(d->closed, 0, n * 4, ctx->stream));           // generation 0: nothing closed
         d->closed_gen = 0;
         d->capacity = n;
+        d->valid = false;
+        d->src_id = 0;
+    }
+    if (!d->state) {
+        BL_HIP(hipMalloc((void**)&d->state, DST_WORDS * sizeof(unsigned int)));
+        BL_HIP(hipMemsetAsync(d->state, 0, DST_WORDS * sizeof(unsigned int), ctx->stream));
+        BL_HIP(hipHostMalloc((void**)&d->h_status, 64, hipHostMallocDefault));
+        memset(d->h_status, 0, 64);
+        BL_HIP(hipHostGetDevicePointer((void**)&d->h_status_dev, d->h_status, 0));
     }
     d->frame = map->frame;
     {
@@ -544,6 +866,19 @@ static int dist_prepare(bl_dist* d, const bl_grid* map)
     return BL_OK;
 }
 
+// May the transform of `map` start from d's current one?  (same lineage, a later version whose log entries are still there,
+// a grid the window kernels handle: rows of whole 16-cell groups, at least DINC_MAX a side, at most 8192 rows)
+static bool dist_can_increment(const bl_dist* d, const bl_grid* map)
+{
+    static const bool off = getenv("BOTLAB_DIST_NO_INCREMENTAL") != nullptr;
+    const int W = map->frame.width, H = map->frame.height;
+    if (off || !d->valid || d->src_id == 0 || d->src_id != map->id || map->mirror_external || !map->log || !d->state) return false;
+    if (d->frame.width != W || d->frame.height != H) return false;
+    if ((W & 15) != 0 || W < DINC_MAX || H < DINC_MAX || (H + DC2_ROWS - 1) / DC2_ROWS > DST_MAX_GROUPS || (W + 2 * DC2_TX - 1) / (2 * DC2_TX) > DST_MAX_GROUPS) return false;
+    if (map->version < d->src_version || map->version - d->src_version > (uint64_t)(BL_DIRTY_LOG - 64)) return false;
+    return d->inc_holdoff == 0;
+}
+
 // setDistances of n grids of one size, all on ds[0]'s stream, as one set of launches (blockIdx.z = grid)
 static int dist_set_distances_batch(int n, bl_dist* const* ds, const bl_grid* const* maps)
 {
@@ -553,49 +888,104 @@ static int dist_set_distances_batch(int n, bl_dist* const* ds, const bl_grid* co
     const int W = maps[0]->frame.width, H = maps[0]->frame.height;
     dist_batch b;
     memset((void*)&b, 0, sizeof(b));
+    bool all_inc = true, all_same = true;
     for (int u = 0; u < n; ++u) {
         BL_CHECK_ARG(ds[u] != nullptr && maps[u] != nullptr && ds[u]->ctx->stream == ctx->stream);
         BL_CHECK_ARG(maps[u]->frame.width == W && maps[u]->frame.height == H);
-        int rc = dist_prepare(ds[u], maps[u]);
+        bl_dist* d = ds[u];
+        // what the device said about the last incremental launch (no waiting: the word is whatever has landed by now)
+        if (d->h_status && *d->h_status == 0xDEADu) { bl_set_error("distance transform: a column group never completed"); *d->h_status = 0; d->valid = false; return BL_ERR_STATE; }
+        if (d->h_status && *d->h_status == (unsigned int)DST_MODE_FULL) { *d->h_status = 0; d->inc_holdoff = 16; }
+        const bool inc = dist_can_increment(d, maps[u]);
+        if (d->inc_holdoff > 0) d->inc_holdoff -= 1;
+        const bool same = inc && maps[u]->version == d->src_version;
+        const uint64_t from = d->src_version;
+        int rc = dist_prepare(d, maps[u]);
         if (rc) return rc;
-        b.cells[u] = maps[u]->cells; b.row[u] = ds[u]->row; b.l1[u] = ds[u]->l1; b.out[u] = nullptr; b.lut[u] = ds[u]->lut;
-        ds[u]->floats_valid = false;
-        b.closed[u] = ds[u]->closed; b.sum_f[u] = ds[u]->sum_f; b.sum_b[u] = ds[u]->sum_b;
+        all_inc = all_inc && inc; all_same = all_same && same;
+        b.cells[u] = maps[u]->cells; b.row[u] = d->row; b.l1[u] = d->l1;
+        b.sum_f[u] = d->sum_f; b.sum_b[u] = d->sum_b; b.state[u] = d->state; b.hstat[u] = d->h_status_dev;
+        b.log[u] = maps[u]->log ? maps[u]->log->dev : nullptr;
+        b.from[u] = (unsigned int)from; b.to[u] = (unsigned int)maps[u]->version;
+    }
+    if (all_same) {                                    // the very maps these grids hold the transforms of
+        for (int u = 0; u < n; ++u) ds[u]->n_same += 1;
+        return BL_OK;
+    }
+    for (int u = 0; u < n; ++u) ds[u]->floats_valid = false;
+    const bool merged = H >= 4 * DC2_ROWS && W >= 4 * DC2_TX && (W & 1) == 0 && (H + DC2_ROWS - 1) / DC2_ROWS <= DST_MAX_GROUPS;
+    const int strips = (H + DC2_ROWS - 1) / DC2_ROWS;
+    const size_t merged_lds = (size_t)2 * strips * 2 * DC2_TX * sizeof(int);
+    static bool attr_set = false;
+    if (!attr_set) {
+        BL_HIP(hipFuncSetAttribute((const void*)k_dist_cols_merged, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * DST_MAX_GROUPS * 2 * DC2_TX * (int)sizeof(int)));
+        attr_set = true;
     }
     hipEvent_t e0, e1;
     int rc = bl_timer_begin(ctx, BL_K_DIST, &e0, &e1);
     if (rc) return rc;
     hipEvent_t f0, f1;
-    rc = bl_timer_begin(ctx, BL_K_DIST_ROWS, &f0, &f1);
-    if (rc) return rc;
-    if (W >= 1024 && (W & 15) == 0) hipLaunchKernelGGL(k_dist_rows_wide, dim3(H, 1, n), dim3(256), 0, ctx->stream, b, W);
-    else hipLaunchKernelGGL(k_dist_rows, dim3(H, 1, n), dim3(256), 0, ctx->stream, b, W);
-    rc = bl_timer_end(ctx, BL_K_DIST_ROWS, f0, f1);
-    if (rc) return rc;
-    if (H >= 4 * DC2_ROWS && W >= 4 * DC2_TX && (W & 1) == 0) {
-        const int nmacro = (H + DC2_ROWS - 1) / DC2_ROWS;
-        const dim3 grid2((W + 2 * DC2_TX - 1) / (2 * DC2_TX), nmacro, n);
-        rc = bl_timer_begin(ctx, BL_K_DIST_COLS_SUMMARY, &f0, &f1);
+    static const bool two_pass = getenv("BOTLAB_DIST_TWO_PASS_COLS") != nullptr;         // A/B: round 2's summary + apply kernels
+    const bool bound_kept = all_inc || (merged && !two_pass);                            // the column pass leaves the bound D behind
+    if (all_inc) {
+        // the window (or, failing that, the whole grid) is settled by the kernels themselves
+        rc = bl_timer_begin(ctx, BL_K_DIST_ROWS, &f0, &f1);
         if (rc) return rc;
-        hipLaunchKernelGGL(k_dist_cols_summary, grid2, dim3(DC2_TX, DC2_TY), 0, ctx->stream, b, W, H);
-        rc = bl_timer_end(ctx, BL_K_DIST_COLS_SUMMARY, f0, f1);
+        hipLaunchKernelGGL(k_dist_rows_inc, dim3(DINC_MAX / DRI_WAVES, 1, n), dim3(64 * DRI_WAVES), 0, ctx->stream, b, W, H);
+        rc = bl_timer_end(ctx, BL_K_DIST_ROWS, f0, f1);
         if (rc) return rc;
         rc = bl_timer_begin(ctx, BL_K_DIST_COLS_APPLY, &f0, &f1);
         if (rc) return rc;
-        hipLaunchKernelGGL(k_dist_cols_apply, grid2, dim3(DC2_TX, DC2_TY), 0, ctx->stream, b, W, H);
+        hipLaunchKernelGGL(k_dist_cols_merged, dim3(DST_MAX_GROUPS + 16, 1, n), dim3(DC2_TX, DC2_TY), merged_lds, ctx->stream, b, W, H);
         rc = bl_timer_end(ctx, BL_K_DIST_COLS_APPLY, f0, f1);
         if (rc) return rc;
     } else {
-        rc = bl_timer_begin(ctx, BL_K_DIST_COLS_APPLY, &f0, &f1);
+        if (!merged) for (int u = 0; u < n; ++u) b.state[u] = nullptr;      // (the small-grid column pass keeps no plan or bound)
+        rc = bl_timer_begin(ctx, BL_K_DIST_ROWS, &f0, &f1);
         if (rc) return rc;
-        hipLaunchKernelGGL(k_dist_cols, dim3((W + DCOL_TX - 1) / DCOL_TX, 1, n), dim3(DCOL_TX, DCOL_TY), 0, ctx->stream, b, W, H);
-        rc = bl_timer_end(ctx, BL_K_DIST_COLS_APPLY, f0, f1);
+        if (W >= 1024 && (W & 15) == 0) hipLaunchKernelGGL(k_dist_rows_wide, dim3(H, 1, n), dim3(256), 0, ctx->stream, b, W);
+        else hipLaunchKernelGGL(k_dist_rows, dim3(H, 1, n), dim3(256), 0, ctx->stream, b, W);
+        rc = bl_timer_end(ctx, BL_K_DIST_ROWS, f0, f1);
         if (rc) return rc;
+        if (merged && !two_pass) {
+            const int groups = (W + 2 * DC2_TX - 1) / (2 * DC2_TX);
+            rc = bl_timer_begin(ctx, BL_K_DIST_COLS_APPLY, &f0, &f1);
+            if (rc) return rc;
+            hipLaunchKernelGGL(k_dist_cols_merged, dim3(groups * strips, 1, n), dim3(DC2_TX, DC2_TY), merged_lds, ctx->stream, b, W, H);
+            rc = bl_timer_end(ctx, BL_K_DIST_COLS_APPLY, f0, f1);
+            if (rc) return rc;
+        } else if (H >= 4 * DC2_ROWS && W >= 4 * DC2_TX && (W & 1) == 0) {
+            const dim3 grid2((W + 2 * DC2_TX - 1) / (2 * DC2_TX), strips, n);
+            rc = bl_timer_begin(ctx, BL_K_DIST_COLS_SUMMARY, &f0, &f1);
+            if (rc) return rc;
+            hipLaunchKernelGGL(k_dist_cols_summary, grid2, dim3(DC2_TX, DC2_TY), 0, ctx->stream, b, W, H);
+            rc = bl_timer_end(ctx, BL_K_DIST_COLS_SUMMARY, f0, f1);
+            if (rc) return rc;
+            rc = bl_timer_begin(ctx, BL_K_DIST_COLS_APPLY, &f0, &f1);
+            if (rc) return rc;
+            hipLaunchKernelGGL(k_dist_cols_apply, grid2, dim3(DC2_TX, DC2_TY), 0, ctx->stream, b, W, H);
+            rc = bl_timer_end(ctx, BL_K_DIST_COLS_APPLY, f0, f1);
+            if (rc) return rc;
+        } else {
+            rc = bl_timer_begin(ctx, BL_K_DIST_COLS_APPLY, &f0, &f1);
+            if (rc) return rc;
+            hipLaunchKernelGGL(k_dist_cols, dim3((W + DCOL_TX - 1) / DCOL_TX, 1, n), dim3(DCOL_TX, DCOL_TY), 0, ctx->stream, b, W, H);
+            rc = bl_timer_end(ctx, BL_K_DIST_COLS_APPLY, f0, f1);
+            if (rc) return rc;
+        }
     }
     BL_HIP(hipGetLastError());
     rc = bl_timer_end(ctx, BL_K_DIST, e0, e1);
     if (rc) return rc;
-    for (int u = 0; u < n; ++u) ds[u]->valid = true;
+    for (int u = 0; u < n; ++u) {
+        bl_dist* d = ds[u];
+        d->valid = true;
+        if (all_inc) d->n_inc += 1; else d->n_full += 1;
+        // l1 is now the transform of this version of this lineage (the small-grid and two-pass column kernels keep no bound D: the
+        // next transform is a full one as well)
+        if (bound_kept) { d->src_id = bl_grid_lineage_id(maps[u]); d->src_version = maps[u]->version; }
+        else d->src_id = 0;
+    }
     return BL_OK;
 }
 
@@ -603,6 +993,21 @@ extern "C" int bl_dist_set_distances(bl_dist* d, const bl_grid* map)
 {
     BL_CHECK_ARG(d != nullptr && map != nullptr);
     return dist_set_distances_batch(1, &d, &map);
+}
+
+// transforms by kind: {incremental launches, whole-grid launches, calls that found the map unchanged, and of the incremental
+// launches those the device ended as: nothing to do, a window, the whole grid after all}  (synchronises; diagnostic)
+extern "C" int bl_dist_debug_stats(bl_dist* d, int64_t* out6)
+{
+    BL_CHECK_ARG(d != nullptr && out6 != nullptr);
+    out6[0] = d->n_inc; out6[1] = d->n_full; out6[2] = d->n_same; out6[3] = out6[4] = out6[5] = 0;
+    if (d->state) {
+        unsigned int st[3];
+        BL_HIP(hipMemcpyAsync(st, d->state + DST_STATS, sizeof(st), hipMemcpyDeviceToHost, d->ctx->stream));
+        BL_HIP(hipStreamSynchronize(d->ctx->stream));
+        out6[3] = st[0]; out6[4] = st[1]; out6[5] = st[2];
+    }
+    return BL_OK;
 }
 
 extern "C" int bl_dist_download(bl_dist* d, float* cells)
@@ -712,7 +1117,7 @@ struct bl_astar_state {
 #define ASTAR_HDR 256
 static_assert(sizeof(astar_result) <= ASTAR_HDR, "result record must fit the header of the output buffer");
 
-#define ASTAR_MAX_UNITS 8
+#define ASTAR_MAX_UNITS 32
 struct astar_unit {
     const uint16_t* l1; const int32_t* cost_lut; int2* heap; int32_t* closed; int32_t* path; astar_result* result;
     const bl_pose_xyt_t* start_dev; bl_pose_xyt_t start_host; int sx, sy, gx, gy;
@@ -1711,6 +2116,8 @@ extern "C" int bl_planner_create_batched(bl_ctx* ctx, int lanes, int batch, bl_p
             if (rc) return rc;
             if (u == 0) L.side = U.ctx;
             U.ctx->astar_small_lds = true;       // co-runs with the SLAM stream's kernels
+            // open list of a unit: 4 M entries (32 MB) unless BOTLAB_PLANNER_OPEN_CAPACITY says otherwise -- up to 4 x 32 units exist
+            U.ctx->astar_capacity = getenv("BOTLAB_PLANNER_OPEN_CAPACITY") ? atoll(getenv("BOTLAB_PLANNER_OPEN_CAPACITY")) : ((int64_t)1 << 22);
             rc = bl_dist_create(U.ctx, &U.dist);
             if (rc) return rc;
             for (int i = 0; i < PLANNER_SLOTS; ++i) {
@@ -1851,6 +2258,7 @@ int bl_planner_reserve(bl_planner* p, const bl_grid* map, bl_planner_snap* out)
     // the lane must have finished with this slot; in steady state it has, long ago -- only then is a stream wait enqueued
     if (L.slot_used[slot] && hipEventQuery(L.slot_free[slot]) != hipSuccess)
         BL_HIP(hipStreamWaitEvent(p->main->stream, L.slot_free[slot], 0));
+    out->grid = snap;
     out->cells = snap->cells;
     snap->mirror_valid = false;                              // (nobody localises on a snapshot, but its cells are about to change)
     out->pose = U.pose[slot];
@@ -1915,6 +2323,7 @@ extern "C" int bl_planner_submit(bl_planner* p, const bl_grid* map, const void* 
     BL_HIP(hipGetLastError());
     rc = bl_timer_end(p->main, BL_K_SNAPSHOT, f0, f1);
     if (rc) return rc;
+    bl_grid_adopt_lineage(sn.grid, map);               // the snapshot holds this version of the map
     return bl_planner_commit(p, goal, params);
 }
 

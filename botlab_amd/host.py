@@ -360,6 +360,12 @@ class ObstacleDistanceGrid:
         check(self.ctx.lib.bl_dist_set_distances(self.h, grid.h))
         self._host = None
 
+    def stats(self):
+        """How the transforms of this grid went out (bl_dist_debug_stats)."""
+        v = (C.c_int64 * 6)()
+        check(self.ctx.lib.bl_dist_debug_stats(self.h, v))
+        return dict(incremental=v[0], full=v[1], unchanged=v[2], nothing=v[3], window=v[4], fallback=v[5])
+
     def shape(self):
         w, h = C.c_int(), C.c_int()
         check(self.ctx.lib.bl_dist_shape(self.h, C.byref(w), C.byref(h)))

@@ -184,7 +184,14 @@ int bl_pf_debug_last(bl_pf* pf, int32_t* resample_idx, int32_t* likelihood_half_
 typedef struct bl_dist bl_dist;
 int bl_dist_create(bl_ctx* ctx, bl_dist** out);
 void bl_dist_destroy(bl_dist* d);
-int bl_dist_set_distances(bl_dist* d, const bl_grid* map);                /* setDistances(map), obstacle_distance_grid.cpp:73-91 */
+/* setDistances(map), obstacle_distance_grid.cpp:73-91.  When `map` is a later state of the very map `d` last transformed --
+ * Mapping::updateMap calls in between, nothing else; a replanner snapshot counts as the map it was taken from -- only the window
+ * those updates can influence is transformed again (grids of at least 1024 cells a side); the result is the full transform's,
+ * bit for bit.  BOTLAB_DIST_NO_INCREMENTAL=1 always transforms the whole grid. */
+int bl_dist_set_distances(bl_dist* d, const bl_grid* map);
+/* diagnostic, six counts: setDistances calls that went out as an incremental launch / as a whole-grid launch / found the map
+ * unchanged; and of the incremental launches those the device ended with nothing to do / a window / the whole grid */
+int bl_dist_debug_stats(bl_dist* d, int64_t* out6);
 int bl_dist_download(bl_dist* d, float* cells);                           /* width*height floats (synchronises) */
 int bl_dist_shape(const bl_dist* d, int* width, int* height);
 int bl_dist_frame(const bl_dist* d, float* meters_per_cell, float* cells_per_meter, float* origin_x, float* origin_y);
@@ -221,7 +228,7 @@ typedef struct bl_planner bl_planner;
 /* lanes (1..4): consecutive submissions go to consecutive side streams, so up to `lanes` replans run concurrently (each
  * is one wavefront on its own CU and latency-bound; independent searches are what the GPU can overlap). */
 int bl_planner_create(bl_ctx* ctx, int lanes, bl_planner** out);
-/* batch (1..8): a lane collects `batch` consecutive submissions and issues their searches as ONE launch, a workgroup each,
+/* batch (1..32): a lane collects `batch` consecutive submissions and issues their searches as ONE launch, a workgroup each,
  * so lanes x batch replans overlap although the runtime multiplexes streams onto four hardware queues.  For grids where a
  * search outlasts a step (2000x2000: ~1.5 ms against 0.2 ms); a result is then available `batch` - 1 submissions later
  * (a fetch that cannot wait for the batch to fill sends it off as it is).  bl_planner_create is batch = 1. */
