@@ -200,6 +200,7 @@ def streaming_kernels(ctx, grid, planner, aplanner, pose_dev, goal_pose, W, H):
     ctx.timing_enable(True, kernels=ids)
     reps = 12
     for _ in range(reps):
+        planner.distances_.forget()                        # the whole-grid kernels, not the window the last map update allows
         planner.setMap(grid)                               # ObstacleDistanceGrid::setDistances on the live map
     if goal_pose is not None:
         for _ in range(reps):                              # the stand-alone snapshot copy (the bench's own rides in the map kernel)
@@ -252,7 +253,7 @@ def main():
                          "4: 2000x2000 maze with a replan per step; 5: 4096x4096, 256k particles); explicit flags still win")
     ap.add_argument("--sub", action="store_true", help="a child run of the default invocation (other_configs): no children of its own")
     ap.add_argument("--no-other-configs", action="store_true", help="default run: skip the short runs of configs 4 and 5")
-    ap.add_argument("--other-steps", type=int, default=200, help="timed steps of each other_configs run")
+    ap.add_argument("--other-steps", type=int, default=1000, help="timed steps of each other_configs run")
     args = ap.parse_args()
     presets = {3: dict(particles=1_000_000, no_astar=True, map="convex_10mx10m_5cm"),     # slam.cpp:36-45: --localization-only <map>
                4: dict(grid=2000, lanes=3, batch=32, depth=128),
@@ -275,7 +276,7 @@ def main():
         raise SystemExit(self_launch(args.gpus))
     other = None
     if args.config == 0 and args.gpus == 1 and args.grid == 200 and not args.sub and not args.no_other_configs and "WORLD_SIZE" not in os.environ:
-        other = run_other_configs(args.other_steps, 40)
+        other = run_other_configs(args.other_steps, 150)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))

@@ -42,6 +42,7 @@ struct bl_dist {
     bool valid;
     // incremental transforms (see "incremental" below): what l1 is the transform of, and the device / pinned words of the scheme
     uint64_t src_id, src_version;
+    bool bound_ok;            // state[DST_DUB] bounds l1's distances (the merged column pass formed it)
     unsigned int* state;      // device: DST_* words
     unsigned int* h_status;   // pinned: the plan the last incremental launch settled on (DST_MODE_*), written by the device
     unsigned int* h_status_dev;
@@ -78,11 +79,8 @@ struct dist_batch {
 #define DST_Y0 3
 #define DST_X1 4
 #define DST_Y1 5
-#define DST_TICKET 6         // work items handed out by the merged column pass
-#define DST_ERROR 7          // a wait that did not end (never seen; the transform is then flagged invalid to the host)
-#define DST_GROUPS 8         // [DST_MAX_GROUPS] per column group: strips whose summaries are published
-#define DST_MAX_GROUPS 64    // grids up to 8192 columns / rows in the merged pass
-#define DST_STATS (DST_GROUPS + DST_MAX_GROUPS)   // [3] incremental launches that ended as: nothing to do, a window, the whole grid (diagnostic)
+#define DST_MAX_GROUPS 64    // grids up to 8192 columns / rows in the region kernels (macro strips whose summaries fit LDS)
+#define DST_STATS 8          // [3] incremental launches that ended as: nothing to do, a window, the whole grid (diagnostic)
 #define DST_WORDS (DST_STATS + 3)
 #define DST_MODE_NONE 0      // nothing changed
 #define DST_MODE_WINDOW 1
@@ -104,8 +102,6 @@ __device__ __forceinline__ void dist_plan_full(unsigned int* state, int W, int H
     state[DST_DUB] = 0u;
     state[DST_MODE] = DST_MODE_FULL;
     state[DST_X0] = 0u; state[DST_Y0] = 0u; state[DST_X1] = (unsigned int)(W - 1); state[DST_Y1] = (unsigned int)(H - 1);
-    state[DST_TICKET] = 0u; state[DST_ERROR] = 0u;
-    for (int i = 0; i < DST_MAX_GROUPS; ++i) state[DST_GROUPS + i] = 0u;
 }
 
 // Row pass: one workgroup per row; d_row[x] = min over sources x' in the row of |x - x'|.
@@ -456,7 +452,7 @@ __global__ __launch_bounds__(DC2_TX * DC2_TY) void k_dist_cols_apply(dist_batch 
         }
     }
     __syncthreads();
-    if (!live || y0 >= H) return;
+    if (live && y0 < H) {
     int E[2], B[2];
     for (int c = 0; c < 2; ++c) {
         // carry entering the macro strip from above (distance at row Y0 - 1) and from below (distance at row Y1)
@@ -488,10 +484,10 @@ __global__ __launch_bounds__(DC2_TX * DC2_TY) void k_dist_cols_apply(dist_batch 
     for (int i = DC2_SUB - 1; i >= 0; --i) {
         if (y0 + i >= H) continue;
         int v[2];
-        for (int c = 0; c < 2; ++c) { B[c] = min(g[i][c], B[c] + 1); v[c] = min(f[i][c], B[c]); }
-        const bool n0 = v[0] >= 0xFFFF, n1 = v[1] >= 0xFFFF;
+        for (int c = 0; c < 2; ++c) { B[c] = min(g[i][c], B[c] + 1); v[c] = min(min(f[i][c], B[c]), 0xFFFF); }
         const size_t at = (size_t)(y0 + i) * W + x;
-        *(unsigned int*)(l1 + at) = (n0 ? 0xFFFFu : (unsigned int)v[0]) | ((n1 ? 0xFFFFu : (unsigned int)v[1]) << 16);
+        *(unsigned int*)(l1 + at) = (unsigned int)v[0] | ((unsigned int)v[1] << 16);
+    }
     }
 }
 
@@ -549,9 +545,7 @@ __global__ __launch_bounds__(64 * DRI_WAVES) void k_dist_rows_inc(dist_batch db,
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         state[DST_MODE] = (unsigned int)mode;
         state[DST_X0] = (unsigned int)x0; state[DST_Y0] = (unsigned int)y0; state[DST_X1] = (unsigned int)x1; state[DST_Y1] = (unsigned int)y1;
-        state[DST_TICKET] = 0u; state[DST_ERROR] = 0u;
         if (mode == DST_MODE_FULL) state[DST_DUB] = 0u;                       // the column pass forms the bound anew
-        for (int i = 0; i < DST_MAX_GROUPS; ++i) state[DST_GROUPS + i] = 0u;
         state[DST_STATS + mode] += 1u;
         if (db.hstat[z]) __hip_atomic_store(db.hstat[z], (unsigned int)mode, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
@@ -615,17 +609,17 @@ __global__ __launch_bounds__(64 * DRI_WAVES) void k_dist_rows_inc(dist_batch db,
     }
 }
 
-// Column pass, summaries and application in ONE launch: a workgroup takes work items (column group of 128 columns, macro strip of
-// 128 rows) of the plan's region by ticket, keeps its tile of `row` in registers, publishes its strip's summaries (distance to the
-// nearest seed inside the strip as seen from its last and from its first row), counts itself in, waits until every strip of its
-// column group is in, chains the others' summaries into the carries entering its strip from above and below, and writes l1:
-// 2 B read + 2 B written per cell (k_dist_cols_summary + k_dist_cols_apply: 4 + 2 and two launches).  In a window plan the rows
-// just above / below the region seed the chains with their OLD distances.
-// Tickets are handed out in arrival order, column group by column group, so the strips a workgroup waits for are held by
-// workgroups that are already running or will get the next free slots: everything below the lowest unfinished group is complete
-// and drains.  A launch with fewer workgroups than items (the incremental form: the region is decided on the device) loops; it
-// needs more workgroups than a column group has strips (DST_MAX_GROUPS), which the host guarantees.
-__global__ __launch_bounds__(DC2_TX * DC2_TY) void k_dist_cols_merged(dist_batch db, int W, int H)
+// Column pass over the plan's region, as two launches of one kernel: PHASE 0 leaves, per macro strip (128 rows) and column of the
+// region, the distance to the nearest seed inside the strip as seen from its last and from its first row; PHASE 1 chains the
+// other strips' summaries into the carries entering a strip from above and below and writes l1.  In a window plan the rows just
+// above / below the region seed the chains with their OLD distances.  A workgroup takes the items (macro strip, column group of
+// 128 columns) blockIdx.x, blockIdx.x + gridDim.x, ... -- column groups of one strip side by side, so that the workgroups running
+// together stream whole rows; the launch is sized for the widest window and loops when the device settled on the whole grid.
+// Nothing in either launch waits for another workgroup (a first form did both phases in one launch, a workgroup waiting for the
+// summaries of its column group: beside the particle filter's kernels too few of its workgroups became resident together, and
+// the waits ran into their cap).
+template <int PHASE>
+__global__ __launch_bounds__(DC2_TX * DC2_TY) void k_dist_cols_region(dist_batch db, int W, int H)
 {
     const int z = blockIdx.z;
     unsigned int* state = db.state[z];
@@ -638,22 +632,18 @@ __global__ __launch_bounds__(DC2_TX * DC2_TY) void k_dist_cols_merged(dist_batch
     int* __restrict__ sum_b = db.sum_b[z];
     __shared__ int s_f[DC2_TY][2 * DC2_TX];
     __shared__ int s_b[DC2_TY][2 * DC2_TX];
-    extern __shared__ int s_dcm_sum[];                               // [2][strips of the grid][128]: the launch sizes it
+    extern __shared__ int s_dcm_sum[];                               // PHASE 1: [2][strips of the grid][128], sized by the launch
     const int strips_cap = (H + DC2_ROWS - 1) / DC2_ROWS;
     int (*s_sf)[2 * DC2_TX] = (int (*)[2 * DC2_TX])s_dcm_sum;
     int (*s_sb)[2 * DC2_TX] = (int (*)[2 * DC2_TX])(s_dcm_sum + (size_t)strips_cap * 2 * DC2_TX);
-    __shared__ int s_item, s_dub;
     const int tx = threadIdx.x, ty = threadIdx.y, t = ty * DC2_TX + tx;
     const int w = x1 - x0 + 1, h = y1 - y0 + 1;
     const int ngroups = (w + 2 * DC2_TX - 1) / (2 * DC2_TX), nstrips = (h + DC2_ROWS - 1) / DC2_ROWS;
     const int nitems = ngroups * nstrips;
     const bool ring = mode == DST_MODE_WINDOW;
-    while (true) {
-        if (t == 0) { s_item = (int)atomicAdd(&state[DST_TICKET], 1u); s_dub = 0; }
-        __syncthreads();
-        const int item = s_item;
-        if (item >= nitems) break;
-        const int cg = item / nstrips, st = item - cg * nstrips;
+    int dmax = 0;
+    for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
+        const int st = item / ngroups, cg = item - st * ngroups;
         const int x = x0 + cg * 2 * DC2_TX + 2 * tx;
         const int Y0 = y0 + st * DC2_ROWS;
         const int ya = Y0 + ty * DC2_SUB;
@@ -668,6 +658,15 @@ __global__ __launch_bounds__(DC2_TX * DC2_TY) void k_dist_cols_merged(dist_batch
             g[i][0] = a == 0xFFFF ? DIST_INF : a;
             g[i][1] = b == 0xFFFF ? DIST_INF : b;
         }
+        if (PHASE == 1) {
+            // the strips' summaries of this column group (PHASE 0's launch), every load in flight beside the tile's
+            for (int i = t; i < nstrips * 2 * DC2_TX; i += DC2_TX * DC2_TY) {
+                const int m = i / (2 * DC2_TX), cx = i - m * (2 * DC2_TX);
+                const int xg = x0 + cg * 2 * DC2_TX + cx;
+                s_sf[m][cx] = xg <= x1 ? sum_f[(size_t)m * W + xg] : DIST_INF;
+                s_sb[m][cx] = xg <= x1 ? sum_b[(size_t)m * W + xg] : DIST_INF;
+            }
+        }
         const int yend = min(y1 + 1, ya + DC2_SUB);                  // one past this thread row's last row
 #pragma unroll
         for (int i = 0; i < DC2_SUB; ++i)
@@ -678,44 +677,23 @@ __global__ __launch_bounds__(DC2_TX * DC2_TY) void k_dist_cols_merged(dist_batch
                 }
         for (int c = 0; c < 2; ++c) { s_f[ty][2 * tx + c] = a_f[c]; s_b[ty][2 * tx + c] = a_b[c]; }
         __syncthreads();
-        if (ty == 0 && live) {
-            for (int c = 0; c < 2; ++c) {
-                int F = DIST_INF, B = DIST_INF;
-                for (int s2 = 0; s2 < DC2_TY; ++s2) {
-                    const int sy0 = Y0 + s2 * DC2_SUB, len = max(0, min(y1 + 1, sy0 + DC2_SUB) - sy0);
-                    if (len > 0) F = min(s_f[s2][2 * tx + c], F + len);
+        if (PHASE == 0) {
+            if (ty == 0 && live) {
+                for (int c = 0; c < 2; ++c) {
+                    int F = DIST_INF, B = DIST_INF;
+                    for (int s2 = 0; s2 < DC2_TY; ++s2) {
+                        const int sy0 = Y0 + s2 * DC2_SUB, len = max(0, min(y1 + 1, sy0 + DC2_SUB) - sy0);
+                        if (len > 0) F = min(s_f[s2][2 * tx + c], F + len);
+                    }
+                    for (int s2 = DC2_TY - 1; s2 >= 0; --s2) {
+                        const int sy0 = Y0 + s2 * DC2_SUB, len = max(0, min(y1 + 1, sy0 + DC2_SUB) - sy0);
+                        if (len > 0) B = min(s_b[s2][2 * tx + c], B + len);
+                    }
+                    sum_f[(size_t)st * W + x + c] = min(F, DIST_INF);
+                    sum_b[(size_t)st * W + x + c] = min(B, DIST_INF);
                 }
-                for (int s2 = DC2_TY - 1; s2 >= 0; --s2) {
-                    const int sy0 = Y0 + s2 * DC2_SUB, len = max(0, min(y1 + 1, sy0 + DC2_SUB) - sy0);
-                    if (len > 0) B = min(s_b[s2][2 * tx + c], B + len);
-                }
-                dst_store(&sum_f[(size_t)st * W + x + c], min(F, DIST_INF));
-                dst_store(&sum_b[(size_t)st * W + x + c], min(B, DIST_INF));
             }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // the summaries have left before the strip counts itself in
-        }
-        __syncthreads();
-        if (t == 0) {
-            __hip_atomic_fetch_add(&state[DST_GROUPS + cg], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            // every strip of the column group (held by running workgroups, see above).  The cap only bounds a wait that cannot
-            // happen by construction (~2 s): the transform is then flagged.
-            long long spins = 0;
-            while (dst_load_u(&state[DST_GROUPS + cg]) < (unsigned int)nstrips) {
-                __builtin_amdgcn_s_sleep(2);
-                if (++spins > (1ll << 24)) { state[DST_ERROR] = 1u; break; }
-            }
-        }
-        __syncthreads();
-        // the other strips' summaries of this column group
-        for (int i = t; i < nstrips * 2 * DC2_TX; i += DC2_TX * DC2_TY) {
-            const int m = i / (2 * DC2_TX), cx = i - m * (2 * DC2_TX);
-            const int xg = x0 + cg * 2 * DC2_TX + cx;
-            s_sf[m][cx] = xg <= x1 ? dst_load(&sum_f[(size_t)m * W + xg]) : DIST_INF;
-            s_sb[m][cx] = xg <= x1 ? dst_load(&sum_b[(size_t)m * W + xg]) : DIST_INF;
-        }
-        __syncthreads();
-        int dmax = 0;
-        if (live && ya <= y1) {
+        } else if (live && ya <= y1) {
             int E[2], B[2];
             for (int c = 0; c < 2; ++c) {
                 // carries entering the strip: the distance at the row just above it / just below it
@@ -747,12 +725,39 @@ __global__ __launch_bounds__(DC2_TX * DC2_TY) void k_dist_cols_merged(dist_batch
                 *(unsigned int*)(l1 + (size_t)(ya + i) * W + x) = (unsigned int)v[0] | ((unsigned int)v[1] << 16);
             }
         }
-        // the bound D: largest value written (0xFFFF where no seed reaches)
-        for (int off = 32; off > 0; off >>= 1) dmax = max(dmax, __shfl_xor(dmax, off, 64));
-        if (tx == 0 && dmax > 0) atomicMax(&s_dub, dmax);
-        __syncthreads();
-        if (t == 0 && s_dub > 0) atomicMax(&state[DST_DUB], (unsigned int)s_dub);
+        __syncthreads();                                             // the LDS arrays are free for the next item
     }
+    if (PHASE == 1) {
+        // the bound D: largest value written (0xFFFF where no seed reaches) -- one atomic per workgroup, and only one that would
+        // raise it (same-address atomics serialise in the L2: one per wave of a whole-grid pass cost 150 us)
+        __shared__ int s_dmax;
+        if (t == 0) s_dmax = 0;
+        __syncthreads();
+        for (int off = 32; off > 0; off >>= 1) dmax = max(dmax, __shfl_xor(dmax, off, 64));
+        if (tx == 0 && dmax > 0) atomicMax(&s_dmax, dmax);
+        __syncthreads();
+        if (t == 0 && (unsigned int)s_dmax > dst_load_u(&state[DST_DUB])) atomicMax(&state[DST_DUB], (unsigned int)s_dmax);
+    }
+}
+
+// The bound D of a transform the whole-grid kernels made (they keep none: an atomic per workgroup would cost them more than this
+// pass over l1 costs the first incremental transform that needs it).  state[DST_DUB] is zero when it starts (dist_plan_full).
+__global__ __launch_bounds__(256) void k_dist_bound(const uint16_t* __restrict__ l1, size_t n8, unsigned int* state)
+{
+    __shared__ int s_dmax;
+    if (threadIdx.x == 0) s_dmax = 0;
+    __syncthreads();
+    unsigned int m = 0;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (size_t)gridDim.x * 256) {
+        const int4 v = ((const int4*)l1)[i];
+        const unsigned int w[4] = {(unsigned int)v.x, (unsigned int)v.y, (unsigned int)v.z, (unsigned int)v.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) m = max(m, max(w[k] & 0xFFFFu, w[k] >> 16));
+    }
+    for (int off = 32; off > 0; off >>= 1) m = max(m, (unsigned int)__shfl_xor((int)m, off, 64));
+    if ((threadIdx.x & 63) == 0 && m > 0) atomicMax(&s_dmax, (int)m);
+    __syncthreads();
+    if (threadIdx.x == 0 && s_dmax > 0) atomicMax(&state[DST_DUB], (unsigned int)s_dmax);
 }
 
 extern "C" int bl_dist_create(bl_ctx* ctx, bl_dist** out)
@@ -894,11 +899,12 @@ static int dist_set_distances_batch(int n, bl_dist* const* ds, const bl_grid* co
         BL_CHECK_ARG(maps[u]->frame.width == W && maps[u]->frame.height == H);
         bl_dist* d = ds[u];
         // what the device said about the last incremental launch (no waiting: the word is whatever has landed by now)
-        if (d->h_status && *d->h_status == 0xDEADu) { bl_set_error("distance transform: a column group never completed"); *d->h_status = 0; d->valid = false; return BL_ERR_STATE; }
         if (d->h_status && *d->h_status == (unsigned int)DST_MODE_FULL) { *d->h_status = 0; d->inc_holdoff = 16; }
         const bool inc = dist_can_increment(d, maps[u]);
         if (d->inc_holdoff > 0) d->inc_holdoff -= 1;
-        const bool same = inc && maps[u]->version == d->src_version;
+        // the very state of the very map d holds the transform of (any grid size; no log needed)
+        const bool same = d->valid && d->src_id != 0 && d->src_id == maps[u]->id && !maps[u]->mirror_external && maps[u]->version == d->src_version &&
+                          d->frame.width == W && d->frame.height == H;
         const uint64_t from = d->src_version;
         int rc = dist_prepare(d, maps[u]);
         if (rc) return rc;
@@ -918,15 +924,16 @@ static int dist_set_distances_batch(int n, bl_dist* const* ds, const bl_grid* co
     const size_t merged_lds = (size_t)2 * strips * 2 * DC2_TX * sizeof(int);
     static bool attr_set = false;
     if (!attr_set) {
-        BL_HIP(hipFuncSetAttribute((const void*)k_dist_cols_merged, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * DST_MAX_GROUPS * 2 * DC2_TX * (int)sizeof(int)));
+        BL_HIP(hipFuncSetAttribute((const void*)k_dist_cols_region<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * DST_MAX_GROUPS * 2 * DC2_TX * (int)sizeof(int)));
         attr_set = true;
     }
     hipEvent_t e0, e1;
     int rc = bl_timer_begin(ctx, BL_K_DIST, &e0, &e1);
     if (rc) return rc;
     hipEvent_t f0, f1;
-    static const bool two_pass = getenv("BOTLAB_DIST_TWO_PASS_COLS") != nullptr;         // A/B: round 2's summary + apply kernels
-    const bool bound_kept = all_inc || (merged && !two_pass);                            // the column pass leaves the bound D behind
+    // BOTLAB_DIST_REGION_COLS=1: a transform of the whole grid goes through the region kernels too (their plan = the grid): tests
+    static const bool region_kernels = getenv("BOTLAB_DIST_REGION_COLS") != nullptr;
+    const bool bound_kept = all_inc || (merged && region_kernels);                       // the column pass leaves the bound D behind
     if (all_inc) {
         // the window (or, failing that, the whole grid) is settled by the kernels themselves
         rc = bl_timer_begin(ctx, BL_K_DIST_ROWS, &f0, &f1);
@@ -934,9 +941,15 @@ static int dist_set_distances_batch(int n, bl_dist* const* ds, const bl_grid* co
         hipLaunchKernelGGL(k_dist_rows_inc, dim3(DINC_MAX / DRI_WAVES, 1, n), dim3(64 * DRI_WAVES), 0, ctx->stream, b, W, H);
         rc = bl_timer_end(ctx, BL_K_DIST_ROWS, f0, f1);
         if (rc) return rc;
+        const int win_items = (DINC_MAX / (2 * DC2_TX)) * (DINC_MAX / DC2_ROWS);       // the widest window's items
+        rc = bl_timer_begin(ctx, BL_K_DIST_COLS_SUMMARY, &f0, &f1);
+        if (rc) return rc;
+        hipLaunchKernelGGL(k_dist_cols_region<0>, dim3(win_items, 1, n), dim3(DC2_TX, DC2_TY), 0, ctx->stream, b, W, H);
+        rc = bl_timer_end(ctx, BL_K_DIST_COLS_SUMMARY, f0, f1);
+        if (rc) return rc;
         rc = bl_timer_begin(ctx, BL_K_DIST_COLS_APPLY, &f0, &f1);
         if (rc) return rc;
-        hipLaunchKernelGGL(k_dist_cols_merged, dim3(DST_MAX_GROUPS + 16, 1, n), dim3(DC2_TX, DC2_TY), merged_lds, ctx->stream, b, W, H);
+        hipLaunchKernelGGL(k_dist_cols_region<1>, dim3(win_items, 1, n), dim3(DC2_TX, DC2_TY), merged_lds, ctx->stream, b, W, H);
         rc = bl_timer_end(ctx, BL_K_DIST_COLS_APPLY, f0, f1);
         if (rc) return rc;
     } else {
@@ -947,11 +960,16 @@ static int dist_set_distances_batch(int n, bl_dist* const* ds, const bl_grid* co
         else hipLaunchKernelGGL(k_dist_rows, dim3(H, 1, n), dim3(256), 0, ctx->stream, b, W);
         rc = bl_timer_end(ctx, BL_K_DIST_ROWS, f0, f1);
         if (rc) return rc;
-        if (merged && !two_pass) {
+        if (merged && region_kernels) {
             const int groups = (W + 2 * DC2_TX - 1) / (2 * DC2_TX);
+            rc = bl_timer_begin(ctx, BL_K_DIST_COLS_SUMMARY, &f0, &f1);
+            if (rc) return rc;
+            hipLaunchKernelGGL(k_dist_cols_region<0>, dim3(groups * strips, 1, n), dim3(DC2_TX, DC2_TY), 0, ctx->stream, b, W, H);
+            rc = bl_timer_end(ctx, BL_K_DIST_COLS_SUMMARY, f0, f1);
+            if (rc) return rc;
             rc = bl_timer_begin(ctx, BL_K_DIST_COLS_APPLY, &f0, &f1);
             if (rc) return rc;
-            hipLaunchKernelGGL(k_dist_cols_merged, dim3(groups * strips, 1, n), dim3(DC2_TX, DC2_TY), merged_lds, ctx->stream, b, W, H);
+            hipLaunchKernelGGL(k_dist_cols_region<1>, dim3(groups * strips, 1, n), dim3(DC2_TX, DC2_TY), merged_lds, ctx->stream, b, W, H);
             rc = bl_timer_end(ctx, BL_K_DIST_COLS_APPLY, f0, f1);
             if (rc) return rc;
         } else if (H >= 4 * DC2_ROWS && W >= 4 * DC2_TX && (W & 1) == 0) {
@@ -983,8 +1001,8 @@ static int dist_set_distances_batch(int n, bl_dist* const* ds, const bl_grid* co
         if (all_inc) d->n_inc += 1; else d->n_full += 1;
         // l1 is now the transform of this version of this lineage (the small-grid and two-pass column kernels keep no bound D: the
         // next transform is a full one as well)
-        if (bound_kept) { d->src_id = bl_grid_lineage_id(maps[u]); d->src_version = maps[u]->version; }
-        else d->src_id = 0;
+        d->src_id = bl_grid_lineage_id(maps[u]); d->src_version = maps[u]->version;
+        d->bound_ok = bound_kept;
     }
     return BL_OK;
 }
@@ -993,6 +1011,14 @@ extern "C" int bl_dist_set_distances(bl_dist* d, const bl_grid* map)
 {
     BL_CHECK_ARG(d != nullptr && map != nullptr);
     return dist_set_distances_batch(1, &d, &map);
+}
+
+// the next setDistances transforms the whole map, whatever `d` holds now (timing the whole-grid kernels; tests)
+extern "C" int bl_dist_forget(bl_dist* d)
+{
+    BL_CHECK_ARG(d != nullptr);
+    d->src_id = 0; d->bound_ok = false;
+    return BL_OK;
 }
 
 // transforms by kind: {incremental launches, whole-grid launches, calls that found the map unchanged, and of the incremental
@@ -2304,6 +2330,61 @@ int bl_planner_commit(bl_planner* p, const bl_pose_xyt_t* goal, const bl_search_
     return BL_OK;
 }
 
+// The same snapshot when the slot still holds an EARLIER version of this very map (a slot is reused every 2 x lanes x batch
+// submissions): only the cells the map updates in between may have changed are copied -- the union of their boxes in the
+// lineage's log (bl_internal.h), settled on the device; a log entry that is gone makes the same launch copy the whole grid.
+// 16 MB per step become ~100 KB on a 4096 x 4096 map (k_planner_snapshot: 9.8 us of the SLAM stream per step there).
+#define SNAP_INC_WGS 128
+__global__ __launch_bounds__(256) void k_planner_snapshot_inc(const int8_t* __restrict__ src, int8_t* __restrict__ dst, int W, int H,
+                                                              const int4* __restrict__ log, unsigned int from, unsigned int to,
+                                                              const bl_pose_xyt_t* __restrict__ src_pose, bl_pose_xyt_t* __restrict__ dst_pose)
+{
+    __shared__ int s_box[5];
+    const int lane = threadIdx.x & 63;
+    if (threadIdx.x < 64) {
+        int bx0 = 0x7fffffff, by0 = 0x7fffffff, bx1 = -1, by1 = -1;
+        bool lost = to - from > (unsigned int)(BL_DIRTY_LOG - 32);
+        if (!lost)
+            for (unsigned int v = from + 1u + (unsigned int)lane; v <= to; v += 64u) {
+                const int4 e = log[v % BL_DIRTY_LOG];
+                if ((unsigned int)e.z != v) { lost = true; continue; }
+                const int x0 = e.x & 0xffff, y0 = (int)((unsigned int)e.x >> 16), x1 = e.y & 0xffff, y1 = (int)((unsigned int)e.y >> 16);
+                if (x1 < x0 || y1 < y0) continue;
+                bx0 = min(bx0, x0); by0 = min(by0, y0); bx1 = max(bx1, x1); by1 = max(by1, y1);
+            }
+        for (int off = 32; off > 0; off >>= 1) {
+            bx0 = min(bx0, __shfl_xor(bx0, off, 64)); by0 = min(by0, __shfl_xor(by0, off, 64));
+            bx1 = max(bx1, __shfl_xor(bx1, off, 64)); by1 = max(by1, __shfl_xor(by1, off, 64));
+        }
+        lost = __builtin_amdgcn_ballot_w64(lost) != 0ull;
+        if (lane == 0) {
+            if (lost) { bx0 = 0; by0 = 0; bx1 = W - 1; by1 = H - 1; }
+            s_box[0] = bx0 & ~15; s_box[1] = by0; s_box[2] = min(bx1 | 15, W - 1); s_box[3] = by1; s_box[4] = bx1 >= bx0 ? 1 : 0;
+        }
+    }
+    __syncthreads();
+    if (blockIdx.x == 0 && threadIdx.x == 0) *dst_pose = *src_pose;
+    if (!s_box[4]) return;
+    const int x0 = s_box[0], y0 = s_box[1], x1 = s_box[2], y1 = s_box[3];
+    const int q = (x1 - x0 + 1) >> 4;                              // 16-byte pieces per row (W is a multiple of 16)
+    const long long total = (long long)q * (y1 - y0 + 1);
+    for (long long base = (long long)blockIdx.x * blockDim.x + threadIdx.x; base < total; base += 4ll * gridDim.x * blockDim.x) {
+        int4 v[4];
+        size_t at[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const long long i = base + (long long)u * gridDim.x * blockDim.x;
+            at[u] = 0;
+            if (i < total) { const int r = (int)(i / q), c = (int)(i - (long long)r * q); at[u] = (size_t)(y0 + r) * W + x0 + 16 * c; v[u] = *(const int4*)(src + at[u]); }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const long long i = base + (long long)u * gridDim.x * blockDim.x;
+            if (i < total) *(int4*)(dst + at[u]) = v[u];
+        }
+    }
+}
+
 extern "C" int bl_planner_submit(bl_planner* p, const bl_grid* map, const void* d_start_pose, const bl_pose_xyt_t* goal,
                                  const bl_search_params_t* params)
 {
@@ -2312,14 +2393,25 @@ extern "C" int bl_planner_submit(bl_planner* p, const bl_grid* map, const void* 
     int rc = bl_planner_reserve(p, map, &sn);
     if (rc) return rc;
     const size_t n = (size_t)map->frame.width * map->frame.height;
-    int blocks = (int)((n / 16 + 255) / 256);
-    if (blocks < 1) blocks = 1;
-    if (blocks > 2048) blocks = 2048;
     hipEvent_t f0, f1;
     rc = bl_timer_begin(p->main, BL_K_SNAPSHOT, &f0, &f1);
     if (rc) return rc;
-    hipLaunchKernelGGL(k_planner_snapshot, dim3(blocks), dim3(256), 0, p->main->stream, map->cells, sn.cells, n,
-                       (const bl_pose_xyt_t*)d_start_pose, sn.pose, sn.done_count, sn.flag, sn.seq);
+    static const bool no_inc = getenv("BOTLAB_SNAPSHOT_NO_INCREMENTAL") != nullptr;
+    const bl_grid* old = sn.grid;
+    const bool inc = !no_inc && !sn.flag && old->id != 0 && old->id == map->id && !map->mirror_external && map->log != nullptr &&
+                     old->version <= map->version && map->version - old->version <= (uint64_t)(BL_DIRTY_LOG - 64) &&
+                     (map->frame.width & 15) == 0 && n >= ((size_t)1 << 20);
+    if (inc) {
+        hipLaunchKernelGGL(k_planner_snapshot_inc, dim3(SNAP_INC_WGS), dim3(256), 0, p->main->stream, map->cells, sn.cells, map->frame.width,
+                           map->frame.height, map->log->dev, (unsigned int)old->version, (unsigned int)map->version,
+                           (const bl_pose_xyt_t*)d_start_pose, sn.pose);
+    } else {
+        int blocks = (int)((n / 16 + 255) / 256);
+        if (blocks < 1) blocks = 1;
+        if (blocks > 2048) blocks = 2048;
+        hipLaunchKernelGGL(k_planner_snapshot, dim3(blocks), dim3(256), 0, p->main->stream, map->cells, sn.cells, n,
+                           (const bl_pose_xyt_t*)d_start_pose, sn.pose, sn.done_count, sn.flag, sn.seq);
+    }
     BL_HIP(hipGetLastError());
     rc = bl_timer_end(p->main, BL_K_SNAPSHOT, f0, f1);
     if (rc) return rc;

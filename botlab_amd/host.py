@@ -360,6 +360,10 @@ class ObstacleDistanceGrid:
         check(self.ctx.lib.bl_dist_set_distances(self.h, grid.h))
         self._host = None
 
+    def forget(self):
+        """The next setDistances transforms the whole map (bl_dist_forget)."""
+        check(self.ctx.lib.bl_dist_forget(self.h))
+
     def stats(self):
         """How the transforms of this grid went out (bl_dist_debug_stats)."""
         v = (C.c_int64 * 6)()

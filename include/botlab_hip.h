@@ -189,6 +189,7 @@ void bl_dist_destroy(bl_dist* d);
  * those updates can influence is transformed again (grids of at least 1024 cells a side); the result is the full transform's,
  * bit for bit.  BOTLAB_DIST_NO_INCREMENTAL=1 always transforms the whole grid. */
 int bl_dist_set_distances(bl_dist* d, const bl_grid* map);
+int bl_dist_forget(bl_dist* d);             /* the next bl_dist_set_distances transforms the whole map, whatever d holds now */
 /* diagnostic, six counts: setDistances calls that went out as an incremental launch / as a whole-grid launch / found the map
  * unchanged; and of the incremental launches those the device ended with nothing to do / a window / the whole grid */
 int bl_dist_debug_stats(bl_dist* d, int64_t* out6);

@@ -16,7 +16,7 @@ grid = bl.OccupancyGrid.from_cells(m["cells"], m["origin"], m["mpc"], cellsPerMe
 planner = bl.MotionPlanner(ctx=ctx)
 t0 = time.perf_counter(); planner.setMap(grid); ctx.sync(); t1 = time.perf_counter()
 for _ in range(5):
-    planner.setMap(grid)
+    planner.distances_.forget(); planner.setMap(grid)
 ctx.sync(); t2 = time.perf_counter()
 print(f"setDistances {side}^2: first {1e3 * (t1 - t0):.2f} ms, then {1e3 * (t2 - t1) / 5:.3f} ms")
 goal = bench.pick_goal(planner.distances_.cells(), m["origin"], poses[0][:2], 0.2, args.goal_l1)
