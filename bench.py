@@ -309,7 +309,17 @@ def main():
     total = args.steps + args.warmup + 34
     cpm = np.float32(1.0 / np.float64(np.float32(0.05)))
 
-    engine = sharded.HipShardEngine(args.particles, rank, world, local_rank)
+    # Sharded runs take the composed finish (own blocks, sources read from their owners' memory, two small all-gathers: DESIGN.md
+    # section 6) when every rank can map every other rank's memory -- asked before the engines are made, because the two forms
+    # cut the particle set at different bounds; otherwise the replicated form (all-gather of the whole record).
+    composed = False
+    if world > 1 and sharded.composed_possible(args.particles, world):
+        probe = bl.Context(local_rank)
+        composed = sharded.ipc_probe(probe, rank, world)
+        probe.close()
+        if rank == 0:
+            sys.stderr.write(f"[bench] shard exchange: {'composed finish' if composed else 'replicated record (no IPC mapping between the ranks)'}\n")
+    engine = sharded.HipShardEngine(args.particles, rank, world, local_rank, composed=composed)
     ctx = engine.ctx
     # The replanner on its own stream(s) (the reference's planner process); consecutive replans overlap on `lanes` streams.
     # Created before anything touches the null stream: the HIP runtime multiplexes streams onto 4 hardware queues (raising
@@ -569,8 +579,9 @@ def main():
                        "particles": N, "grid": [W, H], "rays": R, "pipeline_depth": args.depth, "planner_lanes": args.lanes, "planner_batch": args.batch,
                        "parallelism": f"particle-shard x{world}" if world > 1 else "single GPU",
                        "collective": ("none" if not (world > 1 or spf.force_collectives) else
-                                      ("RCCL all-gather enqueued by the library on the filter's stream" if spf.comm is not None
-                                       else "torch.distributed all_gather_into_tensor"))},
+                                      (("two small RCCL all-gathers (tile sums; records + tables)" if spf.composed else "RCCL all-gather of the whole record")
+                                       + " enqueued by the library on the filter's stream" if spf.comm is not None
+                                       else "torch.distributed all_gather_into_tensor" + (" x2 (composed finish)" if spf.composed else "")))},
             "roofline": {"bound": "hbm", "kernel": "k_mcl_main", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": main_ms,
@@ -587,6 +598,11 @@ def main():
             "final_pose": [pose.x, pose.y, pose.theta],
             "truth_pose": [float(v) for v in poses[k]],
         }
+        if world > 1 or spf.force_collectives:
+            sent, received, own = spf.exchange_bytes_per_update()
+            out["shard_exchange"] = {"form": "composed finish" if spf.composed else "replicated record", "bytes_sent_per_rank_per_step": sent,
+                                     "bytes_received_per_rank_per_step": received, "source_record_bytes_read_by_k_mcl_main": own,
+                                     "replicated_form_would_receive": (world - 1) * engine.S * 16}
         if world == 1 and stream_k is not None:
             out["streaming_kernels"] = stream_k
         if other is not None:

@@ -121,6 +121,19 @@ SIGNATURES = {
     "bl_comm_create": (C.c_int, [_vp, C.c_char_p, C.c_char_p, C.c_int, C.c_int, _P(_vp)]),
     "bl_comm_destroy": (None, [_vp]),
     "bl_comm_all_gather_inplace": (C.c_int, [_vp, _vp, C.c_size_t]),
+    "bl_dev_alloc": (C.c_int, [_vp, C.c_size_t, _P(_vp)]),
+    "bl_dev_free": (C.c_int, [_vp]),
+    "bl_ipc_export": (C.c_int, [_vp, C.c_char_p]),
+    "bl_ipc_open": (C.c_int, [C.c_char_p, _P(_vp)]),
+    "bl_ipc_close": (C.c_int, [_vp]),
+    "bl_pf_shard_setup": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int]),
+    "bl_pf_shard_local_ptrs": (C.c_int, [_vp, _P(_vp), _P(_vp), _P(_vp)]),
+    "bl_pf_shard_set_peer": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp]),
+    "bl_pf_shard_commit": (C.c_int, [_vp]),
+    "bl_pf_shard_buffers": (C.c_int, [_vp, _P(_vp), _P(C.c_size_t), _P(_vp), _P(C.c_size_t)]),
+    "bl_pf_shard_stage": (C.c_int, [_vp, C.c_int]),
+    "bl_pf_shard_exchange": (C.c_int, [_vp, _vp]),
+    "bl_pf_shard_traffic": (C.c_int, [_vp, _vp]),
     "bl_planner_submit_with_map_update_finishing_pf": (C.c_int, [_vp, _vp, _P(Lidar), _vp, C.c_int64, _vp, _P(Pose), _P(SearchParams)]),
     "bl_astar_search_batch": (C.c_int, [_vp, _vp, _P(Pose), _vp, C.c_int, _P(SearchParams), _vp, C.c_int, _vp, _vp]),
     "bl_dist_gather": (C.c_int, [_vp, _vp, C.c_int, _vp]),

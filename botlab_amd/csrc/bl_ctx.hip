@@ -406,6 +406,23 @@ void bl_scan_free(bl_ctx* ctx)
     sd->base = nullptr; sd->alt_times = nullptr; sd->alt_ranges = nullptr; sd->alt_thetas = nullptr; sd->pre_pending = false;
 }
 
+// plain device allocations for a host that has no allocator of its own at hand (botlab_amd/sharded.py probes whether the ranks
+// can map each other's memory before it commits to the composed finish)
+extern "C" int bl_dev_alloc(bl_ctx* ctx, size_t bytes, void** out)
+{
+    BL_CHECK_ARG(ctx != nullptr && out != nullptr && bytes > 0);
+    BL_HIP(hipSetDevice(ctx->device));
+    BL_HIP(hipMalloc(out, bytes));
+    BL_HIP(hipMemsetAsync(*out, 0, bytes, ctx->stream));
+    BL_HIP(hipStreamSynchronize(ctx->stream));
+    return BL_OK;
+}
+extern "C" int bl_dev_free(void* p)
+{
+    if (p) BL_HIP(hipFree(p));
+    return BL_OK;
+}
+
 // ---------------------------------------------------------------- grid lineage + dirty log (bl_internal.h)
 #include <atomic>
 static std::atomic<uint64_t> g_next_lineage{1};

@@ -639,7 +639,7 @@ static int mapping_update_impl(bl_mapping* m, const bl_lidar_t* scan, const bl_p
     a.pre = bl_scan_prefetch_args{};
     a.pre_on = bl_scan_prefetch_take(ctx, &a.pre);
     static_assert(MCLF_WG == MAP_THREADS, "the riding finish uses the map kernel's workgroup size");
-    hipLaunchKernelGGL(k_map_update, dim3(1 + (fin ? fin->groups + MAP_RIDER_WGS - 1 : 0) + a.pre_on), dim3(MAP_THREADS), MAP_LDS_COUNTERS * 2, ctx->stream, a);
+    hipLaunchKernelGGL(k_map_update, dim3(1 + (fin ? fin->groups_wait + MAP_RIDER_WGS - 1 : 0) + a.pre_on), dim3(MAP_THREADS), MAP_LDS_COUNTERS * 2, ctx->stream, a);
     BL_HIP(hipGetLastError());
     rc = bl_timer_end(ctx, BL_K_MAP, e0, e1);
     if (rc) return rc;

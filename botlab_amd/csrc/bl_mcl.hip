@@ -81,6 +81,17 @@ struct bl_pf {
     bool initialized;
     bool pending_end;         // update_begin issued, update_end not yet
     int64_t pending_utime;
+    // composed finish of a sharded set (bl_pf_shard_*): rank, world, particles per rank; the other ranks' exchange records and
+    // weight prefixes as this process sees them (its own included); the exchange blocks of the finish
+    int sh_rank, sh_world, sh_block, sh_world_pending;
+    const float4* sh_peer_rec[2][BL_MAX_SHARDS];                  // host copies of the tables below
+    const unsigned long long* sh_peer_prefix[BL_MAX_SHARDS];
+    bool sh_stage_sums, sh_stage_groups;       // the stages of the running update's exchange that have been enqueued
+    struct mcl_shard_tab* sh_tab;              // device [2]: the tables k_mcl_main reads sources through, for cur = 0 / 1
+    mclf_shards* sh_fin;                       // device [2]: the finish's view, for the record written by an update from cur = 0 / 1
+    char* sh_xchg; size_t sh_xchg_stride;      // the exchange blocks of the finish (this rank's and, gathered, every rank's)
+    int sh_subs_per_rank;
+    int64_t sh_bytes_pulled_bound;             // (diagnostic) upper bound of the bytes the last k_mcl_main may have read from other ranks
 };
 
 // ---------------------------------------------------------------- device helpers
@@ -431,6 +442,21 @@ struct mcl_args {
     int stage_dma;                // whole-grid staging by LDS-DMA (rows of whole dwords, at most 64 of them)
     float max_range_cells;        // longest kept ray in cells
     int main_blocks, main_particles;   // region 1: main_blocks workgroups cover particles [0, main_particles) of the shard
+    // composed finish of a sharded set (null otherwise): source records and weight prefix of particle i lie with rank i / block, as
+    // this process sees that rank's arrays (its own, or another rank's through an IPC mapping), indexed by the global i.  A table
+    // in device memory: indexing a table inside this by-value argument per lane would move the argument into scratch.
+    const struct mcl_shard_tab* sh;
+};
+struct mcl_shard_tab { int world, block; const float4* src[BL_MAX_SHARDS]; const unsigned long long* prefix[BL_MAX_SHARDS]; };
+
+__device__ __forceinline__ float4 mcl_src_at(const mcl_args& a, int i)
+{
+    if (a.sh) return a.sh->src[i / a.sh->block][i];
+    return a.src[i];
+}
+struct mcl_prefix_view {              // what the resampling search reads the cumulative through
+    const mcl_shard_tab* sh; const unsigned long long* flat;
+    __device__ __forceinline__ unsigned long long operator[](int i) const { return sh ? sh->prefix[i / sh->block][i] : flat[i]; }
 };
 
 __device__ __forceinline__ void philox_normals3(uint32_t m, uint32_t step, uint32_t k0, uint32_t k1, float z[3])
@@ -510,7 +536,8 @@ __device__ __forceinline__ bool resample_reaches(double T, unsigned long long v,
     return strict ? T <= __longlong_as_double((long long)v) : T <= (double)v;
 }
 
-__device__ __forceinline__ void resample_bracket(const unsigned long long* __restrict__ prefix, int N, double T, bool active,
+template <class Prefix>
+__device__ __forceinline__ void resample_bracket(const Prefix& prefix, int N, double T, bool active,
                                                  int lane, int* out_lo, int* out_hi, bool strict = false)
 {
     *out_lo = 0; *out_hi = N - 1;
@@ -533,7 +560,8 @@ __device__ __forceinline__ void resample_bracket(const unsigned long long* __res
 }
 
 // second part: the lane's own bisection inside the bracket.  index(T) = first i with T <= prefix[i] (clamped by the bracket).
-__device__ __forceinline__ int resample_bisect(const unsigned long long* __restrict__ prefix, double T, int lo, int hi, bool strict = false)
+template <class Prefix>
+__device__ __forceinline__ int resample_bisect(const Prefix& prefix, double T, int lo, int hi, bool strict = false)
 {
     while (lo < hi) {
         const int mid = (lo + hi) >> 1;
@@ -739,15 +767,16 @@ __global__ __launch_bounds__(BLOCK) void k_mcl_main(mcl_args a)
     // ---- resamplePosteriorDistribution (particle_filter.cpp:84-103): first index with T <= prefix[i], clamped to N-1
     double rs_T = 0.0;
     int rs_lo = 0, rs_hi = a.N - 1;
+    const mcl_prefix_view pview = {a.sh, a.prefix};
     if (a.resample && (!shared_pro || wave < pw)) {                  // whole waves: the narrowing is cooperative
         if (pro_active) { rs_T = a.r + mp * a.M_inv; if (!a.strict) rs_T *= a.state->S; }      // U (particle_filter.cpp:95), or U * S
-        resample_bracket(a.prefix, a.N, rs_T, pro_active, lane, &rs_lo, &rs_hi, a.strict != 0);
+        resample_bracket(pview, a.N, rs_T, pro_active, lane, &rs_lo, &rs_hi, a.strict != 0);
     }
     MCL_STAMP(5);                                                // the bracket is known
     if (pro_active) {
-        if (a.resample) i = resample_bisect(a.prefix, rs_T, rs_lo, rs_hi, a.strict != 0);
+        if (a.resample) i = resample_bisect(pview, rs_T, rs_lo, rs_hi, a.strict != 0);
         MCL_STAMP(6);
-        s = a.src[i];
+        s = mcl_src_at(a, i);
         // ---- ActionModel::applyAction (action_model.cpp:78-103)
         float n1, n2, n3;
         if (a.noise) {
@@ -890,13 +919,18 @@ __global__ __launch_bounds__(BLOCK) void k_mcl_main(mcl_args a)
 // theta from the sin / cos sums and the binade predictions of the x / y accumulators from the others).  The order of every
 // addition is a function of N alone (items in a thread, shuffle tree in a wave, waves in order), so the estimate does not
 // depend on how the particles were sharded: after the all-gather every rank derives it from the record itself.
+// (tile0: the first tile this launch sums -- a rank of a composed finish sums the tiles of its own block only; clear_word: a word
+// the launch zeroes on the way, that rank's table counter)
 __global__ __launch_bounds__(SCAN_THREADS) void k_scan_tile_sums(const float4* __restrict__ rec, int N,
                                                                  unsigned long long* __restrict__ tile_sums,
-                                                                 double* __restrict__ tile_partials)
+                                                                 double* __restrict__ tile_partials, int tile0 = 0,
+                                                                 unsigned long long* clear_word = nullptr)
 {
     __shared__ unsigned long long s[SCAN_THREADS / 64];
     __shared__ double s_pose[SCAN_THREADS / 64][4];
-    const int base = blockIdx.x * SCAN_TILE + threadIdx.x * SCAN_ITEMS;
+    if (clear_word && blockIdx.x == 0 && threadIdx.x == 0) *clear_word = 0ull;
+    const int tile = tile0 + (int)blockIdx.x;
+    const int base = tile * SCAN_TILE + threadIdx.x * SCAN_ITEMS;
     unsigned long long v = 0;
     double e[4] = {0, 0, 0, 0};
     if (tile_partials) {
@@ -924,13 +958,13 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan_tile_sums(const float4* _
     if (threadIdx.x == 0) {
         unsigned long long t = 0;
         for (int w = 0; w < SCAN_THREADS / 64; ++w) t += s[w];
-        tile_sums[blockIdx.x] = t;
-        if (tile_partials) tile_partials[(size_t)blockIdx.x * 5] = (double)t;
+        tile_sums[tile] = t;
+        if (tile_partials) tile_partials[(size_t)tile * 5] = (double)t;
     }
     if (tile_partials && threadIdx.x < 4) {
         double t = 0;
         for (int w = 0; w < SCAN_THREADS / 64; ++w) t += s_pose[w][threadIdx.x];
-        tile_partials[(size_t)blockIdx.x * 5 + 1 + threadIdx.x] = t;
+        tile_partials[(size_t)tile * 5 + 1 + threadIdx.x] = t;
     }
 }
 
@@ -983,6 +1017,14 @@ __global__ __launch_bounds__(MCLF_WG) void k_mcl_finish(mcl_finish_args f)
     if (blockIdx.x == 0) mclf_pose(f, sm, s_fin_scratch, (size_t)MCLF_LDS_BYTES);
     else if (blockIdx.x == 1) mclf_pre_chain(f, sm);
     else mclf_prefix_group(f, (int)blockIdx.x - MCLF_EXTRA_WGS, sm);
+}
+
+// The groups of one rank of a composed finish (bl_mcl_finish.h, mclf_shards): weight prefix of its own particles -- global values:
+// the tile sums of every rank are here by then -- and their sub-tile records and tables, left in the rank's exchange block.
+__global__ __launch_bounds__(MCLF_WG) void k_shard_groups(mcl_finish_args f, int group0)
+{
+    __shared__ mclf_smem sm;
+    mclf_prefix_group(f, group0 + (int)blockIdx.x, sm);
 }
 
 // resamplePosteriorDistribution alone (particle_filter.cpp:84-103): the source index of every output particle, by exactly the
@@ -1229,7 +1271,7 @@ extern "C" void bl_pf_destroy(bl_pf* pf)
     (void)hipStreamSynchronize(pf->ctx->stream);
     if (!pf->rec_external) { if (pf->rec[0]) (void)hipFree(pf->rec[0]); if (pf->rec[1]) (void)hipFree(pf->rec[1]); }
     void* ptrs[] = {pf->tile_partials, pf->fin_recs, pf->fin_tabs, pf->fin_sync, pf->prefix, pf->parent, pf->state, pf->partials, pf->block_sums, pf->dbg_idx, pf->dbg_like,
-                    pf->d_noise, pf->d_export};
+                    pf->d_noise, pf->d_export, pf->sh_xchg, pf->sh_tab, pf->sh_fin};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     delete pf;
 }
@@ -1265,11 +1307,14 @@ static int pf_finish_fill(bl_pf* pf, mcl_finish_args* f)
         f->gthreads = MCLF_GT_LARGE;
     }
     const int groups = mclf_groups(*f);
-    if ((int64_t)groups * (f->gthreads >> 6) > pf->fin_subs_cap) return -1;
     f->groups = groups;
+    f->groups_wait = groups;
+    f->sh = nullptr;
     f->recs = pf->fin_recs;
     f->tabs = pf->fin_tabs;
     f->sync = pf->fin_sync;
+    if (pf->sh_world > 1) return groups;                     // (a composed finish keeps its records in the exchange blocks)
+    if ((int64_t)groups * (f->gthreads >> 6) > pf->fin_subs_cap) return -1;
     return groups;
 }
 
@@ -1291,7 +1336,7 @@ static int pf_scan(bl_pf* pf, int which, int write_pose, int64_t utime)
         f.prefix = pf->prefix; f.state = pf->state; f.utime = utime;
         const int groups = pf_finish_fill(pf, &f);
         if (groups < 0) { bl_set_error("internal: finish launch shape"); return BL_ERR_STATE; }
-        hipLaunchKernelGGL(k_mcl_finish, dim3(MCLF_EXTRA_WGS + groups), dim3(MCLF_WG), MCLF_LDS_BYTES, ctx->stream, f);
+        hipLaunchKernelGGL(k_mcl_finish, dim3(MCLF_EXTRA_WGS + f.groups_wait), dim3(MCLF_WG), MCLF_LDS_BYTES, ctx->stream, f);
     } else {
         hipLaunchKernelGGL(k_scan_write_prefix, dim3(pf->scan_blocks), dim3(SCAN_THREADS), 0, ctx->stream, pf->rec[which], pf->N,
                            pf->block_sums, pf->scan_blocks, pf->prefix, pf->state);
@@ -1552,6 +1597,8 @@ static int pf_launch_main(bl_pf* pf, const bl_grid* map, int R, int rand_value, 
         }
     }
     a.main_blocks = (int)main_blocks; a.main_particles = (int)main_particles;
+    a.sh = pf->sh_world > 1 ? pf->sh_tab + pf->cur : nullptr;       // composed finish: sources lie with their owners
+    pf->sh_stage_sums = pf->sh_stage_groups = false;
     int blocks = (int)(main_blocks + tail_blocks);
     if (blocks > pf->partials_cap) { bl_set_error("internal: partials buffer too small"); return BL_ERR_STATE; }
     hipEvent_t e0, e1;
@@ -1604,11 +1651,13 @@ static int pf_finish_fused(bl_pf* pf, int which, int64_t utime)
     hipEvent_t e0, e1;
     int rc = bl_timer_begin(ctx, BL_K_MCL_SCAN, &e0, &e1);
     if (rc) return rc;
-    hipLaunchKernelGGL(k_mcl_finish, dim3(MCLF_EXTRA_WGS + groups), dim3(MCLF_WG), MCLF_LDS_BYTES, ctx->stream, f);
+    hipLaunchKernelGGL(k_mcl_finish, dim3(MCLF_EXTRA_WGS + f.groups_wait), dim3(MCLF_WG), MCLF_LDS_BYTES, ctx->stream, f);
     BL_HIP(hipGetLastError());
     pf_strict_cumulative(pf, which);
     return bl_timer_end(ctx, BL_K_MCL_SCAN, e0, e1);
 }
+
+static int pf_shard_fin_args(bl_pf* pf, int which, int64_t utime, mcl_finish_args* f);
 
 extern "C" int bl_pf_update_begin(bl_pf* pf, const bl_pose_xyt_t* odometry, const bl_lidar_t* scan, const bl_grid* map,
                                   int rand_value, const float* noise, int* moved)
@@ -1642,8 +1691,22 @@ extern "C" int bl_pf_update_end(bl_pf* pf, bl_pose_xyt_t* out_pose)
     BL_CHECK_ARG(pf != nullptr);
     BL_HIP(hipSetDevice(pf->ctx->device));
     if (pf->pending_end) {
-        int rc = pf->fused_finish ? pf_finish_fused(pf, pf->cur ^ 1, pf->pending_utime)
-                                  : pf_scan(pf, pf->cur ^ 1, 1, pf->pending_utime);
+        int rc;
+        if (pf->sh_world > 1) {
+            // composed finish: the exchange (bl_pf_shard_exchange, or the two stages with the caller's all-gathers) lies behind;
+            // pre-chain + finisher over every rank's blocks
+            if (!pf->sh_stage_groups) { bl_set_error("bl_pf_update_end of a composed shard before its exchange (bl_pf_shard_exchange / bl_pf_shard_stage)"); return BL_ERR_STATE; }
+            mcl_finish_args f;
+            if (pf_shard_fin_args(pf, pf->cur ^ 1, pf->pending_utime, &f) < 0) { bl_set_error("internal: finish launch shape"); return BL_ERR_STATE; }
+            hipEvent_t e0, e1;
+            rc = bl_timer_begin(pf->ctx, BL_K_MCL_SCAN, &e0, &e1);
+            if (rc) return rc;
+            hipLaunchKernelGGL(k_mcl_finish, dim3(MCLF_EXTRA_WGS), dim3(MCLF_WG), MCLF_LDS_BYTES, pf->ctx->stream, f);
+            BL_HIP(hipGetLastError());
+            rc = bl_timer_end(pf->ctx, BL_K_MCL_SCAN, e0, e1);
+        } else
+        rc = pf->fused_finish ? pf_finish_fused(pf, pf->cur ^ 1, pf->pending_utime)
+                              : pf_scan(pf, pf->cur ^ 1, 1, pf->pending_utime);
         if (rc) return rc;
         pf->cur ^= 1;
         pf->parent_utime = pf->pose_utime;       // parent_pose = sample.pose (action_model.cpp:92)
@@ -1660,7 +1723,11 @@ int bl_pf_take_finish(bl_pf* pf, mcl_finish_args* out)
 {
     if (!pf || !pf->pending_end) return 0;
     if (pf->strict) return -1;                               // (strict resampling appends a launch of its own to the finish)
-    if (pf->fused_finish) {
+    if (pf->sh_world > 1) {
+        // composed finish: groups and both all-gathers lie behind (else the caller ends the update the ordinary way, which says so)
+        if (!pf->sh_stage_groups) return -1;
+        if (pf_shard_fin_args(pf, pf->cur ^ 1, pf->pending_utime, out) < 0) return -1;
+    } else if (pf->fused_finish) {
         if (pf_fused_args(pf, pf->cur ^ 1, pf->pending_utime, out) < 0) return -1;
     } else {
         // a shard (the record has just been gathered from every rank) or a launch shape the groups do not tile: the tile sums
@@ -1688,12 +1755,211 @@ int bl_pf_take_finish(bl_pf* pf, mcl_finish_args* out)
     return 1;
 }
 
+
+// ================================================================================================ composed finish of a sharded set
+// SURVEY.md section 8e / DESIGN.md section 6.  Rank r owns the output particles [r * block, min(N, (r + 1) * block)) and keeps the
+// record and the weight prefix of ITS particles only.  Per moved update:
+//   k_mcl_main          own block; the resampling search and the source gather read other ranks' prefix / record where the
+//                       sources lie (their memory, mapped into this process: an interval around the own block, not N x 16 B)
+//   stage 1             tile sums of the own block                      -> all-gather #1 (40 B per 512 particles)
+//   stage 2             groups of the own block: global weight prefix, sub-tile records, tables (the sums of EVERY tile are
+//                       there now: S, the offsets, the binade predictions)   -> all-gather #2 (32 B per 128 particles + tables)
+//   finish              pre-chain + finisher over every rank's blocks (riding in the map kernel, or k_mcl_finish): the 10-us
+//                       part, replicated -- every rank owns the identical estimate, bit for bit the single rank's
+// The two all-gathers are the caller's (bl_pf_shard_exchange runs them on a bl_comm; botlab_amd/sharded.py can also use
+// torch.distributed): they are what orders one rank's kernels against the other ranks' reads of its memory.
+extern "C" int bl_ipc_export(const void* dev_ptr, char* out64)
+{
+    BL_CHECK_ARG(dev_ptr != nullptr && out64 != nullptr);
+    static_assert(sizeof(hipIpcMemHandle_t) <= 64, "IPC handle size");
+    hipIpcMemHandle_t h;
+    BL_HIP(hipIpcGetMemHandle(&h, const_cast<void*>(dev_ptr)));
+    memset(out64, 0, 64);
+    memcpy(out64, &h, sizeof(h));
+    return BL_OK;
+}
+extern "C" int bl_ipc_open(const char* handle64, void** out)
+{
+    BL_CHECK_ARG(handle64 != nullptr && out != nullptr);
+    hipIpcMemHandle_t h;
+    memcpy(&h, handle64, sizeof(h));
+    BL_HIP(hipIpcOpenMemHandle(out, h, hipIpcMemLazyEnablePeerAccess));
+    return BL_OK;
+}
+extern "C" int bl_ipc_close(void* p)
+{
+    if (p) BL_HIP(hipIpcCloseMemHandle(p));
+    return BL_OK;
+}
+
+extern "C" int bl_pf_shard_setup(bl_pf* pf, int rank, int world, int block)
+{
+    BL_CHECK_ARG(pf != nullptr && world >= 2 && world <= BL_MAX_SHARDS && rank >= 0 && rank < world);
+    BL_CHECK_ARG(block > 0 && block % mclf_chunk(MCLF_GT_LARGE) == 0 && block % SCAN_TILE == 0);
+    BL_CHECK_ARG(pf->lo == rank * block && pf->hi == (pf->N < (rank + 1) * block ? pf->N : (rank + 1) * block));
+    BL_CHECK_ARG((int64_t)(world - 1) * block < pf->N);            // every rank owns particles
+    if (pf->rec_external) { bl_set_error("a composed finish keeps its exchange records in the library's own allocations"); return BL_ERR_STATE; }
+    if (pf->strict) { bl_set_error("strict resampling needs the whole particle set on one device"); return BL_ERR_STATE; }
+    BL_HIP(hipSetDevice(pf->ctx->device));
+    if (!pf->prefix) { int rc = pf_alloc(pf); if (rc) return rc; }
+    BL_HIP(hipStreamSynchronize(pf->ctx->stream));
+    // tile sums over the padded particle count (tiles past N sum to zero), one slice per rank
+    const int tiles = world * (block / SCAN_TILE);
+    if (pf->tile_partials) BL_HIP(hipFree(pf->tile_partials));
+    if (pf->block_sums) BL_HIP(hipFree(pf->block_sums));
+    pf->tile_partials = nullptr; pf->block_sums = nullptr;
+    BL_HIP(hipMalloc((void**)&pf->tile_partials, (size_t)tiles * 5 * sizeof(double)));
+    BL_HIP(hipMalloc((void**)&pf->block_sums, (size_t)tiles * sizeof(unsigned long long)));
+    BL_HIP(hipMemsetAsync(pf->tile_partials, 0, (size_t)tiles * 5 * sizeof(double), pf->ctx->stream));
+    pf->scan_blocks = tiles;
+    pf->sh_subs_per_rank = block / MCLF_SUB;
+    pf->sh_xchg_stride = ((size_t)MCLF_XCHG_HDR + (size_t)2 * pf->sh_subs_per_rank * sizeof(ss_rec) +
+                          (size_t)2 * MCLF_TSLOTS * MCLF_SUB * sizeof(mclf_tab_elem) + 255) & ~(size_t)255;
+    if (pf->sh_xchg) BL_HIP(hipFree(pf->sh_xchg));
+    BL_HIP(hipMalloc((void**)&pf->sh_xchg, pf->sh_xchg_stride * world));
+    BL_HIP(hipMemsetAsync(pf->sh_xchg, 0, pf->sh_xchg_stride * world, pf->ctx->stream));
+    if (!pf->sh_tab) BL_HIP(hipMalloc((void**)&pf->sh_tab, 2 * sizeof(mcl_shard_tab)));
+    if (!pf->sh_fin) BL_HIP(hipMalloc((void**)&pf->sh_fin, 2 * sizeof(mclf_shards)));
+    pf->sh_rank = rank; pf->sh_block = block;
+    pf->sh_world = 0;                                              // composed from bl_pf_shard_commit on
+    memset(pf->sh_peer_rec, 0, sizeof(pf->sh_peer_rec)); memset(pf->sh_peer_prefix, 0, sizeof(pf->sh_peer_prefix));
+    pf->sh_world_pending = world;
+    return BL_OK;
+}
+
+// what the other ranks need of this one: its two exchange records and its weight prefix (device pointers; export them with
+// bl_ipc_export for another process)
+extern "C" int bl_pf_shard_local_ptrs(bl_pf* pf, void** rec0, void** rec1, void** prefix)
+{
+    BL_CHECK_ARG(pf != nullptr && pf->prefix != nullptr && rec0 && rec1 && prefix);
+    *rec0 = pf->rec[0]; *rec1 = pf->rec[1]; *prefix = pf->prefix;
+    return BL_OK;
+}
+
+// rank `rank`'s arrays as THIS process sees them (its own pointers for its own rank)
+extern "C" int bl_pf_shard_set_peer(bl_pf* pf, int rank, const void* rec0, const void* rec1, const void* prefix)
+{
+    BL_CHECK_ARG(pf != nullptr && pf->sh_world_pending >= 2 && rank >= 0 && rank < pf->sh_world_pending && rec0 && rec1 && prefix);
+    pf->sh_peer_rec[0][rank] = (const float4*)rec0; pf->sh_peer_rec[1][rank] = (const float4*)rec1;
+    pf->sh_peer_prefix[rank] = (const unsigned long long*)prefix;
+    return BL_OK;
+}
+
+extern "C" int bl_pf_shard_commit(bl_pf* pf)
+{
+    BL_CHECK_ARG(pf != nullptr && pf->sh_world_pending >= 2);
+    if (pf->pending_end) { bl_set_error("update pending"); return BL_ERR_STATE; }
+    const int world = pf->sh_world_pending;
+    for (int r = 0; r < world; ++r) BL_CHECK_ARG(pf->sh_peer_rec[0][r] && pf->sh_peer_rec[1][r] && pf->sh_peer_prefix[r]);
+    BL_CHECK_ARG(pf->sh_peer_rec[0][pf->sh_rank] == pf->rec[0] && pf->sh_peer_prefix[pf->sh_rank] == pf->prefix);
+    BL_HIP(hipSetDevice(pf->ctx->device));
+    mcl_shard_tab tab[2];
+    mclf_shards fin[2];
+    memset(tab, 0, sizeof(tab)); memset((void*)fin, 0, sizeof(fin));
+    for (int c = 0; c < 2; ++c) {
+        tab[c].world = world; tab[c].block = pf->sh_block;
+        fin[c].world = world; fin[c].rank = pf->sh_rank; fin[c].block = pf->sh_block; fin[c].subs_per_rank = pf->sh_subs_per_rank;
+        fin[c].xchg = pf->sh_xchg; fin[c].xchg_stride = pf->sh_xchg_stride;
+        for (int r = 0; r < world; ++r) {
+            tab[c].src[r] = pf->sh_peer_rec[c][r];                 // an update from cur = c reads the records rec[c]
+            tab[c].prefix[r] = pf->sh_peer_prefix[r];
+            fin[c].rec[r] = pf->sh_peer_rec[c ^ 1][r];             // ... and its finish the ones it wrote, rec[c ^ 1]
+        }
+    }
+    BL_HIP(hipMemcpyAsync(pf->sh_tab, tab, sizeof(tab), hipMemcpyHostToDevice, pf->ctx->stream));
+    BL_HIP(hipMemcpyAsync(pf->sh_fin, fin, sizeof(fin), hipMemcpyHostToDevice, pf->ctx->stream));
+    BL_HIP(hipStreamSynchronize(pf->ctx->stream));
+    pf->sh_world = world;
+    pf->sh_stage_sums = pf->sh_stage_groups = false;
+    return BL_OK;
+}
+
+// the two buffers of the exchange: every rank's slice of the tile sums and every rank's block of records / tables
+extern "C" int bl_pf_shard_buffers(bl_pf* pf, void** sums, size_t* sums_bytes_per_rank, void** xchg, size_t* xchg_bytes_per_rank)
+{
+    BL_CHECK_ARG(pf != nullptr && (pf->sh_world >= 2 || pf->sh_world_pending >= 2) && sums && sums_bytes_per_rank && xchg && xchg_bytes_per_rank);
+    *sums = pf->tile_partials; *sums_bytes_per_rank = (size_t)(pf->sh_block / SCAN_TILE) * 5 * sizeof(double);
+    *xchg = pf->sh_xchg; *xchg_bytes_per_rank = pf->sh_xchg_stride;
+    return BL_OK;
+}
+
+// the finish arguments of the record an update from `cur` wrote (the update begun, or the particles as they stand)
+static int pf_shard_fin_args(bl_pf* pf, int which, int64_t utime, mcl_finish_args* f)
+{
+    f->partials = pf->tile_partials; f->nblocks = pf->scan_blocks;
+    f->rec = pf->rec[which]; f->N = pf->N;
+    f->tile = SCAN_TILE; f->main_blocks = pf->scan_blocks; f->main_particles = pf->N; f->tail_tile = 1;
+    f->prefix = pf->prefix; f->state = pf->state; f->utime = utime;
+    if (pf_finish_fill(pf, f) < 0) return -1;
+    f->groups_wait = 0;
+    f->sh = pf->sh_fin + (which ^ 1);
+    f->recs = (ss_rec*)pf->sh_xchg; f->tabs = (mclf_tab_elem*)pf->sh_xchg;      // (non-null: the groups leave records and tables)
+    return f->groups;
+}
+
+// stage 1 (tile sums of the own block) or stage 2 (its groups) of the running update's exchange; the caller all-gathers the
+// corresponding buffer of bl_pf_shard_buffers behind each (in place: this rank's slice is where it belongs)
+extern "C" int bl_pf_shard_stage(bl_pf* pf, int stage)
+{
+    BL_CHECK_ARG(pf != nullptr && pf->sh_world >= 2 && (stage == 1 || stage == 2));
+    if (!pf->pending_end) { bl_set_error("bl_pf_shard_stage without an update begun"); return BL_ERR_STATE; }
+    BL_HIP(hipSetDevice(pf->ctx->device));
+    const int which = pf->cur ^ 1;
+    hipEvent_t e0, e1;
+    int rc = bl_timer_begin(pf->ctx, BL_K_MCL_SCAN, &e0, &e1);
+    if (rc) return rc;
+    if (stage == 1) {
+        const int tiles = pf->sh_block / SCAN_TILE;
+        hipLaunchKernelGGL(k_scan_tile_sums, dim3(tiles), dim3(SCAN_THREADS), 0, pf->ctx->stream, (const float4*)pf->rec[which], pf->N, pf->block_sums,
+                           pf->tile_partials, pf->sh_rank * tiles, (unsigned long long*)(pf->sh_xchg + (size_t)pf->sh_rank * pf->sh_xchg_stride));
+        pf->sh_stage_sums = true;
+    } else {
+        if (!pf->sh_stage_sums) { bl_set_error("bl_pf_shard_stage(2) before stage 1"); return BL_ERR_STATE; }
+        mcl_finish_args f;
+        if (pf_shard_fin_args(pf, which, pf->pending_utime, &f) < 0) { bl_set_error("internal: finish launch shape"); return BL_ERR_STATE; }
+        const int per_rank = pf->sh_block / mclf_chunk(f.gthreads);
+        hipLaunchKernelGGL(k_shard_groups, dim3(per_rank), dim3(MCLF_WG), 0, pf->ctx->stream, f, pf->sh_rank * per_rank);
+        pf->sh_stage_groups = true;
+    }
+    BL_HIP(hipGetLastError());
+    return bl_timer_end(pf->ctx, BL_K_MCL_SCAN, e0, e1);
+}
+
+// both stages with their all-gathers on the library's own communicator (bl_comm.hip), all on the filter's stream
+extern "C" int bl_pf_shard_exchange(bl_pf* pf, bl_comm* c)
+{
+    BL_CHECK_ARG(pf != nullptr && c != nullptr);
+    void* sums; void* xchg; size_t sb, xb;
+    int rc = bl_pf_shard_buffers(pf, &sums, &sb, &xchg, &xb);
+    if (rc) return rc;
+    rc = bl_pf_shard_stage(pf, 1);
+    if (rc) return rc;
+    rc = bl_comm_all_gather_inplace(c, sums, sb / sizeof(float));
+    if (rc) return rc;
+    rc = bl_pf_shard_stage(pf, 2);
+    if (rc) return rc;
+    return bl_comm_all_gather_inplace(c, xchg, xb / sizeof(float));
+}
+
+// bytes of the exchange per rank and update: what this rank sends into the two all-gathers, what it receives from them, and
+// the size of its own block of particle records (its k_mcl_main reads about that much of source records, from wherever they
+// lie; the replicated form receives N x 16 B instead)
+extern "C" int bl_pf_shard_traffic(bl_pf* pf, int64_t* out3)
+{
+    BL_CHECK_ARG(pf != nullptr && out3 != nullptr && pf->sh_world >= 2);
+    const int64_t sums = (int64_t)(pf->sh_block / SCAN_TILE) * 5 * (int64_t)sizeof(double);
+    out3[0] = sums + (int64_t)pf->sh_xchg_stride;
+    out3[1] = (int64_t)(pf->sh_world - 1) * out3[0];
+    out3[2] = (int64_t)pf->n_local * (int64_t)sizeof(float4);
+    return BL_OK;
+}
+
 bl_ctx* bl_pf_ctx(bl_pf* pf) { return pf ? pf->ctx : nullptr; }
 
 int bl_pf_launch_taken_finish(bl_pf* pf, const mcl_finish_args* fin)
 {
     if (!pf || !fin) return BL_ERR_ARG;
-    hipLaunchKernelGGL(k_mcl_finish, dim3(MCLF_EXTRA_WGS + fin->groups), dim3(MCLF_WG), MCLF_LDS_BYTES, pf->ctx->stream, *fin);
+    hipLaunchKernelGGL(k_mcl_finish, dim3(MCLF_EXTRA_WGS + fin->groups_wait), dim3(MCLF_WG), MCLF_LDS_BYTES, pf->ctx->stream, *fin);
     BL_HIP(hipGetLastError());
     return BL_OK;
 }
@@ -1745,6 +2011,7 @@ extern "C" int bl_pf_estimate_posterior_pose(bl_pf* pf, bl_pose_xyt_t* out_pose)
 {
     BL_CHECK_ARG(pf != nullptr);
     if (!pf->initialized || pf->pending_end) { bl_set_error("filter not initialised or update pending"); return BL_ERR_STATE; }
+    if (pf->sh_world > 1) { bl_set_error("estimatePosteriorPose on demand needs the whole record on this device (composed shard)"); return BL_ERR_STATE; }
     BL_HIP(hipSetDevice(pf->ctx->device));
     int rc = pf_scan(pf, pf->cur, 1, pf->pending_utime);
     if (rc) return rc;

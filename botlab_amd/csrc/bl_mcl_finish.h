@@ -40,6 +40,22 @@ struct pf_state {
 
 struct mclf_tab_elem { double t; int se, se1; };       // term; (inclusive prefix << 1 | bad) in the predicted binade and in the next
 
+// Where the finish's inputs lie when the particle set is sharded over ranks and the finish is COMPOSED: every
+// rank runs the groups over its own block of particles only and leaves their records, tables and table counts in its block of an
+// exchange buffer; one small all-gather later every rank holds every block and runs pre-chain + finisher over all of them.
+// Particle records of other ranks (the pre-chain's first sub-tiles, a generic replay) are read from the owner's memory.
+#define BL_MAX_SHARDS 8
+#define MCLF_XCHG_HDR 64                       // bytes in front of a rank's block: [0] its table counts (x: bits 0..15, y: 16..31)
+struct mclf_shards {
+    int world;
+    int rank;
+    int block;                                 // particles per rank: a multiple of the finish groups' chunk and of the scan tile
+    int subs_per_rank;                         // sub-tile records per rank and axis
+    const float4* rec[BL_MAX_SHARDS];          // per rank its exchange record, indexed by GLOBAL particle index (its own block is valid)
+    char* xchg;                                // the ranks' blocks, xchg_stride bytes apart: [header][recs x][recs y][tables x][tables y]
+    size_t xchg_stride;
+};
+
 // partials[b][5]: per block b the sums of units, units*x, units*y, units*sin(theta), units*cos(theta) of its particles (units
 // exact; the others feed theta and the binade predictions only).  Blocks [0, main_blocks) own `tile` particles each from 0 on
 // (clipped to main_particles), the rest own `tail_tile` particles each from main_particles on.
@@ -57,7 +73,10 @@ struct mcl_finish_args {
                                            // [1] the sums behind the first MCLF_PRE_SUBS sub-tiles (x, y float bits), [2] "they are there"
                                            // [3] the finisher's exact x, y (float bits) for the map workgroup of the same launch, [4] "they are there"
                                            //     (mclf_pose with publish writes them, mclf_wait_pose reads and clears them)
-    int groups, gthreads;                  // group workgroups; threads of each that work (256 or 1024)
+    int groups, gthreads;                  // group workgroups (of the whole particle set); threads of each that work (256 or 1024)
+    int groups_wait;                       // groups of THIS launch the finisher waits for (composed finish: 0, they ran in an earlier launch)
+    const mclf_shards* sh;                 // device memory; null: one rank (a table in the argument block itself would be indexed
+                                           // per lane, which moves a by-value argument into scratch for every thread of the kernel)
 };
 
 #define MCLF_POSE_THREADS 256                 // the theta sums' addition order is that of a 256-thread workgroup, whoever runs it
@@ -103,6 +122,7 @@ struct mclf_smem {
     unsigned long long word;                      // the sync word the finisher saw
     float xy[2], first[2];                        // the sums; the sums behind the finisher's own sub-tiles
     unsigned int stats[8];
+    int tbase[2][BL_MAX_SHARDS + 1];              // per axis: first staged slot of every rank's tables (composed finish; one rank: {0, count})
     double pre[2][MCLF_PRE_STEPPED * MCLF_SUB];   // the terms the finisher steps one by one, per axis
 };
 
@@ -166,6 +186,43 @@ __device__ __forceinline__ mclf_tab_elem mclf_load_tab(const mclf_tab_elem* p)
     return e;
 }
 
+// ---- where things lie (one rank: the filter's own arrays; composed finish: the exchange blocks, mclf_shards)
+__device__ __forceinline__ float4 mclf_particle(const mcl_finish_args& f, int i)
+{
+    if (f.sh) return f.sh->rec[i / f.sh->block][i];
+    return f.rec[i];
+}
+__device__ __forceinline__ ss_rec* mclf_rec_ptr(const mcl_finish_args& f, int axis, int s)
+{
+    if (f.sh) {
+        const int spr = f.sh->subs_per_rank, r = s / spr;
+        return (ss_rec*)(f.sh->xchg + (size_t)r * f.sh->xchg_stride + MCLF_XCHG_HDR) + (size_t)axis * spr + (s - r * spr);
+    }
+    return f.recs + (size_t)axis * ((size_t)f.groups * (f.gthreads >> 6)) + s;
+}
+__device__ __forceinline__ mclf_tab_elem* mclf_tab_ptr(const mcl_finish_args& f, int axis, int rank, int slot)
+{
+    if (f.sh)
+        return (mclf_tab_elem*)(f.sh->xchg + (size_t)rank * f.sh->xchg_stride + MCLF_XCHG_HDR + (size_t)2 * f.sh->subs_per_rank * sizeof(ss_rec)) +
+               ((size_t)axis * MCLF_TSLOTS + slot) * MCLF_SUB;
+    return f.tabs + ((size_t)axis * MCLF_TSLOTS + slot) * MCLF_SUB;
+}
+// the word tables are handed out from (x: bits 0..15, y: bits 16..31) -- this rank's own
+__device__ __forceinline__ unsigned long long* mclf_tab_counter(const mcl_finish_args& f)
+{
+    if (f.sh) return (unsigned long long*)(f.sh->xchg + (size_t)f.sh->rank * f.sh->xchg_stride);
+    return f.sync;
+}
+// tables rank r handed out on an axis (at most MCLF_TSLOTS have a slot)
+__device__ __forceinline__ int mclf_tab_count(const mcl_finish_args& f, unsigned long long own_word, int r, int axis)
+{
+    unsigned long long w = own_word;
+    if (f.sh) w = mclf_load_u64((const unsigned long long*)(f.sh->xchg + (size_t)r * f.sh->xchg_stride));
+    return min((int)((w >> (axis ? 16 : 0)) & 0xffffull), MCLF_TSLOTS);
+}
+__device__ __forceinline__ int mclf_rank_of_sub(const mcl_finish_args& f, int s) { return f.sh ? s / f.sh->subs_per_rank : 0; }
+__device__ __forceinline__ int mclf_world(const mcl_finish_args& f) { return f.sh ? f.sh->world : 1; }
+
 // particles [lo, hi) of group g and the first block that belongs to it
 __device__ __forceinline__ void mclf_group_range(const mcl_finish_args& f, int g, int* first_block, int* lo, int* hi)
 {
@@ -207,7 +264,7 @@ __device__ __forceinline__ void mclf_load_terms(const mcl_finish_args& f, int ax
 #pragma unroll
     for (int k = 0; k < MCLF_ITEMS; ++k) {
         const int i = lo + lane * MCLF_ITEMS + k;
-        t[k] = i < hi ? mclf_term(f.rec[i], S, axis) : 0.0;
+        t[k] = i < hi ? mclf_term(mclf_particle(f, i), S, axis) : 0.0;
     }
 }
 
@@ -312,13 +369,13 @@ __device__ __forceinline__ ss_rec mclf_make_record(const mcl_finish_args& f, int
     if (risky && f.tabs) {
         // the table: terms, prefix in the predicted binade (if there is one), prefix in the next binade up
         unsigned long long got = 0;
-        if (lane == 0) got = __hip_atomic_fetch_add(f.sync, axis ? (1ull << 16) : 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (lane == 0) got = __hip_atomic_fetch_add(mclf_tab_counter(f), axis ? (1ull << 16) : 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const int slot = __builtin_amdgcn_readfirstlane((int)((got >> (axis ? 16 : 0)) & 0xffffull));
         if (slot < MCLF_TSLOTS) {
             int p1[MCLF_ITEMS] = {0, 0}, bad1[MCLF_ITEMS] = {1, 1};
             const bool up = key != 0 && (key & 0xff) < 254;
             if (up) mclf_prefix_in(key + 1, t, cnt, p1, bad1);
-            mclf_tab_elem* tab = f.tabs + ((size_t)axis * MCLF_TSLOTS + slot) * MCLF_SUB;
+            mclf_tab_elem* tab = mclf_tab_ptr(f, axis, f.sh ? f.sh->rank : 0, slot);
 #pragma unroll
             for (int k = 0; k < MCLF_ITEMS; ++k) {
                 const int se = key ? ((p[k] << 1) | bad[k]) : 1, se1 = up ? ((p1[k] << 1) | bad1[k]) : 1;
@@ -404,9 +461,9 @@ __device__ __forceinline__ void mclf_prefix_group(const mcl_finish_args& f, int 
     const ss_rec ry = mclf_make_record(f, 1, ty, cnt, py, very_first, lane);
     MCLF_GSTAMP(5);
     if (lane == 0) {
-        const size_t nrec = (size_t)f.groups * nw, s = (size_t)g * nw + wave;
-        mclf_store_rec(f.recs + s, rx);
-        mclf_store_rec(f.recs + nrec + s, ry);
+        const int s = g * nw + wave;
+        mclf_store_rec(mclf_rec_ptr(f, 0, s), rx);
+        mclf_store_rec(mclf_rec_ptr(f, 1, s), ry);
     }
     mclf_drain_stores();                                        // this wave's records and table rows have left (no cache writeback)
     __syncthreads();
@@ -562,10 +619,12 @@ __device__ __forceinline__ mclf_stage mclf_stage_at(char* base, int nbatch)
 }
 
 // One batch of 64 records of an axis, by one wave: composite, and the list entries of its risky records.
-__device__ __forceinline__ void mclf_stage_batch(const mcl_finish_args& f, const mclf_stage& st, ss_rec r, int b, int lane)
+// tbase: first staged slot of every rank's tables on this axis (a record names its table by its rank's own slot number)
+__device__ __forceinline__ void mclf_stage_batch(const mcl_finish_args& f, const mclf_stage& st, ss_rec r, int b, int lane, const int* tbase)
 {
     const bool risky = r.key != SS_ID && (r.key & MCLF_RISKY) != 0;
-    const int tslot = r.key == SS_ID ? -1 : ((r.key >> MCLF_TSLOT_SHIFT) & 0xff) - 1;
+    int tslot = r.key == SS_ID ? -1 : ((r.key >> MCLF_TSLOT_SHIFT) & 0xff) - 1;
+    if (tslot >= 0) tslot += tbase[mclf_rank_of_sub(f, b * 64 + lane)];
     const int pkey = mclf_plain_key(r.key);
     const unsigned long long rmask = __builtin_amdgcn_ballot_w64(risky);
     ss_rec v = r;
@@ -613,11 +672,9 @@ __device__ __forceinline__ ss_rec mclf_join_batches(const mclf_stage& st, int b0
 __device__ __forceinline__ float mclf_walk(const mcl_finish_args& f, int axis, double S, int ra, int rb, float acc, int lane,
                                            unsigned int* replays, unsigned int* phases)
 {
-    const int nrec = f.groups * (f.gthreads >> 6);
-    const ss_rec* recs = f.recs + (size_t)axis * nrec;
     int r0 = ra;
     while (r0 < rb) {
-        ss_rec r = (r0 + lane < rb) ? mclf_load_rec(recs + r0 + lane) : ss_rec_identity();
+        ss_rec r = (r0 + lane < rb) ? mclf_load_rec(mclf_rec_ptr(f, axis, r0 + lane)) : ss_rec_identity();
         r.key = mclf_plain_key(r.key);
         const ss_rec pre = mclf_scan_join(r);
         const int key = __builtin_amdgcn_readfirstlane(ss_key(acc));
@@ -760,7 +817,7 @@ __device__ __forceinline__ void mclf_pre_chain(const mcl_finish_args& f, mclf_sm
 #pragma unroll
             for (int k = 0; k < MCLF_ITEMS; ++k) {
                 const int i = lo + lane * MCLF_ITEMS + k;
-                pre_r[q][k] = i < hi ? f.rec[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+                pre_r[q][k] = i < hi ? mclf_particle(f, i) : make_float4(0.f, 0.f, 0.f, 0.f);
             }
         }
     }
@@ -839,15 +896,23 @@ __device__ __forceinline__ void mclf_pose(const mcl_finish_args& f, mclf_smem& s
     double S = 0.0;
     for (int w = 0; w < MCLF_POSE_THREADS / 64; ++w) S += sm.red[w][0];          // exact integer below 2^53, any order gives it
     if (tid == 0) {
-        // every group has counted itself once its records (and tables) were on their way through the L2
+        // every group of this launch has counted itself once its records (and tables) were on their way through the L2 (a composed
+        // finish waits for none: its groups ran in an earlier launch, and their blocks arrived by the all-gather behind it)
         unsigned long long w;
-        while (((w = mclf_load_u64(f.sync)) >> 32) < (unsigned long long)f.groups) __builtin_amdgcn_s_sleep(1);
+        while (((w = mclf_load_u64(f.sync)) >> 32) < (unsigned long long)f.groups_wait) __builtin_amdgcn_s_sleep(1);
         sm.word = w;
+        // tables: rank r's slot q of an axis is staged as slot tbase[axis][r] + q -- while it is below MCLF_TSLOTS
+        const int world = mclf_world(f);
+        for (int axis = 0; axis < 2; ++axis) {
+            int run = 0;
+            for (int r = 0; r < world; ++r) { sm.tbase[axis][r] = run; run += mclf_tab_count(f, w, r, axis); }
+            sm.tbase[axis][world] = run;
+        }
     }
     __syncthreads();
     MCLF_STAMP(1);
-    const unsigned long long word = sm.word;
-    const int ntab[2] = {min((int)(word & 0xffffull), MCLF_TSLOTS), min((int)((word >> 16) & 0xffffull), MCLF_TSLOTS)};
+    const int sh_world = mclf_world(f);
+    const int ntab[2] = {min(sm.tbase[0][sh_world], MCLF_TSLOTS), min(sm.tbase[1][sh_world], MCLF_TSLOTS)};
     if (staged) {
         // ---- stage a: every wave takes batches of records and tables of both axes; the loads of four items are in flight together
         const int nb2 = 2 * nbatch, items = nb2 + ntab[0] + ntab[1];
@@ -861,10 +926,12 @@ __device__ __forceinline__ void mclf_pose(const mcl_finish_args& f, mclf_smem& s
                 te[u][0].t = 0.0; te[u][0].se = 1; te[u][0].se1 = 1; te[u][1] = te[u][0];
                 if (it < nb2) {
                     const int axis = it >= nbatch ? 1 : 0, b = it - axis * nbatch;
-                    if (b * 64 + lane < nrec) rr[u] = mclf_load_rec(f.recs + (size_t)axis * nrec + b * 64 + lane);
+                    if (b * 64 + lane < nrec) rr[u] = mclf_load_rec(mclf_rec_ptr(f, axis, b * 64 + lane));
                 } else if (it < items) {
                     const int q = it - nb2, axis = q >= ntab[0] ? 1 : 0, slot = q - axis * ntab[0];
-                    const mclf_tab_elem* src = f.tabs + ((size_t)axis * MCLF_TSLOTS + slot) * MCLF_SUB + lane * MCLF_ITEMS;
+                    int r = 0;
+                    while (r + 1 < sh_world && sm.tbase[axis][r + 1] <= slot) ++r;             // the rank whose table this staged slot is
+                    const mclf_tab_elem* src = mclf_tab_ptr(f, axis, r, slot - sm.tbase[axis][r]) + lane * MCLF_ITEMS;
                     te[u][0] = mclf_load_tab(src); te[u][1] = mclf_load_tab(src + 1);
                 }
             }
@@ -873,7 +940,7 @@ __device__ __forceinline__ void mclf_pose(const mcl_finish_args& f, mclf_smem& s
                 const int it = base + u * MCLF_MAXW;
                 if (it < nb2) {
                     const int axis = it >= nbatch ? 1 : 0, b = it - axis * nbatch;
-                    mclf_stage_batch(f, MCLF_STAGE(axis), rr[u], b, lane);
+                    mclf_stage_batch(f, MCLF_STAGE(axis), rr[u], b, lane, sm.tbase[axis]);
                 } else if (it < items) {
                     const int q = it - nb2, axis = q >= ntab[0] ? 1 : 0, slot = q - axis * ntab[0];
                     mclf_tab_elem* dst = MCLF_STAGE(axis).tab + slot * MCLF_SUB + lane * MCLF_ITEMS;

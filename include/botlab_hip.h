@@ -266,6 +266,33 @@ void bl_comm_destroy(bl_comm* c);
 /* rec: world x per_rank_floats floats, this rank's slice already at its offset (bl_pf_exchange_rec_ptr) */
 int bl_comm_all_gather_inplace(bl_comm* c, void* rec, size_t per_rank_floats);
 
+/* Composed finish of a sharded particle set: instead of all-gathering the whole record (N x 16 B into every
+ * rank) each rank keeps its own block, reads the resampling sources it needs from their owners' memory, and the end of an
+ * update exchanges two SMALL all-gathers -- tile sums (40 B per 512 particles), then sub-tile records + tables (32 B per 128
+ * particles + 80 KB) -- before every rank runs the (replicated, ~10 us) chain of estimatePosteriorPose.  Results are the single
+ * rank's, bit for bit.  Set-up, once the filter holds particles: bl_pf_shard_setup (block = particles per rank, a multiple of
+ * 2048, shard = [rank * block, min(N, (rank + 1) * block)) as given to bl_pf_create); hand every rank's three arrays to every
+ * rank (bl_pf_shard_local_ptrs -> bl_ipc_export -> the host's transport -> bl_ipc_open -> bl_pf_shard_set_peer; a rank of the
+ * same process passes the pointers themselves); bl_pf_shard_commit.  Per update: bl_pf_update_begin, bl_pf_shard_exchange (or
+ * bl_pf_shard_stage(1), all-gather of the sums buffer, bl_pf_shard_stage(2), all-gather of the exchange buffer, both in place),
+ * then bl_pf_update_end or one of the *_finishing_pf calls.  The all-gathers are what orders a rank's kernels against the other
+ * ranks' reads of its memory: every rank must run them, on the filter's stream. */
+int bl_dev_alloc(bl_ctx* ctx, size_t bytes, void** out);     /* plain zeroed device memory (the probe of botlab_amd/sharded.py) */
+int bl_dev_free(void* dev_ptr);
+int bl_ipc_export(const void* dev_ptr, char* out_handle64);
+int bl_ipc_open(const char* handle64, void** out_dev_ptr);
+int bl_ipc_close(void* dev_ptr);
+int bl_pf_shard_setup(bl_pf* pf, int rank, int world, int block);
+int bl_pf_shard_local_ptrs(bl_pf* pf, void** rec0, void** rec1, void** prefix);
+int bl_pf_shard_set_peer(bl_pf* pf, int rank, const void* rec0, const void* rec1, const void* prefix);
+int bl_pf_shard_commit(bl_pf* pf);
+int bl_pf_shard_buffers(bl_pf* pf, void** sums, size_t* sums_bytes_per_rank, void** xchg, size_t* xchg_bytes_per_rank);
+int bl_pf_shard_stage(bl_pf* pf, int stage);
+int bl_pf_shard_exchange(bl_pf* pf, bl_comm* c);
+/* bytes per rank and update: sent into the two all-gathers, received from them, and the rank's own block of records (about what
+ * its k_mcl_main reads of source records, from wherever they lie) */
+int bl_pf_shard_traffic(bl_pf* pf, int64_t* out3);
+
 /* The NEXT lidar scan handed over early (a SLAM host has it queued, src/slam/slam.cpp:96-104): it is packed into pinned
  * memory now and copied to the device by the next bl_mapping_update* / bl_planner_submit_with_map_update* launch of this
  * ctx, beside that kernel's own work; the bl_pf_update* / bl_mapping_update* call that later brings the same scan then

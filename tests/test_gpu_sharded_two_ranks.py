@@ -13,7 +13,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 N, STEPS = 30001, 6           # odd N: last shard shorter than the padded block
 
 
-def _run(rank, world, port, out_dir, riding=False):
+def _run(rank, world, port, out_dir, riding=False, composed=False, n=N):
     sys.path.insert(0, HERE)
     sys.path.insert(0, os.path.dirname(HERE))
     import torch
@@ -35,7 +35,14 @@ def _run(rank, world, port, out_dir, riding=False):
     # map kernel -- against the same record-based finish as separate launches on one rank)
     if not (riding and world > 1):
         os.environ["BOTLAB_MCL_NO_FUSED_FINISH"] = "1"
-    eng = sharded.HipShardEngine(N, rank, world, 0)            # both ranks on device 0
+    if composed and world > 1:
+        # the composed finish: ranks keep their own block, map each other's memory (IPC), exchange two small
+        # all-gathers.  First the question bench.py asks: can the ranks map each other's memory at all?
+        assert sharded.composed_possible(n, world)
+        probe = bl.Context(0)
+        assert sharded.ipc_probe(probe, rank, world), "hipIpc between the ranks' processes does not work here"
+        probe.close()
+    eng = sharded.HipShardEngine(n, rank, world, 0, composed=composed and world > 1)            # every rank on device 0
     spf = sharded.ShardedParticleFilter(eng)
     grid = bl.OccupancyGrid.from_cells(m["cells"], m["origin"], m["mpc"], cellsPerMeter=helpers.CPM_DEFAULT, ctx=eng.ctx)
     mapper = bl.Mapping(5.0, 4, 1, ctx=eng.ctx)
@@ -53,14 +60,48 @@ def _run(rank, world, port, out_dir, riding=False):
                 mapper.updateMapDevicePose(sc, eng.pf.poseDevicePtr(), sc.utime, grid)
         est.append((p.utime, p.x, p.y, p.theta))
     parts = spf.particles()
+    if composed and world > 1:
+        assert spf.composed
+        sent, received, own = spf.exchange_bytes_per_update()
+        # the point of the composed form: per rank and update O(block) + O(100 KB), not N x 16 B
+        assert sent <= 90_000 + (eng.S // 128) * 42 and received == (world - 1) * sent      # 32 B of records + 10 B of sums per 128 particles + tables
+        with open(os.path.join(out_dir, f"traffic_w{world}_r{rank}.txt"), "w") as f:
+            f.write(f"{sent} {received} {own} {n * 16}")
     np.save(os.path.join(out_dir, f"grid_w{world}_r{rank}.npy"), grid.cells())
     np.save(os.path.join(out_dir, f"parts_w{world}_r{rank}.npy"), parts)
     np.save(os.path.join(out_dir, f"est_w{world}_r{rank}.npy"), np.array(est, dtype=np.float64))
     with open(os.path.join(out_dir, f"shard_w{world}_r{rank}.txt"), "w") as f:
         f.write(f"{eng.lo} {eng.hi}")
     if world > 1:
+        spf.close()
         dist.barrier()
         dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,riding,n", [(2, False, N), (2, True, N), (3, True, N), (2, True, 200_001)])
+def test_composed_finish_matches_single_rank(tmp_path, world, riding, n):
+    """The composed finish -- own blocks only, sources read from their owners' memory, two small all-gathers -- with 2 and 3 ranks
+    on one device (one process per rank, IPC mappings, collectives over gloo): particles, estimates and the replicated map equal
+    the single rank's bit for bit; 200 001 particles take the large finish groups (1024 threads, 2048 particles)."""
+    import torch.multiprocessing as mp
+    out = str(tmp_path)
+    mp.spawn(_run, args=(1, 0, out, riding, False, n), nprocs=1, join=True)
+    mp.spawn(_run, args=(world, 29900 + os.getpid() % 300 + 7 * world + (300 if riding else 0), out, riding, True, n), nprocs=world, join=True)
+    one = np.load(os.path.join(out, "parts_w1_r0.npy"))
+    e1 = np.load(os.path.join(out, "est_w1_r0.npy"))
+    g1 = np.load(os.path.join(out, "grid_w1_r0.npy"))
+    got = []
+    for r in range(world):
+        lo, hi = map(int, open(os.path.join(out, f"shard_w{world}_r{r}.txt")).read().split())
+        assert lo % 2048 == 0
+        part = np.load(os.path.join(out, f"parts_w{world}_r{r}.npy"))
+        assert part.size == hi - lo
+        got.append(part)
+        assert e1.tobytes() == np.load(os.path.join(out, f"est_w{world}_r{r}.npy")).tobytes(), f"rank {r}: estimates differ"
+        assert np.array_equal(g1, np.load(os.path.join(out, f"grid_w{world}_r{r}.npy"))), f"rank {r}: map differs"
+        sent, received, own, full = map(int, open(os.path.join(out, f"traffic_w{world}_r{r}.txt")).read().split())
+        assert sent + received < full or n < 100_000        # less than the replicated form's N x 16 B once N is large
+    assert np.concatenate(got).tobytes() == one.tobytes()
 
 
 @pytest.mark.parametrize("riding", [False, True])
@@ -68,7 +109,7 @@ def test_two_ranks_one_device_match_single_rank(tmp_path, riding):
     import torch.multiprocessing as mp
     out = str(tmp_path)
     mp.spawn(_run, args=(1, 0, out, riding), nprocs=1, join=True)
-    mp.spawn(_run, args=(2, 29600 + os.getpid() % 300 + (300 if riding else 0), out, riding), nprocs=2, join=True)
+    mp.spawn(_run, args=(2, 29600 + os.getpid() % 300 + (300 if riding else 0), out, riding), nprocs=2, join=True)   # replicated form
     one = np.load(os.path.join(out, "parts_w1_r0.npy"))
     got = []
     for r in range(2):
