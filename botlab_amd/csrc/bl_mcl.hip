@@ -46,6 +46,7 @@ struct bl_pf {
     int cur;
     double* tile_partials;    // [scan_blocks][5]: per-tile sums of units, units*(x, y, sin, cos) from the record (record-based finish)
     ss_rec* fin_recs;         // [2][fin_subs_cap]: sub-tile records of the pose sums (bl_mcl_finish.h)
+    ss_wild* fin_wild;        // [2][fin_subs_cap]: wild maps of the sub-tiles whose sum is predicted to cross binades
     int fin_subs_cap;
     mclf_tab_elem* fin_tabs;  // [2][MCLF_TSLOTS][MCLF_SUB]: tables of the risky sub-tiles
     unsigned long long* fin_sync;     // the finish launches' sync word (zero between launches)
@@ -1226,6 +1227,7 @@ static int pf_alloc(bl_pf* pf)
     BL_HIP(hipMalloc((void**)&pf->tile_partials, (size_t)pf->scan_blocks * 5 * sizeof(double)));
     pf->fin_subs_cap = (int)(N / MCLF_SUB) + 4 * (MCLF_WG / 64);      // main region + tail region, each rounded up to whole groups
     BL_HIP(hipMalloc((void**)&pf->fin_recs, (size_t)2 * pf->fin_subs_cap * sizeof(ss_rec)));
+    if (!getenv("BOTLAB_MCL_NO_WILD")) BL_HIP(hipMalloc((void**)&pf->fin_wild, (size_t)2 * pf->fin_subs_cap * sizeof(ss_wild)));
     BL_HIP(hipMalloc((void**)&pf->fin_tabs, (size_t)2 * MCLF_TSLOTS * MCLF_SUB * sizeof(mclf_tab_elem)));
     BL_HIP(hipMalloc((void**)&pf->fin_sync, MCLF_SYNC_WORDS * sizeof(unsigned long long)));
     BL_HIP(hipMemsetAsync(pf->fin_sync, 0, MCLF_SYNC_WORDS * sizeof(unsigned long long), pf->ctx->stream));
@@ -1270,7 +1272,7 @@ extern "C" void bl_pf_destroy(bl_pf* pf)
     if (!pf) return;
     (void)hipStreamSynchronize(pf->ctx->stream);
     if (!pf->rec_external) { if (pf->rec[0]) (void)hipFree(pf->rec[0]); if (pf->rec[1]) (void)hipFree(pf->rec[1]); }
-    void* ptrs[] = {pf->tile_partials, pf->fin_recs, pf->fin_tabs, pf->fin_sync, pf->prefix, pf->parent, pf->state, pf->partials, pf->block_sums, pf->dbg_idx, pf->dbg_like,
+    void* ptrs[] = {pf->fin_wild, pf->tile_partials, pf->fin_recs, pf->fin_tabs, pf->fin_sync, pf->prefix, pf->parent, pf->state, pf->partials, pf->block_sums, pf->dbg_idx, pf->dbg_like,
                     pf->d_noise, pf->d_export, pf->sh_xchg, pf->sh_tab, pf->sh_fin};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     delete pf;
@@ -1310,6 +1312,7 @@ static int pf_finish_fill(bl_pf* pf, mcl_finish_args* f)
     f->groups = groups;
     f->groups_wait = groups;
     f->sh = nullptr;
+    f->wild = pf->sh_world > 1 ? nullptr : pf->fin_wild;      // (a composed finish keeps to records, tables and replays)
     f->recs = pf->fin_recs;
     f->tabs = pf->fin_tabs;
     f->sync = pf->fin_sync;

@@ -74,6 +74,7 @@ struct mcl_finish_args {
                                            // [3] the finisher's exact x, y (float bits) for the map workgroup of the same launch, [4] "they are there"
                                            //     (mclf_pose with publish writes them, mclf_wait_pose reads and clears them)
     int groups, gthreads;                  // group workgroups (of the whole particle set); threads of each that work (256 or 1024)
+    ss_wild* wild;                         // [2][sub-tiles]: the map of a sub-tile whose sum is predicted to cross binades (bl_serial_sum.h), or null
     int groups_wait;                       // groups of THIS launch the finisher waits for (composed finish: 0, they ran in an earlier launch)
     const mclf_shards* sh;                 // device memory; null: one rank (a table in the argument block itself would be indexed
                                            // per lane, which moves a by-value argument into scratch for every thread of the kernel)
@@ -87,6 +88,7 @@ struct mcl_finish_args {
 #define MCLF_GT_LARGE 1024
 #define MCLF_GT_SWITCH 160000                 // particle count from which the large groups are used
 #define MCLF_RISKY 0x1000                     // flag in a record's key
+#define MCLF_WILD 0x2000                      // ... of a risky record: the sub-tile's wild map is in f.wild
 #define MCLF_TSLOT_SHIFT 16                   // bits 16..23 of a record's key: 1 + the slot of its table
 #define MCLF_KEY_MASK 0xfff
 #define MCLF_MARGIN 4096                      // ulps of slack on the predicted start when deciding "risky"
@@ -184,6 +186,51 @@ __device__ __forceinline__ mclf_tab_elem mclf_load_tab(const mclf_tab_elem* p)
     mclf_tab_elem e;
     e.t = __longlong_as_double((long long)a); e.se = (int)(unsigned int)b; e.se1 = (int)(unsigned int)(b >> 32);
     return e;
+}
+
+__device__ __forceinline__ void mclf_store_wild(ss_wild* p, const ss_wild& w)
+{
+    unsigned long long* q = (unsigned long long*)p;
+    mclf_store_u64(q, (unsigned long long)(unsigned int)w.key_in | ((unsigned long long)(unsigned int)w.key_out << 32));
+    mclf_store_u64(q + 1, (unsigned long long)(unsigned int)w.q | ((unsigned long long)(unsigned int)w.r << 32));
+    mclf_store_u64(q + 2, (unsigned long long)w.a); mclf_store_u64(q + 3, (unsigned long long)w.c);
+    mclf_store_u64(q + 4, (unsigned long long)w.L); mclf_store_u64(q + 5, (unsigned long long)w.H);
+}
+__device__ __forceinline__ ss_wild mclf_load_wild(const ss_wild* p)
+{
+    const unsigned long long* q = (const unsigned long long*)p;
+    const unsigned long long k = mclf_load_u64(q), s2 = mclf_load_u64(q + 1);
+    ss_wild w;
+    w.key_in = (int)(unsigned int)k; w.key_out = (int)(unsigned int)(k >> 32); w.q = (int)(unsigned int)s2; w.r = (int)(unsigned int)(s2 >> 32);
+    w.a = (long long)mclf_load_u64(q + 2); w.c = (long long)mclf_load_u64(q + 3);
+    w.L = (long long)mclf_load_u64(q + 4); w.H = (long long)mclf_load_u64(q + 5);
+    return w;
+}
+static_assert(sizeof(ss_wild) == 48, "wild records are stored as six 64-bit words");
+__device__ __forceinline__ long long mclf_shfl_up_i64(long long v, int off)
+{
+    const int lo = __shfl_up((int)(unsigned int)(unsigned long long)v, off, 64), hi = __shfl_up((int)(unsigned int)((unsigned long long)v >> 32), off, 64);
+    return (long long)(((unsigned long long)(unsigned int)hi << 32) | (unsigned long long)(unsigned int)lo);
+}
+__device__ __forceinline__ ss_wild mclf_shfl_up_wild(const ss_wild& w, int off)
+{
+    ss_wild o;
+    o.key_in = __shfl_up(w.key_in, off, 64); o.key_out = __shfl_up(w.key_out, off, 64); o.q = __shfl_up(w.q, off, 64); o.r = __shfl_up(w.r, off, 64);
+    o.a = mclf_shfl_up_i64(w.a, off); o.c = mclf_shfl_up_i64(w.c, off); o.L = mclf_shfl_up_i64(w.L, off); o.H = mclf_shfl_up_i64(w.H, off);
+    return o;
+}
+__device__ __forceinline__ long long mclf_readlane_i64_(long long v, int lane)
+{
+    const int lo = __builtin_amdgcn_readlane((int)(unsigned int)(unsigned long long)v, lane), hi = __builtin_amdgcn_readlane((int)(unsigned int)((unsigned long long)v >> 32), lane);
+    return (long long)(((unsigned long long)(unsigned int)hi << 32) | (unsigned long long)(unsigned int)lo);
+}
+__device__ __forceinline__ ss_wild mclf_readlane_wild(const ss_wild& w, int lane)
+{
+    ss_wild o;
+    o.key_in = __builtin_amdgcn_readlane(w.key_in, lane); o.key_out = __builtin_amdgcn_readlane(w.key_out, lane);
+    o.q = __builtin_amdgcn_readlane(w.q, lane); o.r = __builtin_amdgcn_readlane(w.r, lane);
+    o.a = mclf_readlane_i64_(w.a, lane); o.c = mclf_readlane_i64_(w.c, lane); o.L = mclf_readlane_i64_(w.L, lane); o.H = mclf_readlane_i64_(w.H, lane);
+    return o;
 }
 
 // ---- where things lie (one rank: the filter's own arrays; composed finish: the exchange blocks, mclf_shards)
@@ -341,7 +388,7 @@ __device__ __forceinline__ void mclf_prefix_in(int key, const double (&t)[MCLF_I
 // Record of one sub-tile (this wave's particles, MCLF_ITEMS consecutive ones per lane, `cnt` of them valid in this lane) for the
 // binade of the predicted start value; a risky one also gets a table if a slot is left.
 __device__ __forceinline__ ss_rec mclf_make_record(const mcl_finish_args& f, int axis, const double (&t)[MCLF_ITEMS], int cnt,
-                                                   double predicted_start, bool very_first, int lane)
+                                                   double predicted_start, bool very_first, int lane, int sub_index)
 {
     // (the first sub-tiles of the sums are the finisher's own work, done while the groups run: the sums start from zero, so
     // nothing is needed from the groups there, and the binade changes every few terms.  Their records are empty runs: no gap
@@ -352,6 +399,35 @@ __device__ __forceinline__ ss_rec mclf_make_record(const mcl_finish_args& f, int
     bool risky = true;
     ss_rec rec = ss_rec_make(MCLF_RISKY, 0, 0, 0);
     if (__builtin_amdgcn_ballot_w64(cnt > 0) == 0) return ss_rec_identity();                 // no particle in this sub-tile
+    if (f.wild && key) {
+        // ---- is the sum PREDICTED to leave its binade inside this sub-tile?  (a sum that hovers around zero does all the time:
+        // the reference starts every run at the origin.)  Then the sub-tile gets a wild map (bl_serial_sum.h) instead of a
+        // record: one scan of step maps over the wave, for the binade sequence a double-precision prefix sum predicts.
+        static_assert(MCLF_ITEMS == 2, "two terms per lane");
+        const double ls = (cnt > 0 ? t[0] : 0.0) + (cnt > 1 ? t[1] : 0.0);
+        double incl = ls;
+        for (int off = 1; off < 64; off <<= 1) { const double o = __shfl_up(incl, off, 64); if (lane >= off) incl += o; }
+        const double P1 = predicted_start + (incl - ls) + (cnt > 0 ? t[0] : 0.0), P2 = P1 + (cnt > 1 ? t[1] : 0.0);
+        const int k2 = ss_key((float)P2);                                   // the key behind this lane's terms ...
+        int k0 = __shfl_up(k2, 1, 64);                                      // ... is the key in front of the next lane's
+        if (lane == 0) k0 = key;
+        const int k1 = cnt > 1 ? ss_key((float)P1) : k2;
+        if (__builtin_amdgcn_ballot_w64(k1 != key || k2 != key) != 0ull) {
+            ss_wild w = cnt > 0 ? ssw_step(k0, k1, t[0]) : ssw_identity(k0);
+            if (cnt > 1) w = ssw_join(w, ssw_step(k1, k2, t[1]));
+            if (cnt > 0 && k0 == 0) w = ssw_invalid();
+            for (int off = 1; off < 64; off <<= 1) {
+                const ss_wild o = mclf_shfl_up_wild(w, off);
+                if (lane >= off) w = ssw_join(o, w);
+            }
+            const ss_wild all = mclf_readlane_wild(w, 63);
+            if (all.key_in != 0 && all.key_in == key) {
+                const int nsub = f.groups * (f.gthreads >> 6);
+                if (lane == 0) mclf_store_wild(f.wild + (size_t)axis * nsub + sub_index, all);
+                return ss_rec_make(MCLF_RISKY | MCLF_WILD, 0, 0, 0);
+            }
+        }
+    }
     if (key) {
         mclf_prefix_in(key, t, cnt, p, bad);
         int lo = SS_SAT, hi = -SS_SAT;
@@ -457,8 +533,8 @@ __device__ __forceinline__ void mclf_prefix_group(const mcl_finish_args& f, int 
     px /= S; py /= S;                                     // predicted accumulators where the group starts ...
     for (int w = 0; w < wave; ++w) { px += sm.wx[w]; py += sm.wy[w]; }      // ... and where this wave's sub-tile starts
     const bool very_first = g * nw + wave < MCLF_PRE_SUBS;
-    const ss_rec rx = mclf_make_record(f, 0, tx, cnt, px, very_first, lane);
-    const ss_rec ry = mclf_make_record(f, 1, ty, cnt, py, very_first, lane);
+    const ss_rec rx = mclf_make_record(f, 0, tx, cnt, px, very_first, lane, g * nw + wave);
+    const ss_rec ry = mclf_make_record(f, 1, ty, cnt, py, very_first, lane, g * nw + wave);
     MCLF_GSTAMP(5);
     if (lane == 0) {
         const int s = g * nw + wave;
@@ -641,7 +717,8 @@ __device__ __forceinline__ void mclf_stage_batch(const mcl_finish_args& f, const
         st.btail[b] = risky ? ss_rec_identity() : seg;
     }
     if (risky) {
-        const int e = atomicAdd(st.nent, 1);
+        // (a wild sub-tile is not something the list handles: its presence sends the chain to mclf_walk, which takes the maps)
+        const int e = atomicAdd(st.nent, (r.key & MCLF_WILD) ? MCLF_MAXENT + 1 : 1);
         if (e < MCLF_MAXENT) {
             mclf_ent en;
             int lo, hi;
@@ -669,8 +746,8 @@ __device__ __forceinline__ ss_rec mclf_join_batches(const mclf_stage& st, int b0
 
 // Records [ra, rb) of an axis walked with the true accumulator straight from global memory, replaying whatever does not fit
 // (the path for everything the staging did not foresee, and the whole chain when the scratch cannot hold the tables).
-__device__ __forceinline__ float mclf_walk(const mcl_finish_args& f, int axis, double S, int ra, int rb, float acc, int lane,
-                                           unsigned int* replays, unsigned int* phases)
+__device__ __forceinline__ float mclf_walk_plain(const mcl_finish_args& f, int axis, double S, int ra, int rb, float acc, int lane,
+                                                 unsigned int* replays, unsigned int* phases)
 {
     int r0 = ra;
     while (r0 < rb) {
@@ -701,6 +778,75 @@ __device__ __forceinline__ float mclf_walk(const mcl_finish_args& f, int axis, d
             r0 = s + 1;
         } else {
             r0 += nb;
+        }
+    }
+    return acc;
+}
+
+// The walk for sums with MANY sub-tiles that do not go by a record (a sum that hovers around zero: a third of its sub-tiles
+// cross binades): 64 records and their wild maps per round trip, the plain records between two risky ones joined once by a
+// segmented scan, and then per risky record one gap (a check and an add) and one wild map (a check and a few integer
+// operations), all from registers.  Whatever does not fit is replayed from the particle records as before.
+__device__ __forceinline__ float mclf_walk(const mcl_finish_args& f, int axis, double S, int ra, int rb, float acc, int lane,
+                                           unsigned int* replays, unsigned int* phases)
+{
+    if (!f.wild) return mclf_walk_plain(f, axis, S, ra, rb, acc, lane, replays, phases);
+    const int nsub = f.groups * (f.gthreads >> 6);
+    for (int r0 = ra; r0 < rb; r0 += 64) {
+        const int nb = min(64, rb - r0);
+        ss_rec r = ss_rec_identity();
+        ss_wild w = ssw_invalid();
+        if (lane < nb) {                                             // both loads in flight together
+            r = mclf_load_rec(mclf_rec_ptr(f, axis, r0 + lane));
+            w = mclf_load_wild(f.wild + (size_t)axis * nsub + r0 + lane);
+        }
+        const bool risky = r.key != SS_ID && (r.key & MCLF_RISKY) != 0;
+        const bool wild = risky && (r.key & MCLF_WILD) != 0;
+        unsigned long long rmask = __builtin_amdgcn_ballot_w64(risky);
+        const unsigned long long wmask = __builtin_amdgcn_ballot_w64(wild);
+        ss_rec v = r;
+        v.key = mclf_plain_key(r.key);
+        if (risky) v = ss_rec_identity();
+        const int head = (lane == 0 || ((rmask >> (lane - 1)) & 1ull)) ? 1 : 0;
+        const ss_rec seg = mclf_scan_join_segmented(v, head);        // lane l: the plain records from the last risky one (exclusive) to l
+        int prev = -1;                                               // last record of the batch taken care of
+        while (true) {
+            const int next = rmask ? __ffsll((long long)rmask) - 1 : nb;
+            if (next - 1 > prev) {                                   // the gap of plain records in front of `next`
+                const ss_rec gap = ss_rec_make(__builtin_amdgcn_readlane(seg.key, next - 1), __builtin_amdgcn_readlane(seg.D, next - 1),
+                                               __builtin_amdgcn_readlane(seg.lo, next - 1), __builtin_amdgcn_readlane(seg.hi, next - 1));
+                if (gap.key != SS_ID) {
+                    const int key = __builtin_amdgcn_readfirstlane(ss_key(acc));
+                    const int M = ss_mag(acc);
+                    if (key != 0 && ss_rec_fits(gap, key, M)) acc = ss_from(key, M + gap.D);
+                    else acc = mclf_walk_plain(f, axis, S, r0 + prev + 1, r0 + next, acc, lane, replays, phases);
+                }
+            }
+            if (next >= nb) break;
+            const int s = r0 + next;
+            bool done = false;
+            if ((wmask >> next) & 1ull) {
+                const ss_wild wn = mclf_readlane_wild(w, next);
+                const int key = __builtin_amdgcn_readfirstlane(ss_key(acc));
+                const long long m = ssw_signed(key, ss_mag(acc));
+                if (key != 0 && ssw_fits(wn, key, m)) {
+                    const long long mo = ssw_apply(wn, m);
+                    acc = ss_from(wn.key_out, (int)(mo < 0 ? -mo : mo));
+                    done = true;
+                }
+            }
+            if (!done) {
+                int lo, hi;
+                mclf_sub_range(f, s, &lo, &hi);
+                if (lo < hi) {
+                    double t[MCLF_ITEMS];
+                    mclf_load_terms(f, axis, S, lo, hi, lane, t);
+                    acc = mclf_replay(t, hi - lo, 0, 0, acc, lane, phases);
+                    *replays += 1;
+                }
+            }
+            prev = next;
+            rmask &= rmask - 1ull;
         }
     }
     return acc;

@@ -125,6 +125,86 @@ SS_HD bool ss_rec_fits(const ss_rec& r, int key, int M)
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
+// Runs that CROSS binades ("wild" runs): a sum that hovers around zero changes its binade -- and its sign -- every few terms, and
+// a record for one binade never fits.  But the binade SEQUENCE is predictable (a double-precision prefix sum of the terms gives
+// every intermediate value to ~1e-9 of its size), and for a given sequence the run is again a function of the incoming integer
+// alone.  With m = +-M the signed magnitude in units of the current binade's ulp u, a step into a binade whose ulp is u' = u 2^k
+//       m' = round((m u + t'') / u'),     t'' = t rounded to a multiple of v' = 2^(e' - 52)  (what fl64(acc + t) keeps of t)
+// is, with T = t'' / v' (an integer) and u' = 2^29 v':
+//       k >= 0:  m' = floor((m 2^(29-k) + T + 2^28) / 2^29) = (m + ((T + 2^28) >> (29 - k))) >> k          (nested floors)
+//       k <  0:  m' = (m << -k) + ((T + 2^28) >> 29)
+// (round half up differs from the hardware's round half even only on exact ties, which are flagged and never applied).  Maps
+//       G(m) = (((m + a) >> q) << r) + c
+// are closed under composition (ssw_join), so a run is summarised by ONE of them plus the interval [L, H] of inputs for which
+// every intermediate value stays strictly inside its predicted binade (each condition is an interval: the maps are monotone).
+// A wild record is only ever applied to an accumulator of its input binade whose magnitude lies in [L, H]: a wrong prediction
+// costs time (the run is replayed), never correctness.  tests/cpp/serial_sum_model.cpp checks all of it against the plain loop.
+#define SSW_INF (1ll << 60)
+#define SSW_MAXSHIFT 30
+struct ss_wild { int key_in, key_out, q, r; long long a, c, L, H; };      // key_in 0: applies to nothing
+
+SS_HD long long ssw_signed(int key, int M) { return (key & 0x200) ? -(long long)M : (long long)M; }
+SS_HD long long ssw_apply(const ss_wild& w, long long m) { return (((m + w.a) >> w.q) * (1ll << w.r)) + w.c; }
+SS_HD bool ssw_fits(const ss_wild& w, int key, long long m) { return w.key_in != 0 && w.key_in == key && m >= w.L && m <= w.H; }
+SS_HD ss_wild ssw_invalid() { ss_wild w; w.key_in = 0; w.key_out = 0; w.q = w.r = 0; w.a = w.c = 0; w.L = 1; w.H = 0; return w; }
+SS_HD ss_wild ssw_identity(int key) { ss_wild w = ssw_invalid(); w.key_in = w.key_out = key; w.L = -SSW_INF; w.H = SSW_INF; return w; }
+
+// inputs m with lo <= G(m) <= hi for G = (a, q, r, c); empty: L > H
+SS_HD void ssw_preimage(long long a, int q, int r, long long c, long long lo, long long hi, long long* L, long long* H)
+{
+    *L = -SSW_INF; *H = SSW_INF;
+    if (lo > -SSW_INF / 2) { const long long alpha = -((-(lo - c)) >> r); *L = alpha * (1ll << q) - a; }          // ceil((lo - c) / 2^r)
+    if (hi < SSW_INF / 2) { const long long beta = (hi - c) >> r; *H = (beta + 1) * (1ll << q) - 1 - a; }         // floor((hi - c) / 2^r)
+}
+
+// One step: an accumulator in binade key0 takes the term t and is predicted to land in binade key1.
+SS_HD ss_wild ssw_step(int key0, int key1, double t)
+{
+    ss_wild w = ssw_invalid();
+    if (!key0 || !key1) return w;
+    const int e1 = (key1 & 0xff) - 127, k = (key1 & 0xff) - (key0 & 0xff);
+    if (k > 28 || k < -8) return w;
+    const double qd = ldexp(t, 52 - e1);
+    if (!(fabs(qd) < 1.0e18)) return w;                                  // also nan
+    const long long T = (long long)rint(qd) + (1ll << 28);               // rint: to nearest even, like the double addition
+    long long lo, hi;
+    if (key1 & 0x200) { lo = -(long long)SS_MHI + 1; hi = -(long long)SS_MLO - 1; } else { lo = SS_MLO + 1; hi = SS_MHI - 1; }
+    if (k >= 0) {
+        const int sh = 29 - k;
+        if ((T & ((1ll << sh) - 1)) == 0) return w;                      // a tie (k = 0), or one for some m (k > 0)
+        w.a = T >> sh; w.q = k; w.r = 0; w.c = 0;
+    } else {
+        if ((T & ((1ll << 29) - 1)) == 0) return w;
+        w.a = 0; w.q = 0; w.r = -k; w.c = T >> 29;
+    }
+    ssw_preimage(w.a, w.q, w.r, w.c, lo, hi, &w.L, &w.H);
+    if (w.L > w.H) return w;
+    w.key_in = key0; w.key_out = key1;
+    return w;
+}
+
+// a, then b (b's input binade must be a's output binade)
+SS_HD ss_wild ssw_join(const ss_wild& A, const ss_wild& B)
+{
+    ss_wild w = ssw_invalid();
+    if (!A.key_in || !B.key_in || A.key_out != B.key_in) return w;
+    if (B.q <= A.r) {
+        w.a = A.a; w.q = A.q; w.r = A.r - B.q + B.r;
+        w.c = (((A.c + B.a) >> B.q) * (1ll << B.r)) + B.c;
+    } else {
+        const long long Bp = (A.c + B.a) >> A.r;
+        w.a = A.a + Bp * (1ll << A.q); w.q = A.q + B.q - A.r; w.r = B.r; w.c = B.c;
+    }
+    if (w.q > SSW_MAXSHIFT || w.r > SSW_MAXSHIFT) return ssw_invalid();
+    long long L, H;
+    ssw_preimage(A.a, A.q, A.r, A.c, B.L, B.H, &L, &H);
+    w.L = L > A.L ? L : A.L; w.H = H < A.H ? H : A.H;
+    if (w.L > w.H) return ssw_invalid();
+    w.key_in = A.key_in; w.key_out = B.key_out;
+    return w;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
 // The same for a DOUBLE accumulator stepped by doubles, c <- fl64(c + w): resamplePosteriorDistribution's cumulative weight
 // (src/slam/particle_filter.cpp:94-99).  One rounding per step (no float stage), 53-bit magnitudes in 64-bit integers.
 #define SSD_MLO (1ll << 52)

@@ -111,6 +111,56 @@ static float scheme(const std::vector<double>& t, int predict_mode, std::mt19937
     return chain(t, recs, st);
 }
 
+// ---- wild runs: per-term binade predictions from a double prefix sum, one map + interval per sub-tile (ssw_*), applied when the
+// true accumulator fits and replaced by plain steps when it does not
+struct WildStats { long subtiles = 0, built = 0, applied = 0, stepped = 0; };
+static float wild_scheme(const std::vector<double>& t, int predict_mode, int join_order, std::mt19937_64& rng, WildStats& ws)
+{
+    const int n = (int)t.size();
+    float acc = 0.0f;
+    double P = 0.0;
+    for (int base = 0; base < n; base += SUB) {
+        const int m = std::min(SUB, n - base);
+        ws.subtiles++;
+        // predictions: the key before the run and after every term
+        double drift = 0.0;
+        if (predict_mode == 1) drift = P * 1e-6 * ((double)(rng() % 2001) - 1000.0) / 1000.0;
+        if (predict_mode == 2) drift = ldexp(1.0, (int)(rng() % 30) - 40);
+        std::vector<int> keys(m + 1);
+        double Q = P + drift;
+        keys[0] = ss_key((float)Q);
+        std::vector<ss_wild> steps(m);
+        for (int i = 0; i < m; ++i) { Q += t[base + i]; keys[i + 1] = ss_key((float)Q); steps[i] = ssw_step(keys[i], keys[i + 1], t[base + i]); }
+        ss_wild rec;
+        if (join_order == 0) {                                   // left to right
+            rec = steps[0];
+            for (int i = 1; i < m; ++i) rec = ssw_join(rec, steps[i]);
+        } else {                                                 // a balanced tree, as a wave's scan joins them
+            std::vector<ss_wild> level = steps;
+            while (level.size() > 1) {
+                std::vector<ss_wild> next;
+                for (size_t i = 0; i + 1 < level.size(); i += 2) next.push_back(ssw_join(level[i], level[i + 1]));
+                if (level.size() & 1) next.push_back(level.back());
+                level.swap(next);
+            }
+            rec = level[0];
+        }
+        if (rec.key_in) ws.built++;
+        const int key = ss_key(acc);
+        const long long ms = key ? ssw_signed(key, ss_mag(acc)) : 0;
+        if (key && ssw_fits(rec, key, ms)) {
+            const long long mo = ssw_apply(rec, ms);
+            acc = ss_from(rec.key_out, (int)(mo < 0 ? -mo : mo));
+            ws.applied++;
+        } else {
+            for (int i = 0; i < m; ++i) acc = ss_exact_step(acc, t[base + i]);
+            ws.stepped++;
+        }
+        for (int i = 0; i < m; ++i) P += t[base + i];
+    }
+    return acc;
+}
+
 // ---- the double accumulator (resampling cumulative): every prefix value, by the phase loop alone
 static long check_double_scheme(std::mt19937_64& rng, long* cases)
 {
@@ -211,7 +261,40 @@ int main(int argc, char** argv)
         }
     }
     for (int round = 0; round < rounds; ++round) failures += check_double_scheme(rng, &cases);
-    printf("cases %ld failures %ld records %ld fitted %ld replays %ld phases %ld exact_steps %ld batches %ld\n", cases, failures, st.records,
-           st.fitted, st.replays, st.phases, st.exact_steps, st.batches);
+    // wild runs: sums that hover around zero (the reference's default start pose), and the adversarial kinds again
+    WildStats ws, ws_zero;
+    for (int round = 0; round < rounds; ++round) {
+        for (int kind = 0; kind < 12; ++kind) {
+            int n = 1 + (int)(rng() % (round % 5 == 0 ? 200000 : 6000));
+            std::vector<double> t(n);
+            const double spread = ldexp(1.0, (int)(rng() % 8) - 7);
+            const double centre = kind < 4 ? 0.0 : (kind < 8 ? spread * 1e-3 * nd(rng) : ldexp(1.0, (int)(rng() % 12) - 8) * ((rng() & 2) ? 1 : -1));
+            const double w = 1.0 / n;
+            for (int i = 0; i < n; ++i) {
+                const float x = (float)(centre + spread * nd(rng));
+                switch (kind % 4) {
+                case 0: t[i] = (w * (1.0 + 0.3 * nd(rng))) * (double)x; break;
+                case 1: t[i] = w * (double)x; break;
+                case 2: t[i] = ldexp((double)((int)(rng() % 65) - 32), -24 - (int)(rng() % 3)); break;       // few bits: ties
+                default: t[i] = (i % 53 == 0) ? -0.7 * (double)i * w * centre : w * (double)x; break;       // jolts
+                }
+            }
+            const float want = plain_loop(t);
+            for (int mode = 0; mode < 3; ++mode)
+                for (int order = 0; order < 2; ++order) {
+                    WildStats& tgt = (kind < 8 && mode == 0) ? ws_zero : ws;
+                    const float got = wild_scheme(t, mode, order, rng, tgt);
+                    cases++;
+                    if (ss_f2u(got) != ss_f2u(want) && !(got != got && want != want)) {
+                        if (failures < 10) fprintf(stderr, "WILD MISMATCH kind %d n %d mode %d order %d: got %.9g want %.9g\n", kind, n, mode, order, got, want);
+                        failures++;
+                    }
+                }
+        }
+    }
+    printf("cases %ld failures %ld records %ld fitted %ld replays %ld phases %ld exact_steps %ld batches %ld wild_subtiles %ld wild_built %ld wild_applied %ld "
+           "zero_subtiles %ld zero_applied %ld\n", cases, failures, st.records,
+           st.fitted, st.replays, st.phases, st.exact_steps, st.batches, ws.subtiles + ws_zero.subtiles, ws.built + ws_zero.built, ws.applied + ws_zero.applied,
+           ws_zero.subtiles, ws_zero.applied);
     return failures ? 1 : 0;
 }
