@@ -399,6 +399,7 @@ __device__ __forceinline__ ss_rec mclf_make_record(const mcl_finish_args& f, int
     bool risky = true;
     ss_rec rec = ss_rec_make(MCLF_RISKY, 0, 0, 0);
     if (__builtin_amdgcn_ballot_w64(cnt > 0) == 0) return ss_rec_identity();                 // no particle in this sub-tile
+    bool have_wild = false, up_only = false;
     if (f.wild && key) {
         // ---- is the sum PREDICTED to leave its binade inside this sub-tile?  (a sum that hovers around zero does all the time:
         // the reference starts every run at the origin.)  Then the sub-tile gets a wild map (bl_serial_sum.h) instead of a
@@ -412,6 +413,10 @@ __device__ __forceinline__ ss_rec mclf_make_record(const mcl_finish_args& f, int
         int k0 = __shfl_up(k2, 1, 64);                                      // ... is the key in front of the next lane's
         if (lane == 0) k0 = key;
         const int k1 = cnt > 1 ? ss_key((float)P1) : k2;
+        // (a sum that only steps UP into the next binade -- what a sum far from zero does log2 N times -- keeps its table: the table
+        // finds the crossing with the true accumulator, wherever it falls; a map needs the predicted step to be the true one:
+        // it gets a table as well, while slots last, and the list-driven chain takes the table)
+        up_only = __builtin_amdgcn_ballot_w64((k1 != key && k1 != key + 1) || (k2 != key && k2 != key + 1)) == 0ull && (key & 0xff) < 254;
         if (__builtin_amdgcn_ballot_w64(k1 != key || k2 != key) != 0ull) {
             ss_wild w = cnt > 0 ? ssw_step(k0, k1, t[0]) : ssw_identity(k0);
             if (cnt > 1) w = ssw_join(w, ssw_step(k1, k2, t[1]));
@@ -424,7 +429,8 @@ __device__ __forceinline__ ss_rec mclf_make_record(const mcl_finish_args& f, int
             if (all.key_in != 0 && all.key_in == key) {
                 const int nsub = f.groups * (f.gthreads >> 6);
                 if (lane == 0) mclf_store_wild(f.wild + (size_t)axis * nsub + sub_index, all);
-                return ss_rec_make(MCLF_RISKY | MCLF_WILD, 0, 0, 0);
+                have_wild = true;
+                if (!up_only) return ss_rec_make(MCLF_RISKY | MCLF_WILD, 0, 0, 0);
             }
         }
     }
@@ -460,6 +466,7 @@ __device__ __forceinline__ ss_rec mclf_make_record(const mcl_finish_args& f, int
             rec.key |= (slot + 1) << MCLF_TSLOT_SHIFT;
         }
     }
+    if (have_wild && (rec.key & MCLF_RISKY)) rec.key |= MCLF_WILD;          // (a record that is not risky goes by the book)
     return rec;
 }
 
@@ -571,14 +578,17 @@ __device__ __forceinline__ float mclf_replay(const double (&t)[MCLF_ITEMS], int 
         for (int i = pos; i < h; ++i) acc = ss_exact_step(acc, mclf_readlane_f64((i & 1) ? t[1] : t[0], i >> 1));
         pos = h;
     }
+    int budget = 4;                                                   // phases before the rest is simply stepped: a sub-tile that leaves
+                                                                      // its binade again and again costs 0.7 us per phase, 2.5 us stepped
     while (pos < n) {
         const int key = __builtin_amdgcn_readfirstlane(ss_key(acc));
-        if (!key) {                                                   // no usable binade (zero, tiny, not finite): the step itself
+        if (!key || budget == 0) {                                    // no usable binade (zero, tiny, not finite): the step itself
             const double tj = mclf_readlane_f64((pos & 1) ? t[1] : t[0], pos >> 1);
             acc = ss_exact_step(acc, tj);
             pos++;
             continue;
         }
+        budget--;
         *phases += 1;
         const int M = ss_mag(acc);
         const ss_bin b = ss_bin_of(key);
@@ -674,12 +684,13 @@ struct mclf_stage {
     mclf_step* step;              // [MCLF_MAXENT + 1]: entry k in sub-tile order with the gap in front of it; [nent]: the gap behind the last
     mclf_ent* ent;                // [MCLF_MAXENT], in arrival order
     int* order;                   // [MCLF_MAXENT]: entries by sub-tile index
+    ss_wild* wmap;                // [MCLF_MAXENT], in arrival order: the wild map of an entry that has one (tslot = -2 - arrival index)
     int* nent;                    // entries handed out (may exceed MCLF_MAXENT: the surplus is not listed)
 };
 __device__ __forceinline__ size_t mclf_stage_bytes(int nbatch)
 {
     return (size_t)MCLF_TSLOTS * MCLF_SUB * sizeof(mclf_tab_elem) + 2 * (size_t)nbatch * sizeof(ss_rec) + (MCLF_MAXENT + 1) * sizeof(mclf_step) +
-           MCLF_MAXENT * sizeof(mclf_ent) + MCLF_MAXENT * sizeof(int) + 16;
+           MCLF_MAXENT * sizeof(mclf_ent) + MCLF_MAXENT * sizeof(int) + MCLF_MAXENT * sizeof(ss_wild) + 16;
 }
 __device__ __forceinline__ mclf_stage mclf_stage_at(char* base, int nbatch)
 {
@@ -690,13 +701,14 @@ __device__ __forceinline__ mclf_stage mclf_stage_at(char* base, int nbatch)
     st.step = (mclf_step*)base; base += (MCLF_MAXENT + 1) * sizeof(mclf_step);
     st.ent = (mclf_ent*)base; base += MCLF_MAXENT * sizeof(mclf_ent);
     st.order = (int*)base; base += MCLF_MAXENT * sizeof(int);
+    st.wmap = (ss_wild*)base; base += MCLF_MAXENT * sizeof(ss_wild);
     st.nent = (int*)base;
     return st;
 }
 
 // One batch of 64 records of an axis, by one wave: composite, and the list entries of its risky records.
 // tbase: first staged slot of every rank's tables on this axis (a record names its table by its rank's own slot number)
-__device__ __forceinline__ void mclf_stage_batch(const mcl_finish_args& f, const mclf_stage& st, ss_rec r, int b, int lane, const int* tbase)
+__device__ __forceinline__ void mclf_stage_batch(const mcl_finish_args& f, const mclf_stage& st, ss_rec r, int b, int lane, const int* tbase, int axis)
 {
     const bool risky = r.key != SS_ID && (r.key & MCLF_RISKY) != 0;
     int tslot = r.key == SS_ID ? -1 : ((r.key >> MCLF_TSLOT_SHIFT) & 0xff) - 1;
@@ -717,14 +729,17 @@ __device__ __forceinline__ void mclf_stage_batch(const mcl_finish_args& f, const
         st.btail[b] = risky ? ss_rec_identity() : seg;
     }
     if (risky) {
-        // (a wild sub-tile is not something the list handles: its presence sends the chain to mclf_walk, which takes the maps)
-        const int e = atomicAdd(st.nent, (r.key & MCLF_WILD) ? MCLF_MAXENT + 1 : 1);
+        const int e = atomicAdd(st.nent, 1);
         if (e < MCLF_MAXENT) {
             mclf_ent en;
             int lo, hi;
             mclf_sub_range(f, b * 64 + lane, &lo, &hi);
             en.s = b * 64 + lane; en.tslot = tslot; en.tkey = pkey; en.lo_n = hi > lo ? ((lo << 8) | (hi - lo - 1)) : -1;
             en.head = seg;                                     // (its own record counts as the identity in the scan)
+            if (tslot < 0 && (r.key & MCLF_WILD) && f.wild) {  // no table: the sub-tile's wild map comes along (one more round trip, per lane)
+                st.wmap[e] = mclf_load_wild(f.wild + (size_t)axis * ((size_t)f.groups * (f.gthreads >> 6)) + b * 64 + lane);
+                en.tslot = -2 - e;
+            }
             st.ent[e] = en;
         }
     }
@@ -796,9 +811,19 @@ __device__ __forceinline__ float mclf_walk(const mcl_finish_args& f, int axis, d
         const int nb = min(64, rb - r0);
         ss_rec r = ss_rec_identity();
         ss_wild w = ssw_invalid();
-        if (lane < nb) {                                             // both loads in flight together
-            r = mclf_load_rec(mclf_rec_ptr(f, axis, r0 + lane));
-            w = mclf_load_wild(f.wild + (size_t)axis * nsub + r0 + lane);
+        if (lane < nb) {
+            // record and map as four 16-byte loads through the L2 (sc1), issued together and waited for once: as eight relaxed
+            // atomic loads they went out one behind the other -- eight round trips to memory per batch
+            const ss_rec* rp = mclf_rec_ptr(f, axis, r0 + lane);
+            const ss_wild* wp = f.wild + (size_t)axis * nsub + r0 + lane;
+            int4 q0, q1, q2, q3;
+            asm volatile("global_load_dwordx4 %0, %4, off sc1\n\tglobal_load_dwordx4 %1, %5, off sc1\n\t"
+                         "global_load_dwordx4 %2, %5, off offset:16 sc1\n\tglobal_load_dwordx4 %3, %5, off offset:32 sc1\n\ts_waitcnt vmcnt(0)"
+                         : "=&v"(q0), "=&v"(q1), "=&v"(q2), "=&v"(q3) : "v"(rp), "v"(wp) : "memory");
+            r = ss_rec_make(q0.x, q0.y, q0.z, q0.w);
+            w.key_in = q1.x; w.key_out = q1.y; w.q = q1.z; w.r = q1.w;
+            w.a = (long long)(((unsigned long long)(unsigned int)q2.y << 32) | (unsigned int)q2.x); w.c = (long long)(((unsigned long long)(unsigned int)q2.w << 32) | (unsigned int)q2.z);
+            w.L = (long long)(((unsigned long long)(unsigned int)q3.y << 32) | (unsigned int)q3.x); w.H = (long long)(((unsigned long long)(unsigned int)q3.w << 32) | (unsigned int)q3.z);
         }
         const bool risky = r.key != SS_ID && (r.key & MCLF_RISKY) != 0;
         const bool wild = risky && (r.key & MCLF_WILD) != 0;
@@ -810,16 +835,22 @@ __device__ __forceinline__ float mclf_walk(const mcl_finish_args& f, int axis, d
         const int head = (lane == 0 || ((rmask >> (lane - 1)) & 1ull)) ? 1 : 0;
         const ss_rec seg = mclf_scan_join_segmented(v, head);        // lane l: the plain records from the last risky one (exclusive) to l
         int prev = -1;                                               // last record of the batch taken care of
+        // between two replays the accumulator travels as integers -- (key, M), wave-uniform: a gap is a compare and an add, a wild
+        // map a compare and a few shifts; the float is only put together again for a replay and at the end of the batch
+        int key = __builtin_amdgcn_readfirstlane(ss_key(acc));
+        int M = __builtin_amdgcn_readfirstlane(ss_mag(acc));
         while (true) {
             const int next = rmask ? __ffsll((long long)rmask) - 1 : nb;
             if (next - 1 > prev) {                                   // the gap of plain records in front of `next`
                 const ss_rec gap = ss_rec_make(__builtin_amdgcn_readlane(seg.key, next - 1), __builtin_amdgcn_readlane(seg.D, next - 1),
                                                __builtin_amdgcn_readlane(seg.lo, next - 1), __builtin_amdgcn_readlane(seg.hi, next - 1));
                 if (gap.key != SS_ID) {
-                    const int key = __builtin_amdgcn_readfirstlane(ss_key(acc));
-                    const int M = ss_mag(acc);
-                    if (key != 0 && ss_rec_fits(gap, key, M)) acc = ss_from(key, M + gap.D);
-                    else acc = mclf_walk_plain(f, axis, S, r0 + prev + 1, r0 + next, acc, lane, replays, phases);
+                    if (key != 0 && ss_rec_fits(gap, key, M)) M += gap.D;
+                    else {
+                        if (key != 0) acc = ss_from_bits(key, M);
+                        acc = mclf_walk_plain(f, axis, S, r0 + prev + 1, r0 + next, acc, lane, replays, phases);
+                        key = __builtin_amdgcn_readfirstlane(ss_key(acc)); M = __builtin_amdgcn_readfirstlane(ss_mag(acc));
+                    }
                 }
             }
             if (next >= nb) break;
@@ -827,11 +858,10 @@ __device__ __forceinline__ float mclf_walk(const mcl_finish_args& f, int axis, d
             bool done = false;
             if ((wmask >> next) & 1ull) {
                 const ss_wild wn = mclf_readlane_wild(w, next);
-                const int key = __builtin_amdgcn_readfirstlane(ss_key(acc));
-                const long long m = ssw_signed(key, ss_mag(acc));
+                const long long m = ssw_signed(key, M);
                 if (key != 0 && ssw_fits(wn, key, m)) {
                     const long long mo = ssw_apply(wn, m);
-                    acc = ss_from(wn.key_out, (int)(mo < 0 ? -mo : mo));
+                    key = wn.key_out; M = (int)(mo < 0 ? -mo : mo);
                     done = true;
                 }
             }
@@ -841,13 +871,19 @@ __device__ __forceinline__ float mclf_walk(const mcl_finish_args& f, int axis, d
                 if (lo < hi) {
                     double t[MCLF_ITEMS];
                     mclf_load_terms(f, axis, S, lo, hi, lane, t);
-                    acc = mclf_replay(t, hi - lo, 0, 0, acc, lane, phases);
+                    // a wild sub-tile whose map does not fit crosses binades every few terms: stepping its 128 terms one by one
+                    // (2.5 us) beats a phase per crossing (0.7 us each, dozens of them)
+                    const bool was_wild = ((wmask >> next) & 1ull) != 0ull;
+                    if (key != 0) acc = ss_from_bits(key, M);
+                    acc = mclf_replay(t, hi - lo, 0, was_wild ? hi - lo : 0, acc, lane, phases);
+                    key = __builtin_amdgcn_readfirstlane(ss_key(acc)); M = __builtin_amdgcn_readfirstlane(ss_mag(acc));
                     *replays += 1;
                 }
             }
             prev = next;
             rmask &= rmask - 1ull;
         }
+        if (key != 0) acc = ss_from_bits(key, M);
     }
     return acc;
 }
@@ -884,14 +920,28 @@ __device__ __forceinline__ float mclf_chain(const mcl_finish_args& f, const mclf
         // the risky sub-tile itself
         if (sp.lo_n >= 0) {
             const int lo = sp.lo_n >> 8, n = (sp.lo_n & 0xff) + 1;
-            if (sp.tslot >= 0 && sp.tslot < ntab) {
+            bool by_map = false;
+            if (sp.tslot <= -2) {                                    // a wild sub-tile: its map, if the accumulator fits
+                ss_wild wn = st->wmap[-2 - sp.tslot];                // (wave-uniform LDS read)
+                wn = mclf_readlane_wild(wn, 0);
+                const int key = __builtin_amdgcn_readfirstlane(ss_key(acc));
+                const long long m = ssw_signed(key, ss_mag(acc));
+                if (key != 0 && ssw_fits(wn, key, m)) {
+                    const long long mo = ssw_apply(wn, m);
+                    acc = ss_from(wn.key_out, (int)(mo < 0 ? -mo : mo));
+                    stats[2] += 1;
+                    by_map = true;
+                }
+            }
+            if (by_map) { }
+            else if (sp.tslot >= 0 && sp.tslot < ntab) {
                 const mclf_tab_elem* row = st->tab + sp.tslot * MCLF_SUB + 2 * lane;
                 mclf_tab_elem el[MCLF_ITEMS] = {row[0], row[1]};
                 acc = mclf_replay_table(el, sp.tkey, n, 0, acc, lane, &stats[1], &stats[2]);
             } else {
                 double t[MCLF_ITEMS];
                 mclf_load_terms(f, axis, S, lo, lo + n, lane, t);
-                acc = mclf_replay(t, n, 0, 0, acc, lane, &stats[1]);
+                acc = mclf_replay(t, n, 0, sp.tslot <= -2 ? n : 0, acc, lane, &stats[1]);      // (a wild one that does not fit: stepped)
                 stats[0] += 1;
             }
         }
@@ -1086,7 +1136,7 @@ __device__ __forceinline__ void mclf_pose(const mcl_finish_args& f, mclf_smem& s
                 const int it = base + u * MCLF_MAXW;
                 if (it < nb2) {
                     const int axis = it >= nbatch ? 1 : 0, b = it - axis * nbatch;
-                    mclf_stage_batch(f, MCLF_STAGE(axis), rr[u], b, lane, sm.tbase[axis]);
+                    mclf_stage_batch(f, MCLF_STAGE(axis), rr[u], b, lane, sm.tbase[axis], axis);
                 } else if (it < items) {
                     const int q = it - nb2, axis = q >= ntab[0] ? 1 : 0, slot = q - axis * ntab[0];
                     mclf_tab_elem* dst = MCLF_STAGE(axis).tab + slot * MCLF_SUB + lane * MCLF_ITEMS;
@@ -1100,7 +1150,7 @@ __device__ __forceinline__ void mclf_pose(const mcl_finish_args& f, mclf_smem& s
         // ---- stage b: the list in sub-tile order (waves 0, 1), then one wave per gap
         if (wave < 2) {
             const mclf_stage a = MCLF_STAGE(wave);
-            const int n = min(*a.nent, MCLF_MAXENT);
+            const int n = *a.nent > MCLF_MAXENT ? 0 : *a.nent;              // (an overflowed list is no list: the chain walks)
             const int mine = lane < n ? a.ent[lane].s : 0x7fffffff;
             int rank = 0;
             for (int j = 0; j < n; ++j) rank += (__builtin_amdgcn_readlane(mine, j) < mine) ? 1 : 0;
@@ -1108,7 +1158,7 @@ __device__ __forceinline__ void mclf_pose(const mcl_finish_args& f, mclf_smem& s
         }
         __syncthreads();
         {
-            const int n0 = min(*MCLF_STAGE(0).nent, MCLF_MAXENT), n1 = min(*MCLF_STAGE(1).nent, MCLF_MAXENT);
+            const int n0 = *MCLF_STAGE(0).nent > MCLF_MAXENT ? 0 : *MCLF_STAGE(0).nent, n1 = *MCLF_STAGE(1).nent > MCLF_MAXENT ? 0 : *MCLF_STAGE(1).nent;
             for (int it = wave; it < n0 + n1 + 2; it += MCLF_MAXW) {
                 const int axis = it > n0 ? 1 : 0, k = it - axis * (n0 + 1);
                 const mclf_stage a = MCLF_STAGE(axis);

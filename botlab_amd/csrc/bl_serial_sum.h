@@ -144,7 +144,9 @@ SS_HD bool ss_rec_fits(const ss_rec& r, int key, int M)
 struct ss_wild { int key_in, key_out, q, r; long long a, c, L, H; };      // key_in 0: applies to nothing
 
 SS_HD long long ssw_signed(int key, int M) { return (key & 0x200) ? -(long long)M : (long long)M; }
-SS_HD long long ssw_apply(const ss_wild& w, long long m) { return (((m + w.a) >> w.q) * (1ll << w.r)) + w.c; }
+SS_HD long long ssw_apply(const ss_wild& w, long long m) { return (long long)((unsigned long long)((m + w.a) >> w.q) << w.r) + w.c; }
+// the float of binade `key` with magnitude M, 2^23 <= M < 2^24, put together from its bits
+SS_HD float ss_from_bits(int key, int M) { return ss_u2f(((uint32_t)(key & 0x200) << 22) | ((uint32_t)(key & 0xff) << 23) | ((uint32_t)M & 0x7fffffu)); }
 SS_HD bool ssw_fits(const ss_wild& w, int key, long long m) { return w.key_in != 0 && w.key_in == key && m >= w.L && m <= w.H; }
 SS_HD ss_wild ssw_invalid() { ss_wild w; w.key_in = 0; w.key_out = 0; w.q = w.r = 0; w.a = w.c = 0; w.L = 1; w.H = 0; return w; }
 SS_HD ss_wild ssw_identity(int key) { ss_wild w = ssw_invalid(); w.key_in = w.key_out = key; w.L = -SSW_INF; w.H = SSW_INF; return w; }
