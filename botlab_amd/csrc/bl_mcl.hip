@@ -771,11 +771,12 @@ __global__ __launch_bounds__(BLOCK) void k_mcl_main(mcl_args a)
     const mcl_prefix_view pview = {a.sh, a.prefix};
     if (a.resample && (!shared_pro || wave < pw)) {                  // whole waves: the narrowing is cooperative
         if (pro_active) { rs_T = a.r + mp * a.M_inv; if (!a.strict) rs_T *= a.state->S; }      // U (particle_filter.cpp:95), or U * S
-        resample_bracket(pview, a.N, rs_T, pro_active, lane, &rs_lo, &rs_hi, a.strict != 0);
+        if (a.sh) resample_bracket(pview, a.N, rs_T, pro_active, lane, &rs_lo, &rs_hi, a.strict != 0);
+        else resample_bracket(a.prefix, a.N, rs_T, pro_active, lane, &rs_lo, &rs_hi, a.strict != 0);
     }
     MCL_STAMP(5);                                                // the bracket is known
     if (pro_active) {
-        if (a.resample) i = resample_bisect(pview, rs_T, rs_lo, rs_hi, a.strict != 0);
+        if (a.resample) i = a.sh ? resample_bisect(pview, rs_T, rs_lo, rs_hi, a.strict != 0) : resample_bisect(a.prefix, rs_T, rs_lo, rs_hi, a.strict != 0);
         MCL_STAMP(6);
         s = mcl_src_at(a, i);
         // ---- ActionModel::applyAction (action_model.cpp:78-103)
@@ -1572,6 +1573,9 @@ static int pf_launch_main(bl_pf* pf, const bl_grid* map, int R, int rand_value, 
     if (map && pf->split_log2_override >= 0) a.split_log2 = pf->split_log2_override;
     else if (map) {
         while (a.split_log2 < 6 && ((int64_t)pf->n_local << a.split_log2) < (int64_t)MCL_MIN_BLOCKS * block) a.split_log2++;
+        // ... and, up to four lanes per particle, until the launch is about two rounds of the machine: 256 000 particles at two
+        // lanes are 1000 workgroups -- one round and a third -- and took 0.309 ms where four lanes (2000 workgroups) take 0.252
+        while (a.split_log2 < 2 && ((int64_t)pf->n_local << a.split_log2) < (int64_t)1400 * block) a.split_log2++;
     }
     while (a.split_log2 > 0 && (1 << a.split_log2) > R) a.split_log2--;
     // Whole rounds.  All workgroups of this VALU-bound kernel take about the same time T, so 782 workgroups on a machine
@@ -1593,7 +1597,10 @@ static int pf_launch_main(bl_pf* pf, const bl_grid* map, int R, int rand_value, 
         if (per_cu < 1) per_cu = 1;
         const int64_t round = (int64_t)cus * per_cu - (int64_t)cus * per_cu / 32;
         const int64_t full = main_blocks / round, excess = main_blocks - full * round;
-        if (full >= 1 && excess > 0 && excess * 8 < round * 5) {
+        // (a particle of the second region costs a wave about a tenth of a region-1 workgroup's time, and the device runs ~6000
+        // such waves at once: past ~25 000 excess particles the second region outlasts the straggling round it replaces --
+        // 65 536 of them made the 256 000-particle launch of BASELINE.json's configs[4] 17 % slower)
+        if (full >= 1 && excess > 0 && excess * 8 < round * 5 && excess * gpb <= 24576) {
             main_blocks = full * round;
             main_particles = main_blocks * gpb;
             tail_blocks = ((int64_t)pf->n_local - main_particles + tail_tile - 1) / tail_tile;

@@ -399,8 +399,23 @@ __device__ __forceinline__ ss_rec mclf_make_record(const mcl_finish_args& f, int
     bool risky = true;
     ss_rec rec = ss_rec_make(MCLF_RISKY, 0, 0, 0);
     if (__builtin_amdgcn_ballot_w64(cnt > 0) == 0) return ss_rec_identity();                 // no particle in this sub-tile
+    if (key) {
+        mclf_prefix_in(key, t, cnt, p, bad);
+        int lo = SS_SAT, hi = -SS_SAT;
+#pragma unroll
+        for (int k = 0; k < MCLF_ITEMS; ++k)
+            if (k < cnt) { lo = min(lo, p[k]); hi = max(hi, p[k]); }
+        lo = mclf_wave_min(lo); hi = mclf_wave_max(hi);
+        const int D = __builtin_amdgcn_readlane(p[MCLF_ITEMS - 1], 63);
+        const bool anybad = __builtin_amdgcn_ballot_w64((bad[0] | bad[1]) != 0) != 0;
+        // "risky": with the predicted start magnitude and a margin for its error the run would not stay inside the binade
+        const int Mp = ss_mag((float)predicted_start);
+        risky = anybad || !(Mp + lo - MCLF_MARGIN > SS_MLO && Mp + hi + MCLF_MARGIN < SS_MHI);
+        rec = anybad ? ss_rec_make(MCLF_RISKY, 0, 0, 0) : ss_rec_make(key | (risky ? MCLF_RISKY : 0), D, lo, hi);
+    }
+    // (only a sub-tile whose in-binade prefix sums come near the binade's ends can leave it: the others skip the prediction scan)
     bool have_wild = false, up_only = false;
-    if (f.wild && key) {
+    if (risky && f.wild && key) {
         // ---- is the sum PREDICTED to leave its binade inside this sub-tile?  (a sum that hovers around zero does all the time:
         // the reference starts every run at the origin.)  Then the sub-tile gets a wild map (bl_serial_sum.h) instead of a
         // record: one scan of step maps over the wave, for the binade sequence a double-precision prefix sum predicts.
@@ -433,20 +448,6 @@ __device__ __forceinline__ ss_rec mclf_make_record(const mcl_finish_args& f, int
                 if (!up_only) return ss_rec_make(MCLF_RISKY | MCLF_WILD, 0, 0, 0);
             }
         }
-    }
-    if (key) {
-        mclf_prefix_in(key, t, cnt, p, bad);
-        int lo = SS_SAT, hi = -SS_SAT;
-#pragma unroll
-        for (int k = 0; k < MCLF_ITEMS; ++k)
-            if (k < cnt) { lo = min(lo, p[k]); hi = max(hi, p[k]); }
-        lo = mclf_wave_min(lo); hi = mclf_wave_max(hi);
-        const int D = __builtin_amdgcn_readlane(p[MCLF_ITEMS - 1], 63);
-        const bool anybad = __builtin_amdgcn_ballot_w64((bad[0] | bad[1]) != 0) != 0;
-        // "risky": with the predicted start magnitude and a margin for its error the run would not stay inside the binade
-        const int Mp = ss_mag((float)predicted_start);
-        risky = anybad || !(Mp + lo - MCLF_MARGIN > SS_MLO && Mp + hi + MCLF_MARGIN < SS_MHI);
-        rec = anybad ? ss_rec_make(MCLF_RISKY, 0, 0, 0) : ss_rec_make(key | (risky ? MCLF_RISKY : 0), D, lo, hi);
     }
     if (risky && f.tabs) {
         // the table: terms, prefix in the predicted binade (if there is one), prefix in the next binade up
