@@ -385,6 +385,33 @@ __device__ __forceinline__ void mclf_prefix_in(int key, const double (&t)[MCLF_I
     for (int k = 0; k < MCLF_ITEMS; ++k) p[k] += excl;
 }
 
+// The wild map of a sub-tile (bl_serial_sum.h): one scan of step maps over the wave, for the binade sequence a double-precision
+// prefix sum of the terms predicts; stored in f.wild when it is valid for the predicted input binade `key`.
+__device__ __forceinline__ bool mclf_build_wild(const mcl_finish_args& f, int axis, const double (&t)[MCLF_ITEMS], int cnt, double predicted_start,
+                                             int key, int lane, int sub_index)
+{
+    static_assert(MCLF_ITEMS == 2, "two terms per lane");
+    const double ls = (cnt > 0 ? t[0] : 0.0) + (cnt > 1 ? t[1] : 0.0);
+    double incl = ls;
+    for (int off = 1; off < 64; off <<= 1) { const double o = __shfl_up(incl, off, 64); if (lane >= off) incl += o; }
+    const double P1 = predicted_start + (incl - ls) + (cnt > 0 ? t[0] : 0.0), P2 = P1 + (cnt > 1 ? t[1] : 0.0);
+    const int k2 = ss_key((float)P2);                                   // the key behind this lane's terms ...
+    int k0 = __shfl_up(k2, 1, 64);                                      // ... is the key in front of the next lane's
+    if (lane == 0) k0 = key;
+    const int k1 = cnt > 1 ? ss_key((float)P1) : k2;
+    ss_wild w = cnt > 0 ? ssw_step(k0, k1, t[0]) : ssw_identity(k0);
+    if (cnt > 1) w = ssw_join(w, ssw_step(k1, k2, t[1]));
+    for (int off = 1; off < 64; off <<= 1) {
+        const ss_wild o = mclf_shfl_up_wild(w, off);
+        if (lane >= off) w = ssw_join(o, w);
+    }
+    const ss_wild all = mclf_readlane_wild(w, 63);
+    if (all.key_in == 0 || all.key_in != key) return false;
+    const int nsub = f.groups * (f.gthreads >> 6);
+    if (lane == 0) mclf_store_wild(f.wild + (size_t)axis * nsub + sub_index, all);
+    return true;
+}
+
 // Record of one sub-tile (this wave's particles, MCLF_ITEMS consecutive ones per lane, `cnt` of them valid in this lane) for the
 // binade of the predicted start value; a risky one also gets a table if a slot is left.
 __device__ __forceinline__ ss_rec mclf_make_record(const mcl_finish_args& f, int axis, const double (&t)[MCLF_ITEMS], int cnt,
@@ -396,7 +423,7 @@ __device__ __forceinline__ ss_rec mclf_make_record(const mcl_finish_args& f, int
     if (very_first) return ss_rec_identity();
     const int key = __builtin_amdgcn_readfirstlane(ss_key((float)predicted_start));
     int p[MCLF_ITEMS] = {0, 0}, bad[MCLF_ITEMS] = {0, 0};
-    bool risky = true;
+    bool risky = true, up_only = false, have_wild = false;
     ss_rec rec = ss_rec_make(MCLF_RISKY, 0, 0, 0);
     if (__builtin_amdgcn_ballot_w64(cnt > 0) == 0) return ss_rec_identity();                 // no particle in this sub-tile
     if (key) {
@@ -412,44 +439,17 @@ __device__ __forceinline__ ss_rec mclf_make_record(const mcl_finish_args& f, int
         const int Mp = ss_mag((float)predicted_start);
         risky = anybad || !(Mp + lo - MCLF_MARGIN > SS_MLO && Mp + hi + MCLF_MARGIN < SS_MHI);
         rec = anybad ? ss_rec_make(MCLF_RISKY, 0, 0, 0) : ss_rec_make(key | (risky ? MCLF_RISKY : 0), D, lo, hi);
+        // the same prefix sums say HOW a risky sub-tile is predicted to leave, if at all: not downwards, and upwards no further
+        // than the next binade (they keep measuring the magnitude there, in this binade's ulps) -- what a sum far from zero does
+        // log2 N times, and what the sub-tiles right behind such a crossing look like (just above the binade's lower end)
+        up_only = !anybad && Mp + lo > SS_MLO && Mp + hi + MCLF_MARGIN < 2 * SS_MHI && (key & 0xff) < 254;
     }
-    // (only a sub-tile whose in-binade prefix sums come near the binade's ends can leave it: the others skip the prediction scan)
-    bool have_wild = false, up_only = false;
-    if (risky && f.wild && key) {
-        // ---- is the sum PREDICTED to leave its binade inside this sub-tile?  (a sum that hovers around zero does all the time:
-        // the reference starts every run at the origin.)  Then the sub-tile gets a wild map (bl_serial_sum.h) instead of a
-        // record: one scan of step maps over the wave, for the binade sequence a double-precision prefix sum predicts.
-        static_assert(MCLF_ITEMS == 2, "two terms per lane");
-        const double ls = (cnt > 0 ? t[0] : 0.0) + (cnt > 1 ? t[1] : 0.0);
-        double incl = ls;
-        for (int off = 1; off < 64; off <<= 1) { const double o = __shfl_up(incl, off, 64); if (lane >= off) incl += o; }
-        const double P1 = predicted_start + (incl - ls) + (cnt > 0 ? t[0] : 0.0), P2 = P1 + (cnt > 1 ? t[1] : 0.0);
-        const int k2 = ss_key((float)P2);                                   // the key behind this lane's terms ...
-        int k0 = __shfl_up(k2, 1, 64);                                      // ... is the key in front of the next lane's
-        if (lane == 0) k0 = key;
-        const int k1 = cnt > 1 ? ss_key((float)P1) : k2;
-        // (a sum that only steps UP into the next binade -- what a sum far from zero does log2 N times -- keeps its table: the table
-        // finds the crossing with the true accumulator, wherever it falls; a map needs the predicted step to be the true one:
-        // it gets a table as well, while slots last, and the list-driven chain takes the table)
-        up_only = __builtin_amdgcn_ballot_w64((k1 != key && k1 != key + 1) || (k2 != key && k2 != key + 1)) == 0ull && (key & 0xff) < 254;
-        if (__builtin_amdgcn_ballot_w64(k1 != key || k2 != key) != 0ull) {
-            ss_wild w = cnt > 0 ? ssw_step(k0, k1, t[0]) : ssw_identity(k0);
-            if (cnt > 1) w = ssw_join(w, ssw_step(k1, k2, t[1]));
-            if (cnt > 0 && k0 == 0) w = ssw_invalid();
-            for (int off = 1; off < 64; off <<= 1) {
-                const ss_wild o = mclf_shfl_up_wild(w, off);
-                if (lane >= off) w = ssw_join(o, w);
-            }
-            const ss_wild all = mclf_readlane_wild(w, 63);
-            if (all.key_in != 0 && all.key_in == key) {
-                const int nsub = f.groups * (f.gthreads >> 6);
-                if (lane == 0) mclf_store_wild(f.wild + (size_t)axis * nsub + sub_index, all);
-                have_wild = true;
-                if (!up_only) return ss_rec_make(MCLF_RISKY | MCLF_WILD, 0, 0, 0);
-            }
-        }
-    }
-    if (risky && f.tabs) {
+    // A risky sub-tile that only steps UP goes by a TABLE while slots last: the table finds the crossing with the true accumulator,
+    // wherever it falls.  Every other one (a sum that hovers around zero leaves its binade up and down and through zero all the
+    // time: the reference starts every run at the origin), and an upward one without a slot, gets a wild map below.
+    const bool dirty = risky && f.wild != nullptr && key != 0;
+    bool got_table = false;
+    if (risky && f.tabs && (!dirty || up_only)) {
         // the table: terms, prefix in the predicted binade (if there is one), prefix in the next binade up
         unsigned long long got = 0;
         if (lane == 0) got = __hip_atomic_fetch_add(mclf_tab_counter(f), axis ? (1ull << 16) : 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -465,7 +465,13 @@ __device__ __forceinline__ ss_rec mclf_make_record(const mcl_finish_args& f, int
                 mclf_store_tab(tab + lane * MCLF_ITEMS + k, t[k], se, se1);
             }
             rec.key |= (slot + 1) << MCLF_TSLOT_SHIFT;
+            got_table = slot < MCLF_TSLOTS / 2;                // (a sum that has used up half of its tables is not one that only
+                                                               // crosses a binade now and then: its sub-tiles get maps as well)
         }
+    }
+    if (dirty && !got_table) {
+        have_wild = mclf_build_wild(f, axis, t, cnt, predicted_start, key, lane, sub_index);
+        if (have_wild && !up_only) return ss_rec_make(MCLF_RISKY | MCLF_WILD, 0, 0, 0);
     }
     if (have_wild && (rec.key & MCLF_RISKY)) rec.key |= MCLF_WILD;          // (a record that is not risky goes by the book)
     return rec;
@@ -763,7 +769,7 @@ __device__ __forceinline__ ss_rec mclf_join_batches(const mclf_stage& st, int b0
 // Records [ra, rb) of an axis walked with the true accumulator straight from global memory, replaying whatever does not fit
 // (the path for everything the staging did not foresee, and the whole chain when the scratch cannot hold the tables).
 __device__ __forceinline__ float mclf_walk_plain(const mcl_finish_args& f, int axis, double S, int ra, int rb, float acc, int lane,
-                                                 unsigned int* replays, unsigned int* phases)
+                                              unsigned int* replays, unsigned int* phases)
 {
     int r0 = ra;
     while (r0 < rb) {
@@ -804,7 +810,7 @@ __device__ __forceinline__ float mclf_walk_plain(const mcl_finish_args& f, int a
 // segmented scan, and then per risky record one gap (a check and an add) and one wild map (a check and a few integer
 // operations), all from registers.  Whatever does not fit is replayed from the particle records as before.
 __device__ __forceinline__ float mclf_walk(const mcl_finish_args& f, int axis, double S, int ra, int rb, float acc, int lane,
-                                           unsigned int* replays, unsigned int* phases)
+                                        unsigned int* replays, unsigned int* phases)
 {
     if (!f.wild) return mclf_walk_plain(f, axis, S, ra, rb, acc, lane, replays, phases);
     const int nsub = f.groups * (f.gthreads >> 6);

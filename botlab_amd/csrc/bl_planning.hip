@@ -32,6 +32,7 @@ struct bl_dist {
     uint16_t* l1;             // L1 distance (0xFFFF: no source anywhere)
     float* cells;             // float distances handed to callers: f[l1], allocated and formed when a caller first asks (floats_valid)
     bool floats_valid;
+    bool floats_handed_out;   // bl_dist_device_ptr has been called: a caller may read the floats without asking again (see there)
     float* lut;               // device f[n]
     int32_t* closed;          // A* closed-cell scratch of this grid: (generation << 3) | move code; an entry of another generation
                               // than the running search's is "not closed" -- no clearing between searches (k_astar)
@@ -58,6 +59,8 @@ struct bl_dist {
 #define DIST_MAX_BATCH 32
 struct dist_batch {
     const int8_t* cells[DIST_MAX_BATCH]; uint16_t* row[DIST_MAX_BATCH]; uint16_t* l1[DIST_MAX_BATCH];
+    float* out[DIST_MAX_BATCH]; const float* lut[DIST_MAX_BATCH];      // small grids: the float grid, written by the column pass when a
+                                                                       // caller holds its device pointer (bl_dist_device_ptr); else null
     int* sum_f[DIST_MAX_BATCH]; int* sum_b[DIST_MAX_BATCH];
     unsigned int* state[DIST_MAX_BATCH]; unsigned int* hstat[DIST_MAX_BATCH];
     const int4* log[DIST_MAX_BATCH]; unsigned int from[DIST_MAX_BATCH], to[DIST_MAX_BATCH];   // incremental: map updates from + 1 .. to of the log
@@ -289,6 +292,8 @@ __global__ __launch_bounds__(DCOL_TX * DCOL_TY) void k_dist_cols(dist_batch db, 
 {
     const uint16_t* __restrict__ row = db.row[blockIdx.z];
     uint16_t* __restrict__ l1 = db.l1[blockIdx.z];
+    float* __restrict__ out = db.out[blockIdx.z];
+    const float* __restrict__ lut = db.lut[blockIdx.z];
     __shared__ int s_fwd[DCOL_TY][DCOL_TX];
     __shared__ int s_bwd[DCOL_TY][DCOL_TX];
     const int tx = threadIdx.x, ty = threadIdx.y;
@@ -337,6 +342,7 @@ __global__ __launch_bounds__(DCOL_TX * DCOL_TY) void k_dist_cols(dist_batch db, 
         int v = min(f, b);
         bool none = v >= 0xFFFF;
         l1[(size_t)y * W + x] = none ? (uint16_t)0xFFFF : (uint16_t)v;
+        if (out) out[(size_t)y * W + x] = none ? -1.0f : lut[v];
     }
 }
 
@@ -910,6 +916,7 @@ static int dist_set_distances_batch(int n, bl_dist* const* ds, const bl_grid* co
         if (rc) return rc;
         all_inc = all_inc && inc; all_same = all_same && same;
         b.cells[u] = maps[u]->cells; b.row[u] = d->row; b.l1[u] = d->l1;
+        b.out[u] = nullptr; b.lut[u] = d->lut;
         b.sum_f[u] = d->sum_f; b.sum_b[u] = d->sum_b; b.state[u] = d->state; b.hstat[u] = d->h_status_dev;
         b.log[u] = maps[u]->log ? maps[u]->log->dev : nullptr;
         b.from[u] = (unsigned int)from; b.to[u] = (unsigned int)maps[u]->version;
@@ -998,6 +1005,8 @@ static int dist_set_distances_batch(int n, bl_dist* const* ds, const bl_grid* co
     for (int u = 0; u < n; ++u) {
         bl_dist* d = ds[u];
         d->valid = true;
+        // a caller that holds the float grid's device pointer gets it formed with every transform (it may not ask again)
+        if (d->floats_handed_out) { const int rcf = dist_floats(d); if (rcf) return rcf; }
         if (all_inc) d->n_inc += 1; else d->n_full += 1;
         // l1 is now the transform of this version of this lineage (the small-grid and two-pass column kernels keep no bound D: the
         // next transform is a full one as well)
@@ -1065,7 +1074,9 @@ extern "C" int bl_dist_frame(const bl_dist* d, float* mpc, float* cpm, float* ox
 
 extern "C" void* bl_dist_device_ptr(bl_dist* d)
 {
-    if (!d || !d->valid) return d ? (void*)d->cells : nullptr;
+    if (!d) return nullptr;
+    d->floats_handed_out = true;                       // from now on every setDistances forms the floats (on d's stream, behind the transform)
+    if (!d->valid) return (void*)d->cells;
     if (dist_floats(d) != BL_OK) return nullptr;
     return (void*)d->cells;
 }

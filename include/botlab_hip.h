@@ -196,10 +196,10 @@ int bl_dist_debug_stats(bl_dist* d, int64_t* out6);
 int bl_dist_download(bl_dist* d, float* cells);                           /* width*height floats (synchronises) */
 int bl_dist_shape(const bl_dist* d, int* width, int* height);
 int bl_dist_frame(const bl_dist* d, float* meters_per_cell, float* cells_per_meter, float* origin_x, float* origin_y);
-/* float* in HBM.  The float grid is formed on the first request after a setDistances, on the ctx stream at the time of THIS
- * call: the contents are valid for work ordered behind this call on that stream and only until the next
- * bl_dist_set_distances on `d` -- a caller that keeps the pointer across setDistances calls must request it again (the
- * address stays the same while the shape does; the floats behind it would be the previous transform's). */
+/* float* in HBM.  A replan never needs the floats (the search reads the integer distances), so they are only formed for callers
+ * that ask: bl_dist_download / bl_dist_gather on demand, and -- once this pointer has been handed out -- with every later
+ * bl_dist_set_distances on `d`, on d's stream behind the transform, so that a caller who keeps the pointer keeps reading the
+ * current transform.  (NULL before the first request on a grid that has never been transformed.) */
 void* bl_dist_device_ptr(bl_dist* d);
 
 /* ------------------------------------------------------------------ search_for_path  (src/planning/astar.hpp:58-61, astar.cpp:9-274)
