@@ -53,6 +53,8 @@ def build_inputs(args, total_steps, ctx=None):
     else:
         # a 0.8 m square loop that keeps >= 0.2 m clearance inside the mapped arena of obstacle_slam (searched offline)
         start, side = (-0.75, 0.2, 0.0), 0.8
+    if getattr(args, "start", None) is not None and args.grid == 200:
+        start, side = tuple(args.start), 0.6
     truth = np.where(m["cells"] > 0, 127, -127).astype(np.int8)
     rng = np.random.default_rng(1234)
     poses = synth.square_trajectory(start, total_steps, step_len=0.02, turn=0.05, side=side)
@@ -153,9 +155,12 @@ def self_launch(n):
     return 0
 
 
-OTHER_CONFIGS = [                                      # (preset, goal_l1 in cells): short runs printed beside the headline
-    (3, 0), (4, 40), (4, 400), (5, 40),                # preset 3 (1M particles on one GPU) has no replan: its goal is unused
+OTHER_CONFIGS = [                                      # (preset, goal_l1 in cells, extra flags): short runs printed beside the headline
+    (0, 0, ["--start", "0", "0", "0"]),                # the headline workload from the reference's own start pose (slam.cpp:64-66): the
+                                                       # float sums of estimatePosteriorPose hover around zero there
+    (3, 0, []), (4, 40, []), (4, 400, []), (5, 40, []),    # preset 3 (1M particles on one GPU) has no replan: its goal is unused
 ]
+OTHER_BUDGET_S = 240.0                                 # wall clock all of them together may take: a slow or hung child costs the others, never the headline
 
 
 def run_other_configs(steps, warmup):
@@ -168,24 +173,29 @@ def run_other_configs(steps, warmup):
     initialises HIP (a child is a fork + exec)."""
     import subprocess
     out = []
-    for cfg, l1 in OTHER_CONFIGS:
+    t_all = time.perf_counter()
+    for cfg, l1, extra in OTHER_CONFIGS:
+        left = OTHER_BUDGET_S - (time.perf_counter() - t_all)
+        if left < 10.0:
+            out.append({"config": cfg, "goal_l1_cells": l1, "flags": extra, "error": "skipped: the other_configs wall-clock budget was spent"})
+            continue
         cmd = [sys.executable, os.path.abspath(__file__), "--config", str(cfg), "--goal-l1", str(max(l1, 1)), "--steps", str(steps), "--warmup", str(warmup),
-               "--cpu-steps", "0", "--sub"]
+               "--cpu-steps", "0", "--sub"] + extra
         t0 = time.perf_counter()
         try:
-            r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=420)
+            r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=min(120.0, left))
             line = [l for l in r.stdout.decode(errors="replace").splitlines() if l.startswith("{")]
             if r.returncode != 0 or not line:
                 err = [l for l in r.stderr.decode(errors="replace").splitlines() if l.strip()]
-                out.append({"config": cfg, "goal_l1_cells": l1, "error": err[-1][-300:] if err else f"exit {r.returncode}"})
+                out.append({"config": cfg, "goal_l1_cells": l1, "flags": extra, "error": err[-1][-300:] if err else f"exit {r.returncode}"})
                 continue
             d = json.loads(line[-1])
-            out.append({"config": cfg, "goal_l1_cells": l1, "workload": d["config"]["workload"], "value": d["value"], "unit": d["unit"],
+            out.append({"config": cfg, "goal_l1_cells": l1, "flags": extra, "workload": d["config"]["workload"], "value": d["value"], "unit": d["unit"],
                         "steps": d["steps"], "warmup": d["warmup"], "ms_per_step": d["ms_per_step"], "astar_pops_per_step": d["astar_pops_per_step"],
                         "stage_ms": d["stage_ms"], "planner": [d["config"]["planner_lanes"], d["config"]["planner_batch"], d["config"]["pipeline_depth"]],
                         "streaming_kernels": d.get("streaming_kernels"), "wall_s": round(time.perf_counter() - t0, 1)})
         except subprocess.TimeoutExpired:
-            out.append({"config": cfg, "goal_l1_cells": l1, "error": "timed out after 420 s"})
+            out.append({"config": cfg, "goal_l1_cells": l1, "flags": extra, "error": "timed out"})
     return out
 
 
@@ -236,6 +246,8 @@ def main():
                     help="the shipped 200x200 map (tests/golden/reference_maps.npz) scans are cast on and the filter localises in")
     ap.add_argument("--max-range", type=float, default=8.0, help="range of the synthetic lidar in metres (rays that hit nothing "
                     "report it)")
+    ap.add_argument("--start", type=float, nargs=3, default=None, metavar=("X", "Y", "THETA"),
+                    help="start pose of the driven loop on a 200x200 map (default: a loop with clearance, see build_inputs)")
     ap.add_argument("--no-astar", action="store_true", help="skip the replan (distance grid + A*) in the step")
     ap.add_argument("--goal", type=float, nargs=2, default=None, metavar=("X", "Y"),
                     help="replan goal in metres (default: a point on the driven loop, see build_inputs)")
@@ -339,7 +351,7 @@ def main():
             # Replan target: a fixed point on the driven loop, 0-0.9 m from the robot (0-450 pops per search).  The
             # reference's cost function (negative obstacle cost, duplicate re-expansion) makes most farther goals on this
             # map take 1e5-2e6 pops, which the reference itself cannot finish; see DESIGN.md "A*".
-            goal = (-0.35, 0.2)
+            goal = (-0.35, 0.2) if args.start is None else (args.start[0] + 0.4, args.start[1])
         else:
             goal = pick_goal(planner.distances_.cells(), m["origin"], poses[0][:2], 0.2, args.goal_l1)
     goal_pose = bl.make_pose(goal[0], goal[1], 0.0) if goal else None
@@ -582,7 +594,9 @@ def main():
                                       (("two small RCCL all-gathers (tile sums; records + tables)" if spf.composed else "RCCL all-gather of the whole record")
                                        + " enqueued by the library on the filter's stream" if spf.comm is not None
                                        else "torch.distributed all_gather_into_tensor" + (" x2 (composed finish)" if spf.composed else "")))},
-            "roofline": {"bound": "hbm", "kernel": "k_mcl_main", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            # ("bound" is the roof SURVEY.md section 8d prescribes for the whole path -- HBM; what actually binds k_mcl_main is VALU
+            # issue: "binding_resource" and the "valu" block say so)
+            "roofline": {"bound": "hbm", "binding_resource": "VALU issue (the kernel's working set is LDS / L2 resident)", "kernel": "k_mcl_main", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": main_ms,
                          "launches_timed": int(stage_ms["mcl_main"][1]), "event_stride": EVENT_STRIDE,

@@ -64,20 +64,26 @@ def test_shard_bounds():
     assert sharded.shard_bounds(100000, 0, 8) == (0, 12500, 12500)
     assert sharded.shard_bounds(601, 1, 2) == (301, 601, 301)
     assert sharded.shard_bounds(10, 3, 4) == (9, 10, 3)
+    # the composed finish cuts at whole finish groups
+    assert sharded.shard_bounds(1_000_000, 7, 8, sharded.COMPOSED_ALIGN) == (7 * 126976, 1_000_000, 126976)
+    assert sharded.shard_bounds(30001, 2, 3, sharded.COMPOSED_ALIGN) == (20480, 30001, 10240)
+    assert sharded.composed_possible(1_000_000, 8) and sharded.composed_possible(30001, 3)
+    assert not sharded.composed_possible(601, 2) and not sharded.composed_possible(100_000, 1)
     with pytest.raises(ValueError):
         sharded.shard_bounds(4, 5, 6)
 
 
-def test_two_rank_gloo_matches_single_rank_and_oracle(tmp_path):
+@pytest.mark.parametrize("world", [2, 3])
+def test_gloo_ranks_match_single_rank_and_oracle(tmp_path, world):
     out = str(tmp_path)
     _run(0, 1, 0, out)                                           # single-rank run in this process
-    port = 29500 + (os.getpid() % 2000)
-    mp.spawn(_run, args=(2, port, out), nprocs=2, join=True)     # two ranks over gloo
+    port = 29500 + (os.getpid() % 2000) + world
+    mp.spawn(_run, args=(world, port, out), nprocs=world, join=True)     # `world` ranks over gloo
     one = np.load(os.path.join(out, "rec_w1_r0.npy"))
-    for r in range(2):
-        two = np.load(os.path.join(out, f"rec_w2_r{r}.npy"))
+    for r in range(world):
+        two = np.load(os.path.join(out, f"rec_w{world}_r{r}.npy"))
         assert one.view(np.uint32).tobytes() == two.view(np.uint32).tobytes(), f"rank {r} record differs from the single-rank run"
-        p1, p2 = np.load(os.path.join(out, "pose_w1_r0.npy")), np.load(os.path.join(out, f"pose_w2_r{r}.npy"))
+        p1, p2 = np.load(os.path.join(out, "pose_w1_r0.npy")), np.load(os.path.join(out, f"pose_w{world}_r{r}.npy"))
         assert p1.tobytes() == p2.tobytes()      # the estimate is formed from the gathered record: independent of the shard count
 
     # and the same sequence through the oracle's ParticleFilter consuming the same noise
