@@ -156,8 +156,10 @@ def self_launch(n):
 
 
 OTHER_CONFIGS = [                                      # (preset, goal_l1 in cells, extra flags): short runs printed beside the headline
-    (0, 0, ["--start", "0", "0", "0"]),                # the headline workload from the reference's own start pose (slam.cpp:64-66): the
-                                                       # float sums of estimatePosteriorPose hover around zero there
+    (0, 0, ["--no-astar"]),                            # updateFilter + updateMap alone from the default start, and ...
+    (0, 0, ["--no-astar", "--start", "0", "0", "0"]),  # ... from the reference's own start pose (slam.cpp:64-66), where the float sums of
+                                                       # estimatePosteriorPose hover around zero: what that costs a step.
+                                                       # (no replan: from there the reference's search to a point 0.4 m ahead takes 9e4 pops)
     (3, 0, []), (4, 40, []), (4, 400, []), (5, 40, []),    # preset 3 (1M particles on one GPU) has no replan: its goal is unused
 ]
 OTHER_BUDGET_S = 240.0                                 # wall clock all of them together may take: a slow or hung child costs the others, never the headline
@@ -533,7 +535,7 @@ def main():
         # passes, gfx950 correction applied); only valid for the configuration they were collected on
         traffic = None
         traffic_src = None
-        for prof in ("r02_mcl_main_traffic.json", "r01_mcl_main_traffic.json"):
+        for prof in ("r03_mcl_main_traffic.json", "r02_mcl_main_traffic.json", "r01_mcl_main_traffic.json"):
             try:
                 tj = json.load(open(os.path.join(ROOT, "profiles", prof)))
                 if world == 1 and tj["config"] == {"particles": N, "grid": [W, H], "rays": R}:
@@ -562,7 +564,7 @@ def main():
         # committed SQ counter pass, against the 1024 SIMDs issuing one per 4 cycles at 2.4 GHz
         valu = None
         import csv
-        for prof in ("r02_mcl_main_pmc_sq.csv", "r01_mcl_main_pmc_sq.csv"):
+        for prof in ("r03_mcl_main_pmc_sq.csv", "r02_mcl_main_pmc_sq.csv", "r01_mcl_main_pmc_sq.csv"):
             try:
                 if world == 1 and traffic is not None and valu is None:
                     for row in csv.reader(open(os.path.join(ROOT, "profiles", prof))):

@@ -1,8 +1,10 @@
-"""Runs on the GPU box (through gpurun): collects the rocprofv3 evidence bench.py's roofline object refers to and writes
-the summaries under gpurun_out/profiles_new/ (copied into profiles/ and committed afterwards).
-  1. kernel trace + stats of the default bench command  -> r02_bench_default_kernel_stats.csv, r02_bench_default.json
-  2. FETCH_SIZE and WRITE_SIZE in two separate --pmc passes -> r02_pmc_hbm_traffic.csv, r02_mcl_main_traffic.json
-  3. SQ instruction / busy counters for k_mcl_main        -> r02_mcl_main_pmc_sq.csv
+"""Runs on the GPU box (through gpurun): collects the rocprofv3 evidence bench.py's roofline object and DESIGN.md refer to and
+writes the summaries under gpurun_out/profiles_new/ (copied into profiles/ and committed afterwards).  For the default command
+(BASELINE.json configs[1]) and for configs[3] / configs[4] (`--config 4`, `--config 5`):
+  1. kernel trace + stats                                     -> <round>_<tag>_kernel_stats.csv, <round>_<tag>_under_rocprof.json
+  2. FETCH_SIZE and WRITE_SIZE in two separate --pmc passes   -> <round>_<tag>_pmc_hbm_traffic.csv (every kernel), and for the
+     default command <round>_mcl_main_traffic.json
+  3. (default command) SQ instruction / busy counters of k_mcl_main -> <round>_mcl_main_pmc_sq.csv
 Every rocprofv3 invocation puts the program itself after `--` and never mixes --pmc with other trace domains."""
 import csv
 import glob
@@ -12,19 +14,21 @@ import sqlite3
 import subprocess
 import sys
 
+ROUND = "r03"
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 OUT = os.path.join(ROOT, "gpurun_out", "profiles_new")
 os.makedirs(OUT, exist_ok=True)
 ENV = dict(os.environ, TMPDIR="/tmp")
 
 
-def run(args, tag):
+def run(args, tag, bench):
     d = os.path.join(ROOT, "gpurun_out", "prof_" + tag)
     subprocess.run(["rm", "-rf", d])
-    cmd = ["rocprofv3"] + args + ["-d", d, "-o", "p", "--", "python3", os.path.join(ROOT, "bench.py")] + BENCH
+    cmd = ["rocprofv3"] + args + ["-d", d, "-o", "p", "--", "python3", os.path.join(ROOT, "bench.py")] + bench
     log = open(os.path.join(OUT, tag + ".log"), "w")
-    subprocess.run(cmd, cwd="/tmp", env=ENV, stdout=log, stderr=subprocess.STDOUT, check=False)
+    subprocess.run(cmd, cwd="/tmp", env=ENV, stdout=log, stderr=subprocess.STDOUT, check=False, timeout=400)
     dbs = glob.glob(os.path.join(d, "**", "*.db"), recursive=True)
+    print("[collect]", tag, "done", flush=True)
     return dbs[0] if dbs else None, os.path.join(OUT, tag + ".log")
 
 
@@ -35,74 +39,96 @@ def bench_line(logpath):
     return None
 
 
-# ---- 1. kernel stats of the default command
-BENCH = ["--cpu-steps", "0", "--no-other-configs"]
-db, log = run(["--kernel-trace", "--stats"], "stats")
-j = bench_line(log)
-if j:
-    json.dump(j, open(os.path.join(OUT, "r02_bench_default_under_rocprof.json"), "w"))
-con = sqlite3.connect(db)
-rows = list(con.execute("select name, count(*), sum(end-start), avg(end-start), min(end-start), max(end-start) from kernels group by name order by 3 desc"))
-tot = sum(r[2] for r in rows)
-with open(os.path.join(OUT, "r02_bench_default_kernel_stats.csv"), "w") as f:
-    f.write("# rocprofv3 --kernel-trace --stats -- python3 bench.py --cpu-steps 0   (summary of the kernel table of the rocpd database)\n")
-    w = csv.writer(f)
-    w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs"])
-    for r in rows:
-        w.writerow([r[0], r[1], r[2], "%.1f" % r[3], "%.2f" % (100.0 * r[2] / tot), r[4], r[5]])
+def short(name):
+    return name.split("(")[0][:70]
 
-# ---- 2. HBM traffic: separate passes
-BENCH = ["--cpu-steps", "0", "--no-other-configs", "--steps", "40", "--warmup", "5"]
-traffic = {}
-lines = []
-for counter in ("FETCH_SIZE", "WRITE_SIZE"):
-    db, log = run(["--pmc", counter, "--kernel-trace"], counter.lower())
-    if not db:
-        continue
-    con = sqlite3.connect(db)
-    tabs = [r[0] for r in con.execute("select name from sqlite_master where type in ('table','view')")]
-    view = "counters_collection" if "counters_collection" in tabs else None
-    if not view:
-        print("no counters view; tables:", tabs)
-        continue
-    cols = [d[1] for d in con.execute(f"pragma table_info({view})")]
-    kcol = "kernel_name" if "kernel_name" in cols else "name"
-    q = f"select {kcol}, count(*), avg(value), min(value), max(value) from {view} where counter_name='{counter}' group by {kcol} order by 3 desc"
-    for name, n, mean, mn, mx in con.execute(q):
-        lines.append([name.split("(")[0][:60], counter, n, "%.3f" % mean, "%.3f" % mn, "%.3f" % mx])
-        if "k_mcl_main<0" in name or "k_mcl_mainILi0" in name:
-            traffic[counter] = (name, mean)
-with open(os.path.join(OUT, "r02_pmc_hbm_traffic.csv"), "w") as f:
-    f.write("# rocprofv3 --pmc FETCH_SIZE (pass 1) / --pmc WRITE_SIZE (pass 2) --kernel-trace -- python3 bench.py --cpu-steps 0 --steps 40 --warmup 5 ; values in KB per dispatch\n")
-    w = csv.writer(f)
-    w.writerow(["kernel", "counter", "dispatches", "mean_KB", "min_KB", "max_KB"])
-    w.writerows(lines)
-if len(traffic) == 2:
-    fk, wk = traffic["FETCH_SIZE"][1], traffic["WRITE_SIZE"][1]
-    json.dump({"kernel": traffic["FETCH_SIZE"][0].split("(")[0], "config": {"particles": 100000, "grid": [200, 200], "rays": 290},
-               "FETCH_SIZE_KB": fk, "WRITE_SIZE_KB": wk,
-               "traffic_bytes_per_launch": (2.0 * fk + wk) * 1024.0,
-               "traffic_bytes_per_launch_uncorrected": (fk + wk) * 1024.0,
-               "note": "MI355X_MICROARCH.md HBM section: on gfx950 FETCH_SIZE counts 64 B per 128 B request for wide coalesced reads, so it is doubled; "
-                       "WRITE_SIZE is exact. Source: profiles/r02_pmc_hbm_traffic.csv (separate --pmc passes)."},
-              open(os.path.join(OUT, "r02_mcl_main_traffic.json"), "w"), indent=1)
 
-# ---- 3. SQ counters of the dominant kernel
-sq = ["SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_INSTS_VMEM_RD", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_WAIT_INST_LDS"]
-db, log = run(["--pmc"] + sq + ["--kernel-trace"], "sq")
-if db:
-    con = sqlite3.connect(db)
-    tabs = [r[0] for r in con.execute("select name from sqlite_master where type in ('table','view')")]
-    if "counters_collection" in tabs:
+def collect(tag, bench, config=None, sq=False):
+    cmdline = "python3 bench.py " + " ".join(bench)
+    # ---- 1. kernel stats
+    db, log = run(["--kernel-trace", "--stats"], tag + "_stats", bench)
+    j = bench_line(log)
+    if j:
+        json.dump(j, open(os.path.join(OUT, f"{ROUND}_{tag}_under_rocprof.json"), "w"))
+    avg_ns = {}
+    if db:
+        con = sqlite3.connect(db)
+        rows = list(con.execute("select name, count(*), sum(end-start), avg(end-start), min(end-start), max(end-start) from kernels group by name order by 3 desc"))
+        tot = sum(r[2] for r in rows)
+        with open(os.path.join(OUT, f"{ROUND}_{tag}_kernel_stats.csv"), "w") as f:
+            f.write(f"# rocprofv3 --kernel-trace --stats -- {cmdline}   (summary of the kernel table of the rocpd database)\n")
+            w = csv.writer(f)
+            w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs"])
+            for r in rows:
+                w.writerow([r[0], r[1], r[2], "%.1f" % r[3], "%.2f" % (100.0 * r[2] / tot), r[4], r[5]])
+                avg_ns[short(r[0])] = r[3]
+    # ---- 2. HBM traffic of every kernel: separate passes
+    pmc_bench = [a for a in bench]
+    for k, v in (("--steps", "40"), ("--warmup", "8")):
+        if k in pmc_bench:
+            pmc_bench[pmc_bench.index(k) + 1] = v
+        else:
+            pmc_bench += [k, v]
+    per = {}
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        db, log = run(["--pmc", counter, "--kernel-trace"], tag + "_" + counter.lower(), pmc_bench)
+        if not db:
+            continue
+        con = sqlite3.connect(db)
+        tabs = [r[0] for r in con.execute("select name from sqlite_master where type in ('table','view')")]
+        if "counters_collection" not in tabs:
+            print("no counters view; tables:", tabs)
+            continue
         cols = [d[1] for d in con.execute("pragma table_info(counters_collection)")]
         kcol = "kernel_name" if "kernel_name" in cols else "name"
-        with open(os.path.join(OUT, "r02_mcl_main_pmc_sq.csv"), "w") as f:
-            f.write("# rocprofv3 --pmc " + " ".join(sq) + " --kernel-trace -- python3 bench.py --cpu-steps 0 --steps 40 --warmup 5 ; mean per dispatch of k_mcl_main\n")
-            w = csv.writer(f)
-            w.writerow(["kernel", "counter", "dispatches", "mean"])
-            for name, cn, n, mean in con.execute(f"select {kcol}, counter_name, count(*), avg(value) from counters_collection where {kcol} like '%k_mcl_main%' group by {kcol}, counter_name"):
-                w.writerow([name.split("(")[0][:40], cn, n, "%.1f" % mean])
-print(open(os.path.join(OUT, "r02_bench_default_kernel_stats.csv")).read()[:1500])
-for fn in ("r02_pmc_hbm_traffic.csv", "r02_mcl_main_traffic.json", "r02_mcl_main_pmc_sq.csv"):
-    p = os.path.join(OUT, fn)
-    print("====", fn); print(open(p).read()[:1500] if os.path.exists(p) else "MISSING")
+        q = f"select {kcol}, count(*), avg(value), min(value), max(value) from counters_collection where counter_name='{counter}' group by {kcol} order by 3 desc"
+        for name, n, mean, mn, mx in con.execute(q):
+            per.setdefault(short(name), {})[counter] = (n, mean, mn, mx)
+    with open(os.path.join(OUT, f"{ROUND}_{tag}_pmc_hbm_traffic.csv"), "w") as f:
+        f.write(f"# rocprofv3 --pmc FETCH_SIZE (pass 1) / --pmc WRITE_SIZE (pass 2) --kernel-trace -- {'python3 bench.py ' + ' '.join(pmc_bench)} ; KB per dispatch.\n"
+                "# hbm_bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024: on gfx950 FETCH_SIZE counts 64 B per 128 B request of a wide coalesced read (MI355X_MICROARCH.md, HBM section)\n")
+        w = csv.writer(f)
+        w.writerow(["kernel", "dispatches", "FETCH_SIZE_mean_KB", "WRITE_SIZE_mean_KB", "hbm_bytes_per_dispatch", "avg_duration_ns_from_kernel_stats", "hbm_GBps"])
+        for name, c in sorted(per.items(), key=lambda kv: -(2 * kv[1].get("FETCH_SIZE", (0, 0))[1] + kv[1].get("WRITE_SIZE", (0, 0))[1])):
+            fk, wk = c.get("FETCH_SIZE", (0, 0.0))[1], c.get("WRITE_SIZE", (0, 0.0))[1]
+            hb = (2.0 * fk + wk) * 1024.0
+            ns = avg_ns.get(name)
+            w.writerow([name, c.get("FETCH_SIZE", c.get("WRITE_SIZE"))[0], "%.3f" % fk, "%.3f" % wk, "%.0f" % hb, "%.1f" % ns if ns else "", "%.1f" % (hb / ns) if ns else ""])
+    if config is not None:
+        for name, c in per.items():
+            if ("k_mcl_main<0" in name or "k_mcl_mainILi0" in name) and len(c) == 2:
+                fk, wk = c["FETCH_SIZE"][1], c["WRITE_SIZE"][1]
+                json.dump({"kernel": name, "config": config, "FETCH_SIZE_KB": fk, "WRITE_SIZE_KB": wk,
+                           "traffic_bytes_per_launch": (2.0 * fk + wk) * 1024.0, "traffic_bytes_per_launch_uncorrected": (fk + wk) * 1024.0,
+                           "note": "MI355X_MICROARCH.md HBM section: on gfx950 FETCH_SIZE counts 64 B per 128 B request for wide coalesced reads, so it is doubled; "
+                                   f"WRITE_SIZE is exact. Source: profiles/{ROUND}_{tag}_pmc_hbm_traffic.csv (separate --pmc passes)."},
+                          open(os.path.join(OUT, f"{ROUND}_mcl_main_traffic.json"), "w"), indent=1)
+    # ---- 3. SQ counters of the dominant kernel
+    if sq:
+        names = ["SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_INSTS_VMEM_RD", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_WAIT_INST_LDS"]
+        db, log = run(["--pmc"] + names + ["--kernel-trace"], tag + "_sq", pmc_bench)
+        if db:
+            con = sqlite3.connect(db)
+            tabs = [r[0] for r in con.execute("select name from sqlite_master where type in ('table','view')")]
+            if "counters_collection" in tabs:
+                cols = [d[1] for d in con.execute("pragma table_info(counters_collection)")]
+                kcol = "kernel_name" if "kernel_name" in cols else "name"
+                with open(os.path.join(OUT, f"{ROUND}_mcl_main_pmc_sq.csv"), "w") as f:
+                    f.write("# rocprofv3 --pmc " + " ".join(names) + f" --kernel-trace -- python3 bench.py {' '.join(pmc_bench)} ; mean per dispatch of k_mcl_main\n")
+                    w = csv.writer(f)
+                    w.writerow(["kernel", "counter", "dispatches", "mean"])
+                    for name, cn, n, mean in con.execute(f"select {kcol}, counter_name, count(*), avg(value) from counters_collection where {kcol} like '%k_mcl_main%' group by {kcol}, counter_name"):
+                        w.writerow([name.split("(")[0][:40], cn, n, "%.1f" % mean])
+
+
+which = sys.argv[1:] or ["default", "config4", "config5"]
+if "default" in which:
+    collect("bench_default", ["--cpu-steps", "0", "--no-other-configs"], config={"particles": 100000, "grid": [200, 200], "rays": 290}, sq=True)
+if "config4" in which:
+    collect("config4", ["--config", "4", "--goal-l1", "400", "--cpu-steps", "0", "--sub", "--steps", "600", "--warmup", "150"])
+if "config5" in which:
+    collect("config5", ["--config", "5", "--goal-l1", "40", "--cpu-steps", "0", "--sub", "--steps", "600", "--warmup", "150"])
+for fn in sorted(os.listdir(OUT)):
+    if fn.endswith(".csv") and ROUND in fn:
+        print("====", fn)
+        print(open(os.path.join(OUT, fn)).read()[:2500])
