@@ -21,10 +21,10 @@ os.makedirs(OUT, exist_ok=True)
 ENV = dict(os.environ, TMPDIR="/tmp")
 
 
-def run(args, tag, bench):
+def run(args, tag, bench, script="bench.py"):
     d = os.path.join(ROOT, "gpurun_out", "prof_" + tag)
     subprocess.run(["rm", "-rf", d])
-    cmd = ["rocprofv3"] + args + ["-d", d, "-o", "p", "--", "python3", os.path.join(ROOT, "bench.py")] + bench
+    cmd = ["rocprofv3"] + args + ["-d", d, "-o", "p", "--", "python3", os.path.join(ROOT, script)] + bench
     log = open(os.path.join(OUT, tag + ".log"), "w")
     subprocess.run(cmd, cwd="/tmp", env=ENV, stdout=log, stderr=subprocess.STDOUT, check=False, timeout=400)
     dbs = glob.glob(os.path.join(d, "**", "*.db"), recursive=True)
@@ -121,7 +121,45 @@ def collect(tag, bench, config=None, sq=False):
                         w.writerow([name.split("(")[0][:40], cn, n, "%.1f" % mean])
 
 
-which = sys.argv[1:] or ["default", "config4", "config5"]
+def collect_streaming():
+    """The HBM-bound kernels one grid / one particle set per launch (tests/tools/stream_kernels_probe.py): duration from the kernel
+    trace, HBM bytes from the two counter passes, beside the bytes the kernel has to move."""
+    script = os.path.join("tests", "tools", "stream_kernels_probe.py")
+    S, N = 4096 * 4096, 1_000_000
+    alg = {"k_planner_snapshot": 2 * S, "k_dist_rows_wide": 3 * S, "k_dist_cols_summary": 2 * S, "k_dist_cols_apply": 4 * S,
+           "k_dist_floats": 6 * S, "k_pf_export": 88 * N, "k_pf_encode_lcm": 80 * N, "k_scan_tile_sums": 16 * N, "k_scan_finish_prefix": 24 * N}
+    db, _ = run(["--kernel-trace", "--stats"], "stream_stats", [], script)
+    dur = {}
+    if db:
+        for name, n, avg, mn in sqlite3.connect(db).execute("select name, count(*), avg(end-start), min(end-start) from kernels group by name"):
+            dur[short(name)] = (n, avg, mn)
+    per = {}
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        db, _ = run(["--pmc", counter, "--kernel-trace"], "stream_" + counter.lower(), [], script)
+        if not db:
+            continue
+        con = sqlite3.connect(db)
+        cols = [d[1] for d in con.execute("pragma table_info(counters_collection)")]
+        kcol = "kernel_name" if "kernel_name" in cols else "name"
+        for name, n, mean in con.execute(f"select {kcol}, count(*), avg(value) from counters_collection where counter_name='{counter}' group by {kcol}"):
+            per.setdefault(short(name), {})[counter] = mean
+    with open(os.path.join(OUT, f"{ROUND}_streaming_kernels.csv"), "w") as f:
+        f.write("# rocprofv3 --kernel-trace --stats / --pmc FETCH_SIZE / --pmc WRITE_SIZE (three runs) -- python3 tests/tools/stream_kernels_probe.py\n"
+                "# 4096 x 4096 grid, 1 000 000 particles, one grid per launch.  hbm_bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 (gfx950 correction, MI355X_MICROARCH.md)\n")
+        w = csv.writer(f)
+        w.writerow(["kernel", "launches", "avg_ns", "min_ns", "algorithmic_bytes", "algorithmic_GBps_at_avg", "frac_of_8TBps", "hbm_bytes_counters", "counters_over_algorithmic"])
+        for k, a in alg.items():
+            if k not in dur:
+                continue
+            n, avg, mn = dur[k]
+            c = per.get(k, {})
+            hb = (2.0 * c.get("FETCH_SIZE", 0.0) + c.get("WRITE_SIZE", 0.0)) * 1024.0 if len(c) == 2 else None
+            w.writerow([k, n, "%.0f" % avg, mn, a, "%.1f" % (a / avg), "%.3f" % (a / avg / 8000.0), "%.0f" % hb if hb else "", "%.3f" % (hb / a) if hb else ""])
+
+
+which = sys.argv[1:] or ["default", "config4", "config5", "stream"]
+if "stream" in which:
+    collect_streaming()
 if "default" in which:
     collect("bench_default", ["--cpu-steps", "0", "--no-other-configs"], config={"particles": 100000, "grid": [200, 200], "rays": 290}, sq=True)
 if "config4" in which:

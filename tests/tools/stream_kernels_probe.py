@@ -29,8 +29,10 @@ big = bl.OccupancyGrid.from_cells(world, (-100.0, -100.0), 0.05, ctx=ctx)
 d = bl.ObstacleDistanceGrid(ctx=ctx)
 ap = bl.AsyncPlanner(ctx=ctx, lanes=1)
 for _ in range(5):
+    d.forget()                              # the full transform every time (an unchanged map would be recognised)
     d.setDistances(big)
     ap.submit(big, pf.poseDevicePtr(), bl.make_pose(0.3, 0.3, 0.0))
     ap.fetch()
+d.cells()                                   # k_dist_floats, once, after the timed transforms
 ctx.sync()
 print("done")
