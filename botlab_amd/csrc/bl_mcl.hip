@@ -50,6 +50,8 @@ struct bl_pf {
     int fin_subs_cap;
     mclf_tab_elem* fin_tabs;  // [2][MCLF_TSLOTS][MCLF_SUB]: tables of the risky sub-tiles
     unsigned long long* fin_sync;     // the finish launches' sync word (zero between launches)
+    unsigned int fin_gen;             // generation of the last finish launch's records (mcl_finish_args.tag; the record slots start out as zeros)
+    int fin_last_nrec;                // sub-tiles per axis of that launch: another count lays the records out differently (slots are zeroed)
     unsigned long long* prefix;
     float4* parent;
     pf_state* state;
@@ -1312,6 +1314,16 @@ static int pf_finish_fill(bl_pf* pf, mcl_finish_args* f)
     const int groups = mclf_groups(*f);
     f->groups = groups;
     f->groups_wait = groups;
+    // the records' generation tag (bl_mcl_finish.h): every launch stores every slot of its layout, so a slot shows the previous
+    // launch's tag until its group is through.  Zeroed slots read as tag 0: generations that are multiples of 256 are skipped,
+    // and a launch whose layout differs from the last one's (first launch, another launch shape) starts from zeroed slots.
+    if (((++pf->fin_gen) & 0xffu) == 0u) ++pf->fin_gen;
+    f->tag = pf->fin_gen;
+    const int nrec = groups * (f->gthreads >> 6);
+    if (pf->sh_world <= 1 && nrec != pf->fin_last_nrec && (int64_t)nrec <= pf->fin_subs_cap) {
+        if (hipMemsetAsync(pf->fin_recs, 0, (size_t)2 * pf->fin_subs_cap * sizeof(ss_rec), pf->ctx->stream) != hipSuccess) return -1;
+        pf->fin_last_nrec = nrec;
+    }
     f->sh = nullptr;
     f->wild = pf->sh_world > 1 ? nullptr : pf->fin_wild;      // (a composed finish keeps to records, tables and replays)
     f->recs = pf->fin_recs;
@@ -2038,6 +2050,9 @@ extern "C" int bl_pf_debug_estimate_stats(bl_pf* pf, uint32_t* out4)   /* eight 
         unsigned int la[2];
         BL_HIP(hipMemcpy(la, pf->state->lookahead, sizeof(la), hipMemcpyDeviceToHost));
         fprintf(stderr, "map updates ahead of the exact pose: %u, run again: %u\n", la[0], la[1]);
+        unsigned int ps[2];
+        BL_HIP(hipMemcpy(ps, pf->state->pre_stats, sizeof(ps), hipMemcpyDeviceToHost));
+        fprintf(stderr, "pre-chain sub-tiles by map / replayed: x %u / %u, y %u / %u\n", ps[0] >> 16, ps[0] & 0xffffu, ps[1] >> 16, ps[1] & 0xffffu);
     }
     if (getenv("BOTLAB_FINISH_STAMPS")) {
         unsigned long long st[6];
@@ -2052,7 +2067,16 @@ extern "C" int bl_pf_debug_estimate_stats(bl_pf* pf, uint32_t* out4)   /* eight 
         fprintf(stderr, "x chain entries (us):");
         for (int k = 1; k < 16; ++k) fprintf(stderr, " %.2f", cs[k] > cs[k - 1] ? (cs[k] - cs[k - 1]) * 0.01 : -1.0);
         fprintf(stderr, "\n");
-        fprintf(stderr, "finisher timeline (us): groups done +%.2f, staged a +%.2f, staged b +%.2f, chains +%.2f, exit +%.2f\n", (st[1] - st[0]) * 0.01,
+        unsigned long long xs[12];
+        BL_HIP(hipMemcpy(xs, pf->state->xstamps, sizeof(xs), hipMemcpyDeviceToHost));
+        fprintf(stderr, "stamped group: loads back %+.2f after its entry; finisher stage a: wave 0 has its first records %+.2f, is through %+.2f after the block sums\n",
+                ((long long)xs[0] - (long long)gs[0]) * 0.01, ((long long)xs[1] - (long long)st[1]) * 0.01, ((long long)xs[2] - (long long)st[1]) * 0.01);
+        fprintf(stderr, "pre-chain wave 0: block sums done %+.2f, past their barrier %+.2f, terms done %+.2f\n", ((long long)xs[8] - (long long)st[0]) * 0.01,
+                ((long long)xs[9] - (long long)st[0]) * 0.01, ((long long)xs[10] - (long long)st[0]) * 0.01);
+        fprintf(stderr, "pre-chain: sums barrier %+.2f, stepped %+.2f, maps barrier %+.2f after the finisher's entry\n", ((long long)xs[5] - (long long)st[0]) * 0.01,
+                ((long long)xs[6] - (long long)st[0]) * 0.01, ((long long)xs[7] - (long long)st[0]) * 0.01);
+        fprintf(stderr, "pre-chain published %+.2f, x chain had its start value %+.2f after the finisher's entry\n", ((long long)xs[3] - (long long)st[0]) * 0.01, ((long long)xs[4] - (long long)st[0]) * 0.01);
+        fprintf(stderr, "finisher timeline (us): block sums +%.2f, records in and staged +%.2f, lists and gaps +%.2f, chains +%.2f, exit +%.2f\n", (st[1] - st[0]) * 0.01,
                 (st[2] - st[1]) * 0.01, (st[3] - st[2]) * 0.01, (st[4] - st[3]) * 0.01, (st[5] - st[4]) * 0.01);
     }
     return BL_OK;

@@ -19,8 +19,10 @@
 //
 // Visibility inside the launch: the MI355X's eight XCDs have separate L2s, and an agent-scope release fence (__threadfence)
 // writes a whole L2 back -- 12 us measured with the prefix stores in it.  So everything a group hands to the finisher goes by
-// agent-scope relaxed atomic stores / loads (write-through, read-through: sc1), ordered by "wait for my stores, barrier, one
-// atomic add"; nothing else of the groups' output is read inside the launch.
+// agent-scope relaxed atomic stores / loads (write-through, read-through: sc1).  A record carries the launch's generation tag in
+// both of its 8-byte halves: the finisher polls the record slots themselves and takes a record when both halves show this
+// launch's tag -- no counter, no barrier, no wait in the groups; a wave that leaves a table or a wild map for a record waits for
+// those stores before it stores the record.  Nothing else of the groups' output is read inside the launch.
 #ifndef BL_MCL_FINISH_H
 #define BL_MCL_FINISH_H
 
@@ -33,9 +35,11 @@ struct pf_state {
     double sums_used[5];      // units, -, -, units*sin, units*cos the estimate was formed from (diagnostic)
     unsigned int chain_stats[8];   // x then y: generic replays, their phases, table replays, gaps walked the slow way (diagnostic)
     unsigned int lookahead[2];     // map updates that ran ahead of the exact pose; of those, the ones that had to run again (diagnostic)
+    unsigned int pre_stats[2];     // x, y: sub-tiles the pre-chain took by a map << 16 | sub-tiles it replayed, summed over the launches (diagnostic)
     unsigned long long cstamps[16]; // the x chain, entry by entry (diagnostic, -DMCLF_STAMPS)
     unsigned long long gstamps[8]; // one group's timeline (diagnostic, -DMCLF_STAMPS)
     unsigned long long stamps[6];  // finisher timeline in 10 ns ticks (diagnostic, -DMCLF_STAMPS)
+    unsigned long long xstamps[12]; // [0] the stamped group's loads are back; [1] the finisher's stage-a loads are back, [2] its wave 0 is through stage a; [3] the pre-chain has published, [4] the x chain has its start value
 };
 
 struct mclf_tab_elem { double t; int se, se1; };       // term; (inclusive prefix << 1 | bad) in the predicted binade and in the next
@@ -69,13 +73,15 @@ struct mcl_finish_args {
     ss_rec* recs;                          // [2][groups * subs]: x records, then y records
     mclf_tab_elem* tabs;                   // [2][MCLF_TSLOTS][MCLF_SUB]
     unsigned long long* sync;              // MCLF_SYNC_WORDS words, zero between launches:
-                                           // [0] bits 32..: groups done; bits 0..15 / 16..31: x / y tables handed out
+                                           // [0] bits 0..15 / 16..31: x / y tables handed out
                                            // [1] the sums behind the first MCLF_PRE_SUBS sub-tiles (x, y float bits), [2] "they are there"
                                            // [3] the finisher's exact x, y (float bits) for the map workgroup of the same launch, [4] "they are there"
                                            //     (mclf_pose with publish writes them, mclf_wait_pose reads and clears them)
     int groups, gthreads;                  // group workgroups (of the whole particle set); threads of each that work (256 or 1024)
     ss_wild* wild;                         // [2][sub-tiles]: the map of a sub-tile whose sum is predicted to cross binades (bl_serial_sum.h), or null
     int groups_wait;                       // groups of THIS launch the finisher waits for (composed finish: 0, they ran in an earlier launch)
+    unsigned int tag;                      // generation of this launch's records: a record slot holds the previous launch's record (another
+                                           // tag) until its group has stored this launch's (mclf_store_rec, mclf_decode_rec)
     const mclf_shards* sh;                 // device memory; null: one rank (a table in the argument block itself would be indexed
                                            // per lane, which moves a by-value argument into scratch for every thread of the kernel)
 };
@@ -97,6 +103,7 @@ struct mcl_finish_args {
 #define MCLF_PRE_SUBS 9                       // sub-tiles at the start of the sums that a workgroup of its own does while the groups run
 #define MCLF_EXTRA_WGS 2                      // workgroups of the launch in front of the groups: finisher, pre-chain
 #define MCLF_PRE_STEPPED 2                    // ... the first of them term by term (a binade change every few terms), the others in-binade
+#define MCLF_TAB_WAVES 4                      // waves of the finisher that fetch tables while the others join gaps (four tables per wave and trip)
 #define MCLF_SYNC_WORDS 8                     // words of the sync block (one 64-byte line; five in use)
 #define MCLF_LDS_BYTES (112 * 1024)           // scratch the finisher wants (the map kernel's counter window serves)
 
@@ -121,11 +128,13 @@ struct mclf_smem {
     double bx[MCLF_MAXW], by[MCLF_MAXW];          // sums of the blocks before the group, per wave
     double wx[MCLF_MAXW], wy[MCLF_MAXW];          // sums of the sub-tiles' terms
     double red[MCLF_POSE_THREADS / 64][5];
-    unsigned long long word;                      // the sync word the finisher saw
     float xy[2], first[2];                        // the sums; the sums behind the finisher's own sub-tiles
     unsigned int stats[8];
-    int tbase[2][BL_MAX_SHARDS + 1];              // per axis: first staged slot of every rank's tables (composed finish; one rank: {0, count})
+    int tbase[2][BL_MAX_SHARDS + 1];              // per axis: first staged slot of every rank's tables (composed finish; one rank: {0, MCLF_TSLOTS})
+    int ntab_seen[2];                             // per axis: 1 + the highest table slot a record of this launch names (one rank)
     double pre[2][MCLF_PRE_STEPPED * MCLF_SUB];   // the terms the finisher steps one by one, per axis
+    double psum[2][MCLF_PRE_SUBS];                // pre-chain: per axis the double sums of the first sub-tiles' terms (predictions)
+    ss_wild pmap[2][MCLF_PRE_SUBS];               // pre-chain: per axis the wild maps of the sub-tiles behind the stepped ones
 };
 
 #ifdef MCLF_STAMPS
@@ -161,17 +170,35 @@ __device__ __forceinline__ void mclf_drain_stores()
 {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
-__device__ __forceinline__ void mclf_store_rec(ss_rec* p, const ss_rec& r)
+// A record in memory: two 8-byte words, each stored by one relaxed atomic store (the unit the memory model keeps whole), each
+// with the launch's tag in it -- word 0: key (24 bits; the empty run's key SS_ID as MCLF_KEY_ID) | tag bits 0..7 << 24 | D << 32;
+// word 1: lo << 1 | tag bit 0, hi << 1 | tag bit 1 (|lo|, |hi| <= 2^29).  Every launch stores every record slot once, so a
+// slot holds the previous launch's record or this one's, and the tags of consecutive launches differ in both words.
+#define MCLF_KEY_ID 0x8000
+__device__ __forceinline__ void mclf_store_rec(ss_rec* p, const ss_rec& r, unsigned int tag)
 {
     unsigned long long* q = (unsigned long long*)p;
-    mclf_store_u64(q, (unsigned long long)(unsigned int)r.key | ((unsigned long long)(unsigned int)r.D << 32));
-    mclf_store_u64(q + 1, (unsigned long long)(unsigned int)r.lo | ((unsigned long long)(unsigned int)r.hi << 32));
+    const unsigned int k = (r.key == SS_ID ? (unsigned int)MCLF_KEY_ID : (unsigned int)r.key) | ((tag & 0xffu) << 24);
+    const unsigned int lo = ((unsigned int)r.lo << 1) | (tag & 1u), hi = ((unsigned int)r.hi << 1) | ((tag >> 1) & 1u);
+    mclf_store_u64(q, (unsigned long long)k | ((unsigned long long)(unsigned int)r.D << 32));
+    mclf_store_u64(q + 1, (unsigned long long)lo | ((unsigned long long)hi << 32));
 }
+// the four dwords of a record slot; *current: both words carry `tag`
+__device__ __forceinline__ ss_rec mclf_decode_rec(const int4& q, unsigned int tag, bool* current)
+{
+    const unsigned int k = (unsigned int)q.x;
+    *current = (k >> 24) == (tag & 0xffu) && ((unsigned int)q.z & 1u) == (tag & 1u) && ((unsigned int)q.w & 1u) == ((tag >> 1) & 1u);
+    const int key = (k & 0xffffffu) == (unsigned int)MCLF_KEY_ID ? SS_ID : (int)(k & 0xffffffu);
+    return ss_rec_make(key, q.y, q.z >> 1, q.w >> 1);
+}
+// a record that is known to be there (the finisher has seen every slot with this launch's tag; a composed finish's arrived
+// through the all-gather)
 __device__ __forceinline__ ss_rec mclf_load_rec(const ss_rec* p)
 {
     const unsigned long long* q = (const unsigned long long*)p;
     const unsigned long long a = mclf_load_u64(q), b = mclf_load_u64(q + 1);
-    return ss_rec_make((int)(unsigned int)a, (int)(unsigned int)(a >> 32), (int)(unsigned int)b, (int)(unsigned int)(b >> 32));
+    bool current;
+    return mclf_decode_rec(make_int4((int)(unsigned int)a, (int)(unsigned int)(a >> 32), (int)(unsigned int)b, (int)(unsigned int)(b >> 32)), 0u, &current);
 }
 __device__ __forceinline__ void mclf_store_tab(mclf_tab_elem* p, double t, int se, int se1)
 {
@@ -234,10 +261,18 @@ __device__ __forceinline__ ss_wild mclf_readlane_wild(const ss_wild& w, int lane
 }
 
 // ---- where things lie (one rank: the filter's own arrays; composed finish: the exchange blocks, mclf_shards)
+// (read through a pointer that SAYS global memory: what comes out of the shard table is a generic pointer to the compiler, and a
+// generic load is a flat load with a full wait behind it -- eighteen of those in a row held the pre-chain's first barrier up by 2 us)
+typedef float mclf_f4 __attribute__((ext_vector_type(4)));
+typedef const mclf_f4 __attribute__((address_space(1)))* mclf_gptr4;
+__device__ __forceinline__ const float4* mclf_particle_ptr(const mcl_finish_args& f, int i)
+{
+    return f.sh ? f.sh->rec[i / f.sh->block] + i : f.rec + i;
+}
 __device__ __forceinline__ float4 mclf_particle(const mcl_finish_args& f, int i)
 {
-    if (f.sh) return f.sh->rec[i / f.sh->block][i];
-    return f.rec[i];
+    const mclf_f4 v = *(mclf_gptr4)mclf_particle_ptr(f, i);
+    return make_float4(v.x, v.y, v.z, v.w);
 }
 __device__ __forceinline__ ss_rec* mclf_rec_ptr(const mcl_finish_args& f, int axis, int s)
 {
@@ -290,6 +325,9 @@ __device__ __forceinline__ void mclf_group_range(const mcl_finish_args& f, int g
 // particles [lo, hi) of sub-tile s (global index: group * waves-per-group + wave)
 __device__ __forceinline__ void mclf_sub_range(const mcl_finish_args& f, int s, int* lo, int* hi)
 {
+    // (a group's chunk is its sub-tiles side by side, and the groups of the main region stand side by side: no division for a
+    // sub-tile that lies wholly inside that region -- the pre-chain asks for its nine one after the other, in one wave)
+    if ((s + 1) * MCLF_SUB <= f.main_particles) { *lo = s * MCLF_SUB; *hi = *lo + MCLF_SUB; return; }
     const int subs = f.gthreads >> 6;
     int first_block, glo, ghi;
     mclf_group_range(f, s / subs, &first_block, &glo, &ghi);
@@ -386,9 +424,8 @@ __device__ __forceinline__ void mclf_prefix_in(int key, const double (&t)[MCLF_I
 }
 
 // The wild map of a sub-tile (bl_serial_sum.h): one scan of step maps over the wave, for the binade sequence a double-precision
-// prefix sum of the terms predicts; stored in f.wild when it is valid for the predicted input binade `key`.
-__device__ __forceinline__ bool mclf_build_wild(const mcl_finish_args& f, int axis, const double (&t)[MCLF_ITEMS], int cnt, double predicted_start,
-                                             int key, int lane, int sub_index)
+// prefix sum of the terms predicts (wave-uniform; key_in 0: none that is valid for the predicted input binade `key`) ...
+__device__ __forceinline__ ss_wild mclf_wild_map(const double (&t)[MCLF_ITEMS], int cnt, double predicted_start, int key, int lane)
 {
     static_assert(MCLF_ITEMS == 2, "two terms per lane");
     const double ls = (cnt > 0 ? t[0] : 0.0) + (cnt > 1 ? t[1] : 0.0);
@@ -406,7 +443,15 @@ __device__ __forceinline__ bool mclf_build_wild(const mcl_finish_args& f, int ax
         if (lane >= off) w = ssw_join(o, w);
     }
     const ss_wild all = mclf_readlane_wild(w, 63);
-    if (all.key_in == 0 || all.key_in != key) return false;
+    if (all.key_in == 0 || all.key_in != key) return ssw_invalid();
+    return all;
+}
+// ... stored in f.wild when it is valid for the predicted input binade `key`
+__device__ __forceinline__ bool mclf_build_wild(const mcl_finish_args& f, int axis, const double (&t)[MCLF_ITEMS], int cnt, double predicted_start,
+                                             int key, int lane, int sub_index)
+{
+    const ss_wild all = mclf_wild_map(t, cnt, predicted_start, key, lane);
+    if (all.key_in == 0) return false;
     const int nsub = f.groups * (f.gthreads >> 6);
     if (lane == 0) mclf_store_wild(f.wild + (size_t)axis * nsub + sub_index, all);
     return true;
@@ -491,14 +536,9 @@ __device__ __forceinline__ void mclf_prefix_group(const mcl_finish_args& f, int 
 #endif
     int first_block, lo, hi;
     mclf_group_range(f, g, &first_block, &lo, &hi);
-    // sums over the blocks: units before the group and in total (exact integers), x / y sums before the group (prediction)
-    unsigned long long before = 0, total = 0;
-    double bx = 0.0, by = 0.0;
-    for (int j = tid; j < f.nblocks; j += gt) {
-        const unsigned long long u = (unsigned long long)f.partials[(size_t)j * 5];
-        total += u;
-        if (j < first_block) { before += u; bx += f.partials[(size_t)j * 5 + 1]; by += f.partials[(size_t)j * 5 + 2]; }
-    }
+    // the group's particles are requested first, the block sums behind them: everything the group reads is in flight at once (the
+    // sums lie in another XCD's memory: read one block per thread and trip, with the two prediction sums behind a branch, they
+    // were four dependent trips of ~0.8 us each in front of everything else the group does)
     const int base = lo + tid * MCLF_ITEMS;
     float4 r[MCLF_ITEMS];
     int cnt = 0;
@@ -507,6 +547,31 @@ __device__ __forceinline__ void mclf_prefix_group(const mcl_finish_args& f, int 
         r[k] = make_float4(0.f, 0.f, 0.f, 0.f);
         if (base + k < hi) { r[k] = f.rec[base + k]; cnt = k + 1; }
     }
+    // sums over the blocks: units before the group and in total (exact integers), x / y sums before the group (prediction)
+    unsigned long long before = 0, total = 0;
+    double bx = 0.0, by = 0.0;
+    for (int j0 = tid; j0 < f.nblocks; j0 += 4 * gt) {
+        double pu[4], px4[4], py4[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int j = j0 + q * gt;
+            const size_t at = (size_t)(j < f.nblocks ? j : 0) * 5;              // (a clamped index: the loads carry no branch)
+            pu[q] = f.partials[at]; px4[q] = f.partials[at + 1]; py4[q] = f.partials[at + 2];
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int j = j0 + q * gt;
+            if (j < f.nblocks) {
+                const unsigned long long u = (unsigned long long)pu[q];
+                total += u;
+                if (j < first_block) { before += u; bx += px4[q]; by += py4[q]; }
+            }
+        }
+    }
+#ifdef MCLF_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (tid == 0 && g == f.groups / 2) f.state->xstamps[0] = MCLF_NOW();
+#endif
     for (int off = 32; off > 0; off >>= 1) { before += __shfl_xor(before, off, 64); total += __shfl_xor(total, off, 64); }
     bx = mclf_wave_sum_all(bx); by = mclf_wave_sum_all(by);
     if (lane == 0) { sm.off[wave] = before; sm.tot[wave] = total; sm.bx[wave] = bx; sm.by[wave] = by; }
@@ -550,15 +615,16 @@ __device__ __forceinline__ void mclf_prefix_group(const mcl_finish_args& f, int 
     const ss_rec rx = mclf_make_record(f, 0, tx, cnt, px, very_first, lane, g * nw + wave);
     const ss_rec ry = mclf_make_record(f, 1, ty, cnt, py, very_first, lane, g * nw + wave);
     MCLF_GSTAMP(5);
+    // a record that names a table or a wild map must not be seen before them: this wave's write-through stores have left (no
+    // cache writeback) before the record goes.  The record itself is its own flag (mclf_decode_rec): nothing waits for it here.
+    const bool side_data = (rx.key != SS_ID && (rx.key & MCLF_RISKY) != 0) || (ry.key != SS_ID && (ry.key & MCLF_RISKY) != 0);
+    if (side_data) mclf_drain_stores();
     if (lane == 0) {
         const int s = g * nw + wave;
-        mclf_store_rec(mclf_rec_ptr(f, 0, s), rx);
-        mclf_store_rec(mclf_rec_ptr(f, 1, s), ry);
+        mclf_store_rec(mclf_rec_ptr(f, 0, s), rx, f.tag);
+        mclf_store_rec(mclf_rec_ptr(f, 1, s), ry, f.tag);
     }
-    mclf_drain_stores();                                        // this wave's records and table rows have left (no cache writeback)
-    __syncthreads();
     MCLF_GSTAMP(6);
-    if (tid == 0) __hip_atomic_fetch_add(f.sync, 1ull << 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #ifdef MCLF_STAMPS
     if (tid == 0 && g == f.groups / 2) { gs[7] = MCLF_NOW(); for (int k = 0; k < 8; ++k) f.state->gstamps[k] = gs[k]; }
 #endif
@@ -715,11 +781,11 @@ __device__ __forceinline__ mclf_stage mclf_stage_at(char* base, int nbatch)
 
 // One batch of 64 records of an axis, by one wave: composite, and the list entries of its risky records.
 // tbase: first staged slot of every rank's tables on this axis (a record names its table by its rank's own slot number)
-__device__ __forceinline__ void mclf_stage_batch(const mcl_finish_args& f, const mclf_stage& st, ss_rec r, int b, int lane, const int* tbase, int axis)
+__device__ __forceinline__ void mclf_stage_batch(const mcl_finish_args& f, const mclf_stage& st, ss_rec r, int b, int lane, const int* tbase, int axis, int* ntab_seen)
 {
     const bool risky = r.key != SS_ID && (r.key & MCLF_RISKY) != 0;
     int tslot = r.key == SS_ID ? -1 : ((r.key >> MCLF_TSLOT_SHIFT) & 0xff) - 1;
-    if (tslot >= 0) tslot += tbase[mclf_rank_of_sub(f, b * 64 + lane)];
+    if (tslot >= 0) { tslot += tbase[mclf_rank_of_sub(f, b * 64 + lane)]; atomicMax(ntab_seen, tslot + 1); }
     const int pkey = mclf_plain_key(r.key);
     const unsigned long long rmask = __builtin_amdgcn_ballot_w64(risky);
     ss_rec v = r;
@@ -827,7 +893,8 @@ __device__ __forceinline__ float mclf_walk(const mcl_finish_args& f, int axis, d
             asm volatile("global_load_dwordx4 %0, %4, off sc1\n\tglobal_load_dwordx4 %1, %5, off sc1\n\t"
                          "global_load_dwordx4 %2, %5, off offset:16 sc1\n\tglobal_load_dwordx4 %3, %5, off offset:32 sc1\n\ts_waitcnt vmcnt(0)"
                          : "=&v"(q0), "=&v"(q1), "=&v"(q2), "=&v"(q3) : "v"(rp), "v"(wp) : "memory");
-            r = ss_rec_make(q0.x, q0.y, q0.z, q0.w);
+            bool current;
+            r = mclf_decode_rec(q0, 0u, &current);
             w.key_in = q1.x; w.key_out = q1.y; w.q = q1.z; w.r = q1.w;
             w.a = (long long)(((unsigned long long)(unsigned int)q2.y << 32) | (unsigned int)q2.x); w.c = (long long)(((unsigned long long)(unsigned int)q2.w << 32) | (unsigned int)q2.z);
             w.L = (long long)(((unsigned long long)(unsigned int)q3.y << 32) | (unsigned int)q3.x); w.H = (long long)(((unsigned long long)(unsigned int)q3.w << 32) | (unsigned int)q3.z);
@@ -964,8 +1031,21 @@ __device__ __forceinline__ void mclf_reduce_partials(const mcl_finish_args& f, m
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (tid < MCLF_POSE_THREADS) {
         double v[5] = {0, 0, 0, 0, 0};
-        for (int b = tid; b < f.nblocks; b += MCLF_POSE_THREADS)
-            for (int k = 0; k < 5; ++k) v[k] += f.partials[(size_t)b * 5 + k];
+        // (four blocks per thread requested together -- a trip to memory each otherwise; the additions keep their order)
+        for (int b0 = tid; b0 < f.nblocks; b0 += 4 * MCLF_POSE_THREADS) {
+            double p[4][5];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int b = b0 + q * MCLF_POSE_THREADS;
+                const size_t at = (size_t)(b < f.nblocks ? b : 0) * 5;
+#pragma unroll
+                for (int k = 0; k < 5; ++k) p[q][k] = f.partials[at + k];
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (b0 + q * MCLF_POSE_THREADS < f.nblocks)
+                    for (int k = 0; k < 5; ++k) v[k] += p[q][k];
+        }
         for (int k = 0; k < 5; ++k) v[k] = mclf_wave_sum(v[k]);
         if (lane == 0) for (int k = 0; k < 5; ++k) sm.red[wave][k] = v[k];
     }
@@ -998,56 +1078,122 @@ __device__ __forceinline__ void mclf_wait_pose(const mcl_finish_args& f, float* 
 }
 
 // The pre-chain workgroup: the float sums over the first MCLF_PRE_SUBS sub-tiles.  The sums start from zero, so nothing is
-// needed from the groups there, and that is where the accumulator changes its binade every few terms: the first sub-tiles are
-// stepped term by term (terms through LDS, one wave-uniform loop of three dependent operations per term), the others by the
-// in-binade replay.  Waves 0 / 1: x / y; the result goes to the finisher through f.sync[1..2].  Called by every thread of the
-// workgroup (barriers).
+// needed from the groups there, and that is where the accumulator changes its binade every few terms.  Waves 0 / 1 (x / y) step
+// the first MCLF_PRE_STEPPED sub-tiles term by term (terms through LDS, one wave-uniform loop of three dependent operations per
+// term); meanwhile every other wave of the workgroup forms the WILD MAP of one (axis, sub-tile) behind them from the double
+// prefix sums of the terms (bl_serial_sum.h: so early in a sum the float accumulator and its double prediction differ by a few
+// ulps, and a step's validity interval is as wide as a term).  Waves 0 / 1 then take a sub-tile by its map -- a check and a few
+// integer operations -- and replay it the in-binade way when the map does not fit (each replay phase is 0.7 us of one wave:
+// seven sub-tiles were 11 us that the finisher's chains waited for).  The result goes to the finisher through f.sync[1..2].
+// Called by every thread of the workgroup (barriers).
+static_assert(MCLF_PRE_SUBS - MCLF_PRE_STEPPED <= (MCLF_WG / 64 - 2) / 2, "one wave per (axis, mapped sub-tile) of the pre-chain");
 __device__ __forceinline__ void mclf_pre_chain(const mcl_finish_args& f, mclf_smem& sm)
 {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (tid >= MCLF_POSE_THREADS) return;
     const int nrec = f.groups * (f.gthreads >> 6);
     const int npre = min(MCLF_PRE_SUBS, nrec);
+    const bool stepper = wave < 2;
+    const int axis = stepper ? wave : ((wave - 2) & 1);
+    const int bq = MCLF_PRE_STEPPED + ((wave - 2) >> 1);                // a builder's sub-tile
+    const bool builder = !stepper && bq < npre;
     // the particles are requested before the block sums are reduced
     float4 pre_r[MCLF_PRE_SUBS][MCLF_ITEMS];
     int cnt[MCLF_PRE_SUBS];
-    if (wave < 2) {
+    if (stepper) {
+        int at[MCLF_PRE_SUBS][MCLF_ITEMS];
 #pragma unroll
         for (int q = 0; q < MCLF_PRE_SUBS; ++q) {
             int lo = 0, hi = 0;
             if (q < npre) mclf_sub_range(f, q, &lo, &hi);
             cnt[q] = hi - lo;
 #pragma unroll
-            for (int k = 0; k < MCLF_ITEMS; ++k) {
-                const int i = lo + lane * MCLF_ITEMS + k;
-                pre_r[q][k] = i < hi ? mclf_particle(f, i) : make_float4(0.f, 0.f, 0.f, 0.f);
-            }
+            for (int k = 0; k < MCLF_ITEMS; ++k) { const int i = lo + lane * MCLF_ITEMS + k; at[q][k] = i < hi ? i : 0; }
+        }
+        // (the loads stand alone, without a branch between them: they go out together; the count decides what is used)
+        if (!f.sh) {
+#pragma unroll
+            for (int q = 0; q < MCLF_PRE_SUBS; ++q)
+#pragma unroll
+                for (int k = 0; k < MCLF_ITEMS; ++k) { const mclf_f4 v = *(mclf_gptr4)(f.rec + at[q][k]); pre_r[q][k] = make_float4(v.x, v.y, v.z, v.w); }
+        } else {
+#pragma unroll
+            for (int q = 0; q < MCLF_PRE_SUBS; ++q)
+#pragma unroll
+                for (int k = 0; k < MCLF_ITEMS; ++k) pre_r[q][k] = mclf_particle(f, at[q][k]);
         }
     }
-    double su = 0.0;
-    for (int b = tid; b < f.nblocks; b += MCLF_POSE_THREADS) su += f.partials[(size_t)b * 5];
-    su = mclf_wave_sum_all(su);
-    if (lane == 0) sm.red[wave][0] = su;
+    float4 br[MCLF_ITEMS] = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)};
+    int bcnt = 0;
+    if (builder) {
+        int lo, hi;
+        mclf_sub_range(f, bq, &lo, &hi);
+        bcnt = max(0, min(MCLF_ITEMS, hi - lo - lane * MCLF_ITEMS));
+#pragma unroll
+        for (int k = 0; k < MCLF_ITEMS; ++k) {
+            const int i = k < bcnt ? lo + lane * MCLF_ITEMS + k : 0;
+            if (!f.sh) { const mclf_f4 v = *(mclf_gptr4)(f.rec + i); br[k] = make_float4(v.x, v.y, v.z, v.w); }
+            else br[k] = mclf_particle(f, i);
+        }
+    }
+    if (tid < MCLF_POSE_THREADS) {
+        double su = 0.0;
+        for (int b0 = tid; b0 < f.nblocks; b0 += 4 * MCLF_POSE_THREADS) {
+            double p[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { const int b = b0 + q * MCLF_POSE_THREADS; p[q] = f.partials[(size_t)(b < f.nblocks ? b : 0) * 5]; }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) if (b0 + q * MCLF_POSE_THREADS < f.nblocks) su += p[q];
+        }
+        su = mclf_wave_sum_all(su);
+        if (lane == 0) sm.red[wave][0] = su;
+    }
+#ifdef MCLF_STAMPS
+    if (tid == 0) f.state->xstamps[8] = MCLF_NOW();
+#endif
     __syncthreads();
-    if (wave >= 2) return;
+#ifdef MCLF_STAMPS
+    if (tid == 0) f.state->xstamps[9] = MCLF_NOW();
+#endif
     double S = 0.0;
     for (int w = 0; w < MCLF_POSE_THREADS / 64; ++w) S += sm.red[w][0];          // exact integer below 2^53, any order gives it
+    // ---- the terms; their double sums per sub-tile (the builders' predictions)
+    double bt[MCLF_ITEMS] = {0.0, 0.0};
+    double* pre = sm.pre[axis];
+    int nstep = 0;
+    if (stepper) {
+#pragma unroll
+        for (int q = 0; q < MCLF_PRE_STEPPED; ++q) {
+            double qs = 0.0;
+            if (q < npre) {
+#pragma unroll
+                for (int k = 0; k < MCLF_ITEMS; ++k) {
+                    const double t = (lane * MCLF_ITEMS + k < cnt[q]) ? mclf_term(pre_r[q][k], S, axis) : 0.0;
+                    pre[q * MCLF_SUB + 2 * lane + k] = t;
+                    qs += t;
+                }
+                nstep = q * MCLF_SUB + cnt[q];                // (a short sub-tile can only be the last one)
+            }
+            qs = mclf_wave_sum_all(qs);
+            if (lane == 0) sm.psum[axis][q] = qs;
+        }
+    } else if (builder) {
+        double qs = 0.0;
+#pragma unroll
+        for (int k = 0; k < MCLF_ITEMS; ++k) { bt[k] = k < bcnt ? mclf_term(br[k], S, axis) : 0.0; qs += bt[k]; }
+        qs = mclf_wave_sum_all(qs);
+        if (lane == 0) sm.psum[axis][bq] = qs;
+    }
+#ifdef MCLF_STAMPS
+    if (tid == 0) f.state->xstamps[10] = MCLF_NOW();
+#endif
+    __syncthreads();
+#ifdef MCLF_STAMPS
+    if (tid == 0) f.state->xstamps[5] = MCLF_NOW();
+#endif
     unsigned int ph = 0;
     float v = 0.0f;
-    double* pre = sm.pre[wave];
-    int nstep = 0;
-#pragma unroll
-    for (int q = 0; q < MCLF_PRE_STEPPED; ++q) {
-        if (q < npre) {
-#pragma unroll
-            for (int k = 0; k < MCLF_ITEMS; ++k)
-                pre[q * MCLF_SUB + 2 * lane + k] = (lane * MCLF_ITEMS + k < cnt[q]) ? mclf_term(pre_r[q][k], S, wave) : 0.0;
-            nstep = q * MCLF_SUB + cnt[q];                    // (a short sub-tile can only be the last one)
-        }
-    }
-    __builtin_amdgcn_wave_barrier();
-    nstep = __builtin_amdgcn_readfirstlane(nstep);
-    {
+    if (stepper) {
+        nstep = __builtin_amdgcn_readfirstlane(nstep);
         int i = 0;
         for (; i + 8 <= nstep; i += 8) {
             double w8[8];
@@ -1057,22 +1203,52 @@ __device__ __forceinline__ void mclf_pre_chain(const mcl_finish_args& f, mclf_sm
             for (int u = 0; u < 8; ++u) v = ss_exact_step(v, w8[u]);
         }
         for (; i < nstep; ++i) v = ss_exact_step(v, pre[i]);
+    } else if (builder) {
+        double start = 0.0;
+        for (int q = 0; q < bq; ++q) start += sm.psum[axis][q];
+        const int key = __builtin_amdgcn_readfirstlane(ss_key((float)start));
+        ss_wild m = ssw_invalid();
+        if (key != 0 && __builtin_amdgcn_ballot_w64(bcnt > 0) != 0ull) m = mclf_wild_map(bt, bcnt, start, key, lane);
+        if (lane == 0) sm.pmap[axis][bq] = m;
     }
+#ifdef MCLF_STAMPS
+    if (tid == 0) f.state->xstamps[6] = MCLF_NOW();
+#endif
+    __syncthreads();
+#ifdef MCLF_STAMPS
+    if (tid == 0) f.state->xstamps[7] = MCLF_NOW();
+#endif
+    if (!stepper) return;
+    unsigned int by_map = 0, replayed = 0;
 #pragma unroll
     for (int q = MCLF_PRE_STEPPED; q < MCLF_PRE_SUBS; ++q) {
         if (q < npre && cnt[q] > 0) {
-            double t[MCLF_ITEMS];
+            ss_wild m = sm.pmap[axis][q];                                  // (wave-uniform LDS read)
+            m = mclf_readlane_wild(m, 0);
+            const int key = __builtin_amdgcn_readfirstlane(ss_key(v));
+            const long long mag = ssw_signed(key, ss_mag(v));
+            if (key != 0 && ssw_fits(m, key, mag)) {
+                const long long mo = ssw_apply(m, mag);
+                v = ss_from_bits(m.key_out, (int)(mo < 0 ? -mo : mo));
+                by_map++;
+            } else {
+                double t[MCLF_ITEMS];
 #pragma unroll
-            for (int k = 0; k < MCLF_ITEMS; ++k) t[k] = (lane * MCLF_ITEMS + k < cnt[q]) ? mclf_term(pre_r[q][k], S, wave) : 0.0;
-            v = mclf_replay(t, cnt[q], 0, 0, v, lane, &ph);
+                for (int k = 0; k < MCLF_ITEMS; ++k) t[k] = (lane * MCLF_ITEMS + k < cnt[q]) ? mclf_term(pre_r[q][k], S, axis) : 0.0;
+                v = mclf_replay(t, cnt[q], 0, 0, v, lane, &ph);
+                replayed++;
+            }
         }
     }
-    if (lane == 0) sm.first[wave] = v;
+    if (lane == 0) { sm.first[wave] = v; f.state->pre_stats[wave] += (by_map << 16) + replayed; }
     __syncthreads();                                           // (waves 0 and 1 only: the others have left)
     if (tid == 0) {
         mclf_store_u64(f.sync + 1, (unsigned long long)__float_as_uint(sm.first[0]) | ((unsigned long long)__float_as_uint(sm.first[1]) << 32));
         mclf_drain_stores();
         mclf_store_u64(f.sync + 2, 1ull);
+#ifdef MCLF_STAMPS
+        f.state->xstamps[3] = MCLF_NOW();
+#endif
     }
 }
 
@@ -1095,66 +1271,126 @@ __device__ __forceinline__ void mclf_pose(const mcl_finish_args& f, mclf_smem& s
     const bool staged = scratch != nullptr && 2 * per_axis <= scratch_bytes;
 #define MCLF_STAGE(axis) mclf_stage_at(scratch + (size_t)(axis) * per_axis, nbatch)
     if (staged && tid < 2) *MCLF_STAGE(tid).nent = 0;
-    __syncthreads();
-    double S = 0.0;
-    for (int w = 0; w < MCLF_POSE_THREADS / 64; ++w) S += sm.red[w][0];          // exact integer below 2^53, any order gives it
     if (tid == 0) {
-        // every group of this launch has counted itself once its records (and tables) were on their way through the L2 (a composed
-        // finish waits for none: its groups ran in an earlier launch, and their blocks arrived by the all-gather behind it)
-        unsigned long long w;
-        while (((w = mclf_load_u64(f.sync)) >> 32) < (unsigned long long)f.groups_wait) __builtin_amdgcn_s_sleep(1);
-        sm.word = w;
-        // tables: rank r's slot q of an axis is staged as slot tbase[axis][r] + q -- while it is below MCLF_TSLOTS
+        // tables: rank r's slot q of an axis is staged as slot tbase[axis][r] + q -- while it is below MCLF_TSLOTS.  A composed
+        // finish knows every rank's count (its groups ran in an earlier launch, their blocks arrived by the all-gather behind it);
+        // with the groups in this launch the records say which slots are in use (ntab_seen, below)
         const int world = mclf_world(f);
         for (int axis = 0; axis < 2; ++axis) {
             int run = 0;
-            for (int r = 0; r < world; ++r) { sm.tbase[axis][r] = run; run += mclf_tab_count(f, w, r, axis); }
+            for (int r = 0; r < world; ++r) { sm.tbase[axis][r] = run; run += f.sh ? mclf_tab_count(f, 0ull, r, axis) : MCLF_TSLOTS; }
             sm.tbase[axis][world] = run;
+            sm.ntab_seen[axis] = 0;
         }
     }
     __syncthreads();
+    double S = 0.0;
+    for (int w = 0; w < MCLF_POSE_THREADS / 64; ++w) S += sm.red[w][0];          // exact integer below 2^53, any order gives it
     MCLF_STAMP(1);
     const int sh_world = mclf_world(f);
-    const int ntab[2] = {min(sm.tbase[0][sh_world], MCLF_TSLOTS), min(sm.tbase[1][sh_world], MCLF_TSLOTS)};
-    if (staged) {
-        // ---- stage a: every wave takes batches of records and tables of both axes; the loads of four items are in flight together
-        const int nb2 = 2 * nbatch, items = nb2 + ntab[0] + ntab[1];
-        for (int base = wave; base < items; base += 4 * MCLF_MAXW) {
-            ss_rec rr[4];
-            mclf_tab_elem te[4][MCLF_ITEMS];
+    {
+        // ---- stage a: every wave takes batches of 64 records of both axes, four per round, as 16-byte loads through the L2 (sc1)
+        // that are waited for once (relaxed atomic 8-byte loads behind a branch per item became flat loads with a wait each).
+        // The groups of this launch are still at work when the finisher gets here: a slot that does not show the launch's tag yet
+        // is read again -- the load that finds the last record of a batch IS its staging load.  (A composed finish takes what the
+        // all-gather brought.)  Lanes without a record read the first one.
+        const bool poll = f.groups_wait > 0;
+        const int nb2 = 2 * nbatch;
+        const void* const dummy = (const void*)mclf_rec_ptr(f, 0, 0);
+        for (int round = 0; round * 4 * MCLF_MAXW < nb2; ++round) {
+            const void* pr[4];
+            bool mine[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                const int it = base + u * MCLF_MAXW;
-                rr[u] = ss_rec_identity();
-                te[u][0].t = 0.0; te[u][0].se = 1; te[u][0].se1 = 1; te[u][1] = te[u][0];
+                const int it = wave + (4 * round + u) * MCLF_MAXW;
+                pr[u] = dummy; mine[u] = false;
                 if (it < nb2) {
                     const int axis = it >= nbatch ? 1 : 0, b = it - axis * nbatch;
-                    if (b * 64 + lane < nrec) rr[u] = mclf_load_rec(mclf_rec_ptr(f, axis, b * 64 + lane));
-                } else if (it < items) {
-                    const int q = it - nb2, axis = q >= ntab[0] ? 1 : 0, slot = q - axis * ntab[0];
-                    int r = 0;
-                    while (r + 1 < sh_world && sm.tbase[axis][r + 1] <= slot) ++r;             // the rank whose table this staged slot is
-                    const mclf_tab_elem* src = mclf_tab_ptr(f, axis, r, slot - sm.tbase[axis][r]) + lane * MCLF_ITEMS;
-                    te[u][0] = mclf_load_tab(src); te[u][1] = mclf_load_tab(src + 1);
+                    if (b * 64 + lane < nrec) { pr[u] = (const void*)mclf_rec_ptr(f, axis, b * 64 + lane); mine[u] = true; }
                 }
             }
+            ss_rec rr[4];
+            while (true) {
+                int4 q[4];
+                asm volatile("global_load_dwordx4 %0, %4, off sc1\n\tglobal_load_dwordx4 %1, %5, off sc1\n\t"
+                             "global_load_dwordx4 %2, %6, off sc1\n\tglobal_load_dwordx4 %3, %7, off sc1\n\ts_waitcnt vmcnt(0)"
+                             : "=&v"(q[0]), "=&v"(q[1]), "=&v"(q[2]), "=&v"(q[3]) : "v"(pr[0]), "v"(pr[1]), "v"(pr[2]), "v"(pr[3]) : "memory");
+                bool late = false;
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int it = base + u * MCLF_MAXW;
-                if (it < nb2) {
-                    const int axis = it >= nbatch ? 1 : 0, b = it - axis * nbatch;
-                    mclf_stage_batch(f, MCLF_STAGE(axis), rr[u], b, lane, sm.tbase[axis], axis);
-                } else if (it < items) {
-                    const int q = it - nb2, axis = q >= ntab[0] ? 1 : 0, slot = q - axis * ntab[0];
-                    mclf_tab_elem* dst = MCLF_STAGE(axis).tab + slot * MCLF_SUB + lane * MCLF_ITEMS;
-                    dst[0] = te[u][0];
-                    dst[1] = te[u][1];
+                for (int u = 0; u < 4; ++u) {
+                    bool current;
+                    rr[u] = mclf_decode_rec(q[u], f.tag, &current);
+                    if (!mine[u]) rr[u] = ss_rec_identity();
+                    late |= mine[u] && poll && !current;
+                }
+                if (__builtin_amdgcn_ballot_w64(late) == 0ull) break;
+                __builtin_amdgcn_s_sleep(1);
+            }
+#ifdef MCLF_STAMPS
+            if (tid == 0 && round == 0) f.state->xstamps[1] = MCLF_NOW();
+#endif
+            if (staged) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int it = wave + (4 * round + u) * MCLF_MAXW;
+                    if (it < nb2) {
+                        const int axis = it >= nbatch ? 1 : 0, b = it - axis * nbatch;
+                        mclf_stage_batch(f, MCLF_STAGE(axis), rr[u], b, lane, sm.tbase[axis], axis, &sm.ntab_seen[axis]);
+                    }
                 }
             }
         }
-        __syncthreads();
-        MCLF_STAMP(2);
-        // ---- stage b: the list in sub-tile order (waves 0, 1), then one wave per gap
+    }
+#ifdef MCLF_STAMPS
+    if (tid == 0) f.state->xstamps[2] = MCLF_NOW();
+#endif
+    __syncthreads();                                             // every record of this launch has been seen: the groups are through
+    MCLF_STAMP(2);
+    const int ntab[2] = {min(f.sh ? sm.tbase[0][sh_world] : sm.ntab_seen[0], MCLF_TSLOTS), min(f.sh ? sm.tbase[1][sh_world] : sm.ntab_seen[1], MCLF_TSLOTS)};
+    if (staged) {
+        // ---- stage b: the last MCLF_TAB_WAVES waves bring the tables the records name into LDS (a round trip to memory that nothing
+        // below waits for before the chain's barrier) while waves 0, 1 put the lists in sub-tile order and the other waves join the gaps
+        if (wave >= MCLF_MAXW - MCLF_TAB_WAVES) {
+            const int ntabs = ntab[0] + ntab[1], tw = wave - (MCLF_MAXW - MCLF_TAB_WAVES), tnw = MCLF_TAB_WAVES;
+            const void* const dummy = (const void*)mclf_rec_ptr(f, 0, 0);
+            for (int round = 0; round * 4 * tnw < ntabs; ++round) {
+                const void* pt[4][2];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int q = tw + (4 * round + u) * tnw;
+                    pt[u][0] = dummy; pt[u][1] = dummy;
+                    if (q < ntabs) {
+                        const int axis = q >= ntab[0] ? 1 : 0, slot = q - axis * ntab[0];
+                        int r = 0;
+                        while (r + 1 < sh_world && sm.tbase[axis][r + 1] <= slot) ++r;             // the rank whose table this staged slot is
+                        const mclf_tab_elem* src = mclf_tab_ptr(f, axis, r, slot - sm.tbase[axis][r]) + lane * MCLF_ITEMS;
+                        pt[u][0] = (const void*)src; pt[u][1] = (const void*)(src + 1);
+                    }
+                }
+                int4 qt[4][2];
+                asm volatile("global_load_dwordx4 %0, %8, off sc1\n\tglobal_load_dwordx4 %1, %9, off sc1\n\t"
+                             "global_load_dwordx4 %2, %10, off sc1\n\tglobal_load_dwordx4 %3, %11, off sc1\n\t"
+                             "global_load_dwordx4 %4, %12, off sc1\n\tglobal_load_dwordx4 %5, %13, off sc1\n\t"
+                             "global_load_dwordx4 %6, %14, off sc1\n\tglobal_load_dwordx4 %7, %15, off sc1\n\ts_waitcnt vmcnt(0)"
+                             : "=&v"(qt[0][0]), "=&v"(qt[0][1]), "=&v"(qt[1][0]), "=&v"(qt[1][1]), "=&v"(qt[2][0]), "=&v"(qt[2][1]), "=&v"(qt[3][0]), "=&v"(qt[3][1])
+                             : "v"(pt[0][0]), "v"(pt[0][1]), "v"(pt[1][0]), "v"(pt[1][1]), "v"(pt[2][0]), "v"(pt[2][1]), "v"(pt[3][0]), "v"(pt[3][1])
+                             : "memory");
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int q = tw + (4 * round + u) * tnw;
+                    if (q < ntabs) {
+                        const int axis = q >= ntab[0] ? 1 : 0, slot = q - axis * ntab[0];
+                        mclf_tab_elem* dst = MCLF_STAGE(axis).tab + slot * MCLF_SUB + lane * MCLF_ITEMS;
+#pragma unroll
+                        for (int k = 0; k < MCLF_ITEMS; ++k) {
+                            mclf_tab_elem e;
+                            e.t = __hiloint2double(qt[u][k].y, qt[u][k].x); e.se = qt[u][k].z; e.se1 = qt[u][k].w;
+                            dst[k] = e;
+                        }
+                    }
+                }
+            }
+        }
         if (wave < 2) {
             const mclf_stage a = MCLF_STAGE(wave);
             const int n = *a.nent > MCLF_MAXENT ? 0 : *a.nent;              // (an overflowed list is no list: the chain walks)
@@ -1164,9 +1400,9 @@ __device__ __forceinline__ void mclf_pose(const mcl_finish_args& f, mclf_smem& s
             if (lane < n) a.order[rank] = lane;
         }
         __syncthreads();
-        {
+        if (wave < MCLF_MAXW - MCLF_TAB_WAVES) {
             const int n0 = *MCLF_STAGE(0).nent > MCLF_MAXENT ? 0 : *MCLF_STAGE(0).nent, n1 = *MCLF_STAGE(1).nent > MCLF_MAXENT ? 0 : *MCLF_STAGE(1).nent;
-            for (int it = wave; it < n0 + n1 + 2; it += MCLF_MAXW) {
+            for (int it = wave; it < n0 + n1 + 2; it += MCLF_MAXW - MCLF_TAB_WAVES) {
                 const int axis = it > n0 ? 1 : 0, k = it - axis * (n0 + 1);
                 const mclf_stage a = MCLF_STAGE(axis);
                 const int n = axis ? n1 : n0;
@@ -1196,6 +1432,9 @@ __device__ __forceinline__ void mclf_pose(const mcl_finish_args& f, mclf_smem& s
         // the sums behind the first sub-tiles, from the pre-chain workgroup (long done by now, as a rule)
         while (mclf_load_u64(f.sync + 2) == 0ull) __builtin_amdgcn_s_sleep(1);
         const unsigned long long fw = mclf_load_u64(f.sync + 1);
+#ifdef MCLF_STAMPS
+        if (tid == 0) f.state->xstamps[4] = MCLF_NOW();
+#endif
         const float first = __uint_as_float((unsigned int)(wave ? fw >> 32 : fw));
         const mclf_stage mine = MCLF_STAGE(wave);
         const float v = mclf_chain(f, staged ? &mine : nullptr, wave ? ntab[1] : ntab[0], wave, S, first, lane, stats);
@@ -1204,7 +1443,7 @@ __device__ __forceinline__ void mclf_pose(const mcl_finish_args& f, mclf_smem& s
     __syncthreads();
     MCLF_STAMP(4);
     if (tid == 0) {
-        mclf_store_u64(f.sync, 0ull);                        // the next launch on this stream counts from zero again
+        mclf_store_u64(f.sync, 0ull);                        // the next launch on this stream hands its tables out from slot 0 again
         mclf_store_u64(f.sync + 1, 0ull);
         mclf_store_u64(f.sync + 2, 0ull);
         double tot[5] = {0, 0, 0, 0, 0};
