@@ -67,6 +67,11 @@ struct map_args {
     int pre_on; bl_scan_prefetch_args pre;
 };
 
+#ifdef MCLF_STAMPS
+#define XSTAMP(i) do { if (threadIdx.x == 0 && a.fin_on) a.fin.state->xstamps[i] = MCLF_NOW(); } while (0)
+#else
+#define XSTAMP(i) do { } while (0)
+#endif
 #ifdef BL_MAP_STAMPS
 #define MSTAMP(i) do { if (threadIdx.x == 0) a.stamps[i] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
 #else
@@ -400,7 +405,9 @@ __device__ __forceinline__ void map_update_body(const map_args& a, int8_t* snap,
             MSTAMP(5);
             if (prov) {
                 // hit and miss counts stand in LDS, nothing has been stored to the grid yet: now the reference's x, y
+                XSTAMP(15);
                 take_exact_pose();
+                XSTAMP(11);
                 const bl_pose3 pe2 = {lds_pose->x, lds_pose->y, pe.theta};
                 if (tid < a.R) {
                     const int4 ray2 = map_ray_cells(a, pb, pe2, pre_range, pre_theta, pre_time);
@@ -409,6 +416,7 @@ __device__ __forceinline__ void map_update_body(const map_args& a, int8_t* snap,
                 __syncthreads();
                 if (s_redo) return 1;                                 // some ray's cells moved: count again with the exact pose
                 prov = false;                                         // every ray has the reference's cells: the counts are the reference's
+                XSTAMP(12);
             }
             // leaders finish their end cell: v' = max(-128, min(127, v + hit*H) - miss*M), then hide it from the window pass
             if (leader) {
@@ -445,6 +453,7 @@ __device__ __forceinline__ void map_update_body(const map_args& a, int8_t* snap,
             }
             __syncthreads();
         }
+        XSTAMP(13);
         // window pass: thread (tx, ty) owns column bx0 + tx (+256, ...) and every 4th row; 8 rows per batch so the byte loads
         // of a batch are in flight together (a serial load -> store chain per cell cost ~1 us per cell per thread)
         const int tx = tid & 255, ty = tid >> 8;
@@ -512,6 +521,7 @@ __device__ __forceinline__ void map_update_body(const map_args& a, int8_t* snap,
             }
         }
         __syncthreads();
+        XSTAMP(14);
         MSTAMP(6);
     }
     return 0;

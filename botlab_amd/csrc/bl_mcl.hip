@@ -2067,7 +2067,7 @@ extern "C" int bl_pf_debug_estimate_stats(bl_pf* pf, uint32_t* out4)   /* eight 
         fprintf(stderr, "x chain entries (us):");
         for (int k = 1; k < 16; ++k) fprintf(stderr, " %.2f", cs[k] > cs[k - 1] ? (cs[k] - cs[k - 1]) * 0.01 : -1.0);
         fprintf(stderr, "\n");
-        unsigned long long xs[12];
+        unsigned long long xs[16];
         BL_HIP(hipMemcpy(xs, pf->state->xstamps, sizeof(xs), hipMemcpyDeviceToHost));
         fprintf(stderr, "stamped group: loads back %+.2f after its entry; finisher stage a: wave 0 has its first records %+.2f, is through %+.2f after the block sums\n",
                 ((long long)xs[0] - (long long)gs[0]) * 0.01, ((long long)xs[1] - (long long)st[1]) * 0.01, ((long long)xs[2] - (long long)st[1]) * 0.01);
@@ -2076,6 +2076,9 @@ extern "C" int bl_pf_debug_estimate_stats(bl_pf* pf, uint32_t* out4)   /* eight 
         fprintf(stderr, "pre-chain: sums barrier %+.2f, stepped %+.2f, maps barrier %+.2f after the finisher's entry\n", ((long long)xs[5] - (long long)st[0]) * 0.01,
                 ((long long)xs[6] - (long long)st[0]) * 0.01, ((long long)xs[7] - (long long)st[0]) * 0.01);
         fprintf(stderr, "pre-chain published %+.2f, x chain had its start value %+.2f after the finisher's entry\n", ((long long)xs[3] - (long long)st[0]) * 0.01, ((long long)xs[4] - (long long)st[0]) * 0.01);
+        fprintf(stderr, "map workgroup: counts stand %+.2f, exact pose taken %+.2f, verified %+.2f, leaders done %+.2f, window done %+.2f after the finisher's entry\n",
+                ((long long)xs[15] - (long long)st[0]) * 0.01, ((long long)xs[11] - (long long)st[0]) * 0.01, ((long long)xs[12] - (long long)st[0]) * 0.01,
+                ((long long)xs[13] - (long long)st[0]) * 0.01, ((long long)xs[14] - (long long)st[0]) * 0.01);
         fprintf(stderr, "finisher timeline (us): block sums +%.2f, records in and staged +%.2f, lists and gaps +%.2f, chains +%.2f, exit +%.2f\n", (st[1] - st[0]) * 0.01,
                 (st[2] - st[1]) * 0.01, (st[3] - st[2]) * 0.01, (st[4] - st[3]) * 0.01, (st[5] - st[4]) * 0.01);
     }

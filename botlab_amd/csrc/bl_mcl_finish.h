@@ -39,7 +39,7 @@ struct pf_state {
     unsigned long long cstamps[16]; // the x chain, entry by entry (diagnostic, -DMCLF_STAMPS)
     unsigned long long gstamps[8]; // one group's timeline (diagnostic, -DMCLF_STAMPS)
     unsigned long long stamps[6];  // finisher timeline in 10 ns ticks (diagnostic, -DMCLF_STAMPS)
-    unsigned long long xstamps[12]; // [0] the stamped group's loads are back; [1] the finisher's stage-a loads are back, [2] its wave 0 is through stage a; [3] the pre-chain has published, [4] the x chain has its start value
+    unsigned long long xstamps[16]; // [0] the stamped group's loads are back; [1] the finisher's stage-a loads are back, [2] its wave 0 is through stage a; [3] the pre-chain has published, [4] the x chain has its start value
 };
 
 struct mclf_tab_elem { double t; int se, se1; };       // term; (inclusive prefix << 1 | bad) in the predicted binade and in the next
@@ -74,8 +74,8 @@ struct mcl_finish_args {
     mclf_tab_elem* tabs;                   // [2][MCLF_TSLOTS][MCLF_SUB]
     unsigned long long* sync;              // MCLF_SYNC_WORDS words, zero between launches:
                                            // [0] bits 0..15 / 16..31: x / y tables handed out
-                                           // [1] the sums behind the first MCLF_PRE_SUBS sub-tiles (x, y float bits), [2] "they are there"
-                                           // [3] the finisher's exact x, y (float bits) for the map workgroup of the same launch, [4] "they are there"
+                                           // [1], [2] the x / y sum behind the first MCLF_PRE_SUBS sub-tiles: float bits | 1 << 32 ("it is there")
+                                           // [3], [4] the finisher's exact x / y for the map workgroup of the same launch, likewise
                                            //     (mclf_pose with publish writes them, mclf_wait_pose reads and clears them)
     int groups, gthreads;                  // group workgroups (of the whole particle set); threads of each that work (256 or 1024)
     ss_wild* wild;                         // [2][sub-tiles]: the map of a sub-tile whose sum is predicted to cross binades (bl_serial_sum.h), or null
@@ -591,10 +591,13 @@ __device__ __forceinline__ void mclf_prefix_group(const mcl_finish_args& f, int 
     unsigned long long off0 = incl - run, S_u = 0;
     double px = 0.0, py = 0.0;
     for (int w = 0; w < nw; ++w) { off0 += sm.off[w]; S_u += sm.tot[w]; px += sm.bx[w]; py += sm.by[w]; if (w < wave) off0 += sm.wave[w]; }
+    // (the prefix is the NEXT kernel's input; the records are what the finisher of this launch is waiting for: they go first)
+    if (!f.recs) {
 #pragma unroll
-    for (int k = 0; k < MCLF_ITEMS; ++k)
-        if (base + k < hi) f.prefix[base + k] = off0 + loc[k];
-    if (!f.recs) return;
+        for (int k = 0; k < MCLF_ITEMS; ++k)
+            if (base + k < hi) f.prefix[base + k] = off0 + loc[k];
+        return;
+    }
     MCLF_GSTAMP(3);
     // ---- the sub-tile records of the two float accumulators
     const double S = (double)S_u;
@@ -624,6 +627,9 @@ __device__ __forceinline__ void mclf_prefix_group(const mcl_finish_args& f, int 
         mclf_store_rec(mclf_rec_ptr(f, 0, s), rx, f.tag);
         mclf_store_rec(mclf_rec_ptr(f, 1, s), ry, f.tag);
     }
+#pragma unroll
+    for (int k = 0; k < MCLF_ITEMS; ++k)
+        if (base + k < hi) f.prefix[base + k] = off0 + loc[k];
     MCLF_GSTAMP(6);
 #ifdef MCLF_STAMPS
     if (tid == 0 && g == f.groups / 2) { gs[7] = MCLF_NOW(); for (int k = 0; k < 8; ++k) f.state->gstamps[k] = gs[k]; }
@@ -1069,10 +1075,14 @@ __device__ __forceinline__ bl_pose_xyt_t mclf_approx_pose(const double (&tot)[5]
 // one thread: wait for the finisher's x, y (mclf_pose with publish), clear the mailbox for the next launch
 __device__ __forceinline__ void mclf_wait_pose(const mcl_finish_args& f, float* x, float* y)
 {
-    while (mclf_load_u64(f.sync + 4) == 0ull) __builtin_amdgcn_s_sleep(1);
-    const unsigned long long w = mclf_load_u64(f.sync + 3);
-    *x = __uint_as_float((unsigned int)w);
-    *y = __uint_as_float((unsigned int)(w >> 32));
+    unsigned long long wx, wy;
+    while (true) {                                   // (both words requested together; each says by itself that it is there)
+        wx = mclf_load_u64(f.sync + 3); wy = mclf_load_u64(f.sync + 4);
+        if (((wx & wy) >> 32) & 1ull) break;
+        __builtin_amdgcn_s_sleep(1);
+    }
+    *x = __uint_as_float((unsigned int)wx);
+    *y = __uint_as_float((unsigned int)wy);
     mclf_store_u64(f.sync + 4, 0ull);
     mclf_store_u64(f.sync + 3, 0ull);
 }
@@ -1243,9 +1253,8 @@ __device__ __forceinline__ void mclf_pre_chain(const mcl_finish_args& f, mclf_sm
     if (lane == 0) { sm.first[wave] = v; f.state->pre_stats[wave] += (by_map << 16) + replayed; }
     __syncthreads();                                           // (waves 0 and 1 only: the others have left)
     if (tid == 0) {
-        mclf_store_u64(f.sync + 1, (unsigned long long)__float_as_uint(sm.first[0]) | ((unsigned long long)__float_as_uint(sm.first[1]) << 32));
-        mclf_drain_stores();
-        mclf_store_u64(f.sync + 2, 1ull);
+        mclf_store_u64(f.sync + 1, (unsigned long long)__float_as_uint(sm.first[0]) | (1ull << 32));
+        mclf_store_u64(f.sync + 2, (unsigned long long)__float_as_uint(sm.first[1]) | (1ull << 32));
 #ifdef MCLF_STAMPS
         f.state->xstamps[3] = MCLF_NOW();
 #endif
@@ -1430,12 +1439,12 @@ __device__ __forceinline__ void mclf_pose(const mcl_finish_args& f, mclf_smem& s
     if (wave < 2) {                                                                // wave 0: pose.x, wave 1: pose.y
         unsigned int stats[4] = {0, 0, 0, 0};
         // the sums behind the first sub-tiles, from the pre-chain workgroup (long done by now, as a rule)
-        while (mclf_load_u64(f.sync + 2) == 0ull) __builtin_amdgcn_s_sleep(1);
-        const unsigned long long fw = mclf_load_u64(f.sync + 1);
+        unsigned long long fw;
+        while ((((fw = mclf_load_u64(f.sync + 1 + wave)) >> 32) & 1ull) == 0ull) __builtin_amdgcn_s_sleep(1);
 #ifdef MCLF_STAMPS
         if (tid == 0) f.state->xstamps[4] = MCLF_NOW();
 #endif
-        const float first = __uint_as_float((unsigned int)(wave ? fw >> 32 : fw));
+        const float first = __uint_as_float((unsigned int)fw);
         const mclf_stage mine = MCLF_STAGE(wave);
         const float v = mclf_chain(f, staged ? &mine : nullptr, wave ? ntab[1] : ntab[0], wave, S, first, lane, stats);
         if (lane == 0) { sm.xy[wave] = v; for (int k = 0; k < 4; ++k) sm.stats[4 * wave + k] = stats[k]; }
@@ -1457,9 +1466,8 @@ __device__ __forceinline__ void mclf_pose(const mcl_finish_args& f, mclf_smem& s
         f.state->pose = p;
         if (publish) {
             // another workgroup of this launch (the map update) is waiting for x and y: f.sync[3] / [4], which that workgroup clears
-            mclf_store_u64(f.sync + 3, (unsigned long long)__float_as_uint(p.x) | ((unsigned long long)__float_as_uint(p.y) << 32));
-            mclf_drain_stores();
-            mclf_store_u64(f.sync + 4, 1ull);
+            mclf_store_u64(f.sync + 3, (unsigned long long)__float_as_uint(p.x) | (1ull << 32));
+            mclf_store_u64(f.sync + 4, (unsigned long long)__float_as_uint(p.y) | (1ull << 32));
         }
         for (int k = 0; k < 5; ++k) f.state->sums_used[k] = tot[k];
         for (int k = 0; k < 8; ++k) f.state->chain_stats[k] = sm.stats[k];
