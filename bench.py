@@ -224,7 +224,7 @@ def streaming_kernels(ctx, grid, planner, aplanner, pose_dev, goal_pose, W, H):
     wide = W >= 1024 and W % 16 == 0
     tall = H >= 512 and W >= 256 and W % 2 == 0
     spec = [("k_dist_rows_wide" if wide else "k_dist_rows", _capi.BL_K_DIST_ROWS, 3.0 * cells),             # int8 in, uint16 out
-            ("k_dist_cols_summary", _capi.BL_K_DIST_COLS_SUMMARY, 2.0 * cells),                           # uint16 in
+            ("k_dist_cols_summary+carry", _capi.BL_K_DIST_COLS_SUMMARY, 2.0 * cells),                     # uint16 in (+ 1 MB of strip summaries)
             ("k_dist_cols_apply" if tall else "k_dist_cols", _capi.BL_K_DIST_COLS_APPLY, 4.0 * cells),   # uint16 in; uint16 out
             ("k_planner_snapshot", _capi.BL_K_SNAPSHOT, 2.0 * cells)]                                     # int8 in, int8 out
     out = {}

@@ -352,7 +352,8 @@ __global__ __launch_bounds__(DCOL_TX * DCOL_TY) void k_dist_cols(dist_batch db, 
 // strip"; 64 lanes x 2 columns, 16 thread rows x 8 rows, everything a thread touches stays in registers):
 //   k_dist_cols_summary  per macro strip and column: distance to the nearest source inside the strip, seen from its last
 //                        row (downward chain) and from its first row (upward chain)             -- reads `row` once
-//   k_dist_cols_apply    chains the summaries of the strips above / below into the carry entering this strip, then the
+//   k_dist_cols_carry    (grids up to 4096 rows) per column the summaries turned into the carries entering each strip
+//   k_dist_cols_apply    takes the carry entering its strip (or chains the other strips' summaries itself), then the
 //                        same down / up passes as k_dist_cols                                   -- reads `row` once
 // 4 B read + 10 B written per cell instead of 6 + 12, and (W / 128) x (H / 128) workgroups.
 #define DC2_TX 64
@@ -416,6 +417,44 @@ __global__ __launch_bounds__(DC2_TX * DC2_TY) void k_dist_cols_summary(dist_batc
     }
 }
 
+// Between the two: the summaries of a column's macro strips turned, in place, into the carries ENTERING each strip -- sum_f[m] =
+// distance at the last row of strip m - 1 seen from above (the downward chain through strips 0 .. m - 1), sum_b[m] = distance at
+// the first row of strip m + 1 seen from below.  A thread per column, every summary of the column requested before the chains
+// run (up to DC2_STAGE strips: grids up to 4096 rows).  1 MB at 4096^2; with it k_dist_cols_apply reads two values per column
+// instead of staging 32 KB of other strips' summaries per workgroup and chaining through them in every thread.
+__global__ __launch_bounds__(256) void k_dist_cols_carry(dist_batch db, int W, int H)
+{
+    int* __restrict__ sum_f = db.sum_f[blockIdx.z];
+    int* __restrict__ sum_b = db.sum_b[blockIdx.z];
+    const int x = blockIdx.x * 256 + threadIdx.x;
+    const int nmacro = (H + DC2_ROWS - 1) / DC2_ROWS;
+    if (x >= W) return;
+    int f[DC2_STAGE], b[DC2_STAGE];
+#pragma unroll
+    for (int m = 0; m < DC2_STAGE; ++m) {
+        f[m] = DIST_INF; b[m] = DIST_INF;
+        if (m < nmacro) { f[m] = sum_f[(size_t)m * W + x]; b[m] = sum_b[(size_t)m * W + x]; }
+    }
+    int e = DIST_INF;
+#pragma unroll
+    for (int m = 0; m < DC2_STAGE; ++m)
+        if (m < nmacro) {
+            const int len = min(H, (m + 1) * DC2_ROWS) - m * DC2_ROWS;
+            sum_f[(size_t)m * W + x] = min(e, DIST_INF);
+            e = min(f[m], e + len);
+        }
+    int c = DIST_INF;
+#pragma unroll
+    for (int m = DC2_STAGE - 1; m >= 0; --m)
+        if (m < nmacro) {
+            const int len = min(H, (m + 1) * DC2_ROWS) - m * DC2_ROWS;
+            sum_b[(size_t)m * W + x] = min(c, DIST_INF);
+            c = min(b[m], c + len);
+        }
+}
+
+// CARRIED: sum_f / sum_b hold the carries entering each strip (k_dist_cols_carry ran); otherwise the strips' summaries
+template <bool CARRIED>
 __global__ __launch_bounds__(DC2_TX * DC2_TY) void k_dist_cols_apply(dist_batch db, int W, int H)
 {
     const uint16_t* __restrict__ row = db.row[blockIdx.z];
@@ -446,8 +485,13 @@ __global__ __launch_bounds__(DC2_TX * DC2_TY) void k_dist_cols_apply(dist_batch 
     for (int c = 0; c < 2; ++c) { s_f[ty][2 * tx + c] = a_f[c]; s_b[ty][2 * tx + c] = a_b[c]; }
     // The other strips' summaries of this workgroup's 128 columns, staged in LDS with every load in flight at once: chained
     // straight from memory they were up to 2 x 31 dependent L2 round trips per thread -- 20 of the kernel's 45 us at 4096^2.
-    __shared__ int s_sf[DC2_STAGE][2 * DC2_TX], s_sb[DC2_STAGE][2 * DC2_TX];
-    const bool staged = nmacro <= DC2_STAGE;
+    __shared__ int s_sf[CARRIED ? 1 : DC2_STAGE][2 * DC2_TX], s_sb[CARRIED ? 1 : DC2_STAGE][2 * DC2_TX];
+    const bool staged = !CARRIED && nmacro <= DC2_STAGE;
+    int2 cf = make_int2(DIST_INF, DIST_INF), cb = make_int2(DIST_INF, DIST_INF);
+    if (CARRIED && live) {                                      // (x is even, W is even: one 8-byte load per array)
+        cf = *(const int2*)(sum_f + (size_t)blockIdx.y * W + x);
+        cb = *(const int2*)(sum_b + (size_t)blockIdx.y * W + x);
+    }
     if (staged) {
         const int t = ty * DC2_TX + tx;
         for (int i = t; i < nmacro * 2 * DC2_TX; i += DC2_TX * DC2_TY) {
@@ -463,6 +507,8 @@ __global__ __launch_bounds__(DC2_TX * DC2_TY) void k_dist_cols_apply(dist_batch 
     for (int c = 0; c < 2; ++c) {
         // carry entering the macro strip from above (distance at row Y0 - 1) and from below (distance at row Y1)
         int e = DIST_INF, b = DIST_INF;
+        if (CARRIED) { e = c ? cf.y : cf.x; b = c ? cb.y : cb.x; }
+        else {
         for (int m = 0; m < (int)blockIdx.y; ++m) {
             const int len = min(H, (m + 1) * DC2_ROWS) - m * DC2_ROWS;
             e = min(staged ? s_sf[m][2 * tx + c] : sum_f[(size_t)m * W + x + c], e + len);
@@ -470,6 +516,7 @@ __global__ __launch_bounds__(DC2_TX * DC2_TY) void k_dist_cols_apply(dist_batch 
         for (int m = nmacro - 1; m > (int)blockIdx.y; --m) {
             const int len = min(H, (m + 1) * DC2_ROWS) - m * DC2_ROWS;
             b = min(staged ? s_sb[m][2 * tx + c] : sum_b[(size_t)m * W + x + c], b + len);
+        }
         }
         // ... then through the thread rows above / below this one inside the strip
         for (int s = 0; s < ty; ++s) {
@@ -984,11 +1031,15 @@ static int dist_set_distances_batch(int n, bl_dist* const* ds, const bl_grid* co
             rc = bl_timer_begin(ctx, BL_K_DIST_COLS_SUMMARY, &f0, &f1);
             if (rc) return rc;
             hipLaunchKernelGGL(k_dist_cols_summary, grid2, dim3(DC2_TX, DC2_TY), 0, ctx->stream, b, W, H);
+            const bool carried = (H + DC2_ROWS - 1) / DC2_ROWS <= DC2_STAGE;
+            // (the small carry kernel is timed with the summaries it turns into carries)
+            if (carried) hipLaunchKernelGGL(k_dist_cols_carry, dim3((W + 255) / 256, 1, n), dim3(256), 0, ctx->stream, b, W, H);
             rc = bl_timer_end(ctx, BL_K_DIST_COLS_SUMMARY, f0, f1);
             if (rc) return rc;
             rc = bl_timer_begin(ctx, BL_K_DIST_COLS_APPLY, &f0, &f1);
             if (rc) return rc;
-            hipLaunchKernelGGL(k_dist_cols_apply, grid2, dim3(DC2_TX, DC2_TY), 0, ctx->stream, b, W, H);
+            if (carried) hipLaunchKernelGGL(k_dist_cols_apply<true>, grid2, dim3(DC2_TX, DC2_TY), 0, ctx->stream, b, W, H);
+            else hipLaunchKernelGGL(k_dist_cols_apply<false>, grid2, dim3(DC2_TX, DC2_TY), 0, ctx->stream, b, W, H);
             rc = bl_timer_end(ctx, BL_K_DIST_COLS_APPLY, f0, f1);
             if (rc) return rc;
         } else {

@@ -126,7 +126,7 @@ def collect_streaming():
     trace, HBM bytes from the two counter passes, beside the bytes the kernel has to move."""
     script = os.path.join("tests", "tools", "stream_kernels_probe.py")
     S, N = 4096 * 4096, 1_000_000
-    alg = {"k_planner_snapshot": 2 * S, "k_dist_rows_wide": 3 * S, "k_dist_cols_summary": 2 * S, "k_dist_cols_apply": 4 * S,
+    alg = {"k_planner_snapshot": 2 * S, "k_dist_rows_wide": 3 * S, "k_dist_cols_summary": 2 * S, "k_dist_cols_carry": 4 * 32 * 4096 * 4, "k_dist_cols_apply": 4 * S,
            "k_dist_floats": 6 * S, "k_pf_export": 88 * N, "k_pf_encode_lcm": 80 * N, "k_scan_tile_sums": 16 * N, "k_scan_finish_prefix": 24 * N}
     db, _ = run(["--kernel-trace", "--stats"], "stream_stats", [], script)
     dur = {}
@@ -149,10 +149,11 @@ def collect_streaming():
         w = csv.writer(f)
         w.writerow(["kernel", "launches", "avg_ns", "min_ns", "algorithmic_bytes", "algorithmic_GBps_at_avg", "frac_of_8TBps", "hbm_bytes_counters", "counters_over_algorithmic"])
         for k, a in alg.items():
-            if k not in dur:
+            names = [nm for nm in dur if k in nm]           # (a template instance is "void k<...>")
+            if not names:
                 continue
-            n, avg, mn = dur[k]
-            c = per.get(k, {})
+            n, avg, mn = dur[names[0]]
+            c = per.get(names[0], {})
             hb = (2.0 * c.get("FETCH_SIZE", 0.0) + c.get("WRITE_SIZE", 0.0)) * 1024.0 if len(c) == 2 else None
             w.writerow([k, n, "%.0f" % avg, mn, a, "%.1f" % (a / avg), "%.3f" % (a / avg / 8000.0), "%.0f" % hb if hb else "", "%.3f" % (hb / a) if hb else ""])
 
