@@ -122,6 +122,7 @@ SIGNATURES = {
     "bl_comm_destroy": (None, [_vp]),
     "bl_comm_all_gather_inplace": (C.c_int, [_vp, _vp, C.c_size_t]),
     "bl_dev_alloc": (C.c_int, [_vp, C.c_size_t, _P(_vp)]),
+    "bl_dev_word": (C.c_int, [_vp, _vp, C.c_int, _P(C.c_uint32)]),
     "bl_dev_free": (C.c_int, [_vp]),
     "bl_ipc_export": (C.c_int, [_vp, C.c_char_p]),
     "bl_ipc_open": (C.c_int, [C.c_char_p, _P(_vp)]),

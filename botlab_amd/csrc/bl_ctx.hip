@@ -423,6 +423,28 @@ extern "C" int bl_dev_free(void* p)
     return BL_OK;
 }
 
+// One 32-bit word of device memory written (write != 0) or read by a KERNEL of this context's device -- the access the particle
+// filter's kernels make to another rank's arrays: a mapping that opens but cannot be read this way must not be trusted.
+__global__ void k_dev_word(unsigned int* p, int write, unsigned int v, unsigned int* out)
+{
+    if (write) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    else *out = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+extern "C" int bl_dev_word(bl_ctx* ctx, void* dev_ptr, int write, uint32_t* value)
+{
+    BL_CHECK_ARG(ctx != nullptr && dev_ptr != nullptr && value != nullptr);
+    BL_HIP(hipSetDevice(ctx->device));
+    unsigned int* out = nullptr;
+    BL_HIP(hipMalloc((void**)&out, sizeof(unsigned int)));
+    hipLaunchKernelGGL(k_dev_word, dim3(1), dim3(1), 0, ctx->stream, (unsigned int*)dev_ptr, write, (unsigned int)*value, out);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess && !write) e = hipMemcpyAsync(value, out, sizeof(unsigned int), hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    (void)hipFree(out);
+    if (e != hipSuccess) { bl_set_error("bl_dev_word: %s", hipGetErrorString(e)); return BL_ERR_HIP; }
+    return BL_OK;
+}
+
 // ---------------------------------------------------------------- grid lineage + dirty log (bl_internal.h)
 #include <atomic>
 static std::atomic<uint64_t> g_next_lineage{1};

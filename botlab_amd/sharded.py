@@ -165,15 +165,19 @@ def ipc_probe(ctx, rank, world, group=None):
     before it makes the engines, because the composed form fixes other shard bounds than the replicated one."""
     lib = ctx.lib
     ok, handle, p = True, None, C.c_void_p()
+    def word_of(r):                                  # what rank r leaves in its probe buffer
+        return (0x9E3779B1 * (r + 1)) & 0xFFFFFFFF
+
     try:
         check(lib.bl_dev_alloc(ctx.h, 4096, C.byref(p)))
+        check(lib.bl_dev_word(ctx.h, p, 1, C.byref(C.c_uint32(word_of(rank)))))
         buf = C.create_string_buffer(64)
         check(lib.bl_ipc_export(p, buf))
         handle = bytes(buf.raw)
     except Exception:                                # noqa: BLE001
         ok = False
     gathered = [None] * world
-    dist.all_gather_object(gathered, handle, group=group)
+    dist.all_gather_object(gathered, handle, group=group)       # (behind every rank's write: bl_dev_word synchronises)
     opened = []
     if ok and all(h is not None for h in gathered):
         for r, h in enumerate(gathered):
@@ -184,6 +188,10 @@ def ipc_probe(ctx, rank, world, group=None):
                 ok = False
                 break
             opened.append(q)
+            got = C.c_uint32(0)                      # ... and a kernel of THIS device reads what the owner wrote
+            if lib.bl_dev_word(ctx.h, q, 0, C.byref(got)) != 0 or got.value != word_of(r):
+                ok = False
+                break
     else:
         ok = False
     dev = "cpu" if dist.get_backend(group) != "nccl" else torch.device("cuda", ctx.device)

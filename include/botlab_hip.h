@@ -279,6 +279,7 @@ int bl_comm_all_gather_inplace(bl_comm* c, void* rec, size_t per_rank_floats);
  * ranks' reads of its memory: every rank must run them, on the filter's stream. */
 int bl_dev_alloc(bl_ctx* ctx, size_t bytes, void** out);     /* plain zeroed device memory (the probe of botlab_amd/sharded.py) */
 int bl_dev_free(void* dev_ptr);
+int bl_dev_word(bl_ctx* ctx, void* dev_ptr, int write, uint32_t* value);   /* one word written / read by a kernel of ctx's device (the probe: a peer mapping must be readable by kernels) */
 int bl_ipc_export(const void* dev_ptr, char* out_handle64);
 int bl_ipc_open(const char* handle64, void** out_dev_ptr);
 int bl_ipc_close(void* dev_ptr);
