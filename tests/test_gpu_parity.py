@@ -631,6 +631,49 @@ def test_step_pipeline_with_device_pose_equals_host_pose_path(oracle, maps, gpu_
     assert max(len(r[1]) for r in out[0][0]) > 3
 
 
+def test_step_pipeline_batched32_equals_synchronous_steps(maps, gpu_ctx):
+    """A replanner lane that collects 32 submissions per launch (bench.py's presets for the large grids: 3 x 32 searches in flight):
+    40 steps with the filter's end riding in the map kernel, the first launch a full batch of 32 and the rest flushed by the drain,
+    give the poses, paths and map of the call-by-call device-pose form."""
+    m = maps["obstacle_slam_10mx10m_5cm"]
+    truth = np.where(m["cells"] > 0, 127, -127).astype(np.int8)
+    n = 40
+    poses = synth.square_trajectory((-0.75, 0.2, 0.0), n, step_len=0.02, turn=0.05, side=0.8)
+    scans = [synth.raycast_scan(truth, m["origin"], 0.05, poses[k - 1], poses[k], 1_000_000 + k * 100_000) for k in range(1, n + 1)]
+    goal = bl.make_pose(-0.35, 0.2, 0.0)
+    out = []
+    for form in ("sync", "batched32", "batched32x2"):
+        g = _grid_from_map(m, gpu_ctx)
+        pf = bl.ParticleFilter(2000, ctx=gpu_ctx)
+        pf.initializeFilterAtPose(bl.make_pose(-0.75, 0.2, 0.0, utime=int(scans[0].times[0])), seed=5)
+        pf.setNoiseSeed(9)
+        mapper = bl.Mapping(5.0, 4, 1, ctx=gpu_ctx)
+        planner = bl.MotionPlanner(ctx=gpu_ctx)
+        aplanner = bl.AsyncPlanner(ctx=gpu_ctx, lanes=1 if form == "batched32" else 2, batch=32) if form != "sync" else None
+        rec = []
+        for k, sc in enumerate(scans):
+            odo = bl.make_pose(*poses[k + 1], utime=sc.utime)
+            if aplanner is None:
+                pf.updateFilter(odo, sc, g, rand_value=1000 + k, want_pose=False)
+                mapper.updateMapDevicePose(sc, pf.poseDevicePtr(), sc.utime, g)
+                planner.setMap(g)
+                bl.search_for_path_begin(goal, planner.distances_, planner.searchParams_, start_dev=pf.poseDevicePtr())
+                path = bl.search_for_path_end(planner.distances_)
+                rec.append(((path[0].utime, path[0].x, path[0].y, path[0].theta), [(p.x, p.y, p.theta) for p in path]))
+            else:
+                pf.updateBegin(odo, sc, g, 1000 + k)
+                aplanner.submit_with_map_update_finishing(mapper, sc, pf, sc.utime, g, goal)
+        if aplanner is not None:
+            for _ in scans:                                       # every result, in submission order
+                path = aplanner.fetch()
+                rec.append(((path[0].utime, path[0].x, path[0].y, path[0].theta), [(p.x, p.y, p.theta) for p in path]))
+        out.append((rec, g.cells().copy()))
+    for o in out[1:]:
+        assert o[0] == out[0][0]
+        assert np.array_equal(o[1], out[0][1])
+    assert max(len(r[1]) for r in out[0][0]) > 3
+
+
 @pytest.mark.parametrize("N,rays", [(1000, 290), (100_000, 290), (300_000, 290), (3000, 1500)])
 def test_filter_end_riding_in_map_kernel_equals_separate_calls(maps, gpu_ctx, N, rays):
     """bl_mapping_update_finishing_pf: updateFilter's end (weight prefix, unit total, pose estimate) computed inside the map
