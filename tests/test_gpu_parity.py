@@ -52,7 +52,8 @@ def test_distance_grid_reference_test_grid(oracle, gpu_ctx):
                                    (70, 12304),       # ... three chunks plus a ragged fourth (12304 = 3 * 4096 + 16)
                                    (600, 1040),       # large-grid column pass, last macro strip partial (600 = 4 * 128 + 88)
                                    (1029, 1024),      # ... one row into the ninth macro strip
-                                   (515, 1026)])      # W not a multiple of 16: wide rows off, large-grid column pass on
+                                   (515, 1026),       # W not a multiple of 16: wide rows off, large-grid column pass on
+                                   (4230, 512)])      # more than 32 macro strips: no carry kernel, the apply kernel chains the summaries itself
 def test_distance_grid_ragged_shapes(oracle, gpu_ctx, shape):
     rng = np.random.default_rng(shape[0] * 1000 + shape[1])
     h, w = shape
