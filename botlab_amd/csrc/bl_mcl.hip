@@ -2023,8 +2023,12 @@ extern "C" int bl_pf_update_action_only(bl_pf* pf, const bl_pose_xyt_t* odometry
 extern "C" int bl_pf_pose_estimate(bl_pf* pf, bl_pose_xyt_t* out_pose)
 {
     BL_CHECK_ARG(pf != nullptr && out_pose != nullptr && pf->state != nullptr);
-    BL_HIP(hipMemcpyAsync(out_pose, &pf->state->pose, sizeof(bl_pose_xyt_t), hipMemcpyDeviceToHost, pf->ctx->stream));
+    struct { bl_pose_xyt_t pose; unsigned int wait_timeouts; } h;
+    static_assert(offsetof(pf_state, wait_timeouts) == offsetof(pf_state, pose) + sizeof(bl_pose_xyt_t), "the counter is read with the pose");
+    BL_HIP(hipMemcpyAsync(&h, &pf->state->pose, sizeof(h), hipMemcpyDeviceToHost, pf->ctx->stream));
     BL_HIP(hipStreamSynchronize(pf->ctx->stream));
+    *out_pose = h.pose;
+    if (h.wait_timeouts != 0) { bl_set_error("a wait inside a finish launch gave up (%u): the estimate is not valid", h.wait_timeouts); return BL_ERR_STATE; }
     return BL_OK;
 }
 

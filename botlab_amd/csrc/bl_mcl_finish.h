@@ -32,6 +32,7 @@
 struct pf_state {
     double S;                 // total weight units of rec[cur]
     bl_pose_xyt_t pose;       // posteriorPose_
+    unsigned int wait_timeouts;    // waits inside a finish launch that ran into MCLF_SPIN_LIMIT (never, unless a launch lost workgroups); read with the pose
     double sums_used[5];      // units, -, -, units*sin, units*cos the estimate was formed from (diagnostic)
     unsigned int chain_stats[8];   // x then y: generic replays, their phases, table replays, gaps walked the slow way (diagnostic)
     unsigned int lookahead[2];     // map updates that ran ahead of the exact pose; of those, the ones that had to run again (diagnostic)
@@ -104,6 +105,7 @@ struct mcl_finish_args {
 #define MCLF_EXTRA_WGS 2                      // workgroups of the launch in front of the groups: finisher, pre-chain
 #define MCLF_PRE_STEPPED 2                    // ... the first of them term by term (a binade change every few terms), the others in-binade
 #define MCLF_TAB_WAVES 4                      // waves of the finisher that fetch tables while the others join gaps (four tables per wave and trip)
+#define MCLF_SPIN_LIMIT (1u << 20)               // polls (~1.3 us each) after which a wait inside the launch gives up: ~1.4 s
 #define MCLF_SYNC_WORDS 8                     // words of the sync block (one 64-byte line; five in use)
 #define MCLF_LDS_BYTES (112 * 1024)           // scratch the finisher wants (the map kernel's counter window serves)
 
@@ -1076,9 +1078,11 @@ __device__ __forceinline__ bl_pose_xyt_t mclf_approx_pose(const double (&tot)[5]
 __device__ __forceinline__ void mclf_wait_pose(const mcl_finish_args& f, float* x, float* y)
 {
     unsigned long long wx, wy;
+    unsigned int spins = 0;
     while (true) {                                   // (both words requested together; each says by itself that it is there)
         wx = mclf_load_u64(f.sync + 3); wy = mclf_load_u64(f.sync + 4);
         if (((wx & wy) >> 32) & 1ull) break;
+        if (++spins > MCLF_SPIN_LIMIT) { atomicAdd(&f.state->wait_timeouts, 1u); break; }    // (every wait of the launch has an end)
         __builtin_amdgcn_s_sleep(1);
     }
     *x = __uint_as_float((unsigned int)wx);
@@ -1319,6 +1323,7 @@ __device__ __forceinline__ void mclf_pose(const mcl_finish_args& f, mclf_smem& s
                 }
             }
             ss_rec rr[4];
+            unsigned int spins = 0;
             while (true) {
                 int4 q[4];
                 asm volatile("global_load_dwordx4 %0, %4, off sc1\n\tglobal_load_dwordx4 %1, %5, off sc1\n\t"
@@ -1333,6 +1338,7 @@ __device__ __forceinline__ void mclf_pose(const mcl_finish_args& f, mclf_smem& s
                     late |= mine[u] && poll && !current;
                 }
                 if (__builtin_amdgcn_ballot_w64(late) == 0ull) break;
+                if (++spins > MCLF_SPIN_LIMIT) { if (lane == 0) atomicAdd(&f.state->wait_timeouts, 1u); break; }
                 __builtin_amdgcn_s_sleep(1);
             }
 #ifdef MCLF_STAMPS
@@ -1440,7 +1446,11 @@ __device__ __forceinline__ void mclf_pose(const mcl_finish_args& f, mclf_smem& s
         unsigned int stats[4] = {0, 0, 0, 0};
         // the sums behind the first sub-tiles, from the pre-chain workgroup (long done by now, as a rule)
         unsigned long long fw;
-        while ((((fw = mclf_load_u64(f.sync + 1 + wave)) >> 32) & 1ull) == 0ull) __builtin_amdgcn_s_sleep(1);
+        unsigned int spins = 0;
+        while ((((fw = mclf_load_u64(f.sync + 1 + wave)) >> 32) & 1ull) == 0ull) {
+            if (++spins > MCLF_SPIN_LIMIT) { if (lane == 0) atomicAdd(&f.state->wait_timeouts, 1u); break; }
+            __builtin_amdgcn_s_sleep(1);
+        }
 #ifdef MCLF_STAMPS
         if (tid == 0) f.state->xstamps[4] = MCLF_NOW();
 #endif
