@@ -87,6 +87,7 @@ SIGNATURES = {
     "bl_pf_pose_device_ptr": (_vp, [_vp]),
     "bl_pf_estimate_posterior_pose": (C.c_int, [_vp, _vp]),
     "bl_pf_debug_estimate_stats": (C.c_int, [_vp, _vp]),
+    "bl_pf_debug_set_finish_generation": (C.c_int, [_vp, C.c_uint32]),
     "bl_pf_set_strict_resampling": (C.c_int, [_vp, C.c_int]),
     "bl_pf_debug_resample": (C.c_int, [_vp, C.c_int, _vp]),
     "bl_pf_debug_enable": (C.c_int, [_vp, C.c_int]),

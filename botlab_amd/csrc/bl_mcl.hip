@@ -2089,6 +2089,15 @@ extern "C" int bl_pf_debug_estimate_stats(bl_pf* pf, uint32_t* out4)   /* eight 
     return BL_OK;
 }
 
+// The generation the NEXT finish launch's records are tagged with follows from this one (tests: the tag's wrap-around, where the
+// host skips the generations whose tag reads like zeroed slots)
+extern "C" int bl_pf_debug_set_finish_generation(bl_pf* pf, uint32_t generation)
+{
+    BL_CHECK_ARG(pf != nullptr);
+    pf->fin_gen = generation;
+    return BL_OK;
+}
+
 // Strict resampling on / off.  Takes effect with the next prefix the filter forms (an update's end, an upload of particles,
 // initializeFilterAtPose); switching it on for a filter that already holds particles re-forms the prefix at once.
 extern "C" int bl_pf_set_strict_resampling(bl_pf* pf, int on)

@@ -159,6 +159,7 @@ int bl_pf_estimate_posterior_pose(bl_pf* pf, bl_pose_xyt_t* out_pose);
 /* diagnostics of the last estimate, eight values: for the x sum, then for the y sum -- sub-tiles replayed generically, phases
  * of those replays, sub-tiles stepped through by their table, gaps walked the slow way (bl_serial_sum.h, bl_mcl_finish.h) */
 int bl_pf_debug_estimate_stats(bl_pf* pf, uint32_t* out8);
+int bl_pf_debug_set_finish_generation(bl_pf* pf, uint32_t generation);   /* tests: the record tags of the finish launches wrap every 256 launches */
 /* Strict resampling (off by default).  The update's resampler normally compares U_m * S with an exact integer prefix of the
  * weight units; the reference (particle_filter.cpp:84-103) compares U_m with a sequentially rounded double sum of the
  * normalised weights.  The two agree unless U_m falls within that sum's rounding error of a partial sum -- measured: never for

@@ -117,3 +117,31 @@ def test_estimate_worst_case_is_bounded(oracle, gpu_ctx, N, limit_us, centre):
     with open(os.path.join("gpurun_out", f"estimate_worst_{N}_{centre[0]}_{centre[1]}.json"), "w") as fh:
         json.dump({"particles": N, "centre": centre, "spread": 0.05, "us_per_estimate": us, "limit_us": limit_us}, fh)
     assert us <= limit_us, (N, centre, us)
+
+
+def test_estimate_across_the_record_tag_wrap(oracle, gpu_ctx):
+    """The finisher takes a record when both of its halves carry the launch's generation tag (8 bits + 2 bits); the host skips the
+    generations whose tag would read like zeroed slots.  Estimates stay bit-equal across the wrap (.. 254, 255, 257, 258 ..) and
+    far out in the generation count (the 32-bit counter's own wrap)."""
+    N = 20_000
+    rng = np.random.default_rng(11)
+    p = np.zeros(N, PARTICLE_DTYPE)
+    pf = bl.ParticleFilter(N, ctx=gpu_ctx)
+    try:
+        for start in (250, 0xFFFFFFF8):
+            check = gpu_ctx.lib.bl_pf_debug_set_finish_generation(pf.h, start)
+            assert check == 0
+            for k in range(12):
+                p["x"] = (-0.75 + 0.02 * rng.standard_normal(N)).astype(np.float32)
+                p["y"] = (0.2 * (k - 5) + 0.02 * rng.standard_normal(N)).astype(np.float32)
+                p["theta"] = (0.1 * rng.standard_normal(N)).astype(np.float32)
+                pf.setParticles(p, (1000 * rng.integers(1, 400, N)).astype(np.uint32))
+                est = pf.estimatePosteriorPose()
+                got = pf.particles()
+                want = oracle_lib.OPose()
+                oracle.lib.orc_estimate_pose(np.ascontiguousarray(got).ctypes.data, N, C.byref(want))
+                a = np.array([est.x, est.y], np.float32).view(np.uint32)
+                b = np.array([want.x, want.y], np.float32).view(np.uint32)
+                assert np.array_equal(a, b), (start, k, (est.x, est.y), (want.x, want.y))
+    finally:
+        pf.close()
