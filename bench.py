@@ -260,7 +260,7 @@ def main():
                     "(distance grid + A*, ~0.4 ms) spans several steps and a lane sends its batch off when it is full, so fewer than "
                     "~lanes x batch + 2 leaves the SLAM stream waiting for the host")
     ap.add_argument("--lanes", type=int, default=2, help="replanner streams: consecutive replans run concurrently (1..4)")
-    ap.add_argument("--batch", type=int, default=4, help="replans a lane collects and searches in one launch (1..32): lanes x batch "
+    ap.add_argument("--batch", type=int, default=4, help="replans a lane collects and searches in one launch (1..64): lanes x batch "
                     "searches overlap; for grids where a search outlasts several steps (use with --depth >= lanes x batch)")
     ap.add_argument("--config", type=int, default=0, choices=[0, 2, 3, 4, 5],
                     help="BASELINE.json configs[i - 1] as a preset (0/2: the default, configs[1]; 3: 1M-particle MCL, no replan; "
@@ -270,7 +270,7 @@ def main():
     ap.add_argument("--other-steps", type=int, default=1000, help="timed steps of each other_configs run")
     args = ap.parse_args()
     presets = {3: dict(particles=1_000_000, no_astar=True, map="convex_10mx10m_5cm"),     # slam.cpp:36-45: --localization-only <map>
-               4: dict(grid=2000, lanes=3, batch=32, depth=128),
+               4: dict(grid=2000, lanes=3, batch=64, depth=256),
                5: dict(grid=4096, particles=256_000, lanes=3, batch=16, depth=64)}
     for key, val in presets.get(args.config, {}).items():
         if getattr(args, key) == ap.get_default(key):

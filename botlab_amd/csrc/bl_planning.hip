@@ -1205,7 +1205,7 @@ struct bl_astar_state {
 #define ASTAR_HDR 256
 static_assert(sizeof(astar_result) <= ASTAR_HDR, "result record must fit the header of the output buffer");
 
-#define ASTAR_MAX_UNITS 32
+#define ASTAR_MAX_UNITS 64
 struct astar_unit {
     const uint16_t* l1; const int32_t* cost_lut; int2* heap; int32_t* closed; int32_t* path; astar_result* result;
     const bl_pose_xyt_t* start_dev; bl_pose_xyt_t start_host; int sx, sy, gx, gy;
@@ -2290,8 +2290,11 @@ static int planner_launch_lane(bl_planner* p, int l)
         BL_HIP(hipStreamWaitEvent(L.side->stream, L.unit[0].snap_ready[slot], 0));
         bl_dist* bd[PLANNER_MAX_BATCH]; const bl_grid* bm[PLANNER_MAX_BATCH];
         for (int u = 0; u < L.filled; ++u) { bd[u] = L.unit[u].dist; bm[u] = L.unit[u].snap[slot]; }
-        int rc = dist_set_distances_batch(L.filled, bd, bm);
-        if (rc) return rc;
+        // (the transform's kernels take their grids' pointers by value: DIST_MAX_BATCH of them per launch)
+        for (int u0 = 0; u0 < L.filled; u0 += DIST_MAX_BATCH) {
+            const int rc = dist_set_distances_batch(L.filled - u0 < DIST_MAX_BATCH ? L.filled - u0 : DIST_MAX_BATCH, bd + u0, bm + u0);
+            if (rc) return rc;
+        }
     }
     bl_ctx* ctxs[PLANNER_MAX_BATCH]; bl_dist* dists[PLANNER_MAX_BATCH]; const void* starts[PLANNER_MAX_BATCH];
     bl_pose_xyt_t goals[PLANNER_MAX_BATCH]; bl_search_params_t params[PLANNER_MAX_BATCH];

@@ -633,7 +633,7 @@ def test_step_pipeline_with_device_pose_equals_host_pose_path(oracle, maps, gpu_
 
 
 def test_step_pipeline_batched32_equals_synchronous_steps(maps, gpu_ctx):
-    """A replanner lane that collects 32 submissions per launch (bench.py's presets for the large grids: 3 x 32 searches in flight):
+    """A replanner lane that collects 32 or 64 submissions per launch (bench.py's presets for the large grids: up to 3 x 64 searches in flight):
     40 steps with the filter's end riding in the map kernel, the first launch a full batch of 32 and the rest flushed by the drain,
     give the poses, paths and map of the call-by-call device-pose form."""
     m = maps["obstacle_slam_10mx10m_5cm"]
@@ -643,14 +643,14 @@ def test_step_pipeline_batched32_equals_synchronous_steps(maps, gpu_ctx):
     scans = [synth.raycast_scan(truth, m["origin"], 0.05, poses[k - 1], poses[k], 1_000_000 + k * 100_000) for k in range(1, n + 1)]
     goal = bl.make_pose(-0.35, 0.2, 0.0)
     out = []
-    for form in ("sync", "batched32", "batched32x2"):
+    for form in ("sync", "batched32", "batched32x2", "batched64"):       # (64: one launch of 40 searches, the distance grids in two)
         g = _grid_from_map(m, gpu_ctx)
         pf = bl.ParticleFilter(2000, ctx=gpu_ctx)
         pf.initializeFilterAtPose(bl.make_pose(-0.75, 0.2, 0.0, utime=int(scans[0].times[0])), seed=5)
         pf.setNoiseSeed(9)
         mapper = bl.Mapping(5.0, 4, 1, ctx=gpu_ctx)
         planner = bl.MotionPlanner(ctx=gpu_ctx)
-        aplanner = bl.AsyncPlanner(ctx=gpu_ctx, lanes=1 if form == "batched32" else 2, batch=32) if form != "sync" else None
+        aplanner = bl.AsyncPlanner(ctx=gpu_ctx, lanes=2 if form == "batched32x2" else 1, batch=64 if form == "batched64" else 32) if form != "sync" else None
         rec = []
         for k, sc in enumerate(scans):
             odo = bl.make_pose(*poses[k + 1], utime=sc.utime)
