@@ -256,11 +256,11 @@ def main():
     ap.add_argument("--goal-l1", type=int, default=40, help="without --goal on a non-default grid: max L1 distance (cells) "
                     "of the replan goal from the start")
     ap.add_argument("--cpu-steps", type=int, default=25, help="steps of the CPU baseline sample (0 = skip)")
-    ap.add_argument("--depth", type=int, default=10, help="steps enqueued ahead of fetching a result (0 = synchronous steps); a replan "
+    ap.add_argument("--depth", type=int, default=14, help="steps enqueued ahead of fetching a result (0 = synchronous steps); a replan "
                     "(distance grid + A*, ~0.4 ms) spans several steps and a lane sends its batch off when it is full, so fewer than "
                     "~lanes x batch + 2 leaves the SLAM stream waiting for the host")
     ap.add_argument("--lanes", type=int, default=2, help="replanner streams: consecutive replans run concurrently (1..4)")
-    ap.add_argument("--batch", type=int, default=4, help="replans a lane collects and searches in one launch (1..64): lanes x batch "
+    ap.add_argument("--batch", type=int, default=6, help="replans a lane collects and searches in one launch (1..64): lanes x batch "
                     "searches overlap; for grids where a search outlasts several steps (use with --depth >= lanes x batch)")
     ap.add_argument("--config", type=int, default=0, choices=[0, 2, 3, 4, 5],
                     help="BASELINE.json configs[i - 1] as a preset (0/2: the default, configs[1]; 3: 1M-particle MCL, no replan; "
