@@ -1817,7 +1817,7 @@ extern "C" int bl_ipc_close(void* p)
 extern "C" int bl_pf_shard_setup(bl_pf* pf, int rank, int world, int block)
 {
     BL_CHECK_ARG(pf != nullptr && world >= 2 && world <= BL_MAX_SHARDS && rank >= 0 && rank < world);
-    BL_CHECK_ARG(block > 0 && block % mclf_chunk(MCLF_GT_LARGE) == 0 && block % SCAN_TILE == 0);
+    BL_CHECK_ARG(block > 0 && block % mclf_chunk(mclf_gthreads(pf->N)) == 0 && block % SCAN_TILE == 0);   // whole finish groups, whole scan tiles
     BL_CHECK_ARG(pf->lo == rank * block && pf->hi == (pf->N < (rank + 1) * block ? pf->N : (rank + 1) * block));
     BL_CHECK_ARG((int64_t)(world - 1) * block < pf->N);            // every rank owns particles
     if (pf->rec_external) { bl_set_error("a composed finish keeps its exchange records in the library's own allocations"); return BL_ERR_STATE; }

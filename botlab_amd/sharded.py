@@ -26,7 +26,14 @@ from . import host
 from ._capi import check
 
 
-COMPOSED_ALIGN = 2048       # a rank's block is whole finish groups (2 x 1024 particles) and whole scan tiles (512)
+COMPOSED_ALIGN = 2048       # a rank's block is whole finish groups (2 x 1024 particles) and whole scan tiles (512) ...
+
+
+def composed_align(num_particles):
+    """... for the particle counts whose finish runs large groups; below that (bl_mcl_finish.h: MCLF_GT_SWITCH) a group is
+    2 x 256 particles = one scan tile, and blocks of 512 let eight ranks share 100 000 particles."""
+    return COMPOSED_ALIGN if num_particles >= 160_000 else 512
+
 
 
 def shard_bounds(num_particles, rank, world, align=1):
@@ -53,7 +60,8 @@ def composed_possible(num_particles, world):
     if world < 2 or world > 8 or os.environ.get("BOTLAB_SHARD_REPLICATED"):
         return False
     S = (num_particles + world - 1) // world
-    S = (S + COMPOSED_ALIGN - 1) // COMPOSED_ALIGN * COMPOSED_ALIGN
+    a = composed_align(num_particles)
+    S = (S + a - 1) // a * a
     return (world - 1) * S < num_particles
 
 
@@ -66,7 +74,7 @@ class HipShardEngine:
     def __init__(self, num_particles, rank, world, device, composed=False):
         self.N, self.rank, self.world = num_particles, rank, world
         self.composed = bool(composed)
-        self.lo, self.hi, self.S = shard_bounds(num_particles, rank, world, COMPOSED_ALIGN if self.composed else 1)
+        self.lo, self.hi, self.S = shard_bounds(num_particles, rank, world, composed_align(num_particles) if self.composed else 1)
         self.device = torch.device("cuda", device)
         torch.cuda.set_device(self.device)
         # ONE explicit stream carries both the library's kernels and the collectives (issued under

@@ -272,7 +272,7 @@ int bl_comm_all_gather_inplace(bl_comm* c, void* rec, size_t per_rank_floats);
  * update exchanges two SMALL all-gathers -- tile sums (40 B per 512 particles), then sub-tile records + tables (32 B per 128
  * particles + 80 KB) -- before every rank runs the (replicated, ~10 us) chain of estimatePosteriorPose.  Results are the single
  * rank's, bit for bit.  Set-up, once the filter holds particles: bl_pf_shard_setup (block = particles per rank, a multiple of
- * 2048, shard = [rank * block, min(N, (rank + 1) * block)) as given to bl_pf_create); hand every rank's three arrays to every
+ * 2048 -- of 512 for fewer than 160 000 particles --, shard = [rank * block, min(N, (rank + 1) * block)) as given to bl_pf_create); hand every rank's three arrays to every
  * rank (bl_pf_shard_local_ptrs -> bl_ipc_export -> the host's transport -> bl_ipc_open -> bl_pf_shard_set_peer; a rank of the
  * same process passes the pointers themselves); bl_pf_shard_commit.  Per update: bl_pf_update_begin, bl_pf_shard_exchange (or
  * bl_pf_shard_stage(1), all-gather of the sums buffer, bl_pf_shard_stage(2), all-gather of the exchange buffer, both in place),

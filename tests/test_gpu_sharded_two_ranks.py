@@ -78,7 +78,7 @@ def _run(rank, world, port, out_dir, riding=False, composed=False, n=N):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,riding,n", [(2, False, N), (2, True, N), (3, True, N), (2, True, 200_001)])
+@pytest.mark.parametrize("world,riding,n", [(2, False, N), (2, True, N), (3, True, N), (2, True, 200_001), (4, True, 3500)])   # (3500 over four ranks: blocks of 1024, the small groups' alignment)
 def test_composed_finish_matches_single_rank(tmp_path, world, riding, n):
     """The composed finish -- own blocks only, sources read from their owners' memory, two small all-gathers -- with 2 and 3 ranks
     on one device (one process per rank, IPC mappings, collectives over gloo): particles, estimates and the replicated map equal
@@ -93,7 +93,8 @@ def test_composed_finish_matches_single_rank(tmp_path, world, riding, n):
     got = []
     for r in range(world):
         lo, hi = map(int, open(os.path.join(out, f"shard_w{world}_r{r}.txt")).read().split())
-        assert lo % 2048 == 0
+        from botlab_amd import sharded
+        assert lo % sharded.composed_align(n) == 0
         part = np.load(os.path.join(out, f"parts_w{world}_r{r}.npy"))
         assert part.size == hi - lo
         got.append(part)

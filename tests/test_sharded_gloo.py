@@ -66,9 +66,11 @@ def test_shard_bounds():
     assert sharded.shard_bounds(10, 3, 4) == (9, 10, 3)
     # the composed finish cuts at whole finish groups
     assert sharded.shard_bounds(1_000_000, 7, 8, sharded.COMPOSED_ALIGN) == (7 * 126976, 1_000_000, 126976)
-    assert sharded.shard_bounds(30001, 2, 3, sharded.COMPOSED_ALIGN) == (20480, 30001, 10240)
+    assert sharded.shard_bounds(30001, 2, 3, sharded.composed_align(30001)) == (20480, 30001, 10240)
+    assert sharded.composed_align(1_000_000) == 2048 and sharded.composed_align(100_000) == 512
+    assert sharded.composed_possible(100_000, 8) and sharded.shard_bounds(100_000, 7, 8, 512) == (89600, 100_000, 12800)
     assert sharded.composed_possible(1_000_000, 8) and sharded.composed_possible(30001, 3)
-    assert not sharded.composed_possible(601, 2) and not sharded.composed_possible(100_000, 1)
+    assert sharded.composed_possible(601, 2) and not sharded.composed_possible(500, 2) and not sharded.composed_possible(100_000, 1)
     with pytest.raises(ValueError):
         sharded.shard_bounds(4, 5, 6)
 
