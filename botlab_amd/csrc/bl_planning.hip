@@ -346,6 +346,73 @@ __global__ __launch_bounds__(DCOL_TX * DCOL_TY) void k_dist_cols(dist_batch db, 
     }
 }
 
+// The same for grids of up to DCOL_TY x DCOLS_ROWS rows (the 200 x 200 maps of the headline configuration): a thread's rows live in
+// registers -- every load of the kernel is requested before the first is used, where the loops above made ~40 dependent trips
+// through L2 per thread (13 rows, three passes: 23 us alone for 40 000 cells, the longer half of every replan's setDistances).
+#define DCOLS_ROWS 16
+__global__ __launch_bounds__(DCOL_TX * DCOL_TY) void k_dist_cols_small(dist_batch db, int W, int H)
+{
+    const uint16_t* __restrict__ row = db.row[blockIdx.z];
+    uint16_t* __restrict__ l1 = db.l1[blockIdx.z];
+    float* __restrict__ out = db.out[blockIdx.z];
+    const float* __restrict__ lut = db.lut[blockIdx.z];
+    __shared__ int s_fwd[DCOL_TY][DCOL_TX];
+    __shared__ int s_bwd[DCOL_TY][DCOL_TX];
+    const int tx = threadIdx.x, ty = threadIdx.y;
+    const int x = blockIdx.x * DCOL_TX + tx;
+    const int rows_per = (H + DCOL_TY - 1) / DCOL_TY;           // <= DCOLS_ROWS (the host checks)
+    const int y0 = min(ty * rows_per, H), y1 = min(y0 + rows_per, H);
+    const bool live = x < W;
+    int g[DCOLS_ROWS];
+#pragma unroll
+    for (int i = 0; i < DCOLS_ROWS; ++i) {
+        const int y = y0 + i;
+        int v = 0xFFFF;
+        if (live && y < y1) v = row[(size_t)y * W + x];
+        g[i] = v == 0xFFFF ? DIST_INF : v;
+    }
+    int a_f = DIST_INF, a_b = DIST_INF;
+#pragma unroll
+    for (int i = 0; i < DCOLS_ROWS; ++i)
+        if (y0 + i < y1) { a_f = min(a_f, g[i] + (y1 - 1 - (y0 + i))); a_b = min(a_b, g[i] + i); }
+    s_fwd[ty][tx] = a_f;
+    s_bwd[ty][tx] = a_b;
+    __syncthreads();
+    if (!live) return;
+    int E = DIST_INF;
+    for (int s = 0; s < ty; ++s) {
+        const int sy0 = min(s * rows_per, H), sy1 = min(sy0 + rows_per, H);
+        E = min(s_fwd[s][tx], E + (sy1 - sy0));
+    }
+    int B = DIST_INF;
+    for (int s = DCOL_TY - 1; s > ty; --s) {
+        const int sy0 = min(s * rows_per, H), sy1 = min(sy0 + rows_per, H);
+        B = min(s_bwd[s][tx], B + (sy1 - sy0));
+    }
+    int f[DCOLS_ROWS];
+    int d = E;
+#pragma unroll
+    for (int i = 0; i < DCOLS_ROWS; ++i) { d = min(g[i], d + 1); f[i] = d; }
+    int b = B;
+    int v[DCOLS_ROWS];
+#pragma unroll
+    for (int i = DCOLS_ROWS - 1; i >= 0; --i) {
+        if (y0 + i < y1) { b = min(g[i], b + 1); v[i] = min(min(f[i], b), 0xFFFF); } else v[i] = 0xFFFF;
+    }
+    float fo[DCOLS_ROWS];
+    if (out) {
+#pragma unroll
+        for (int i = 0; i < DCOLS_ROWS; ++i) fo[i] = (y0 + i < y1 && v[i] < 0xFFFF) ? lut[v[i]] : -1.0f;
+    }
+#pragma unroll
+    for (int i = 0; i < DCOLS_ROWS; ++i)
+        if (y0 + i < y1) {
+            const size_t at = (size_t)(y0 + i) * W + x;
+            l1[at] = (uint16_t)v[i];
+            if (out) out[at] = fo[i];
+        }
+}
+
 // ---- column pass for large grids ------------------------------------------------------------------------------------
 // k_dist_cols has W / 64 workgroups: 64 of them on a 4096-wide grid, a quarter of the CUs, each streaming narrow 128-byte
 // rows (measured 0.62 ms = 0.45 TB/s of traffic at 4096^2).  Here a workgroup owns 128 columns x 128 rows (a "macro
@@ -1045,7 +1112,8 @@ static int dist_set_distances_batch(int n, bl_dist* const* ds, const bl_grid* co
         } else {
             rc = bl_timer_begin(ctx, BL_K_DIST_COLS_APPLY, &f0, &f1);
             if (rc) return rc;
-            hipLaunchKernelGGL(k_dist_cols, dim3((W + DCOL_TX - 1) / DCOL_TX, 1, n), dim3(DCOL_TX, DCOL_TY), 0, ctx->stream, b, W, H);
+            if (H <= DCOL_TY * DCOLS_ROWS) hipLaunchKernelGGL(k_dist_cols_small, dim3((W + DCOL_TX - 1) / DCOL_TX, 1, n), dim3(DCOL_TX, DCOL_TY), 0, ctx->stream, b, W, H);
+            else hipLaunchKernelGGL(k_dist_cols, dim3((W + DCOL_TX - 1) / DCOL_TX, 1, n), dim3(DCOL_TX, DCOL_TY), 0, ctx->stream, b, W, H);
             rc = bl_timer_end(ctx, BL_K_DIST_COLS_APPLY, f0, f1);
             if (rc) return rc;
         }
