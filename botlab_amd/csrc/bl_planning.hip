@@ -165,6 +165,46 @@ __global__ __launch_bounds__(256) void k_dist_rows(dist_batch db, int W)
     }
 }
 
+// Row pass for narrow grids (W <= 256, a multiple of 4: the 200 x 200 maps): a WAVE owns a row, a lane four consecutive cells
+// (one 4-byte load, one 8-byte store); both scans run on the same registers, nothing goes through LDS and nothing waits for a
+// barrier -- k_dist_rows spends a 256-thread workgroup, eight barriers and a read-back of its own output on such a row.
+__global__ __launch_bounds__(256) void k_dist_rows_narrow(dist_batch db, int W, int H)
+{
+    const int8_t* __restrict__ cells = db.cells[blockIdx.z];
+    uint16_t* __restrict__ row = db.row[blockIdx.z];
+    if (blockIdx.x == 0 && threadIdx.x == 0) dist_plan_full(db.state[blockIdx.z], W, H);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int y = blockIdx.x * 4 + wave;
+    if (y >= H) return;
+    const int x0 = lane * 4;
+    int raw = -1;                                               // 0xFF bytes: free cells, no source
+    if (x0 < W) raw = *(const int*)(cells + (size_t)y * W + x0);
+    int b[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) b[i] = (int)(int8_t)(raw >> (8 * i));
+    int last = -DIST_INF, first = DIST_INF;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) if (b[i] >= 0) last = x0 + i;       // is_cell_occupied: logOdds >= 0 (obstacle_distance_grid.cpp:125-128)
+#pragma unroll
+    for (int i = 3; i >= 0; --i) if (b[i] >= 0) first = x0 + i;
+    int il = last, ir = first;
+    for (int off = 1; off < 64; off <<= 1) {
+        const int t = __shfl_up(il, off, 64); if (lane >= off) il = max(il, t);
+        const int u = __shfl_down(ir, off, 64); if (lane + off < 64) ir = min(ir, u);
+    }
+    int bl = __shfl_up(il, 1, 64), br = __shfl_down(ir, 1, 64);
+    if (lane == 0) bl = -DIST_INF;
+    if (lane == 63) br = DIST_INF;
+    if (x0 < W) {
+        unsigned int o[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { if (b[i] >= 0) bl = x0 + i; o[i] = (unsigned int)min(x0 + i - bl, 0xFFFF); }
+#pragma unroll
+        for (int i = 3; i >= 0; --i) { if (b[i] >= 0) br = x0 + i; o[i] = min(o[i], (unsigned int)min(br - (x0 + i), 0xFFFF)); }
+        *(uint2*)(row + (size_t)y * W + x0) = make_uint2(o[0] | (o[1] << 16), o[2] | (o[3] << 16));
+    }
+}
+
 // Row pass for wide grids (W a multiple of 16): a thread owns 16 consecutive cells (one 16-byte load, two 16-byte
 // stores), a workgroup a 4096-cell chunk of the row; nearest source to the left = exclusive max-scan of the threads' last
 // source index (wave shuffles + one LDS exchange), to the right the mirrored min-scan; chunks of rows wider than 4096 are
@@ -1078,6 +1118,7 @@ static int dist_set_distances_batch(int n, bl_dist* const* ds, const bl_grid* co
         rc = bl_timer_begin(ctx, BL_K_DIST_ROWS, &f0, &f1);
         if (rc) return rc;
         if (W >= 1024 && (W & 15) == 0) hipLaunchKernelGGL(k_dist_rows_wide, dim3(H, 1, n), dim3(256), 0, ctx->stream, b, W);
+        else if (W <= 256 && (W & 3) == 0) hipLaunchKernelGGL(k_dist_rows_narrow, dim3((H + 3) / 4, 1, n), dim3(256), 0, ctx->stream, b, W, H);
         else hipLaunchKernelGGL(k_dist_rows, dim3(H, 1, n), dim3(256), 0, ctx->stream, b, W);
         rc = bl_timer_end(ctx, BL_K_DIST_ROWS, f0, f1);
         if (rc) return rc;
