@@ -31,6 +31,7 @@ HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8 TB/s
 EVENT_STRIDE = 7                 # every 7th k_mcl_main launch of the timed region carries start/stop events (a timed launch costs ~4 us of stream
                                  # time); 7 shares no factor with the replanner batches (4, 8): 8 sampled the launches a lane's burst of
                                  # distance transforms runs beside, every time (0.075 ms against 0.066 in the trace of all launches)
+EVENT_STRIDE_LONG = 17           # ... runs of more than 400 steps: the events of every 7th launch cost 1 % of the steps/s (10 860 against 10 965 without any)
 
 
 def load_map(name):
@@ -460,11 +461,12 @@ def main():
         k += 1
     drain()
     ctx.timing_reset()
+    event_stride = EVENT_STRIDE if args.steps <= 400 else EVENT_STRIDE_LONG
     if not os.environ.get("BENCH_NO_EVENTS"):
         # HIP events of the dominant kernel only (roofline leg), on every EVENT_STRIDE-th launch of the timed region: the
         # launch carries its own start / stop events (hipExtLaunchKernelGGL), which hold the kernel's begin and end time stamps
         # -- a pair of hipEventRecord calls around it also measures the launch gap (~13 us here)
-        ctx.timing_stride(EVENT_STRIDE)
+        ctx.timing_stride(event_stride)
         ctx.timing_enable(True, kernels=[_capi.BL_K_MCL_MAIN])
     pops_total[0] = 0
     host_t[0] = host_t[1] = 0.0
@@ -601,7 +603,7 @@ def main():
             "roofline": {"bound": "hbm", "binding_resource": "VALU issue (the kernel's working set is LDS / L2 resident)", "kernel": "k_mcl_main", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": main_ms,
-                         "launches_timed": int(stage_ms["mcl_main"][1]), "event_stride": EVENT_STRIDE,
+                         "launches_timed": int(stage_ms["mcl_main"][1]), "event_stride": event_stride,
                          "particle_rays_per_s": (n_local * R) / (main_ms * 1e-3) if main_ms > 0 else 0.0,
                          "valu": valu, "other_kernels": others,
                          "step": {"algorithmic_bytes": round(step_bytes, 1), "achieved": round(step_gbs, 3), "frac": step_gbs / HBM_PEAK_GBS}},
