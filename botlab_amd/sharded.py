@@ -185,12 +185,18 @@ def ipc_probe(ctx, rank, world, group=None):
     except Exception:                                # noqa: BLE001
         ok = False
     gathered = [None] * world
-    dist.all_gather_object(gathered, handle, group=group)       # (behind every rank's write: bl_dev_word synchronises)
+    dist.all_gather_object(gathered, (handle, int(ctx.device)), group=group)      # (behind every rank's write: bl_dev_word synchronises)
+    devices = [g[1] for g in gathered]
+    gathered = [g[0] for g in gathered]
     opened = []
     if ok and all(h is not None for h in gathered):
         for r, h in enumerate(gathered):
             if r == rank:
                 continue
+            # a kernel that reads a mapping of a device this one has no peer access to faults instead of failing: ask first
+            if devices[r] != int(ctx.device) and not torch.cuda.can_device_access_peer(int(ctx.device), devices[r]):
+                ok = False
+                break
             q = C.c_void_p()
             if lib.bl_ipc_open(h, C.byref(q)) != 0:
                 ok = False
