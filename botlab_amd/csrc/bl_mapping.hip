@@ -229,7 +229,7 @@ __device__ __forceinline__ void map_update_body(const map_args& a, int8_t* snap,
     }
     // the exact pose into *lds_pose (one thread waits for the finisher), visible to the workgroup behind the barrier
     auto take_exact_pose = [&]() {
-        if (tid == 0) { float x, y; mclf_wait_pose(a.fin, &x, &y); lds_pose->x = x; lds_pose->y = y; }
+        if (tid == 0) { float x = lds_pose->x, y = lds_pose->y; (void)mclf_wait_pose(a.fin, &x, &y); lds_pose->x = x; lds_pose->y = y; }
         __syncthreads();
     };
     bool snap_stored = false;

@@ -2028,7 +2028,12 @@ extern "C" int bl_pf_pose_estimate(bl_pf* pf, bl_pose_xyt_t* out_pose)
     BL_HIP(hipMemcpyAsync(&h, &pf->state->pose, sizeof(h), hipMemcpyDeviceToHost, pf->ctx->stream));
     BL_HIP(hipStreamSynchronize(pf->ctx->stream));
     *out_pose = h.pose;
-    if (h.wait_timeouts != 0) { bl_set_error("a wait inside a finish launch gave up (%u): the estimate is not valid", h.wait_timeouts); return BL_ERR_STATE; }
+    if (h.wait_timeouts != 0) {
+        // reported once: the count belongs to the launches since the last estimate was fetched, not to every later one
+        BL_HIP(hipMemsetAsync(&pf->state->wait_timeouts, 0, sizeof(unsigned int), pf->ctx->stream));
+        bl_set_error("a wait inside a finish launch gave up (%u): the estimate is not valid", h.wait_timeouts);
+        return BL_ERR_STATE;
+    }
     return BL_OK;
 }
 

@@ -1092,20 +1092,26 @@ __device__ __forceinline__ bl_pose_xyt_t mclf_approx_pose(const double (&tot)[5]
     return p;
 }
 // one thread: wait for the finisher's x, y (mclf_pose with publish), clear the mailbox for the next launch
-__device__ __forceinline__ void mclf_wait_pose(const mcl_finish_args& f, float* x, float* y)
+// Returns false when the wait gave up (x, y untouched: the caller keeps its provisional pose; the count reaches the host with the
+// next bl_pf_pose_estimate, which reports it once and clears it).
+__device__ __forceinline__ bool mclf_wait_pose(const mcl_finish_args& f, float* x, float* y)
 {
     unsigned long long wx, wy;
     unsigned int spins = 0;
+    bool ok = true;
     while (true) {                                   // (both words requested together; each says by itself that it is there)
         wx = mclf_load_u64(f.sync + 3); wy = mclf_load_u64(f.sync + 4);
         if (((wx & wy) >> 32) & 1ull) break;
-        if (++spins > MCLF_SPIN_LIMIT) { atomicAdd(&f.state->wait_timeouts, 1u); break; }    // (every wait of the launch has an end)
+        if (++spins > MCLF_SPIN_LIMIT) { atomicAdd(&f.state->wait_timeouts, 1u); ok = false; break; }    // (every wait of the launch has an end)
         __builtin_amdgcn_s_sleep(1);
     }
-    *x = __uint_as_float((unsigned int)wx);
-    *y = __uint_as_float((unsigned int)wy);
+    if (ok) {
+        *x = __uint_as_float((unsigned int)wx);
+        *y = __uint_as_float((unsigned int)wy);
+    }
     mclf_store_u64(f.sync + 4, 0ull);
     mclf_store_u64(f.sync + 3, 0ull);
+    return ok;
 }
 
 // The pre-chain workgroup: the float sums over the first MCLF_PRE_SUBS sub-tiles.  The sums start from zero, so nothing is

@@ -705,7 +705,8 @@ __global__ __launch_bounds__(64 * DRI_WAVES) void k_dist_rows_inc(dist_batch db,
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         state[DST_MODE] = (unsigned int)mode;
         state[DST_X0] = (unsigned int)x0; state[DST_Y0] = (unsigned int)y0; state[DST_X1] = (unsigned int)x1; state[DST_Y1] = (unsigned int)y1;
-        if (mode == DST_MODE_FULL) state[DST_DUB] = 0u;                       // the column pass forms the bound anew
+        // (DST_DUB is NOT touched here: workgroups of this launch that start later still form their plan from it.  A whole-grid
+        // plan has it reset by the first column launch, which starts when every workgroup of this one has ended.)
         state[DST_STATS + mode] += 1u;
         if (db.hstat[z]) __hip_atomic_store(db.hstat[z], (unsigned int)mode, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
@@ -785,6 +786,9 @@ __global__ __launch_bounds__(DC2_TX * DC2_TY) void k_dist_cols_region(dist_batch
     unsigned int* state = db.state[z];
     const int mode = (int)state[DST_MODE];
     if (mode == DST_MODE_NONE) return;
+    // a whole-grid plan forms the bound D anew: PHASE 0 (which neither reads nor raises it) clears it between the row launch,
+    // whose workgroups all planned from the old value, and PHASE 1, which raises it to the largest distance written
+    if (PHASE == 0 && mode == DST_MODE_FULL && blockIdx.x == 0 && threadIdx.x == 0 && threadIdx.y == 0) state[DST_DUB] = 0u;
     const int x0 = (int)state[DST_X0], y0 = (int)state[DST_Y0], x1 = (int)state[DST_X1], y1 = (int)state[DST_Y1];
     const uint16_t* __restrict__ row = db.row[z];
     uint16_t* __restrict__ l1 = db.l1[z];
@@ -901,7 +905,8 @@ __global__ __launch_bounds__(DC2_TX * DC2_TY) void k_dist_cols_region(dist_batch
 }
 
 // The bound D of a transform the whole-grid kernels made (they keep none: an atomic per workgroup would cost them more than this
-// pass over l1 costs the first incremental transform that needs it).  state[DST_DUB] is zero when it starts (dist_plan_full).
+// pass over l1 costs the first incremental transform that needs it).  The host clears state[DST_DUB] on the stream before it
+// (dist_set_distances_batch, the units with !bound_ok).
 __global__ __launch_bounds__(256) void k_dist_bound(const uint16_t* __restrict__ l1, size_t n8, unsigned int* state)
 {
     __shared__ int s_dmax;
@@ -1083,10 +1088,13 @@ static int dist_set_distances_batch(int n, bl_dist* const* ds, const bl_grid* co
     const bool merged = H >= 4 * DC2_ROWS && W >= 4 * DC2_TX && (W & 1) == 0 && (H + DC2_ROWS - 1) / DC2_ROWS <= DST_MAX_GROUPS;
     const int strips = (H + DC2_ROWS - 1) / DC2_ROWS;
     const size_t merged_lds = (size_t)2 * strips * 2 * DC2_TX * sizeof(int);
-    static bool attr_set = false;
-    if (!attr_set) {
-        BL_HIP(hipFuncSetAttribute((const void*)k_dist_cols_region<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * DST_MAX_GROUPS * 2 * DC2_TX * (int)sizeof(int)));
-        attr_set = true;
+    {   // the attribute belongs to the device that is current when it is set: once per device this process drives
+        static unsigned long long attr_set_devices = 0ull;
+        const unsigned long long bit = 1ull << (ctx->device & 63);
+        if (!(attr_set_devices & bit)) {
+            BL_HIP(hipFuncSetAttribute((const void*)k_dist_cols_region<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * DST_MAX_GROUPS * 2 * DC2_TX * (int)sizeof(int)));
+            attr_set_devices |= bit;
+        }
     }
     hipEvent_t e0, e1;
     int rc = bl_timer_begin(ctx, BL_K_DIST, &e0, &e1);
@@ -1096,6 +1104,16 @@ static int dist_set_distances_batch(int n, bl_dist* const* ds, const bl_grid* co
     static const bool region_kernels = getenv("BOTLAB_DIST_REGION_COLS") != nullptr;
     const bool bound_kept = all_inc || (merged && region_kernels);                       // the column pass leaves the bound D behind
     if (all_inc) {
+        // The window is B dilated by D + 1, so D must bound l1 as it stands: the whole-grid kernels leave none behind
+        // (dist_plan_full: zero) -- the first incremental transform after one of them forms it, one read of l1.
+        for (int u = 0; u < n; ++u) {
+            bl_dist* d = ds[u];
+            if (d->bound_ok) continue;
+            const size_t n8 = (size_t)W * H / 8;                                         // (W a multiple of 16: dist_can_increment)
+            BL_HIP(hipMemsetAsync(d->state + DST_DUB, 0, sizeof(unsigned int), ctx->stream));
+            hipLaunchKernelGGL(k_dist_bound, dim3((unsigned int)std::min<size_t>((n8 + 255) / 256, 2048)), dim3(256), 0, ctx->stream, d->l1, n8, d->state);
+            d->bound_ok = true;
+        }
         // the window (or, failing that, the whole grid) is settled by the kernels themselves
         rc = bl_timer_begin(ctx, BL_K_DIST_ROWS, &f0, &f1);
         if (rc) return rc;
@@ -1201,6 +1219,19 @@ extern "C" int bl_dist_debug_stats(bl_dist* d, int64_t* out6)
         BL_HIP(hipMemcpyAsync(st, d->state + DST_STATS, sizeof(st), hipMemcpyDeviceToHost, d->ctx->stream));
         BL_HIP(hipStreamSynchronize(d->ctx->stream));
         out6[3] = st[0]; out6[4] = st[1]; out6[5] = st[2];
+    }
+    return BL_OK;
+}
+
+// the bound D the next incremental transform would build its window from, and whether the host counts it as formed
+// (synchronises; diagnostic: tests assert D >= every finite distance of the grid)
+extern "C" int bl_dist_debug_bound(bl_dist* d, int* formed, unsigned int* bound)
+{
+    BL_CHECK_ARG(d != nullptr && formed != nullptr && bound != nullptr);
+    *formed = d->bound_ok ? 1 : 0; *bound = 0;
+    if (d->state) {
+        BL_HIP(hipMemcpyAsync(bound, d->state + DST_DUB, sizeof(unsigned int), hipMemcpyDeviceToHost, d->ctx->stream));
+        BL_HIP(hipStreamSynchronize(d->ctx->stream));
     }
     return BL_OK;
 }

@@ -370,6 +370,12 @@ class ObstacleDistanceGrid:
         check(self.ctx.lib.bl_dist_debug_stats(self.h, v))
         return dict(incremental=v[0], full=v[1], unchanged=v[2], nothing=v[3], window=v[4], fallback=v[5])
 
+    def bound(self):
+        """(formed, D): the bound the next incremental transform dilates its window by (bl_dist_debug_bound)."""
+        f, b = C.c_int(), C.c_uint()
+        check(self.ctx.lib.bl_dist_debug_bound(self.h, C.byref(f), C.byref(b)))
+        return bool(f.value), int(b.value)
+
     def shape(self):
         w, h = C.c_int(), C.c_int()
         check(self.ctx.lib.bl_dist_shape(self.h, C.byref(w), C.byref(h)))

@@ -194,6 +194,10 @@ int bl_dist_forget(bl_dist* d);             /* the next bl_dist_set_distances tr
 /* diagnostic, six counts: setDistances calls that went out as an incremental launch / as a whole-grid launch / found the map
  * unchanged; and of the incremental launches those the device ended with nothing to do / a window / the whole grid */
 int bl_dist_debug_stats(bl_dist* d, int64_t* out6);
+/* diagnostic: the bound D (an upper bound of every finite L1 distance of the grid, in cells) the next incremental transform
+ * dilates its window by, and whether it has been formed (the whole-grid kernels leave none; the first incremental transform
+ * after one forms it) */
+int bl_dist_debug_bound(bl_dist* d, int* formed, unsigned int* bound);
 int bl_dist_download(bl_dist* d, float* cells);                           /* width*height floats (synchronises) */
 int bl_dist_shape(const bl_dist* d, int* width, int* height);
 int bl_dist_frame(const bl_dist* d, float* meters_per_cell, float* cells_per_meter, float* origin_x, float* origin_y);
@@ -230,7 +234,7 @@ typedef struct bl_planner bl_planner;
 /* lanes (1..4): consecutive submissions go to consecutive side streams, so up to `lanes` replans run concurrently (each
  * is one wavefront on its own CU and latency-bound; independent searches are what the GPU can overlap). */
 int bl_planner_create(bl_ctx* ctx, int lanes, bl_planner** out);
-/* batch (1..32): a lane collects `batch` consecutive submissions and issues their searches as ONE launch, a workgroup each,
+/* batch (1..64): a lane collects `batch` consecutive submissions and issues their searches as ONE launch, a workgroup each,
  * so lanes x batch replans overlap although the runtime multiplexes streams onto four hardware queues.  For grids where a
  * search outlasts a step (2000x2000: ~1.5 ms against 0.2 ms); a result is then available `batch` - 1 submissions later
  * (a fetch that cannot wait for the batch to fill sends it off as it is).  bl_planner_create is batch = 1. */

@@ -143,3 +143,60 @@ def test_replanner_snapshots_carry_the_lineage(maps, gpu_ctx):
         assert [(q.x, q.y, q.theta) for q in path] == [(q.x, q.y, q.theta) for q in exp], k
         g2.close()
     ap.close(); pf.close(); g.close()
+
+
+@pytest.mark.parametrize("lattice", [128, 0])
+def test_incremental_window_is_dilated_by_the_true_bound(oracle, gpu_ctx, lattice):
+    """A fully explored free hall (every cell known free, so no source hides behind the scan box's edge), wider than the scan box;
+    a hit turns a free cell into a source inside it.  Cells far OUTSIDE the box are then nearer to the new source than to their
+    old one: the window must be the box dilated by the bound D of the whole grid (+ 1), not by whatever the last window saw.
+    With a pillar lattice every 128 cells D is small enough for a window; without it the window exceeds DINC_MAX and the device
+    falls back to the whole grid -- both must equal the oracle.  (The whole-grid kernels leave no bound behind: the first
+    incremental transform after one has to form it.)"""
+    size = 1536
+    cells = np.full((size, size), -1, np.int8)                # known free, one hit away from being a source
+    cells[0, :] = cells[-1, :] = 127
+    cells[:, 0] = cells[:, -1] = 127
+    if lattice:
+        for y in range(lattice, size - 2, lattice):
+            for x in range(lattice, size - 2, lattice):
+                cells[y:y + 2, x:x + 2] = 127
+    world = np.where(cells > 0, 127, -127).astype(np.int8)
+    c = size // 2
+    world[c + 20:c + 26, c + 30:c + 36] = 127                  # an obstacle the map does not hold yet, 1.5 m from the start
+    half = size * 0.05 / 2.0
+    origin = (np.float32(-half), np.float32(-half))
+    g = bl.OccupancyGrid.from_cells(cells, origin, np.float32(0.05), cellsPerMeter=helpers.CPM_DEFAULT, ctx=gpu_ctx)
+    mapper = bl.Mapping(5.0, 4, 1, ctx=gpu_ctx)
+    inc = bl.ObstacleDistanceGrid(ctx=gpu_ctx)
+    poses = synth.square_trajectory((0.2, 0.2, 0.0), 12, step_len=0.05, turn=0.1, side=1.0)
+    scans = synth.raycast_scans_gpu(world, origin, 0.05, poses, 1_000_000, 100_000, gpu_ctx, max_range=4.5)
+    inc.setDistances(g)                                       # whole grid
+    before = oracle.set_distances(g.cells(), g.mpc, g.cpm, g.origin)
+    assert np.array_equal(_l1_of(inc), before.view(np.uint32))
+    changed_far = 0
+    for k in range(1, len(poses)):
+        p = poses[k]
+        mapper.updateMap(scans[k - 1], bl.make_pose(p[0], p[1], p[2], utime=scans[k - 1].utime), g)
+        inc.setDistances(g)
+        exp = oracle.set_distances(g.cells(), g.mpc, g.cpm, g.origin)
+        assert np.array_equal(_l1_of(inc), exp.view(np.uint32)), f"step {k}"
+        formed, D = inc.bound()
+        finite = exp[exp >= 0]
+        # (after a fall-back to the whole grid the host stays with the whole-grid kernels for a while: no bound then)
+        assert formed or not lattice
+        if formed:
+            assert D >= int(round(float(finite.max()) / 0.1)) - 1, (k, D, float(finite.max()))
+        # cells more than 5 m + 2 cells from the robot (outside any scan box dilated by 1) whose distance changed
+        yy, xx = np.nonzero(exp != before)
+        if len(yy):
+            far = np.maximum(np.abs(xx - c), np.abs(yy - c)) > 110 + 20
+            changed_far += int(far.sum())
+        before = exp
+    assert changed_far > 0                                    # the case really reaches beyond the box
+    st = inc.stats()
+    if lattice:
+        assert st["incremental"] == len(poses) - 1 and st["window"] >= len(poses) - 3, st
+    else:
+        assert st["incremental"] >= 1 and st["fallback"] >= 1, st
+    inc.close(); g.close()
