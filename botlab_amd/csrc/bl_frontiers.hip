@@ -35,6 +35,7 @@ struct frontier_args {
                                 // [5], [6] time stamps, [7] touches found (k_frontier_touches), [8] "take the one-workgroup sweep" flag
     int phase;                  // k_frontiers: 0 flood + sweep (small grids), 1 flood only, 2 sweep only (and only if counts[8] is set)
     uint2* touch;               // (key, cell) of every frontier cell the flood touched, in no order; FR_TOUCH_MAX entries
+    uint8_t* nb;                // large grids: per cell, the static classes of its four neighbours, 2 bits each (k_frontier_nb)
 };
 
 __device__ __forceinline__ unsigned int ld_claim(const unsigned int* p)
@@ -455,6 +456,365 @@ __global__ __launch_bounds__(FR_T) void k_frontiers(frontier_args a)
     }
 }
 
+// ---- large grids: the flood with everything a level needs in LDS ---------------------------------------------------------------
+// The level loop of k_frontiers<false> pays a global round trip per level for the class bytes of the neighbours (39 ms for 3582
+// levels at 4096^2, 11 us a level).  Here a level needs NO global load that was not issued a level earlier:
+//   * k_frontier_nb leaves, per cell, the STATIC classes of its four neighbours in one byte (free / frontier / other); a queue
+//     entry carries its cell's byte, loaded when the cell was claimed (the load flies while the level's scan runs);
+//   * what is dynamic -- which free neighbours are already visited -- needs no memory either: the 4-connected grid is
+//     bipartite, so every visited neighbour of an unvisited cell nc reached from level L lies in level L itself (a visited
+//     neighbour at a lower level would have claimed nc earlier).  The cells of the running level sit in an LDS hash
+//     (cell -> queue position); a claimer (p, n) of nc looks up nc's three other neighbours there: those it finds are nc's
+//     other claimers (it wins iff none has a smaller position: the key 4p+n order) and, with p itself, nc's visited-neighbour
+//     mask, which travels in nc's queue entry and spares the next level the claims on its own parents.
+// No atomics decide anything (the hash is insert-once, lookup-only), the queue order is the thread order, one scan places the
+// winners: four workgroup barriers and no exposed global latency per level.  Entries are x | y << 14 | mask << 28.  Levels wider
+// than FL_QMAX cells, and the first one (the robot cell may lie off the grid), take the generic path over cls[] / claim[].
+#define FL_T 1024
+#define FL_MAXB 8                          // chunks of 1024 positions a level may have
+#define FL_QMAX (FL_T * FL_MAXB)
+#define FL_HS 16384                        // hash slots: twice the widest level
+#define FL_LDS_BYTES (2 * FL_QMAX * 4 + 2 * FL_QMAX + (FL_HS + 32) * 4 + 256)
+#define FL_XY(x, y) ((unsigned int)(x) | ((unsigned int)(y) << 14))
+
+__global__ __launch_bounds__(256) void k_frontier_nb(frontier_args a)
+{
+    const long long ncell = (long long)a.W * a.H;
+    for (long long c = (long long)blockIdx.x * 256 + threadIdx.x; c < ncell; c += (long long)gridDim.x * 256) {
+        const int x = (int)(c % a.W), y = (int)(c / a.W);
+        unsigned int b = 0;
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+            const int nx = x + (n == 0 ? -1 : (n == 1 ? 1 : 0)), ny = y + (n == 2 ? 1 : (n == 3 ? -1 : 0));
+            if (nx < 0 || ny < 0 || nx >= a.W || ny >= a.H) continue;
+            const unsigned int k = a.cls[(size_t)ny * a.W + nx];
+            if (k == 1u || k == 2u) b |= k << (2 * n);                 // (the robot cell, class 3, is visited from the start: "other")
+        }
+        a.nb[c] = (uint8_t)b;
+    }
+}
+
+// A workgroup barrier that orders LDS traffic only.  __syncthreads() also waits for every outstanding global store and load of
+// the wave (s_waitcnt vmcnt(0)): with the level's queue / class stores and the next level's neighbour bytes in flight that is two
+// exposed global round trips per level -- the very cost this kernel exists to avoid.  Nothing a level reads from global memory
+// was written by the same launch (the generic path, which does, keeps __syncthreads and is entered behind one).
+__device__ __forceinline__ void fl_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+__device__ __forceinline__ int fl_excl_scan(int v, int* s_wave, int* total)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int incl = v;
+    for (int off = 1; off < 64; off <<= 1) {
+        int t = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += t;
+    }
+    if (lane == 63) s_wave[wave] = incl;               // (s_wave is read only between this barrier and the level's last one)
+    fl_barrier();
+    int base = 0, tot = 0;
+    for (int w = 0; w < FL_T / 64; ++w) { int x = s_wave[w]; if (w < wave) base += x; tot += x; }
+    *total = tot;
+    return base + incl - v;
+}
+
+// The level's hash, one 32-bit word per slot.  home = (x + FL_HC y) mod FL_HS -- the homes of a cell's neighbours are the cell's
+// home plus a constant, lanes that hold the cells of a diagonal or straight run of the front read different LDS banks, and no
+// multiplication is spent (the flood is bound by VALU issue: 16 waves on 4 SIMDs, four cycles an instruction) -- and an entry that
+// sits d slots behind its home stores y | d << 14, which with the slot names its cell exactly, beside the cell's queue position:
+// y | d << 14 | position << 19.  Linear probing without wrap-around (FL_PAD spare slots behind the table), insert-once (one
+// atomicCAS), never deleted while lookups run: a lookup ends at the first empty slot.  d <= FL_DMAX, or the level is given up.
+// A cell code off the grid (x - 1 at x = 0 borrows from y) names no cell of the level as long as W, H <= FL_MAX_SIDE.
+#define FL_EMPTY 0xFFFFFFFFu
+#define FL_DMAX 30
+#define FL_PAD 32
+#define FL_HC 90
+#define FL_MAX_SIDE 16380
+__device__ __forceinline__ unsigned int fl_home(unsigned int x, unsigned int y) { return (x + FL_HC * y) & (FL_HS - 1); }
+
+#ifdef FL_STAMPS
+__device__ long long g_fl_stamp[8];
+#define FLS(i) do { if (threadIdx.x == 0) { const long long t_ = wall_clock64(); g_fl_stamp[i] += t_ - t_prev; t_prev = t_; } } while (0)
+#else
+#define FLS(i) do { } while (0)
+#endif
+
+// exclusive prefix of a per-lane count 0..3 over the workgroup (ballots inside the wave, one LDS word per wave, a 16-lane DPP scan
+// over the waves): *total = the workgroup's sum.  One barrier.
+__device__ __forceinline__ int fl_scan_small(int v, int* s_wave, int* total)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const unsigned long long b0 = __ballot(v & 1), b1 = __ballot(v & 2);
+    const int below = (int)__builtin_amdgcn_mbcnt_hi((unsigned int)(b0 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)b0, 0u)) +
+                      2 * (int)__builtin_amdgcn_mbcnt_hi((unsigned int)(b1 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)b1, 0u));
+    if (lane == 0) s_wave[wave] = __popcll(b0) + 2 * __popcll(b1);
+    fl_barrier();
+    int t = s_wave[lane & 15];                               // lanes 0..15 of every row: the sixteen waves' sums
+    t += __builtin_amdgcn_update_dpp(0, t, 0x111, 0xf, 0xf, false);      // row_shr:1 ... inclusive scan inside the row of 16
+    t += __builtin_amdgcn_update_dpp(0, t, 0x112, 0xf, 0xf, false);
+    t += __builtin_amdgcn_update_dpp(0, t, 0x114, 0xf, 0xf, false);
+    t += __builtin_amdgcn_update_dpp(0, t, 0x118, 0xf, 0xf, false);
+    *total = __builtin_amdgcn_readlane(t, 15);
+    const int base = wave == 0 ? 0 : __builtin_amdgcn_readlane(t, wave - 1);
+    return base + below;
+}
+
+// A level of hi - lo <= FL_QMAX cells whose entries are in s_qc / s_nbc; leaves the next level's in s_qn / s_nbn.  Thread t takes
+// the positions t, t + 1024, ... (a chunk of 1024 at a time: inside a chunk thread order = queue order, one scan per chunk places
+// its winners behind those of the chunks before).  Returns the next level's size (beyond FL_QMAX only a.queue holds it), or -1
+// with nothing changed but the (emptied) table when an entry would not fit within FL_DMAX slots of its home.
+__device__ __forceinline__ int fl_level(const frontier_args& a, const unsigned int* s_qc, unsigned int* s_qn, const uint8_t* s_nbc, uint8_t* s_nbn,
+                                        unsigned int* s_tab, int* s_wave, int* s_flag, int lo, int hi)
+{
+#ifdef FL_STAMPS
+    long long t_prev = wall_clock64();
+#endif
+    const int tid = threadIdx.x, width = hi - lo;
+    const int nchunk = (width + FL_T - 1) / FL_T;
+    // ---- the level's cells into the table
+    bool overflow = false;
+    for (int ch = 0; ch < nchunk; ++ch) {
+        const int p = ch * FL_T + tid;
+        if (p >= width) break;
+        const unsigned int e = s_qc[p];
+        const unsigned int x = e & 0x3FFFu, y = (e >> 14) & 0x3FFFu;
+        const unsigned int home = fl_home(x, y), body = y | ((unsigned int)p << 19);
+        unsigned int d = 0;
+        for (; d <= FL_DMAX; ++d)
+            if (atomicCAS(&s_tab[home + d], FL_EMPTY, body | (d << 14)) == FL_EMPTY) break;
+        if (d > FL_DMAX) overflow = true;
+    }
+    if (overflow) *s_flag = 1;
+    FLS(0);
+    fl_barrier();
+    FLS(1);
+    int base = 0;
+    const bool gave_up = *s_flag != 0;
+    if (!gave_up) {
+    for (int ch = 0; ch < nchunk; ++ch) {
+        const int p = ch * FL_T + tid;
+        unsigned int wxy[4], wnb[4];
+        unsigned int winmask = 0;
+        if (p < width) {
+            const unsigned int ent = s_qc[p], nbb = s_nbc[p];
+            const unsigned int x = ent & 0x3FFFu, y = (ent >> 14) & 0x3FFFu, xy = ent & 0x0FFFFFFFu;
+            const unsigned int vmask = ent >> 28;
+            unsigned int f = nbb & ~(nbb >> 1) & 0x55u;                 // bit 2n: neighbour n is free
+            const unsigned int t2 = (nbb >> 1) & ~nbb & 0x55u;          // bit 2n: neighbour n is a frontier cell
+            f = (f | (f >> 1)) & 0x33u; f = (f | (f >> 2)) & 0x0Fu;
+            const unsigned int cand = f & ~vmask;                      // free neighbours that are not parents
+            if (t2 != 0u) {
+#pragma unroll
+                for (int n = 0; n < 4; ++n)
+                    if ((t2 >> (2 * n)) & 1u) {
+                        const int nx = (int)x + (n == 0 ? -1 : (n == 1 ? 1 : 0)), ny = (int)y + (n == 2 ? 1 : (n == 3 ? -1 : 0));
+                        atomicMin(&a.claim[(size_t)ny * a.W + nx], ((unsigned int)(lo + p) << 2) | (unsigned int)n);
+                    }
+            }
+            if (cand != 0u) {
+                // Who else of this level touches the cells p can claim?  The three other neighbours of p + d_n are among the eight
+                // cells at distance 2 of p: index 0..3 = p + 2 d_n; 4 = (-1,+1), 5 = (-1,-1), 6 = (+1,+1), 7 = (+1,-1); cell i
+                // matters to the candidates cm[i].  Looked up once per position, first and second probe in one LDS read.
+                const unsigned int home = fl_home(x, y);
+                unsigned int found = 0, earlier = 0, unresolved = 0;
+                // every read of the position first (cells no candidate asks for read the position's own home: harmless) ...
+                unsigned int w0[8], w1[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const unsigned int cm = i < 4 ? (1u << i) : (i == 4 ? 0x5u : (i == 5 ? 0x9u : (i == 6 ? 0x6u : 0xAu)));
+                    const int dx = i == 0 ? -2 : (i == 1 ? 2 : (i < 4 ? 0 : (i < 6 ? -1 : 1)));
+                    const int dy = i == 2 ? 2 : (i == 3 ? -2 : (i < 4 ? 0 : ((i == 4 || i == 6) ? 1 : -1)));
+                    const unsigned int hq = (home + ((cand & cm) ? (unsigned int)((dx + FL_HC * dy) & (FL_HS - 1)) : 0u)) & (FL_HS - 1);
+                    w0[i] = s_tab[hq]; w1[i] = s_tab[hq + 1];
+                }
+                // ... then what they say, without a branch
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const unsigned int cm = i < 4 ? (1u << i) : (i == 4 ? 0x5u : (i == 5 ? 0x9u : (i == 6 ? 0x6u : 0xAu)));
+                    const int dy = i == 2 ? 2 : (i == 3 ? -2 : (i < 4 ? 0 : ((i == 4 || i == 6) ? 1 : -1)));
+                    const unsigned int k13 = (y + (unsigned int)dy) << 13;             // the key y | 0 << 14, shifted to the top
+                    const bool need = (cand & cm) != 0u;
+                    const bool m0 = (w0[i] << 13) == k13, m1 = (w1[i] << 13) == k13 + (1u << 27);
+                    const bool hit = need && (m0 || m1);
+                    const unsigned int pos = (m0 ? w0[i] : w1[i]) >> 19;
+                    found |= hit ? (1u << i) : 0u;
+                    earlier |= (hit && pos < (unsigned int)p) ? (1u << i) : 0u;
+                    unresolved |= (need && !(m0 || m1) && max(w0[i], w1[i]) != FL_EMPTY) ? (1u << i) : 0u;   // neither probe ended the chain
+                }
+                while (unresolved) {                                   // third and later probes: rare
+                    const int i0 = __ffs((int)unresolved) - 1;
+                    unresolved &= unresolved - 1u;
+                    const int dx = i0 == 0 ? -2 : (i0 == 1 ? 2 : (i0 < 4 ? 0 : (i0 < 6 ? -1 : 1)));
+                    const int dy = i0 == 2 ? 2 : (i0 == 3 ? -2 : (i0 < 4 ? 0 : ((i0 == 4 || i0 == 6) ? 1 : -1)));
+                    const unsigned int hq = (home + (unsigned int)((dx + FL_HC * dy) & (FL_HS - 1))) & (FL_HS - 1);
+                    const unsigned int k13 = (y + (unsigned int)dy) << 13;
+                    for (unsigned int d = 2; d <= FL_DMAX; ++d) {
+                        const unsigned int w = s_tab[hq + d];
+                        if (w == FL_EMPTY) break;
+                        if ((w << 13) == k13 + (d << 27)) { found |= 1u << i0; if ((w >> 19) < (unsigned int)p) earlier |= 1u << i0; break; }
+                    }
+                }
+#pragma unroll
+                for (int n = 0; n < 4; ++n) {
+                    if (!((cand >> n) & 1u)) continue;
+                    // neighbours of nc = p + d_n other than p: m = n (straight on: cell n) and the two perpendicular ones
+                    // n = 0 (-1,0): m = 2 -> cell 4, m = 3 -> cell 5;   n = 1 (+1,0): m = 2 -> 6, m = 3 -> 7
+                    // n = 2 (0,+1): m = 0 -> cell 4, m = 1 -> cell 6;   n = 3 (0,-1): m = 0 -> 5, m = 1 -> 7
+                    const int ma = n < 2 ? 2 : 0, mb = n < 2 ? 3 : 1;
+                    const int ia = n == 0 ? 4 : (n == 1 ? 6 : (n == 2 ? 4 : 5));
+                    const int ib = n == 0 ? 5 : (n == 1 ? 7 : (n == 2 ? 6 : 7));
+                    if (earlier & ((1u << n) | (1u << ia) | (1u << ib))) continue;     // a claimer in front of p
+                    const unsigned int vm = (1u << (n ^ 1)) | (((found >> n) & 1u) << n) | (((found >> ia) & 1u) << ma) | (((found >> ib) & 1u) << mb);
+                    const int dxy = n == 0 ? -1 : (n == 1 ? 1 : (n == 2 ? (1 << 14) : -(1 << 14)));
+                    const int dc = n == 0 ? -1 : (n == 1 ? 1 : (n == 2 ? a.W : -a.W));
+                    wxy[n] = (xy + (unsigned int)dxy) | (vm << 28);
+                    wnb[n] = a.nb[(int)(y * (unsigned int)a.W + x) + dc];              // in flight while the scan runs
+                    winmask |= 1u << n;
+                }
+            }
+        }
+        int total;
+        FLS(2);
+        int at = base + fl_scan_small(__popc(winmask), s_wave + (ch & 1) * (FL_T / 64), &total);
+        FLS(3);
+#pragma unroll
+        for (int n = 0; n < 4; ++n)
+            if ((winmask >> n) & 1u) {
+                const unsigned int e = wxy[n];
+                if (at < FL_QMAX) { s_qn[at] = e; s_nbn[at] = (uint8_t)wnb[n]; }
+                a.queue[hi + at] = (int)((e >> 14) & 0x3FFFu) * a.W + (int)(e & 0x3FFFu);
+                at += 1;
+            }
+        base += total;
+        FLS(4);
+    }
+    }
+    // ---- the table is emptied (every lookup of the level lies before the last scan's barrier -- or, when the level was given
+    // up, before the barrier above): 16 slots per thread, whole
+    {
+        uint4* t4 = (uint4*)s_tab;
+        const uint4 e4 = make_uint4(FL_EMPTY, FL_EMPTY, FL_EMPTY, FL_EMPTY);
+#pragma unroll
+        for (int i = 0; i < FL_HS / 4 / FL_T; ++i) t4[i * FL_T + tid] = e4;
+        if (tid < FL_PAD / 4) t4[FL_HS / 4 + tid] = e4;
+    }
+    fl_barrier();
+    if (gave_up) { if (tid == 0) *s_flag = 0; fl_barrier(); return -1; }
+    FLS(5);
+    return base;
+}
+
+// entries of the level lo..hi (cells in a.queue, marks in cls[]) into s_q / s_nb: after a level of the generic path
+__device__ __forceinline__ void fl_refill(const frontier_args& a, unsigned int* s_q, uint8_t* s_nb, int lo, int hi)
+{
+    for (int p = (int)threadIdx.x; p < hi - lo; p += FL_T) {
+        const int c = a.queue[lo + p];
+        const int x = c % a.W, y = c / a.W;
+        unsigned int vm = 0;
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+            const int nx = x + (n == 0 ? -1 : (n == 1 ? 1 : 0)), ny = y + (n == 2 ? 1 : (n == 3 ? -1 : 0));
+            if (nx < 0 || ny < 0 || nx >= a.W || ny >= a.H) continue;
+            if (a.cls[(size_t)ny * a.W + nx] == 4) vm |= 1u << n;
+        }
+        s_q[p] = FL_XY(x, y) | (vm << 28);
+        s_nb[p] = a.nb[c];
+    }
+    __syncthreads();
+}
+
+// a level of any width over cls[] / claim[] (the level loop of k_frontiers, without its LDS mirrors)
+__device__ __forceinline__ int fl_level_generic(const frontier_args& a, int* s_wave, int lo, int hi)
+{
+    const int tid = threadIdx.x;
+    for (int p = lo + tid; p < hi; p += FL_T) {
+        int x, y;
+        if (p == 0) { x = a.rx; y = a.ry; } else { const int c = a.queue[p]; x = c % a.W; y = c / a.W; }
+        for (int n = 0; n < 4; ++n) {
+            const int nx = x + (n == 0 ? -1 : (n == 1 ? 1 : 0)), ny = y + (n == 2 ? 1 : (n == 3 ? -1 : 0));
+            if (nx < 0 || ny < 0 || nx >= a.W || ny >= a.H) continue;
+            const int c = ny * a.W + nx;
+            const int k = a.cls[c];
+            if (k == 1 || k == 2) atomicMin(&a.claim[c], ((unsigned int)p << 2) | (unsigned int)n);
+        }
+    }
+    __syncthreads();
+    int newhi = hi;
+    for (int base = lo; base < hi; base += FL_T) {
+        const int p = base + tid;
+        int wins = 0, wc[4];
+        if (p < hi) {
+            int x, y;
+            if (p == 0) { x = a.rx; y = a.ry; } else { const int c0 = a.queue[p]; x = c0 % a.W; y = c0 / a.W; }
+            for (int n = 0; n < 4; ++n) {
+                const int nx = x + (n == 0 ? -1 : (n == 1 ? 1 : 0)), ny = y + (n == 2 ? 1 : (n == 3 ? -1 : 0));
+                if (nx < 0 || ny < 0 || nx >= a.W || ny >= a.H) continue;
+                const int c = ny * a.W + nx;
+                if (a.cls[c] == 1 && ld_claim(&a.claim[c]) == (((unsigned int)p << 2) | (unsigned int)n)) wc[wins++] = c;
+            }
+        }
+        int total;
+        const int off = block_excl_scan(wins, s_wave, &total);
+        for (int j = 0; j < wins; ++j) a.queue[newhi + off + j] = wc[j];
+        newhi += total;
+    }
+    __syncthreads();
+    // winners become visited only now: a cell claimed in this level must look unvisited to every claimer of the level
+    for (int q = hi + tid; q < newhi; q += FL_T) a.cls[a.queue[q]] = 4;
+    __syncthreads();
+    return newhi - hi;
+}
+
+__global__ __launch_bounds__(FL_T) void k_frontier_flood(frontier_args a)
+{
+    const long long t_begin = wall_clock64();
+    extern __shared__ __align__(16) uint8_t s_fl[];
+    unsigned int* s_q0 = (unsigned int*)s_fl;                                  // [2][FL_QMAX]
+    unsigned int* s_tab = (unsigned int*)(s_fl + 2 * FL_QMAX * 4);
+    uint8_t* s_nb0 = s_fl + 2 * FL_QMAX * 4 + (FL_HS + FL_PAD) * 4;             // [2][FL_QMAX]
+    int* s_wave = (int*)(s_fl + 2 * FL_QMAX * 4 + (FL_HS + FL_PAD) * 4 + 2 * FL_QMAX);     // [2][16]
+    int* s_flag = s_wave + 2 * (FL_T / 64);
+    const int tid = threadIdx.x;
+    for (int i = tid; i < FL_HS + FL_PAD; i += FL_T) s_tab[i] = FL_EMPTY;
+    if (tid == 0) *s_flag = 0;
+    __syncthreads();
+    int lo = 0, hi = 1, levels = 0, cur = 0;
+    int marked = 1;                                        // queue positions below it carry the visited mark (cls 4)
+    bool packed = false;                                   // s_q[cur] / s_nb[cur] hold the level lo..hi
+    // the packed levels leave the visited marks to whoever needs them: the generic path and the refill read cls[]
+    auto catch_up = [&]() {
+        __syncthreads();                                   // the packed levels' queue stores have landed
+        for (int q = marked + tid; q < hi; q += FL_T) a.cls[a.queue[q]] = 4;
+        __syncthreads();
+        marked = hi;
+    };
+    while (lo < hi) {
+        const int width = hi - lo;
+        int total = -1;
+        if (lo > 0 && width <= FL_QMAX) {
+            unsigned int* qc = s_q0 + cur * FL_QMAX; unsigned int* qn = s_q0 + (cur ^ 1) * FL_QMAX;
+            uint8_t* nc = s_nb0 + cur * FL_QMAX; uint8_t* nn = s_nb0 + (cur ^ 1) * FL_QMAX;
+            if (!packed) { catch_up(); fl_refill(a, qc, nc, lo, hi); }
+            total = fl_level(a, qc, qn, nc, nn, s_tab, s_wave, s_flag, lo, hi);
+            packed = total >= 0 && total <= FL_QMAX;
+            if (total >= 0) cur ^= 1;
+        }
+        if (total < 0) {
+            catch_up();
+            total = fl_level_generic(a, s_wave, lo, hi);
+            marked = hi + total;
+            packed = false;
+        }
+        lo = hi; hi += total; levels += 1;
+    }
+    if (tid == 0) { a.counts[2] = hi; a.counts[3] = levels; a.counts[5] = (int)(wall_clock64() - t_begin); a.counts[7] = 0; a.counts[8] = 0; }
+#ifdef FL_STAMPS
+    if (tid == 0) {
+        printf("[flood stamps, 100 MHz ticks] insert %lld  barrier1 %lld  claims %lld  scan %lld  write %lld  barrier4 %lld\n",
+               g_fl_stamp[0], g_fl_stamp[1], g_fl_stamp[2], g_fl_stamp[3], g_fl_stamp[4], g_fl_stamp[5]);
+        for (int i = 0; i < 8; ++i) g_fl_stamp[i] = 0;
+    }
+#endif
+}
+
 // ---- large grids: the frontier sweep as two launches ------------------------------------------------------------------------
 // The one-workgroup sweep walks the whole free-space queue again (7 M positions at 4096^2) to find the touches in key order, and
 // grows each frontier level by level with three global round trips per level -- frontiers are thin curves, so a level holds two
@@ -600,13 +960,14 @@ struct bl_frontier_scratch {
     int cap_frontiers = 0;
     int32_t* h_counts = nullptr;
     uint2* touch = nullptr;
+    uint8_t* nb = nullptr;
 };
 
 void bl_frontier_scratch_free(bl_ctx* ctx)
 {
     bl_frontier_scratch* s = ctx->frontier;
     if (!s) return;
-    void* dev[] = {s->cls, s->claim, s->fclaim, s->queue, s->out_cells, s->out_offsets, s->counts, s->touch};
+    void* dev[] = {s->cls, s->claim, s->fclaim, s->queue, s->out_cells, s->out_offsets, s->counts, s->touch, s->nb};
     for (void* q : dev) if (q) (void)hipFree(q);
     if (s->h_counts) (void)hipHostFree(s->h_counts);
     delete s;
@@ -626,12 +987,13 @@ extern "C" int bl_frontiers_find(bl_ctx* ctx, const bl_grid* map, const bl_pose_
     const size_t n = (size_t)W * H;
     if (s->cells < n) {
         BL_HIP(hipStreamSynchronize(ctx->stream));
-        void* dev[] = {s->cls, s->claim, s->fclaim, s->queue, s->out_cells, s->out_offsets};
+        void* dev[] = {s->cls, s->claim, s->fclaim, s->queue, s->out_cells, s->out_offsets, s->nb};
         for (void* q : dev) if (q) BL_HIP(hipFree(q));
-        s->cls = nullptr; s->claim = nullptr; s->fclaim = nullptr; s->queue = nullptr; s->out_cells = nullptr; s->out_offsets = nullptr;
+        s->cls = nullptr; s->claim = nullptr; s->fclaim = nullptr; s->queue = nullptr; s->out_cells = nullptr; s->out_offsets = nullptr; s->nb = nullptr;
         s->cells = 0;
         s->cap_frontiers = (int)(n / 4 + 4);               // components are 8-separated: at most one per 2x2 block
         BL_HIP(hipMalloc((void**)&s->cls, n));
+        BL_HIP(hipMalloc((void**)&s->nb, n));
         BL_HIP(hipMalloc((void**)&s->claim, n * 4));
         BL_HIP(hipMalloc((void**)&s->fclaim, n * 4));
         BL_HIP(hipMalloc((void**)&s->queue, (n + 1) * 4));
@@ -647,15 +1009,16 @@ extern "C" int bl_frontiers_find(bl_ctx* ctx, const bl_grid* map, const bl_pose_
     bl_global_to_cell((double)robot_pose->x, (double)robot_pose->y, map->frame, &a.rx, &a.ry);      // :39
     a.cls = s->cls; a.claim = s->claim; a.fclaim = s->fclaim; a.queue = s->queue;
     a.out_cells = s->out_cells; a.out_offsets = s->out_offsets; a.cap_frontiers = s->cap_frontiers; a.counts = s->counts;
-    a.phase = 0; a.touch = s->touch;
+    a.phase = 0; a.touch = s->touch; a.nb = s->nb;
     hipEvent_t e0, e1;
     int rc = bl_timer_begin(ctx, BL_K_FRONTIERS, &e0, &e1);
     if (rc) return rc;
     if (n <= (size_t)FR_CLS_LDS) {
-        static bool attr_set = false;
-        if (!attr_set) {
+        static unsigned long long attr_set_devices = 0ull;
+        const unsigned long long bit = 1ull << (ctx->device & 63);
+        if (!(attr_set_devices & bit)) {
             BL_HIP(hipFuncSetAttribute((const void*)k_frontiers<true>, hipFuncAttributeMaxDynamicSharedMemorySize, FR_CLS_LDS));
-            attr_set = true;
+            attr_set_devices |= bit;
         }
         hipLaunchKernelGGL(k_frontiers<true>, dim3(1), dim3(FR_T), (n + 15) & ~(size_t)15, ctx->stream, a);
     } else {
@@ -667,7 +1030,20 @@ extern "C" int bl_frontiers_find(bl_ctx* ctx, const bl_grid* map, const bl_pose_
             hipLaunchKernelGGL(k_frontiers<false>, dim3(1), dim3(FR_T), 0, ctx->stream, a);
         } else {
             a.phase = 1;
-            hipLaunchKernelGGL(k_frontiers<false>, dim3(1), dim3(FR_T), 0, ctx->stream, a);
+            static const bool old_flood = getenv("BOTLAB_FRONTIER_OLD_FLOOD") != nullptr;                 // A/B runs
+            if (!old_flood && W <= FL_MAX_SIDE && H <= FL_MAX_SIDE) {
+                // the flood with its levels' state in LDS (k_frontier_flood): entries are 14-bit coordinates
+                static unsigned long long attr_set_devices = 0ull;
+                const unsigned long long bit = 1ull << (ctx->device & 63);
+                if (!(attr_set_devices & bit)) {
+                    BL_HIP(hipFuncSetAttribute((const void*)k_frontier_flood, hipFuncAttributeMaxDynamicSharedMemorySize, FL_LDS_BYTES));
+                    attr_set_devices |= bit;
+                }
+                hipLaunchKernelGGL(k_frontier_nb, dim3((unsigned int)cblocks), dim3(256), 0, ctx->stream, a);
+                hipLaunchKernelGGL(k_frontier_flood, dim3(1), dim3(FL_T), FL_LDS_BYTES, ctx->stream, a);
+            } else {
+                hipLaunchKernelGGL(k_frontiers<false>, dim3(1), dim3(FR_T), 0, ctx->stream, a);
+            }
             hipLaunchKernelGGL(k_frontier_touches, dim3((unsigned int)cblocks), dim3(256), 0, ctx->stream, a);
             hipLaunchKernelGGL(k_frontier_grow, dim3(1), dim3(FR_T), 0, ctx->stream, a);
             a.phase = 2;
