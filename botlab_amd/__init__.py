@@ -5,12 +5,12 @@ the Python host mirror of the reference's class surfaces used by tests and bench
 call raises if the HIP library is missing or no GPU is visible.
 """
 from ._capi import BotlabHipError, Lidar, Particle, Pose, SearchParams, load  # noqa: F401
-from .host import (AsyncPlanner, Context, LidarScan, Mapping, MotionPlanner, MotionPlannerParams, ObstacleDistanceGrid,  # noqa: F401
+from .host import (AsyncExplorer, AsyncPlanner, Context, LidarScan, Mapping, MotionPlanner, MotionPlannerParams, ObstacleDistanceGrid,  # noqa: F401
                    OccupancyGrid, ParticleFilter, PARTICLE_DTYPE, POSE_DTYPE, default_context, make_pose,
                    search_for_path, search_for_path_begin, search_for_path_end, search_for_path_batch, Frontiers,
                    find_map_frontiers, plan_path_to_frontier, ExploringMap)
 
-__all__ = ["AsyncPlanner", "BotlabHipError", "Lidar", "Particle", "Pose", "SearchParams", "load", "Context", "LidarScan", "Mapping",
+__all__ = ["AsyncExplorer", "AsyncPlanner", "BotlabHipError", "Lidar", "Particle", "Pose", "SearchParams", "load", "Context", "LidarScan", "Mapping",
            "MotionPlanner", "MotionPlannerParams", "ObstacleDistanceGrid", "OccupancyGrid", "ParticleFilter",
            "PARTICLE_DTYPE", "POSE_DTYPE", "default_context", "make_pose", "search_for_path", "search_for_path_begin",
            "search_for_path_end", "search_for_path_batch", "Frontiers", "find_map_frontiers", "plan_path_to_frontier", "ExploringMap"]

@@ -40,6 +40,14 @@ class MotionPlannerState(C.Structure):
     _fields_ = [("robot_radius", C.c_double), ("search", SearchParams), ("num_frontiers", C.c_int32), ("prev_goal", Pose)]
 
 
+class ExploreResult(C.Structure):
+    """bl_explore_result_t: one Exploration::executeExploringMap step (exploration.cpp:277-369)."""
+    _fields_ = [("next_state", C.c_int32), ("status", C.c_int32), ("num_frontiers", C.c_int32), ("frontier_cells", C.c_int32),
+                ("planned", C.c_int32), ("path_length", C.c_int32), ("pops", C.c_int64), ("pushes", C.c_int64), ("searches", C.c_int64),
+                ("bfs_cells", C.c_int32), ("bfs_levels", C.c_int32), ("pose", Pose), ("target", Pose), ("frontiers_ms", C.c_float),
+                ("plan_ms", C.c_float)]
+
+
 BL_K_MCL_MAIN, BL_K_MCL_SCAN, BL_K_MAP, BL_K_DIST, BL_K_ASTAR, BL_K_FRONTIERS = range(6)
 BL_K_DIST_ROWS, BL_K_DIST_COLS_SUMMARY, BL_K_DIST_COLS_APPLY, BL_K_SNAPSHOT = range(6, 10)
 BL_OK, BL_ERR_HIP, BL_ERR_ARG, BL_ERR_CAPACITY, BL_ERR_STATE = range(5)
@@ -165,6 +173,13 @@ SIGNATURES = {
     "bl_pf_encode_particles_lcm": (C.c_int64, [_vp, C.c_int64, _vp, C.c_int64]),
     "bl_grid_encode_lcm": (C.c_int64, [_vp, C.c_int64, _vp, C.c_int64]),
     "bl_sim_cast_beams": (C.c_int, [_vp, _vp, C.c_double, C.c_double, C.c_double, _vp, _vp, _vp, C.c_int, C.c_double, _vp]),
+    "bl_explorer_create": (C.c_int, [_vp, C.c_int, C.c_double, _P(_vp)]),
+    "bl_explorer_destroy": (None, [_vp]),
+    "bl_explorer_set_state": (C.c_int, [_vp, _P(Pose), _P(Pose)]),
+    "bl_explorer_submit": (C.c_int, [_vp, _vp, _vp]),
+    "bl_explorer_pending": (C.c_int, [_vp]),
+    "bl_explorer_fetch": (C.c_int, [_vp, _P(ExploreResult), _vp, C.c_int]),
+    "bl_explorer_frontiers": (C.c_int, [_vp, _P(_vp)]),
     "bl_plan_path_to_frontier": (C.c_int, [_vp, _vp, _P(Pose), _vp, _P(MotionPlannerState), _vp, C.c_int, _P(C.c_int), _P(Pose),
                                            _vp]),
 }

@@ -17,6 +17,10 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <chrono>
+#include <deque>
+#include <vector>
+
 #include "bl_internal.h"
 
 #define FR_T 1024
@@ -36,7 +40,15 @@ struct frontier_args {
     int phase;                  // k_frontiers: 0 flood + sweep (small grids), 1 flood only, 2 sweep only (and only if counts[8] is set)
     uint2* touch;               // (key, cell) of every frontier cell the flood touched, in no order; FR_TOUCH_MAX entries
     uint8_t* nb;                // large grids: per cell, the static classes of its four neighbours, 2 bits each (k_frontier_nb)
+    const bl_pose_xyt_t* d_pose; // the robot pose in device memory (then rx, ry are formed by every kernel that needs them), or null
+    bl_frame frame;
 };
+
+// robotCell = global_position_to_grid_cell(robotPose) (frontiers.cpp:39) when the pose lives on the device
+__device__ __forceinline__ void fr_robot_cell(frontier_args& a)
+{
+    if (a.d_pose) { const bl_pose_xyt_t rp = *a.d_pose; bl_global_to_cell((double)rp.x, (double)rp.y, a.frame, &a.rx, &a.ry); }
+}
 
 __device__ __forceinline__ unsigned int ld_claim(const unsigned int* p)
 {
@@ -107,6 +119,7 @@ __device__ __forceinline__ void fr_classify(const frontier_args& a, uint8_t* cls
 
 __global__ __launch_bounds__(256) void k_frontier_classify(frontier_args a)
 {
+    fr_robot_cell(a);
     const long long ncell = (long long)a.W * a.H;
     for (long long c = (long long)blockIdx.x * 256 + threadIdx.x; c < ncell; c += (long long)gridDim.x * 256) fr_classify(a, a.cls, c);
 }
@@ -197,6 +210,7 @@ __device__ __forceinline__ int fr_level_lds(const frontier_args& a, uint8_t* cls
 template <bool CLS_LDS>
 __global__ __launch_bounds__(FR_T) void k_frontiers(frontier_args a)
 {
+    fr_robot_cell(a);
     const long long t_begin = wall_clock64();
     extern __shared__ uint8_t s_cls[];
     __shared__ int s_wave[FR_T / 64];
@@ -765,6 +779,7 @@ __device__ __forceinline__ int fl_level_generic(const frontier_args& a, int* s_w
 
 __global__ __launch_bounds__(FL_T) void k_frontier_flood(frontier_args a)
 {
+    fr_robot_cell(a);
     const long long t_begin = wall_clock64();
     extern __shared__ __align__(16) uint8_t s_fl[];
     unsigned int* s_q0 = (unsigned int*)s_fl;                                  // [2][FL_QMAX]
@@ -974,11 +989,9 @@ void bl_frontier_scratch_free(bl_ctx* ctx)
     ctx->frontier = nullptr;
 }
 
-extern "C" int bl_frontiers_find(bl_ctx* ctx, const bl_grid* map, const bl_pose_xyt_t* robot_pose, double min_frontier_length,
-                                 bl_frontiers** out)
+// The kernels of one find_map_frontiers on ctx's stream, the robot pose from the host or read on the device; nothing waits.
+static int frontiers_launch(bl_ctx* ctx, const bl_grid* map, const bl_pose_xyt_t* robot_pose, const bl_pose_xyt_t* d_pose)
 {
-    BL_CHECK_ARG(ctx != nullptr && map != nullptr && robot_pose != nullptr && out != nullptr);
-    BL_CHECK_ARG(map->ctx == ctx);
     const int W = map->frame.width, H = map->frame.height;
     BL_CHECK_ARG(W >= 1 && H >= 1 && (int64_t)W * H < ((int64_t)1 << 28));          // claim keys are 4 * queue position + n
     BL_HIP(hipSetDevice(ctx->device));
@@ -1006,7 +1019,8 @@ extern "C" int bl_frontiers_find(bl_ctx* ctx, const bl_grid* map, const bl_pose_
     }
     frontier_args a;
     a.cells = map->cells; a.W = W; a.H = H;
-    bl_global_to_cell((double)robot_pose->x, (double)robot_pose->y, map->frame, &a.rx, &a.ry);      // :39
+    a.rx = a.ry = 0; a.d_pose = d_pose; a.frame = map->frame;
+    if (!d_pose) bl_global_to_cell((double)robot_pose->x, (double)robot_pose->y, map->frame, &a.rx, &a.ry);      // :39
     a.cls = s->cls; a.claim = s->claim; a.fclaim = s->fclaim; a.queue = s->queue;
     a.out_cells = s->out_cells; a.out_offsets = s->out_offsets; a.cap_frontiers = s->cap_frontiers; a.counts = s->counts;
     a.phase = 0; a.touch = s->touch; a.nb = s->nb;
@@ -1054,6 +1068,14 @@ extern "C" int bl_frontiers_find(bl_ctx* ctx, const bl_grid* map, const bl_pose_
     rc = bl_timer_end(ctx, BL_K_FRONTIERS, e0, e1);
     if (rc) return rc;
     BL_HIP(hipMemcpyAsync(s->h_counts, s->counts, 16 * 4, hipMemcpyDeviceToHost, ctx->stream));
+    return BL_OK;
+}
+
+// ... and their result, once the stream has run them (frontiers.cpp:66-72: the length filter; cell centres as global points)
+static int frontiers_collect(bl_ctx* ctx, const bl_frame& frame, double min_frontier_length, bl_frontiers** out)
+{
+    bl_frontier_scratch* s = ctx->frontier;
+    const int W = frame.width;
     BL_HIP(hipStreamSynchronize(ctx->stream));
     const int nf = s->h_counts[0], total = s->h_counts[1];
     if (getenv("BOTLAB_FRONTIER_STAMPS"))
@@ -1070,17 +1092,27 @@ extern "C" int bl_frontiers_find(bl_ctx* ctx, const bl_grid* map, const bl_pose_
     for (int k = 0; k < nf; ++k) {
         const int cnt = offs[k + 1] - offs[k];
         // f.cells.size() * map.metersPerCell() >= minFrontierLength: size_t * float -> float, compared as double (:69)
-        if (!((double)((float)(size_t)cnt * map->frame.mpc) >= min_frontier_length)) continue;
+        if (!((double)((float)(size_t)cnt * frame.mpc) >= min_frontier_length)) continue;
         for (int i = offs[k]; i < offs[k + 1]; ++i) {
             const int cx = cells[i] % W, cy = cells[i] / W;
             // grid_position_to_global_position(Point<int>) narrowed to Point<float> (grid_utils.hpp:14-19, frontiers.cpp:268)
-            f->xy.push_back((float)((double)map->frame.ox + (double)cx * (double)map->frame.mpc));
-            f->xy.push_back((float)((double)map->frame.oy + (double)cy * (double)map->frame.mpc));
+            f->xy.push_back((float)((double)frame.ox + (double)cx * (double)frame.mpc));
+            f->xy.push_back((float)((double)frame.oy + (double)cy * (double)frame.mpc));
         }
         f->offsets.push_back((int32_t)(f->xy.size() / 2));
     }
     *out = f;
     return BL_OK;
+}
+
+extern "C" int bl_frontiers_find(bl_ctx* ctx, const bl_grid* map, const bl_pose_xyt_t* robot_pose, double min_frontier_length,
+                                 bl_frontiers** out)
+{
+    BL_CHECK_ARG(ctx != nullptr && map != nullptr && robot_pose != nullptr && out != nullptr);
+    BL_CHECK_ARG(map->ctx == ctx);
+    int rc = frontiers_launch(ctx, map, robot_pose, nullptr);
+    if (rc) return rc;
+    return frontiers_collect(ctx, map->frame, min_frontier_length, out);
 }
 
 extern "C" int bl_frontiers_from_host(const int32_t* offsets, int count, const float* xy, bl_frontiers** out)
@@ -1114,3 +1146,192 @@ extern "C" int bl_frontiers_stats(const bl_frontiers* f, int* bfs_cells, int* bf
     return BL_OK;
 }
 extern "C" void bl_frontiers_destroy(bl_frontiers* f) { delete f; }
+
+// =============================================================================================== the exploration step on side streams
+// Exploration::executeExploringMap (src/planning/exploration.cpp:277-369) consumes every map the SLAM process publishes: setMap
+// (distance transform), find_map_frontiers, and -- when the robot is within 0.5 m of its target or has none -- plan_path_to_frontier.
+// bl_explorer is that arrangement on one device, as the replanner (bl_planner) is for a fixed goal: a submission snapshots the map
+// and the device-resident pose on the SLAM stream; a lane (a ctx with its own stream, distance grid and frontier scratch) runs
+// setDistances + the frontier kernels against the snapshot while the SLAM stream goes on; the fetch -- in submission order -- takes
+// the frontier lists to the host, applies the re-planning rule with the state the steps share (currentTarget_, currentPath_) and,
+// when a plan is due, runs plan_path_to_frontier on that lane.  One flood is one workgroup: the lanes' floods run side by side.
+#define EXPLORER_MAX_LANES 16
+struct explorer_lane {
+    bl_ctx* ctx; bl_dist* dist; bl_grid* snap;
+    bl_pose_xyt_t* d_pose; bl_pose_xyt_t* h_pose;      // the snapshot's pose: device, and pinned host copy
+    hipEvent_t snap_ready, t0, t1;
+    bool busy;
+};
+struct bl_explorer {
+    bl_ctx* main;
+    int lanes, next;
+    explorer_lane lane[EXPLORER_MAX_LANES];
+    std::deque<int>* order;                             // lanes with a submission, oldest first
+    bl_motion_planner_t planner;                        // MotionPlanner: robot radius, search parameters, num_frontiers, prev_goal
+    bl_pose_xyt_t target;                               // currentTarget_
+    std::vector<bl_pose_xyt_t>* path;                   // currentPath_
+    bl_frontiers* last;                                 // frontiers_ of the last fetched step
+    double min_frontier_length;
+};
+
+extern "C" int bl_explorer_create(bl_ctx* ctx, int lanes, double robot_radius, bl_explorer** out)
+{
+    BL_CHECK_ARG(ctx != nullptr && out != nullptr && lanes >= 1 && lanes <= EXPLORER_MAX_LANES && robot_radius > 0.0);
+    BL_HIP(hipSetDevice(ctx->device));
+    bl_explorer* e = new bl_explorer();
+    memset((void*)e, 0, sizeof(*e));
+    e->main = ctx; e->lanes = lanes;
+    e->order = new std::deque<int>();
+    e->path = new std::vector<bl_pose_xyt_t>();
+    e->min_frontier_length = 0.35;                      // kMinFrontierLength's default (frontiers.hpp:36)
+    // MotionPlanner(params) + setParams (motion_planner.cpp:9-16, 105-110): minDist = robotRadius, maxDist = 10 minDist, exponent 1
+    e->planner.robot_radius = robot_radius;
+    e->planner.search.minDistanceToObstacle = robot_radius;
+    e->planner.search.maxDistanceWithCost = 10.0 * robot_radius;
+    e->planner.search.distanceCostExponent = 1.0;
+    e->planner.num_frontiers = 1;
+    e->planner.prev_goal.x = 1e9f; e->planner.prev_goal.y = 1e9f;   // never set by the reference's exploration loop (D5)
+    for (int l = 0; l < lanes; ++l) {
+        explorer_lane& L = e->lane[l];
+        int rc = bl_ctx_create(ctx->device, nullptr, &L.ctx);
+        if (rc) return rc;
+        L.ctx->astar_small_lds = true;                  // its searches co-run with the SLAM stream's kernels
+        rc = bl_dist_create(L.ctx, &L.dist);
+        if (rc) return rc;
+        BL_HIP(hipMalloc((void**)&L.d_pose, sizeof(bl_pose_xyt_t)));
+        BL_HIP(hipHostMalloc((void**)&L.h_pose, sizeof(bl_pose_xyt_t), hipHostMallocDefault));
+        BL_HIP(hipEventCreateWithFlags(&L.snap_ready, hipEventDisableTiming));
+        BL_HIP(hipEventCreate(&L.t0));
+        BL_HIP(hipEventCreate(&L.t1));
+    }
+    *out = e;
+    return BL_OK;
+}
+
+extern "C" void bl_explorer_destroy(bl_explorer* e)
+{
+    if (!e) return;
+    (void)hipStreamSynchronize(e->main->stream);
+    for (int l = 0; l < e->lanes; ++l) {
+        explorer_lane& L = e->lane[l];
+        if (!L.ctx) continue;
+        (void)hipStreamSynchronize(L.ctx->stream);
+        if (L.snap) bl_grid_destroy(L.snap);
+        if (L.dist) bl_dist_destroy(L.dist);
+        if (L.d_pose) (void)hipFree(L.d_pose);
+        if (L.h_pose) (void)hipHostFree(L.h_pose);
+        if (L.snap_ready) (void)hipEventDestroy(L.snap_ready);
+        if (L.t0) (void)hipEventDestroy(L.t0);
+        if (L.t1) (void)hipEventDestroy(L.t1);
+        bl_ctx_destroy(L.ctx);
+    }
+    if (e->last) bl_frontiers_destroy(e->last);
+    delete e->order; delete e->path;
+    delete e;
+}
+
+extern "C" int bl_explorer_set_state(bl_explorer* e, const bl_pose_xyt_t* target, const bl_pose_xyt_t* prev_goal)
+{
+    BL_CHECK_ARG(e != nullptr);
+    if (target) e->target = *target;
+    if (prev_goal) e->planner.prev_goal = *prev_goal;
+    return BL_OK;
+}
+
+extern "C" int bl_explorer_submit(bl_explorer* e, const bl_grid* map, const void* d_pose)
+{
+    BL_CHECK_ARG(e != nullptr && map != nullptr && d_pose != nullptr && map->ctx == e->main);
+    explorer_lane& L = e->lane[e->next];
+    if (L.busy) { bl_set_error("every explorer lane holds a submission: fetch first"); return BL_ERR_STATE; }
+    BL_HIP(hipSetDevice(e->main->device));
+    if (L.snap && (L.snap->frame.width != map->frame.width || L.snap->frame.height != map->frame.height)) { bl_grid_destroy(L.snap); L.snap = nullptr; }
+    if (!L.snap) {
+        int rc = bl_grid_create(L.ctx, map->frame.width, map->frame.height, map->frame.mpc, map->frame.cpm, map->frame.ox, map->frame.oy, &L.snap);
+        if (rc) return rc;
+        BL_HIP(hipStreamSynchronize(L.ctx->stream));    // its zero-fill ran on the lane's stream
+    }
+    L.snap->frame = map->frame;
+    L.snap->mirror_valid = false;
+    // (the lane is idle: its last submission has been fetched, and a fetch leaves nothing behind on the lane's stream)
+    int rc = bl_snapshot_enqueue(e->main, map, L.snap, d_pose, L.d_pose, nullptr, nullptr, 0ull);
+    if (rc) return rc;
+    BL_HIP(hipEventRecord(L.snap_ready, e->main->stream));
+    BL_HIP(hipStreamWaitEvent(L.ctx->stream, L.snap_ready, 0));
+    rc = bl_dist_set_distances(L.dist, L.snap);         // planner_.setMap(currentMap_) (:299)
+    if (rc) return rc;
+    BL_HIP(hipEventRecord(L.t0, L.ctx->stream));
+    rc = frontiers_launch(L.ctx, L.snap, nullptr, L.d_pose);   // find_map_frontiers(currentMap_, currentPose_) (:300)
+    if (rc) return rc;
+    BL_HIP(hipEventRecord(L.t1, L.ctx->stream));
+    BL_HIP(hipMemcpyAsync(L.h_pose, L.d_pose, sizeof(bl_pose_xyt_t), hipMemcpyDeviceToHost, L.ctx->stream));
+    L.busy = true;
+    e->order->push_back(e->next);
+    e->next = (e->next + 1) % e->lanes;
+    return BL_OK;
+}
+
+extern "C" int bl_explorer_pending(const bl_explorer* e) { return e ? (int)e->order->size() : 0; }
+
+extern "C" int bl_explorer_fetch(bl_explorer* e, bl_explore_result_t* out, bl_pose_xyt_t* out_path, int cap)
+{
+    BL_CHECK_ARG(e != nullptr && out != nullptr && (cap == 0 || out_path != nullptr) && cap >= 0);
+    if (e->order->empty()) { bl_set_error("no exploration step pending"); return BL_ERR_STATE; }
+    const int l = e->order->front();
+    e->order->pop_front();
+    explorer_lane& L = e->lane[l];
+    memset(out, 0, sizeof(*out));
+    bl_frontiers* fr = nullptr;
+    int rc = frontiers_collect(L.ctx, L.snap->frame, e->min_frontier_length, &fr);      // (waits for the lane's stream)
+    L.busy = false;
+    if (rc) return rc;
+    if (e->last) bl_frontiers_destroy(e->last);
+    e->last = fr;
+    float fms = 0.0f;
+    (void)hipEventElapsedTime(&fms, L.t0, L.t1);
+    const bl_pose_xyt_t pose = *L.h_pose;
+    const int nf = (int)fr->offsets.size() - 1;
+    e->planner.num_frontiers = nf;                                                       // planner_.setNumFrontiers (:302)
+    // :307-311 -- sqrt(pow(dx, 2) + pow(dy, 2)) in double from float differences, stored to a float
+    float currDist = 0.0f;
+    if (e->target.x != 0 || e->target.y != 0) {
+        const double dx = (double)(pose.x - e->target.x), dy = (double)(pose.y - e->target.y);
+        currDist = (float)std::sqrt(dx * dx + dy * dy);
+    }
+    int64_t st[3] = {0, 0, 0};
+    double plan_ms = 0.0;
+    if (currDist <= 0.5f && nf > 0) {                                                    // :316-321
+        const auto w0 = std::chrono::steady_clock::now();
+        std::vector<bl_pose_xyt_t> buf((size_t)1 << 16);
+        int len = 0;
+        bl_pose_xyt_t goal;
+        rc = bl_plan_path_to_frontier(L.ctx, fr, &pose, L.dist, &e->planner, buf.data(), (int)buf.size(), &len, &goal, st);
+        if (rc) return rc;
+        if (len > (int)buf.size()) { bl_set_error("path of %d poses does not fit", len); return BL_ERR_CAPACITY; }
+        e->path->assign(buf.begin(), buf.begin() + len);
+        if (len > 1) e->target = (*e->path)[(size_t)len - 1];
+        out->planned = 1;
+        plan_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - w0).count();
+    }
+    // :335-368 (D10: the status the reference leaves unset when frontiers remain but no path was found is FAILED)
+    const int path_len = (int)e->path->size();
+    out->status = nf == 0 ? 1 : (path_len > 1 ? 0 : 2);                                   // COMPLETE / IN_PROGRESS / FAILED
+    out->next_state = out->status == 0 ? 1 : (out->status == 1 ? 2 : 4);                  // EXPLORING_MAP / RETURNING_HOME / FAILED_EXPLORATION
+    out->num_frontiers = nf;
+    out->frontier_cells = (int)(fr->xy.size() / 2);
+    out->path_length = path_len;
+    out->pops = st[0]; out->pushes = st[1]; out->searches = st[2];
+    out->bfs_cells = fr->bfs_cells; out->bfs_levels = fr->bfs_levels;
+    out->pose = pose; out->target = e->target;
+    out->frontiers_ms = fms; out->plan_ms = (float)plan_ms;
+    for (int i = 0; i < path_len && i < cap; ++i) out_path[i] = (*e->path)[(size_t)i];
+    return BL_OK;
+}
+
+// frontiers_ of the last fetched step (a copy the caller owns)
+extern "C" int bl_explorer_frontiers(const bl_explorer* e, bl_frontiers** out)
+{
+    BL_CHECK_ARG(e != nullptr && out != nullptr);
+    if (!e->last) { bl_set_error("no exploration step fetched yet"); return BL_ERR_STATE; }
+    *out = new bl_frontiers(*e->last);
+    return BL_OK;
+}

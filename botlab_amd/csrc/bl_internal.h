@@ -127,6 +127,10 @@ void bl_grid_adopt_lineage(bl_grid* snap, const bl_grid* src);   // snap's cells
 // a map update is about to be enqueued on g: its log entry (null when the log cannot be had) and the version it will carry
 int4* bl_grid_log_next(bl_grid* g, uint64_t* version);
 
+// bl_planning.hip: map + device pose snapshot on main's stream (whole grid, or the dirty cells when snap holds an earlier version)
+int bl_snapshot_enqueue(struct bl_ctx* main, const bl_grid* map, bl_grid* snap, const void* d_pose, bl_pose_xyt_t* snap_pose,
+                        unsigned int* done_count, unsigned long long* flag, unsigned long long seq);
+
 // where a replanner submission wants its map + pose snapshot, and the number to publish in *flag when it is complete
 struct bl_planner_snap {
     bl_grid* grid;                    // the snapshot grid itself (its lineage is set once the copy is enqueued)

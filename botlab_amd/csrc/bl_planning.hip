@@ -2590,6 +2590,39 @@ __global__ __launch_bounds__(256) void k_planner_snapshot_inc(const int8_t* __re
     }
 }
 
+// Map + pose snapshot on main's stream into a grid of the same size (the whole grid, or -- when `snap` still holds an earlier
+// version of this very map -- the cells the updates in between may have changed); the snapshot then carries the map's lineage.
+// flag / done_count / seq: the replanner's flag hand-over (null / 0: none).
+int bl_snapshot_enqueue(bl_ctx* main, const bl_grid* map, bl_grid* snap, const void* d_pose, bl_pose_xyt_t* snap_pose,
+                        unsigned int* done_count, unsigned long long* flag, unsigned long long seq)
+{
+    const size_t n = (size_t)map->frame.width * map->frame.height;
+    hipEvent_t f0, f1;
+    int rc = bl_timer_begin(main, BL_K_SNAPSHOT, &f0, &f1);
+    if (rc) return rc;
+    static const bool no_inc = getenv("BOTLAB_SNAPSHOT_NO_INCREMENTAL") != nullptr;
+    const bl_grid* old = snap;
+    const bool inc = !no_inc && !flag && old->id != 0 && old->id == map->id && !map->mirror_external && map->log != nullptr &&
+                     old->version <= map->version && map->version - old->version <= (uint64_t)(BL_DIRTY_LOG - 64) &&
+                     (map->frame.width & 15) == 0 && n >= ((size_t)1 << 20);
+    if (inc) {
+        hipLaunchKernelGGL(k_planner_snapshot_inc, dim3(SNAP_INC_WGS), dim3(256), 0, main->stream, map->cells, snap->cells, map->frame.width,
+                           map->frame.height, map->log->dev, (unsigned int)old->version, (unsigned int)map->version,
+                           (const bl_pose_xyt_t*)d_pose, snap_pose);
+    } else {
+        int blocks = (int)((n / 16 + 255) / 256);
+        if (blocks < 1) blocks = 1;
+        if (blocks > 2048) blocks = 2048;
+        hipLaunchKernelGGL(k_planner_snapshot, dim3(blocks), dim3(256), 0, main->stream, map->cells, snap->cells, n,
+                           (const bl_pose_xyt_t*)d_pose, snap_pose, done_count, flag, seq);
+    }
+    BL_HIP(hipGetLastError());
+    rc = bl_timer_end(main, BL_K_SNAPSHOT, f0, f1);
+    if (rc) return rc;
+    bl_grid_adopt_lineage(snap, map);                  // the snapshot holds this version of the map
+    return BL_OK;
+}
+
 extern "C" int bl_planner_submit(bl_planner* p, const bl_grid* map, const void* d_start_pose, const bl_pose_xyt_t* goal,
                                  const bl_search_params_t* params)
 {
@@ -2597,30 +2630,8 @@ extern "C" int bl_planner_submit(bl_planner* p, const bl_grid* map, const void* 
     bl_planner_snap sn;
     int rc = bl_planner_reserve(p, map, &sn);
     if (rc) return rc;
-    const size_t n = (size_t)map->frame.width * map->frame.height;
-    hipEvent_t f0, f1;
-    rc = bl_timer_begin(p->main, BL_K_SNAPSHOT, &f0, &f1);
+    rc = bl_snapshot_enqueue(p->main, map, sn.grid, d_start_pose, sn.pose, sn.done_count, sn.flag, sn.seq);
     if (rc) return rc;
-    static const bool no_inc = getenv("BOTLAB_SNAPSHOT_NO_INCREMENTAL") != nullptr;
-    const bl_grid* old = sn.grid;
-    const bool inc = !no_inc && !sn.flag && old->id != 0 && old->id == map->id && !map->mirror_external && map->log != nullptr &&
-                     old->version <= map->version && map->version - old->version <= (uint64_t)(BL_DIRTY_LOG - 64) &&
-                     (map->frame.width & 15) == 0 && n >= ((size_t)1 << 20);
-    if (inc) {
-        hipLaunchKernelGGL(k_planner_snapshot_inc, dim3(SNAP_INC_WGS), dim3(256), 0, p->main->stream, map->cells, sn.cells, map->frame.width,
-                           map->frame.height, map->log->dev, (unsigned int)old->version, (unsigned int)map->version,
-                           (const bl_pose_xyt_t*)d_start_pose, sn.pose);
-    } else {
-        int blocks = (int)((n / 16 + 255) / 256);
-        if (blocks < 1) blocks = 1;
-        if (blocks > 2048) blocks = 2048;
-        hipLaunchKernelGGL(k_planner_snapshot, dim3(blocks), dim3(256), 0, p->main->stream, map->cells, sn.cells, n,
-                           (const bl_pose_xyt_t*)d_start_pose, sn.pose, sn.done_count, sn.flag, sn.seq);
-    }
-    BL_HIP(hipGetLastError());
-    rc = bl_timer_end(p->main, BL_K_SNAPSHOT, f0, f1);
-    if (rc) return rc;
-    bl_grid_adopt_lineage(sn.grid, map);               // the snapshot holds this version of the map
     return bl_planner_commit(p, goal, params);
 }
 

@@ -587,6 +587,47 @@ class ExploringMap:
                 STATUS_FAILED: STATE_FAILED_EXPLORATION}[self.status]                # :352-368
 
 
+class AsyncExplorer:
+    """bl_explorer: ExploringMap's step (exploration.cpp:277-369) on side streams -- submit(map, device pose) snapshots both on
+    the SLAM stream; a lane runs setMap + find_map_frontiers against the snapshot; fetch() hands the steps back in order and
+    applies the 0.5 m re-planning rule with the state they share, running plan_path_to_frontier on that lane when it is due."""
+
+    def __init__(self, ctx=None, lanes=1, robotRadius=0.2):
+        self.ctx = ctx or default_context()
+        self.lanes = int(lanes)
+        h = C.c_void_p()
+        check(self.ctx.lib.bl_explorer_create(self.ctx.h, self.lanes, float(robotRadius), C.byref(h)))
+        self.h = h
+        self._buf = (Pose * 65536)()
+
+    def submit(self, grid, pose_dev):
+        check(self.ctx.lib.bl_explorer_submit(self.h, grid.h, pose_dev))
+
+    def pending(self):
+        return self.ctx.lib.bl_explorer_pending(self.h)
+
+    def fetch(self, want_path=True):
+        """-> (bl_explore_result_t as _capi.ExploreResult, currentPath_ as a list of poses or None)"""
+        r = _capi.ExploreResult()
+        check(self.ctx.lib.bl_explorer_fetch(self.h, C.byref(r), self._buf, 65536 if want_path else 0))
+        path = [Pose(p.utime, p.x, p.y, p.theta) for p in self._buf[:min(r.path_length, 65536)]] if want_path else None
+        return r, path
+
+    def frontiers(self):
+        h = C.c_void_p()
+        check(self.ctx.lib.bl_explorer_frontiers(self.h, C.byref(h)))
+        return Frontiers(self.ctx, h)
+
+    def setState(self, target=None, prev_goal=None):
+        check(self.ctx.lib.bl_explorer_set_state(self.h, C.byref(target) if target is not None else None,
+                                                 C.byref(prev_goal) if prev_goal is not None else None))
+
+    def close(self):
+        if self.h:
+            self.ctx.lib.bl_explorer_destroy(self.h)
+            self.h = None
+
+
 class AsyncPlanner:
     """bl_planner: MotionPlanner.setMap + planPath run on a second stream against a snapshot of the map and of the
     device-resident pose (the reference's planner process, src/planning/exploration.cpp:300-317)."""

@@ -396,6 +396,37 @@ int bl_plan_path_to_frontier(bl_ctx* ctx, const bl_frontiers* frontiers, const b
                              const bl_motion_planner_t* planner, bl_pose_xyt_t* out_path, int cap, int* out_len,
                              bl_pose_xyt_t* chosen_goal, int64_t* stats);
 
+
+/* ------------------------------------------------------------------ the exploration step, asynchronously  (src/planning/exploration.cpp:277-369)
+ * Exploration::executeExploringMap on every published map: planner_.setMap, find_map_frontiers, and -- when the robot is within
+ * 0.5 m of currentTarget_ or has none -- plan_path_to_frontier; then the status / next-state rule (:332-368; D10).  A submission
+ * snapshots the map and the device-resident pose on ctx's stream; one of `lanes` side streams runs the distance transform and the
+ * frontier search against the snapshot; bl_explorer_fetch hands back the steps in submission order and applies the rule with the
+ * state consecutive steps share (currentTarget_, currentPath_), running plan_path_to_frontier on that lane when it is due.  At
+ * most `lanes` submissions may be pending. */
+typedef struct bl_explorer bl_explorer;
+typedef struct {
+    int32_t next_state;      /* exploration_status_t: 1 EXPLORING_MAP, 2 RETURNING_HOME, 4 FAILED_EXPLORATION */
+    int32_t status;          /* 0 IN_PROGRESS, 1 COMPLETE, 2 FAILED */
+    int32_t num_frontiers;   /* frontiers_.size() */
+    int32_t frontier_cells;
+    int32_t planned;         /* 1: plan_path_to_frontier ran in this step */
+    int32_t path_length;     /* currentPath_.path_length after the step */
+    int64_t pops, pushes, searches;   /* of this step's plan_path_to_frontier */
+    int32_t bfs_cells, bfs_levels;    /* free cells the frontier search flooded, and its depth */
+    bl_pose_xyt_t pose;      /* currentPose_ of the step (the snapshot's) */
+    bl_pose_xyt_t target;    /* currentTarget_ after the step */
+    float frontiers_ms;      /* device time of find_map_frontiers' kernels */
+    float plan_ms;           /* host wall time of plan_path_to_frontier (0 when it did not run) */
+} bl_explore_result_t;
+int bl_explorer_create(bl_ctx* ctx, int lanes, double robot_radius, bl_explorer** out);  /* lanes 1..16; MotionPlannerParams::robotRadius (a double: motion_planner.hpp:27-35) */
+void bl_explorer_destroy(bl_explorer* e);
+int bl_explorer_set_state(bl_explorer* e, const bl_pose_xyt_t* target, const bl_pose_xyt_t* prev_goal);   /* currentTarget_ / setPrevGoal; null: unchanged */
+int bl_explorer_submit(bl_explorer* e, const bl_grid* map, const void* d_pose);          /* d_pose: bl_pose_xyt_t in HBM (e.g. bl_pf_pose_device_ptr) */
+int bl_explorer_pending(const bl_explorer* e);
+int bl_explorer_fetch(bl_explorer* e, bl_explore_result_t* out, bl_pose_xyt_t* out_path, int cap);   /* out_path: currentPath_, up to cap poses */
+int bl_explorer_frontiers(const bl_explorer* e, bl_frontiers** out);                     /* frontiers_ of the last fetched step (caller destroys) */
+
 #ifdef __cplusplus
 }
 #endif
