@@ -32,6 +32,8 @@ EVENT_STRIDE = 7                 # every 7th k_mcl_main launch of the timed regi
                                  # time); 7 shares no factor with the replanner batches (4, 8): 8 sampled the launches a lane's burst of
                                  # distance transforms runs beside, every time (0.075 ms against 0.066 in the trace of all launches)
 EVENT_STRIDE_LONG = 17           # ... runs of more than 400 steps: the events of every 7th launch cost 1 % of the steps/s (10 860 against 10 965 without any)
+EVENT_STRIDE_SHORT_RUN = 1       # ... runs of at most 50 steps (the driver's 20): every launch, or the roofline leg rests on three samples
+EXPLORE_EVERY = 5                # one exploration step per published map = every 5th SLAM step (slam.cpp:284-289, exploration.cpp:300-317)
 
 
 def load_map(name):
@@ -42,6 +44,31 @@ def load_map(name):
 def build_inputs(args, total_steps, ctx=None):
     from botlab_amd import synth
     m = load_map(args.map)
+    if getattr(args, "explore", False):
+        # The exploration loop's world: the shipped obstacle_slam arena in every 200-cell tile, sealed (whatever the shipped map does
+        # not know to be free is solid), so that the explored region stays an arena of the reference's own size: with the reference's
+        # cost function plan_path_to_frontier costs ~100 pops per explored free cell (1e6 on this arena; an open hall of 7.5 m
+        # radius overflows a 1.2e7-pop open list -- tests/test_gpu_exploring_map_large.py).  The map starts with the centre
+        # tile's arena known up to column 110 and everything else unknown.
+        arena = load_map("obstacle_slam_10mx10m_5cm")["cells"]
+        G = args.grid
+        reps = (G + 199) // 200
+        truth = np.tile(np.where(arena < 0, -127, 127).astype(np.int8), (reps, reps))[:G, :G].copy()
+        truth[0, :] = truth[-1, :] = 127
+        truth[:, 0] = truth[:, -1] = 127
+        t0 = (G // 2 // 200) * 200
+        cells = np.zeros((G, G), np.int8)
+        a = arena.copy()
+        a[:, 110:] = 0
+        cells[t0:t0 + 200, t0:t0 + 200] = a
+        half = G * 0.05 / 2.0
+        origin = (np.float32(-half), np.float32(-half))
+        off = (float(origin[0]) + t0 * 0.05 + 5.0, float(origin[1]) + t0 * 0.05 + 5.0)
+        m = dict(cells=cells, origin=origin, mpc=np.float32(0.05))
+        start = (-0.75 + off[0], 0.2 + off[1], 0.0)
+        rands = np.random.default_rng(99).integers(0, 2**31 - 1, size=total_steps + 4)
+        poses, odo, scans = record_exploration(args, total_steps, ctx, m, truth, start, rands)
+        return m, truth, poses, odo, scans, rands
     if args.grid != 200:
         cells = synth.tile_world(load_map("astar_maze")["cells"], args.grid)
         half = args.grid * 0.05 / 2.0
@@ -73,6 +100,76 @@ def build_inputs(args, total_steps, ctx=None):
                                             max_range=max_range, noise_sigma=0.005, rng=rng))
     rands = np.random.default_rng(99).integers(0, 2**31 - 1, size=total_steps + 4)
     return m, truth, poses, odo, scans, rands
+
+
+def record_exploration(args, total_steps, ctx, m, truth, start, rands):
+    """The inputs of an exploration run are not known in advance: the robot drives where plan_path_to_frontier sends it, and that
+    depends on the map the SLAM loop has built so far.  So the loop is run ONCE here, untimed and synchronously -- scan cast from
+    the truth world at the robot's pose, filter update, map update, on every 5th step the exploration step, the robot then
+    following currentPath_ at 0.02 m (or 0.05 rad) per step as the reference's motion controller would -- and its scans and
+    odometry are recorded.  The timed run replays them through the pipelined loop: the filter and the map are deterministic, so
+    the exploration steps meet the same maps and poses and take the same decisions, at the rate a real exploration takes them."""
+    import botlab_amd as bl
+    from botlab_amd import synth
+    cpm = np.float32(1.0 / np.float64(np.float32(0.05)))
+    rng = np.random.default_rng(1234)
+    origin, mpc = m["origin"], float(m["mpc"])
+    max_range = getattr(args, "max_range", synth.MAX_RANGE)
+    grid = bl.OccupancyGrid.from_cells(m["cells"], origin, m["mpc"], cellsPerMeter=cpm, ctx=ctx)
+    mapper = bl.Mapping(5.0, 4, 1, ctx=ctx)
+    pf = bl.ParticleFilter(args.particles, ctx=ctx)
+    ex = bl.AsyncExplorer(ctx=ctx, lanes=1, robotRadius=0.2)
+    pose = np.array(start, dtype=np.float64)
+    poses, odo, scans = [pose.copy()], [pose.copy()], []
+    path, wp = [], 0
+    plans = 0
+    t_rec = time.perf_counter()
+    for k in range(total_steps):
+        # ---- the robot's motion of this step: along the path, turning in place towards the next waypoint first
+        nxt = pose.copy()
+        while wp < len(path) and np.hypot(path[wp][0] - pose[0], path[wp][1] - pose[1]) < 0.02:
+            wp += 1
+        if wp < len(path):
+            dx, dy = path[wp][0] - pose[0], path[wp][1] - pose[1]
+            want = np.arctan2(dy, dx)
+            dth = np.arctan2(np.sin(want - pose[2]), np.cos(want - pose[2]))
+            if abs(dth) > 0.05:
+                nxt[2] = pose[2] + np.sign(dth) * 0.05
+            else:
+                step = min(0.02, float(np.hypot(dx, dy)))
+                nxt[:] = (pose[0] + step * np.cos(want), pose[1] + step * np.sin(want), want)
+        else:
+            nxt[2] = pose[2] + 0.05                           # no path (yet, or any more): look around
+        nxt[2] = np.arctan2(np.sin(nxt[2]), np.cos(nxt[2]))
+        sc = synth.raycast_scan(truth, origin, mpc, pose, nxt, 1_000_000 + (k + 1) * 100_000, max_range=max_range, noise_sigma=0.005, rng=rng)
+        # odometry: the truth motion + drift, accumulated in the odometry frame (synth.odometry_from_truth, one step)
+        d = nxt - pose
+        dist_ = float(np.hypot(d[0], d[1]))
+        head = np.arctan2(d[1], d[0]) - pose[2] if dist_ > 1e-12 else 0.0
+        dth_ = np.arctan2(np.sin(d[2]), np.cos(d[2]))
+        dist_n = dist_ + (rng.normal(0, 1e-3) if dist_ > 0 else 0.0)
+        dth_n = dth_ + rng.normal(0, 3e-3)
+        po = odo[-1]
+        odo.append(np.array([po[0] + dist_n * np.cos(po[2] + head), po[1] + dist_n * np.sin(po[2] + head),
+                             np.arctan2(np.sin(po[2] + dth_n), np.cos(po[2] + dth_n))]))
+        poses.append(nxt.copy())
+        scans.append(sc)
+        pose = nxt
+        # ---- the SLAM step and, on every 5th, the exploration step
+        if k == 0:
+            pf.initializeFilterAtPose(bl.make_pose(*odo[0], utime=int(scans[0].times[0])), seed=42)
+        oo = odo[-1]
+        est = pf.updateFilter(bl.make_pose(oo[0], oo[1], oo[2], utime=sc.utime), sc, grid, rand_value=int(rands[k]))
+        mapper.updateMap(sc, est, grid)
+        if k % EXPLORE_EVERY == 0:
+            ex.submit(grid, pf.poseDevicePtr())
+            r, pth = ex.fetch()
+            if r.planned and r.path_length > 1:
+                path, wp = [(q.x, q.y) for q in pth], 1
+                plans += 1
+    sys.stderr.write(f"[bench] exploration recorded: {total_steps} steps, {plans} plans, {time.perf_counter() - t_rec:.1f} s\n")
+    ex.close(); pf.close(); mapper.close(); grid.close()
+    return poses, odo, scans
 
 
 def pick_goal(dist_cells, origin, start_xy, radius, max_l1_cells):
@@ -161,9 +258,16 @@ OTHER_CONFIGS = [                                      # (preset, goal_l1 in cel
     (0, 0, ["--no-astar", "--start", "0", "0", "0"]),  # ... from the reference's own start pose (slam.cpp:64-66), where the float sums of
                                                        # estimatePosteriorPose hover around zero: what that costs a step.
                                                        # (no replan: from there the reference's search to a point 0.4 m ahead takes 9e4 pops)
-    (3, 0, []), (4, 40, []), (4, 400, []), (5, 40, []),    # preset 3 (1M particles on one GPU) has no replan: its goal is unused
+    (3, 0, []), (4, 40, []), (4, 400, []),                 # preset 3 (1M particles on one GPU) has no replan: its goal is unused
+    (5, 0, []),                                            # BASELINE.json configs[4] as written: SLAM + the exploration step on every 5th map
+    (5, 0, ["--explore-mode", "newest-map"]),              # ... with the reference's process arrangement: SLAM never waits for the explorer
+    (5, 40, ["--fixed-goal"]),                             # ... and its fixed-goal form (SLAM + a replan per step), as in earlier rounds
+    (0, 0, ["--particles", "1000"]), (0, 0, ["--particles", "10000"]),          # north_star's particle sweep below the headline's 100k
+    # closed-loop latency: every step's pose and path fetched before the next step is enqueued (slam.cpp:191-207 is synchronous per scan)
+    (0, 0, ["--depth", "0", "--lanes", "1", "--batch", "1", "--sync-steps", "200"]),
+    (4, 400, ["--depth", "0", "--lanes", "1", "--batch", "1", "--sync-steps", "200"]),
 ]
-OTHER_BUDGET_S = 240.0                                 # wall clock all of them together may take: a slow or hung child costs the others, never the headline
+OTHER_BUDGET_S = 330.0                                 # wall clock all of them together may take: a slow or hung child costs the others, never the headline
 
 
 def run_other_configs(steps, warmup):
@@ -182,7 +286,12 @@ def run_other_configs(steps, warmup):
         if left < 10.0:
             out.append({"config": cfg, "goal_l1_cells": l1, "flags": extra, "error": "skipped: the other_configs wall-clock budget was spent"})
             continue
-        cmd = [sys.executable, os.path.abspath(__file__), "--config", str(cfg), "--goal-l1", str(max(l1, 1)), "--steps", str(steps), "--warmup", str(warmup),
+        child_steps = steps
+        if "--sync-steps" in extra:
+            i = extra.index("--sync-steps")
+            child_steps = int(extra[i + 1])
+            extra = extra[:i] + extra[i + 2:]
+        cmd = [sys.executable, os.path.abspath(__file__), "--config", str(cfg), "--goal-l1", str(max(l1, 1)), "--steps", str(child_steps), "--warmup", str(warmup),
                "--cpu-steps", "0", "--sub"] + extra
         t0 = time.perf_counter()
         try:
@@ -196,7 +305,8 @@ def run_other_configs(steps, warmup):
             out.append({"config": cfg, "goal_l1_cells": l1, "flags": extra, "workload": d["config"]["workload"], "value": d["value"], "unit": d["unit"],
                         "steps": d["steps"], "warmup": d["warmup"], "ms_per_step": d["ms_per_step"], "astar_pops_per_step": d["astar_pops_per_step"],
                         "stage_ms": d["stage_ms"], "planner": [d["config"]["planner_lanes"], d["config"]["planner_batch"], d["config"]["pipeline_depth"]],
-                        "streaming_kernels": d.get("streaming_kernels"), "wall_s": round(time.perf_counter() - t0, 1)})
+                        "streaming_kernels": d.get("streaming_kernels"), "explore": d.get("explore"), "particles": d["config"]["particles"],
+                        "wall_s": round(time.perf_counter() - t0, 1)})
         except subprocess.TimeoutExpired:
             out.append({"config": cfg, "goal_l1_cells": l1, "flags": extra, "error": "timed out"})
     return out
@@ -266,6 +376,17 @@ def main():
     ap.add_argument("--config", type=int, default=0, choices=[0, 2, 3, 4, 5],
                     help="BASELINE.json configs[i - 1] as a preset (0/2: the default, configs[1]; 3: 1M-particle MCL, no replan; "
                          "4: 2000x2000 maze with a replan per step; 5: 4096x4096, 256k particles); explicit flags still win")
+    ap.add_argument("--explore", action="store_true", help="the exploration loop (BASELINE.json configs[4]): instead of a replan to a fixed goal, every "
+                    "5th step submits Exploration::executeExploringMap's step -- setMap + find_map_frontiers + plan_path_to_frontier under the "
+                    "0.5 m rule -- to the explorer lanes (preset 5 turns it on)")
+    ap.add_argument("--fixed-goal", action="store_true", help="preset 5 without the exploration step: SLAM + a replan to a fixed goal per step")
+    ap.add_argument("--explore-lanes", type=int, default=4, help="explorer side streams: exploration steps of consecutive maps overlap")
+    ap.add_argument("--explore-mode", choices=["every-map", "newest-map"], default="every-map",
+                    help="every-map: every published map gets its exploration step; the SLAM thread takes finished steps back itself and "
+                         "waits when all lanes are busy (a plan_path_to_frontier of seconds stalls it).  newest-map: the reference's "
+                         "arrangement -- the exploration process is a separate LCM subscriber that works on the newest map it has when it "
+                         "is free (exploration.cpp:93-109, 296-298) and the SLAM process never waits for it: a second host thread takes the "
+                         "steps back, and a map published while every lane is busy is not explored (counted)")
     ap.add_argument("--sub", action="store_true", help="a child run of the default invocation (other_configs): no children of its own")
     ap.add_argument("--no-other-configs", action="store_true", help="default run: skip the short runs of configs 4 and 5")
     ap.add_argument("--other-steps", type=int, default=1000, help="timed steps of each other_configs run")
@@ -276,6 +397,10 @@ def main():
     for key, val in presets.get(args.config, {}).items():
         if getattr(args, key) == ap.get_default(key):
             setattr(args, key, val)
+    if args.config == 5 and not args.fixed_goal:
+        args.explore = True
+    if args.explore:
+        args.no_astar = True                       # the exploration step is the planner's work; no fixed-goal replan beside it
 
     # stdout carries ONE JSON line: anything native code prints there (RCCL writes a version banner to stdout when its first
     # communicator comes up) goes to stderr instead
@@ -360,6 +485,8 @@ def main():
     goal_pose = bl.make_pose(goal[0], goal[1], 0.0) if goal else None
 
     spf.initializeFilterAtPose(bl.make_pose(*odo[0], utime=int(scans[0].times[0])), seed=42)
+    explorer = bl.AsyncExplorer(ctx=ctx, lanes=args.explore_lanes, robotRadius=0.2) if args.explore else None
+    ex_log = []                       # one entry per fetched exploration step
 
     if goal_pose is not None:
         # setup, not measurement: every replanner unit creates its scratch (open-list heap, snapshot grids, result slots) on
@@ -379,6 +506,48 @@ def main():
     ride_finish = not os.environ.get("BENCH_NO_RIDE")
     in_flight = []                  # steps enqueued whose result has not been fetched yet
 
+    def explore_fetch():
+        r, _ = explorer.fetch(want_path=False)
+        ex_log.append((r.status, r.num_frontiers, r.frontier_cells, r.planned, r.pops, r.searches, r.path_length, r.bfs_cells, r.bfs_levels,
+                       r.frontiers_ms, r.plan_ms))
+
+    ex_skipped = [0]
+    ex_thread = [None]
+    ex_outstanding = [0]              # newest-map mode: submissions the worker thread has not taken back yet
+    import threading
+    ex_cv = threading.Condition()
+
+    def explore_worker():
+        while True:
+            with ex_cv:
+                while ex_outstanding[0] == 0:
+                    ex_cv.wait()
+                if ex_outstanding[0] < 0:
+                    return
+            explore_fetch()               # (the library call releases the interpreter lock)
+            with ex_cv:
+                ex_outstanding[0] -= 1
+                ex_cv.notify_all()
+
+    def explore_submit():
+        if args.explore_mode == "newest-map":
+            if ex_thread[0] is None:
+                ex_thread[0] = threading.Thread(target=explore_worker, daemon=True)
+                ex_thread[0].start()
+            if explorer.pending() >= args.explore_lanes:
+                ex_skipped[0] += 1        # the explorer is busy (planning): this map is not explored
+                return
+            explorer.submit(grid, pose_dev)
+            with ex_cv:
+                ex_outstanding[0] += 1
+                ex_cv.notify_all()
+            return
+        # every-map: the published map and the pose of this step go to an explorer lane; the oldest step is taken back first when
+        # every lane holds one (its plan_path_to_frontier, when due, runs inside that fetch: the host waits, the SLAM stream runs on)
+        while explorer.pending() >= args.explore_lanes:
+            explore_fetch()
+        explorer.submit(grid, pose_dev)
+
     def enqueue(k):
         # Everything of one step is enqueued on the ctx stream; the pose estimate stays on the device and feeds the map
         # update and the A* start there.
@@ -395,6 +564,8 @@ def main():
                 aplanner.submit_with_map_update_finishing(mapper, sc, engine.pf, sc.utime, grid, goal_pose)
             else:
                 mapper.updateMapFinishingFilter(sc, engine.pf, sc.utime, grid)
+            if explorer is not None and k % EXPLORE_EVERY == 0:
+                explore_submit()
             in_flight.append(k)
             return
         spf.updateFilter(odo_pose, sc, grid, int(rands[k]), want_pose=False)
@@ -406,6 +577,8 @@ def main():
             aplanner.submit_with_map_update(mapper, sc, pose_dev, sc.utime, grid, goal_pose)
         else:
             mapper.updateMapDevicePose(sc, pose_dev, sc.utime, grid)
+        if explorer is not None and k % EXPLORE_EVERY == 0:
+            explore_submit()
         in_flight.append(k)
 
     last_pose = [None]
@@ -442,6 +615,12 @@ def main():
         return last
 
     def drain():
+        if explorer is not None and args.explore_mode == "newest-map":
+            with ex_cv:
+                while ex_outstanding[0] > 0:
+                    ex_cv.wait()
+        while explorer is not None and explorer.pending():
+            explore_fetch()
         while in_flight:
             fetch()
         if goal_pose is None or last_pose[0] is None:
@@ -461,7 +640,7 @@ def main():
         k += 1
     drain()
     ctx.timing_reset()
-    event_stride = EVENT_STRIDE if args.steps <= 400 else EVENT_STRIDE_LONG
+    event_stride = EVENT_STRIDE_SHORT_RUN if args.steps <= 50 else (EVENT_STRIDE if args.steps <= 400 else EVENT_STRIDE_LONG)
     if not os.environ.get("BENCH_NO_EVENTS"):
         # HIP events of the dominant kernel only (roofline leg), on every EVENT_STRIDE-th launch of the timed region: the
         # launch carries its own start / stop events (hipExtLaunchKernelGGL), which hold the kernel's begin and end time stamps
@@ -471,6 +650,8 @@ def main():
     pops_total[0] = 0
     host_t[0] = host_t[1] = 0.0
     del step_wall[:]
+    del ex_log[:]
+    ex_skipped[0] = 0
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -490,6 +671,8 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    ex_timed = list(ex_log)
+    ex_skipped_timed = ex_skipped[0]
     main_ms_total, main_n = ctx.timing_get(_capi.BL_K_MCL_MAIN)
     host_ms = (1e3 * host_t[0] / args.steps, 1e3 * host_t[1] / args.steps)
     slowest = sorted(step_wall, reverse=True)[:4]
@@ -577,6 +760,12 @@ def main():
                                     "source": "profiles/" + prof + " (rocprofv3 --pmc SQ_INSTS_VALU pass of this command, not measured in this run)"}
             except (OSError, ValueError):
                 continue
+        if args.explore:
+            world_name = "sealed obstacle_slam arena in every 200-cell tile; the map starts with the centre arena known up to column 110, the rest unknown"
+        elif args.grid == 200:
+            world_name = f"continuing from the shipped, already built {args.map} map"
+        else:
+            world_name = "tiled astar/maze world, the map starts as the truth-derived map"
         out = {
             "metric": "SLAM steps/sec (map+MCL+A*)",
             "value": args.steps / elapsed,
@@ -590,8 +779,9 @@ def main():
             "vs_baseline": None,
             "dtype": "int8 grid / f32 poses with f64 intermediates / int64 weights",
             "data": "synthetic",
-            "config": {"workload": f"full SLAM step on {W}x{H} @5cm grid ({('shipped ' + args.map + ' map') if args.grid == 200 else 'tiled astar/maze world'}), {N} particles, "
-                                   f"{R} rays, A* replan {'off' if goal is None else 'on'}",
+            "config": {"workload": f"full SLAM step on {W}x{H} @5cm grid ({world_name}), {N} particles, "
+                                   f"{R} rays, " + ("exploration step (setMap + find_map_frontiers + plan_path_to_frontier under the 0.5 m rule) on every "
+                                                    f"{EXPLORE_EVERY}th map" if args.explore else f"A* replan {'off' if goal is None else 'on'}"),
                        "particles": N, "grid": [W, H], "rays": R, "pipeline_depth": args.depth, "planner_lanes": args.lanes, "planner_batch": args.batch,
                        "parallelism": f"particle-shard x{world}" if world > 1 else "single GPU",
                        "collective": ("none" if not (world > 1 or spf.force_collectives) else
@@ -621,10 +811,41 @@ def main():
             out["shard_exchange"] = {"form": "composed finish" if spf.composed else "replicated record", "bytes_sent_per_rank_per_step": sent,
                                      "bytes_received_per_rank_per_step": received, "source_record_bytes_read_by_k_mcl_main": own,
                                      "replicated_form_would_receive": (world - 1) * engine.S * 16}
+        if args.explore:
+            n_ex = len(ex_timed)
+            planned = [e for e in ex_timed if e[3]]
+            out["explore"] = {
+                "mode": args.explore_mode, "exploration_steps": n_ex, "maps_published": args.steps // EXPLORE_EVERY, "maps_not_explored": ex_skipped_timed,
+                "every_nth_slam_step": EXPLORE_EVERY, "lanes": args.explore_lanes,
+                "status_counts": {"in_progress": sum(e[0] == 0 for e in ex_timed), "complete": sum(e[0] == 1 for e in ex_timed), "failed": sum(e[0] == 2 for e in ex_timed)},
+                "frontiers_per_step": (sum(e[1] for e in ex_timed) / n_ex) if n_ex else 0.0,
+                "frontier_cells_per_step": (sum(e[2] for e in ex_timed) / n_ex) if n_ex else 0.0,
+                "flooded_cells_per_step": (sum(e[7] for e in ex_timed) / n_ex) if n_ex else 0.0,
+                "flood_levels_per_step": (sum(e[8] for e in ex_timed) / n_ex) if n_ex else 0.0,
+                "plans": len(planned), "pops_per_plan": (sum(e[4] for e in planned) / len(planned)) if planned else 0.0,
+                "searches_per_plan": (sum(e[5] for e in planned) / len(planned)) if planned else 0.0,
+                "stage_ms": {"frontiers": round(sum(e[9] for e in ex_timed) / n_ex, 4) if n_ex else 0.0,
+                             "plan_to_frontier": round(sum(e[10] for e in planned) / len(planned), 3) if planned else 0.0},
+                "plan_ms_total": round(sum(e[10] for e in planned), 2),
+            }
         if world == 1 and stream_k is not None:
             out["streaming_kernels"] = stream_k
         if other is not None:
             out["other_configs"] = other
+            # closed-loop latency and the particle sweep, lifted out of the rows above
+            lat = {}
+            for r in other:
+                if "error" in r:
+                    continue
+                if r.get("planner") and r["planner"][2] == 0:
+                    lat["headline" if r["config"] == 0 else f"config{r['config']}_goal{r['goal_l1_cells']}"] = {
+                        "sync_ms_per_step": r["ms_per_step"], "sync_steps_per_s": r["value"], "steps": r["steps"],
+                        "meets_1kHz_closed_loop": bool(r["value"] >= 1000.0)}
+            out["latency"] = lat
+            out["particle_sweep_steps_per_s"] = {str(r["particles"]): round(r["value"], 1) for r in other
+                                                 if "error" not in r and r["config"] in (0, 3) and not r["flags"][:1] == ["--no-astar"]
+                                                 and (not r.get("planner") or r["planner"][2] != 0)}
+            out["particle_sweep_steps_per_s"][str(args.particles)] = round(args.steps / elapsed, 1)
         if args.cpu_steps > 0 and world == 1:
             out["cpu_baseline"] = cpu_baseline(args, m, odo, scans, rands, goal, args.cpu_steps)
         sys.stdout.flush()

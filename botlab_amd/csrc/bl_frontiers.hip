@@ -19,6 +19,7 @@
 
 #include <chrono>
 #include <deque>
+#include <mutex>
 #include <vector>
 
 #include "bl_internal.h"
@@ -1172,6 +1173,9 @@ struct bl_explorer {
     std::vector<bl_pose_xyt_t>* path;                   // currentPath_
     bl_frontiers* last;                                 // frontiers_ of the last fetched step
     double min_frontier_length;
+    // submit (the SLAM thread) and fetch (possibly another thread: the reference's exploration PROCESS) share `order` and the lanes'
+    // busy flags; a lane's other members belong to submit while it is idle and to fetch while it is busy
+    std::mutex* mu;
 };
 
 extern "C" int bl_explorer_create(bl_ctx* ctx, int lanes, double robot_radius, bl_explorer** out)
@@ -1182,6 +1186,7 @@ extern "C" int bl_explorer_create(bl_ctx* ctx, int lanes, double robot_radius, b
     memset((void*)e, 0, sizeof(*e));
     e->main = ctx; e->lanes = lanes;
     e->order = new std::deque<int>();
+    e->mu = new std::mutex();
     e->path = new std::vector<bl_pose_xyt_t>();
     e->min_frontier_length = 0.35;                      // kMinFrontierLength's default (frontiers.hpp:36)
     // MotionPlanner(params) + setParams (motion_planner.cpp:9-16, 105-110): minDist = robotRadius, maxDist = 10 minDist, exponent 1
@@ -1226,7 +1231,7 @@ extern "C" void bl_explorer_destroy(bl_explorer* e)
         bl_ctx_destroy(L.ctx);
     }
     if (e->last) bl_frontiers_destroy(e->last);
-    delete e->order; delete e->path;
+    delete e->order; delete e->path; delete e->mu;
     delete e;
 }
 
@@ -1242,7 +1247,10 @@ extern "C" int bl_explorer_submit(bl_explorer* e, const bl_grid* map, const void
 {
     BL_CHECK_ARG(e != nullptr && map != nullptr && d_pose != nullptr && map->ctx == e->main);
     explorer_lane& L = e->lane[e->next];
-    if (L.busy) { bl_set_error("every explorer lane holds a submission: fetch first"); return BL_ERR_STATE; }
+    {
+        std::lock_guard<std::mutex> g(*e->mu);
+        if (L.busy) { bl_set_error("every explorer lane holds a submission: fetch first"); return BL_ERR_STATE; }
+    }
     BL_HIP(hipSetDevice(e->main->device));
     if (L.snap && (L.snap->frame.width != map->frame.width || L.snap->frame.height != map->frame.height)) { bl_grid_destroy(L.snap); L.snap = nullptr; }
     if (!L.snap) {
@@ -1264,25 +1272,42 @@ extern "C" int bl_explorer_submit(bl_explorer* e, const bl_grid* map, const void
     if (rc) return rc;
     BL_HIP(hipEventRecord(L.t1, L.ctx->stream));
     BL_HIP(hipMemcpyAsync(L.h_pose, L.d_pose, sizeof(bl_pose_xyt_t), hipMemcpyDeviceToHost, L.ctx->stream));
-    L.busy = true;
-    e->order->push_back(e->next);
+    {
+        std::lock_guard<std::mutex> g(*e->mu);
+        L.busy = true;
+        e->order->push_back(e->next);
+    }
     e->next = (e->next + 1) % e->lanes;
     return BL_OK;
 }
 
-extern "C" int bl_explorer_pending(const bl_explorer* e) { return e ? (int)e->order->size() : 0; }
+// submissions not handed back yet (the one a fetch is working on included)
+extern "C" int bl_explorer_pending(const bl_explorer* e)
+{
+    if (!e) return 0;
+    std::lock_guard<std::mutex> g(*e->mu);
+    int n = 0;
+    for (int l = 0; l < e->lanes; ++l) n += e->lane[l].busy ? 1 : 0;
+    return n;
+}
 
 extern "C" int bl_explorer_fetch(bl_explorer* e, bl_explore_result_t* out, bl_pose_xyt_t* out_path, int cap)
 {
     BL_CHECK_ARG(e != nullptr && out != nullptr && (cap == 0 || out_path != nullptr) && cap >= 0);
-    if (e->order->empty()) { bl_set_error("no exploration step pending"); return BL_ERR_STATE; }
-    const int l = e->order->front();
-    e->order->pop_front();
+    int l;
+    {
+        std::lock_guard<std::mutex> g(*e->mu);
+        if (e->order->empty()) { bl_set_error("no exploration step pending"); return BL_ERR_STATE; }
+        l = e->order->front();
+        e->order->pop_front();
+    }
     explorer_lane& L = e->lane[l];
+    // the lane is idle again when this call returns, whatever way
+    struct release { bl_explorer* e; explorer_lane* L; ~release() { std::lock_guard<std::mutex> g(*e->mu); L->busy = false; } } rel{e, &L};
+    BL_HIP(hipSetDevice(e->main->device));
     memset(out, 0, sizeof(*out));
     bl_frontiers* fr = nullptr;
     int rc = frontiers_collect(L.ctx, L.snap->frame, e->min_frontier_length, &fr);      // (waits for the lane's stream)
-    L.busy = false;
     if (rc) return rc;
     if (e->last) bl_frontiers_destroy(e->last);
     e->last = fr;

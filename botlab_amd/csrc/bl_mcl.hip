@@ -94,6 +94,17 @@ struct bl_pf {
     mclf_shards* sh_fin;                       // device [2]: the finish's view, for the record written by an update from cur = 0 / 1
     char* sh_xchg; size_t sh_xchg_stride;      // the exchange blocks of the finish (this rank's and, gathered, every rank's)
     int sh_subs_per_rank;
+    // peer-store form of the exchange (bl_pf_shard_peer_*): no collective -- every rank pushes its slice of the tile sums and its
+    // exchange block into every other rank's buffers (their memory, mapped into this process) and raises a per-source counter
+    // there; the consuming launches are preceded by a one-wave wait on those counters
+    bool sh_peer;                              // the form is set up (every rank's buffers are mapped)
+    unsigned long long* sh_flags;              // device: [2][BL_MAX_SHARDS] -- the update number rank r's sums / block are here for
+    double* sh_peer_sums[BL_MAX_SHARDS];       // every rank's tile-sum buffer (both parities), exchange blocks and counters as THIS process sees them
+    char* sh_peer_xchg[BL_MAX_SHARDS];
+    unsigned long long* sh_peer_flags[BL_MAX_SHARDS];
+    struct shard_peers* sh_peers_dev;          // device copy of the three tables
+    unsigned long long sh_gen;                 // moved updates exchanged so far
+    int sh_tiles_all;                          // tiles of the padded particle set (one parity of the tile-sum buffer)
     int64_t sh_bytes_pulled_bound;             // (diagnostic) upper bound of the bytes the last k_mcl_main may have read from other ranks
 };
 
@@ -1276,7 +1287,7 @@ extern "C" void bl_pf_destroy(bl_pf* pf)
     (void)hipStreamSynchronize(pf->ctx->stream);
     if (!pf->rec_external) { if (pf->rec[0]) (void)hipFree(pf->rec[0]); if (pf->rec[1]) (void)hipFree(pf->rec[1]); }
     void* ptrs[] = {pf->fin_wild, pf->tile_partials, pf->fin_recs, pf->fin_tabs, pf->fin_sync, pf->prefix, pf->parent, pf->state, pf->partials, pf->block_sums, pf->dbg_idx, pf->dbg_like,
-                    pf->d_noise, pf->d_export, pf->sh_xchg, pf->sh_tab, pf->sh_fin};
+                    pf->d_noise, pf->d_export, pf->sh_xchg, pf->sh_tab, pf->sh_fin, pf->sh_flags, pf->sh_peers_dev};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     delete pf;
 }
@@ -1830,10 +1841,16 @@ extern "C" int bl_pf_shard_setup(bl_pf* pf, int rank, int world, int block)
     if (pf->tile_partials) BL_HIP(hipFree(pf->tile_partials));
     if (pf->block_sums) BL_HIP(hipFree(pf->block_sums));
     pf->tile_partials = nullptr; pf->block_sums = nullptr;
-    BL_HIP(hipMalloc((void**)&pf->tile_partials, (size_t)tiles * 5 * sizeof(double)));
+    BL_HIP(hipMalloc((void**)&pf->tile_partials, (size_t)2 * tiles * 5 * sizeof(double)));      // (two parities: the peer-store form)
     BL_HIP(hipMalloc((void**)&pf->block_sums, (size_t)tiles * sizeof(unsigned long long)));
-    BL_HIP(hipMemsetAsync(pf->tile_partials, 0, (size_t)tiles * 5 * sizeof(double), pf->ctx->stream));
+    BL_HIP(hipMemsetAsync(pf->tile_partials, 0, (size_t)2 * tiles * 5 * sizeof(double), pf->ctx->stream));
     pf->scan_blocks = tiles;
+    pf->sh_tiles_all = tiles;
+    pf->sh_peer = false; pf->sh_gen = 0;
+    if (!pf->sh_flags) BL_HIP(hipMalloc((void**)&pf->sh_flags, 2 * BL_MAX_SHARDS * sizeof(unsigned long long)));
+    BL_HIP(hipMemsetAsync(pf->sh_flags, 0, 2 * BL_MAX_SHARDS * sizeof(unsigned long long), pf->ctx->stream));
+    memset(pf->sh_peer_sums, 0, sizeof(pf->sh_peer_sums)); memset(pf->sh_peer_xchg, 0, sizeof(pf->sh_peer_xchg));
+    memset(pf->sh_peer_flags, 0, sizeof(pf->sh_peer_flags));
     pf->sh_subs_per_rank = block / MCLF_SUB;
     pf->sh_xchg_stride = ((size_t)MCLF_XCHG_HDR + (size_t)2 * pf->sh_subs_per_rank * sizeof(ss_rec) +
                           (size_t)2 * MCLF_TSLOTS * MCLF_SUB * sizeof(mclf_tab_elem) + 255) & ~(size_t)255;
@@ -1896,11 +1913,18 @@ extern "C" int bl_pf_shard_commit(bl_pf* pf)
     return BL_OK;
 }
 
+// The tile sums of the running update.  The collective forms keep one buffer (the all-gather orders its reuse); the peer-store
+// form keeps two and alternates: a rank that runs ahead pushes the NEXT update's sums while this one's finish still reads these.
+static double* pf_shard_partials(const bl_pf* pf)
+{
+    return pf->tile_partials + (pf->sh_peer ? (size_t)(pf->sh_gen & 1ull) * (size_t)pf->sh_tiles_all * 5 : 0);
+}
+
 // the two buffers of the exchange: every rank's slice of the tile sums and every rank's block of records / tables
 extern "C" int bl_pf_shard_buffers(bl_pf* pf, void** sums, size_t* sums_bytes_per_rank, void** xchg, size_t* xchg_bytes_per_rank)
 {
     BL_CHECK_ARG(pf != nullptr && (pf->sh_world >= 2 || pf->sh_world_pending >= 2) && sums && sums_bytes_per_rank && xchg && xchg_bytes_per_rank);
-    *sums = pf->tile_partials; *sums_bytes_per_rank = (size_t)(pf->sh_block / SCAN_TILE) * 5 * sizeof(double);
+    *sums = pf_shard_partials(pf); *sums_bytes_per_rank = (size_t)(pf->sh_block / SCAN_TILE) * 5 * sizeof(double);
     *xchg = pf->sh_xchg; *xchg_bytes_per_rank = pf->sh_xchg_stride;
     return BL_OK;
 }
@@ -1908,7 +1932,7 @@ extern "C" int bl_pf_shard_buffers(bl_pf* pf, void** sums, size_t* sums_bytes_pe
 // the finish arguments of the record an update from `cur` wrote (the update begun, or the particles as they stand)
 static int pf_shard_fin_args(bl_pf* pf, int which, int64_t utime, mcl_finish_args* f)
 {
-    f->partials = pf->tile_partials; f->nblocks = pf->scan_blocks;
+    f->partials = pf_shard_partials(pf); f->nblocks = pf->scan_blocks;
     f->rec = pf->rec[which]; f->N = pf->N;
     f->tile = SCAN_TILE; f->main_blocks = pf->scan_blocks; f->main_particles = pf->N; f->tail_tile = 1;
     f->prefix = pf->prefix; f->state = pf->state; f->utime = utime;
@@ -1933,7 +1957,7 @@ extern "C" int bl_pf_shard_stage(bl_pf* pf, int stage)
     if (stage == 1) {
         const int tiles = pf->sh_block / SCAN_TILE;
         hipLaunchKernelGGL(k_scan_tile_sums, dim3(tiles), dim3(SCAN_THREADS), 0, pf->ctx->stream, (const float4*)pf->rec[which], pf->N, pf->block_sums,
-                           pf->tile_partials, pf->sh_rank * tiles, (unsigned long long*)(pf->sh_xchg + (size_t)pf->sh_rank * pf->sh_xchg_stride));
+                           pf_shard_partials(pf), pf->sh_rank * tiles, (unsigned long long*)(pf->sh_xchg + (size_t)pf->sh_rank * pf->sh_xchg_stride));
         pf->sh_stage_sums = true;
     } else {
         if (!pf->sh_stage_sums) { bl_set_error("bl_pf_shard_stage(2) before stage 1"); return BL_ERR_STATE; }
@@ -1963,6 +1987,183 @@ extern "C" int bl_pf_shard_exchange(bl_pf* pf, bl_comm* c)
     return bl_comm_all_gather_inplace(c, xchg, xb / sizeof(float));
 }
 
+// ---- peer-store form: the exchange without a collective ---------------------------------------------------------------------
+// Two RCCL all-gathers cost ~40 us of latency each whatever they carry (10 KB and 87 KB per rank at 1M particles / 8 ranks), next
+// to ~130 us of kernels: by the builder's own budget 2.9x at 8 ranks where north_star asks for 6x.  Here a rank copies its slice
+// of the tile sums, and later its exchange block, straight into the same place of every other rank's buffer -- their memory,
+// mapped into this process (hipIpc), 16-byte system-scope stores over xGMI -- fences, and then stores the update's number into
+// its slot of every rank's counter table.  A consuming launch is preceded by a one-wave launch that waits until every slot of the
+// local table has reached the update's number (system-scope loads, a spin limit as everywhere).  Layouts, kernels and results are
+// those of the collective form, bit for bit.  What orders the REUSE of a buffer without a collective:
+//   * tile sums: two parities (a rank ahead pushes the next update's sums while this one's finish still reads these);
+//   * exchange blocks: rank B's groups of update u + 1 need every rank's tile sums of u + 1, and rank A pushes those behind its
+//     finish of update u on its stream -- so B cannot overwrite its block in A's memory while A still reads update u's;
+//   * records / weight prefix read by another rank's k_mcl_main: as in the collective form they are complete when the owner's
+//     block has arrived (the push is a later launch on the owner's stream), and they are rewritten only behind the owner's
+//     groups of the next update, which wait for the reader's tile sums of that update.
+struct shard_peers { double* sums[BL_MAX_SHARDS]; char* xchg[BL_MAX_SHARDS]; unsigned long long* flags[BL_MAX_SHARDS]; };
+
+typedef int shard_i4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void shard_store_sys(void* dst, const shard_i4 v)
+{
+    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" :: "v"(dst), "v"(v) : "memory");
+}
+
+// Workgroup r of `world`: `bytes` (a multiple of 16) at src + off -> rank r's buffer + off, then rank r's flags[kind][rank] = gen
+// (workgroup `rank` has nothing to do: its own copy is the source).  A workgroup per destination: the links to the seven
+// neighbours carry their copies side by side, and no workgroup waits for another.
+__global__ __launch_bounds__(1024) void k_shard_push(const shard_peers* __restrict__ peers, int kind, size_t off, size_t bytes, int rank, int world,
+                                                     unsigned long long gen)
+{
+    const int r = blockIdx.x;
+    if (r == rank || r >= world) return;
+    const char* src = (kind == 0 ? (const char*)peers->sums[rank] : (const char*)peers->xchg[rank]) + off;
+    char* dst = (kind == 0 ? (char*)peers->sums[r] : peers->xchg[r]) + off;
+    const size_t n16 = bytes / 16;
+    for (size_t i = threadIdx.x; i < n16; i += blockDim.x) shard_store_sys(dst + i * 16, ((const shard_i4*)src)[i]);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0)
+        __hip_atomic_store(peers->flags[r] + kind * BL_MAX_SHARDS + rank, gen, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// One wave: until every other rank's slot of this rank's counter table has reached `gen` (lane r watches rank r)
+__global__ __launch_bounds__(64) void k_shard_wait(const unsigned long long* __restrict__ flags, int kind, int rank, int world, unsigned long long gen,
+                                                   pf_state* __restrict__ state)
+{
+    const int r = threadIdx.x;
+    if (r >= world || r == rank) return;
+    unsigned int spins = 0;
+    while (__hip_atomic_load(flags + kind * BL_MAX_SHARDS + r, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < gen) {
+        if (++spins > MCLF_SPIN_LIMIT) { atomicAdd(&state->wait_timeouts, 1u); break; }
+        __builtin_amdgcn_s_sleep(8);
+    }
+}
+
+// what the other ranks need of this one for the peer-store form: its tile-sum buffer, its exchange blocks and its counter table
+extern "C" int bl_pf_shard_local_ptrs_peer(bl_pf* pf, void** sums, void** xchg, void** flags)
+{
+    BL_CHECK_ARG(pf != nullptr && pf->tile_partials != nullptr && pf->sh_xchg != nullptr && pf->sh_flags != nullptr && sums && xchg && flags);
+    *sums = pf->tile_partials; *xchg = pf->sh_xchg; *flags = pf->sh_flags;
+    return BL_OK;
+}
+
+extern "C" int bl_pf_shard_set_peer_buffers(bl_pf* pf, int rank, void* sums, void* xchg, void* flags)
+{
+    BL_CHECK_ARG(pf != nullptr && pf->sh_world_pending >= 2 && rank >= 0 && rank < pf->sh_world_pending && sums && xchg && flags);
+    pf->sh_peer_sums[rank] = (double*)sums; pf->sh_peer_xchg[rank] = (char*)xchg; pf->sh_peer_flags[rank] = (unsigned long long*)flags;
+    return BL_OK;
+}
+
+// after bl_pf_shard_commit: switch the exchange to the peer-store form (every rank's buffers have been handed in)
+extern "C" int bl_pf_shard_peer_commit(bl_pf* pf)
+{
+    BL_CHECK_ARG(pf != nullptr && pf->sh_world >= 2);
+    if (pf->pending_end) { bl_set_error("update pending"); return BL_ERR_STATE; }
+    for (int r = 0; r < pf->sh_world; ++r) BL_CHECK_ARG(pf->sh_peer_sums[r] && pf->sh_peer_xchg[r] && pf->sh_peer_flags[r]);
+    BL_CHECK_ARG(pf->sh_peer_sums[pf->sh_rank] == pf->tile_partials && pf->sh_peer_xchg[pf->sh_rank] == pf->sh_xchg && pf->sh_peer_flags[pf->sh_rank] == pf->sh_flags);
+    BL_HIP(hipSetDevice(pf->ctx->device));
+    shard_peers h;
+    memset((void*)&h, 0, sizeof(h));
+    for (int r = 0; r < pf->sh_world; ++r) { h.sums[r] = pf->sh_peer_sums[r]; h.xchg[r] = pf->sh_peer_xchg[r]; h.flags[r] = pf->sh_peer_flags[r]; }
+    if (!pf->sh_peers_dev) BL_HIP(hipMalloc((void**)&pf->sh_peers_dev, sizeof(shard_peers)));
+    BL_HIP(hipMemcpyAsync(pf->sh_peers_dev, &h, sizeof(h), hipMemcpyHostToDevice, pf->ctx->stream));
+    BL_HIP(hipStreamSynchronize(pf->ctx->stream));
+    pf->sh_peer = true;
+    pf->sh_gen = 0;
+    return BL_OK;
+}
+
+extern "C" int bl_pf_shard_peer_active(const bl_pf* pf) { return pf && pf->sh_peer ? 1 : 0; }
+
+// First contact, before any update relies on it: every rank pushes a pattern into every other rank's tile-sum buffer and raises
+// its counter (number `probe_gen`, counted like an update); then waits for everybody's counter and checks everybody's pattern.
+// Returns BL_OK with *ok = 1 when this rank has seen every other rank's bytes arrive within the device-side spin limit; the caller
+// agrees on the answer over its rendezvous (all ranks must take the same form) and calls bl_pf_shard_peer_reset.
+__global__ __launch_bounds__(64) void k_shard_probe_fill(double* own_slice, int words, int rank, unsigned long long gen)
+{
+    for (int i = threadIdx.x; i < words; i += 64) own_slice[i] = (double)((rank + 1) * 1000003ull + gen * 7919ull + (unsigned long long)i);
+}
+__global__ __launch_bounds__(64) void k_shard_probe_check(const double* sums, int words_per_rank, int rank, int world, unsigned long long gen, int* bad)
+{
+    for (int r = 0; r < world; ++r) {
+        if (r == rank) continue;
+        const double* sl = sums + (size_t)r * words_per_rank;
+        for (int i = threadIdx.x; i < words_per_rank; i += 64) {
+            const double v = __hip_atomic_load(sl + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            if (v != (double)((r + 1) * 1000003ull + gen * 7919ull + (unsigned long long)i)) atomicAdd(bad, 1);
+        }
+    }
+}
+extern "C" int bl_pf_shard_peer_selftest(bl_pf* pf, int* ok)
+{
+    BL_CHECK_ARG(pf != nullptr && pf->sh_peer && ok != nullptr);
+    *ok = 0;
+    BL_HIP(hipSetDevice(pf->ctx->device));
+    const int tiles = pf->sh_block / SCAN_TILE, words = tiles * 5;
+    const unsigned long long gen = ++pf->sh_gen;
+    double* mine = pf_shard_partials(pf) + (size_t)pf->sh_rank * words;
+    const size_t off = (size_t)((char*)mine - (char*)pf->tile_partials);
+    int* d_bad = nullptr;
+    BL_HIP(hipMalloc((void**)&d_bad, 2 * sizeof(int)));
+    BL_HIP(hipMemsetAsync(d_bad, 0, 2 * sizeof(int), pf->ctx->stream));
+    unsigned int before = 0, after = 0;
+    BL_HIP(hipMemcpyAsync(&before, &pf->state->wait_timeouts, 4, hipMemcpyDeviceToHost, pf->ctx->stream));
+    hipLaunchKernelGGL(k_shard_probe_fill, dim3(1), dim3(64), 0, pf->ctx->stream, mine, words, pf->sh_rank, gen);
+    hipLaunchKernelGGL(k_shard_push, dim3(pf->sh_world), dim3(1024), 0, pf->ctx->stream, pf->sh_peers_dev, 0, off, (size_t)words * 8, pf->sh_rank, pf->sh_world, gen);
+    hipLaunchKernelGGL(k_shard_wait, dim3(1), dim3(64), 0, pf->ctx->stream, pf->sh_flags, 0, pf->sh_rank, pf->sh_world, gen, pf->state);
+    hipLaunchKernelGGL(k_shard_probe_check, dim3(1), dim3(64), 0, pf->ctx->stream, pf_shard_partials(pf), words, pf->sh_rank, pf->sh_world, gen, d_bad);
+    BL_HIP(hipGetLastError());
+    int bad[2] = {0, 0};
+    BL_HIP(hipMemcpyAsync(bad, d_bad, sizeof(bad), hipMemcpyDeviceToHost, pf->ctx->stream));
+    BL_HIP(hipMemcpyAsync(&after, &pf->state->wait_timeouts, 4, hipMemcpyDeviceToHost, pf->ctx->stream));
+    BL_HIP(hipStreamSynchronize(pf->ctx->stream));
+    (void)hipFree(d_bad);
+    if (after != before) BL_HIP(hipMemsetAsync(&pf->state->wait_timeouts, 0, 4, pf->ctx->stream));     // (the probe's own time-out is its answer)
+    *ok = (bad[0] == 0 && after == before) ? 1 : 0;
+    return BL_OK;
+}
+
+// leave the peer-store form (the ranks agreed to: a rank's self-test failed); the collective forms take over.  Counters restart.
+extern "C" int bl_pf_shard_peer_reset(bl_pf* pf, int keep)
+{
+    BL_CHECK_ARG(pf != nullptr);
+    if (pf->pending_end) { bl_set_error("update pending"); return BL_ERR_STATE; }
+    if (!keep) pf->sh_peer = false;
+    return BL_OK;
+}
+
+// both stages of the running update's exchange in the peer-store form, everything on the filter's stream
+extern "C" int bl_pf_shard_exchange_peer(bl_pf* pf)
+{
+    BL_CHECK_ARG(pf != nullptr && pf->sh_world >= 2 && pf->sh_peer);
+    if (!pf->pending_end) { bl_set_error("bl_pf_shard_exchange_peer without an update begun"); return BL_ERR_STATE; }
+    BL_HIP(hipSetDevice(pf->ctx->device));
+    const unsigned long long gen = ++pf->sh_gen;            // (pf_shard_partials follows: this update's parity)
+    const int tiles = pf->sh_block / SCAN_TILE;
+    int rc = bl_pf_shard_stage(pf, 1);
+    if (rc) return rc;
+    hipEvent_t e0, e1;
+    rc = bl_timer_begin(pf->ctx, BL_K_MCL_SCAN, &e0, &e1);
+    if (rc) return rc;
+    const size_t sums_off = (size_t)((char*)(pf_shard_partials(pf) + (size_t)pf->sh_rank * tiles * 5) - (char*)pf->tile_partials);
+    hipLaunchKernelGGL(k_shard_push, dim3(pf->sh_world), dim3(1024), 0, pf->ctx->stream, pf->sh_peers_dev, 0, sums_off, (size_t)tiles * 5 * sizeof(double),
+                       pf->sh_rank, pf->sh_world, gen);
+    hipLaunchKernelGGL(k_shard_wait, dim3(1), dim3(64), 0, pf->ctx->stream, pf->sh_flags, 0, pf->sh_rank, pf->sh_world, gen, pf->state);
+    rc = bl_timer_end(pf->ctx, BL_K_MCL_SCAN, e0, e1);
+    if (rc) return rc;
+    rc = bl_pf_shard_stage(pf, 2);
+    if (rc) return rc;
+    rc = bl_timer_begin(pf->ctx, BL_K_MCL_SCAN, &e0, &e1);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_shard_push, dim3(pf->sh_world), dim3(1024), 0, pf->ctx->stream, pf->sh_peers_dev, 1, (size_t)pf->sh_rank * pf->sh_xchg_stride,
+                       pf->sh_xchg_stride, pf->sh_rank, pf->sh_world, gen);
+    hipLaunchKernelGGL(k_shard_wait, dim3(1), dim3(64), 0, pf->ctx->stream, pf->sh_flags, 1, pf->sh_rank, pf->sh_world, gen, pf->state);
+    BL_HIP(hipGetLastError());
+    return bl_timer_end(pf->ctx, BL_K_MCL_SCAN, e0, e1);
+}
+
 // bytes of the exchange per rank and update: what this rank sends into the two all-gathers, what it receives from them, and
 // the size of its own block of particle records (its k_mcl_main reads about that much of source records, from wherever they
 // lie; the replicated form receives N x 16 B instead)
@@ -1972,6 +2173,7 @@ extern "C" int bl_pf_shard_traffic(bl_pf* pf, int64_t* out3)
     const int64_t sums = (int64_t)(pf->sh_block / SCAN_TILE) * 5 * (int64_t)sizeof(double);
     out3[0] = sums + (int64_t)pf->sh_xchg_stride;
     out3[1] = (int64_t)(pf->sh_world - 1) * out3[0];
+    if (pf->sh_peer) out3[0] = out3[1];                      // peer-store form: the slice and the block are stored once per other rank
     out3[2] = (int64_t)pf->n_local * (int64_t)sizeof(float4);
     return BL_OK;
 }

@@ -17,6 +17,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <chrono>
 #include <cmath>
 #include <deque>
 #include <map>
@@ -2095,9 +2096,9 @@ static int astar_batch_prepare(bl_ctx* ctx, const bl_dist* d, int want)
 {
     bl_astar_state* s = ctx->astar;
     const size_t cells = (size_t)d->frame.width * d->frame.height;
-    // searches per launch: bounded by 2 GB of closed grids
+    // searches per launch: bounded by 8 GB of closed grids (64 searches at 4096 x 4096)
     int cap = ASTAR_BATCH_MAX;
-    while (cap > 1 && (size_t)cap * cells * 4 > ((size_t)2 << 30)) cap >>= 1;
+    while (cap > 1 && (size_t)cap * cells * 4 > ((size_t)8 << 30)) cap >>= 1;
     if (want < cap) cap = want < 8 ? 8 : want;
     if (cap > ASTAR_BATCH_MAX) cap = ASTAR_BATCH_MAX;
     if (s->b_cap >= cap && s->b_cells >= cells) return BL_OK;
@@ -2726,33 +2727,49 @@ extern "C" int bl_plan_path_to_frontier(bl_ctx* ctx, const bl_frontiers* frontie
     const float cpx = frontiers->xy[2 * (size_t)mid], cpy = frontiers->xy[2 * (size_t)mid + 1];
 
     std::map<long long, frontier_search> cache;                         // goal cell -> planPath result
-    struct cand { float x, y; int cx, cy; bool valid; };
+    struct cand { float x, y; int cx, cy; bool valid; int ring; };
     std::vector<cand> cands;
     std::vector<int32_t> q;
     std::vector<float> qv;
 
-    // check_valid (:87-102) for every candidate of `cands`, in three batched rounds
-    auto evaluate = [&]() -> int {
-        const int n = (int)cands.size();
+    // check_valid (:87-102), first half, for the candidates cands[from..): isValidGoal by one gather of the goal cells' distances.
+    // Returns the number of goal cells among them that no search has been run for yet (they are entered into `todo`).
+    std::vector<int2> todo;
+    std::vector<long long> todo_key;
+    auto validity = [&](size_t from, int* fresh) -> int {
+        const int n = (int)(cands.size() - from);
+        *fresh = 0;
+        if (n == 0) return BL_OK;
         q.resize(2 * (size_t)n); qv.resize((size_t)n);
         for (int i = 0; i < n; ++i) {
-            bl_global_to_cell((double)cands[i].x, (double)cands[i].y, frame, &cands[i].cx, &cands[i].cy);    // motion_planner.cpp:61
-            q[2 * (size_t)i] = cands[i].cx; q[2 * (size_t)i + 1] = cands[i].cy;
+            cand& c = cands[from + (size_t)i];
+            bl_global_to_cell((double)c.x, (double)c.y, frame, &c.cx, &c.cy);    // motion_planner.cpp:61
+            q[2 * (size_t)i] = c.cx; q[2 * (size_t)i + 1] = c.cy;
         }
         int rc = bl_dist_gather(dist, q.data(), n, qv.data());
         if (rc) return rc;
-        std::vector<int2> todo;
-        std::vector<long long> todo_key;
         for (int i = 0; i < n; ++i) {
-            cands[i].valid = mp_is_valid_goal(pl, cands[i].x, cands[i].y, qv[i]);
-            if (!cands[i].valid) continue;
-            const long long key = ((long long)cands[i].cy << 32) | (unsigned int)cands[i].cx;
-            if (cache.find(key) == cache.end()) { cache[key] = frontier_search(); todo.push_back(make_int2(cands[i].cx, cands[i].cy)); todo_key.push_back(key); }
+            cand& c = cands[from + (size_t)i];
+            c.valid = mp_is_valid_goal(pl, c.x, c.y, qv[i]);
+            if (!c.valid) continue;
+            const long long key = ((long long)c.cy << 32) | (unsigned int)c.cx;
+            if (cache.find(key) == cache.end()) { cache[key] = frontier_search(); todo.push_back(make_int2(c.cx, c.cy)); todo_key.push_back(key); *fresh += 1; }
         }
+        return BL_OK;
+    };
+    // ... second half, for every candidate gathered so far: planPath (one batch of searches, one per goal cell not searched yet)
+    // and isPathSafe (one gather over all path poses)
+    auto evaluate = [&]() -> int {
+        const int n = (int)cands.size();
+        int rc = BL_OK;
         if (!todo.empty()) {
+            static const bool trace = getenv("BOTLAB_PLAN_TRACE") != nullptr;
+            const auto w0 = std::chrono::steady_clock::now();
+            long long max_pops = 0, sum_pops = 0; int n_found = 0;
             rc = astar_batch_cells(ctx, dist, &robotPose, todo.data(), (int)todo.size(), &pl.search,
                                    [&](int i, bool found, const int32_t* pc, int len, long long po, long long pu) {
-                                       (void)found;
+                                       if (po > max_pops) max_pops = po;
+                                       sum_pops += po; n_found += found ? 1 : 0;
                                        frontier_search& fs = cache[todo_key[i]];
                                        fs.path.resize((size_t)1 + len);
                                        astar_cells_to_path(frame, robotPose, pc, len, fs.path.data(), 1 + len);
@@ -2760,6 +2777,10 @@ extern "C" int bl_plan_path_to_frontier(bl_ctx* ctx, const bl_frontiers* frontie
                                        pops += po; pushes += pu; searches += 1;
                                    });
             if (rc) return rc;
+            if (trace)
+                fprintf(stderr, "[plan] batch of %d searches: %d found, %lld pops in all, longest %lld, %.1f ms\n", (int)todo.size(), n_found, sum_pops,
+                        max_pops, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - w0).count());
+            todo.clear(); todo_key.clear();
         }
         // isPathSafe (motion_planner.cpp:77-96) of every candidate path with >= 3 poses: one gather for all poses
         q.clear();
@@ -2789,40 +2810,69 @@ extern "C" int bl_plan_path_to_frontier(bl_ctx* ctx, const bl_frontiers* frontie
         return BL_OK;
     };
 
+    // The sweep of :143-199 takes one ring of the expanding square after the other and stops at the first ring that holds a valid
+    // candidate.  The rings are independent of each other, so several CAN be evaluated ahead of the rule (BOTLAB_FRONTIER_SPECULATE=n:
+    // rings are gathered until they ask for n goal cells not searched yet, their searches run side by side as one batch, and the
+    // rule is then applied ring by ring, in the reference's order, to the same outcome).  Off by default (n = 1: one ring per
+    // batch, the reference's own sequence), because it does not pay: a plan's searches already arrive as ONE batch (the first ring
+    // with goals of enough clearance), whose length is its longest search (5.4e5 pops, 1.4 s on the cut arena), while the rings
+    // behind hold goals that are expensive or unreachable (68 searches, 1.0e7 pops, 8.7 s with n = 64 there).
     bool foundPose = false;
     float square_radius = .025;
     float sq_len = .025;
     bl_pose_xyt_t goal_pose; memset(&goal_pose, 0, sizeof(goal_pose));    // D1
     int wraps = 0;
+    static const int speculate = getenv("BOTLAB_FRONTIER_SPECULATE") ? atoi(getenv("BOTLAB_FRONTIER_SPECULATE")) : 1;
     while (!foundPose) {
-        const float top_height = cpy + square_radius;
-        const float bot_height = cpy - square_radius;
-        const float left_bound = cpy + square_radius;       // sic: built from the y coordinate (:176-177)
-        const float right_bound = cpy - square_radius;
+        // ---- gather rings ahead (the radius sequence of :194-197, the D8 cut after the second wrap included)
         cands.clear();
-        for (float i = -square_radius; i <= square_radius; i += sq_len) {
-            cands.push_back(cand{cpx + i, top_height, 0, 0, false});
-            cands.push_back(cand{cpx + i, bot_height, 0, 0, false});
-        }
-        for (float i = -square_radius; i <= square_radius; i += sq_len) {
-            cands.push_back(cand{right_bound, cpy + i, 0, 0, false});
-            cands.push_back(cand{left_bound, cpy + i, 0, 0, false});
+        struct ring_info { size_t begin, end; bool wraps_here; };
+        std::vector<ring_info> rings;
+        float r_spec = square_radius;
+        int wraps_spec = wraps, pending = (int)todo.size();
+        while (true) {
+            const float top_height = cpy + r_spec;
+            const float bot_height = cpy - r_spec;
+            const float left_bound = cpy + r_spec;          // sic: built from the y coordinate (:176-177)
+            const float right_bound = cpy - r_spec;
+            const size_t begin = cands.size();
+            const int ring = (int)rings.size();
+            for (float i = -r_spec; i <= r_spec; i += sq_len) {
+                cands.push_back(cand{cpx + i, top_height, 0, 0, false, ring});
+                cands.push_back(cand{cpx + i, bot_height, 0, 0, false, ring});
+            }
+            for (float i = -r_spec; i <= r_spec; i += sq_len) {
+                cands.push_back(cand{right_bound, cpy + i, 0, 0, false, ring});
+                cands.push_back(cand{left_bound, cpy + i, 0, 0, false, ring});
+            }
+            int fresh = 0;
+            int rc = validity(begin, &fresh);
+            if (rc) return rc;
+            pending += fresh;
+            bool wrap = false, last = false;
+            if (r_spec < 0.5) r_spec += sq_len;
+            else { r_spec = 0.05; wrap = true; if (++wraps_spec == 2) last = true; }     // (D8: the sweep ends there if nothing was found)
+            rings.push_back(ring_info{begin, cands.size(), wrap});
+            if (last || pending >= speculate || speculate <= 1) break;
         }
         int rc = evaluate();
         if (rc) return rc;
-        // the sweep's assignments in the reference's order: first of each pair if valid, else the second (:153-193)
-        for (size_t i = 0; i + 1 < cands.size(); i += 2) {
-            if (cands[i].valid) { foundPose = true; goal_pose.x = cands[i].x; goal_pose.y = cands[i].y; }
-            else if (cands[i + 1].valid) { foundPose = true; goal_pose.x = cands[i + 1].x; goal_pose.y = cands[i + 1].y; }
-        }
-        if (square_radius < 0.5) square_radius += sq_len;
-        else {
-            square_radius = 0.05;
-            if (++wraps == 2 && !foundPose) {                                    // D8
-                if (stats) { stats[0] = pops; stats[1] = pushes; stats[2] = searches; }
-                *out_len = 1;
-                return BL_OK;
+        // ---- the rule, ring by ring: first of each pair if valid, else the second (:153-193); then the radius update (:194-197)
+        for (const ring_info& rg : rings) {
+            for (size_t i = rg.begin; i + 1 < rg.end; i += 2) {
+                if (cands[i].valid) { foundPose = true; goal_pose.x = cands[i].x; goal_pose.y = cands[i].y; }
+                else if (cands[i + 1].valid) { foundPose = true; goal_pose.x = cands[i + 1].x; goal_pose.y = cands[i + 1].y; }
             }
+            if (square_radius < 0.5) square_radius += sq_len;
+            else {
+                square_radius = 0.05;
+                if (++wraps == 2 && !foundPose) {                                    // D8
+                    if (stats) { stats[0] = pops; stats[1] = pushes; stats[2] = searches; }
+                    *out_len = 1;
+                    return BL_OK;
+                }
+            }
+            if (foundPose) break;
         }
     }
     goal_pose.theta = robotPose.theta;                                           // :209

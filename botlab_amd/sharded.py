@@ -124,6 +124,38 @@ class HipShardEngine:
             check(lib.bl_pf_shard_set_peer(self.pf.h, r, ptrs[0], ptrs[1], ptrs[2]))
         check(lib.bl_pf_shard_commit(self.pf.h))
 
+    # ---- peer-store form of the exchange: the tile-sum buffer, the exchange blocks and the counter table of every rank
+    def local_handles_peer(self):
+        lib = self.ctx.lib
+        ptrs = [C.c_void_p() for _ in range(3)]
+        check(lib.bl_pf_shard_local_ptrs_peer(self.pf.h, *[C.byref(p) for p in ptrs]))
+        out = []
+        for p in ptrs:
+            buf = C.create_string_buffer(64)
+            check(lib.bl_ipc_export(p, buf))
+            out.append(bytes(buf.raw))
+        return out, [p.value for p in ptrs]
+
+    def set_peers_peer(self, handles_by_rank, own_ptrs):
+        lib = self.ctx.lib
+        for r, hs in enumerate(handles_by_rank):
+            if r == self.rank:
+                ptrs = own_ptrs
+            else:
+                ptrs = []
+                for h in hs:
+                    q = C.c_void_p()
+                    check(lib.bl_ipc_open(h, C.byref(q)))
+                    self._opened.append(q)
+                    ptrs.append(q.value)
+            check(lib.bl_pf_shard_set_peer_buffers(self.pf.h, r, ptrs[0], ptrs[1], ptrs[2]))
+        check(lib.bl_pf_shard_peer_commit(self.pf.h))
+
+    def peer_selftest(self):
+        ok = C.c_int(0)
+        check(self.ctx.lib.bl_pf_shard_peer_selftest(self.pf.h, C.byref(ok)))
+        return bool(ok.value)
+
     def shard_buffers(self):
         """(tile-sums buffer, exchange buffer) of the composed finish as flat float32 tensors over the library's memory."""
         lib = self.ctx.lib
@@ -233,6 +265,8 @@ class ShardedParticleFilter:
         self._stream_current = False
         self.comm = None
         self.composed = False
+        self.peer = False                    # composed finish whose exchange is peer stores (no collective)
+        self.peer_why = ""
         self._sums = self._xchg = None
         if (self.world > 1 or self.force_collectives) and dist.is_initialized() and hasattr(engine, "ctx") \
                 and dist.get_backend(self.group) == "nccl" and not os.environ.get("BOTLAB_TORCH_COLLECTIVES"):
@@ -271,6 +305,44 @@ class ShardedParticleFilter:
             raise RuntimeError(f"composed finish: a rank could not map another rank's memory ({why or 'another rank'})")
         self._sums, self._xchg = eng.shard_buffers()
         self.composed = True
+        self.peer = False
+        if not os.environ.get("BOTLAB_SHARD_NO_PEER_STORES") and hasattr(eng, "local_handles_peer"):
+            self._setup_peer_stores()
+
+    def _setup_peer_stores(self):
+        """The exchange without collectives: every rank maps the others' tile-sum buffers, exchange blocks and counter tables, then
+        a self-test pushes a pattern to every rank and checks every rank's pattern (device-side spin limit: a dead link gives 'no',
+        not a hang).  ALL ranks keep the form or all leave it for the collective one -- agreed over torch.distributed."""
+        eng = self.engine
+        ok, why = True, ""
+        try:
+            handles, own = eng.local_handles_peer()
+        except Exception as e:                       # noqa: BLE001
+            ok, why, handles, own = False, repr(e), None, None
+        if not self._everyone(ok):
+            self.peer_why = f"buffers could not be exported ({why or 'another rank'})"
+            return
+        gathered = [None] * self.world
+        dist.all_gather_object(gathered, handles, group=self.group)
+        try:
+            eng.set_peers_peer(gathered, own)
+        except Exception as e:                       # noqa: BLE001
+            ok, why = False, repr(e)
+        if not self._everyone(ok):
+            # (a rank that did commit leaves the form again: nobody may push into buffers some rank has not mapped)
+            if ok:
+                check(eng.ctx.lib.bl_pf_shard_peer_reset(eng.pf.h, 0))
+            self.peer_why = f"a rank could not map another rank's buffers ({why or 'another rank'})"
+            return
+        dist.barrier(group=self.group)               # every rank has committed before anybody pushes
+        try:
+            ok = eng.peer_selftest()
+        except Exception as e:                       # noqa: BLE001
+            ok, why = False, repr(e)
+        keep = self._everyone(ok)
+        check(eng.ctx.lib.bl_pf_shard_peer_reset(eng.pf.h, 1 if keep else 0))
+        self.peer = keep
+        self.peer_why = "" if keep else f"the self-test failed on some rank ({why or ('this rank' if not ok else 'another rank')})"
 
     def _direct_comm(self):
         """The library's own RCCL communicator (csrc/bl_comm.hip): the all-gather is then ONE call that enqueues the collective
@@ -370,6 +442,9 @@ class ShardedParticleFilter:
     def _exchange_composed(self):
         """tile sums -> all-gather #1 -> groups -> all-gather #2, everything on the filter's stream."""
         lib, pf = self.engine.ctx.lib, self.engine.pf.h
+        if getattr(self, "peer", False):
+            check(lib.bl_pf_shard_exchange_peer(pf))     # no collective: pushes into the other ranks' buffers + counter waits
+            return
         if self.comm is not None:
             check(lib.bl_pf_shard_exchange(pf, self.comm))
             return

@@ -298,6 +298,21 @@ int bl_pf_shard_exchange(bl_pf* pf, bl_comm* c);
 /* bytes per rank and update: sent into the two all-gathers, received from them, and the rank's own block of records (about what
  * its k_mcl_main reads of source records, from wherever they lie) */
 int bl_pf_shard_traffic(bl_pf* pf, int64_t* out3);
+/* The same exchange WITHOUT a collective (peer-store form): every rank copies its slice of the tile sums, then its exchange
+ * block, straight into every other rank's buffers (mapped like the records: bl_pf_shard_local_ptrs_peer -> bl_ipc_export -> ...
+ * -> bl_ipc_open -> bl_pf_shard_set_peer_buffers for every rank, after bl_pf_shard_commit; then bl_pf_shard_peer_commit), raises a
+ * per-source counter there, and waits for the other ranks' counters in front of the launches that consume the data: two ~40 us
+ * collective latencies per update become two pushes over xGMI.  Layouts and results are the collective form's.  First contact:
+ * bl_pf_shard_peer_selftest pushes a pattern to every rank and checks every rank's pattern (device-side spin limit: it cannot
+ * hang); the ranks agree on the outcome over their rendezvous and either keep the form (bl_pf_shard_peer_reset(pf, 1)) or all
+ * leave it (..., 0) for the collective forms.  Per update: bl_pf_update_begin, bl_pf_shard_exchange_peer, then as above. */
+int bl_pf_shard_local_ptrs_peer(bl_pf* pf, void** sums, void** xchg, void** flags);
+int bl_pf_shard_set_peer_buffers(bl_pf* pf, int rank, void* sums, void* xchg, void* flags);
+int bl_pf_shard_peer_commit(bl_pf* pf);
+int bl_pf_shard_peer_active(const bl_pf* pf);
+int bl_pf_shard_peer_selftest(bl_pf* pf, int* ok);
+int bl_pf_shard_peer_reset(bl_pf* pf, int keep);
+int bl_pf_shard_exchange_peer(bl_pf* pf);
 
 /* The NEXT lidar scan handed over early (a SLAM host has it queued, src/slam/slam.cpp:96-104): it is packed into pinned
  * memory now and copied to the device by the next bl_mapping_update* / bl_planner_submit_with_map_update* launch of this
@@ -403,7 +418,9 @@ int bl_plan_path_to_frontier(bl_ctx* ctx, const bl_frontiers* frontiers, const b
  * snapshots the map and the device-resident pose on ctx's stream; one of `lanes` side streams runs the distance transform and the
  * frontier search against the snapshot; bl_explorer_fetch hands back the steps in submission order and applies the rule with the
  * state consecutive steps share (currentTarget_, currentPath_), running plan_path_to_frontier on that lane when it is due.  At
- * most `lanes` submissions may be pending. */
+ * most `lanes` submissions may be pending.  bl_explorer_submit / bl_explorer_pending on one thread and bl_explorer_fetch on
+ * another (the reference's exploration PROCESS beside its SLAM process) may run concurrently; bl_explorer_pending counts the
+ * submission a fetch is still working on. */
 typedef struct bl_explorer bl_explorer;
 typedef struct {
     int32_t next_state;      /* exploration_status_t: 1 EXPLORING_MAP, 2 RETURNING_HOME, 4 FAILED_EXPLORATION */

@@ -13,7 +13,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 N, STEPS = 30001, 6           # odd N: last shard shorter than the padded block
 
 
-def _run(rank, world, port, out_dir, riding=False, composed=False, n=N):
+def _run(rank, world, port, out_dir, riding=False, composed=False, n=N, peer=True):
     sys.path.insert(0, HERE)
     sys.path.insert(0, os.path.dirname(HERE))
     import torch
@@ -35,6 +35,8 @@ def _run(rank, world, port, out_dir, riding=False, composed=False, n=N):
     # map kernel -- against the same record-based finish as separate launches on one rank)
     if not (riding and world > 1):
         os.environ["BOTLAB_MCL_NO_FUSED_FINISH"] = "1"
+    if not peer:
+        os.environ["BOTLAB_SHARD_NO_PEER_STORES"] = "1"
     if composed and world > 1:
         # the composed finish: ranks keep their own block, map each other's memory (IPC), exchange two small
         # all-gathers.  First the question bench.py asks: can the ranks map each other's memory at all?
@@ -64,7 +66,13 @@ def _run(rank, world, port, out_dir, riding=False, composed=False, n=N):
         assert spf.composed
         sent, received, own = spf.exchange_bytes_per_update()
         # the point of the composed form: per rank and update O(block) + O(100 KB), not N x 16 B
-        assert sent <= 90_000 + (eng.S // 128) * 42 and received == (world - 1) * sent      # 32 B of records + 10 B of sums per 128 particles + tables
+        per_peer = 90_000 + (eng.S // 128) * 42                                      # 32 B of records + 10 B of sums per 128 particles + tables
+        if spf.peer:                 # no collective: a rank stores its slice and block once per other rank
+            assert sent == received and received <= (world - 1) * per_peer
+        else:
+            assert sent <= per_peer and received == (world - 1) * sent
+        with open(os.path.join(out_dir, f"form_w{world}_r{rank}.txt"), "w") as f:
+            f.write("peer" if spf.peer else "collective")
         with open(os.path.join(out_dir, f"traffic_w{world}_r{rank}.txt"), "w") as f:
             f.write(f"{sent} {received} {own} {n * 16}")
     np.save(os.path.join(out_dir, f"grid_w{world}_r{rank}.npy"), grid.cells())
@@ -78,15 +86,16 @@ def _run(rank, world, port, out_dir, riding=False, composed=False, n=N):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,riding,n", [(2, False, N), (2, True, N), (3, True, N), (2, True, 200_001), (4, True, 3500)])   # (3500 over four ranks: blocks of 1024, the small groups' alignment)
-def test_composed_finish_matches_single_rank(tmp_path, world, riding, n):
+@pytest.mark.parametrize("world,riding,n,peer", [(2, False, N, True), (2, True, N, True), (3, True, N, False), (2, True, 200_001, True), (4, True, 3500, True),   # (3500 over four ranks: blocks of 1024, the small groups' alignment)
+                                                 (2, True, N, False), (6, True, 100_000, True)])
+def test_composed_finish_matches_single_rank(tmp_path, world, riding, n, peer):
     """The composed finish -- own blocks only, sources read from their owners' memory, two small all-gathers -- with 2 and 3 ranks
     on one device (one process per rank, IPC mappings, collectives over gloo): particles, estimates and the replicated map equal
     the single rank's bit for bit; 200 001 particles take the large finish groups (1024 threads, 2048 particles)."""
     import torch.multiprocessing as mp
     out = str(tmp_path)
     mp.spawn(_run, args=(1, 0, out, riding, False, n), nprocs=1, join=True)
-    mp.spawn(_run, args=(world, 29900 + os.getpid() % 300 + 7 * world + (300 if riding else 0), out, riding, True, n), nprocs=world, join=True)
+    mp.spawn(_run, args=(world, 29900 + os.getpid() % 300 + 7 * world + (300 if riding else 0), out, riding, True, n, peer), nprocs=world, join=True)
     one = np.load(os.path.join(out, "parts_w1_r0.npy"))
     e1 = np.load(os.path.join(out, "est_w1_r0.npy"))
     g1 = np.load(os.path.join(out, "grid_w1_r0.npy"))
@@ -101,7 +110,8 @@ def test_composed_finish_matches_single_rank(tmp_path, world, riding, n):
         assert e1.tobytes() == np.load(os.path.join(out, f"est_w{world}_r{r}.npy")).tobytes(), f"rank {r}: estimates differ"
         assert np.array_equal(g1, np.load(os.path.join(out, f"grid_w{world}_r{r}.npy"))), f"rank {r}: map differs"
         sent, received, own, full = map(int, open(os.path.join(out, f"traffic_w{world}_r{r}.txt")).read().split())
-        assert sent + received < full or n < 100_000        # less than the replicated form's N x 16 B once N is large
+        assert received < full or n < 100_000               # less than the replicated form's N x 16 B once N is large
+        assert open(os.path.join(out, f"form_w{world}_r{r}.txt")).read() == ("peer" if peer else "collective")
     assert np.concatenate(got).tobytes() == one.tobytes()
 
 
