@@ -221,9 +221,26 @@ def cpu_baseline(args, m, odo, scans, rands, goal, n_steps):
                        f"{os.cpu_count()} host cores visible")
 
 
+PHASE_LIMIT_S = {                  # how long a multi-rank run may stay in one phase before the launcher ends it (first contact with
+    "start": 240.0,                # several devices: a hang in a collective or in a peer mapping must end the run with the phase's name)
+    "process-group": 180.0, "ipc-probe": 120.0, "engine": 180.0, "inputs": 600.0, "filter-init": 240.0, "planner-setup": 180.0,
+    "warmup": 300.0, "timed": 600.0, "stage-pass": 300.0, "report": 300.0, "teardown": 120.0,
+}
+
+
+def phase(json_fd, name):
+    """One line per phase on the launcher's pipe (rank 0 only): the watchdog of self_launch reads them."""
+    if int(os.environ.get("RANK", "0")) == 0 and os.environ.get("BENCH_PHASES"):
+        os.write(json_fd, f"[bench-phase] {name}\n".encode())
+
+
 def self_launch(n):
     """`python bench.py --gpus N` without a launcher: run N ranks under torch.distributed.run on this node (the same command the
-    contract quotes), pass rank 0's single JSON line through, return non-zero if any rank failed or no line came out."""
+    contract quotes) as a CHILD process group, pass rank 0's single JSON line through, return non-zero if any rank failed or no
+    line came out.  A watchdog: rank 0 reports its phases; a phase that outlasts its limit gets the whole child group killed (the
+    group this launcher started, by its id) and the launcher exits non-zero with the phase's name -- never a re-exec."""
+    import selectors
+    import signal
     import socket
     import subprocess
     with socket.socket() as s:
@@ -234,17 +251,49 @@ def self_launch(n):
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     env.setdefault("OMP_NUM_THREADS", "1")
-    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env)
-    line = None
-    for raw in proc.stdout:
-        txt = raw.decode(errors="replace").strip()
-        if txt.startswith("{") and '"metric"' in txt:
-            line = txt
-        elif txt:
-            print(txt, file=sys.stderr)
+    env["BENCH_PHASES"] = "1"
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, start_new_session=True)
+    sel = selectors.DefaultSelector()
+    sel.register(proc.stdout, selectors.EVENT_READ)
+    os.set_blocking(proc.stdout.fileno(), False)
+    line, cur, t_phase, buf = None, "start", time.monotonic(), b""
+    scale = float(os.environ.get("BENCH_WATCHDOG_SCALE", "1"))
+    while True:
+        ready = sel.select(timeout=1.0)
+        if ready:
+            chunk = proc.stdout.read()
+            if chunk:
+                buf += chunk
+                while b"\n" in buf:
+                    raw, buf = buf.split(b"\n", 1)
+                    txt = raw.decode(errors="replace").strip()
+                    if txt.startswith("[bench-phase] "):
+                        cur, t_phase = txt[len("[bench-phase] "):], time.monotonic()
+                        print(f"[bench] {n} ranks: {cur}", file=sys.stderr)
+                    elif txt.startswith("{") and '"metric"' in txt:
+                        line = txt
+                    elif txt:
+                        print(txt, file=sys.stderr)
+            elif proc.poll() is not None:
+                break
+        elif proc.poll() is not None:
+            break
+        if time.monotonic() - t_phase > scale * PHASE_LIMIT_S.get(cur, 300.0):
+            print(f"bench.py: the {n}-rank run spent more than {scale * PHASE_LIMIT_S.get(cur, 300.0):.0f} s in phase '{cur}': ending its process group",
+                  file=sys.stderr)
+            try:
+                os.killpg(proc.pid, signal.SIGTERM)
+                try:
+                    proc.wait(timeout=15)
+                except subprocess.TimeoutExpired:
+                    os.killpg(proc.pid, signal.SIGKILL)
+            except ProcessLookupError:
+                pass
+            proc.wait()
+            return 3
     rc = proc.wait()
     if rc != 0:
-        print(f"bench.py: the {n}-rank launch failed (exit {rc})", file=sys.stderr)
+        print(f"bench.py: the {n}-rank launch failed (exit {rc}) in phase '{cur}'", file=sys.stderr)
         return rc
     if line is None:
         print("bench.py: the ranks finished without a result line", file=sys.stderr)
@@ -420,6 +469,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if os.environ.get("BENCH_TEST_HANG") and "WORLD_SIZE" in os.environ:     # test hook (tests/test_bench_launcher_cpu.py): a rank that never gets anywhere
+        time.sleep(3600)
     if world != args.gpus:
         raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: start it as `python bench.py --gpus N` or under "
                          f"torch.distributed.run with --nproc-per-node equal to --gpus")
@@ -431,6 +482,7 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: botlab_amd has no CPU path")
+    phase(json_fd, "process-group")
     # Test hook (tests/test_gpu_bench_two_ranks.py): exercise the N > 1 code path on a one-GPU box -- every rank on cuda:0 and
     # the collectives over gloo (RCCL refuses two ranks on one device).  Never set by the driver.
     one_device = bool(os.environ.get("BENCH_TEST_ONE_DEVICE"))
@@ -453,18 +505,27 @@ def main():
     # section 6) when every rank can map every other rank's memory -- asked before the engines are made, because the two forms
     # cut the particle set at different bounds; otherwise the replicated form (all-gather of the whole record).
     composed = False
+    phase(json_fd, "ipc-probe")
+    if world > 1:
+        # first contact with several devices: say what the runtime reports before anything relies on it
+        nd = torch.cuda.device_count()
+        if rank == 0 and not one_device:
+            pairs = [f"{a}->{b}:{int(torch.cuda.can_device_access_peer(a, b))}" for a in range(min(world, nd)) for b in range(min(world, nd)) if a != b]
+            sys.stderr.write(f"[bench] can_device_access_peer: {' '.join(pairs)}\n")
     if world > 1 and sharded.composed_possible(args.particles, world):
         probe = bl.Context(local_rank)
         composed = sharded.ipc_probe(probe, rank, world)
         probe.close()
         if rank == 0:
-            sys.stderr.write(f"[bench] shard exchange: {'composed finish' if composed else 'replicated record (no IPC mapping between the ranks)'}\n")
+            sys.stderr.write(f"[bench] shard finish: {'composed (own blocks, sources read from their owners)' if composed else 'replicated record (no IPC mapping between the ranks)'}\n")
+    phase(json_fd, "engine")
     engine = sharded.HipShardEngine(args.particles, rank, world, local_rank, composed=composed)
     ctx = engine.ctx
     # The replanner on its own stream(s) (the reference's planner process); consecutive replans overlap on `lanes` streams.
     # Created before anything touches the null stream: the HIP runtime multiplexes streams onto 4 hardware queues (raising
     # GPU_MAX_HW_QUEUES costs ~50 us of launch latency per kernel, measured), and two lanes sharing a queue serialise.
     aplanner = bl.AsyncPlanner(ctx=ctx, lanes=args.lanes, batch=args.batch)
+    phase(json_fd, "inputs")
     m, truth, poses, odo, scans, rands = build_inputs(args, total, ctx)
     spf = sharded.ShardedParticleFilter(engine)
     grid = bl.OccupancyGrid.from_cells(m["cells"], m["origin"], m["mpc"], cellsPerMeter=cpm, ctx=ctx)
@@ -484,7 +545,12 @@ def main():
             goal = pick_goal(planner.distances_.cells(), m["origin"], poses[0][:2], 0.2, args.goal_l1)
     goal_pose = bl.make_pose(goal[0], goal[1], 0.0) if goal else None
 
+    phase(json_fd, "filter-init")
     spf.initializeFilterAtPose(bl.make_pose(*odo[0], utime=int(scans[0].times[0])), seed=42)
+    if world > 1 and rank == 0:
+        form = "peer stores (no collective)" if getattr(spf, "peer", False) else ("two small all-gathers" if spf.composed else "all-gather of the whole record")
+        sys.stderr.write(f"[bench] shard exchange form: {form}" + (f" -- peer stores not taken: {spf.peer_why}" if spf.composed and not spf.peer and spf.peer_why else "") + "\n")
+    phase(json_fd, "planner-setup")
     explorer = bl.AsyncExplorer(ctx=ctx, lanes=args.explore_lanes, robotRadius=0.2) if args.explore else None
     ex_log = []                       # one entry per fetched exploration step
 
@@ -634,6 +700,7 @@ def main():
     gc.freeze()
     gc.disable()
 
+    phase(json_fd, "warmup")
     k = 0
     for _ in range(args.warmup):
         step(k)
@@ -655,6 +722,7 @@ def main():
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
+    phase(json_fd, "timed")
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step(k)
@@ -671,6 +739,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    phase(json_fd, "stage-pass")
     ex_timed = list(ex_log)
     ex_skipped_timed = ex_skipped[0]
     main_ms_total, main_n = ctx.timing_get(_capi.BL_K_MCL_MAIN)
@@ -708,6 +777,7 @@ def main():
 
     if os.environ.get("BOTLAB_FINISH_LOOKAHEAD") and world == 1:
         engine.pf.debugEstimateStats()          # the library prints the map update's look-ahead counters to stderr
+    phase(json_fd, "report")
     if rank == 0:
         N, R = args.particles, scans[0].num_ranges
         W, H = m["cells"].shape[1], m["cells"].shape[0]
@@ -785,6 +855,7 @@ def main():
                        "particles": N, "grid": [W, H], "rays": R, "pipeline_depth": args.depth, "planner_lanes": args.lanes, "planner_batch": args.batch,
                        "parallelism": f"particle-shard x{world}" if world > 1 else "single GPU",
                        "collective": ("none" if not (world > 1 or spf.force_collectives) else
+                                      "none: peer stores over the ranks' IPC mappings + counter waits" if getattr(spf, "peer", False) else
                                       (("two small RCCL all-gathers (tile sums; records + tables)" if spf.composed else "RCCL all-gather of the whole record")
                                        + " enqueued by the library on the filter's stream" if spf.comm is not None
                                        else "torch.distributed all_gather_into_tensor" + (" x2 (composed finish)" if spf.composed else "")))},
@@ -808,7 +879,11 @@ def main():
         }
         if world > 1 or spf.force_collectives:
             sent, received, own = spf.exchange_bytes_per_update()
-            out["shard_exchange"] = {"form": "composed finish" if spf.composed else "replicated record", "bytes_sent_per_rank_per_step": sent,
+            out["shard_exchange"] = {"form": ("composed finish, peer stores (no collective)" if getattr(spf, "peer", False) else
+                                              ("composed finish, two small all-gathers" if spf.composed else "replicated record, one all-gather")),
+                                     "peer_stores_not_taken_because": (spf.peer_why if spf.composed and not getattr(spf, "peer", False) else None),
+                                     "measured_on_more_than_one_device": bool(world > 1 and not one_device),
+                                     "bytes_sent_per_rank_per_step": sent,
                                      "bytes_received_per_rank_per_step": received, "source_record_bytes_read_by_k_mcl_main": own,
                                      "replicated_form_would_receive": (world - 1) * engine.S * 16}
         if args.explore:
@@ -850,6 +925,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(args, m, odo, scans, rands, goal, args.cpu_steps)
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(out) + "\n").encode())
+    phase(json_fd, "teardown")
     if dist.is_initialized():
         dist.barrier()
         torch.cuda.synchronize()

@@ -152,6 +152,7 @@ SIGNATURES = {
     "bl_pf_shard_peer_selftest": (C.c_int, [_vp, _P(C.c_int)]),
     "bl_pf_shard_peer_reset": (C.c_int, [_vp, C.c_int]),
     "bl_pf_shard_exchange_peer": (C.c_int, [_vp]),
+    "bl_pf_shard_exchange_peer_phase": (C.c_int, [_vp, C.c_int]),
     "bl_planner_submit_with_map_update_finishing_pf": (C.c_int, [_vp, _vp, _P(Lidar), _vp, C.c_int64, _vp, _P(Pose), _P(SearchParams)]),
     "bl_astar_search_batch": (C.c_int, [_vp, _vp, _P(Pose), _vp, C.c_int, _P(SearchParams), _vp, C.c_int, _vp, _vp]),
     "bl_dist_gather": (C.c_int, [_vp, _vp, C.c_int, _vp]),

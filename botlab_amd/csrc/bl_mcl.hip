@@ -2009,7 +2009,13 @@ __device__ __forceinline__ void shard_store_sys(void* dst, const shard_i4 v)
     asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" :: "v"(dst), "v"(v) : "memory");
 }
 
-// Workgroup r of `world`: `bytes` (a multiple of 16) at src + off -> rank r's buffer + off, then rank r's flags[kind][rank] = gen
+typedef int shard_i2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void shard_store_sys8(void* dst, const shard_i2 v)
+{
+    asm volatile("global_store_dwordx2 %0, %1, off sc0 sc1" :: "v"(dst), "v"(v) : "memory");
+}
+
+// Workgroup r of `world`: `bytes` (a multiple of 8) at src + off -> rank r's buffer + off, then rank r's flags[kind][rank] = gen
 // (workgroup `rank` has nothing to do: its own copy is the source).  A workgroup per destination: the links to the seven
 // neighbours carry their copies side by side, and no workgroup waits for another.
 __global__ __launch_bounds__(1024) void k_shard_push(const shard_peers* __restrict__ peers, int kind, size_t off, size_t bytes, int rank, int world,
@@ -2019,8 +2025,13 @@ __global__ __launch_bounds__(1024) void k_shard_push(const shard_peers* __restri
     if (r == rank || r >= world) return;
     const char* src = (kind == 0 ? (const char*)peers->sums[rank] : (const char*)peers->xchg[rank]) + off;
     char* dst = (kind == 0 ? (char*)peers->sums[r] : peers->xchg[r]) + off;
-    const size_t n16 = bytes / 16;
-    for (size_t i = threadIdx.x; i < n16; i += blockDim.x) shard_store_sys(dst + i * 16, ((const shard_i4*)src)[i]);
+    if (((off | bytes) & 15) == 0) {
+        const size_t n16 = bytes / 16;
+        for (size_t i = threadIdx.x; i < n16; i += blockDim.x) shard_store_sys(dst + i * 16, ((const shard_i4*)src)[i]);
+    } else {                                                 // a slice of doubles that is not whole 16-byte pieces (an odd number of tiles)
+        const size_t n8 = bytes / 8;
+        for (size_t i = threadIdx.x; i < n8; i += blockDim.x) shard_store_sys8(dst + i * 8, ((const shard_i2*)src)[i]);
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __threadfence_system();
     __syncthreads();
@@ -2134,34 +2145,51 @@ extern "C" int bl_pf_shard_peer_reset(bl_pf* pf, int keep)
     return BL_OK;
 }
 
-// both stages of the running update's exchange in the peer-store form, everything on the filter's stream
-extern "C" int bl_pf_shard_exchange_peer(bl_pf* pf)
+// The running update's exchange in the peer-store form, on the filter's stream, in three phases: 0 = tile sums of the own block,
+// pushed to every rank; 1 = wait for every rank's sums, the own block's groups, their block pushed to every rank; 2 = wait for
+// every rank's block.  (Phases so that ONE process that drives several ranks -- tests -- can enqueue every rank's pushes before
+// any rank's wait: streams that share a hardware queue run in submission order.)
+extern "C" int bl_pf_shard_exchange_peer_phase(bl_pf* pf, int phase)
 {
-    BL_CHECK_ARG(pf != nullptr && pf->sh_world >= 2 && pf->sh_peer);
+    BL_CHECK_ARG(pf != nullptr && pf->sh_world >= 2 && pf->sh_peer && phase >= 0 && phase <= 2);
     if (!pf->pending_end) { bl_set_error("bl_pf_shard_exchange_peer without an update begun"); return BL_ERR_STATE; }
     BL_HIP(hipSetDevice(pf->ctx->device));
-    const unsigned long long gen = ++pf->sh_gen;            // (pf_shard_partials follows: this update's parity)
     const int tiles = pf->sh_block / SCAN_TILE;
-    int rc = bl_pf_shard_stage(pf, 1);
-    if (rc) return rc;
     hipEvent_t e0, e1;
-    rc = bl_timer_begin(pf->ctx, BL_K_MCL_SCAN, &e0, &e1);
-    if (rc) return rc;
-    const size_t sums_off = (size_t)((char*)(pf_shard_partials(pf) + (size_t)pf->sh_rank * tiles * 5) - (char*)pf->tile_partials);
-    hipLaunchKernelGGL(k_shard_push, dim3(pf->sh_world), dim3(1024), 0, pf->ctx->stream, pf->sh_peers_dev, 0, sums_off, (size_t)tiles * 5 * sizeof(double),
-                       pf->sh_rank, pf->sh_world, gen);
-    hipLaunchKernelGGL(k_shard_wait, dim3(1), dim3(64), 0, pf->ctx->stream, pf->sh_flags, 0, pf->sh_rank, pf->sh_world, gen, pf->state);
-    rc = bl_timer_end(pf->ctx, BL_K_MCL_SCAN, e0, e1);
-    if (rc) return rc;
-    rc = bl_pf_shard_stage(pf, 2);
-    if (rc) return rc;
-    rc = bl_timer_begin(pf->ctx, BL_K_MCL_SCAN, &e0, &e1);
-    if (rc) return rc;
-    hipLaunchKernelGGL(k_shard_push, dim3(pf->sh_world), dim3(1024), 0, pf->ctx->stream, pf->sh_peers_dev, 1, (size_t)pf->sh_rank * pf->sh_xchg_stride,
-                       pf->sh_xchg_stride, pf->sh_rank, pf->sh_world, gen);
-    hipLaunchKernelGGL(k_shard_wait, dim3(1), dim3(64), 0, pf->ctx->stream, pf->sh_flags, 1, pf->sh_rank, pf->sh_world, gen, pf->state);
+    int rc;
+    if (phase == 0) {
+        if (pf->sh_stage_sums) { bl_set_error("exchange phase 0 twice in one update"); return BL_ERR_STATE; }
+        pf->sh_gen += 1;                                     // (pf_shard_partials follows: this update's parity)
+        rc = bl_pf_shard_stage(pf, 1);
+        if (rc) return rc;
+        rc = bl_timer_begin(pf->ctx, BL_K_MCL_SCAN, &e0, &e1);
+        if (rc) return rc;
+        const size_t sums_off = (size_t)((char*)(pf_shard_partials(pf) + (size_t)pf->sh_rank * tiles * 5) - (char*)pf->tile_partials);
+        hipLaunchKernelGGL(k_shard_push, dim3(pf->sh_world), dim3(1024), 0, pf->ctx->stream, pf->sh_peers_dev, 0, sums_off,
+                           (size_t)tiles * 5 * sizeof(double), pf->sh_rank, pf->sh_world, pf->sh_gen);
+    } else if (phase == 1) {
+        if (!pf->sh_stage_sums || pf->sh_stage_groups) { bl_set_error("exchange phase 1 out of order"); return BL_ERR_STATE; }
+        hipLaunchKernelGGL(k_shard_wait, dim3(1), dim3(64), 0, pf->ctx->stream, pf->sh_flags, 0, pf->sh_rank, pf->sh_world, pf->sh_gen, pf->state);
+        rc = bl_pf_shard_stage(pf, 2);
+        if (rc) return rc;
+        rc = bl_timer_begin(pf->ctx, BL_K_MCL_SCAN, &e0, &e1);
+        if (rc) return rc;
+        hipLaunchKernelGGL(k_shard_push, dim3(pf->sh_world), dim3(1024), 0, pf->ctx->stream, pf->sh_peers_dev, 1, (size_t)pf->sh_rank * pf->sh_xchg_stride,
+                           pf->sh_xchg_stride, pf->sh_rank, pf->sh_world, pf->sh_gen);
+    } else {
+        if (!pf->sh_stage_groups) { bl_set_error("exchange phase 2 out of order"); return BL_ERR_STATE; }
+        rc = bl_timer_begin(pf->ctx, BL_K_MCL_SCAN, &e0, &e1);
+        if (rc) return rc;
+        hipLaunchKernelGGL(k_shard_wait, dim3(1), dim3(64), 0, pf->ctx->stream, pf->sh_flags, 1, pf->sh_rank, pf->sh_world, pf->sh_gen, pf->state);
+    }
     BL_HIP(hipGetLastError());
     return bl_timer_end(pf->ctx, BL_K_MCL_SCAN, e0, e1);
+}
+
+extern "C" int bl_pf_shard_exchange_peer(bl_pf* pf)
+{
+    for (int phase = 0; phase < 3; ++phase) { const int rc = bl_pf_shard_exchange_peer_phase(pf, phase); if (rc) return rc; }
+    return BL_OK;
 }
 
 // bytes of the exchange per rank and update: what this rank sends into the two all-gathers, what it receives from them, and

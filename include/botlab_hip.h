@@ -313,6 +313,7 @@ int bl_pf_shard_peer_active(const bl_pf* pf);
 int bl_pf_shard_peer_selftest(bl_pf* pf, int* ok);
 int bl_pf_shard_peer_reset(bl_pf* pf, int keep);
 int bl_pf_shard_exchange_peer(bl_pf* pf);
+int bl_pf_shard_exchange_peer_phase(bl_pf* pf, int phase);   /* 0 sums + push, 1 wait + groups + push, 2 wait: one process driving several ranks enqueues every rank's phase p before any rank's p + 1 */
 
 /* The NEXT lidar scan handed over early (a SLAM host has it queued, src/slam/slam.cpp:96-104): it is packed into pinned
  * memory now and copied to the device by the next bl_mapping_update* / bl_planner_submit_with_map_update* launch of this

@@ -53,3 +53,18 @@ def test_launcher_parent_does_not_import_torch():
         assert not any(m.startswith(("torch", "botlab_amd")) for m in imports(funcs[name])), name
     main_src = ast.get_source_segment(src, funcs["main"])
     assert main_src.index("run_other_configs(") < main_src.index("import torch") and main_src.index("self_launch(") < main_src.index("import torch")
+
+
+def test_watchdog_ends_a_hung_rank_group_and_names_the_phase():
+    """A multi-rank run that stops making progress (first contact with several devices: a hang inside a collective or a peer
+    mapping) is ended by the launcher parent: the child process group is killed, the exit status is non-zero, the phase is named."""
+    env = dict(os.environ, BENCH_TEST_ONE_DEVICE="1", BENCH_TEST_HANG="1", BENCH_WATCHDOG_SCALE="0.05")      # 'start' may last 12 s
+    import time
+    t0 = time.time()
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--cpu-steps", "0",
+                          "--particles", "500"], env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    err = out.stderr.decode()
+    assert out.returncode == 3, err[-1500:]
+    assert "in phase 'start'" in err and "ending its process group" in err
+    assert time.time() - t0 < 120
+    assert '"metric"' not in out.stdout.decode()

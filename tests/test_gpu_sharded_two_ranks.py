@@ -72,7 +72,7 @@ def _run(rank, world, port, out_dir, riding=False, composed=False, n=N, peer=Tru
         else:
             assert sent <= per_peer and received == (world - 1) * sent
         with open(os.path.join(out_dir, f"form_w{world}_r{rank}.txt"), "w") as f:
-            f.write("peer" if spf.peer else "collective")
+            f.write("peer" if spf.peer else "collective" + (": " + spf.peer_why if peer else ""))
         with open(os.path.join(out_dir, f"traffic_w{world}_r{rank}.txt"), "w") as f:
             f.write(f"{sent} {received} {own} {n * 16}")
     np.save(os.path.join(out_dir, f"grid_w{world}_r{rank}.npy"), grid.cells())
@@ -87,7 +87,7 @@ def _run(rank, world, port, out_dir, riding=False, composed=False, n=N, peer=Tru
 
 
 @pytest.mark.parametrize("world,riding,n,peer", [(2, False, N, True), (2, True, N, True), (3, True, N, False), (2, True, 200_001, True), (4, True, 3500, True),   # (3500 over four ranks: blocks of 1024, the small groups' alignment)
-                                                 (2, True, N, False), (6, True, 100_000, True)])
+                                                 (2, True, N, False), (5, True, 100_000, True)])
 def test_composed_finish_matches_single_rank(tmp_path, world, riding, n, peer):
     """The composed finish -- own blocks only, sources read from their owners' memory, two small all-gathers -- with 2 and 3 ranks
     on one device (one process per rank, IPC mappings, collectives over gloo): particles, estimates and the replicated map equal
@@ -135,3 +135,131 @@ def test_two_ranks_one_device_match_single_rank(tmp_path, riding):
     g1 = np.load(os.path.join(out, "grid_w1_r0.npy"))
     for r in range(2):
         assert np.array_equal(g1, np.load(os.path.join(out, f"grid_w2_r{r}.npy")))      # the replicated map stays identical
+
+
+def _run_inproc(_unused_rank, world, out_dir, n, steps):
+    """`world` ranks of the composed finish with the peer-store exchange inside ONE process (the GPU box admits six processes on its
+    card; eight ranks need another arrangement): every rank is its own ctx + stream + filter + map, ranks hand each other their raw
+    device pointers (the same-process path of the C ABI), and the driver enqueues every rank's exchange phase p before any rank's
+    phase p + 1 -- streams that share a hardware queue run in submission order, so a wait never sits in front of the push it waits
+    for."""
+    sys.path.insert(0, HERE)
+    sys.path.insert(0, os.path.dirname(HERE))
+    import ctypes as C
+    import helpers
+    import botlab_amd as bl
+    from botlab_amd import sharded, synth
+    from botlab_amd._capi import check
+    m = helpers.load_reference_maps()["convex_10mx10m_5cm" if n >= 1_000_000 else "obstacle_slam_10mx10m_5cm"]
+    truth = np.where(m["cells"] > 0, 127, -127).astype(np.int8)
+    start = (-0.4, -0.4, 0.0) if n >= 1_000_000 else (-0.75, 0.2, 0.0)
+    poses = synth.square_trajectory(start, steps, step_len=0.03, turn=0.05, side=0.8)
+    scans = [synth.raycast_scan(truth, m["origin"], 0.05, poses[k - 1], poses[k], 1_000_000 + k * 100_000) for k in range(1, steps + 1)]
+    assert sharded.composed_possible(n, world)
+    engs = [sharded.HipShardEngine(n, r, world, 0, composed=True) for r in range(world)]
+    lib = engs[0].ctx.lib
+    grids = [bl.OccupancyGrid.from_cells(m["cells"], m["origin"], m["mpc"], cellsPerMeter=helpers.CPM_DEFAULT, ctx=e.ctx) for e in engs]
+    mappers = [bl.Mapping(5.0, 4, 1, ctx=e.ctx) for e in engs]
+    for e in engs:
+        e.init_at_pose(bl.make_pose(*start, utime=int(scans[0].times[0])), 21)
+        e.shard_setup()
+
+    def ptrs_of(e, fn):                       # every rank's arrays to every rank: the pointers themselves
+        p3 = [C.c_void_p() for _ in range(3)]
+        check(fn(e.pf.h, *[C.byref(q) for q in p3]))
+        return [q.value for q in p3]
+
+    recs = [ptrs_of(e, lib.bl_pf_shard_local_ptrs) for e in engs]
+    for e in engs:
+        for r in range(world):
+            check(lib.bl_pf_shard_set_peer(e.pf.h, r, *recs[r]))
+        check(lib.bl_pf_shard_commit(e.pf.h))
+    bufs = [ptrs_of(e, lib.bl_pf_shard_local_ptrs_peer) for e in engs]
+    for e in engs:
+        for r in range(world):
+            check(lib.bl_pf_shard_set_peer_buffers(e.pf.h, r, *bufs[r]))
+        check(lib.bl_pf_shard_peer_commit(e.pf.h))
+        assert lib.bl_pf_shard_peer_active(e.pf.h) == 1
+    est = [[] for _ in engs]
+    for k, sc in enumerate(scans):
+        odo = bl.make_pose(*poses[k + 1], utime=sc.utime)
+        moved = [e.begin(odo, sc, g, 900 + k) for e, g in zip(engs, grids)]
+        assert len(set(moved)) == 1
+        if moved[0]:
+            for phase in range(3):
+                for e in engs:
+                    check(lib.bl_pf_shard_exchange_peer_phase(e.pf.h, phase))
+                if os.environ.get("SHARD_PROBE_SYNC"):
+                    for e in engs:
+                        e.ctx.sync()
+        for e, g, mp_ in zip(engs, grids, mappers):
+            mp_.updateMapFinishingFilter(sc, e.pf, sc.utime, g)         # the finish rides in every rank's map kernel
+        for r, e in enumerate(engs):
+            p = e.pf.poseEstimate()
+            est[r].append((p.utime, p.x, p.y, p.theta))
+    for r, (e, g) in enumerate(zip(engs, grids)):
+        np.save(os.path.join(out_dir, f"grid_w{world}_r{r}.npy"), g.cells())
+        np.save(os.path.join(out_dir, f"parts_w{world}_r{r}.npy"), e.particles())
+        np.save(os.path.join(out_dir, f"est_w{world}_r{r}.npy"), np.array(est[r], dtype=np.float64))
+        sent, received, own = e.traffic()
+        with open(os.path.join(out_dir, f"shard_w{world}_r{r}.txt"), "w") as f:
+            f.write(f"{e.lo} {e.hi} {sent} {received} {e.S}")
+
+
+def _run_single(_unused_rank, out_dir, n, steps):
+    """the one-rank reference of _run_inproc: the record-based finish as separate launches"""
+    sys.path.insert(0, HERE)
+    sys.path.insert(0, os.path.dirname(HERE))
+    os.environ["BOTLAB_MCL_NO_FUSED_FINISH"] = "1"
+    import helpers
+    import botlab_amd as bl
+    from botlab_amd import sharded, synth
+    m = helpers.load_reference_maps()["convex_10mx10m_5cm" if n >= 1_000_000 else "obstacle_slam_10mx10m_5cm"]
+    truth = np.where(m["cells"] > 0, 127, -127).astype(np.int8)
+    start = (-0.4, -0.4, 0.0) if n >= 1_000_000 else (-0.75, 0.2, 0.0)
+    poses = synth.square_trajectory(start, steps, step_len=0.03, turn=0.05, side=0.8)
+    scans = [synth.raycast_scan(truth, m["origin"], 0.05, poses[k - 1], poses[k], 1_000_000 + k * 100_000) for k in range(1, steps + 1)]
+    eng = sharded.HipShardEngine(n, 0, 1, 0)
+    spf = sharded.ShardedParticleFilter(eng)
+    grid = bl.OccupancyGrid.from_cells(m["cells"], m["origin"], m["mpc"], cellsPerMeter=helpers.CPM_DEFAULT, ctx=eng.ctx)
+    mapper = bl.Mapping(5.0, 4, 1, ctx=eng.ctx)
+    spf.initializeFilterAtPose(bl.make_pose(*start, utime=int(scans[0].times[0])), seed=21)
+    est = []
+    for k, sc in enumerate(scans):
+        p = spf.updateFilter(bl.make_pose(*poses[k + 1], utime=sc.utime), sc, grid, 900 + k)
+        mapper.updateMapDevicePose(sc, eng.pf.poseDevicePtr(), sc.utime, grid)
+        est.append((p.utime, p.x, p.y, p.theta))
+    np.save(os.path.join(out_dir, "grid_w1_r0.npy"), grid.cells())
+    np.save(os.path.join(out_dir, "parts_w1_r0.npy"), spf.particles())
+    np.save(os.path.join(out_dir, "est_w1_r0.npy"), np.array(est, dtype=np.float64))
+
+
+@pytest.mark.parametrize("n,steps", [(100_000, 5), (1_000_000, 3)])
+def test_eight_ranks_peer_store_exchange_match_single_rank(tmp_path, n, steps):
+    """BASELINE.json configs[2]'s shape -- eight ranks, 100 000 and 1 000 000 particles (8 x 126 976: large groups, a ragged last
+    block of 111 168) -- through the composed finish with the peer-store exchange: particles, estimates and every rank's map equal
+    the single rank's bit for bit, and a rank stores (world - 1) x (its tile sums + its exchange block) per update, nothing else."""
+    import torch.multiprocessing as mp
+    out = str(tmp_path)
+    world = 8
+    mp.spawn(_run_single, args=(out, n, steps), nprocs=1, join=True)
+    mp.spawn(_run_inproc, args=(world, out, n, steps), nprocs=1, join=True)
+    one = np.load(os.path.join(out, "parts_w1_r0.npy"))
+    e1 = np.load(os.path.join(out, "est_w1_r0.npy"))
+    g1 = np.load(os.path.join(out, "grid_w1_r0.npy"))
+    got = []
+    from botlab_amd import sharded
+    for r in range(world):
+        lo, hi, sent, received, S = map(int, open(os.path.join(out, f"shard_w{world}_r{r}.txt")).read().split())
+        assert (lo, hi) == sharded.shard_bounds(n, r, world, sharded.composed_align(n))[:2]
+        part = np.load(os.path.join(out, f"parts_w{world}_r{r}.npy"))
+        assert part.size == hi - lo
+        got.append(part)
+        assert e1.tobytes() == np.load(os.path.join(out, f"est_w{world}_r{r}.npy")).tobytes(), f"rank {r}: estimates differ"
+        assert np.array_equal(g1, np.load(os.path.join(out, f"grid_w{world}_r{r}.npy"))), f"rank {r}: map differs"
+        per_peer = (S // 512) * 40 + 64 + 2 * (S // 128) * 16 + 2 * 20 * 128 * 16 + 255       # tile sums + [header, records, tables] rounded to 256
+        assert sent == received and (world - 1) * ((S // 512) * 40) < sent <= (world - 1) * per_peer, (sent, per_peer)
+        assert sent < n * 16 * (world - 1) // world             # less than the replicated form receives ((world - 1) / world x N x 16 B); 1M: 1/16 of it
+        if n >= 1_000_000:
+            assert sent < n * 16 // 16
+    assert np.concatenate(got).tobytes() == one.tobytes()
