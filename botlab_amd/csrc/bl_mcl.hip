@@ -27,7 +27,7 @@
 #include "bl_internal.h"
 #include "bl_mcl_finish.h"
 
-#define MCL_LDS_RAYS 768                      // rays whose (range, theta) table is staged in LDS (more: read from global memory)
+#define MCL_LDS_RAYS 384                      // rays whose (range, theta, cos theta, sin theta) table is staged in LDS at a time (longer scans: several passes)
 #define MCL_MIN_BLOCKS 512                    // split rays over lanes until the launch has at least this many workgroups (2 per CU)
 #define MCL_WIN_SMALL_BYTES (64 * 1024)       // whole-grid staging budget (200x200 int8 framed = 41 KB -> three workgroups per CU)
 #define MCL_WIN_MAX 208                       // window side: 208^2 = 42 KB, three workgroups per CU like the whole-grid image of a 200x200 map
@@ -306,10 +306,19 @@ __device__ __forceinline__ void ray_cells_pk(float2_t start, float cpm, float ra
 }
 
 // ---- the same two cells WITHOUT the exact sinf / cosf for almost every ray.
-// The reference takes sinf / cosf of theta' = wrap_to_pi(d), d = pose.theta - ray theta.  v_sin_f32 / v_cos_f32 of d / 2pi differ
-// from those values by at most MCL_TRIG_EPS for EVERY float d in [-3pi - 0.01, pi + 0.01] -- the wrap's own rounding and the
-// scaling included (tests/tools/sincos_hw_probe.hip: exhaustive over the 2 170 595 470 floats of that range, 8.81e-7 for the
-// sine, 7.75e-7 for the cosine) -- which is the range of d when every theta of the scan lies in [0, 6.2831] (theta_simple).
+// The reference takes sinf / cosf of theta' = wrap_to_pi(d), d = fl(pose.theta - ray theta).  Here the direction comes from the
+// addition theorems: cos(p - r) = cp cr + sp sr, sin(p - r) = sp cr - cp sr, with (cp, sp) the particle's and (cr, sr) the ray's
+// pair, each formed in double and rounded to float once -- two packed instructions per ray where v_sin_f32 and v_cos_f32 (quarter
+// rate each, and a multiply in front) cost nine issue slots.  How far that is from the reference's float values, for every float
+// p in [-pi, pi] and r in [0, 6.2832] (theta_simple), with u = 2^-24:
+//     the reference's angle: |fl(p - r) - (p - r)| <= 4.8e-7 (half an ulp below 16: p - r reaches -3 pi), the wrap's own rounding
+//         <= 1.2e-7 (half an ulp below 4: it adds 2 pi in double and rounds once); sinf / cosf of it, rounded: + 6e-8    <= 6.6e-7
+//     the four table values: each within 0.56 ulp = 3.3e-8 of the true value (libm's sinf / cosf); into the two products: <= 3.3e-8
+//         (|cr| + |cp| + |sr| + |sp|) <= 9.4e-8; the product's and the fma's own roundings: 2 x 3e-8                    <= 1.6e-7
+// together <= 8.2e-7 < MCL_TRIG_EPS = 9.3e-7 (measured maximum over 1e10 random pairs: bl_debug_trig_addition_probe,
+// profiles/r04_trig_addition_probe.json).
+// The guard band below is the one the hardware-sine form was proven with (tests/tools/sincos_hw_probe.hip measured 8.81e-7 for it);
+// it is kept, so the exact path behind it is taken as often as before.
 // With dir' = dir + eta, |eta| <= eps, and u = 2^-24 the relative error of one float operation:
 //     |fl(range * dir') - fl(range * dir)|      <= range * (eps + 2u)
 //     |t' - t|, t = fl(fl(range * dir) * cpm)   <= range * cpm * (eps + 4u) (1 + 2u)
@@ -318,9 +327,10 @@ __device__ __forceinline__ void ray_cells_pk(float2_t start, float cpm, float ra
 // so the truncated cells agree whenever e' (x') is farther than B1 (B2) from every integer, B1 = range * k1 + k2, B2 = range * 2 k1
 // + k2 with k1 = 1.02 * cpm * (eps + 4u) and k2 = 2.04u * (a bound on the particle's cell coordinates: |start| + 2 * longest
 // ray + 8).  A ray inside a band (1-4 in a thousand) makes its whole wave take the exact path for that round and keeps the exact
-// cells; everything downstream is integer.  (The guard costs ~15 instructions, the exact sinf / cosf with the wrap 36.)
-// MCL_TRIG_EPS: 5.5 % above the larger measured maximum.  bl_debug_trig_probe repeats the exhaustive measurement with the very
-// function the ray loop calls (hw_sincos_unwrapped), and tests/test_gpu_trig_guard.py asserts both maxima stay 5 % below it.
+// cells; everything downstream is integer.
+// MCL_TRIG_EPS: 5.5 % above the larger maximum measured for the hardware form (bl_debug_trig_probe, kept: BOTLAB_MCL_HW_TRIG=1 takes
+// that form), 13 % above the addition form's analytic bound and 45 % above its measured maximum; tests/test_gpu_trig_guard.py
+// asserts the measured maxima of both forms stay below it.
 #define MCL_TRIG_EPS 9.3e-7f
 __device__ __forceinline__ void hw_sincos_unwrapped(float d, float* sn, float* cs)
 {
@@ -328,10 +338,27 @@ __device__ __forceinline__ void hw_sincos_unwrapped(float d, float* sn, float* c
     asm("v_sin_f32 %0, %1" : "=v"(*sn) : "v"(rev));
     asm("v_cos_f32 %0, %1" : "=v"(*cs) : "v"(rev));
 }
-__device__ __forceinline__ void ray_cells_fast(float2_t start, float cpm, float range, float d, float k1, float k2, short2_t& E, short2_t& X)
+// (range, theta, cos theta, sin theta): cosf / sinf as libm rounds them (bl_sincosf_cells: a double polynomial rounded once,
+// within 0.56 ulp -- a double sincos here cost the staging waves more than the transcendentals it replaces saved the ray loop)
+__device__ __forceinline__ float4 ray_table_entry(float range, float theta)
 {
     float sn, cs;
-    hw_sincos_unwrapped(d, &sn, &cs);
+    bl_sincosf_cells(theta, &sn, &cs);
+    return make_float4(range, theta, cs, sn);
+}
+// (cos, sin)(p - r) from (cp, sp) and (cr, sr): v_pk_mul_f32 + v_pk_fma_f32
+__device__ __forceinline__ float2_t trig_by_addition(float2_t pcs, float cr, float sr)
+{
+    const float2_t a = {pcs.y, -pcs.x};                      // (sp, -cp)
+    const float2_t t = a * float2_t{sr, sr};
+    return __builtin_elementwise_fma(pcs, float2_t{cr, cr}, t);           // (cp cr + sp sr, sp cr - cp sr)
+}
+__device__ __forceinline__ void ray_cells_fast(float2_t start, float cpm, float range, float d, float2_t pcs, float cr, float sr, float k1, float k2,
+                                               short2_t& E, short2_t& X)
+{
+    float sn, cs;
+    if (pcs.x > 1.5f) hw_sincos_unwrapped(d, &sn, &cs);      // (wave-uniform: BOTLAB_MCL_HW_TRIG marks the pair)
+    else { const float2_t dir = trig_by_addition(pcs, cr, sr); cs = dir.x; sn = dir.y; }
     float2_t e, x;
     ray_points_pk(start, cpm, range, cs, sn, e, x);
     const float B1 = __builtin_fmaf(range, k1, k2), B2 = __builtin_fmaf(range, k1 + k1, k2);
@@ -452,7 +479,8 @@ struct mcl_args {
     int split_log2;               // each particle's rays are spread over 2^split_log2 adjacent lanes
     int pk_ok;                    // grid and scan admit the packed 16-bit scoring path (see score_ray_pk)
     int theta_simple;             // every theta of the scan lies in [0, 6.2831] (see wrap_to_pi_cells)
-    int fast_trig;                // hardware sine / cosine with a guard band and the exact path behind it (ray_cells_fast)
+    int fast_trig;                // ray directions without the exact sinf / cosf, a guard band and the exact path behind it (ray_cells_fast):
+                                  // 1 by the addition theorems, 2 by the hardware sine / cosine, 0 off
     int stage_dma;                // whole-grid staging by LDS-DMA (rows of whole dwords, at most 64 of them)
     float max_range_cells;        // longest kept ray in cells
     int main_blocks, main_particles;   // region 1: main_blocks workgroups cover particles [0, main_particles) of the shard
@@ -495,14 +523,14 @@ __device__ __forceinline__ void philox_normals3(uint32_t m, uint32_t step, uint3
 #define MCL_RAY_LOOP(SCORE_EXPR)                                                        \
     do {                                                                                \
         const int rounds_ = cnt >> sl2;                                                 \
-        int off_ = sub * 8;                          /* byte offset of the table entry */ \
-        for (int k_ = 0; k_ < rounds_; ++k_, off_ += split * 8) {                       \
+        int off_ = sub * 16;                         /* byte offset of the table entry */ \
+        for (int k_ = 0; k_ < rounds_; ++k_, off_ += split * 16) {                      \
             const float2 rt = *(const float2*)((const char*)s_ray + off_);              \
             float sn, cs;                                                               \
             bl_sincosf_cells(wrap_to_pi_cells(pth_r - rt.y, theta_simple), &sn, &cs);                   \
             acc += SCORE_EXPR;                                                          \
         }                                                                               \
-        if ((off_ >> 3) < cnt) {                                                        \
+        if ((off_ >> 4) < cnt) {                                                        \
             const float2 rt = *(const float2*)((const char*)s_ray + off_);              \
             float sn, cs;                                                               \
             bl_sincosf_cells(wrap_to_pi_cells(pth_r - rt.y, theta_simple), &sn, &cs);                   \
@@ -510,24 +538,26 @@ __device__ __forceinline__ void philox_normals3(uint32_t m, uint32_t step, uint3
         }                                                                               \
     } while (0)
 
-// The same loops with the two cells from ray_cells_fast (theta_simple scans only)
-#define MCL_RAY_LOOP_FAST(PM)                                                           \
+// The same loops with the two cells from ray_cells_fast (theta_simple scans only): the direction by the addition theorems from
+// the particle's (cos, sin) pair pcs_ and the table's.  Rays [LO, HI) of the chunk (LO a multiple of the split).
+#define MCL_RAY_LOOP_FAST_RANGE(PM, LO, HI)                                             \
     do {                                                                                \
-        const int rounds_ = cnt >> sl2;                                                 \
-        int off_ = sub * 8;                                                             \
-        for (int k_ = 0; k_ < rounds_; ++k_, off_ += split * 8) {                       \
-            const float2 rt = *(const float2*)((const char*)s_ray + off_);              \
+        const int rounds_ = ((HI) - (LO)) >> sl2;                                       \
+        int off_ = ((LO) + sub) * 16;                                                   \
+        for (int k_ = 0; k_ < rounds_; ++k_, off_ += split * 16) {                      \
+            const float4 rt = *(const float4*)((const char*)s_ray + off_);              \
             short2_t E_, X_;                                                            \
-            ray_cells_fast(start, a.frame.cpm, rt.x, pth_r - rt.y, trig_k1, trig_k2, E_, X_);   \
+            ray_cells_fast(start, a.frame.cpm, rt.x, pth_r - rt.y, pcs_, rt.z, rt.w, trig_k1, trig_k2, E_, X_);   \
             acc += score_cells_pk(PM, S, E_, X_);                                       \
         }                                                                               \
-        if ((off_ >> 3) < cnt) {                                                        \
-            const float2 rt = *(const float2*)((const char*)s_ray + off_);              \
+        if ((off_ >> 4) < (HI)) {                                                       \
+            const float4 rt = *(const float4*)((const char*)s_ray + off_);              \
             short2_t E_, X_;                                                            \
-            ray_cells_fast(start, a.frame.cpm, rt.x, pth_r - rt.y, trig_k1, trig_k2, E_, X_);   \
+            ray_cells_fast(start, a.frame.cpm, rt.x, pth_r - rt.y, pcs_, rt.z, rt.w, trig_k1, trig_k2, E_, X_);   \
             acc += score_cells_pk(PM, S, E_, X_);                                       \
         }                                                                               \
     } while (0)
+#define MCL_RAY_LOOP_FAST(PM) MCL_RAY_LOOP_FAST_RANGE(PM, 0, cnt)
 
 // ---- resampling search, first part: a wave narrows the range its lanes have to bisect -----------------------------------
 // The lanes of a wave resample consecutive particles, so their targets T ascend and every lane's source index lies
@@ -648,10 +678,13 @@ __global__ __launch_bounds__(BLOCK) void k_mcl_main(mcl_args a)
     extern __shared__ __align__(16) signed char s_dyn[];
     __shared__ double s_part[BLOCK / 64][5];
     __shared__ map_window s_win;
-    // (range, theta) of the kept rays, MCL_LDS_RAYS at a time: one ds_read_b64 per ray.  (A table that is read from LDS or,
-    // past its size, from global memory makes every access a FLAT load behind two scalar branches.)
-    __shared__ float2 s_ray[MCL_LDS_RAYS];
+    // (range, theta, cos theta, sin theta) of the kept rays, MCL_LDS_RAYS at a time: one ds_read_b128 per ray.  (A table that is
+    // read from LDS or, past its size, from global memory makes every access a FLAT load behind two scalar branches.)  The cosine
+    // and sine are those of the ray's own angle, formed in double and rounded once (ray_table_entry): the fast ray loop gets the
+    // direction of pose.theta - theta from them by the addition theorems instead of two transcendentals per particle-ray.
+    __shared__ float4 s_ray[MCL_LDS_RAYS];
     __shared__ float4 s_pp[BLOCK / 4];                      // shared prologue: (theta, start x, start y, -) per particle
+    __shared__ float2 s_pcs[BLOCK / 4];                     // ... and (cos theta, sin theta), formed in double and rounded once
     __shared__ int s_acc[BLOCK / 4];                        // shared prologue: half-unit score per particle
     const lds_i8_t* s_map = (const lds_i8_t*)s_dyn;
     int* s_map32 = (int*)s_dyn;
@@ -710,7 +743,7 @@ __global__ __launch_bounds__(BLOCK) void k_mcl_main(mcl_args a)
         const int sw = wave - pw;
         const int st = tid - pw * 64, n_st = n_sw * 64;
         const int cnt0 = a.R < MCL_LDS_RAYS ? a.R : MCL_LDS_RAYS;
-        for (int n = st; n < cnt0; n += n_st) s_ray[n] = make_float2(a.ranges[n], a.thetas[n]);
+        for (int n = st; n < cnt0; n += n_st) s_ray[n] = ray_table_entry(a.ranges[n], a.thetas[n]);
         if (MAP_MODE == 1) {
             // the whole grid as a framed image: rows -MCL_FRAME..H+MCL_FRAME-1, columns -4..stride-5 (zeros outside)
             const int wq = win.stride >> 2;
@@ -775,6 +808,8 @@ __global__ __launch_bounds__(BLOCK) void k_mcl_main(mcl_args a)
     MCL_STAMP_T(4, pw * 64);                                     // a staging wave is through
     // ---- phase 1b: per-particle prologue
     double t_units = 0, t_x = 0, t_y = 0, t_s = 0, t_c = 0;
+    float2 pcs_own = make_float2(2.0f, 0.0f);               // (2, -): "take the hardware sine / cosine" (a.fast_trig == 2)
+    float pth_sin = 0.0f, pth_cos = 1.0f;
     int i = mp;
     float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
     float px = 0.f, py = 0.f, pth = 0.f, sx0 = 0.f, sy0 = 0.f;
@@ -810,18 +845,22 @@ __global__ __launch_bounds__(BLOCK) void k_mcl_main(mcl_args a)
         py = (float)((double)s.y + (double)n2 * hs);
         pth = bl_wrap_to_pi(s.z + n1 + n3);
         if (a.cells) bl_global_to_grid(px, py, a.frame, &sx0, &sy0);
+        bl_sincosf(pth, &pth_sin, &pth_cos);                 // (the estimate's partial sums need them anyway: particle_filter.cpp:151-152)
+        if (a.cells && a.fast_trig == 1) pcs_own = make_float2(pth_cos, pth_sin);
     }
     // guard-band offset of the fast trig path for this particle: 2.04 u times a bound on its cell coordinates (ray_cells_fast)
     const float trig_reach = 2.0f * a.max_range_cells + 8.0f;
     const float k2_own = 1.2159e-7f * (__builtin_fmaxf(__builtin_fabsf(sx0), __builtin_fabsf(sy0)) + trig_reach);
     MCL_STAMP(7);                                                // prologue arithmetic done
-    if (shared_pro && tid < P) s_pp[tid] = make_float4(pth, sx0, sy0, k2_own);
+    if (shared_pro && tid < P) { s_pp[tid] = make_float4(pth, sx0, sy0, k2_own); s_pcs[tid] = pcs_own; }
     __syncthreads();                                            // map, ray table and particle table are in place
     MCL_STAMP(1);
 
     // what the ray loop needs of this lane's particle
     float r_pth = pth, r_sx0 = sx0, r_sy0 = sy0, trig_k2 = k2_own;
-    if (shared_pro) { const float4 e = s_pp[jl]; r_pth = e.x; r_sx0 = e.y; r_sy0 = e.z; trig_k2 = e.w; }
+    float2 r_pcs = pcs_own;
+    if (shared_pro) { const float4 e = s_pp[jl]; r_pth = e.x; r_sx0 = e.y; r_sy0 = e.z; trig_k2 = e.w; r_pcs = s_pcs[jl]; }
+    const float2_t pcs_ = {r_pcs.x, r_pcs.y};
     const float trig_k1 = 1.02f * a.frame.cpm * (MCL_TRIG_EPS + 2.3842e-7f);      // 4u = 2^-22
     const bool fast_trig = a.fast_trig != 0;                                       // wave-uniform
     const int isx0 = (int)r_sx0, isy0 = (int)r_sy0;
@@ -838,7 +877,7 @@ __global__ __launch_bounds__(BLOCK) void k_mcl_main(mcl_args a)
             const int cnt = a.R - base < MCL_LDS_RAYS ? a.R - base : MCL_LDS_RAYS;
             if (base > 0) {
                 __syncthreads();                                    // every lane is done with the previous chunk
-                for (int n = tid; n < cnt; n += BLOCK) s_ray[n] = make_float2(a.ranges[base + n], a.thetas[base + n]);
+                for (int n = tid; n < cnt; n += BLOCK) s_ray[n] = ray_table_entry(a.ranges[base + n], a.thetas[base + n]);
                 __syncthreads();
             }
             if (!active) continue;
@@ -871,7 +910,7 @@ __global__ __launch_bounds__(BLOCK) void k_mcl_main(mcl_args a)
                 const bl_pose3 pb = {s.x, s.y, s.z};            // INTERP: the prologue is not shared, these are this lane's own
                 const bl_pose3 pe = {px, py, pth};
                 for (int n = sub; n < cnt; n += split) {    // the host uploads only rays with range > 0.15f (moving_laser_scan.cpp:24)
-                    const float2 rt = s_ray[n];
+                    const float4 rt = s_ray[n];
                     float theta, sx, sy;
                     int isx, isy;
                     if (INTERP) {
@@ -905,8 +944,7 @@ __global__ __launch_bounds__(BLOCK) void k_mcl_main(mcl_args a)
         a.parent[jp] = make_float4(s.x, s.y, s.z, 0.0f);
         if (a.dbg_idx) { a.dbg_idx[jp] = i; a.dbg_like[jp] = acc; }
         // ---- estimatePosteriorPose (particle_filter.cpp:144-160) partial sums
-        float sth, cth;
-        bl_sincosf(pth, &sth, &cth);
+        const float sth = pth_sin, cth = pth_cos;           // sinf / cosf of the particle's heading, from the prologue
         t_units = (double)units;
         t_x = t_units * (double)px;
         t_y = t_units * (double)py;
@@ -1536,7 +1574,8 @@ static int pf_launch_main(bl_pf* pf, const bl_grid* map, int R, int rand_value, 
     // packed 16-bit scoring: grid up to 8192 a side, the longest kept ray spans at most 4000 cells (see score_ray_pk)
     a.theta_simple = ctx->scan.thetas_simple ? 1 : 0;
     a.max_range_cells = map ? ctx->scan.max_range * a.frame.cpm : 0.0f;
-    a.fast_trig = (a.theta_simple && !pf->no_fast_trig) ? 1 : 0;
+    static const bool hw_trig = getenv("BOTLAB_MCL_HW_TRIG") != nullptr;        // the round-3 form of the fast path (A/B runs, tests)
+    a.fast_trig = (a.theta_simple && !pf->no_fast_trig) ? (hw_trig ? 2 : 1) : 0;
     a.stage_dma = pf->no_stage_dma ? 0 : 1;
     a.pk_ok = (map && a.frame.width <= 8192 && a.frame.height <= 8192 && ctx->scan.max_range * a.frame.cpm <= 4000.0f &&
                !pf->no_packed) ? 1 : 0;
@@ -1585,6 +1624,9 @@ static int pf_launch_main(bl_pf* pf, const bl_grid* map, int R, int rand_value, 
                 a.win_h = side < H + 2 * MCL_FRAME ? side : H + 2 * MCL_FRAME;
                 lds_bytes = a.win_w * a.win_h;
                 mode = 2;
+                // (Tried in round 4: the scan's rays packed longest first and the rounds of rays longer than the window's half side
+                // scored from the framed image directly, without the window attempt and its ballot -- 0.1156 ms against 0.1133 at
+                // 2000 x 2000 / 100k particles: what a large grid costs is the L2 gathers of the long rays themselves.)
             }
         }
     }
@@ -2404,6 +2446,59 @@ extern "C" int bl_debug_trig_probe(bl_ctx* ctx, float* max_sin_err, float* max_c
     *max_sin_err = h[0]; *max_cos_err = h[1];
     if (eps_used) *eps_used = MCL_TRIG_EPS;
     if (floats_checked) *floats_checked = (uint64_t)bp + 1ull + (uint64_t)bn + 1ull;
+    return BL_OK;
+}
+
+// |direction by the addition theorems - the reference's sinf / cosf of wrap_to_pi(fl(p - r))| over random pairs: p a float of
+// [-pi, pi] (a particle's wrapped heading), r a float of [0, 6.2831] (a theta_simple scan's ray angle), with the very functions the
+// ray loop calls (ray_table_entry, trig_by_addition; bl_sincosf_cells / wrap_to_pi_cells on the exact side).
+__global__ __launch_bounds__(256) void k_trig_addition_probe(unsigned long long pairs_per_thread, unsigned int seed, unsigned int* out_max)
+{
+    unsigned int ms = 0, mc = 0;
+    // xorshift128+ per thread, seeded by a mix of the thread index
+    unsigned long long s0 = (0x9E3779B97F4A7C15ull * ((unsigned long long)blockIdx.x * blockDim.x + threadIdx.x + 1ull)) ^ ((unsigned long long)seed << 17);
+    unsigned long long s1 = 0xD1B54A32D192ED03ull * (s0 | 1ull);
+    for (unsigned long long k = 0; k < pairs_per_thread; ++k) {
+        unsigned long long x = s0; const unsigned long long y = s1;
+        s0 = y; x ^= x << 23; s1 = x ^ y ^ (x >> 17) ^ (y >> 26);
+        const unsigned long long rnd = s1 + y;
+        const float up = (float)(unsigned int)(rnd >> 40) * (1.0f / 16777216.0f);           // 24 bits each
+        const float ur = (float)(unsigned int)((rnd >> 16) & 0xFFFFFFull) * (1.0f / 16777216.0f);
+        const float p = bl_wrap_to_pi((up - 0.5f) * 6.2831855f);
+        const float r = ur * 6.2831f;
+        float ps, pc;
+        bl_sincosf(p, &ps, &pc);
+        const float2_t pcs = {pc, ps};
+        const float4 rt = ray_table_entry(1.0f, r);
+        const float2_t dir = trig_by_addition(pcs, rt.z, rt.w);
+        float sn, cs;
+        bl_sincosf_cells(wrap_to_pi_cells(p - r, true), &sn, &cs);
+        const float es = __builtin_fabsf(dir.y - sn), ec = __builtin_fabsf(dir.x - cs);
+        ms = max(ms, __float_as_uint(es)); mc = max(mc, __float_as_uint(ec));
+    }
+    for (int off = 32; off > 0; off >>= 1) { ms = max(ms, (unsigned int)__shfl_xor((int)ms, off, 64)); mc = max(mc, (unsigned int)__shfl_xor((int)mc, off, 64)); }
+    if ((threadIdx.x & 63) == 0) { atomicMax(out_max, ms); atomicMax(out_max + 1, mc); }
+}
+
+extern "C" int bl_debug_trig_addition_probe(bl_ctx* ctx, uint64_t pairs, uint32_t seed, float* max_sin_err, float* max_cos_err, float* eps_used,
+                                            uint64_t* pairs_checked)
+{
+    BL_CHECK_ARG(ctx != nullptr && max_sin_err != nullptr && max_cos_err != nullptr && pairs >= 1);
+    BL_HIP(hipSetDevice(ctx->device));
+    unsigned int* d_max = nullptr;
+    BL_HIP(hipMalloc((void**)&d_max, 8));
+    BL_HIP(hipMemsetAsync(d_max, 0, 8, ctx->stream));
+    const unsigned long long threads = 8192ull * 256ull;
+    const unsigned long long per = (pairs + threads - 1) / threads;
+    hipLaunchKernelGGL(k_trig_addition_probe, dim3(8192), dim3(256), 0, ctx->stream, per, seed, d_max);
+    BL_HIP(hipGetLastError());
+    float h[2];
+    BL_HIP(hipMemcpyAsync(h, d_max, 8, hipMemcpyDeviceToHost, ctx->stream));
+    BL_HIP(hipStreamSynchronize(ctx->stream));
+    BL_HIP(hipFree(d_max));
+    *max_sin_err = h[0]; *max_cos_err = h[1];
+    if (eps_used) *eps_used = MCL_TRIG_EPS;
+    if (pairs_checked) *pairs_checked = per * threads;
     return BL_OK;
 }
 

@@ -179,6 +179,11 @@ int bl_pf_debug_enable(bl_pf* pf, int on);
  * reference's sinf / cosf(wrap_to_pi(angle)), exhaustively over every float of the angle's range; *eps_used is the bound
  * the kernel's guard band is built on (both maxima must stay below it). */
 int bl_debug_trig_probe(bl_ctx* ctx, float* max_sin_err, float* max_cos_err, float* eps_used, uint64_t* floats_checked);
+/* The same for the form the ray loop takes by default -- the direction of pose.theta - ray theta by the addition theorems from the
+ * particle's and the ray's (cos, sin) pairs: maxima of |that - the reference's sinf / cosf of wrap_to_pi(fl(p - r))| over `pairs`
+ * random (p, r), p in [-pi, pi], r in [0, 6.2831], with the functions the loop calls (Monte Carlo: the pairs are 2^48). */
+int bl_debug_trig_addition_probe(bl_ctx* ctx, uint64_t pairs, uint32_t seed, float* max_sin_err, float* max_cos_err, float* eps_used,
+                                 uint64_t* pairs_checked);
 int bl_pf_debug_last(bl_pf* pf, int32_t* resample_idx, int32_t* likelihood_half_units);
 
 /* ------------------------------------------------------------------ ObstacleDistanceGrid  (src/planning/obstacle_distance_grid.hpp:28-96) */

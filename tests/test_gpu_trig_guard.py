@@ -36,10 +36,37 @@ def test_hardware_trig_stays_inside_the_guard_band(gpu_ctx):
     assert ms.value * 1.05 <= eps.value and mc.value * 1.05 <= eps.value, report
 
 
-def test_fast_trig_on_and_off_give_identical_likelihoods(oracle, maps, gpu_ctx, monkeypatch):
-    """100 000 particles x 3 updates on the shipped obstacle_slam map, Philox noise: the default (fast path with guard band)
-    and BOTLAB_MCL_NO_FAST_TRIG (exact sinf / cosf for every ray) must agree in every likelihood, every resampling index, every
-    particle and the estimate -- 5.8e7 particle-rays per run."""
+def test_trig_by_addition_stays_inside_the_guard_band(gpu_ctx):
+    """The default form of the fast path: the ray's direction from the particle's and the ray's (cos, sin) pairs by the addition
+    theorems (bl_mcl.hip, ray_cells_fast).  Its distance from the reference's sinf / cosf is bounded analytically by 8.2e-7; this
+    measures it over 4e9 random pairs with the functions the ray loop calls (the committed figure, profiles/r04_trig_addition_probe.json,
+    is from 1e10) and asserts the same constant the band is built from, with at least 25 % to spare."""
+    ms, mc, eps, n = C.c_float(), C.c_float(), C.c_float(), C.c_uint64()
+    check(gpu_ctx.lib.bl_debug_trig_addition_probe(gpu_ctx.h, 4_000_000_000, 20261004, C.byref(ms), C.byref(mc), C.byref(eps), C.byref(n)))
+    report = dict(pairs_checked=int(n.value), max_sin_err=float(ms.value), max_cos_err=float(mc.value), eps_used=float(eps.value),
+                  analytic_bound=8.2e-7, margin=float(eps.value) / max(float(ms.value), float(mc.value)) - 1.0)
+    os.makedirs("gpurun_out", exist_ok=True)
+    with open(os.path.join("gpurun_out", "trig_addition_probe.json"), "w") as fh:
+        json.dump(report, fh)
+    assert n.value >= 4_000_000_000
+    assert 0.0 < ms.value and 0.0 < mc.value
+    assert ms.value <= 8.2e-7 and mc.value <= 8.2e-7, report          # the derived bound holds for every pair seen
+    assert ms.value * 1.25 <= eps.value and mc.value * 1.25 <= eps.value, report
+
+
+@pytest.mark.parametrize("form", ["addition", "hardware"])
+def test_fast_trig_on_and_off_give_identical_likelihoods(oracle, maps, gpu_ctx, monkeypatch, form):
+    """100 000 particles x 3 updates on the shipped obstacle_slam map, Philox noise: the fast path with guard band -- the default
+    form (direction by the addition theorems) and the hardware sine / cosine form (BOTLAB_MCL_HW_TRIG: read once per process, so
+    this case runs in a child) -- and BOTLAB_MCL_NO_FAST_TRIG (exact sinf / cosf for every ray) must agree in every likelihood,
+    every resampling index, every particle and the estimate -- 5.8e7 particle-rays per run."""
+    if form == "hardware":
+        import subprocess, sys
+        env = dict(os.environ, BOTLAB_MCL_HW_TRIG="1")
+        r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", os.path.abspath(__file__), "-k", "identical_likelihoods and addition"],
+                           env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+        assert r.returncode == 0, r.stdout.decode()[-2000:]
+        return
     N = 100_000
     m = maps["obstacle_slam_10mx10m_5cm"]
     truth = np.where(m["cells"] > 0, 127, -127).astype(np.int8)
