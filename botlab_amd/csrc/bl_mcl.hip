@@ -1889,7 +1889,15 @@ extern "C" int bl_pf_shard_setup(bl_pf* pf, int rank, int world, int block)
     pf->scan_blocks = tiles;
     pf->sh_tiles_all = tiles;
     pf->sh_peer = false; pf->sh_gen = 0;
-    if (!pf->sh_flags) BL_HIP(hipMalloc((void**)&pf->sh_flags, 2 * BL_MAX_SHARDS * sizeof(unsigned long long)));
+    if (!pf->sh_flags) {
+        // The counters are POLLED while other devices store into them: fine-grained device memory, which this device's L2 does not
+        // keep (a coarse-grained line, once fetched by a poll, would be served from the L2 for ever: a remote store does not pass
+        // through it).  The data buffers are read by launches that START after the wait (a launch begins with an acquire).
+        if (hipExtMallocWithFlags((void**)&pf->sh_flags, 4096, hipDeviceMallocFinegrained) != hipSuccess) {
+            (void)hipGetLastError();
+            BL_HIP(hipMalloc((void**)&pf->sh_flags, 4096));
+        }
+    }
     BL_HIP(hipMemsetAsync(pf->sh_flags, 0, 2 * BL_MAX_SHARDS * sizeof(unsigned long long), pf->ctx->stream));
     memset(pf->sh_peer_sums, 0, sizeof(pf->sh_peer_sums)); memset(pf->sh_peer_xchg, 0, sizeof(pf->sh_peer_xchg));
     memset(pf->sh_peer_flags, 0, sizeof(pf->sh_peer_flags));
