@@ -14,7 +14,7 @@ import sqlite3
 import subprocess
 import sys
 
-ROUND = "r03"
+ROUND = "r04"
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 OUT = os.path.join(ROOT, "gpurun_out", "profiles_new")
 os.makedirs(OUT, exist_ok=True)
@@ -158,7 +158,7 @@ def collect_streaming():
             w.writerow([k, n, "%.0f" % avg, mn, a, "%.1f" % (a / avg), "%.3f" % (a / avg / 8000.0), "%.0f" % hb if hb else "", "%.3f" % (hb / a) if hb else ""])
 
 
-which = sys.argv[1:] or ["default", "config4", "config5", "stream"]
+which = sys.argv[1:] or ["default", "config4", "config5", "config5explore", "frontiers", "stream"]
 if "stream" in which:
     collect_streaming()
 if "default" in which:
@@ -166,7 +166,20 @@ if "default" in which:
 if "config4" in which:
     collect("config4", ["--config", "4", "--goal-l1", "400", "--cpu-steps", "0", "--sub", "--steps", "600", "--warmup", "150"])
 if "config5" in which:
-    collect("config5", ["--config", "5", "--goal-l1", "40", "--cpu-steps", "0", "--sub", "--steps", "600", "--warmup", "150"])
+    collect("config5_fixed_goal", ["--config", "5", "--fixed-goal", "--goal-l1", "40", "--cpu-steps", "0", "--sub", "--steps", "600", "--warmup", "150"])
+if "config5explore" in which:
+    collect("config5_explore", ["--config", "5", "--cpu-steps", "0", "--sub", "--steps", "600", "--warmup", "150"])
+if "frontiers" in which:
+    # find_map_frontiers on the explored-disc worlds (2000^2, 4096^2): kernel durations of the flood and the sweep
+    db, _ = run(["--kernel-trace", "--stats"], "frontier_stats", [], os.path.join("tests", "tools", "frontier_flood_probe.py"))
+    if db:
+        rows = list(sqlite3.connect(db).execute("select name, count(*), sum(end-start), avg(end-start), min(end-start), max(end-start) from kernels group by name order by 3 desc"))
+        with open(os.path.join(OUT, f"{ROUND}_frontier_kernels.csv"), "w") as f:
+            f.write("# rocprofv3 --kernel-trace --stats -- python3 tests/tools/frontier_flood_probe.py   (3 x find_map_frontiers at 2000^2 and at 4096^2, explored disc)\n")
+            w = csv.writer(f)
+            w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "MinNs", "MaxNs"])
+            for r in rows:
+                w.writerow([r[0][:90], r[1], r[2], "%.1f" % r[3], r[4], r[5]])
 for fn in sorted(os.listdir(OUT)):
     if fn.endswith(".csv") and ROUND in fn:
         print("====", fn)
