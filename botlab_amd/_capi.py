@@ -132,6 +132,7 @@ SIGNATURES = {
     "bl_comm_create": (C.c_int, [_vp, C.c_char_p, C.c_char_p, C.c_int, C.c_int, _P(_vp)]),
     "bl_comm_destroy": (None, [_vp]),
     "bl_comm_all_gather_inplace": (C.c_int, [_vp, _vp, C.c_size_t]),
+    "bl_dev_enable_peer_access": (C.c_int, [C.c_int, C.c_int]),
     "bl_dev_alloc": (C.c_int, [_vp, C.c_size_t, _P(_vp)]),
     "bl_dev_word": (C.c_int, [_vp, _vp, C.c_int, _P(C.c_uint32)]),
     "bl_dev_free": (C.c_int, [_vp]),

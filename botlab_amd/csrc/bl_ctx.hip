@@ -17,6 +17,21 @@ void bl_set_error(const char* fmt, ...)
 }
 
 extern "C" const char* bl_last_error(void) { return g_err; }
+
+// Kernels of `device` may read and write memory of `peer_device` through pointers of the same process (a host that drives
+// several devices from one process: include/botlab/sharded_filter.hpp).  BL_OK when it is (or already was) enabled.
+extern "C" int bl_dev_enable_peer_access(int device, int peer_device)
+{
+    if (device == peer_device) return BL_OK;
+    int can = 0;
+    BL_HIP(hipDeviceCanAccessPeer(&can, device, peer_device));
+    if (!can) { bl_set_error("device %d cannot access device %d", device, peer_device); return BL_ERR_STATE; }
+    BL_HIP(hipSetDevice(device));
+    const hipError_t e = hipDeviceEnablePeerAccess(peer_device, 0);
+    if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) { bl_set_error("hipDeviceEnablePeerAccess(%d -> %d): %s", device, peer_device, hipGetErrorString(e)); return BL_ERR_HIP; }
+    (void)hipGetLastError();
+    return BL_OK;
+}
 extern "C" const char* bl_version(void) { return "botlab_hip 0.1 (gfx950)"; }
 
 void bl_astar_free(bl_ctx* ctx);   // bl_planning.hip

@@ -65,3 +65,13 @@ static void check_exploring_map(const botlab_hip::OccupancyGrid& map, const pose
     int8_t next = ex.execute(map, pose);
     (void)next; (void)ex.status; (void)ex.currentPath_; (void)ex.currentTarget_;
 }
+
+// sharded_filter.hpp
+#include <botlab/sharded_filter.hpp>
+static void check_sharded_filter(const int8_t* cells, const bl_pose_xyt_t& pose, const bl_lidar_t& scan)
+{
+    botlab_hip::ShardedFilterGroup g(100000, std::vector<int>(4, 0), 200, 200, 0.05f, 20.0f, -5.0f, -5.0f, cells);
+    g.initializeFilterAtPose(pose, 1);
+    g.step(pose, scan, 7);
+    (void)g.poseEstimate(); (void)g.particles(); (void)g.mapCells(0, 200, 200); (void)g.world(); (void)g.rank(0);
+}

@@ -287,6 +287,7 @@ int bl_comm_all_gather_inplace(bl_comm* c, void* rec, size_t per_rank_floats);
  * bl_pf_shard_stage(1), all-gather of the sums buffer, bl_pf_shard_stage(2), all-gather of the exchange buffer, both in place),
  * then bl_pf_update_end or one of the *_finishing_pf calls.  The all-gathers are what orders a rank's kernels against the other
  * ranks' reads of its memory: every rank must run them, on the filter's stream. */
+int bl_dev_enable_peer_access(int device, int peer_device);   /* one process driving several devices (include/botlab/sharded_filter.hpp): kernels of `device` may use `peer_device`'s pointers */
 int bl_dev_alloc(bl_ctx* ctx, size_t bytes, void** out);     /* plain zeroed device memory (the probe of botlab_amd/sharded.py) */
 int bl_dev_free(void* dev_ptr);
 int bl_dev_word(bl_ctx* ctx, void* dev_ptr, int write, uint32_t* value);   /* one word written / read by a kernel of ctx's device (the probe: a peer mapping must be readable by kernels) */
