@@ -75,3 +75,13 @@ static void check_sharded_filter(const int8_t* cells, const bl_pose_xyt_t& pose,
     g.step(pose, scan, 7);
     (void)g.poseEstimate(); (void)g.particles(); (void)g.mapCells(0, 200, 200); (void)g.world(); (void)g.rank(0);
 }
+
+template <class F>
+static void check_async_exploring_map(const botlab_hip::OccupancyGrid& map, const F& filter)
+{
+    botlab_hip::AsyncExploringMapT<pose_xyt_t, robot_path_t> ex(2, 0.2);
+    if (ex.submit(map, filter)) { bl_explore_result_t info; (void)ex.fetch(&info); }
+    (void)ex.pending(); (void)ex.status; (void)ex.currentPath_; (void)ex.currentTarget_; (void)ex.device();
+}
+
+void touch_async_exploring_map(const botlab_hip::OccupancyGrid& map, const ParticleFilter& filter) { check_async_exploring_map(map, filter); }

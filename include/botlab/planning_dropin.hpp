@@ -222,6 +222,60 @@ public:
     int8_t status;
 };
 
+// The same step for a host that runs SLAM and exploration in one process: bl_explorer (botlab_hip.h) snapshots the map and the
+// filter's device-resident pose behind a map update and runs setMap + find_map_frontiers on a side stream; fetch() -- from this
+// thread or from an exploration thread of its own -- applies the 0.5 m rule and plans when due (exploration.cpp:299-368).
+template <class Pose, class Path>
+class AsyncExploringMapT {
+public:
+    explicit AsyncExploringMapT(int lanes = 2, double robotRadius = 0.2) : status(2), h_(nullptr), lanes_(lanes)
+    {
+        if (bl_explorer_create(default_ctx(), lanes, robotRadius, &h_) != BL_OK) { std::fprintf(stderr, "bl_explorer_create: %s\n", bl_last_error()); std::abort(); }
+        currentTarget_.utime = 0; currentTarget_.x = 0; currentTarget_.y = 0; currentTarget_.theta = 0;
+        currentPath_.utime = 0; currentPath_.path_length = 0;
+    }
+    ~AsyncExploringMapT() { if (h_) bl_explorer_destroy(h_); }
+    AsyncExploringMapT(const AsyncExploringMapT&) = delete;
+    AsyncExploringMapT& operator=(const AsyncExploringMapT&) = delete;
+
+    // behind Mapping::updateMap of the step whose pose `filter` holds on the device; false: every lane holds a step (fetch first)
+    template <class Filter>
+    bool submit(const OccupancyGrid& currentMap, const Filter& filter)
+    {
+        if (bl_explorer_pending(h_) >= lanes()) return false;
+        if (bl_explorer_submit(h_, currentMap.device(), bl_pf_pose_device_ptr(filter.device())) != BL_OK) { std::fprintf(stderr, "bl_explorer_submit: %s\n", bl_last_error()); std::abort(); }
+        return true;
+    }
+    int pending() const { return bl_explorer_pending(h_); }
+    // the oldest submitted step: the next state (exploration_status_t); status / currentTarget_ / currentPath_ as ExploringMapT keeps them
+    int8_t fetch(bl_explore_result_t* info = nullptr)
+    {
+        std::vector<bl_pose_xyt_t> buf(65536);
+        bl_explore_result_t r;
+        if (bl_explorer_fetch(h_, &r, buf.data(), (int)buf.size()) != BL_OK) { std::fprintf(stderr, "bl_explorer_fetch: %s\n", bl_last_error()); std::abort(); }
+        status = (int8_t)r.status;
+        currentTarget_.utime = r.target.utime; currentTarget_.x = r.target.x; currentTarget_.y = r.target.y; currentTarget_.theta = r.target.theta;
+        currentPath_.path.resize((size_t)r.path_length);
+        for (int i = 0; i < r.path_length; ++i) {
+            currentPath_.path[(size_t)i].utime = buf[(size_t)i].utime; currentPath_.path[(size_t)i].x = buf[(size_t)i].x;
+            currentPath_.path[(size_t)i].y = buf[(size_t)i].y; currentPath_.path[(size_t)i].theta = buf[(size_t)i].theta;
+        }
+        currentPath_.path_length = r.path_length;
+        if (info) *info = r;
+        return (int8_t)r.next_state;
+    }
+    bl_explorer* device() const { return h_; }
+
+    Pose currentTarget_;
+    Path currentPath_;
+    int8_t status;
+
+private:
+    int lanes() const { return lanes_; }
+    bl_explorer* h_;
+    int lanes_;
+};
+
 }  // namespace botlab_hip
 
 #endif  // BOTLAB_PLANNING_DROPIN_HPP
