@@ -97,5 +97,36 @@ def test_exploring_map_large_grid_matches_oracle(oracle, maps, gpu_ctx, size):
         assert res.frontiers_ms > 0.0 and res.bfs_cells > 1000
     assert sum(g[0].planned for g in got) >= 2 and sum(g[0].pops for g in got) > 100_000
     axp.close()
+
+    # ---- once more with submit and fetch on DIFFERENT threads (the reference's exploration process beside its SLAM process): the
+    # submitting thread waits for a free lane, the fetching thread takes the steps back; same maps in the same order, same results
+    import threading
+    import time
+    axp = bl.AsyncExplorer(ctx=gpu_ctx, lanes=2, robotRadius=0.2)
+    got2, errors = [], []
+
+    def fetcher():
+        try:
+            for _ in range(len(grids)):
+                while axp.pending() == 0:
+                    time.sleep(0.0005)
+                res, path = axp.fetch()
+                got2.append((res.next_state, res.status, res.num_frontiers, [(p.utime, p.x, p.y, p.theta) for p in path],
+                             (np.float32(res.target.x), np.float32(res.target.y))))
+        except Exception as e:                          # noqa: BLE001 -- reported by the main thread
+            errors.append(e)
+
+    th = threading.Thread(target=fetcher)
+    th.start()
+    for k in range(len(grids)):
+        while axp.pending() >= 2:
+            time.sleep(0.0005)
+        axp.submit(grids[k], poses[k].data_ptr())
+    th.join(timeout=300)
+    assert not th.is_alive() and not errors, errors
+    for k, g2 in enumerate(got2):
+        enxt, est, efr, epath, etarget = expected[k]
+        assert g2 == (enxt, est, len(efr), epath, etarget), k
+    axp.close()
     for g in grids:
         g.close()
