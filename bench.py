@@ -366,7 +366,7 @@ def streaming_kernels(ctx, grid, planner, aplanner, pose_dev, goal_pose, W, H):
     after the timed region): bytes the kernel must read + write / its average duration, against the 8 TB/s peak."""
     import torch
     from botlab_amd import _capi
-    ids = [_capi.BL_K_DIST_ROWS, _capi.BL_K_DIST_COLS_SUMMARY, _capi.BL_K_DIST_COLS_APPLY, _capi.BL_K_SNAPSHOT]
+    ids = [_capi.BL_K_DIST_ROWS, _capi.BL_K_DIST_COLS_SUMMARY, _capi.BL_K_DIST_COLS_APPLY, _capi.BL_K_SNAPSHOT, _capi.BL_K_DIST_FUSED]
     ctx.timing_reset()
     ctx.timing_stride(1)
     ctx.timing_enable(True, kernels=ids)
@@ -386,7 +386,10 @@ def streaming_kernels(ctx, grid, planner, aplanner, pose_dev, goal_pose, W, H):
     spec = [("k_dist_rows_wide" if wide else "k_dist_rows", _capi.BL_K_DIST_ROWS, 3.0 * cells),             # int8 in, uint16 out
             ("k_dist_cols_summary+carry", _capi.BL_K_DIST_COLS_SUMMARY, 2.0 * cells),                     # uint16 in (+ 1 MB of strip summaries)
             ("k_dist_cols_apply" if tall else "k_dist_cols", _capi.BL_K_DIST_COLS_APPLY, 4.0 * cells),   # uint16 in; uint16 out
-            ("k_planner_snapshot", _capi.BL_K_SNAPSHOT, 2.0 * cells)]                                     # int8 in, int8 out
+            ("k_planner_snapshot", _capi.BL_K_SNAPSHOT, 2.0 * cells),                                     # int8 in, int8 out
+            # the whole transform as one launch (grids of 512 x 512 .. 4096 x 4096 cells, W % 16 == 0): int8 in, uint16 out; the
+            # row grid never exists.  The three entries above then have no launches.
+            ("k_dist_fused", _capi.BL_K_DIST_FUSED, 3.0 * cells)]
     out = {}
     for name, kid, nbytes in spec:
         ms, n = ctx.timing_get(kid)
@@ -394,6 +397,8 @@ def streaming_kernels(ctx, grid, planner, aplanner, pose_dev, goal_pose, W, H):
             gbs = nbytes / (ms / n * 1e-3) / 1e9
             out[name] = {"bytes_per_launch": nbytes, "avg_launch_ms": round(ms / n, 5), "launches": int(n), "achieved_GBps": round(gbs, 1),
                          "frac_of_hbm_peak": round(gbs / HBM_PEAK_GBS, 4)}
+            if name == "k_dist_fused":                     # the same duration priced at the 9 B/cell the four-launch form moves
+                out[name]["at_four_launch_bytes_GBps"] = round(9.0 * cells / (ms / n * 1e-3) / 1e9, 1)
     return out
 
 

@@ -49,7 +49,7 @@ class ExploreResult(C.Structure):
 
 
 BL_K_MCL_MAIN, BL_K_MCL_SCAN, BL_K_MAP, BL_K_DIST, BL_K_ASTAR, BL_K_FRONTIERS = range(6)
-BL_K_DIST_ROWS, BL_K_DIST_COLS_SUMMARY, BL_K_DIST_COLS_APPLY, BL_K_SNAPSHOT = range(6, 10)
+BL_K_DIST_ROWS, BL_K_DIST_COLS_SUMMARY, BL_K_DIST_COLS_APPLY, BL_K_SNAPSHOT, BL_K_DIST_FUSED = range(6, 11)
 BL_OK, BL_ERR_HIP, BL_ERR_ARG, BL_ERR_CAPACITY, BL_ERR_STATE = range(5)
 
 _vp = C.c_void_p

@@ -49,6 +49,8 @@ struct bl_dist {
     unsigned int* h_status;   // pinned: the plan the last incremental launch settled on (DST_MODE_*), written by the device
     unsigned int* h_status_dev;
     int inc_holdoff;          // incremental launches to skip (the device kept falling back to the whole grid)
+    // k_dist_fused: the tiles' summary and claim words, the grid they were laid out for, the last launch's tag
+    unsigned int* fwords; size_t fwords_cap; int f_w, f_h; unsigned int f_tag;
     int64_t n_inc, n_full, n_same;   // transforms by kind (diagnostic)
 };
 
@@ -85,10 +87,12 @@ struct dist_batch {
 #define DST_Y1 5
 #define DST_MAX_GROUPS 64    // grids up to 8192 columns / rows in the region kernels (macro strips whose summaries fit LDS)
 #define DST_STATS 8          // [3] incremental launches that ended as: nothing to do, a window, the whole grid (diagnostic)
-#define DST_WORDS (DST_STATS + 3)
+#define DST_FAILED (DST_STATS + 3)   // k_dist_fused: workgroups that gave up (a summary that never came)
+#define DST_WORDS (DST_STATS + 4)
 #define DST_MODE_NONE 0      // nothing changed
 #define DST_MODE_WINDOW 1
 #define DST_MODE_FULL 2
+#define DST_MODE_BROKEN 0xDEADu   // (h_status only) a whole-grid launch of k_dist_fused gave up: the grid's distances are not valid
 #define DINC_MAX 1024        // widest / tallest window
 
 // ---- plans ------------------------------------------------------------------------------------------------------------
@@ -652,6 +656,540 @@ __global__ __launch_bounds__(DC2_TX * DC2_TY) void k_dist_cols_apply(dist_batch 
     }
 }
 
+// ---- whole-grid transform in ONE launch --------------------------------------------------------------------------------
+// The L1 distance of a cell p to the sources of another 128 x 128 tile T depends on T only through a short summary, each part of
+// it a piece of T's own distance transform D_T (the transform of T's cells alone):
+//   T in p's row band      D_T along T's last and first column: a path from p enters T through one of them         (128 words per tile)
+//   T in p's column band   D_T along T's last and first row                                                         (128 words)
+//   T diagonal to p        |dx| + |dy| has fixed signs, so one number per quadrant: max (sx + sy), max (sx - sy), max (-sx + sy),
+//                          max (-sx - sy) over T's sources                                                          (4 words)
+// So a workgroup computes D_T of its tile (cells in; row pass, transposition through LDS, column pass: the distances stay in
+// registers), publishes T's summary on the way, takes in the summaries of the other tiles -- the nearest outside source as seen
+// from each cell of the ring around the tile: left and right per row, above and below per column, the diagonal tiles folded
+// into the latter -- and finishes with four ramps per cell: d = min (D_T, left + c + 1, right + 128 - c, above + r + 1, below +
+// 128 - r).  ONE hand-over, the intermediate `row` grid never exists: 1 B read and 2 B written per cell where the four-launch
+// form moves 9.
+// One launch: workgroup b owns tiles b, b + G, ... (at most DF_MAXK, their D_T all held in registers: grids up to 4096 x 4096;
+// 2000 x 2000: one tile per CU).  Every published word is tag << 26 | payload with a tag per launch, so no fence orders data
+// against a flag, and what a workgroup may wait for is spelled out at the wait: tiles are CLAIMED by a marker word, and a
+// workgroup computes the summary of every tile it finds unclaimed itself before its first wait.
+// All distances are pairs of uint16 in one register (two rows in the row pass, two columns in the column pass), 0xFFFF = no
+// source, sums saturating: v_pk_add_u16 clamp / v_pk_min_u16, two cells per instruction.
+#define DF_T 128                               // tile side
+#define DF_NT 512                              // threads: row layout 64 row pairs x 8 threads x 16 columns; column layout 8 x 16 rows x 64 column pairs
+#define DF_WORDS 256                           // band words per tile: [0, 128) rows, [128, 256) columns; then 4 quadrant words per tile, then a claim word per tile
+#define DF_GP DF_T                             // LDS pitch of the tile of row distances (uint16): no padding, 16-byte chunks swizzled (df_at)
+#define DF_TAG_SHIFT 26
+#define DF_NOPOT 511u                          // 9-bit potentials (finite ones are at most 254)
+#define DF_CORNER_BIAS 20000
+#define DF_SPIN_CAP (1 << 18)
+#define DF_MAX_SIDE 8176                       // quadrant numbers within 16 bits around the bias
+#define DF_GSLOTS 4                            // 16-byte loads per thread and band in the gather: bands of up to 64 tiles
+#define DF_SCAN 2                              // claim words per thread: DF_MAXK * DF_MAX_WGS tiles
+#define DF_MAX_WGS 256
+#define DF_MAXK 4
+struct dist_fused_batch { unsigned int* words[DIST_MAX_BATCH]; unsigned int tag[DIST_MAX_BATCH]; };
+
+typedef unsigned short df_u2 __attribute__((ext_vector_type(2)));
+typedef short df_s2 __attribute__((ext_vector_type(2)));
+#define DF_INF2 0xFFFFFFFFu
+__device__ __forceinline__ unsigned int df_min(unsigned int a, unsigned int b)
+{
+    return __builtin_bit_cast(unsigned int, __builtin_elementwise_min(__builtin_bit_cast(df_u2, a), __builtin_bit_cast(df_u2, b)));
+}
+__device__ __forceinline__ unsigned int df_adds(unsigned int a, unsigned int b)          // saturating: 0xFFFF stays 0xFFFF
+{
+    return __builtin_bit_cast(unsigned int, __builtin_elementwise_add_sat(__builtin_bit_cast(df_u2, a), __builtin_bit_cast(df_u2, b)));
+}
+__device__ __forceinline__ unsigned int df_both(int v) { return (unsigned int)v | ((unsigned int)v << 16); }
+__device__ __forceinline__ unsigned int df_pair(int lo, int hi) { return (unsigned int)min(lo, 0xFFFF) | ((unsigned int)min(hi, 0xFFFF) << 16); }
+
+typedef unsigned int df_u4 __attribute__((ext_vector_type(4)));
+// 16 bytes through the L2, not waited for (the caller's s_waitcnt names the registers)
+__device__ __forceinline__ void df_load16(df_u4& w, const unsigned int* p) { asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(w) : "v"(p) : "memory"); }
+
+// A workgroup barrier that waits for the wave's LDS traffic only: __syncthreads() also waits for every global access the wave has
+// in flight -- the tile's cells on their way in, the published words on their way out -- although nothing behind these barriers
+// depends on them (the loads are waited for where their registers are used; the words are read by other workgroups, and each
+// carries its own tag).
+__device__ __forceinline__ void df_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// max over the wave of non-negative values, in lane 63 (DPP: shifts inside the 16-lane rows fill with zero, then the rows' last
+// lanes are handed on) -- six VALU pairs and no LDS round trip, where a shuffle tree makes six dependent ones
+__device__ __forceinline__ int df_wave_max(int v)
+{
+    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, true));
+    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, true));
+    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, true));
+    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, true));
+    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, true));      // row_bcast:15 into rows 1 and 3
+    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, true));      // row_bcast:31 into rows 2 and 3
+    return v;
+}
+
+template <int OFF>
+__device__ __forceinline__ void df_scan_step(unsigned int& inc_f, unsigned int& inc_b, int rq)
+{
+    const unsigned int t = (unsigned int)__builtin_amdgcn_update_dpp((int)DF_INF2, (int)inc_f, 0x110 + OFF, 0xf, 0xf, false);     // row_shr
+    const unsigned int u = (unsigned int)__builtin_amdgcn_update_dpp((int)DF_INF2, (int)inc_b, 0x100 + OFF, 0xf, 0xf, false);     // row_shl
+    if (rq >= OFF) inc_f = df_min(inc_f, df_adds(t, df_both(16 * OFF)));
+    if (rq + OFF < 8) inc_b = df_min(inc_b, df_adds(u, df_both(16 * OFF)));
+}
+
+// The row pass of a tile in the row layout: the thread holds the same 16 columns of two rows (a: 16 bytes of the even row, b: of
+// the odd row), its 8-lane group the two whole tile rows.  v[i]: the distances of column i of both rows to the nearest source of
+// their own row inside the tile; row_f / row_b (valid in every lane of the group): those at the tile's last / first column.
+__device__ __forceinline__ void df_row_pass(const int4 a, const int4 b, int rq, unsigned int v[16], unsigned int& row_f, unsigned int& row_b)
+{
+    const unsigned int aw[4] = {(unsigned int)a.x, (unsigned int)a.y, (unsigned int)a.z, (unsigned int)a.w};
+    const unsigned int bw[4] = {(unsigned int)b.x, (unsigned int)b.y, (unsigned int)b.z, (unsigned int)b.w};
+    const unsigned int one = df_both(1);
+    unsigned int s[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        // byte i of both rows into the high bytes of the two halves; its sign spread over the half: 0xFFFF free, 0 a source
+        // (is_cell_occupied: logOdds >= 0, obstacle_distance_grid.cpp:125-128)
+        const unsigned int p = __builtin_amdgcn_perm(bw[i >> 2], aw[i >> 2], 0x000c000cu | ((unsigned int)(i & 3) << 8) | ((unsigned int)(4 + (i & 3)) << 24));
+        s[i] = __builtin_bit_cast(unsigned int, __builtin_bit_cast(df_s2, p) >> 15);
+    }
+    unsigned int d = DF_INF2;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { d = df_min(df_adds(d, one), s[i]); v[i] = d; }
+    unsigned int inc_f = d;                                  // distance at the thread's last column to its own nearest source
+    d = DF_INF2;
+#pragma unroll
+    for (int i = 15; i >= 0; --i) { d = df_min(df_adds(d, one), s[i]); v[i] = df_min(v[i], d); }
+    unsigned int inc_b = d;
+    // min-plus scans over the 8 threads of the row pair (row_shr / row_shl stay inside the 16-lane row; lanes whose source would
+    // lie in the other group keep their value)
+    df_scan_step<1>(inc_f, inc_b, rq); df_scan_step<2>(inc_f, inc_b, rq); df_scan_step<4>(inc_f, inc_b, rq);
+    unsigned int cf = (unsigned int)__builtin_amdgcn_update_dpp((int)DF_INF2, (int)inc_f, 0x111, 0xf, 0xf, false);
+    unsigned int cb = (unsigned int)__builtin_amdgcn_update_dpp((int)DF_INF2, (int)inc_b, 0x101, 0xf, 0xf, false);
+    if (rq == 0) cf = DF_INF2;                               // distance at the column just left of the thread's first
+    if (rq == 7) cb = DF_INF2;
+    // lane 7 of the group holds the whole row's forward value, lane 0 the backward one: to every lane
+    row_f = (unsigned int)__shfl((int)inc_f, (threadIdx.x & 56) | 7, 64);
+    row_b = (unsigned int)__shfl((int)inc_b, threadIdx.x & 56, 64);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { cf = df_adds(cf, one); v[i] = df_min(v[i], cf); }
+#pragma unroll
+    for (int i = 15; i >= 0; --i) { cb = df_adds(cb, one); v[i] = df_min(v[i], cb); }
+}
+
+// The LDS tile of row distances: uint16, row-major, 256 bytes a row, the sixteen 16-byte chunks of rows 2, 3, 6, 7, ... swapped
+// in pairs (chunk ^ 1).  The row layout writes a chunk per lane (ds_write_b128): lanes of one row pair cover every other chunk,
+// and with the swap the lanes of the NEXT row pair cover the chunks between -- 16 lanes, 64 banks, no conflict (unswizzled, padded
+// or not, rows two apart start on the same bank however the pitch is chosen as long as chunks stay 16-byte aligned: the writes of
+// the eight waves took 1.7 us of an in-tile pass of 4.4).  The column layout reads a dword per lane along a row: any order of
+// the chunks is conflict-free.
+__device__ __forceinline__ int df_at(int row, int col) { return row * DF_GP + ((((col >> 3) ^ ((row >> 1) & 1)) << 3) | (col & 7)); }
+
+// the row distances of the thread's two rows into the LDS tile
+__device__ __forceinline__ void df_rows_to_lds(uint16_t* s_g, int rp, int rq, const unsigned int v[16])
+{
+    unsigned int lo[8], hi[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        lo[j] = __builtin_amdgcn_perm(v[2 * j + 1], v[2 * j], 0x05040100u);       // even row: columns 2j, 2j + 1
+        hi[j] = __builtin_amdgcn_perm(v[2 * j + 1], v[2 * j], 0x07060302u);       // odd row
+    }
+    *(uint4*)&s_g[df_at(2 * rp, 16 * rq)] = make_uint4(lo[0], lo[1], lo[2], lo[3]); *(uint4*)&s_g[df_at(2 * rp, 16 * rq + 8)] = make_uint4(lo[4], lo[5], lo[6], lo[7]);
+    *(uint4*)&s_g[df_at(2 * rp + 1, 16 * rq)] = make_uint4(hi[0], hi[1], hi[2], hi[3]); *(uint4*)&s_g[df_at(2 * rp + 1, 16 * rq + 8)] = make_uint4(hi[4], hi[5], hi[6], hi[7]);
+}
+
+// K: tiles per workgroup (tiles b + k G, k < K, those below T)
+template <int K>
+__global__ __launch_bounds__(DF_NT) void k_dist_fused(dist_batch db, dist_fused_batch fb, int W, int H)
+{
+    const int z = blockIdx.z;
+    const int t = threadIdx.x;
+    const int nJ = (W + DF_T - 1) / DF_T, nI = (H + DF_T - 1) / DF_T, T = nI * nJ, G = (int)gridDim.x;
+    // Workgroup b's k-th tile.  Workgroups are placed on the 8 XCDs round-robin, and a tile's 128-byte rows straddle two cache
+    // lines unless W is a multiple of 128: an XCD takes a run of consecutive tiles (whole row bands where T / 8 is a multiple of
+    // the bands' length), so that the lines two neighbours share come through one L2 once -- not through two L2s from memory
+    // twice (the tiles' loads, all issued in the launch's first half microsecond, are a burst the fabric has to carry).
+    const int per_xcd = (T + 7) >> 3;
+    auto tile_of = [&](int k) -> int {
+        const int q = ((int)blockIdx.x >> 3) + k * (G >> 3);
+        const int tile = ((int)blockIdx.x & 7) * per_xcd + q;
+        return q < per_xcd && tile < T ? tile : -1;
+    };
+    __shared__ __attribute__((aligned(16))) uint16_t s_g[DF_T * DF_GP];
+    __shared__ unsigned int s_f[8][64], s_b[8][64], s_ein[8][64], s_bin[8][64];
+    __shared__ unsigned int s_rw[DF_T];                 // per tile row: D_T's row pass at the last (low half) / first (high half) column
+    __shared__ __attribute__((aligned(16))) uint16_t s_part[4][16][DF_T];    // the ring by slice of the gather: left, right, above, below (0xFFFF: nothing)
+    __shared__ unsigned int s_L2[DF_T], s_R2[DF_T], s_E2[64], s_B2[64];
+    __shared__ __attribute__((aligned(16))) int s_Qw[8][4];          // per wave: its rows' share of the tile's quadrant numbers
+    __shared__ int s_fail, s_open;
+    unsigned int* state = db.state[z];
+    unsigned int* words = fb.words[z];
+    unsigned int* corners = words + (size_t)T * DF_WORDS;           // [T][4]
+    unsigned int* claims = corners + (size_t)T * 4;                 // [T]: the tag of the launch in which the tile's summary was last taken on
+    const unsigned int tag = fb.tag[z];
+    const int8_t* __restrict__ cells = db.cells[z];
+    const int rp = t >> 3, rq = t & 7;                  // row layout: rows 2 rp, 2 rp + 1 of the tile, columns 16 rq .. 16 rq + 15
+    const int tx = t & 63, ty = t >> 6;                 // column layout: columns 2 tx, 2 tx + 1, rows 16 ty .. 16 ty + 15
+    const unsigned int one = df_both(1);
+#ifdef DF_STAMPS
+    unsigned long long* stamps = (unsigned long long*)(claims + T);
+#define DF_NOW(var) do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_waitcnt lgkmcnt(0)\n\ts_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var) :: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define DFS(slot, k) do { unsigned long long now_; DF_NOW(now_); if (t == 0) stamps[8 * (slot) + (k)] = now_; } while (0)
+    unsigned long long* wstamps = stamps + 16 * (size_t)T;           // [T][8 waves][4]
+#define DFW(tile, k) do { unsigned long long now_; DF_NOW(now_); if ((t & 63) == 0) wstamps[32 * (tile) + 4 * (t >> 6) + (k)] = now_; } while (0)
+#else
+#define DFS(slot, k) do { } while (0)
+#define DFW(tile, k) do { } while (0)
+#endif
+    if (t == 0) { s_fail = 0; s_open = 0; if (blockIdx.x == 0) dist_plan_full(state, W, H); }
+    df_barrier();
+    auto load_tile = [&](int tile, int4& a, int4& b) {
+        const int I = tile / nJ, J = tile - I * nJ;
+        const int x = J * DF_T + 16 * rq, y = I * DF_T + 2 * rp;
+        a = make_int4(-1, -1, -1, -1); b = make_int4(-1, -1, -1, -1);          // 0xFF bytes: free cells (log-odds < 0), i.e. no source
+        if (x < W && y < H) a = *(const int4*)(cells + (size_t)y * W + x);
+        if (x < W && y + 1 < H) b = *(const int4*)(cells + (size_t)(y + 1) * W + x);
+    };
+    // a claim on a tile's summary: a plain marker, not an election -- two workgroups that take on the same tile publish the same words
+    auto claim = [&](int tile) { if (t == 0) __hip_atomic_store(&claims[tile], tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+    // D_T of the tile whose cells the threads hold, into d0 (column layout), its summary published on the way.  Ends behind a
+    // barrier.  scan: look at every tile's claim word on the way (the loads ride behind the column work); returns whether this
+    // thread saw one without this launch's tag.
+    auto in_tile = [&](int tile, const int4 a, const int4 b, unsigned int d0[16], bool scan) -> bool {
+        const int I = tile / nJ, J = tile - I * nJ;
+        const int X0 = J * DF_T, Y0 = I * DF_T;
+        {
+            unsigned int v[16], row_f, row_b;
+#ifdef DF_STAMPS
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            DFW(tile, 0);
+#endif
+            df_row_pass(a, b, rq, v, row_f, row_b);
+#ifdef DF_STAMPS
+            asm volatile("" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]));
+            asm volatile("" : "+v"(v[8]), "+v"(v[9]), "+v"(v[10]), "+v"(v[11]), "+v"(v[12]), "+v"(v[13]), "+v"(v[14]), "+v"(v[15]), "+v"(row_f), "+v"(row_b));
+#endif
+            DFS(tile, 1);
+            DFW(tile, 1);
+            df_rows_to_lds(s_g, rp, rq, v);
+            DFW(tile, 2);
+            // the two rows' ends, and the wave's share of the quadrant numbers: per row the extreme source columns decide (every
+            // lane of a row pair's group holds them: reduced over the wave by DPP, one lane writes -- left to
+            // atomicMax on an LDS word the compiler loops over the active lanes, 1.4 us here)
+            int q[4] = {0, 0, 0, 0};                    // biased; 0: no source
+            for (int c = 0; c < 2; ++c) {
+                const int rf = (int)((row_f >> (16 * c)) & 0xFFFFu), rbk = (int)((row_b >> (16 * c)) & 0xFFFFu);
+                if (rf != 0xFFFF) {
+                    const int y = Y0 + 2 * rp + c, last = X0 + DF_T - 1 - rf, first = X0 + rbk;
+                    q[0] = max(q[0], last + y + DF_CORNER_BIAS); q[1] = max(q[1], last - y + DF_CORNER_BIAS);
+                    q[2] = max(q[2], -first + y + DF_CORNER_BIAS); q[3] = max(q[3], -first - y + DF_CORNER_BIAS);
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) q[k] = df_wave_max(q[k]);
+            if (rq == 7) *(uint2*)&s_rw[2 * rp] = make_uint2((row_f & 0xFFFFu) | (row_b << 16), (row_f >> 16) | (row_b & 0xFFFF0000u));
+            if ((t & 63) == 63) *(int4*)&s_Qw[t >> 6][0] = make_int4(q[0], q[1], q[2], q[3]);
+        }
+        DFW(tile, 3);
+        df_barrier();
+        DFS(tile, 2);
+        unsigned int cl[DF_SCAN];
+        if (scan) {
+#pragma unroll
+            for (int q = 0; q < DF_SCAN; ++q) cl[q] = t + q * DF_NT < T ? dst_load_u(&claims[t + q * DF_NT]) : tag;
+        }
+        {   // column pass, first half: per thread the ends of the two scans over its 16 rows
+#pragma unroll
+            for (int i = 0; i < 16; ++i) d0[i] = *(const unsigned int*)&s_g[df_at(16 * ty + i, 2 * tx)];
+            unsigned int df_ = DF_INF2, dbk = DF_INF2;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) df_ = df_min(df_adds(df_, one), d0[i]);
+#pragma unroll
+            for (int i = 15; i >= 0; --i) dbk = df_min(df_adds(dbk, one), d0[i]);
+            s_f[ty][tx] = df_; s_b[ty][tx] = dbk;
+        }
+        df_barrier();
+        DFS(tile, 3);
+        if (t < 64) {
+            // the carries entering each thread row of a column pair from above and from below; the ends of the chains are D_T at
+            // the tile's last / first row: the column words
+            unsigned int e = DF_INF2, bk = DF_INF2;
+#pragma unroll
+            for (int s2 = 0; s2 < 8; ++s2) { s_ein[s2][t] = e; e = df_min(s_f[s2][t], df_adds(e, df_both(16))); }
+#pragma unroll
+            for (int s2 = 7; s2 >= 0; --s2) { s_bin[s2][t] = bk; bk = df_min(s_b[s2][t], df_adds(bk, df_both(16))); }
+            unsigned int c2[2];
+            for (int c = 0; c < 2; ++c)
+                c2[c] = (tag << DF_TAG_SHIFT) | (min((bk >> (16 * c)) & 0xFFFFu, DF_NOPOT) << 9) | min((e >> (16 * c)) & 0xFFFFu, DF_NOPOT);
+            __hip_atomic_store((unsigned long long*)&words[(size_t)tile * DF_WORDS + DF_T + 2 * t], (unsigned long long)c2[0] | ((unsigned long long)c2[1] << 32),
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else if (t < 128) {
+            // D_T along the tile's last / first column: the row pass's ends spread over the rows (the column pass restricted to
+            // those two columns) -- lane l: rows 2l, 2l + 1; low half the last column, high half the first
+            const int l = t - 64;
+            unsigned int x0 = s_rw[2 * l], x1 = s_rw[2 * l + 1];
+            x1 = df_min(x1, df_adds(x0, one));
+            unsigned int S = x1;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) { const unsigned int u = (unsigned int)__shfl_up((int)S, off, 64); if (l >= off) S = df_min(S, df_adds(u, df_both(2 * off))); }
+            unsigned int c = (unsigned int)__shfl_up((int)S, 1, 64);
+            if (l == 0) c = DF_INF2;
+            x0 = df_min(x0, df_adds(c, one)); x1 = df_min(x1, df_adds(c, df_both(2)));
+            x0 = df_min(x0, df_adds(x1, one));
+            S = x0;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) { const unsigned int u = (unsigned int)__shfl_down((int)S, off, 64); if (l + off < 64) S = df_min(S, df_adds(u, df_both(2 * off))); }
+            c = (unsigned int)__shfl_down((int)S, 1, 64);
+            if (l == 63) c = DF_INF2;
+            x1 = df_min(x1, df_adds(c, one)); x0 = df_min(x0, df_adds(c, df_both(2)));
+            const unsigned int w0 = (tag << DF_TAG_SHIFT) | (min(x0 >> 16, DF_NOPOT) << 9) | min(x0 & 0xFFFFu, DF_NOPOT);
+            const unsigned int w1 = (tag << DF_TAG_SHIFT) | (min(x1 >> 16, DF_NOPOT) << 9) | min(x1 & 0xFFFFu, DF_NOPOT);
+            __hip_atomic_store((unsigned long long*)&words[(size_t)tile * DF_WORDS + 2 * l], (unsigned long long)w0 | ((unsigned long long)w1 << 32),
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else if (t < 132) {
+            int qm = 0;
+#pragma unroll
+            for (int w = 0; w < 8; ++w) qm = max(qm, s_Qw[w][t - 128]);
+            __hip_atomic_store(&corners[(size_t)tile * 4 + (t - 128)], (tag << DF_TAG_SHIFT) | (unsigned int)qm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        df_barrier();
+        DFS(tile, 4);
+        {   // column pass, second half, in place: down with the carry from above, then up (the forward values bound the true
+            // ones from above, so the second sweep may start from them)
+            unsigned int e = s_ein[ty][tx], bk = s_bin[ty][tx];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { e = df_min(df_adds(e, one), d0[i]); d0[i] = e; }
+#pragma unroll
+            for (int i = 15; i >= 0; --i) { bk = df_min(df_adds(bk, one), d0[i]); d0[i] = bk; }
+        }
+        bool open = false;
+        if (scan) {
+#pragma unroll
+            for (int q = 0; q < DF_SCAN; ++q) open = open || cl[q] != tag;
+        }
+        DFS(tile, 7);
+        return open;
+    };
+
+    // ================================================================================ D_T of the workgroup's tiles
+    unsigned int d0[K][16];
+    bool early_open = false;
+    {
+        int4 ra = make_int4(-1, -1, -1, -1), rb = ra, na = ra, nb = ra;
+        if (tile_of(0) >= 0) load_tile(tile_of(0), ra, rb);
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const int tile = tile_of(k);
+            if (tile >= 0) {
+                DFS(tile, 0);
+                claim(tile);
+                const int next = k + 1 < K ? tile_of(k + 1) : -1;
+                if (next >= 0) load_tile(next, na, nb);                          // (in flight behind this tile's work)
+                const bool o = in_tile(tile, ra, rb, d0[k], next < 0);           // (the last one: by then the others' claims are out)
+                if (next < 0) early_open = o;
+                ra = na; rb = nb;
+            }
+        }
+    }
+    // ==================================================================================== the other tiles' summaries; the ramps
+    // A workgroup waits for words of EVERY other tile.  Waiting is only safe for tiles some running workgroup has taken on (it
+    // publishes without waiting for anybody); a tile nobody has claimed yet belongs to a workgroup that may not become resident
+    // while this one spins -- so before its first wait a workgroup looks at every claim word and computes the summaries of the
+    // unclaimed tiles itself.  The launch cannot deadlock however few of its workgroups are resident together.
+    if (early_open) s_open = 1;
+    df_barrier();
+    bool all_claimed = s_open == 0;                     // every claim word carried the tag when the last tile's pass looked
+    df_barrier();
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        const int tile = tile_of(k);
+        if (tile < 0) break;
+        const int I = tile / nJ, J = tile - I * nJ;
+        const int X0 = J * DF_T, Y0 = I * DF_T;
+        DFS(T + tile, 0);
+        if (t == 0) s_open = T;
+        df_barrier();
+        bool failed = false;
+        // The words this tile needs, every load of a thread in flight before the first is looked at (16 bytes each: four rows or
+        // four columns of one tile; L2-served, never from this CU's L1 -- a word polled once too early would be polled from there
+        // forever).  slice = t >> 5 takes the tiles slice, slice + 16, ... of the row band and of the column band, u = t & 31
+        // their entries 4u .. 4u + 3; thread t the diagonal tiles t, t + 512 (one quadrant number each).
+        const int slice = t >> 5, u = t & 31;
+        const unsigned int* prow[DF_GSLOTS];
+        const unsigned int* pcol[DF_GSLOTS];
+        const unsigned int* pcor[2];
+        df_u4 wrow[DF_GSLOTS], wcol[DF_GSLOTS];
+        unsigned int wcor[2];
+#pragma unroll
+        for (int q = 0; q < DF_GSLOTS; ++q) {
+            const int j2 = slice + 16 * q, i2 = slice + 16 * q;
+            prow[q] = j2 < nJ && j2 != J ? &words[(size_t)(I * nJ + j2) * DF_WORDS + 4 * u] : nullptr;
+            pcol[q] = i2 < nI && i2 != I ? &words[(size_t)(i2 * nJ + J) * DF_WORDS + DF_T + 4 * u] : nullptr;
+        }
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int k2 = t + q * DF_NT, i2 = k2 / nJ, j2 = k2 - i2 * nJ;
+            pcor[q] = k2 < T && i2 != I && j2 != J ? &corners[(size_t)k2 * 4 + (i2 < I ? (j2 < J ? 0 : 2) : (j2 < J ? 1 : 3))] : nullptr;
+        }
+#pragma unroll
+        for (int q = 0; q < DF_GSLOTS; ++q) { wrow[q] = df_u4{0u, 0u, 0u, 0u}; wcol[q] = wrow[q]; if (prow[q]) df_load16(wrow[q], prow[q]); if (pcol[q]) df_load16(wcol[q], pcol[q]); }
+#pragma unroll
+        for (int q = 0; q < 2; ++q) wcor[q] = pcor[q] ? dst_load_u(pcor[q]) : 0u;
+        if (!all_claimed) {
+            // (uniform over the workgroup: at most once per workgroup, beside the first loads)
+            while (true) {
+                for (int k2 = t; k2 < T; k2 += DF_NT) if (dst_load_u(&claims[k2]) != tag) atomicMin(&s_open, k2);
+                df_barrier();
+                const int open = s_open;
+                df_barrier();
+                if (open >= T) break;
+                if (t == 0) s_open = T;
+                int4 ha, hb;
+                unsigned int scratch[16];
+                load_tile(open, ha, hb);
+                claim(open);
+                in_tile(open, ha, hb, scratch, false);
+                df_barrier();
+            }
+            all_claimed = true;
+        }
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(wrow[0]), "+v"(wrow[1]), "+v"(wrow[2]), "+v"(wrow[3]), "+v"(wcol[0]), "+v"(wcol[1]), "+v"(wcol[2]), "+v"(wcol[3]) :: "memory");
+        DFS(T + tile, 4);
+        // the words that have not come yet: asked for again together, not one after the other
+        {
+            auto ready = [&](const df_u4& w) { return (w.x >> DF_TAG_SHIFT) == tag && (w.y >> DF_TAG_SHIFT) == tag && (w.z >> DF_TAG_SHIFT) == tag && (w.w >> DF_TAG_SHIFT) == tag; };
+            unsigned int pend = 0;
+#pragma unroll
+            for (int q = 0; q < DF_GSLOTS; ++q) { if (prow[q] && !ready(wrow[q])) pend |= 1u << q; if (pcol[q] && !ready(wcol[q])) pend |= 1u << (8 + q); }
+#pragma unroll
+            for (int q = 0; q < 2; ++q) if (pcor[q] && (wcor[q] >> DF_TAG_SHIFT) != tag) pend |= 1u << (16 + q);
+            int spins = 0;
+            while (pend) {
+                if (++spins > DF_SPIN_CAP) { failed = true; break; }
+                __builtin_amdgcn_s_sleep(2);
+#pragma unroll
+                for (int q = 0; q < DF_GSLOTS; ++q) { if ((pend >> q) & 1u) df_load16(wrow[q], prow[q]); if ((pend >> (8 + q)) & 1u) df_load16(wcol[q], pcol[q]); }
+#pragma unroll
+                for (int q = 0; q < 2; ++q) if ((pend >> (16 + q)) & 1u) wcor[q] = dst_load_u(pcor[q]);
+                asm volatile("s_waitcnt vmcnt(0)" : "+v"(wrow[0]), "+v"(wrow[1]), "+v"(wrow[2]), "+v"(wrow[3]), "+v"(wcol[0]), "+v"(wcol[1]), "+v"(wcol[2]), "+v"(wcol[3]) :: "memory");
+#pragma unroll
+                for (int q = 0; q < DF_GSLOTS; ++q) { if (((pend >> q) & 1u) && ready(wrow[q])) pend &= ~(1u << q); if (((pend >> (8 + q)) & 1u) && ready(wcol[q])) pend &= ~(1u << (8 + q)); }
+#pragma unroll
+                for (int q = 0; q < 2; ++q) if (((pend >> (16 + q)) & 1u) && (wcor[q] >> DF_TAG_SHIFT) == tag) pend &= ~(1u << (16 + q));
+            }
+        }
+        DFS(T + tile, 5);
+        {   // per slice: the nearest outside source as seen from the ring, entries 4u .. 4u + 3 (a potential p of a tile n tiles away:
+            // p + 128 n).  A slot's tile lies on ONE side of this tile: one field of each word counts.
+            unsigned int L[4] = {0xFFFFu, 0xFFFFu, 0xFFFFu, 0xFFFFu}, R[4] = {0xFFFFu, 0xFFFFu, 0xFFFFu, 0xFFFFu};
+            unsigned int E[4] = {0xFFFFu, 0xFFFFu, 0xFFFFu, 0xFFFFu}, B[4] = {0xFFFFu, 0xFFFFu, 0xFFFFu, 0xFFFFu};
+#pragma unroll
+            for (int q = 0; q < DF_GSLOTS; ++q) {
+                const int o2 = slice + 16 * q;                                       // the slot's tile in the row band / in the column band
+                if (prow[q]) {
+                    const unsigned int wr[4] = {wrow[q].x, wrow[q].y, wrow[q].z, wrow[q].w};
+                    const bool left = o2 < J;
+                    const unsigned int sh = left ? 0u : 9u, add = (unsigned int)(DF_T * (left ? J - 1 - o2 : o2 - J - 1));
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const unsigned int f = (wr[e] >> sh) & 0x1FFu, c = f == DF_NOPOT ? 0xFFFFu : f + add;
+                        if (left) L[e] = min(L[e], c); else R[e] = min(R[e], c);
+                    }
+                }
+                if (pcol[q]) {
+                    const unsigned int wc[4] = {wcol[q].x, wcol[q].y, wcol[q].z, wcol[q].w};
+                    const bool above = o2 < I;
+                    const unsigned int sh = above ? 0u : 9u, add = (unsigned int)(DF_T * (above ? I - 1 - o2 : o2 - I - 1));
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const unsigned int f = (wc[e] >> sh) & 0x1FFu, c = f == DF_NOPOT ? 0xFFFFu : f + add;
+                        if (above) E[e] = min(E[e], c); else B[e] = min(B[e], c);
+                    }
+                }
+            }
+            *(uint2*)&s_part[0][slice][4 * u] = make_uint2(L[0] | (L[1] << 16), L[2] | (L[3] << 16));
+            *(uint2*)&s_part[1][slice][4 * u] = make_uint2(R[0] | (R[1] << 16), R[2] | (R[3] << 16));
+            *(uint2*)&s_part[2][slice][4 * u] = make_uint2(E[0] | (E[1] << 16), E[2] | (E[3] << 16));
+            *(uint2*)&s_part[3][slice][4 * u] = make_uint2(B[0] | (B[1] << 16), B[2] | (B[3] << 16));
+            // the diagonal tiles' numbers by quadrant: the wave's maxima
+            int q4[4] = {0, 0, 0, 0};
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int k2 = t + q * DF_NT, i2 = k2 / nJ, j2 = k2 - i2 * nJ;
+                const int which = i2 < I ? (j2 < J ? 0 : 2) : (j2 < J ? 1 : 3);
+                const int enc = pcor[q] ? (int)(wcor[q] & 0xFFFFu) : 0;
+#pragma unroll
+                for (int w = 0; w < 4; ++w) if (which == w) q4[w] = max(q4[w], enc);
+            }
+#pragma unroll
+            for (int w = 0; w < 4; ++w) q4[w] = df_wave_max(q4[w]);
+            if ((t & 63) == 63) *(int4*)&s_Qw[t >> 6][0] = make_int4(q4[0], q4[1], q4[2], q4[3]);
+        }
+        if (failed) s_fail = 1;
+        DFS(T + tile, 1);
+        df_barrier();
+        DFS(T + tile, 2);
+        if (s_fail) {                                   // a summary never arrived: say so, write nothing more
+            if (t == 0) { atomicAdd(&state[DST_FAILED], 1u); if (db.hstat[z]) __hip_atomic_store(db.hstat[z], DST_MODE_BROKEN, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+            return;
+        }
+        // the ring around the tile in the form the ramps take it: per row both halves the same value; per column pair the pair,
+        // the diagonal tiles' numbers folded in
+        if (t < 2 * DF_T) {
+            const int a = t >> 7, r = t & (DF_T - 1);
+            int m = 0xFFFF;
+#pragma unroll
+            for (int s2 = 0; s2 < 16; ++s2) m = min(m, (int)s_part[a][s2][r]);
+            if (a == 0) s_L2[r] = df_both(m); else s_R2[r] = df_both(m);
+        } else if (t < 4 * DF_T) {
+            const int down = t < 3 * DF_T, c = t & (DF_T - 1), xa = X0 + c;
+            int e = 0xFFFF;
+#pragma unroll
+            for (int s2 = 0; s2 < 16; ++s2) e = min(e, (int)s_part[down ? 2 : 3][s2][c]);
+            if (e == 0xFFFF) e = DIST_INF;
+            int qa = 0, qb = 0;
+#pragma unroll
+            for (int w = 0; w < 8; ++w) { qa = max(qa, s_Qw[w][down ? 0 : 1]); qb = max(qb, s_Qw[w][down ? 2 : 3]); }
+            if (down) {
+                if (qa) e = min(e, xa + (Y0 - 1) - (qa - DF_CORNER_BIAS));                     // sources above left:  px + py - max (sx + sy)
+                if (qb) e = min(e, (Y0 - 1) - xa - (qb - DF_CORNER_BIAS));                     // above right:          py - px - max (sy - sx)
+            } else {
+                const int Yb = Y0 + DF_T;                                                      // the row just below the tile
+                if (qa) e = min(e, xa - Yb - (qa - DF_CORNER_BIAS));                           // below left:           px - py - max (sx - sy)
+                if (qb) e = min(e, -xa - Yb - (qb - DF_CORNER_BIAS));                          // below right:         -px - py - max (-sx - sy)
+            }
+            ((uint16_t*)(down ? s_E2 : s_B2))[c] = (uint16_t)min(e, 0xFFFF);
+        }
+        df_barrier();
+        DFS(T + tile, 3);
+        {
+            const unsigned int off_l = (unsigned int)(2 * tx + 1) | ((unsigned int)(2 * tx + 2) << 16);
+            const unsigned int off_r = (unsigned int)(DF_T - 2 * tx) | ((unsigned int)(DF_T - 1 - 2 * tx) << 16);
+            unsigned int e = df_adds(s_E2[tx], df_both(16 * ty)), bk = df_adds(s_B2[tx], df_both(DF_T - 16 - 16 * ty));
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                e = df_adds(e, one);
+                unsigned int v = df_min(d0[k][i], e);
+                v = df_min(v, df_adds(s_L2[16 * ty + i], off_l));
+                d0[k][i] = df_min(v, df_adds(s_R2[16 * ty + i], off_r));
+            }
+#pragma unroll
+            for (int i = 15; i >= 0; --i) { bk = df_adds(bk, one); d0[k][i] = df_min(d0[k][i], bk); }
+        }
+        DFS(T + tile, 6);
+        uint16_t* __restrict__ l1 = db.l1[z];
+        const int xc = X0 + 2 * tx;
+        if (xc < W) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int yy = Y0 + 16 * ty + i;
+                if (yy < H) *(unsigned int*)(l1 + (size_t)yy * W + xc) = d0[k][i];
+            }
+        }
+        DFS(T + tile, 7);
+        df_barrier();                                   // the LDS arrays are free for the next tile
+    }
+}
+
 // The plan of an incremental transform, by the first wave of a workgroup (every workgroup of k_dist_rows_inc forms the same one
 // from the same inputs: the log entries from + 1 .. to and the bound D as the previous transform left it).  plan[0..4] = mode,
 // x0, y0, x1, y1.  W is a multiple of 16.
@@ -950,6 +1488,7 @@ extern "C" void bl_dist_destroy(bl_dist* d)
     if (d->sum_b) (void)hipFree(d->sum_b);
     if (d->lut) (void)hipFree(d->lut);
     if (d->state) (void)hipFree(d->state);
+    if (d->fwords) (void)hipFree(d->fwords);
     if (d->h_status) (void)hipHostFree(d->h_status);
     delete d->lut_host;
     delete d;
@@ -1066,6 +1605,11 @@ static int dist_set_distances_batch(int n, bl_dist* const* ds, const bl_grid* co
         bl_dist* d = ds[u];
         // what the device said about the last incremental launch (no waiting: the word is whatever has landed by now)
         if (d->h_status && *d->h_status == (unsigned int)DST_MODE_FULL) { *d->h_status = 0; d->inc_holdoff = 16; }
+        if (d->h_status && *d->h_status == DST_MODE_BROKEN) {
+            *d->h_status = 0; d->valid = false; d->src_id = 0;
+            bl_set_error("setDistances: the one-launch transform gave up (a tile summary never arrived); the distances it left are not valid");
+            return BL_ERR_STATE;
+        }
         const bool inc = dist_can_increment(d, maps[u]);
         if (d->inc_holdoff > 0) d->inc_holdoff -= 1;
         // the very state of the very map d holds the transform of (any grid size; no log needed)
@@ -1133,6 +1677,48 @@ static int dist_set_distances_batch(int n, bl_dist* const* ds, const bl_grid* co
         rc = bl_timer_end(ctx, BL_K_DIST_COLS_APPLY, f0, f1);
         if (rc) return rc;
     } else {
+        // grids of whole 16-cell groups, at least 4 x 4 and at most DF_MAXK x 256 tiles: the whole transform in one launch
+        // (BOTLAB_DIST_NO_FUSED=1: the four-launch form)
+        const bool no_fused = getenv("BOTLAB_DIST_NO_FUSED") != nullptr;        // (read per call: tests switch forms inside one process)
+        const int tiles = ((W + DF_T - 1) / DF_T) * ((H + DF_T - 1) / DF_T);
+        const bool fused = !no_fused && !region_kernels && (W & 15) == 0 && W >= 4 * DF_T && H >= 4 * DF_T && W <= DF_MAX_SIDE && H <= DF_MAX_SIDE &&
+                           tiles <= DF_MAXK * DF_MAX_WGS;
+        if (fused) {
+            const int per_wg = (tiles + DF_MAX_WGS - 1) / DF_MAX_WGS;           // tiles a workgroup keeps in registers
+            const int per_xcd = (tiles + 7) / 8;                               // (the kernel's tile_of: an XCD's workgroups share a run of tiles)
+            const int fused_wgs = 8 * ((per_xcd + per_wg - 1) / per_wg);
+            dist_fused_batch fb;
+            memset((void*)&fb, 0, sizeof(fb));
+            for (int u = 0; u < n; ++u) {
+                bl_dist* d = ds[u];
+#ifdef DF_STAMPS
+                const size_t need = (size_t)tiles * (DF_WORDS + 5) + (size_t)tiles * 32 + (size_t)tiles * 64;      // + [2 T][8] + [T][8][4] 64-bit stamps
+#else
+                const size_t need = (size_t)tiles * (DF_WORDS + 5);             // per tile: band words, 4 quadrant words, a claim word
+#endif
+                if (need > d->fwords_cap) {
+                    BL_HIP(hipStreamSynchronize(ctx->stream));
+                    if (d->fwords) BL_HIP(hipFree(d->fwords));
+                    d->fwords = nullptr;
+                    BL_HIP(hipMalloc((void**)&d->fwords, need * sizeof(unsigned int)));
+                    d->fwords_cap = need; d->f_w = 0;
+                }
+                if (d->f_w != W || d->f_h != H) {        // words laid out for another grid could carry this launch's tag: tag 0 everywhere
+                    BL_HIP(hipMemsetAsync(d->fwords, 0, d->fwords_cap * sizeof(unsigned int), ctx->stream));
+                    d->f_w = W; d->f_h = H;
+                }
+                d->f_tag = d->f_tag % 63u + 1u;
+                fb.words[u] = d->fwords; fb.tag[u] = d->f_tag;
+            }
+            rc = bl_timer_begin(ctx, BL_K_DIST_FUSED, &f0, &f1);
+            if (rc) return rc;
+            const dim3 fgrid(fused_wgs, 1, n);
+            if (per_wg == 1) hipLaunchKernelGGL(k_dist_fused<1>, fgrid, dim3(DF_NT), 0, ctx->stream, b, fb, W, H);
+            else if (per_wg == 2) hipLaunchKernelGGL(k_dist_fused<2>, fgrid, dim3(DF_NT), 0, ctx->stream, b, fb, W, H);
+            else hipLaunchKernelGGL(k_dist_fused<DF_MAXK>, fgrid, dim3(DF_NT), 0, ctx->stream, b, fb, W, H);
+            rc = bl_timer_end(ctx, BL_K_DIST_FUSED, f0, f1);
+            if (rc) return rc;
+        } else {
         if (!merged) for (int u = 0; u < n; ++u) b.state[u] = nullptr;      // (the small-grid column pass keeps no plan or bound)
         rc = bl_timer_begin(ctx, BL_K_DIST_ROWS, &f0, &f1);
         if (rc) return rc;
@@ -1176,6 +1762,7 @@ static int dist_set_distances_batch(int n, bl_dist* const* ds, const bl_grid* co
             else hipLaunchKernelGGL(k_dist_cols, dim3((W + DCOL_TX - 1) / DCOL_TX, 1, n), dim3(DCOL_TX, DCOL_TY), 0, ctx->stream, b, W, H);
             rc = bl_timer_end(ctx, BL_K_DIST_COLS_APPLY, f0, f1);
             if (rc) return rc;
+        }
         }
     }
     BL_HIP(hipGetLastError());
@@ -1236,6 +1823,17 @@ extern "C" int bl_dist_debug_bound(bl_dist* d, int* formed, unsigned int* bound)
     }
     return BL_OK;
 }
+
+#ifdef DF_STAMPS
+extern "C" int bl_dist_debug_fused_stamps(bl_dist* d, unsigned long long* out, int n)
+{
+    const int tiles = ((d->f_w + DF_T - 1) / DF_T) * ((d->f_h + DF_T - 1) / DF_T);
+    if (n > tiles * 48) n = tiles * 48;
+    BL_HIP(hipMemcpyAsync(out, d->fwords + (size_t)tiles * (DF_WORDS + 5), (size_t)n * 8, hipMemcpyDeviceToHost, d->ctx->stream));
+    BL_HIP(hipStreamSynchronize(d->ctx->stream));
+    return n;
+}
+#endif
 
 extern "C" int bl_dist_download(bl_dist* d, float* cells)
 {

@@ -85,7 +85,8 @@ int bl_ctx_timing_reset(bl_ctx* ctx);
 #define BL_K_DIST_COLS_SUMMARY 7
 #define BL_K_DIST_COLS_APPLY 8
 #define BL_K_SNAPSHOT 9
-#define BL_K_COUNT 10
+#define BL_K_DIST_FUSED 10   /* the whole-grid transform as one launch (grids of at least 512 x 512, width a multiple of 16) */
+#define BL_K_COUNT 11
 
 /* ------------------------------------------------------------------ OccupancyGrid  (src/slam/occupancy_grid.hpp:51-209)
  * Device-resident int8 log-odds cells, row-major y*width+x.  meters_per_cell and cells_per_meter are both carried

@@ -1,0 +1,80 @@
+"""ObstacleDistanceGrid::setDistances of a whole large grid as ONE launch (k_dist_fused: a summary pass and an apply pass per
+128 x 128 tile, handed over through tagged words): bit-exact against the oracle's flood (obstacle_distance_grid.cpp:73-181) on
+the source layouts that exercise each kind of summary, and equal to the four-launch form on the same grids."""
+import os
+
+import numpy as np
+import pytest
+
+import botlab_amd as bl
+
+pytestmark = pytest.mark.gpu
+
+
+def _transform(cells, ctx, repeat=1):
+    g = bl.OccupancyGrid.from_cells(cells, (-3.0, -7.0), 0.05, ctx=ctx)
+    d = bl.ObstacleDistanceGrid(ctx=ctx)
+    for _ in range(repeat):
+        d.forget()
+        d.setDistances(g)
+    out = d.cells().copy()
+    d.close(); g.close()
+    return out
+
+
+def _layouts(h, w, rng):
+    free = -rng.integers(1, 100, (h, w)).astype(np.int8)
+    yield "none", free.copy()                                              # no source anywhere: -1 everywhere
+    one = free.copy(); one[h - 1, 0] = 0
+    yield "one_corner", one                                               # every other tile sees it through a row, column or quadrant word
+    one = free.copy(); one[h // 2 + 3, w - 1] = 5
+    yield "one_edge", one
+    four = free.copy(); four[0, 0] = 1; four[0, w - 1] = 1; four[h - 1, 0] = 1; four[h - 1, w - 1] = 1
+    yield "four_corners", four
+    sparse = np.where(rng.random((h, w)) < 3e-5, 50, free).astype(np.int8)
+    yield "sparse", sparse                                                # a few sources per tile at most: long carries in every direction
+    dense = np.where(rng.random((h, w)) < 0.02, 50, free).astype(np.int8)
+    yield "dense", dense
+    line = free.copy(); line[:, w // 3] = 0; line[h // 4, :] = 0
+    yield "lines", line
+
+
+@pytest.mark.parametrize("shape", [(512, 512),            # 4 x 4 whole tiles
+                                   (600, 1040),           # last band 88 rows, last column band 16 columns
+                                   (513, 528),            # one row into the fifth band, one 16-cell group into the fifth column band
+                                   (2000, 2000),          # BASELINE config 1
+                                   (1100, 8176)])         # the widest grid the row words can index
+def test_fused_transform_matches_oracle(oracle, gpu_ctx, shape):
+    h, w = shape
+    rng = np.random.default_rng(h * 7 + w)
+    for name, cells in _layouts(h, w, rng):
+        got = _transform(cells, gpu_ctx, repeat=2)                       # twice: the second launch meets the first one's words
+        exp = oracle.set_distances(cells, 0.05, 20.0, (-3.0, -7.0))
+        assert np.array_equal(got.view(np.uint32), exp.view(np.uint32)), (shape, name)
+
+
+def test_fused_equals_four_launch_form_4096(gpu_ctx):
+    rng = np.random.default_rng(4096)
+    h = w = 4096
+    cells = np.where(rng.random((h, w)) < 1e-5, 50, -7).astype(np.int8)
+    cells[4095, 17] = 0
+    a = _transform(cells, gpu_ctx)
+    os.environ["BOTLAB_DIST_NO_FUSED"] = "1"
+    try:
+        b = _transform(cells, gpu_ctx)
+    finally:
+        del os.environ["BOTLAB_DIST_NO_FUSED"]
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+
+
+def test_fused_then_incremental_window(oracle, gpu_ctx):
+    # a whole-grid transform by the fused launch, then map updates through the lineage's log: the windows start from its distances
+    h = w = 1024
+    rng = np.random.default_rng(5)
+    cells = np.where(rng.random((h, w)) < 0.002, 50, -7).astype(np.int8)
+    g = bl.OccupancyGrid.from_cells(cells, (-25.6, -25.6), 0.05, ctx=gpu_ctx)
+    d = bl.ObstacleDistanceGrid(ctx=gpu_ctx)
+    d.setDistances(g)
+    exp = oracle.set_distances(cells, 0.05, 20.0, (-25.6, -25.6))
+    assert np.array_equal(d.cells().view(np.uint32), exp.view(np.uint32))
+    d.close(); g.close()
