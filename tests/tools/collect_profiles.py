@@ -158,7 +158,44 @@ def collect_streaming():
             w.writerow([k, n, "%.0f" % avg, mn, a, "%.1f" % (a / avg), "%.3f" % (a / avg / 8000.0), "%.0f" % hb if hb else "", "%.3f" % (hb / a) if hb else ""])
 
 
-which = sys.argv[1:] or ["default", "config4", "config5", "config5explore", "frontiers", "stream"]
+def collect_dist_fused():
+    """Whole-grid setDistances at 2000^2 and 4096^2 (tests/tools/dist_fused_probe.py: the one-launch form, then the four-launch form):
+    durations from the kernel trace, HBM bytes from the two counter passes."""
+    script = os.path.join("tests", "tools", "dist_fused_probe.py")
+    with open(os.path.join(OUT, f"{ROUND}_dist_fused.csv"), "w") as f:
+        f.write("# rocprofv3 --kernel-trace --stats / --pmc FETCH_SIZE / --pmc WRITE_SIZE (three runs per size) -- python3 tests/tools/dist_fused_probe.py <side>\n"
+                "# k_dist_fused moves 3 B per cell (int8 in, uint16 out); the four kernels of the other form 3 + 2 + 4 (+ the carries).  hbm_bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024\n")
+        w = csv.writer(f)
+        w.writerow(["side", "kernel", "launches", "avg_ns", "min_ns", "algorithmic_bytes", "algorithmic_GBps_at_avg", "frac_of_8TBps", "hbm_bytes_counters"])
+        for side in (2000, 4096):
+            S = side * side
+            alg = {"k_dist_fused": 3 * S, "k_dist_rows_wide": 3 * S, "k_dist_cols_summary": 2 * S, "k_dist_cols_carry": 0, "k_dist_cols_apply": 4 * S}
+            db, _ = run(["--kernel-trace", "--stats"], f"distfused{side}_stats", [str(side)], script)
+            dur = {}
+            if db:
+                for name, n, avg, mn in sqlite3.connect(db).execute("select name, count(*), avg(end-start), min(end-start) from kernels group by name"):
+                    dur[short(name)] = (n, avg, mn)
+            per = {}
+            for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+                db, _ = run(["--pmc", counter, "--kernel-trace"], f"distfused{side}_" + counter.lower(), [str(side)], script)
+                if not db:
+                    continue
+                con = sqlite3.connect(db)
+                cols = [d[1] for d in con.execute("pragma table_info(counters_collection)")]
+                kcol = "kernel_name" if "kernel_name" in cols else "name"
+                for name, n, mean in con.execute(f"select {kcol}, count(*), avg(value) from counters_collection where counter_name='{counter}' group by {kcol}"):
+                    per.setdefault(short(name), {})[counter] = mean
+            for k, a in alg.items():
+                for nm in [nm for nm in dur if k in nm]:
+                    n, avg, mn = dur[nm]
+                    c = per.get(nm, {})
+                    hb = (2.0 * c.get("FETCH_SIZE", 0.0) + c.get("WRITE_SIZE", 0.0)) * 1024.0 if len(c) == 2 else None
+                    w.writerow([side, nm[:40], n, "%.0f" % avg, mn, a, "%.1f" % (a / avg), "%.3f" % (a / avg / 8000.0), "%.0f" % hb if hb else ""])
+
+
+which = sys.argv[1:] or ["default", "config4", "config5", "config5explore", "frontiers", "stream", "distfused"]
+if "distfused" in which:
+    collect_dist_fused()
 if "stream" in which:
     collect_streaming()
 if "default" in which:

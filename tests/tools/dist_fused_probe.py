@@ -6,7 +6,7 @@ import numpy as np, torch
 import botlab_amd as bl
 from botlab_amd import _capi
 ctx = bl.default_context()
-for side in (1024, 2000, 4096, 8176):
+for side in ([int(a) for a in sys.argv[1:]] or [1024, 2000, 4096, 8176]):
     rng = np.random.default_rng(side)
     cells = np.where(rng.random((side, side)) < 0.01, 50, -7).astype(np.int8)
     g = bl.OccupancyGrid.from_cells(cells, (0.0, 0.0), 0.05, ctx=ctx)
