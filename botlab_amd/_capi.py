@@ -109,6 +109,7 @@ SIGNATURES = {
     "bl_dist_debug_stats": (C.c_int, [_vp, _vp]),
     "bl_dist_forget": (C.c_int, [_vp]),
     "bl_dist_debug_bound": (C.c_int, [_vp, _vp, _vp]),
+    "bl_dist_debug_fused": (C.c_int, [_vp, _vp]),
     "bl_dist_shape": (C.c_int, [_vp, _P(C.c_int), _P(C.c_int)]),
     "bl_dist_frame": (C.c_int, [_vp, _P(C.c_float), _P(C.c_float), _P(C.c_float), _P(C.c_float)]),
     "bl_dist_device_ptr": (_vp, [_vp]),

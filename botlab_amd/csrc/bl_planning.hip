@@ -88,7 +88,8 @@ struct dist_batch {
 #define DST_MAX_GROUPS 64    // grids up to 8192 columns / rows in the region kernels (macro strips whose summaries fit LDS)
 #define DST_STATS 8          // [3] incremental launches that ended as: nothing to do, a window, the whole grid (diagnostic)
 #define DST_FAILED (DST_STATS + 3)   // k_dist_fused: workgroups that gave up (a summary that never came)
-#define DST_WORDS (DST_STATS + 4)
+#define DST_HELPED (DST_STATS + 4)   // k_dist_fused: summaries computed in place of a workgroup that had not claimed its tile yet
+#define DST_WORDS (DST_STATS + 5)
 #define DST_MODE_NONE 0      // nothing changed
 #define DST_MODE_WINDOW 1
 #define DST_MODE_FULL 2
@@ -688,7 +689,7 @@ __global__ __launch_bounds__(DC2_TX * DC2_TY) void k_dist_cols_apply(dist_batch 
 #define DF_SCAN 2                              // claim words per thread: DF_MAXK * DF_MAX_WGS tiles
 #define DF_MAX_WGS 256
 #define DF_MAXK 4
-struct dist_fused_batch { unsigned int* words[DIST_MAX_BATCH]; unsigned int tag[DIST_MAX_BATCH]; };
+struct dist_fused_batch { unsigned int* words[DIST_MAX_BATCH]; unsigned int tag[DIST_MAX_BATCH]; unsigned int test_delay; };
 
 typedef unsigned short df_u2 __attribute__((ext_vector_type(2)));
 typedef short df_s2 __attribute__((ext_vector_type(2)));
@@ -705,8 +706,10 @@ __device__ __forceinline__ unsigned int df_both(int v) { return (unsigned int)v 
 __device__ __forceinline__ unsigned int df_pair(int lo, int hi) { return (unsigned int)min(lo, 0xFFFF) | ((unsigned int)min(hi, 0xFFFF) << 16); }
 
 typedef unsigned int df_u4 __attribute__((ext_vector_type(4)));
-// 16 bytes through the L2, not waited for (the caller's s_waitcnt names the registers)
-__device__ __forceinline__ void df_load16(df_u4& w, const unsigned int* p) { asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(w) : "v"(p) : "memory"); }
+// 16 bytes through the L2, not waited for: the caller's `s_waitcnt vmcnt(0)` statement names the registers, and nothing that could
+// make the compiler move them may stand between the two (the operand is read-write so that a load under a condition redefines the
+// SAME register, not a copy the compiler merges afterwards -- the data lands asynchronously, a copy made before the wait is stale)
+__device__ __forceinline__ void df_load16(df_u4& w, const unsigned int* p) { asm volatile("global_load_dwordx4 %0, %1, off sc1" : "+v"(w) : "v"(p) : "memory"); }
 
 // A workgroup barrier that waits for the wave's LDS traffic only: __syncthreads() also waits for every global access the wave has
 // in flight -- the tile's cells on their way in, the published words on their way out -- although nothing behind these barriers
@@ -841,6 +844,7 @@ __global__ __launch_bounds__(DF_NT) void k_dist_fused(dist_batch db, dist_fused_
 #define DFW(tile, k) do { } while (0)
 #endif
     if (t == 0) { s_fail = 0; s_open = 0; if (blockIdx.x == 0) dist_plan_full(state, W, H); }
+    if (fb.test_delay && (blockIdx.x & 1)) for (unsigned int i = 0; i < fb.test_delay; ++i) __builtin_amdgcn_s_sleep(64);     // (tests: a workgroup that starts late)
     df_barrier();
     auto load_tile = [&](int tile, int4& a, int4& b) {
         const int I = tile / nJ, J = tile - I * nJ;
@@ -1035,18 +1039,23 @@ __global__ __launch_bounds__(DF_NT) void k_dist_fused(dist_batch db, dist_fused_
 #pragma unroll
         for (int q = 0; q < 2; ++q) wcor[q] = pcor[q] ? dst_load_u(pcor[q]) : 0u;
         if (!all_claimed) {
-            // (uniform over the workgroup: at most once per workgroup, beside the first loads)
+            // (uniform over the workgroup: at most once per workgroup.  The words asked for above are awaited first: the registers
+            // they land in are the compiler's to move once the code below needs room)
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(wrow[0]), "+v"(wrow[1]), "+v"(wrow[2]), "+v"(wrow[3]), "+v"(wcol[0]), "+v"(wcol[1]), "+v"(wcol[2]), "+v"(wcol[3]) :: "memory");
+            const int first = tile_of(0);                   // (workgroups start their search at their own tile: they take different ones)
             while (true) {
-                for (int k2 = t; k2 < T; k2 += DF_NT) if (dst_load_u(&claims[k2]) != tag) atomicMin(&s_open, k2);
+                for (int k2 = t; k2 < T; k2 += DF_NT) if (dst_load_u(&claims[k2]) != tag) atomicMin(&s_open, k2 >= first ? k2 - first : k2 + T - first);
                 df_barrier();
-                const int open = s_open;
+                const int rot = s_open;
                 df_barrier();
-                if (open >= T) break;
+                if (rot >= T) break;
+                const int open = rot + first < T ? rot + first : rot + first - T;
                 if (t == 0) s_open = T;
                 int4 ha, hb;
                 unsigned int scratch[16];
                 load_tile(open, ha, hb);
                 claim(open);
+                if (t == 0) atomicAdd(&state[DST_HELPED], 1u);
                 in_tile(open, ha, hb, scratch, false);
                 df_barrier();
             }
@@ -1689,6 +1698,7 @@ static int dist_set_distances_batch(int n, bl_dist* const* ds, const bl_grid* co
             const int fused_wgs = 8 * ((per_xcd + per_wg - 1) / per_wg);
             dist_fused_batch fb;
             memset((void*)&fb, 0, sizeof(fb));
+            if (const char* e = getenv("BOTLAB_DIST_FUSED_TEST_DELAY")) fb.test_delay = (unsigned int)atoi(e);
             for (int u = 0; u < n; ++u) {
                 bl_dist* d = ds[u];
 #ifdef DF_STAMPS
@@ -1807,6 +1817,19 @@ extern "C" int bl_dist_debug_stats(bl_dist* d, int64_t* out6)
         BL_HIP(hipMemcpyAsync(st, d->state + DST_STATS, sizeof(st), hipMemcpyDeviceToHost, d->ctx->stream));
         BL_HIP(hipStreamSynchronize(d->ctx->stream));
         out6[3] = st[0]; out6[4] = st[1]; out6[5] = st[2];
+    }
+    return BL_OK;
+}
+
+extern "C" int bl_dist_debug_fused(bl_dist* d, int64_t* out2)
+{
+    BL_CHECK_ARG(d != nullptr && out2 != nullptr);
+    out2[0] = out2[1] = 0;
+    if (d->state) {
+        unsigned int st[2];
+        BL_HIP(hipMemcpyAsync(st, d->state + DST_FAILED, sizeof(st), hipMemcpyDeviceToHost, d->ctx->stream));
+        BL_HIP(hipStreamSynchronize(d->ctx->stream));
+        out2[0] = st[0]; out2[1] = st[1];
     }
     return BL_OK;
 }

@@ -376,6 +376,12 @@ class ObstacleDistanceGrid:
         check(self.ctx.lib.bl_dist_debug_bound(self.h, C.byref(f), C.byref(b)))
         return bool(f.value), int(b.value)
 
+    def fusedStats(self):
+        """(gave_up, helped) of the one-launch whole-grid transform (bl_dist_debug_fused)."""
+        v = (C.c_int64 * 2)()
+        check(self.ctx.lib.bl_dist_debug_fused(self.h, v))
+        return int(v[0]), int(v[1])
+
     def shape(self):
         w, h = C.c_int(), C.c_int()
         check(self.ctx.lib.bl_dist_shape(self.h, C.byref(w), C.byref(h)))

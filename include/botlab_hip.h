@@ -204,6 +204,11 @@ int bl_dist_debug_stats(bl_dist* d, int64_t* out6);
  * dilates its window by, and whether it has been formed (the whole-grid kernels leave none; the first incremental transform
  * after one forms it) */
 int bl_dist_debug_bound(bl_dist* d, int* formed, unsigned int* bound);
+/* diagnostic, the one-launch whole-grid transform (grids of 512 x 512 .. 4096 x 4096 cells, width a multiple of 16): workgroups
+ * that gave up waiting for another tile's summary (never, unless the device is broken: the next bl_dist_set_distances then
+ * returns BL_ERR_STATE), and tile summaries a workgroup computed in place of one that had not started yet.
+ * BOTLAB_DIST_FUSED_TEST_DELAY=<n> holds every second workgroup back at its start (tests of that path). */
+int bl_dist_debug_fused(bl_dist* d, int64_t* out2);
 int bl_dist_download(bl_dist* d, float* cells);                           /* width*height floats (synchronises) */
 int bl_dist_shape(const bl_dist* d, int* width, int* height);
 int bl_dist_frame(const bl_dist* d, float* meters_per_cell, float* cells_per_meter, float* origin_x, float* origin_y);

@@ -78,3 +78,51 @@ def test_fused_then_incremental_window(oracle, gpu_ctx):
     exp = oracle.set_distances(cells, 0.05, 20.0, (-25.6, -25.6))
     assert np.array_equal(d.cells().view(np.uint32), exp.view(np.uint32))
     d.close(); g.close()
+
+
+@pytest.mark.parametrize("shape", [(2000, 2000), (2304, 2048)])
+def test_fused_with_late_workgroups(oracle, gpu_ctx, shape):
+    # every second workgroup is held back ~100 us at its start: the others find its tiles unclaimed and compute their summaries
+    # themselves instead of waiting for a workgroup that, for all they know, is not resident -- same distances, and the path ran
+    h, w = shape
+    rng = np.random.default_rng(77)
+    cells = np.where(rng.random((h, w)) < 0.003, 50, -7).astype(np.int8)
+    cells[h - 1, 0] = 0
+    g = bl.OccupancyGrid.from_cells(cells, (-3.0, -7.0), 0.05, ctx=gpu_ctx)
+    d = bl.ObstacleDistanceGrid(ctx=gpu_ctx)
+    os.environ["BOTLAB_DIST_FUSED_TEST_DELAY"] = "60"
+    try:
+        d.setDistances(g)
+        got = d.cells().copy()
+    finally:
+        del os.environ["BOTLAB_DIST_FUSED_TEST_DELAY"]
+    gave_up, helped = d.fusedStats()
+    exp = oracle.set_distances(cells, 0.05, 20.0, (-3.0, -7.0))
+    assert np.array_equal(got.view(np.uint32), exp.view(np.uint32))
+    assert gave_up == 0 and helped > 0, (gave_up, helped)
+    d.forget(); d.setDistances(g)                                  # and undisturbed again: nobody helps
+    assert np.array_equal(d.cells().view(np.uint32), exp.view(np.uint32))
+    assert d.fusedStats() == (0, helped)
+    d.close(); g.close()
+
+
+def test_fused_transforms_on_four_streams_at_once(oracle):
+    # four contexts (streams), each transforming its own 2000 x 2000 grid eight times over, all enqueued before anything is
+    # awaited: more workgroups than the device holds at once, every launch waiting only for its own tiles
+    h = w = 2000
+    ctxs = [bl.Context() for _ in range(4)]
+    grids, dists, exps = [], [], []
+    for k, c in enumerate(ctxs):
+        rng = np.random.default_rng(100 + k)
+        cells = np.where(rng.random((h, w)) < 0.001 * (k + 1), 50, -7).astype(np.int8)
+        grids.append(bl.OccupancyGrid.from_cells(cells, (0.0, 0.0), 0.05, ctx=c))
+        dists.append(bl.ObstacleDistanceGrid(ctx=c))
+        exps.append(oracle.set_distances(cells, 0.05, 20.0, (0.0, 0.0)))
+    for _ in range(8):
+        for g, d in zip(grids, dists):
+            d.forget(); d.setDistances(g)
+    for d, e in zip(dists, exps):
+        assert np.array_equal(d.cells().view(np.uint32), e.view(np.uint32))
+        assert d.fusedStats()[0] == 0
+    for g, d, c in zip(grids, dists, ctxs):
+        d.close(); g.close(); c.close()
