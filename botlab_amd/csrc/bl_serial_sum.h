@@ -206,6 +206,26 @@ SS_HD ss_wild ssw_join(const ss_wild& A, const ss_wild& B)
     return w;
 }
 
+// An in-binade record as a wild map: m' = m +- D on exactly the inputs ss_rec_fits accepts (the record's key must be a plain
+// binade key: not 0, not SS_ID).  With it a whole batch of sub-tiles -- plain records and wild maps alike -- composes into ONE
+// map (ssw_join is associative), and the true accumulator lies in the composite's interval exactly when it would have fitted
+// every record of the batch one after the other.  Checked by the CPU model (composed_scheme); the kernels do NOT use it yet:
+// one wave scanning 64 of the 48-byte maps takes 6.5 us, and every sub-tile that has to be stepped costs another scan -- 233
+// against 196 us at 100 000 particles around the origin.  It needs the finisher's idle waves to compose
+// batches side by side and a tree per batch to restart from.
+SS_HD ss_wild ssw_from_rec(const ss_rec& r)
+{
+    ss_wild w = ssw_invalid();
+    if (r.key == 0 || r.key == SS_ID) return w;
+    const long long mlo = (long long)SS_MLO + 1 - (long long)r.lo, mhi = (long long)SS_MHI - 1 - (long long)r.hi;      // magnitudes that stay inside
+    if (mlo > mhi) return w;
+    const bool neg = (r.key & 0x200) != 0;
+    w.key_in = w.key_out = r.key;
+    w.c = neg ? -(long long)r.D : (long long)r.D;
+    w.L = neg ? -mhi : mlo; w.H = neg ? -mlo : mhi;
+    return w;
+}
+
 // ---------------------------------------------------------------------------------------------------------------------------
 // The same for a DOUBLE accumulator stepped by doubles, c <- fl64(c + w): resamplePosteriorDistribution's cumulative weight
 // (src/slam/particle_filter.cpp:94-99).  One rounding per step (no float stage), 53-bit magnitudes in 64-bit integers.

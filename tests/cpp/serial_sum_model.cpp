@@ -161,6 +161,65 @@ static float wild_scheme(const std::vector<double>& t, int predict_mode, int joi
     return acc;
 }
 
+// ---- batches composed: per sub-tile either the in-binade record as a map (ssw_from_rec) or, where the double prediction sees
+// the sub-tile leave its binade, its wild map; 64 of them joined into one map (the way a wave's inclusive scan joins them: lane l
+// holds the join of maps first..l), the longest prefix that fits the true accumulator applied at once, the sub-tile behind it
+// stepped, and on from there -- mclf_walk's loop
+struct ComposedStats { long batches = 0, scans = 0, jumped = 0, stepped = 0; };
+static float composed_scheme(const std::vector<double>& t, int predict_mode, std::mt19937_64& rng, ComposedStats& cs)
+{
+    const int n = (int)t.size();
+    const int nsub = (n + SUB - 1) / SUB;
+    // stage A: one map per sub-tile from a double-precision prediction of its start value
+    std::vector<ss_wild> maps(nsub);
+    double P = 0.0;
+    for (int s = 0; s < nsub; ++s) {
+        const int base = s * SUB, m = std::min(SUB, n - base);
+        double drift = 0.0;
+        if (predict_mode == 1) drift = P * 1e-6 * ((double)(rng() % 2001) - 1000.0) / 1000.0;
+        if (predict_mode == 2) drift = ldexp(1.0, (int)(rng() % 30) - 40);
+        double Q = P + drift;
+        const int key0 = ss_key((float)Q);
+        bool leaves = false;
+        std::vector<ss_wild> steps(m);
+        int kprev = key0;
+        for (int i = 0; i < m; ++i) { Q += t[base + i]; const int k = ss_key((float)Q); steps[i] = ssw_step(kprev, k, t[base + i]); if (k != key0) leaves = true; kprev = k; }
+        if (!leaves && key0) maps[s] = ssw_from_rec(make_record(t, s, P + drift));
+        else { ss_wild rec = steps[0]; for (int i = 1; i < m; ++i) rec = ssw_join(rec, steps[i]); maps[s] = rec; }
+        for (int i = 0; i < m; ++i) P += t[base + i];
+    }
+    // the chain
+    float acc = 0.0f;
+    for (int b0 = 0; b0 < nsub; b0 += LANES) {
+        const int nb = std::min(LANES, nsub - b0);
+        cs.batches++;
+        int pos = 0;
+        while (pos < nb) {
+            cs.scans++;
+            std::vector<ss_wild> pre(nb);
+            for (int l = pos; l < nb; ++l) pre[l] = l == pos ? maps[b0 + l] : ssw_join(pre[l - 1], maps[b0 + l]);
+            const int key = ss_key(acc);
+            const long long ms = key ? ssw_signed(key, ss_mag(acc)) : 0;
+            int p = 0;
+            while (pos + p < nb && key && ssw_fits(pre[pos + p], key, ms)) ++p;
+            if (p > 0) {
+                const ss_wild& w = pre[pos + p - 1];
+                const long long mo = ssw_apply(w, ms);
+                acc = ss_from(w.key_out, (int)(mo < 0 ? -mo : mo));
+                cs.jumped += p;
+                pos += p;
+            }
+            if (pos < nb) {
+                const int base = (b0 + pos) * SUB, m = std::min(SUB, n - base);
+                for (int i = 0; i < m; ++i) acc = ss_exact_step(acc, t[base + i]);
+                cs.stepped++;
+                pos += 1;
+            }
+        }
+    }
+    return acc;
+}
+
 // ---- the double accumulator (resampling cumulative): every prefix value, by the phase loop alone
 static long check_double_scheme(std::mt19937_64& rng, long* cases)
 {
@@ -263,6 +322,7 @@ int main(int argc, char** argv)
     for (int round = 0; round < rounds; ++round) failures += check_double_scheme(rng, &cases);
     // wild runs: sums that hover around zero (the reference's default start pose), and the adversarial kinds again
     WildStats ws, ws_zero;
+    ComposedStats cs, cs_zero;
     for (int round = 0; round < rounds; ++round) {
         for (int kind = 0; kind < 12; ++kind) {
             int n = 1 + (int)(rng() % (round % 5 == 0 ? 200000 : 6000));
@@ -280,6 +340,14 @@ int main(int argc, char** argv)
                 }
             }
             const float want = plain_loop(t);
+            for (int mode = 0; mode < 3; ++mode) {
+                const float got = composed_scheme(t, mode, rng, kind < 8 && mode == 0 ? cs_zero : cs);
+                cases++;
+                if (ss_f2u(got) != ss_f2u(want) && !(got != got && want != want)) {
+                    if (failures < 10) fprintf(stderr, "COMPOSED MISMATCH kind %d n %d mode %d: got %.9g want %.9g\n", kind, n, mode, got, want);
+                    failures++;
+                }
+            }
             for (int mode = 0; mode < 3; ++mode)
                 for (int order = 0; order < 2; ++order) {
                     WildStats& tgt = (kind < 8 && mode == 0) ? ws_zero : ws;
@@ -293,8 +361,8 @@ int main(int argc, char** argv)
         }
     }
     printf("cases %ld failures %ld records %ld fitted %ld replays %ld phases %ld exact_steps %ld batches %ld wild_subtiles %ld wild_built %ld wild_applied %ld "
-           "zero_subtiles %ld zero_applied %ld\n", cases, failures, st.records,
+           "zero_subtiles %ld zero_applied %ld composed_batches %ld composed_scans %ld composed_jumped %ld composed_stepped %ld zero_batches %ld zero_scans %ld zero_jumped %ld zero_stepped %ld\n", cases, failures, st.records,
            st.fitted, st.replays, st.phases, st.exact_steps, st.batches, ws.subtiles + ws_zero.subtiles, ws.built + ws_zero.built, ws.applied + ws_zero.applied,
-           ws_zero.subtiles, ws_zero.applied);
+           ws_zero.subtiles, ws_zero.applied, cs.batches, cs.scans, cs.jumped, cs.stepped, cs_zero.batches, cs_zero.scans, cs_zero.jumped, cs_zero.stepped);
     return failures ? 1 : 0;
 }
