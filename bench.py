@@ -380,6 +380,17 @@ def streaming_kernels(ctx, grid, planner, aplanner, pose_dev, goal_pose, W, H):
             aplanner.fetch()
     torch.cuda.synchronize()
     ctx.timing_enable(False)
+    # the whole-grid transform again, 60 times back to back without events (an event pair around a launch adds ~3 us to a 11 us
+    # kernel): wall time per transform between two synchronisations -- an upper bound of the kernel's duration that still holds
+    # the gaps between launches (rocprofv3's kernel trace: profiles/r04_dist_fused.csv)
+    for _ in range(5):
+        planner.distances_.forget(); planner.setMap(grid)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(60):
+        planner.distances_.forget(); planner.setMap(grid)
+    torch.cuda.synchronize()
+    dist_b2b_ms = (time.perf_counter() - t0) / 60.0 * 1e3
     cells = float(W) * H
     wide = W >= 1024 and W % 16 == 0
     tall = H >= 512 and W >= 256 and W % 2 == 0
@@ -397,8 +408,11 @@ def streaming_kernels(ctx, grid, planner, aplanner, pose_dev, goal_pose, W, H):
             gbs = nbytes / (ms / n * 1e-3) / 1e9
             out[name] = {"bytes_per_launch": nbytes, "avg_launch_ms": round(ms / n, 5), "launches": int(n), "achieved_GBps": round(gbs, 1),
                          "frac_of_hbm_peak": round(gbs / HBM_PEAK_GBS, 4)}
-            if name == "k_dist_fused":                     # the same duration priced at the 9 B/cell the four-launch form moves
-                out[name]["at_four_launch_bytes_GBps"] = round(9.0 * cells / (ms / n * 1e-3) / 1e9, 1)
+            if name == "k_dist_fused":
+                out[name]["back_to_back_ms_per_transform"] = round(dist_b2b_ms, 5)
+                out[name]["achieved_GBps_back_to_back"] = round(nbytes / (dist_b2b_ms * 1e-3) / 1e9, 1)
+                # the same time priced at the 9 B/cell the four-launch form moves (what round 3's review asked for: >= 2 800)
+                out[name]["at_four_launch_bytes_GBps"] = round(9.0 * cells / (dist_b2b_ms * 1e-3) / 1e9, 1)
     return out
 
 
