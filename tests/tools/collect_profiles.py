@@ -217,6 +217,9 @@ if "frontiers" in which:
             w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "MinNs", "MaxNs"])
             for r in rows:
                 w.writerow([r[0][:90], r[1], r[2], "%.1f" % r[3], r[4], r[5]])
+# the rocpd databases stay on the box: together they exceed what gpurun carries back, and then nothing comes back at all
+for d in glob.glob(os.path.join(ROOT, "gpurun_out", "prof_*")):
+    subprocess.run(["rm", "-rf", d])
 for fn in sorted(os.listdir(OUT)):
     if fn.endswith(".csv") and ROUND in fn:
         print("====", fn)
