@@ -1375,6 +1375,7 @@ static int pf_finish_fill(bl_pf* pf, mcl_finish_args* f)
     }
     f->sh = nullptr;
     f->wild = pf->sh_world > 1 ? nullptr : pf->fin_wild;      // (a composed finish keeps to records, tables and replays)
+    f->no_trees = getenv("BOTLAB_MCL_NO_TREES") != nullptr ? 1 : 0;
     f->recs = pf->fin_recs;
     f->tabs = pf->fin_tabs;
     f->sync = pf->fin_sync;

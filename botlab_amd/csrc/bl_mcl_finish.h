@@ -85,6 +85,7 @@ struct mcl_finish_args {
                                            // tag) until its group has stored this launch's (mclf_store_rec, mclf_decode_rec)
     const mclf_shards* sh;                 // device memory; null: one rank (a table in the argument block itself would be indexed
                                            // per lane, which moves a by-value argument into scratch for every thread of the kernel)
+    int no_trees;                          // BOTLAB_MCL_NO_TREES: an overflowed list is walked by the chain's wave alone (tests, A/B)
 };
 
 #define MCLF_POSE_THREADS 256                 // the theta sums' addition order is that of a 256-thread workgroup, whoever runs it
@@ -647,7 +648,9 @@ __device__ __forceinline__ double mclf_readlane_f64(double v, int lane)
 // A sub-tile of n terms (lane l holds terms 2l, 2l+1) replayed from term `pos` on with the true accumulator by one wave (all 64
 // lanes call it; acc is wave-uniform): in-binade integer prefix sums up to the first step that leaves the binade, ties or is
 // too large, that step in real arithmetic, and on (bl_serial_sum.h).  Terms before `head` are simply stepped.
-__device__ __forceinline__ float mclf_replay(const double (&t)[MCLF_ITEMS], int n, int pos, int head, float acc, int lane, unsigned int* phases)
+// lds_terms: MCLF_SUB doubles of LDS this wave may use, or null
+__device__ __forceinline__ float mclf_replay(const double (&t)[MCLF_ITEMS], int n, int pos, int head, float acc, int lane, unsigned int* phases,
+                                             double* lds_terms = nullptr)
 {
     static_assert(MCLF_ITEMS == 2, "the replay indexes two terms per lane");
     n = __builtin_amdgcn_readfirstlane(n); pos = __builtin_amdgcn_readfirstlane(pos); head = __builtin_amdgcn_readfirstlane(head);
@@ -655,8 +658,18 @@ __device__ __forceinline__ float mclf_replay(const double (&t)[MCLF_ITEMS], int 
         // the first terms of a sum: the accumulator changes its binade every few terms, so they are stepped one by one (the
         // term reads do not depend on the accumulator; the loop carries three dependent operations per term)
         const int h = min(head, n);
+        if (lds_terms) {
+            // through LDS: the reads run ahead of the chain of roundings (30 cycles a term); fetched from the lanes' registers by
+            // readlane with a computed lane, a term took 195 cycles -- 10.9 us for a sub-tile, of which a sum hovering around zero
+            // has a dozen (100 000 particles) to a hundred (1 000 000)
+            *(double2*)&lds_terms[2 * lane] = make_double2(t[0], t[1]);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll 8
-        for (int i = pos; i < h; ++i) acc = ss_exact_step(acc, mclf_readlane_f64((i & 1) ? t[1] : t[0], i >> 1));
+            for (int i = pos; i < h; ++i) acc = ss_exact_step(acc, ((volatile double*)lds_terms)[i]);
+        } else {
+#pragma unroll 8
+            for (int i = pos; i < h; ++i) acc = ss_exact_step(acc, mclf_readlane_f64((i & 1) ? t[1] : t[0], i >> 1));
+        }
         pos = h;
     }
     int budget = 4;                                                   // phases before the rest is simply stepped: a sub-tile that leaves
@@ -987,14 +1000,182 @@ __device__ __forceinline__ float mclf_walk(const mcl_finish_args& f, int axis, d
     return acc;
 }
 
+// ---- the walk with composition trees ---------------------------------------------------------------------------------------
+// A sum that hovers around zero hands the chain a few hundred sub-tiles that do not go by a record (mclf_walk).  One wave taking
+// them one after the other -- a gap, a map, a gap, a map: 0.6 us each -- was 170 of the estimate's 200 us at 100 000 particles
+// around the origin.  But every record is a map of the signed magnitude (a plain record m -> m +- D on the inputs it fits,
+// ssw_from_rec; a wild sub-tile its wild map), maps compose (ssw_join), and the true accumulator fits a composite exactly when it
+// fits every part in turn.  So while the chain's wave walks, the finisher's other waves -- idle until now -- compose: each takes
+// a batch of 64 records, joins them pairwise up a binary tree (127 nodes: node (k, j) = records j 2^k .. (j + 1) 2^k - 1 of the
+// batch) and leaves the tree in LDS; the chain takes a whole batch with ONE check of its root, and where the root does not fit
+// (13 of 773 sub-tiles at 100k, 92 of 7 800 at 1M: the sum passing through zero, where no prediction of its binades holds) walks
+// down to the record that does not, steps it, and climbs again -- a dozen checks instead of a scan.  A wrong map costs time,
+// never correctness: nothing is applied without its check.
+#define MCLF_TREE_NODES 128                    // 127 in use: level k at [128 - (128 >> k), ...)
+#define MCLF_TREE_RING 6                       // trees in flight per axis (they live in the axis' table area: 20 tables = 40 KB)
+#define MCLF_WILD_ID 0x7ffffff0                // key_in of a node that composes as the identity (no record below it)
+struct mclf_trees { ss_wild* nodes; volatile int* ready; volatile int* consumed; volatile int* abort; };
+__device__ __forceinline__ mclf_trees mclf_trees_at(const mclf_stage& st)
+{
+    mclf_trees t;
+    t.nodes = (ss_wild*)st.tab;
+    int* w = (int*)((char*)st.tab + (size_t)MCLF_TREE_RING * MCLF_TREE_NODES * sizeof(ss_wild));
+    t.ready = w; t.consumed = w + MCLF_TREE_RING; t.abort = w + MCLF_TREE_RING + 1;
+    return t;
+}
+static_assert((size_t)MCLF_TREE_RING * MCLF_TREE_NODES * sizeof(ss_wild) + (MCLF_TREE_RING + 2) * sizeof(int) <= (size_t)MCLF_TSLOTS * MCLF_SUB * sizeof(mclf_tab_elem),
+              "the trees live in the table area of their axis");
+__device__ __forceinline__ int mclf_tree_off(int k) { return MCLF_TREE_NODES - (MCLF_TREE_NODES >> k); }
+
+__device__ __forceinline__ long long mclf_shfl_down_i64(long long v, int off)
+{
+    const int lo = __shfl_down((int)(unsigned int)(unsigned long long)v, off, 64), hi = __shfl_down((int)(unsigned int)((unsigned long long)v >> 32), off, 64);
+    return (long long)(((unsigned long long)(unsigned int)hi << 32) | (unsigned long long)(unsigned int)lo);
+}
+__device__ __forceinline__ ss_wild mclf_shfl_down_wild(const ss_wild& w, int off)
+{
+    ss_wild o;
+    o.key_in = __shfl_down(w.key_in, off, 64); o.key_out = __shfl_down(w.key_out, off, 64); o.q = __shfl_down(w.q, off, 64); o.r = __shfl_down(w.r, off, 64);
+    o.a = mclf_shfl_down_i64(w.a, off); o.c = mclf_shfl_down_i64(w.c, off); o.L = mclf_shfl_down_i64(w.L, off); o.H = mclf_shfl_down_i64(w.H, off);
+    return o;
+}
+
+// record r0 + lane of an axis and its wild map (lanes >= nb: the empty record), as four 16-byte loads through the L2 waited for once
+__device__ __forceinline__ void mclf_load_rec_and_map(const mcl_finish_args& f, int axis, int r0, int nb, int lane, ss_rec* r, ss_wild* w)
+{
+    const int nsub = f.groups * (f.gthreads >> 6);
+    *r = ss_rec_identity();
+    *w = ssw_invalid();
+    if (lane < nb) {
+        const ss_rec* rp = mclf_rec_ptr(f, axis, r0 + lane);
+        const ss_wild* wp = f.wild + (size_t)axis * nsub + r0 + lane;
+        int4 q0, q1, q2, q3;
+        asm volatile("global_load_dwordx4 %0, %4, off sc1\n\tglobal_load_dwordx4 %1, %5, off sc1\n\t"
+                     "global_load_dwordx4 %2, %5, off offset:16 sc1\n\tglobal_load_dwordx4 %3, %5, off offset:32 sc1\n\ts_waitcnt vmcnt(0)"
+                     : "=&v"(q0), "=&v"(q1), "=&v"(q2), "=&v"(q3) : "v"(rp), "v"(wp) : "memory");
+        bool current;
+        *r = mclf_decode_rec(q0, 0u, &current);
+        w->key_in = q1.x; w->key_out = q1.y; w->q = q1.z; w->r = q1.w;
+        w->a = (long long)(((unsigned long long)(unsigned int)q2.y << 32) | (unsigned int)q2.x); w->c = (long long)(((unsigned long long)(unsigned int)q2.w << 32) | (unsigned int)q2.z);
+        w->L = (long long)(((unsigned long long)(unsigned int)q3.y << 32) | (unsigned int)q3.x); w->H = (long long)(((unsigned long long)(unsigned int)q3.w << 32) | (unsigned int)q3.z);
+    }
+}
+
+// A helper wave (index hidx of nh) of an axis: the trees of the walk's batches hidx, hidx + nh, ... (records [ra, rb) in batches of
+// 64 from ra on), each into ring slot batch % MCLF_TREE_RING once the chain is through with the batch that had it.
+__device__ __forceinline__ void mclf_tree_helper(const mcl_finish_args& f, const mclf_trees& tr, int axis, int ra, int rb, int hidx, int nh, int lane)
+{
+    const int nbat = (rb - ra + 63) >> 6;
+    for (int bi = hidx; bi < nbat; bi += nh) {
+        unsigned int spins = 0;
+        while (*tr.consumed < bi - MCLF_TREE_RING + 1 && *tr.abort == 0) {
+            if (++spins > MCLF_SPIN_LIMIT) return;
+            __builtin_amdgcn_s_sleep(2);
+        }
+        if (*tr.abort != 0) return;
+        const int r0 = ra + 64 * bi, nb = min(64, rb - r0);
+        ss_rec r;
+        ss_wild w;
+        mclf_load_rec_and_map(f, axis, r0, nb, lane, &r, &w);
+        const bool risky = r.key != SS_ID && (r.key & MCLF_RISKY) != 0;
+        const bool wild = risky && (r.key & MCLF_WILD) != 0;
+        ss_rec pr = r;
+        pr.key = mclf_plain_key(r.key);
+        ss_wild cur = ssw_invalid();
+        bool cur_id = lane >= nb || r.key == SS_ID;
+        if (!cur_id) cur = risky ? (wild ? w : ssw_invalid()) : ssw_from_rec(pr);
+        ss_wild* slot = tr.nodes + (size_t)(bi % MCLF_TREE_RING) * MCLF_TREE_NODES;
+        { ss_wild out = cur; if (cur_id) out.key_in = MCLF_WILD_ID; slot[lane] = out; }
+#pragma unroll
+        for (int k = 1; k <= 6; ++k) {
+            const int h = 1 << (k - 1);
+            const ss_wild o = mclf_shfl_down_wild(cur, h);
+            const bool o_id = __shfl_down((int)cur_id, h, 64) != 0;
+            if ((lane & ((1 << k) - 1)) == 0) {
+                if (!o_id) {
+                    if (cur_id) { cur = o; cur_id = false; }
+                    else cur = ssw_join(cur, o);
+                }
+                ss_wild out = cur;
+                if (cur_id) out.key_in = MCLF_WILD_ID;
+                slot[mclf_tree_off(k) + (lane >> k)] = out;
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           // the tree stands in LDS before its flag does
+        if (lane == 0) tr.ready[bi % MCLF_TREE_RING] = bi + 1;
+    }
+}
+
+// mclf_walk's job by the trees the helper waves leave (records [ra, rb), the chain's wave, acc wave-uniform)
+__device__ __forceinline__ float mclf_walk_trees(const mcl_finish_args& f, const mclf_trees& tr, int axis, double S, int ra, int rb, float acc, int lane,
+                                                 unsigned int* replays, unsigned int* phases, double* lds_terms)
+{
+    const int nbat = (rb - ra + 63) >> 6;
+    for (int bi = 0; bi < nbat; ++bi) {
+        const int r0 = ra + 64 * bi, nb = min(64, rb - r0);
+        unsigned int spins = 0;
+        while (tr.ready[bi % MCLF_TREE_RING] != bi + 1) {
+            if (++spins > MCLF_SPIN_LIMIT) {                        // (never, unless a helper died: the rest the old way)
+                if (lane == 0) { *tr.abort = 1; atomicAdd(&f.state->wait_timeouts, 1u); }
+                return mclf_walk(f, axis, S, r0, rb, acc, lane, replays, phases);
+            }
+            __builtin_amdgcn_s_sleep(1);
+        }
+        const ss_wild* slot = tr.nodes + (size_t)(bi % MCLF_TREE_RING) * MCLF_TREE_NODES;
+        int key = __builtin_amdgcn_readfirstlane(ss_key(acc));
+        int M = __builtin_amdgcn_readfirstlane(ss_mag(acc));
+        int pos = 0;
+        while (pos < nb) {
+            int k = pos ? min(__ffs(pos) - 1, 6) : 6;
+            while (true) {
+                // (a wave-uniform LDS read: every lane holds the node, the decisions are taken once for the wave)
+                const ss_wild wn = slot[mclf_tree_off(k) + (pos >> k)];
+                if (__builtin_amdgcn_readfirstlane(wn.key_in) == MCLF_WILD_ID) { pos += 1 << k; break; }
+                const long long m = ssw_signed(key, M);
+                if (__builtin_amdgcn_readfirstlane((int)(key != 0 && ssw_fits(wn, key, m))) != 0) {
+                    const long long mo = ssw_apply(wn, m);
+                    key = __builtin_amdgcn_readfirstlane(wn.key_out); M = __builtin_amdgcn_readfirstlane((int)(mo < 0 ? -mo : mo));
+                    pos += 1 << k;
+                    break;
+                }
+                if (k == 0) {
+                    // the record itself does not go by its map: stepped from the particle records
+                    const int s = r0 + pos;
+                    int lo, hi;
+                    mclf_sub_range(f, s, &lo, &hi);
+                    if (lo < hi) {
+                        double t[MCLF_ITEMS];
+                        mclf_load_terms(f, axis, S, lo, hi, lane, t);
+                        // (a wild sub-tile whose map does not fit crosses binades every few terms: its 128 terms one by one, 2.5 us,
+                        // beat a phase per crossing; a plain one: the in-binade phases)
+                        const bool was_wild = __builtin_amdgcn_readfirstlane((int)(wn.key_in != wn.key_out || wn.q != 0 || wn.r != 0 || wn.key_in == 0)) != 0;
+                        if (key != 0) acc = ss_from_bits(key, M);
+                        acc = mclf_replay(t, hi - lo, 0, was_wild ? hi - lo : 0, acc, lane, phases, lds_terms);
+                        key = __builtin_amdgcn_readfirstlane(ss_key(acc)); M = __builtin_amdgcn_readfirstlane(ss_mag(acc));
+                        *replays += 1;
+                    }
+                    pos += 1;
+                    break;
+                }
+                k -= 1;
+            }
+        }
+        if (key != 0) acc = ss_from_bits(key, M);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (lane == 0) *tr.consumed = bi + 1;
+    }
+    return acc;
+}
+
 // One axis' float accumulator over all particles, by one wave (all 64 lanes; the result is wave-uniform).
 // `first`: the accumulator behind the first MCLF_PRE_SUBS sub-tiles (mclf_pose).
 __device__ __forceinline__ float mclf_chain(const mcl_finish_args& f, const mclf_stage* st, int ntab, int axis, double S, float first, int lane,
-                                            unsigned int* stats)
+                                            unsigned int* stats, bool trees = false, double* lds_terms = nullptr)
 {
     const int nrec = f.groups * (f.gthreads >> 6);
     // (a list that overflowed is no list: the gaps between listed entries would skip the unlisted risky records)
     const int done = min(MCLF_PRE_SUBS, nrec);
+    if (st && trees) { const mclf_trees tr = mclf_trees_at(*st); return mclf_walk_trees(f, tr, axis, S, done, nrec, first, lane, &stats[0], &stats[1], lds_terms); }
     if (!st || *st->nent > MCLF_MAXENT) return mclf_walk(f, axis, S, done, nrec, first, lane, &stats[0], &stats[1]);
     const int nent = __builtin_amdgcn_readfirstlane(*st->nent);
     float acc = first;                                           // the first sub-tiles are done (mclf_pose)
@@ -1040,7 +1221,7 @@ __device__ __forceinline__ float mclf_chain(const mcl_finish_args& f, const mclf
             } else {
                 double t[MCLF_ITEMS];
                 mclf_load_terms(f, axis, S, lo, lo + n, lane, t);
-                acc = mclf_replay(t, n, 0, sp.tslot <= -2 ? n : 0, acc, lane, &stats[1]);      // (a wild one that does not fit: stepped)
+                acc = mclf_replay(t, n, 0, sp.tslot <= -2 ? n : 0, acc, lane, &stats[1], lds_terms);      // (a wild one that does not fit: stepped)
                 stats[0] += 1;
             }
         }
@@ -1465,6 +1646,25 @@ __device__ __forceinline__ void mclf_pose(const mcl_finish_args& f, mclf_smem& s
         __syncthreads();
     }
     MCLF_STAMP(3);
+    // an axis whose list overflowed (the sum hovers around zero) is walked with composition trees: its table area holds them, the
+    // waves that would idle through the chains build them (mclf_tree_helper)
+    bool trees[2] = {false, false};
+    if (staged && f.wild != nullptr && f.sh == nullptr && f.no_trees == 0) {
+        for (int ax = 0; ax < 2; ++ax) trees[ax] = *MCLF_STAGE(ax).nent > MCLF_MAXENT && nrec > MCLF_PRE_SUBS;
+        if (tid < 2 && trees[tid]) {
+            const mclf_trees tr = mclf_trees_at(MCLF_STAGE(tid));
+            for (int q = 0; q < MCLF_TREE_RING; ++q) tr.ready[q] = 0;
+            *tr.consumed = 0; *tr.abort = 0;
+        }
+        if (trees[0] || trees[1]) __syncthreads();
+    }
+    if (wave >= 2 && (trees[0] || trees[1])) {
+        const bool both = trees[0] && trees[1];
+        const int ax = both ? (wave & 1) : (trees[0] ? 0 : 1);
+        const int hidx = both ? (wave - 2) >> 1 : wave - 2, nh = both ? (MCLF_MAXW - 2) / 2 : MCLF_MAXW - 2;
+        const mclf_stage hs = MCLF_STAGE(ax);
+        mclf_tree_helper(f, mclf_trees_at(hs), ax, min(MCLF_PRE_SUBS, nrec), nrec, hidx, nh, lane);
+    }
     if (wave < 2) {                                                                // wave 0: pose.x, wave 1: pose.y
         unsigned int stats[4] = {0, 0, 0, 0};
         // the sums behind the first sub-tiles, from the pre-chain workgroup (long done by now, as a rule)
@@ -1479,7 +1679,7 @@ __device__ __forceinline__ void mclf_pose(const mcl_finish_args& f, mclf_smem& s
 #endif
         const float first = __uint_as_float((unsigned int)fw);
         const mclf_stage mine = MCLF_STAGE(wave);
-        const float v = mclf_chain(f, staged ? &mine : nullptr, wave ? ntab[1] : ntab[0], wave, S, first, lane, stats);
+        const float v = mclf_chain(f, staged ? &mine : nullptr, wave ? ntab[1] : ntab[0], wave, S, first, lane, stats, trees[wave], &sm.pre[wave][0]);      // (sm.pre: the pre-chain workgroup's buffer, idle in this one)
         if (lane == 0) { sm.xy[wave] = v; for (int k = 0; k < 4; ++k) sm.stats[4 * wave + k] = stats[k]; }
     }
     __syncthreads();
