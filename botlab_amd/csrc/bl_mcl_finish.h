@@ -665,7 +665,7 @@ __device__ __forceinline__ float mclf_replay(const double (&t)[MCLF_ITEMS], int 
             *(double2*)&lds_terms[2 * lane] = make_double2(t[0], t[1]);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll 8
-            for (int i = pos; i < h; ++i) acc = ss_exact_step(acc, ((volatile double*)lds_terms)[i]);
+            for (int i = pos; i < h; ++i) acc = ss_exact_step(acc, lds_terms[i]);       // (plain reads behind the statement above: the compiler batches them ahead of the roundings)
         } else {
 #pragma unroll 8
             for (int i = pos; i < h; ++i) acc = ss_exact_step(acc, mclf_readlane_f64((i & 1) ? t[1] : t[0], i >> 1));
@@ -1126,38 +1126,44 @@ __device__ __forceinline__ float mclf_walk_trees(const mcl_finish_args& f, const
         int M = __builtin_amdgcn_readfirstlane(ss_mag(acc));
         int pos = 0;
         while (pos < nb) {
-            int k = pos ? min(__ffs(pos) - 1, 6) : 6;
-            while (true) {
-                // (a wave-uniform LDS read: every lane holds the node, the decisions are taken once for the wave)
-                const ss_wild wn = slot[mclf_tree_off(k) + (pos >> k)];
-                if (__builtin_amdgcn_readfirstlane(wn.key_in) == MCLF_WILD_ID) { pos += 1 << k; break; }
-                const long long m = ssw_signed(key, M);
-                if (__builtin_amdgcn_readfirstlane((int)(key != 0 && ssw_fits(wn, key, m))) != 0) {
+            // the nodes that start at record pos: (k, pos >> k) for k up to the number of trailing zeros of pos (the whole batch at
+            // pos = 0) -- lane k tests node k, all in one LDS round trip; the largest that fits carries the accumulator 2^k records on
+            const int kmax = pos ? min(__ffs(pos) - 1, 6) : 6;
+            const bool have = lane <= kmax;
+            ss_wild nd = ssw_invalid();
+            if (have) nd = slot[mclf_tree_off(lane) + (pos >> lane)];
+            const long long m = ssw_signed(key, M);
+            const bool okl = have && (nd.key_in == MCLF_WILD_ID || (key != 0 && ssw_fits(nd, key, m)));
+            const unsigned long long okm = __builtin_amdgcn_ballot_w64(okl);
+            if (okm) {
+                const int kb = 63 - __clzll((long long)okm);
+                const ss_wild wn = mclf_readlane_wild(nd, kb);
+                if (wn.key_in != MCLF_WILD_ID) {
                     const long long mo = ssw_apply(wn, m);
-                    key = __builtin_amdgcn_readfirstlane(wn.key_out); M = __builtin_amdgcn_readfirstlane((int)(mo < 0 ? -mo : mo));
-                    pos += 1 << k;
-                    break;
+                    key = wn.key_out; M = (int)(mo < 0 ? -mo : mo);
                 }
-                if (k == 0) {
-                    // the record itself does not go by its map: stepped from the particle records
-                    const int s = r0 + pos;
-                    int lo, hi;
-                    mclf_sub_range(f, s, &lo, &hi);
-                    if (lo < hi) {
-                        double t[MCLF_ITEMS];
-                        mclf_load_terms(f, axis, S, lo, hi, lane, t);
-                        // (a wild sub-tile whose map does not fit crosses binades every few terms: its 128 terms one by one, 2.5 us,
-                        // beat a phase per crossing; a plain one: the in-binade phases)
-                        const bool was_wild = __builtin_amdgcn_readfirstlane((int)(wn.key_in != wn.key_out || wn.q != 0 || wn.r != 0 || wn.key_in == 0)) != 0;
-                        if (key != 0) acc = ss_from_bits(key, M);
-                        acc = mclf_replay(t, hi - lo, 0, was_wild ? hi - lo : 0, acc, lane, phases, lds_terms);
-                        key = __builtin_amdgcn_readfirstlane(ss_key(acc)); M = __builtin_amdgcn_readfirstlane(ss_mag(acc));
-                        *replays += 1;
-                    }
-                    pos += 1;
-                    break;
+                pos += 1 << kb;
+                continue;
+            }
+            // the record itself does not go by its map: stepped from the particle records
+            {
+                const int lk_in = __builtin_amdgcn_readlane(nd.key_in, 0), lk_out = __builtin_amdgcn_readlane(nd.key_out, 0);
+                const int lq = __builtin_amdgcn_readlane(nd.q, 0), lr = __builtin_amdgcn_readlane(nd.r, 0);
+                const int s = r0 + pos;
+                int lo, hi;
+                mclf_sub_range(f, s, &lo, &hi);
+                if (lo < hi) {
+                    double t[MCLF_ITEMS];
+                    mclf_load_terms(f, axis, S, lo, hi, lane, t);
+                    // (a wild sub-tile whose map does not fit crosses binades every few terms: its 128 terms one by one beat a phase
+                    // per crossing; a plain one: the in-binade phases)
+                    const bool was_wild = lk_in != lk_out || lq != 0 || lr != 0 || lk_in == 0;
+                    if (key != 0) acc = ss_from_bits(key, M);
+                    acc = mclf_replay(t, hi - lo, 0, was_wild ? hi - lo : 0, acc, lane, phases, lds_terms);
+                    key = __builtin_amdgcn_readfirstlane(ss_key(acc)); M = __builtin_amdgcn_readfirstlane(ss_mag(acc));
+                    *replays += 1;
                 }
-                k -= 1;
+                pos += 1;
             }
         }
         if (key != 0) acc = ss_from_bits(key, M);

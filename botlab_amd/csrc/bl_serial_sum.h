@@ -209,10 +209,7 @@ SS_HD ss_wild ssw_join(const ss_wild& A, const ss_wild& B)
 // An in-binade record as a wild map: m' = m +- D on exactly the inputs ss_rec_fits accepts (the record's key must be a plain
 // binade key: not 0, not SS_ID).  With it a whole batch of sub-tiles -- plain records and wild maps alike -- composes into ONE
 // map (ssw_join is associative), and the true accumulator lies in the composite's interval exactly when it would have fitted
-// every record of the batch one after the other.  Checked by the CPU model (composed_scheme); the kernels do NOT use it yet:
-// one wave scanning 64 of the 48-byte maps takes 6.5 us, and every sub-tile that has to be stepped costs another scan -- 233
-// against 196 us at 100 000 particles around the origin.  It needs the finisher's idle waves to compose
-// batches side by side and a tree per batch to restart from.
+// every record of the batch one after the other (CPU model: composed_scheme; kernels: mclf_tree_helper / mclf_walk_trees).
 SS_HD ss_wild ssw_from_rec(const ss_rec& r)
 {
     ss_wild w = ssw_invalid();
