@@ -676,6 +676,13 @@ __device__ __forceinline__ float mclf_replay(const double (&t)[MCLF_ITEMS], int 
                                                                       // its binade again and again costs 0.7 us per phase, 2.5 us stepped
     while (pos < n) {
         const int key = __builtin_amdgcn_readfirstlane(ss_key(acc));
+        if (key && budget == 0 && lds_terms) {                        // the phases are spent: the rest term by term, through LDS
+            *(double2*)&lds_terms[2 * lane] = make_double2(t[0], t[1]);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll 8
+            for (int i = pos; i < n; ++i) acc = ss_exact_step(acc, lds_terms[i]);
+            break;
+        }
         if (!key || budget == 0) {                                    // no usable binade (zero, tiny, not finite): the step itself
             const double tj = mclf_readlane_f64((pos & 1) ? t[1] : t[0], pos >> 1);
             acc = ss_exact_step(acc, tj);
