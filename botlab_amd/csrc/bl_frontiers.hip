@@ -883,7 +883,7 @@ __global__ __launch_bounds__(FR_T) void k_frontier_grow(frontier_args a)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const long long t_begin = wall_clock64();
     const int T = a.counts[7];
-    if (T > FR_TOUCH_MAX) { if (tid == 0) a.counts[8] = 1; return; }
+    if (T > FR_TOUCH_MAX || a.W > 65535 || a.H > 32767) { if (tid == 0) a.counts[8] = 1; return; }      // (the ring packs x | y << 16)
     unsigned int tk[FR_TOUCH_PER_THREAD]; int tc[FR_TOUCH_PER_THREAD];
 #pragma unroll
     for (int j = 0; j < FR_TOUCH_PER_THREAD; ++j) {
@@ -912,21 +912,22 @@ __global__ __launch_bounds__(FR_T) void k_frontier_grow(frontier_args a)
             // ---- grow_frontier (:249-288) by one wave, serially in queue order; xDeltas {-1,-1,-1,1,1,1,0,0}, yDeltas {0,1,-1,0,1,-1,1,-1}
             const int seed = s_seed;
             int head = 0, tail = 1, fail = 0;
-            if (lane == 0) { fq[0] = seed; s_ring[0] = seed; }
+            // (the ring holds x | y << 16: a division by the grid's width per queue entry and lane is forty instructions of this lone wave)
+            if (lane == 0) { fq[0] = seed; s_ring[0] = (seed % a.W) | ((seed / a.W) << 16); }
             (void)fr_hash_test_and_set(s_hash, seed, lane);
             const int n = lane & 7, qi = lane >> 3;
             const int dx = n < 3 ? -1 : (n < 6 ? 1 : 0);
             const int dy = (n == 1 || n == 4 || n == 6) ? 1 : ((n == 2 || n == 5 || n == 7) ? -1 : 0);
             while (head < tail && !fail) {
                 const int nb = min(tail - head, 8);
-                int nc = -1;
+                int nc = -1, nxy = 0;
                 if (qi < nb) {
                     const int q = head + qi;
-                    int c;
-                    if (tail - q <= FR_RING) c = s_ring[q & (FR_RING - 1)];
-                    else c = __hip_atomic_load(&fq[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    const int x = c % a.W + dx, y = c / a.W + dy;
-                    if (x >= 0 && y >= 0 && x < a.W && y < a.H) nc = y * a.W + x;
+                    int cx, cy;
+                    if (tail - q <= FR_RING) { const int e = s_ring[q & (FR_RING - 1)]; cx = e & 0xFFFF; cy = e >> 16; }
+                    else { const int c = __hip_atomic_load(&fq[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); cx = c % a.W; cy = c / a.W; }
+                    const int x = cx + dx, y = cy + dy;
+                    if (x >= 0 && y >= 0 && x < a.W && y < a.H) { nc = y * a.W + x; nxy = x | (y << 16); }
                 }
                 const bool isf = nc >= 0 && a.cls[nc] == 2;                     // class 2 does not change while a frontier grows
                 unsigned long long m = __ballot(isf);
@@ -934,11 +935,11 @@ __global__ __launch_bounds__(FR_T) void k_frontier_grow(frontier_args a)
                 while (m) {
                     const int l = __ffsll((long long)m) - 1;                     // ascending lane = queue order, then neighbour order
                     m &= m - 1ull;
-                    const int x = __builtin_amdgcn_readlane(nc, l);
+                    const int x = __builtin_amdgcn_readlane(nc, l), xy = __builtin_amdgcn_readlane(nxy, l);
                     const int r = fr_hash_test_and_set(s_hash, x, lane);
                     if (r < 0 || tail >= FR_HASH / 2) { fail = 1; break; }
                     if (r == 0) {
-                        if (lane == 0) { __hip_atomic_store(&fq[tail], x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); s_ring[tail & (FR_RING - 1)] = x; }
+                        if (lane == 0) { __hip_atomic_store(&fq[tail], x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); s_ring[tail & (FR_RING - 1)] = xy; }
                         tail += 1;
                     }
                 }
