@@ -2049,11 +2049,15 @@ __device__ __forceinline__ void heap_sift_up(int2* g_heap, int hole, int2 value,
     int2 e = make_int2(0, 0);
     if (IN_LDS) e = lds_entry(v ? anc : 0);               // (unconditional: a clamped index costs less than a branch around the read)
     else if (v) e = heap_read<LDSN>(g_heap, anc);
-    const unsigned long long m = __ballot(v && (e.x > value.x));
+    // (the lanes' compare as a mask, ANDed with the mask of the lanes that hold an ancestor: ballot(a && b) makes hipcc put the
+    // flag into a register and compare it again -- a few more links in a chain that a lone wave walks at ~15 cycles a link)
+    const unsigned long long m = __builtin_amdgcn_sicmp(e.x, value.x, 38 /* signed > */) & (D >= 64 ? ~0ull : ((1ull << D) - 1ull));
     const int t = __ffsll((long long)~m) - 1;           // length of the leading run
     if (IN_LDS) {
-        if (lane < t) lds_entry_store(below, e);
-        if (lane == 0) lds_entry_store((int)(hp >> t) - 1, value);
+        // (no branches around the stores: lanes with nothing to write aim at the dummy entry behind the LDS levels -- a lone wave
+        // pays more for a skipped branch region than for a store)
+        lds_entry_store(lane < t ? below : LDSN, e);
+        lds_entry_store(lane == 0 ? (int)(hp >> t) - 1 : LDSN, value);
     } else {
         if (lane < t) heap_write<LDSN>(g_heap, below, e);
         if (lane == 0) heap_write<LDSN>(g_heap, (int)(hp >> t) - 1, value);
@@ -2093,14 +2097,13 @@ __device__ __forceinline__ void heap_adjust(int2* g_heap, int len, int2 value, i
             if (two) { fl = heap_read<LDSN>(g_heap, cl).x; fr = heap_read<LDSN>(g_heap, cl + 1).x; }
         }
         // right child preferred unless comp(right, left), i.e. right.fCost > left.fCost; a lone left child -> left
-        const unsigned long long M = __ballot(valid && two && !(fr > fl));
-        const bool on_path = valid && (((M ^ areq) & amask) == 0ull);
-        const unsigned long long P = __ballot(on_path);
+        const unsigned long long vmask = __builtin_amdgcn_ballot_w64(valid), tmask = __builtin_amdgcn_ballot_w64(two);
+        const unsigned long long M = __builtin_amdgcn_sicmp(fr, fl, 41 /* signed <= */) & vmask & tmask;
+        const unsigned long long P = __builtin_amdgcn_uicmpl((M ^ areq) & amask, 0ull, 32 /* == */) & vmask;
+        const bool on_path = ((P >> lane) & 1ull) != 0ull;
         const int cur = 63 - __clzll((long long)P);     // deepest on-path lane
-        if (on_path && lane > 0) {
-            if (IN_LDS) lds_entry_store((node - 1) >> 1, e);
-            else heap_write<LDSN>(g_heap, (node - 1) >> 1, e);
-        }
+        if (IN_LDS) lds_entry_store(on_path && lane > 0 ? (node - 1) >> 1 : LDSN, e);      // (unconditional: see heap_sift_up)
+        else if (on_path && lane > 0) heap_write<LDSN>(g_heap, (node - 1) >> 1, e);
         hole = __builtin_amdgcn_readlane(node, cur);
         if (!(cur >= 31 && 2 * hole + 1 < len)) break;
     }
@@ -2262,8 +2265,11 @@ __global__ __launch_bounds__(64) void k_astar(astar_args a)
         STAMP(t1);
         len -= 1;
         if (len > 0) {
-            if (len <= LDSN) {
-                const int2 value = heap_read<LDSN>(g_heap, len);
+            if (len < LDSN) {
+                // (the last entry straight from LDS: read through heap_read -- which may take it from HBM -- the value carries a wait
+                // for EVERY load in flight into the sift-up, the expansion's neighbour loads included: they then ran beside the
+                // walk only, not beside the whole pop)
+                const int2 value = lds_entry(len);
                 heap_adjust<true, LDSN>(g_heap, len, value, lane, lk, lj - 1, amask, areq);
             } else {
                 const int2 value = heap_read<LDSN>(g_heap, len);
