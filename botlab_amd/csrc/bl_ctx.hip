@@ -4,6 +4,8 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <chrono>
+
 #include "bl_internal.h"
 
 static thread_local char g_err[512] = "";
@@ -62,6 +64,24 @@ extern "C" int bl_ctx_create(int device, void* stream, bl_ctx** out)
         c->own_stream = true;
     }
     *out = c;
+    return BL_OK;
+}
+
+// A context whose own stream has the device's LOWEST priority: for work that may keep a hardware queue busy for seconds (a plan to
+// a frontier is one kernel of up to 10^6 pops).  Streams of one priority share the runtime's few hardware queues, and a stream
+// that lands behind such a kernel on its queue waits for it -- the SLAM stream did, in one run out of a few, for longer than the
+// scan staging's patience.  Streams of another priority have queues of their own.
+int bl_ctx_create_low_priority(int device, bl_ctx** out)
+{
+    BL_CHECK_ARG(out != nullptr);
+    BL_HIP(hipSetDevice(device));
+    int least = 0, greatest = 0;
+    BL_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
+    hipStream_t st = nullptr;
+    BL_HIP(hipStreamCreateWithPriority(&st, hipStreamNonBlocking, least));
+    int rc = bl_ctx_create(device, (void*)st, out);
+    if (rc) { (void)hipStreamDestroy(st); return rc; }
+    (*out)->own_stream = true;
     return BL_OK;
 }
 
@@ -250,10 +270,19 @@ struct bl_scan_slots {
 static int scan_wait_seq(bl_scan_slots* sl, unsigned long long seq)
 {
     if (seq == 0) return BL_OK;
+    // (patience by the clock, not by the count of polls: a fetch may sit behind another stream's long kernel on a shared hardware
+    // queue; two minutes of nothing is a dead device)
     long spins = 0;
+    std::chrono::steady_clock::time_point t0;
     while (__atomic_load_n(sl->h_seq, __ATOMIC_ACQUIRE) < seq) {
-        if (++spins > 2000000000L) { bl_set_error("scan staging: fetch %llu never completed", seq); return BL_ERR_STATE; }
-        if ((spins & 1023) == 0) sched_yield();
+        if ((++spins & 1023) == 0) {
+            sched_yield();
+            if (spins == 1024) t0 = std::chrono::steady_clock::now();
+            else if ((spins & 0xFFFFF) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(120)) {
+                bl_set_error("scan staging: fetch %llu never completed", seq);
+                return BL_ERR_STATE;
+            }
+        }
     }
     return BL_OK;
 }

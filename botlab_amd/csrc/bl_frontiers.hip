@@ -1199,7 +1199,10 @@ extern "C" int bl_explorer_create(bl_ctx* ctx, int lanes, double robot_radius, b
     e->planner.prev_goal.x = 1e9f; e->planner.prev_goal.y = 1e9f;   // never set by the reference's exploration loop (D5)
     for (int l = 0; l < lanes; ++l) {
         explorer_lane& L = e->lane[l];
-        int rc = bl_ctx_create(ctx->device, nullptr, &L.ctx);
+        // a lane's stream has the lowest priority (BOTLAB_EXPLORER_NORMAL_PRIORITY=1: the default one): a plan to a frontier is one
+        // kernel of up to seconds, and streams of one priority share the runtime's four hardware queues -- with its stream behind
+        // a lane's on one queue the SLAM loop ran at 182 instead of 3 700 steps/s (4096 x 4096, the explorer on every newest map)
+        int rc = getenv("BOTLAB_EXPLORER_NORMAL_PRIORITY") ? bl_ctx_create(ctx->device, nullptr, &L.ctx) : bl_ctx_create_low_priority(ctx->device, &L.ctx);
         if (rc) return rc;
         L.ctx->astar_small_lds = true;                  // its searches co-run with the SLAM stream's kernels
         rc = bl_dist_create(L.ctx, &L.dist);

@@ -11,6 +11,8 @@
 #include "bl_math.h"
 
 void bl_set_error(const char* fmt, ...);
+struct bl_ctx;
+int bl_ctx_create_low_priority(int device, bl_ctx** out);      // bl_ctx.hip: own stream of the lowest priority (long-running work)
 
 #define BL_HIP(call)                                                                              \
     do {                                                                                          \
