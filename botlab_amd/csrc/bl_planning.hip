@@ -2020,18 +2020,25 @@ __device__ __forceinline__ void lds_entry_store(int i, int2 v)
 {
     ((volatile lds_ll_t*)s_heap)[i] = ((long long)(unsigned int)v.x) | ((long long)v.y << 32);
 }
+// The part of the heap in HBM through a pointer that SAYS global memory: what comes out of the argument block is a generic pointer
+// to the compiler, a generic access is a FLAT instruction, and a flat load counts on the LDS counter too -- every wait for an LDS
+// read then also waited for the heap's loads in flight, and the other way round.
+typedef __attribute__((address_space(1))) int2 gint2_t;
+__device__ __forceinline__ int2 gheap_load(const int2* g_heap, int i) { const gint2_t* p = (const gint2_t*)(g_heap + i); return make_int2(p->x, p->y); }
+__device__ __forceinline__ void gheap_store(int2* g_heap, int i, int2 v) { gint2_t* p = (gint2_t*)(g_heap + i); p->x = v.x; p->y = v.y; }
+
 template <int LDSN>
 __device__ __forceinline__ int2 heap_read(const int2* g_heap, int i)
 {
     int2 v = lds_entry(i < LDSN ? i : LDSN);
-    if (i >= LDSN) v = g_heap[i];
+    if (i >= LDSN) v = gheap_load(g_heap, i);
     return v;
 }
 template <int LDSN>
 __device__ __forceinline__ void heap_write(int2* g_heap, int i, int2 v)
 {
     lds_entry_store(i < LDSN ? i : LDSN, v);
-    if (i >= LDSN) g_heap[i] = v;
+    if (i >= LDSN) gheap_store(g_heap, i, v);
 }
 
 // std::__push_heap(first, hole, 0, value, greater-by-fCost) (stl_heap.h:128-146) by one wavefront: lane a holds the
@@ -2138,9 +2145,9 @@ __device__ __forceinline__ void heap_adjust_fused(int2* g_heap, int len, int2 va
         int2 e = lds_entry(valid && node < LDSN ? node : LDSN);
         int fl = lds_entry(vt && cl < LDSN ? cl : LDSN).x, fr = lds_entry(vt && cl + 1 < LDSN ? cl + 1 : LDSN).x;
         int2 eg = make_int2(0, 0), flg = make_int2(0, 0), frg = make_int2(0, 0);
-        if (valid && node >= LDSN) eg = g_heap[node];
-        if (vt && cl >= LDSN) flg = g_heap[cl];
-        if (vt && cl + 1 >= LDSN) frg = g_heap[cl + 1];
+        if (valid && node >= LDSN) eg = gheap_load(g_heap, node);
+        if (vt && cl >= LDSN) flg = gheap_load(g_heap, cl);
+        if (vt && cl + 1 >= LDSN) frg = gheap_load(g_heap, cl + 1);
         if (valid && node >= LDSN) e = eg;
         if (vt && cl >= LDSN) fl = flg.x;
         if (vt && cl + 1 >= LDSN) fr = frg.x;
@@ -2281,7 +2288,7 @@ __global__ __launch_bounds__(64) void k_astar(astar_args a)
         // closedList.push_back(nNode): only the first entry per cell is ever observed (is_member / get_member).  Lane 4 has
         // loaded the popped cell's own entry: it is closed now unless an earlier pop of this search closed it
         if (lane == 4 && inb && ((unsigned int)my_closed >> 3) != a.closed_gen)
-            a.closed[cy * a.W + cx] = (int)((a.closed_gen << 3) | (unsigned int)(res.pops == 0 ? 4 : tdir));
+            *(__attribute__((address_space(1))) int*)(a.closed + (cy * a.W + cx)) = (int)((a.closed_gen << 3) | (unsigned int)(res.pops == 0 ? 4 : tdir));      // (a global, not a flat store: gheap_load)
         const bool nclosed = inb && lane < 4 && ((unsigned int)my_closed >> 3) == a.closed_gen;
         if (!inb) my_l1 = 0xFFFF;
         STAMP(t2);
@@ -2290,7 +2297,7 @@ __global__ __launch_bounds__(64) void k_astar(astar_args a)
         int my_cost = ASTAR_INVALID_COST;
         if (inb && my_l1 != 0xFFFF) {
             const int ci = min(my_l1, a.cost_n - 1);
-            if (cost_in_lds) my_cost = s_cost[ci]; else my_cost = a.cost_lut[ci];
+            if (cost_in_lds) my_cost = s_cost[ci]; else my_cost = *(const __attribute__((address_space(1))) int*)(a.cost_lut + ci);
         }
         // gCost of the popped node: fCost - hCost - oCost of its cell (the start node carries zeros, astar.cpp:66-69)
         const int ax = abs(a.gx - nx), ay = abs(a.gy - ny);                     // get_hCost (:170-179); lane 4: the cell itself
