@@ -2315,6 +2315,20 @@ __global__ __launch_bounds__(64) void k_astar(astar_args a)
         const int ey = (ny << 17) | (nx << 2) | lane;
         if (goal_m) push_m &= (goal_m & (0u - goal_m)) - 1u;                    // neighbours before the goal neighbour only
         STAMP(tb);
+        {
+            // the usual case -- room for all of them and every hole inside the LDS levels -- without the per-push checks (each a
+            // branch of this lone wave)
+            const int npush = __popc(push_m);
+            if (npush > 0 && len + npush <= LDSN && len + npush <= a.heap_cap) {
+                while (push_m) {
+                    const int kk = __ffs((int)push_m) - 1;
+                    push_m &= push_m - 1u;
+                    heap_sift_up<true, LDSN>(g_heap, len, make_int2(__builtin_amdgcn_readlane(f, kk), __builtin_amdgcn_readlane(ey, kk)), lane);
+                    len += 1;
+                }
+                res.pushes += npush;
+            }
+        }
         while (push_m) {
             const int kk = __ffs((int)push_m) - 1;
             push_m &= push_m - 1u;
