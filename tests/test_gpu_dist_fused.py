@@ -1,6 +1,7 @@
 """ObstacleDistanceGrid::setDistances of a whole large grid as ONE launch (k_dist_fused: a summary pass and an apply pass per
 128 x 128 tile, handed over through tagged words): bit-exact against the oracle's flood (obstacle_distance_grid.cpp:73-181) on
-the source layouts that exercise each kind of summary, and equal to the four-launch form on the same grids."""
+the source layouts that exercise each kind of summary, and equal to the four-launch form on the same grids.  (The windows of the
+incremental transform start from this kernel's distances in tests/test_gpu_dist_incremental.py: 2000 x 2000 and 4096 x 4096 SLAM runs.)"""
 import os
 
 import numpy as np
@@ -65,19 +66,6 @@ def test_fused_equals_four_launch_form_4096(gpu_ctx):
     finally:
         del os.environ["BOTLAB_DIST_NO_FUSED"]
     assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
-
-
-def test_fused_then_incremental_window(oracle, gpu_ctx):
-    # a whole-grid transform by the fused launch, then map updates through the lineage's log: the windows start from its distances
-    h = w = 1024
-    rng = np.random.default_rng(5)
-    cells = np.where(rng.random((h, w)) < 0.002, 50, -7).astype(np.int8)
-    g = bl.OccupancyGrid.from_cells(cells, (-25.6, -25.6), 0.05, ctx=gpu_ctx)
-    d = bl.ObstacleDistanceGrid(ctx=gpu_ctx)
-    d.setDistances(g)
-    exp = oracle.set_distances(cells, 0.05, 20.0, (-25.6, -25.6))
-    assert np.array_equal(d.cells().view(np.uint32), exp.view(np.uint32))
-    d.close(); g.close()
 
 
 @pytest.mark.parametrize("shape", [(2000, 2000), (2304, 2048)])
