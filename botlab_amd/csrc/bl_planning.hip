@@ -1954,6 +1954,7 @@ struct bl_astar_state {
     // cost table cache key
     bool lut_valid; bl_search_params_t lut_params; int lut_n; const void* lut_owner;
     int lut_eff;                       // entries [lut_eff - 1, lut_n) of the cost table are all equal: the kernel clamps the index to lut_eff - 1
+    int lut_min;                       // smallest obstacle cost of a valid cell: fCost >= lut_min (k_astar2 keeps fCost in 16 bits)
     // batch form
     int b_cap; size_t b_cells; int64_t b_heap_each; size_t b_path_each;
     int2* b_heap; int32_t* b_closed; int32_t* b_path; int32_t* b_pool; char* b_results; int2* b_goals;
@@ -2388,6 +2389,43 @@ __global__ __launch_bounds__(64) void k_astar(astar_args a)
     if (lane == 0) { *a.result = res; if (a.host_out) *(astar_result*)a.host_out = res; }
 }
 
+#include "bl_astar2.h"
+
+// Test entry: n heap operations (key >= 0: push of (key, payload), key in [1, 65534]; key < 0: pop) on k_astar2's open list with
+// the storage tiers of configuration cfg (0: a2_big, 1: a2_small, 2: a2_test); out_*: the popped entries in order; cycles[4]:
+// device cycles and counts of pushes and pops.
+extern "C" int bl_debug_heap2_replay(bl_ctx* ctx, const int32_t* keys, const uint32_t* pays, int n, int cfg, int64_t cap,
+                                     uint32_t* out_keys, uint32_t* out_pays, int* out_n, uint64_t* cycles)
+{
+    const int cfg_in = cfg;
+    cfg &= 15;                    // (+16: the general forms only, without the hand-scheduled ones)
+    BL_CHECK_ARG(ctx != nullptr && keys != nullptr && pays != nullptr && n >= 0 && cfg >= 0 && cfg <= 2 && cap >= 2 && cap <= AH_MAX_CAP);
+    BL_CHECK_ARG(out_keys != nullptr && out_pays != nullptr && out_n != nullptr);
+    BL_HIP(hipSetDevice(ctx->device));
+    int* d_keys = nullptr; unsigned* d_pays = nullptr; int2* d_heap = nullptr; unsigned* d_ok = nullptr; unsigned* d_op = nullptr; int* d_n = nullptr;
+    unsigned long long* d_cyc = nullptr;
+    const size_t nn = (size_t)(n > 0 ? n : 1);
+    BL_HIP(hipMalloc((void**)&d_keys, nn * 4)); BL_HIP(hipMalloc((void**)&d_pays, nn * 4));
+    BL_HIP(hipMalloc((void**)&d_heap, (size_t)cap * 8)); BL_HIP(hipMalloc((void**)&d_ok, nn * 4)); BL_HIP(hipMalloc((void**)&d_op, nn * 4));
+    BL_HIP(hipMalloc((void**)&d_n, 4)); BL_HIP(hipMalloc((void**)&d_cyc, 32));
+    BL_HIP(hipMemcpyAsync(d_keys, keys, (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
+    BL_HIP(hipMemcpyAsync(d_pays, pays, (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
+    BL_HIP(hipMemsetAsync(d_heap, 0xA5, (size_t)cap * 8, ctx->stream));
+    if (cfg == 0) {
+        BL_HIP(hipFuncSetAttribute((const void*)k_heap2_probe<a2_big>, hipFuncAttributeMaxDynamicSharedMemorySize, a2_big::BYTES));
+        hipLaunchKernelGGL((k_heap2_probe<a2_big>), dim3(1), dim3(64), a2_big::BYTES, ctx->stream, d_keys, d_pays, n, d_heap, (int)cap, d_ok, d_op, d_n, d_cyc, (cfg_in & 16) ? 0 : 1);
+    } else if (cfg == 1) hipLaunchKernelGGL((k_heap2_probe<a2_small>), dim3(1), dim3(64), a2_small::BYTES, ctx->stream, d_keys, d_pays, n, d_heap, (int)cap, d_ok, d_op, d_n, d_cyc, (cfg_in & 16) ? 0 : 1);
+    else hipLaunchKernelGGL((k_heap2_probe<a2_test>), dim3(1), dim3(64), a2_test::BYTES, ctx->stream, d_keys, d_pays, n, d_heap, (int)cap, d_ok, d_op, d_n, d_cyc, (cfg_in & 16) ? 0 : 1);
+    BL_HIP(hipGetLastError());
+    BL_HIP(hipMemcpyAsync(out_n, d_n, 4, hipMemcpyDeviceToHost, ctx->stream));
+    BL_HIP(hipStreamSynchronize(ctx->stream));
+    if (*out_n > 0) { BL_HIP(hipMemcpy(out_keys, d_ok, (size_t)*out_n * 4, hipMemcpyDeviceToHost)); BL_HIP(hipMemcpy(out_pays, d_op, (size_t)*out_n * 4, hipMemcpyDeviceToHost)); }
+    if (cycles) BL_HIP(hipMemcpy(cycles, d_cyc, 32, hipMemcpyDeviceToHost));
+    void* all[] = {d_keys, d_pays, d_heap, d_ok, d_op, d_n, d_cyc};
+    for (void* q : all) BL_HIP(hipFree(q));
+    return BL_OK;
+}
+
 void bl_astar_free(bl_ctx* ctx)
 {
     bl_astar_state* s = ctx->astar;
@@ -2426,6 +2464,7 @@ static int astar_prepare(bl_ctx* ctx, const bl_dist* d)
         ctx->astar = new bl_astar_state();
         memset((void*)ctx->astar, 0, sizeof(bl_astar_state));
         ctx->astar->path_head = ASTAR_PATH_HEAD;
+        if (getenv("BOTLAB_ASTAR_NO_TURBO")) { const bool off = false; BL_HIP(hipMemcpyToSymbol(HIP_SYMBOL(a2_turbo_enabled), &off, sizeof(off))); }
         if (const char* e = getenv("BOTLAB_ASTAR_PATH_HEAD")) { const int v = atoi(e); if (v >= 1 && v <= ASTAR_PATH_HEAD) ctx->astar->path_head = v; }
         for (int i = 0; i < ASTAR_SLOTS; ++i) {
             BL_HIP(hipHostMalloc((void**)&ctx->astar->h_out[i], ASTAR_HDR + ASTAR_PATH_HEAD * 4, hipHostMallocDefault));
@@ -2444,6 +2483,7 @@ static int astar_prepare(bl_ctx* ctx, const bl_dist* d)
         BL_HIP(hipMalloc((void**)&s->heap, (size_t)want * sizeof(int2)));
         s->heap_cap = want;
         BL_HIP(hipFuncSetAttribute((const void*)k_astar<AH_LDS, AH_COST_LDS>, hipFuncAttributeMaxDynamicSharedMemorySize, AH_LDS_BYTES));
+        BL_HIP(hipFuncSetAttribute((const void*)k_astar2<a2_big>, hipFuncAttributeMaxDynamicSharedMemorySize, a2_big::BYTES));
     }
     size_t n = (size_t)d->frame.width * d->frame.height;
     if (n < ASTAR_PATH_HEAD) n = ASTAR_PATH_HEAD;
@@ -2511,6 +2551,9 @@ static int astar_prepare_lut(bl_ctx* ctx, const bl_dist* d, const bl_search_para
     int eff = ln;
     while (eff > 1 && s->h_cost[eff - 2] == s->h_cost[ln - 1]) eff--;
     s->lut_eff = eff;
+    int lo = 0;
+    for (int n = 0; n < ln; ++n) if (s->h_cost[n] != ASTAR_INVALID_COST && s->h_cost[n] < lo) lo = s->h_cost[n];
+    s->lut_min = lo;
     s->lut_valid = true; s->lut_n = ln; s->lut_owner = (const void*)d; s->lut_params = *params;
     return BL_OK;
 }
@@ -2555,6 +2598,7 @@ static int astar_fill(bl_ctx* ctx, const bl_dist* d, const bl_pose_xyt_t* start,
         memset(&a.start_host, 0, sizeof(a.start_host));
     }
     a.max_pops = 1ll << 31;
+    if (const char* e = getenv("BOTLAB_ASTAR_MAX_POPS")) { const long long v = atoll(e); if (v > 0) a.max_pops = v; }      // probes: stop after v pops
     bl_dist* dm = const_cast<bl_dist*>(d);           // closed[] is search scratch that travels with the grid
     if (++dm->closed_gen >= (1u << 28)) {            // (a wrap every 2.7e8 searches: start over from a zeroed array)
         BL_HIP(hipMemsetAsync(dm->closed, 0, (size_t)a.W * a.H * 4, ctx->stream));
@@ -2578,7 +2622,15 @@ static int astar_after(bl_ctx* ctx, const bl_dist* d)
     return BL_OK;
 }
 
-static void astar_launch_kernel(bl_ctx* ctx, const astar_args& a, int workgroups)
+// k_astar2 keeps an entry's fCost in 16 bits: usable when no valid cell's obstacle cost can take an fCost to -32768 or below
+// (the reference's own parameters give -3998 at the least).  BOTLAB_ASTAR_V1=1: k_astar's 8-byte entries (probes, A/B runs).
+static bool astar_split_ok(const bl_astar_state* s)
+{
+    static const bool force_v1 = getenv("BOTLAB_ASTAR_V1") != nullptr;
+    return !force_v1 && s->lut_valid && s->lut_min > -32768;
+}
+
+static void astar_launch_kernel(bl_ctx* ctx, const astar_args& a, int workgroups, bool split)
 {
     // The 40 KB footprint is for searches that share CUs with the particle filter (the replanner's units): beside its
     // whole-grid LDS image or its LDS window (3 x ~50 KB per CU) a 147 KB heap needs a CU of its own, and a dozen searches in
@@ -2586,10 +2638,11 @@ static void astar_launch_kernel(bl_ctx* ctx, const astar_args& a, int workgroups
     // with the small footprint, the searches themselves no slower).  A search that runs alone takes the 147 KB heap: an open
     // list spilling past the LDS levels pays an HBM round trip per heap level.
     static const bool force_small = getenv("BOTLAB_ASTAR_SMALL_LDS") != nullptr;     // probes: the replanner's footprint on a lone search
-    if (ctx->astar_small_lds || force_small)
-        hipLaunchKernelGGL((k_astar<AH_LDS_SMALL, AH_COST_LDS_SMALL>), dim3(workgroups), dim3(64), AH_LDS_SMALL_BYTES, ctx->stream, a);
-    else
-        hipLaunchKernelGGL((k_astar<AH_LDS, AH_COST_LDS>), dim3(workgroups), dim3(64), AH_LDS_BYTES, ctx->stream, a);
+    const bool small = ctx->astar_small_lds || force_small;
+    if (split && small) hipLaunchKernelGGL((k_astar2<a2_small>), dim3(workgroups), dim3(64), a2_small::BYTES, ctx->stream, a);
+    else if (split) hipLaunchKernelGGL((k_astar2<a2_big>), dim3(workgroups), dim3(64), a2_big::BYTES, ctx->stream, a);
+    else if (small) hipLaunchKernelGGL((k_astar<AH_LDS_SMALL, AH_COST_LDS_SMALL>), dim3(workgroups), dim3(64), AH_LDS_SMALL_BYTES, ctx->stream, a);
+    else hipLaunchKernelGGL((k_astar<AH_LDS, AH_COST_LDS>), dim3(workgroups), dim3(64), AH_LDS_BYTES, ctx->stream, a);
 }
 
 static int astar_launch(bl_ctx* ctx, const bl_dist* d, const bl_pose_xyt_t* start, const void* d_start,
@@ -2601,7 +2654,7 @@ static int astar_launch(bl_ctx* ctx, const bl_dist* d, const bl_pose_xyt_t* star
     hipEvent_t e0, e1;
     rc = bl_timer_begin(ctx, BL_K_ASTAR, &e0, &e1);
     if (rc) return rc;
-    astar_launch_kernel(ctx, a, 1);
+    astar_launch_kernel(ctx, a, 1, astar_split_ok(ctx->astar));
     BL_HIP(hipGetLastError());
     rc = bl_timer_end(ctx, BL_K_ASTAR, e0, e1);
     if (rc) return rc;
@@ -2616,6 +2669,7 @@ static int astar_launch_units(int n, bl_ctx* const* ctxs, bl_dist* const* dists,
     BL_CHECK_ARG(n >= 1 && n <= ASTAR_MAX_UNITS);
     if (n == 1) return astar_launch(ctxs[0], dists[0], nullptr, d_starts[0], &goals[0], &params[0]);
     astar_args a;
+    bool split = true;
     int rc0 = astar_prepare(ctxs[0], dists[0]);
     if (rc0) return rc0;
     bl_astar_state* s0 = ctxs[0]->astar;
@@ -2627,6 +2681,7 @@ static int astar_launch_units(int n, bl_ctx* const* ctxs, bl_dist* const* dists,
         BL_CHECK_ARG(dists[b]->frame.width == dists[0]->frame.width && dists[b]->frame.height == dists[0]->frame.height);
         int rc = astar_fill(ctxs[b], dists[b], nullptr, d_starts[b], &goals[b], &params[b], &a);
         if (rc) return rc;
+        split = split && astar_split_ok(ctxs[b]->astar);
         astar_unit& u = units[b];
         u.l1 = a.l1; u.cost_lut = a.cost_lut; u.heap = a.heap; u.closed = a.closed; u.path = a.path; u.result = a.result;
         u.start_dev = a.start_dev; u.start_host = a.start_host; u.sx = a.sx; u.sy = a.sy; u.gx = a.gx; u.gy = a.gy;
@@ -2637,7 +2692,7 @@ static int astar_launch_units(int n, bl_ctx* const* ctxs, bl_dist* const* dists,
     hipEvent_t e0, e1;
     int rc = bl_timer_begin(ctx, BL_K_ASTAR, &e0, &e1);
     if (rc) return rc;
-    astar_launch_kernel(ctx, a, n);
+    astar_launch_kernel(ctx, a, n, split);
     BL_HIP(hipGetLastError());
     rc = bl_timer_end(ctx, BL_K_ASTAR, e0, e1);
     if (rc) return rc;
@@ -2777,6 +2832,7 @@ static int astar_batch_prepare(bl_ctx* ctx, const bl_dist* d, int want)
     BL_HIP(hipHostMalloc((void**)&s->hb_pool, s->hb_pool_cap * 4, hipHostMallocDefault));
     s->b_cap = cap; s->b_cells = cells; s->b_heap_each = heap_each; s->b_path_each = path_each;
     BL_HIP(hipFuncSetAttribute((const void*)k_astar<AH_LDS, AH_COST_LDS>, hipFuncAttributeMaxDynamicSharedMemorySize, AH_LDS_BYTES));
+    BL_HIP(hipFuncSetAttribute((const void*)k_astar2<a2_big>, hipFuncAttributeMaxDynamicSharedMemorySize, a2_big::BYTES));
     return BL_OK;
 }
 
@@ -2826,7 +2882,8 @@ static int astar_batch_cells(bl_ctx* ctx, const bl_dist* d, const bl_pose_xyt_t*
         hipEvent_t e0, e1;
         rc = bl_timer_begin(ctx, BL_K_ASTAR, &e0, &e1);
         if (rc) return rc;
-        hipLaunchKernelGGL((k_astar<AH_LDS, AH_COST_LDS>), dim3(m), dim3(64), AH_LDS_BYTES, ctx->stream, a);
+        if (astar_split_ok(s)) hipLaunchKernelGGL((k_astar2<a2_big>), dim3(m), dim3(64), a2_big::BYTES, ctx->stream, a);
+        else hipLaunchKernelGGL((k_astar<AH_LDS, AH_COST_LDS>), dim3(m), dim3(64), AH_LDS_BYTES, ctx->stream, a);
         BL_HIP(hipGetLastError());
         rc = bl_timer_end(ctx, BL_K_ASTAR, e0, e1);
         if (rc) return rc;

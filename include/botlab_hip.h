@@ -225,6 +225,13 @@ void* bl_dist_device_ptr(bl_dist* d);
 int bl_astar_search(bl_ctx* ctx, const bl_dist* distances, const bl_pose_xyt_t* start, const bl_pose_xyt_t* goal,
                     const bl_search_params_t* params, bl_pose_xyt_t* out_path, int cap, int* out_len, int64_t* stats);
 int bl_astar_set_open_capacity(bl_ctx* ctx, int64_t nodes);
+/* Test entry for the search's open list (std::priority_queue<Node, vector, greater>, astar.cpp:75-76,117-135, as the wave-parallel
+ * std::push_heap / std::pop_heap of k_astar2): replays n operations -- keys[i] in [1, 65534]: push (keys[i], pays[i]); keys[i] < 0:
+ * pop -- and returns the popped (key, payload) pairs in order.  cfg 0 / 1 / 2: the storage tiers of a lone search, of a
+ * co-running search, of the tests (every tier within a few thousand entries).  cycles (optional, 4 x uint64): device cycles and
+ * counts of pushes and of pops. */
+int bl_debug_heap2_replay(bl_ctx* ctx, const int32_t* keys, const uint32_t* pays, int n, int cfg, int64_t capacity,
+                          uint32_t* out_keys, uint32_t* out_pays, int* out_n, uint64_t* cycles);
 /* Asynchronous form for step pipelines: enqueue the search, fetch the result later.  Up to 4 searches may be in flight;
  * results are fetched in launch order and fetching waits for that search only (work enqueued after it keeps running). */
 int bl_astar_search_async(bl_ctx* ctx, const bl_dist* distances, const bl_pose_xyt_t* start, const bl_pose_xyt_t* goal,

@@ -1142,4 +1142,27 @@ void orc_slam_state(void* d, int* out6, orc_pose_t* currentPose, int8_t* cells)
     if (cells) std::memcpy(cells, s->cells.data(), s->cells.size());
 }
 
+
+// The open list as the reference holds it: std::priority_queue<Node, std::vector<Node>, std::greater<Node>> compares fCost only
+// (astar.hpp:41-44, astar.cpp:75-76), i.e. std::push_heap / std::pop_heap of libstdc++ decide the order of equal costs.  Replays
+// n operations (keys[i] >= 0: push (keys[i], pays[i]); < 0: pop) and returns the popped pairs in order: what the device heap of
+// the HIP path is compared with entry for entry.
+int orc_heap_replay(const int32_t* keys, const uint32_t* pays, int n, int64_t cap, uint32_t* out_keys, uint32_t* out_pays)
+{
+    struct E { int32_t f; uint32_t pay; };
+    struct G { bool operator()(const E& a, const E& b) const { return a.f > b.f; } };
+    std::vector<E> h;
+    int no = 0;
+    for (int i = 0; i < n; ++i) {
+        if (keys[i] >= 0) {
+            if (static_cast<int64_t>(h.size()) < cap) { h.push_back(E{keys[i], pays[i]}); std::push_heap(h.begin(), h.end(), G()); }
+        } else if (!h.empty()) {
+            std::pop_heap(h.begin(), h.end(), G());
+            out_keys[no] = static_cast<uint32_t>(h.back().f); out_pays[no] = h.back().pay; ++no;
+            h.pop_back();
+        }
+    }
+    return no;
+}
+
 }  // extern "C"

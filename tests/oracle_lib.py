@@ -84,6 +84,8 @@ class Oracle:
         L.orc_search_for_path.restype = C.c_int
         L.orc_search_for_path.argtypes = [C.POINTER(OPose), C.POINTER(OPose), C.POINTER(OGrid), C.POINTER(OSearchParams),
                                           C.c_int, C.c_void_p, C.c_int, C.c_void_p]
+        L.orc_heap_replay.restype = C.c_int
+        L.orc_heap_replay.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_void_p, C.c_void_p]
         L.orc_action_create.restype = C.c_void_p
         L.orc_action_destroy.argtypes = [C.c_void_p]
         L.orc_action_update.restype = C.c_int
