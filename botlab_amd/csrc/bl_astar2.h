@@ -44,8 +44,8 @@ template <int KLV, int PLV> struct a2cfg {
     static_assert(FD >= 1 && FD <= 5, "round layout");
     static_assert(PLV >= FD + 5 && PLV <= FD + 9, "payload tier boundary must fall into the third round");
 };
-typedef a2cfg<15, 11> a2_big;       // 128 KB keys + 16 KB payloads + cost table: a search that has a CU to itself
-typedef a2cfg<13, 9> a2_small;      // 32 KB + 4 KB: beside the particle filter's workgroups
+typedef a2cfg<14, 13> a2_big;       // 64 KB keys (32 767 entries) + 64 KB payloads (16 383): a search that has a CU to itself
+typedef a2cfg<12, 11> a2_small;     // 16 KB keys (8 191) + 16 KB payloads (4 095): beside the particle filter's workgroups
 typedef a2cfg<11, 6> a2_test;       // tests: every storage tier within a few thousand entries
 
 typedef __attribute__((address_space(3))) unsigned short a2_lds_u16;
@@ -629,11 +629,15 @@ __global__ __launch_bounds__(64) void k_astar2(astar_args a)
     static_assert((C::TBL_OFF & 15) == 0, "table alignment");
     const bool turbo = fast && cost_in_lds && a2_turbo_enabled;
     {
-        a2_lds_u32* row = (a2_lds_u32*)(size_t)(tbl + 32u * (unsigned)lane);
+        a2_lds_u32* row = (a2_lds_u32*)(size_t)(tbl + 64u * (unsigned)lane);
+        // cells two steps from the popped one (lanes 0..7): their lines are asked for one expansion ahead
+        const int pdx = lane == 0 ? 2 : (lane == 1 ? -2 : (lane == 4 || lane == 5 ? 1 : (lane == 6 || lane == 7 ? -1 : 0)));
+        const int pdy = lane == 2 ? 2 : (lane == 3 ? -2 : (lane == 4 || lane == 6 ? 1 : (lane == 5 || lane == 7 ? -1 : 0)));
+        row[8] = (unsigned)pdx; row[9] = (unsigned)pdy;
         row[0] = (unsigned)ln.lk; row[1] = (unsigned)ln.ljm1; row[2] = ln.amask; row[3] = ln.areq; row[4] = ln.sh1; row[5] = ln.sh0;
         row[6] = (unsigned)(lane == 0 ? 1 : (lane == 1 ? -1 : 0)); row[7] = (unsigned)(lane == 2 ? 1 : (lane == 3 ? -1 : 0));
         if (lane == 0) {
-            a2_lds_u32* sc = (a2_lds_u32*)(size_t)(tbl + 2048u);
+            a2_lds_u32* sc = (a2_lds_u32*)(size_t)(tbl + 4096u);
             sc[A2T_SC_W] = (unsigned)a.W; sc[A2T_SC_H] = (unsigned)a.H; sc[A2T_SC_GX] = (unsigned)a.gx; sc[A2T_SC_GY] = (unsigned)a.gy;
             sc[A2T_SC_GEN] = a.closed_gen; sc[A2T_SC_CN1] = (unsigned)(a.cost_n - 1);
             sc[A2T_SC_MAXPOPS] = a.max_pops > 0x7fffffffll ? 0x7fffffffu : (unsigned)a.max_pops;
@@ -642,6 +646,7 @@ __global__ __launch_bounds__(64) void k_astar2(astar_args a)
             sc[A2T_SC_CLOSED] = (unsigned)(size_t)a.closed; sc[A2T_SC_CLOSED + 1] = (unsigned)((size_t)a.closed >> 32);
             sc[A2T_SC_PB] = pbase; sc[A2T_SC_CB] = cbase;
             sc[A2T_SC_LVL1] = 1u << (C::FD + 1); sc[A2T_SC_LVL2] = 1u << (C::FD + 6);
+            for (int q = 16; q < 24; ++q) sc[q] = 0;
         }
         __syncthreads();
     }
@@ -773,6 +778,12 @@ __global__ __launch_bounds__(64) void k_astar2(astar_args a)
     tr1 = __builtin_amdgcn_s_memrealtime();
     res.stamps[0] = (long long)acc_all; res.stamps[1] = (long long)acc_adj; res.stamps[2] = (long long)acc_nb;
     res.stamps[3] = (long long)(tr1 - tr0); res.stamps[4] = (long long)acc_wait; res.stamps[5] = (long long)acc_push;
+    if (turbo) {
+        // the straight-line loop's own sums (table words 16 .. 21) on top: checks + top -> [0] (with the rest), pop -> [1], expansion -> [2], load wait -> [4], pushes -> [5]
+        const a2_lds_u32* sc = (const a2_lds_u32*)(size_t)(tbl + 4096u);
+        const long long m0 = sc[16], m1 = sc[17], m2 = sc[18], m3 = sc[19], m4 = sc[20], m5 = sc[21];
+        res.stamps[0] += m0 + m1 + m2 + m3 + m4 + m5; res.stamps[1] += m2; res.stamps[4] += m3; res.stamps[2] += m4; res.stamps[5] += m5;
+    }
 #endif
     if (a.pool && res.status == ASTAR_ST_FOUND) {
         __threadfence();
