@@ -25,6 +25,7 @@
 #define BL_ASTAR2_H
 
 #include "bl_astar2_turbo.h"
+#include "bl_astar2_deep.h"
 
 #define A2_COSTN 256
 #define A2_INF 0xFFFFu
@@ -40,6 +41,7 @@ template <int KLV, int PLV> struct a2cfg {
     static constexpr int TBL_OFF = COST_OFF + A2_COSTN * 4;  // constants of the straight-line loop (bl_astar2_turbo.h)
     static constexpr int BYTES = TBL_OFF + A2T_TBL_BYTES;
     static constexpr int LEV = KLV;                          // deepest heap level whose keys are LDS
+    static constexpr int PLEV = PLV;                         // ... whose payloads are
     static constexpr int FD = KLV - 10;                      // levels the first sift-down round descends: rounds start at levels 0, FD, FD + 5, KLV
     static_assert(FD >= 1 && FD <= 5, "round layout");
     static_assert(PLV >= FD + 5 && PLV <= FD + 9, "payload tier boundary must fall into the third round");
@@ -628,6 +630,7 @@ __global__ __launch_bounds__(64) void k_astar2(astar_args a)
     const unsigned tbl = kbase + C::TBL_OFF;
     static_assert((C::TBL_OFF & 15) == 0, "table alignment");
     const bool turbo = fast && cost_in_lds && a2_turbo_enabled;
+    const bool deep = turbo && C::PLEV == C::LEV - 1 && (long long)a.heap_cap >= (1ll << (C::LEV + 6));
     {
         a2_lds_u32* row = (a2_lds_u32*)(size_t)(tbl + 64u * (unsigned)lane);
         // cells two steps from the popped one (lanes 0..7): their lines are asked for one expansion ahead
@@ -646,7 +649,10 @@ __global__ __launch_bounds__(64) void k_astar2(astar_args a)
             sc[A2T_SC_CLOSED] = (unsigned)(size_t)a.closed; sc[A2T_SC_CLOSED + 1] = (unsigned)((size_t)a.closed >> 32);
             sc[A2T_SC_PB] = pbase; sc[A2T_SC_CB] = cbase;
             sc[A2T_SC_LVL1] = 1u << (C::FD + 1); sc[A2T_SC_LVL2] = 1u << (C::FD + 6);
-            for (int q = 16; q < 24; ++q) sc[q] = 0;
+            sc[A2T_SC_GK] = (unsigned)(size_t)gk; sc[A2T_SC_GK + 1] = (unsigned)((size_t)gk >> 32);
+            sc[A2T_SC_GP] = (unsigned)(size_t)gp; sc[A2T_SC_GP + 1] = (unsigned)((size_t)gp >> 32);
+            sc[A2T_SC_DLIM] = ((1u << (C::LEV + 6)) - 4u) - ((unsigned)C::PLN + 2u);     // the deep loop runs while PLN + 2 <= length <= 2^(LEV + 6) - 4
+            for (int q = 24; q < 32; ++q) sc[q] = 0;
         }
         __syncthreads();
     }
@@ -683,6 +689,24 @@ __global__ __launch_bounds__(64) void k_astar2(astar_args a)
             if (code == 2u) { goal_m = gm; cx = (int)((ptop >> 2) & 0x7fffu); cy = (int)(ptop >> 17); res.status = ASTAR_ST_FOUND; break; }
             if (code == 3u) { res.status = ASTAR_ST_LIMIT; break; }
             if (len == 0) break;
+        }
+        if (deep && len >= (unsigned)C::PLN + 2u && len <= (1u << (C::LEV + 6)) - 4u) {
+            // ... and its form for open lists that reach into global memory (bl_astar2_deep.h)
+            unsigned code, gm, ptop;
+            unsigned s_len = (unsigned)__builtin_amdgcn_readfirstlane((int)len), s_pops = (unsigned)__builtin_amdgcn_readfirstlane((int)pops);
+            unsigned s_pushes = (unsigned)__builtin_amdgcn_readfirstlane((int)pushes);
+            asm volatile(A2D_BODY
+                         : [len] "+s"(s_len), [pops] "+s"(s_pops), [pushes] "+s"(s_pushes), [code] "=&s"(code), [gm] "=&s"(gm), [pt] "=&s"(ptop)
+                         : [tbl] "s"(__builtin_amdgcn_readfirstlane((int)tbl)), [kmax] "n"(C::KEY_BYTES - 4), [kmax2] "n"(C::KEY_BYTES - 2), [pln] "n"(C::PLN),
+                           [kslots] "n"(C::KSLOTS), [kslotsm1] "n"(C::KSLOTS - 1), [dlo] "n"(C::PLN + 2),
+                           [ok0lo] "n"((unsigned)(((2ull << ((1 << (C::FD + 1)) - 2)) - 1ull) & 0xffffffffull)),
+                           [ok0hi] "n"((unsigned)(((2ull << ((1 << (C::FD + 1)) - 2)) - 1ull) >> 32))
+                         : A2D_CLOBBERS);
+            len = s_len; pops = s_pops; pushes = s_pushes;
+            if (code == 2u) { goal_m = gm; cx = (int)((ptop >> 2) & 0x7fffu); cy = (int)(ptop >> 17); res.status = ASTAR_ST_FOUND; break; }
+            if (code == 3u) { res.status = ASTAR_ST_LIMIT; break; }
+            if (len == 0) break;
+            if (len >= 2u && len <= (unsigned)C::PLN - 3u) continue;        // back in the LDS regime
         }
         if (pops >= max_pops) { res.status = ASTAR_ST_LIMIT; break; }
         STAMP(t0);
@@ -781,7 +805,7 @@ __global__ __launch_bounds__(64) void k_astar2(astar_args a)
     if (turbo) {
         // the straight-line loop's own sums (table words 16 .. 21) on top: checks + top -> [0] (with the rest), pop -> [1], expansion -> [2], load wait -> [4], pushes -> [5]
         const a2_lds_u32* sc = (const a2_lds_u32*)(size_t)(tbl + 4096u);
-        const long long m0 = sc[16], m1 = sc[17], m2 = sc[18], m3 = sc[19], m4 = sc[20], m5 = sc[21];
+        const long long m0 = sc[24], m1 = sc[25], m2 = sc[26], m3 = sc[27], m4 = sc[28], m5 = sc[29];
         res.stamps[0] += m0 + m1 + m2 + m3 + m4 + m5; res.stamps[1] += m2; res.stamps[4] += m3; res.stamps[2] += m4; res.stamps[5] += m5;
     }
 #endif

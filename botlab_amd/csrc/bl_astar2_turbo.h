@@ -33,7 +33,10 @@
 #define A2T_SC_CB 13
 #define A2T_SC_LVL1 14
 #define A2T_SC_LVL2 15
-#define A2T_TBL_BYTES (4096 + 96)
+#define A2T_SC_GK 16
+#define A2T_SC_GP 18
+#define A2T_SC_DLIM 20
+#define A2T_TBL_BYTES (4096 + 128)
 
 // one sift-down round: node N, child C_, knext K, payload P (of the child), mask SQ, lane mask OK (see a2_round_lds); FILL =
 // instructions of the expansion that need nothing from the round: they run while the round's LDS read is under way
@@ -189,8 +192,8 @@
 // shares, not the undisturbed loop's times.
 #ifdef BL_ASTAR_STAMPS
 #define A2T_STAMP(K) "s_memtime s[100:101]\n\ts_waitcnt lgkmcnt(0)\n\ts_sub_u32 s43, s100, s43\n\tv_add_u32 v25" K ", s43, v25" K "\n\ts_mov_b32 s43, s100\n\t"
-#define A2T_STAMPS_IN "v_mov_b32 v245, %[tbl]\n\tds_read_b128 v[250:253], v245 offset:4160\n\tds_read_b64 v[254:255], v245 offset:4176\n\ts_memtime s[100:101]\n\ts_waitcnt lgkmcnt(0)\n\ts_mov_b32 s43, s100\n\t"
-#define A2T_STAMPS_OUT "v_mov_b32 v245, %[tbl]\n\tds_write_b128 v245, v[250:253] offset:4160\n\tds_write_b64 v245, v[254:255] offset:4176\n\t"
+#define A2T_STAMPS_IN "v_mov_b32 v245, %[tbl]\n\tds_read_b128 v[250:253], v245 offset:4192\n\tds_read_b64 v[254:255], v245 offset:4208\n\ts_memtime s[100:101]\n\ts_waitcnt lgkmcnt(0)\n\ts_mov_b32 s43, s100\n\t"
+#define A2T_STAMPS_OUT "v_mov_b32 v245, %[tbl]\n\tds_write_b128 v245, v[250:253] offset:4192\n\tds_write_b64 v245, v[254:255] offset:4208\n\t"
 #define A2T_STAMP_CLOBBERS , "s43", "s100", "s101", "v245", "v250", "v251", "v252", "v253", "v254", "v255"
 #else
 #define A2T_STAMP(K) ""
@@ -198,6 +201,79 @@
 #define A2T_STAMPS_OUT ""
 #define A2T_STAMP_CLOBBERS
 #endif
+
+#define A2T_NBR                                                                                               \
+    /* ---- the loads of this expansion: lanes 0..3 the neighbours (astar.cpp:215-216), lane 4 the cell itself */ \
+    "v_bfe_u32 v228, v196, 2, 15\n\t"                                                                         \
+    "v_lshrrev_b32 v229, 17, v196\n\t"                                                                        \
+    "v_add_u32 v210, v228, v186\n\t"                                                                          \
+    "v_add_u32 v211, v229, v187\n\t"                                                                          \
+    "v_cmp_gt_u32 vcc, s44, v210\n\t"                                                                         \
+    "v_cmp_gt_u32_e64 s[94:95], s45, v211\n\t"                                                                \
+    "s_and_b64 s[94:95], s[94:95], vcc\n\t"                                                                   \
+    "s_and_b64 s[94:95], s[94:95], s[66:67]\n\t"                                                              \
+    "v_mad_u32_u24 v212, v211, s44, v210\n\t"                                                                 \
+    "v_cndmask_b32_e64 v212, 0, v212, s[94:95]\n\t"                                                           \
+    "v_lshlrev_b32 v213, 1, v212\n\t"                                                                         \
+    "v_lshlrev_b32 v214, 2, v212\n\t"                                                                         \
+    "global_load_ushort v215, v213, s[52:53]\n\t"                                                             \
+    "global_load_dword v216, v214, s[54:55] sc1\n\t"                                                          \
+    /* the lines of the cells two steps away, asked for now and never waited for: the next expansions find them in the L2 */ \
+    "v_add_u32 v246, v228, v178\n\t"                                                                          \
+    "v_add_u32 v247, v229, v179\n\t"                                                                          \
+    "v_cmp_gt_u32 vcc, s44, v246\n\t"                                                                         \
+    "v_cmp_gt_u32_e64 s[68:69], s45, v247\n\t"                                                                \
+    "s_and_b64 s[68:69], s[68:69], vcc\n\t"                                                                   \
+    "s_and_b64 s[68:69], s[68:69], s[98:99]\n\t"                                                              \
+    "v_mad_u32_u24 v246, v247, s44, v246\n\t"                                                                 \
+    "v_cndmask_b32_e64 v246, 0, v246, s[68:69]\n\t"                                                           \
+    "v_lshlrev_b32 v247, 2, v246\n\t"                                                                         \
+    "v_lshlrev_b32 v246, 1, v246\n\t"                                                                         \
+    "global_load_ushort v248, v246, s[52:53]\n\t"                                                             \
+    "global_load_dword v249, v247, s[54:55]\n\t"
+
+// the expansion proper (the loads of A2T_NBR have arrived): closes the popped cell, then key v226 / payload v227 of every neighbour's
+// entry, the lanes to push -> s87, the goal neighbours -> s88 (astar.cpp:95-135, 213-233)
+#define A2T_EXPAND(TAG)                                                                                      \
+    "v_lshrrev_b32 v222, 3, v216\n\t"                                                                         \
+    "v_cmp_ne_u32 vcc, s48, v222\n\t"           /* not closed by this search (lane 4: the popped cell itself) */ \
+    "s_and_b64 s[68:69], vcc, s[96:97]\n\t"                                                                   \
+    "s_andn2_b64 s[92:93], s[94:95], s[96:97]\n\t"   /* neighbour lanes inside the grid */                    \
+    "s_and_b64 s[92:93], s[92:93], vcc\n\t"          /* ... and not closed */                                 \
+    "s_mov_b64 exec, s[68:69]\n\t"                                                                            \
+    "global_store_dword v214, v218, s[54:55]\n\t"    /* closedList.push_back: the first entry per cell is the one observed */ \
+    "s_mov_b64 exec, -1\n\t"                                                                                  \
+    "s_add_i32 s41, s41, 1\n\t"                                                                               \
+    "v_min_u32 v223, s49, v215\n\t"                                                                           \
+    "v_lshl_add_u32 v223, v223, 2, s57\n\t"                                                                   \
+    "ds_read_b32 v224, v223\n\t"                     /* isValid + get_oCost by the cell's L1 distance */      \
+    "v_cmp_ne_u32 vcc, 0xffff, v215\n\t"                                                                      \
+    "s_and_b64 s[92:93], s[92:93], vcc\n\t"                                                                   \
+    "s_and_b64 s[36:37], s[36:37], vcc\n\t"                                                                   \
+    "s_and_b64 s[36:37], s[36:37], s[94:95]\n\t"                                                              \
+    "s_andn2_b64 s[36:37], s[36:37], s[96:97]\n\t"   /* goal neighbours: in grid, lanes 0..3 */               \
+    "v_add_u32 v217, 0xffff8000, v192\n\t"           /* fCost of the popped entry */                          \
+    "s_waitcnt lgkmcnt(0)\n\t"                                                                                \
+    "v_cmp_ne_u32 vcc, 0x80000000, v224\n\t"         /* the cell is valid */                                  \
+    "s_and_b64 s[92:93], s[92:93], vcc\n\t"                                                                   \
+    "s_and_b64 s[36:37], s[36:37], vcc\n\t"                                                                   \
+    "v_add_u32 v225, v219, v224\n\t"                 /* hCost + oCost */                                      \
+    "v_sub_u32 v226, v217, v225\n\t"                 /* lane 4: gCost of the popped node (never the start node here: its */ \
+    "s_nop 0\n\t"                                    /* expansion has a one-entry list; a lane read needs a wait state */ \
+    "v_readlane_b32 s86, v226, 4\n\t"                /* behind the VALU write of its source on gfx950) */     \
+    "s_add_i32 s86, s86, 0x800a\n\t"                 /* + 10 (get_gCost), + 32768 (key bias) */               \
+    "v_add_u32 v226, s86, v225\n\t"                  /* key of the neighbour's entry */                       \
+    "v_cmp_gt_u32 vcc, 0xffff, v226\n\t"             /* fNew < INT16_MAX (astar.cpp:103,124) */               \
+    "s_and_b64 s[92:93], s[92:93], vcc\n\t"                                                                   \
+    "s_mov_b32 s87, s92\n\t"                                                                                  \
+    "s_mov_b32 s88, s36\n\t"                                                                                  \
+    "s_cmp_eq_u32 s88, 0\n\t"                                                                                 \
+    "s_cbranch_scc1 " TAG "f\n\t"                                                                                  \
+    "s_sub_i32 s70, 0, s88\n\t"                      /* neighbours before the goal neighbour only */          \
+    "s_and_b32 s70, s70, s88\n\t"                                                                             \
+    "s_add_i32 s70, s70, -1\n\t"                                                                              \
+    "s_and_b32 s87, s87, s70\n\t"                                                                             \
+    TAG ":\n\t"
 
 #define A2T_RSF(dst, idx) "v_readfirstlane_b32 " dst ", " idx "\n\t"
 
@@ -259,38 +335,11 @@
     "ds_read_b32 v197, v195\n\t"                                                                              \
     "s_add_i32 s40, s40, -1\n\t"                                                                              \
     "s_waitcnt lgkmcnt(3)\n\t"                                                                                \
-    /* ---- the loads of this expansion: lanes 0..3 the neighbours (astar.cpp:215-216), lane 4 the cell itself */ \
-    "v_bfe_u32 v228, v196, 2, 15\n\t"                                                                         \
-    "v_lshrrev_b32 v229, 17, v196\n\t"                                                                        \
-    "v_add_u32 v210, v228, v186\n\t"                                                                          \
-    "v_add_u32 v211, v229, v187\n\t"                                                                          \
-    "v_cmp_gt_u32 vcc, s44, v210\n\t"                                                                         \
-    "v_cmp_gt_u32_e64 s[94:95], s45, v211\n\t"                                                                \
-    "s_and_b64 s[94:95], s[94:95], vcc\n\t"                                                                   \
-    "s_and_b64 s[94:95], s[94:95], s[66:67]\n\t"                                                              \
-    "v_mad_u32_u24 v212, v211, s44, v210\n\t"                                                                 \
-    "v_cndmask_b32_e64 v212, 0, v212, s[94:95]\n\t"                                                           \
-    "v_lshlrev_b32 v213, 1, v212\n\t"                                                                         \
-    "v_lshlrev_b32 v214, 2, v212\n\t"                                                                         \
-    "global_load_ushort v215, v213, s[52:53]\n\t"                                                             \
-    "global_load_dword v216, v214, s[54:55] sc1\n\t"                                                          \
+    A2T_NBR                                                                                                   \
     /* the slot the last entry leaves is "behind the heap" from here on */                                    \
     "s_mov_b64 exec, 1\n\t"                                                                                   \
     "ds_write_b16 v191, v176\n\t"                                                                             \
     "s_mov_b64 exec, -1\n\t"                                                                                  \
-    /* the lines of the cells two steps away, asked for now and never waited for: the next expansions find them in the L2 */ \
-    "v_add_u32 v246, v228, v178\n\t"                                                                          \
-    "v_add_u32 v247, v229, v179\n\t"                                                                          \
-    "v_cmp_gt_u32 vcc, s44, v246\n\t"                                                                         \
-    "v_cmp_gt_u32_e64 s[68:69], s45, v247\n\t"                                                                \
-    "s_and_b64 s[68:69], s[68:69], vcc\n\t"                                                                   \
-    "s_and_b64 s[68:69], s[68:69], s[98:99]\n\t"                                                              \
-    "v_mad_u32_u24 v246, v247, s44, v246\n\t"                                                                 \
-    "v_cndmask_b32_e64 v246, 0, v246, s[68:69]\n\t"                                                           \
-    "v_lshlrev_b32 v247, 2, v246\n\t"                                                                         \
-    "v_lshlrev_b32 v246, 1, v246\n\t"                                                                         \
-    "global_load_ushort v248, v246, s[52:53]\n\t"                                                             \
-    "global_load_dword v249, v247, s[54:55]\n\t"                                                              \
     /* ---- openList.pop(): rounds, the climb, one pass of stores */                                          \
     A2T_STAMP("1")                                                                                            \
     "s_mov_b32 s78, 1\n\t"                                                                                    \
@@ -313,45 +362,7 @@
     A2T_STAMP("2")                                                                                            \
     "s_waitcnt vmcnt(2)\n\t"                                                                                  \
     A2T_STAMP("3")                                                                                            \
-    "v_lshrrev_b32 v222, 3, v216\n\t"                                                                         \
-    "v_cmp_ne_u32 vcc, s48, v222\n\t"           /* not closed by this search (lane 4: the popped cell itself) */ \
-    "s_and_b64 s[68:69], vcc, s[96:97]\n\t"                                                                   \
-    "s_andn2_b64 s[92:93], s[94:95], s[96:97]\n\t"   /* neighbour lanes inside the grid */                    \
-    "s_and_b64 s[92:93], s[92:93], vcc\n\t"          /* ... and not closed */                                 \
-    "s_mov_b64 exec, s[68:69]\n\t"                                                                            \
-    "global_store_dword v214, v218, s[54:55]\n\t"    /* closedList.push_back: the first entry per cell is the one observed */ \
-    "s_mov_b64 exec, -1\n\t"                                                                                  \
-    "s_add_i32 s41, s41, 1\n\t"                                                                               \
-    "v_min_u32 v223, s49, v215\n\t"                                                                           \
-    "v_lshl_add_u32 v223, v223, 2, s57\n\t"                                                                   \
-    "ds_read_b32 v224, v223\n\t"                     /* isValid + get_oCost by the cell's L1 distance */      \
-    "v_cmp_ne_u32 vcc, 0xffff, v215\n\t"                                                                      \
-    "s_and_b64 s[92:93], s[92:93], vcc\n\t"                                                                   \
-    "s_and_b64 s[36:37], s[36:37], vcc\n\t"                                                                   \
-    "s_and_b64 s[36:37], s[36:37], s[94:95]\n\t"                                                              \
-    "s_andn2_b64 s[36:37], s[36:37], s[96:97]\n\t"   /* goal neighbours: in grid, lanes 0..3 */               \
-    "v_add_u32 v217, 0xffff8000, v192\n\t"           /* fCost of the popped entry */                          \
-    "s_waitcnt lgkmcnt(0)\n\t"                                                                                \
-    "v_cmp_ne_u32 vcc, 0x80000000, v224\n\t"         /* the cell is valid */                                  \
-    "s_and_b64 s[92:93], s[92:93], vcc\n\t"                                                                   \
-    "s_and_b64 s[36:37], s[36:37], vcc\n\t"                                                                   \
-    "v_add_u32 v225, v219, v224\n\t"                 /* hCost + oCost */                                      \
-    "v_sub_u32 v226, v217, v225\n\t"                 /* lane 4: gCost of the popped node (never the start node here: its */ \
-    "s_nop 0\n\t"                                    /* expansion has a one-entry list; a lane read needs a wait state */ \
-    "v_readlane_b32 s86, v226, 4\n\t"                /* behind the VALU write of its source on gfx950) */     \
-    "s_add_i32 s86, s86, 0x800a\n\t"                 /* + 10 (get_gCost), + 32768 (key bias) */               \
-    "v_add_u32 v226, s86, v225\n\t"                  /* key of the neighbour's entry */                       \
-    "v_cmp_gt_u32 vcc, 0xffff, v226\n\t"             /* fNew < INT16_MAX (astar.cpp:103,124) */               \
-    "s_and_b64 s[92:93], s[92:93], vcc\n\t"                                                                   \
-    "s_mov_b32 s87, s92\n\t"                                                                                  \
-    "s_mov_b32 s88, s36\n\t"                                                                                  \
-    "s_cmp_eq_u32 s88, 0\n\t"                                                                                 \
-    "s_cbranch_scc1 45f\n\t"                                                                                  \
-    "s_sub_i32 s70, 0, s88\n\t"                      /* neighbours before the goal neighbour only */          \
-    "s_and_b32 s70, s70, s88\n\t"                                                                             \
-    "s_add_i32 s70, s70, -1\n\t"                                                                              \
-    "s_and_b32 s87, s87, s70\n\t"                                                                             \
-    "45:\n\t"                                                                                                 \
+    A2T_EXPAND("45")                                                                                          \
     A2T_STAMP("4")                                                                                            \
     A2T_PUSH_CHECK("50f") A2T_PUSH_REST                                                                       \
     A2T_PUSH_CHECK("50f") A2T_PUSH_READ A2T_PUSH_REST                                                         \

@@ -51,13 +51,28 @@ __global__ __launch_bounds__(64) void k_probe(unsigned long long* out, unsigned 
     { TIC(); asm volatile(R16("s_cmp_eq_u32 %0, 12345\ns_cbranch_scc1 1f\n" "s_nop 0\n1:\n") :: "s"(s1) : "scc"); TOC(20); }   // conditional branches not taken
     { TIC(); asm volatile(R16("s_cmp_lg_u32 %0, 12345\ns_cbranch_scc1 1f\n" R16("s_nop 0\n") "1:\n") :: "s"(s1) : "scc"); TOC(21); }   // conditional branches taken over 64 bytes
     { TIC(); asm volatile(R16("s_and_saveexec_b64 %0, vcc\ns_cbranch_execz 1f\ns_nop 0\n1:\ns_or_b64 exec, exec, %0\n") : "+s"(m) :: "memory"); TOC(22); }   // the compiler's divergent-if frame, body executed or skipped
+    {   // does a vector-memory instruction issued with EXEC = 0 count in vmcnt?  A cold load, then a load under an empty mask, then
+        // s_waitcnt vmcnt(1): if the masked one counts, the wait lasts as long as the cold load
+        unsigned long long p = (unsigned long long)(gbuf + 1024 + 64 * seed); unsigned off = (lane * 4) & 255, r0 = 0, r1 = 0;
+        TIC();
+        asm volatile("global_load_dword %0, %2, %3 sc1 sc0\n\ts_mov_b64 exec, 0\n\tglobal_load_dword %1, %2, %3 offset:2048\n\ts_mov_b64 exec, -1\n\ts_waitcnt vmcnt(1)\n"
+                     : "+v"(r0), "+v"(r1) : "v"(off), "s"(p) : "memory");
+        TOC(23);
+        v7 += r0 + r1;
+    }
+    {   unsigned long long p = (unsigned long long)(gbuf + 4096 + 64 * seed); unsigned off = (lane * 4) & 255, r0 = 0;
+        TIC();
+        asm volatile("global_load_dword %0, %1, %2 sc1 sc0\n\ts_waitcnt vmcnt(0)\n" : "+v"(r0) : "v"(off), "s"(p) : "memory");
+        TOC(24);
+        v7 += r0;
+    }
     if (v0 + v2 + v3 + v4 + v5 + v6 + v7 + s0 + (unsigned)m == 0x12345678u) out[63] = 1;
 }
 
 int main()
 {
     unsigned long long* d_out; unsigned int* d_g;
-    CHECK(hipMalloc((void**)&d_out, 64 * 8)); CHECK(hipMalloc((void**)&d_g, 4096));
+    CHECK(hipMalloc((void**)&d_out, 64 * 8)); CHECK(hipMalloc((void**)&d_g, 65536));
     std::vector<unsigned int> g(1024);
     for (int i = 0; i < 1024; ++i) g[i] = ((i * 37 + 11) & 1023) * 4;
     CHECK(hipMemcpy(d_g, g.data(), 4096, hipMemcpyHostToDevice));
@@ -68,14 +83,15 @@ int main()
                            "16 masked ds_write_b16 (exec set / restored)", "16 x (s_flbit -> v_readlane -> s_add)", "16 taken s_branch", "64 s_nop 0",
                            "16 x (ds_write, ds_read same address)", "16 dependent global loads (first touch)", "16 dependent global loads (warm)",
                            "16 x push tail (cmp, not, ff1, bfm, exec, ds_write, exec, v_add)", "16 x 3 dependent VALU", "16 x 5 dependent SALU",
-                           "16 taken s_branch over 64 bytes", "16 taken s_branch over 512 bytes", "16 x (s_cmp, s_cbranch not taken, s_nop)", "16 x (s_cmp, s_cbranch taken over 64 bytes)", "16 x (saveexec, cbranch_execz, nop, or exec)"};
-    const int per[] = {1, 64, 64, 64, 48, 32, 16, 32, 48, 48, 16, 64, 32, 16, 16, 128, 48, 80, 16, 16, 48, 32, 64};
+                           "16 taken s_branch over 64 bytes", "16 taken s_branch over 512 bytes", "16 x (s_cmp, s_cbranch not taken, s_nop)", "16 x (s_cmp, s_cbranch taken over 64 bytes)", "16 x (saveexec, cbranch_execz, nop, or exec)",
+                           "cold load + load under EXEC = 0 + vmcnt(1)", "cold load + vmcnt(0)"};
+    const int per[] = {1, 64, 64, 64, 48, 32, 16, 32, 48, 48, 16, 64, 32, 16, 16, 128, 48, 80, 16, 16, 48, 32, 64, 1, 1};
     for (int rep = 0; rep < 3; ++rep) {
         hipLaunchKernelGGL(k_probe, dim3(1), dim3(64), 65536, 0, d_out, d_g, rep);
         CHECK(hipDeviceSynchronize());
         CHECK(hipMemcpy(h, d_out, sizeof(h), hipMemcpyDeviceToHost));
     }
-    for (int i = 0; i < 23; ++i)
+    for (int i = 0; i < 25; ++i)
         printf("%-68s %6llu cycles  (%.1f per instruction after the clock's %llu)\n", names[i], h[i], i ? (double)((long long)h[i] - (long long)h[0]) / per[i] : 0.0, h[0]);
     return 0;
 }
