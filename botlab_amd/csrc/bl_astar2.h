@@ -630,7 +630,9 @@ __global__ __launch_bounds__(64) void k_astar2(astar_args a)
     const unsigned tbl = kbase + C::TBL_OFF;
     static_assert((C::TBL_OFF & 15) == 0, "table alignment");
     const bool turbo = fast && cost_in_lds && a2_turbo_enabled;
-    const bool deep = turbo && C::PLEV == C::LEV - 1 && (long long)a.heap_cap >= (1ll << (C::LEV + 6));
+    // (two rounds in global memory reach level LEV + 10 >= 22; the scratch bounds the list at 2^25 entries)
+    const unsigned deep_max = (unsigned)min((long long)a.heap_cap, 1ll << min(C::LEV + 11, 25)) - 4u;
+    const bool deep = turbo && C::PLEV == C::LEV - 1 && deep_max > (unsigned)C::PLN + 8u && deep_max < 0x7fffffffu;
     {
         a2_lds_u32* row = (a2_lds_u32*)(size_t)(tbl + 64u * (unsigned)lane);
         // cells two steps from the popped one (lanes 0..7): their lines are asked for one expansion ahead
@@ -651,7 +653,7 @@ __global__ __launch_bounds__(64) void k_astar2(astar_args a)
             sc[A2T_SC_LVL1] = 1u << (C::FD + 1); sc[A2T_SC_LVL2] = 1u << (C::FD + 6);
             sc[A2T_SC_GK] = (unsigned)(size_t)gk; sc[A2T_SC_GK + 1] = (unsigned)((size_t)gk >> 32);
             sc[A2T_SC_GP] = (unsigned)(size_t)gp; sc[A2T_SC_GP + 1] = (unsigned)((size_t)gp >> 32);
-            sc[A2T_SC_DLIM] = ((1u << (C::LEV + 6)) - 4u) - ((unsigned)C::PLN + 2u);     // the deep loop runs while PLN + 2 <= length <= 2^(LEV + 6) - 4
+            sc[A2T_SC_DLIM] = deep_max - ((unsigned)C::PLN + 2u);                         // the deep loop runs while PLN + 2 <= length <= deep_max
             for (int q = 24; q < 32; ++q) sc[q] = 0;
         }
         __syncthreads();
@@ -690,7 +692,7 @@ __global__ __launch_bounds__(64) void k_astar2(astar_args a)
             if (code == 3u) { res.status = ASTAR_ST_LIMIT; break; }
             if (len == 0) break;
         }
-        if (deep && len >= (unsigned)C::PLN + 2u && len <= (1u << (C::LEV + 6)) - 4u) {
+        if (deep && len >= (unsigned)C::PLN + 2u && len <= deep_max) {
             // ... and its form for open lists that reach into global memory (bl_astar2_deep.h)
             unsigned code, gm, ptop;
             unsigned s_len = (unsigned)__builtin_amdgcn_readfirstlane((int)len), s_pops = (unsigned)__builtin_amdgcn_readfirstlane((int)pops);

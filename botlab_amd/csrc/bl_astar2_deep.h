@@ -1,6 +1,6 @@
 // bl_astar2_deep.h -- the search loop of k_astar2 as one instruction stream for open lists that reach into global memory:
-// PLN + 2 <= length <= 2^(LEV + 6) - 4 (keys of levels 0 .. LEV and payloads of levels 0 .. LEV - 1 in LDS, the rest in the
-// search's global scratch; the walk of a pop takes three rounds in LDS and at most one in global memory).  Same operations as
+// PLN + 2 <= length <= capacity - 4 (keys of levels 0 .. LEV and payloads of levels 0 .. LEV - 1 in LDS, the rest in the
+// search's global scratch; the walk of a pop takes three rounds in LDS and one or two in global memory: up to 2^25 entries).  Same operations as
 // bl_astar2.h's C++ forms (a2_pop_deep, a2_push_general) and the same expansion as bl_astar2_turbo.h (its macros are used here).
 //
 // What the order of an iteration buys: a global round trip costs a lone wavefront 300 - 900 cycles, and nothing in the
@@ -25,41 +25,41 @@
     "global_load_dword v154, v153, s[32:33]\n\t"                                                              \
     "s_mov_b64 exec, -1\n\t"
 
-// the round in global memory, first half: node v155, 2 node + 1 -> v156, the children's keys asked for (v159; lanes without a left
-// child keep 0xFFFFFFFF); valid lanes -> s[82:83]
-#define A2D_ROUND3_ASK                                                                                        \
-    "v_lshl_add_u32 v155, s78, v180, v181\n\t"                                                                \
-    "v_cmp_gt_u32_e64 s[82:83], s40, v155\n\t"                                                                \
-    "s_and_b64 s[82:83], s[82:83], s[64:65]\n\t"                                                              \
-    "v_lshl_add_u32 v156, v155, 1, 1\n\t"                                                                     \
-    "v_cmp_gt_u32 vcc, s40, v156\n\t"                                                                         \
-    "s_and_b64 s[68:69], vcc, s[82:83]\n\t"                                                                   \
-    "v_lshl_add_u32 v220, v155, 2, 4\n\t"                                                                     \
-    "v_mov_b32 v159, -1\n\t"                                                                                  \
+// a round in global memory, first half: node N, 2 node + 1 -> C_, the children's keys asked for (PAIR; lanes without a left
+// child keep 0xFFFFFFFF); valid lanes -> SQ
+#define A2D_GROUND_ASK(N, C_, PAIR, SQ)                                                                       \
+    "v_lshl_add_u32 " N ", s78, v180, v181\n\t"                                                               \
+    "v_cmp_gt_u32_e64 " SQ ", s40, " N "\n\t"                                                                 \
+    "s_and_b64 " SQ ", " SQ ", s[64:65]\n\t"                                                                  \
+    "v_lshl_add_u32 " C_ ", " N ", 1, 1\n\t"                                                                  \
+    "v_cmp_gt_u32 vcc, s40, " C_ "\n\t"                                                                       \
+    "s_and_b64 s[68:69], vcc, " SQ "\n\t"                                                                     \
+    "v_lshl_add_u32 v220, " N ", 2, 4\n\t"                                                                    \
+    "v_mov_b32 " PAIR ", -1\n\t"                                                                              \
     "s_mov_b64 exec, s[68:69]\n\t"                                                                            \
-    "global_load_dword v159, v220, s[30:31]\n\t"                                                              \
+    "global_load_dword " PAIR ", v220, s[30:31]\n\t"                                                          \
     "s_mov_b64 exec, -1\n\t"
-// second half (the keys have arrived): a missing right child reads 0xFFFF; then as A2T_ROUND: mask s[82:83], child v156, knext
-// v157; the child's payload asked for (v158)
-#define A2D_ROUND3_DECIDE                                                                                     \
-    "v_add_u32 v221, 1, v156\n\t"                                                                             \
+// second half (the keys have arrived): a missing right child reads 0xFFFF; then as A2T_ROUND: mask SQ, child C_, knext K; the
+// child's payload asked for (P); the walk's deepest lane -> s70
+#define A2D_GROUND_DECIDE(N, C_, K, P, PAIR, SQ)                                                              \
+    "v_add_u32 v221, 1, " C_ "\n\t"                                                                           \
     "v_cmp_gt_u32 vcc, s40, v221\n\t"                                                                         \
-    "v_or_b32 v221, 0xffff0000, v159\n\t"                                                                     \
+    "v_or_b32 v221, 0xffff0000, " PAIR "\n\t"                                                                 \
     "s_nop 0\n\t"                                                                                             \
-    "v_cndmask_b32 v159, v221, v159, vcc\n\t"                                                                 \
-    "v_cmp_le_u32_sdwa vcc, v159, v159 src0_sel:WORD_1 src1_sel:WORD_0\n\t"                                   \
-    "v_min_u32_sdwa v157, v159, v159 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:WORD_1\n\t" \
+    "v_cndmask_b32 " PAIR ", v221, " PAIR ", vcc\n\t"                                                         \
+    "v_cmp_le_u32_sdwa vcc, " PAIR ", " PAIR " src0_sel:WORD_1 src1_sel:WORD_0\n\t"                           \
+    "v_min_u32_sdwa " K ", " PAIR ", " PAIR " dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:WORD_1\n\t" \
     "s_nop 1\n\t"                                                                                             \
     "v_and_b32 v222, vcc_lo, v182\n\t"                                                                        \
-    "v_addc_co_u32 v156, vcc, 0, v156, vcc\n\t"                                                               \
+    "v_addc_co_u32 " C_ ", vcc, 0, " C_ ", vcc\n\t"                                                           \
     "v_cmp_eq_u32 vcc, v222, v183\n\t"                                                                        \
-    "s_and_b64 s[82:83], vcc, s[82:83]\n\t"                                                                   \
-    "s_flbit_i32_b64 s70, s[82:83]\n\t"                                                                       \
+    "s_and_b64 " SQ ", vcc, " SQ "\n\t"                                                                       \
+    "s_flbit_i32_b64 s70, " SQ "\n\t"                                                                         \
     "s_sub_i32 s70, 63, s70\n\t"                                                                              \
-    "s_bitset0_b64 s[82:83], s70\n\t"                                                                         \
-    "v_lshlrev_b32 v220, 2, v156\n\t"                                                                         \
-    "s_mov_b64 exec, s[82:83]\n\t"                                                                            \
-    "global_load_dword v158, v220, s[32:33]\n\t"                                                              \
+    "s_bitset0_b64 " SQ ", s70\n\t"                                                                           \
+    "v_lshlrev_b32 v220, 2, " C_ "\n\t"                                                                       \
+    "s_mov_b64 exec, " SQ "\n\t"                                                                              \
+    "global_load_dword " P ", v220, s[32:33]\n\t"                                                             \
     "s_mov_b64 exec, -1\n\t"
 
 // the value (key v193, payload v197) lands on node s71, whichever tier it is in
@@ -85,8 +85,8 @@
     "global_store_dword v222, v197, s[32:33]\n\t"                                                             \
     "s_mov_b64 exec, -1\n\t"
 
-// stores of the round in global memory under mask M: lane 0's node sits on level LEV (an LDS key slot), the others' keys and all
-// payloads are global
+// stores of the first round in global memory under mask M: lane 0's node sits on level LEV (an LDS key slot), the others' keys
+// and all payloads are global
 #define A2D_STORE3(M)                                                                                         \
     "s_mov_b64 exec, -1\n\t"                                                                                  \
     "v_lshl_add_u32 v220, v155, 1, 2\n\t"                                                                     \
@@ -97,6 +97,15 @@
     "global_store_short v220, v157, s[30:31]\n\t"                                                             \
     "s_mov_b64 exec, " M "\n\t"                                                                               \
     "global_store_dword v221, v158, s[32:33]\n\t"                                                             \
+    "s_mov_b64 exec, -1\n\t"
+// ... of the second: everything global
+#define A2D_STORE4(M)                                                                                         \
+    "s_mov_b64 exec, -1\n\t"                                                                                  \
+    "v_lshl_add_u32 v220, v171, 1, 2\n\t"                                                                     \
+    "v_lshlrev_b32 v221, 2, v171\n\t"                                                                         \
+    "s_mov_b64 exec, " M "\n\t"                                                                               \
+    "global_store_short v220, v173, s[30:31]\n\t"                                                             \
+    "global_store_dword v221, v174, s[32:33]\n\t"                                                             \
     "s_mov_b64 exec, -1\n\t"
 
 // push_back + std::push_heap for a hole beyond the LDS payloads: READ asks for the ancestors' keys and payloads in whichever tier
@@ -282,13 +291,21 @@
     "s_branch 1b\n\t"                                                                                         \
     /* ================================================================== the walk goes on in global memory */ \
     "30:\n\t"                                                                                                 \
-    A2D_ROUND3_ASK                                                                                            \
+    A2D_GROUND_ASK("v155", "v156", "v159", "s[82:83]")                                                        \
     "s_waitcnt vmcnt(4)\n\t"                         /* the neighbours' loads (the round's keys still travel) */ \
     A2T_EXPAND("42")                                                                                          \
     "s_waitcnt vmcnt(1)\n\t"                                                                                  \
     "v_cndmask_b32_e64 v193, v193, v169, s[38:39]\n\t"                                                        \
     "v_cndmask_b32_e64 v243, v243, v154, s[84:85]\n\t"                                                        \
-    A2D_ROUND3_DECIDE                                                                                         \
+    A2D_GROUND_DECIDE("v155", "v156", "v157", "v158", "v159", "s[82:83]")                                     \
+    /* (open lists beyond 2^(LEV + 6) entries: the walk's node on the round's last level has a child -> a second global round) */ \
+    "v_readlane_b32 s78, v155, s70\n\t"                                                                       \
+    "s_lshl_b32 s71, s78, 1\n\t"                                                                              \
+    "s_add_i32 s71, s71, 1\n\t"                                                                               \
+    "s_cmp_lt_u32 s71, s40\n\t"                                                                               \
+    "s_cselect_b32 s71, s70, 0\n\t"                                                                           \
+    "s_cmp_ge_u32 s71, 31\n\t"                                                                                \
+    "s_cbranch_scc1 60f\n\t"                                                                                  \
     A2T_CLIMB("v156", "v157", "s[82:83]", "31f")                                                              \
     "32:\n\t"                                                                                                 \
     A2T_ADDR("v200", "v204") A2T_ADDR("v205", "v209") A2T_ADDR("v240", "v244")                                \
@@ -298,6 +315,28 @@
     A2D_STORE3("s[82:83]")                                                                                    \
     A2D_LAND                                                                                                  \
     "s_branch 45b\n\t"                                                                                        \
+    /* -- five rounds */                                                                                      \
+    "60:\n\t"                                                                                                 \
+    "s_add_i32 s78, s78, 1\n\t"                                                                               \
+    A2D_GROUND_ASK("v171", "v172", "v175", "s[34:35]")                                                        \
+    "s_waitcnt vmcnt(0)\n\t"                                                                                  \
+    A2D_GROUND_DECIDE("v171", "v172", "v173", "v174", "v175", "s[34:35]")                                     \
+    A2T_CLIMB("v172", "v173", "s[34:35]", "61f")                                                              \
+    "62:\n\t"                                                                                                 \
+    A2T_ADDR("v200", "v204") A2T_ADDR("v205", "v209") A2T_ADDR("v240", "v244")                                \
+    "s_waitcnt vmcnt(0) lgkmcnt(0)\n\t"                                                                       \
+    A2T_STORE("v200", "v204", "v202", "v203", "s[72:73]") A2T_STORE("v205", "v209", "v207", "v208", "s[74:75]") \
+    A2T_STORE("v240", "v244", "v242", "v243", "s[76:77]")                                                     \
+    A2D_STORE3("s[82:83]")                                                                                    \
+    A2D_STORE4("s[34:35]")                                                                                    \
+    A2D_LAND                                                                                                  \
+    "s_branch 45b\n\t"                                                                                        \
+    "61:\n\t"                                                                                                 \
+    A2T_RARE_UP("s[34:35]", "v156", "v157", "s[82:83]", "62b", "63")                                          \
+    A2T_RARE_UP("s[82:83]", "v241", "v242", "s[76:77]", "62b", "64")                                          \
+    A2T_RARE_UP("s[76:77]", "v206", "v207", "s[74:75]", "62b", "65")                                          \
+    A2T_RARE_UP("s[74:75]", "v201", "v202", "s[72:73]", "62b", "66")                                          \
+    A2T_RARE_ROOT("s[72:73]", "62b")                                                                          \
     /* rare climbs */                                                                                         \
     "31:\n\t"                                                                                                 \
     A2T_RARE_UP("s[82:83]", "v241", "v242", "s[76:77]", "32b", "33")                                          \
@@ -328,6 +367,6 @@
 
 #define A2D_CLOBBERS A2T_CLOBBERS, "s30", "s31", "s32", "s33", "s34", "s35",                                  \
     "v150", "v151", "v152", "v153", "v154", "v155", "v156", "v157", "v158", "v159", "v160", "v161", "v162", "v163", "v164", "v165", "v166", "v167", \
-    "v168", "v169", "v170"
+    "v168", "v169", "v170", "v171", "v172", "v173", "v174", "v175"
 
 #endif
