@@ -630,6 +630,7 @@ __global__ __launch_bounds__(64) void k_astar2(astar_args a)
     const unsigned tbl = kbase + C::TBL_OFF;
     static_assert((C::TBL_OFF & 15) == 0, "table alignment");
     const bool turbo = fast && cost_in_lds && a2_turbo_enabled;
+    const bool ahead = (long long)a.W * a.H * 6 > (3ll << 20);
     // (two rounds in global memory reach level LEV + 10 >= 22; the scratch bounds the list at 2^25 entries)
     const unsigned deep_max = (unsigned)min((long long)a.heap_cap, 1ll << min(C::LEV + 11, 25)) - 4u;
     const bool deep = turbo && C::PLEV == C::LEV - 1 && deep_max > (unsigned)C::PLN + 8u && deep_max < 0x7fffffffu;
@@ -681,7 +682,14 @@ __global__ __launch_bounds__(64) void k_astar2(astar_args a)
             unsigned code, gm, ptop;
             unsigned s_len = (unsigned)__builtin_amdgcn_readfirstlane((int)len), s_pops = (unsigned)__builtin_amdgcn_readfirstlane((int)pops);
             unsigned s_pushes = (unsigned)__builtin_amdgcn_readfirstlane((int)pushes);
-            asm volatile(A2T_BODY
+            // (grids whose distance + closed arrays fit the L2 gain nothing from asking for lines ahead)
+            if (ahead) asm volatile(A2T_BODY(A2T_PREFETCH, "2")
+                         : [len] "+s"(s_len), [pops] "+s"(s_pops), [pushes] "+s"(s_pushes), [code] "=&s"(code), [gm] "=&s"(gm), [pt] "=&s"(ptop)
+                         : [tbl] "s"(__builtin_amdgcn_readfirstlane((int)tbl)), [kmax] "n"(C::KEY_BYTES - 4), [pln] "n"(C::PLN),
+                           [ok0lo] "n"((unsigned)(((2ull << ((1 << (C::FD + 1)) - 2)) - 1ull) & 0xffffffffull)),
+                           [ok0hi] "n"((unsigned)(((2ull << ((1 << (C::FD + 1)) - 2)) - 1ull) >> 32))
+                         : A2T_CLOBBERS);
+            else asm volatile(A2T_BODY("", "0")
                          : [len] "+s"(s_len), [pops] "+s"(s_pops), [pushes] "+s"(s_pushes), [code] "=&s"(code), [gm] "=&s"(gm), [pt] "=&s"(ptop)
                          : [tbl] "s"(__builtin_amdgcn_readfirstlane((int)tbl)), [kmax] "n"(C::KEY_BYTES - 4), [pln] "n"(C::PLN),
                            [ok0lo] "n"((unsigned)(((2ull << ((1 << (C::FD + 1)) - 2)) - 1ull) & 0xffffffffull)),

@@ -253,6 +253,7 @@
     "global_load_dword v197, v170, s[32:33]\n\t"                                                              \
     "s_waitcnt lgkmcnt(2)\n\t"                                                                                \
     A2T_NBR                                                                                                   \
+    A2T_PREFETCH                                                                                              \
     /* the slot the last entry leaves is "behind the heap" from here on (an LDS slot: 0xFFFF) */              \
     "s_andn2_b64 exec, 1, s[38:39]\n\t"                                                                       \
     "ds_write_b16 v191, v176\n\t"                                                                             \

@@ -157,9 +157,8 @@
     "s_add_i32 s70, s87, -1\n\t"                                                                              \
     "s_and_b32 s87, s87, s70\n\t"                                                                             \
     "v_readlane_b32 s89, v226, s91\n\t"                                                                       \
-    "v_readlane_b32 s90, v227, s91\n\t"                                                                       \
     "s_waitcnt lgkmcnt(1)\n\t"                                                                                \
-    "s_nop 0\n\t"                                                                                             \
+    "s_nop 1\n\t"                                                                                             \
     "v_cmp_lt_u32 vcc, s89, v234\n\t"                                                                         \
     "s_not_b64 s[92:93], vcc\n\t"                                                                             \
     "s_ff1_i32_b64 s70, s[92:93]\n\t"                                                                         \
@@ -170,16 +169,14 @@
     "s_add_i32 s70, s70, s56\n\t"                                                                             \
     "s_add_i32 s70, s70, -4\n\t"                                                                              \
     "s_waitcnt lgkmcnt(0)\n\t"                                                                                \
+    "v_mov_b32 v232, s71\n\t"                                                                                 \
+    "v_mov_b32 v238, s70\n\t"                                                                                 \
     "s_mov_b64 exec, s[92:93]\n\t"                                                                            \
     "ds_write_b16 v236, v234\n\t"                                                                             \
     "ds_write_b32 v237, v235\n\t"                                                                             \
-    "s_mov_b64 exec, 1\n\t"                                                                                   \
-    "v_mov_b32 v232, s71\n\t"                                                                                 \
-    "v_mov_b32 v233, s89\n\t"                                                                                 \
-    "v_mov_b32 v238, s70\n\t"                                                                                 \
-    "v_mov_b32 v239, s90\n\t"                                                                                 \
-    "ds_write_b16 v232, v233\n\t"                                                                             \
-    "ds_write_b32 v238, v239\n\t"                                                                             \
+    "s_lshl_b64 exec, 1, s91\n\t"                    /* the entry itself: straight from the lane that holds it */ \
+    "ds_write_b16 v232, v226\n\t"                                                                             \
+    "ds_write_b32 v238, v227\n\t"                                                                             \
     "s_mov_b64 exec, -1\n\t"                                                                                  \
     "s_add_i32 s40, s40, 1\n\t"                                                                               \
     "s_add_i32 s42, s42, 1\n\t"
@@ -217,8 +214,11 @@
     "v_lshlrev_b32 v213, 1, v212\n\t"                                                                         \
     "v_lshlrev_b32 v214, 2, v212\n\t"                                                                         \
     "global_load_ushort v215, v213, s[52:53]\n\t"                                                             \
-    "global_load_dword v216, v214, s[54:55] sc1\n\t"                                                          \
-    /* the lines of the cells two steps away, asked for now and never waited for: the next expansions find them in the L2 */ \
+    "global_load_dword v216, v214, s[54:55] sc1\n\t"
+
+// the lines of the cells two steps away, asked for now and never waited for (grids that do not fit the L2: the next expansions
+// find them there)
+#define A2T_PREFETCH                                                                                          \
     "v_add_u32 v246, v228, v178\n\t"                                                                          \
     "v_add_u32 v247, v229, v179\n\t"                                                                          \
     "v_cmp_gt_u32 vcc, s44, v246\n\t"                                                                         \
@@ -277,7 +277,7 @@
 
 #define A2T_RSF(dst, idx) "v_readfirstlane_b32 " dst ", " idx "\n\t"
 
-#define A2T_BODY                                                                                              \
+#define A2T_BODY(PREFETCH, VMWAIT)                                                                            \
     /* ---- entry: state and constants */                                                                     \
     "s_mov_b32 s40, %[len]\n\t"                                                                               \
     "s_mov_b32 s41, %[pops]\n\t"                                                                              \
@@ -336,6 +336,7 @@
     "s_add_i32 s40, s40, -1\n\t"                                                                              \
     "s_waitcnt lgkmcnt(3)\n\t"                                                                                \
     A2T_NBR                                                                                                   \
+    PREFETCH                                                                                                  \
     /* the slot the last entry leaves is "behind the heap" from here on */                                    \
     "s_mov_b64 exec, 1\n\t"                                                                                   \
     "ds_write_b16 v191, v176\n\t"                                                                             \
@@ -360,7 +361,7 @@
     "40:\n\t"                                                                                                 \
     A2T_PUSH_READ                               /* (the first push's ancestors: read while the expansion computes) */ \
     A2T_STAMP("2")                                                                                            \
-    "s_waitcnt vmcnt(2)\n\t"                                                                                  \
+    "s_waitcnt vmcnt(" VMWAIT ")\n\t"                                                                         \
     A2T_STAMP("3")                                                                                            \
     A2T_EXPAND("45")                                                                                          \
     A2T_STAMP("4")                                                                                            \

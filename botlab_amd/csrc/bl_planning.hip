@@ -3049,7 +3049,9 @@ extern "C" int bl_planner_create_batched(bl_ctx* ctx, int lanes, int batch, bl_p
             int rc = bl_ctx_create(ctx->device, u == 0 ? nullptr : (void*)L.side->stream, &U.ctx);
             if (rc) return rc;
             if (u == 0) L.side = U.ctx;
-            U.ctx->astar_small_lds = true;       // co-runs with the SLAM stream's kernels
+            // searches that co-run with the SLAM stream's kernels take the small LDS footprint; a planner with one search in flight
+            // (the closed loop: every path fetched before the next step) gives it a CU's whole LDS
+            U.ctx->astar_small_lds = lanes * batch > 1;
             // open list of a unit: 4 M entries (32 MB) unless BOTLAB_PLANNER_OPEN_CAPACITY says otherwise -- up to 4 x 32 units exist
             U.ctx->astar_capacity = getenv("BOTLAB_PLANNER_OPEN_CAPACITY") ? atoll(getenv("BOTLAB_PLANNER_OPEN_CAPACITY")) : ((int64_t)1 << 22);
             rc = bl_dist_create(U.ctx, &U.dist);
