@@ -205,7 +205,7 @@ def cpu_baseline(args, m, odo, scans, rands, goal, n_steps):
     res = pf.update(orc.pose(*o, utime=scans[0].utime), scans[0], cells, m["mpc"], cpm, m["origin"], int(rands[0]))
     om.update(scans[0], res["pose"], cells, m["mpc"], cpm, m["origin"])
     t0 = time.perf_counter()
-    pops = 0
+    pops, plans, t_plan = 0, 0, 0.0
     for k in range(1, 1 + n_steps):
         o = odo[k + 1]
         res = pf.update(orc.pose(*o, utime=scans[k].utime), scans[k], cells, m["mpc"], cpm, m["origin"], int(rands[k]))
@@ -214,11 +214,94 @@ def cpu_baseline(args, m, odo, scans, rands, goal, n_steps):
             d = orc.set_distances(cells, m["mpc"], cpm, m["origin"])
             _, st = orc.search(res["pose"], orc.pose(goal[0], goal[1], 0.0), d, m["mpc"], cpm, m["origin"], 0.2, 2.0)
             pops += st[0]
+        elif getattr(args, "explore", False) and k % 5 == 0:
+            # the exploration step on every 5th map (slam.cpp:285-289 publishes it, exploration.cpp:277-369 plans on it)
+            tp = time.perf_counter()
+            d = orc.set_distances(cells, m["mpc"], cpm, m["origin"])
+            fr = orc.find_frontiers(cells, m["mpc"], cpm, m["origin"], res["pose"])
+            if fr:
+                _, _, st = orc.plan_path_to_frontier(fr, res["pose"], d, m["mpc"], cpm, m["origin"], 0.2, 0.2, 2.0)
+                pops += st[0]
+                plans += 1
+            t_plan += time.perf_counter() - tp
     dt = time.perf_counter() - t0
+    what = f"A* {pops // max(n_steps, 1)} pops/step"
+    if getattr(args, "explore", False):
+        what = f"an exploration step on every 5th map: {plans} plans to a frontier, {pops} pops, {t_plan:.2f} s of the {dt:.2f} s"
     return dict(value=n_steps / dt, unit="steps/s", cores=1, kind="port",
                 sample=f"{n_steps} full steps of the same workload ({N} particles, {scans[0].num_ranges} rays, "
-                       f"{cells.shape[1]}x{cells.shape[0]} grid, A* {pops // max(n_steps, 1)} pops/step), oracle on 1 thread, "
+                       f"{cells.shape[1]}x{cells.shape[0]} grid, {what}), oracle on 1 thread, "
                        f"{os.cpu_count()} host cores visible")
+
+
+ASTAR_FIXTURE_MAPS = ["empty", "filled", "narrow", "wide", "convex", "maze"]
+ASTAR_FIXTURE_EXCLUDED = {("narrow", 2): "the search must exhaust the whole free side (2.6e8 pops in the reference's own algorithm): excluded on both sides"}
+
+
+def astar_fixtures(ctx, reps=5, long_pops=100_000, cpu=True):
+    """The reference's own published table: astar_test (src/planning/astar_test.cpp:196-332, 407-426) runs planner.planPath on the
+    start / goal pairs of data/astar/*_poses.txt for its six maps (robotRadius 0.1, :227-228), files the wall time of every call
+    under 'successful' (path_length > 1) or 'failed' planning attempts per map and prints mean / median / std in microseconds
+    (report/saptadeb-botlab.tex:172 quotes them).  The same table for the HIP path (MotionPlanner.planPath through the C ABI: the
+    validity gather + k_astar2 + the path's way back to the host, `reps` calls per pair -- one for searches of more than
+    `long_pops` pops) and for the CPU oracle on one host core, with the pops behind every row.  The median is the exact one
+    (astar_test's boost accumulator estimates it)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import helpers
+    import botlab_amd as bl
+    orc = None
+    if cpu:
+        import oracle_lib
+        orc = oracle_lib.load_oracle()
+    cpm = helpers.CPM_DEFAULT
+    cases = helpers.load_astar_cases()
+
+    def stats(v):
+        if not v:
+            return None
+        a = np.asarray(v, dtype=np.float64)
+        return {"n": int(a.size), "mean_us": round(float(a.mean()), 1), "median_us": round(float(np.median(a)), 1), "std_us": round(float(a.std()), 1)}
+
+    rows = {}
+    for name in ASTAR_FIXTURE_MAPS:
+        m = load_map("astar_" + name)
+        g = bl.OccupancyGrid.from_cells(m["cells"], m["origin"], m["mpc"], cellsPerMeter=cpm, ctx=ctx)
+        planner = bl.MotionPlanner(bl.MotionPlannerParams(0.1), ctx=ctx)
+        planner.setMap(g)
+        dist = orc.set_distances(m["cells"], m["mpc"], cpm, m["origin"]) if orc else None
+        gs, gf, cs, cf, pops, excluded = [], [], [], [], 0, []
+        for i, row in enumerate(cases[name]):
+            if (name, i) in ASTAR_FIXTURE_EXCLUDED:
+                excluded.append({"case": i, "why": ASTAR_FIXTURE_EXCLUDED[(name, i)]})
+                continue
+            s, gl = bl.make_pose(row["start"][0], row["start"][1], 0.0), bl.make_pose(row["goal"][0], row["goal"][1], 0.0)
+            n_rep = reps
+            for r in range(reps):
+                if r >= n_rep:
+                    break
+                ctx.sync()
+                t0 = time.perf_counter()
+                path, st = planner.planPath(s, gl, return_stats=True)
+                dt = (time.perf_counter() - t0) * 1e6
+                (gs if len(path) > 1 else gf).append(dt)
+                if r == 0:
+                    pops += st[0]
+                    if st[0] > long_pops:
+                        n_rep = 1
+            if orc:
+                os_, og = orc.pose(*row["start"], 0.0), orc.pose(*row["goal"], 0.0)
+                t0 = time.perf_counter()
+                if orc.is_valid_goal(og, dist, m["mpc"], cpm, m["origin"], 0.1, 0.1):
+                    exp, est = orc.search(os_, og, dist, m["mpc"], cpm, m["origin"], 0.1, 1.0)
+                    ok = len(exp) > 1
+                else:
+                    ok = False
+                (cs if ok else cf).append((time.perf_counter() - t0) * 1e6)
+        rows[name] = {"pairs": len(cases[name]) - len(excluded), "pops": int(pops), "hip": {"success": stats(gs), "failed": stats(gf)},
+                      "cpu_oracle_1_core": {"success": stats(cs), "failed": stats(cf)} if orc else None}
+        if excluded:
+            rows[name]["excluded"] = excluded
+    return {"source": "data/astar fixtures (tests/golden), astar_test.cpp:306-332, 407-426", "reps_per_pair": reps, "rows": rows}
 
 
 PHASE_LIMIT_S = {                  # how long a multi-rank run may stay in one phase before the launcher ends it (first contact with
@@ -316,7 +399,7 @@ OTHER_CONFIGS = [                                      # (preset, goal_l1 in cel
     (0, 0, ["--depth", "0", "--lanes", "1", "--batch", "1", "--sync-steps", "200"]),
     (4, 400, ["--depth", "0", "--lanes", "1", "--batch", "1", "--sync-steps", "200"]),
 ]
-OTHER_BUDGET_S = 330.0                                 # wall clock all of them together may take: a slow or hung child costs the others, never the headline
+OTHER_BUDGET_S = 420.0                                 # wall clock all of them together may take: a slow or hung child costs the others, never the headline
 
 
 def run_other_configs(steps, warmup):
@@ -340,11 +423,14 @@ def run_other_configs(steps, warmup):
             i = extra.index("--sync-steps")
             child_steps = int(extra[i + 1])
             extra = extra[:i] + extra[i + 2:]
+        # rows with a planner leg carry their own CPU baseline: the oracle on a short sample of the same inputs (pops stated)
+        planner_leg = cfg in (4, 5) and "--explore-mode" not in extra
+        cpu_steps = (5 if cfg == 5 and "--fixed-goal" not in extra else 3) if planner_leg else 0
         cmd = [sys.executable, os.path.abspath(__file__), "--config", str(cfg), "--goal-l1", str(max(l1, 1)), "--steps", str(child_steps), "--warmup", str(warmup),
-               "--cpu-steps", "0", "--sub"] + extra
+               "--cpu-steps", str(cpu_steps), "--sub"] + extra
         t0 = time.perf_counter()
         try:
-            r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=min(120.0, left))
+            r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=min(150.0, left))
             line = [l for l in r.stdout.decode(errors="replace").splitlines() if l.startswith("{")]
             if r.returncode != 0 or not line:
                 err = [l for l in r.stderr.decode(errors="replace").splitlines() if l.strip()]
@@ -355,6 +441,7 @@ def run_other_configs(steps, warmup):
                         "steps": d["steps"], "warmup": d["warmup"], "ms_per_step": d["ms_per_step"], "astar_pops_per_step": d["astar_pops_per_step"],
                         "stage_ms": d["stage_ms"], "planner": [d["config"]["planner_lanes"], d["config"]["planner_batch"], d["config"]["pipeline_depth"]],
                         "streaming_kernels": d.get("streaming_kernels"), "explore": d.get("explore"), "particles": d["config"]["particles"],
+                        "cpu_baseline": d.get("cpu_baseline"),
                         "wall_s": round(time.perf_counter() - t0, 1)})
         except subprocess.TimeoutExpired:
             out.append({"config": cfg, "goal_l1_cells": l1, "flags": extra, "error": "timed out"})
@@ -457,6 +544,7 @@ def main():
                          "steps back, and a map published while every lane is busy is not explored (counted)")
     ap.add_argument("--preheat-ms", type=float, default=300.0, help="milliseconds of unrelated GPU load (matrix products) before the warmup steps, "
                     "so that a short run is not a measurement of the clock ramp after the idle seconds of input synthesis (0 = off)")
+    ap.add_argument("--astar-fixtures", action="store_true", help="only the reference's own A* table (astar_test's six maps): one JSON line")
     ap.add_argument("--sub", action="store_true", help="a child run of the default invocation (other_configs): no children of its own")
     ap.add_argument("--no-other-configs", action="store_true", help="default run: skip the short runs of configs 4 and 5")
     ap.add_argument("--other-steps", type=int, default=1000, help="timed steps of each other_configs run")
@@ -503,6 +591,11 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: botlab_amd has no CPU path")
+    if args.astar_fixtures:
+        torch.cuda.init()
+        table = astar_fixtures(bl.default_context(), reps=5)
+        os.write(json_fd, (json.dumps({"astar_fixtures": table}) + "\n").encode())
+        return
     phase(json_fd, "process-group")
     # Test hook (tests/test_gpu_bench_two_ranks.py): exercise the N > 1 code path on a one-GPU box -- every rank on cuda:0 and
     # the collectives over gloo (RCCL refuses two ranks on one device).  Never set by the driver.
@@ -975,6 +1068,9 @@ def main():
             out["particle_sweep_steps_per_s"][str(args.particles)] = round(args.steps / elapsed, 1)
         if args.cpu_steps > 0 and world == 1:
             out["cpu_baseline"] = cpu_baseline(args, m, odo, scans, rands, goal, args.cpu_steps)
+        if other is not None and world == 1:
+            # the reference's own published table (astar_test's six maps), HIP path beside the CPU oracle
+            out["astar_fixtures"] = astar_fixtures(ctx, reps=3)
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     phase(json_fd, "teardown")

@@ -726,10 +726,11 @@ class MotionPlanner:
             return float(self.distances_(gx, gy)) > self.params_.robotRadius
         return False
 
-    def planPath(self, start, goal, searchParams=None):
+    def planPath(self, start, goal, searchParams=None, return_stats=False):
         if not self.isValidGoal(goal):
-            return [Pose(start.utime, start.x, start.y, start.theta)]   # failedPath (motion_planner.cpp:28-40)
-        return search_for_path(start, goal, self.distances_, searchParams or self.searchParams_)
+            failed = [Pose(start.utime, start.x, start.y, start.theta)]   # failedPath (motion_planner.cpp:28-40)
+            return (failed, (0, 0)) if return_stats else failed
+        return search_for_path(start, goal, self.distances_, searchParams or self.searchParams_, return_stats=return_stats)
 
     def isPathSafe(self, path):
         # motion_planner.cpp:77-96 (one gather for all poses); a pose outside the grid is unsafe
