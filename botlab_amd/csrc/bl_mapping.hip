@@ -113,6 +113,10 @@ __device__ __forceinline__ void map_update_body(const map_args& a, int8_t* snap,
 __global__ __launch_bounds__(MAP_THREADS) void k_map_update(map_args a)
 {
     __shared__ mclf_smem s_fin;
+    // the finish that rides here belongs to a sharded particle set whose exchange gave up (k_shard_wait, bl_mcl.hip): no finish, and
+    // no map store from a pose that was never formed -- the scan's way to the device (the last rider) still runs
+    const bool broken = a.fin_on && a.fin.sh && __hip_atomic_load(&a.fin.state->shard_broken, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
+    if (broken && !(a.pre_on && blockIdx.x == gridDim.x - 1 && blockIdx.x > 0)) return;
     if (blockIdx.x > 0) {                                       // riders
         if (a.pre_on && blockIdx.x == gridDim.x - 1) {
             for (int i = threadIdx.x; i < a.pre.kept; i += MAP_THREADS) {

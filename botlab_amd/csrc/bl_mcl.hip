@@ -98,6 +98,7 @@ struct bl_pf {
     // exchange block into every other rank's buffers (their memory, mapped into this process) and raises a per-source counter
     // there; the consuming launches are preceded by a one-wave wait on those counters
     bool sh_peer;                              // the form is set up (every rank's buffers are mapped)
+    bool sh_broken;                            // the host has seen pf_state::shard_broken (sticky until the shards are set up again)
     unsigned long long* sh_flags;              // device: [2][BL_MAX_SHARDS] -- the update number rank r's sums / block are here for
     double* sh_peer_sums[BL_MAX_SHARDS];       // every rank's tile-sum buffer (both parities), exchange blocks and counters as THIS process sees them
     char* sh_peer_xchg[BL_MAX_SHARDS];
@@ -696,6 +697,8 @@ __global__ __launch_bounds__(BLOCK) void k_mcl_main(mcl_args a)
     // Two regions in one launch (see "Whole rounds" in pf_launch_main): workgroups [0, main_blocks) take BLOCK >> split_log2
     // particles each, 2^split_log2 lanes per particle; the workgroups after them take the remaining particles one per
     // wave (64 lanes over the rays), so that the last partial round of the machine lasts a tenth of a full one.
+    // composed shard whose exchange gave up (k_shard_wait): the other ranks' records and prefix are not what this update needs
+    if (a.sh && __hip_atomic_load(&a.state->shard_broken, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;
     const bool tail = (int)blockIdx.x >= a.main_blocks;
     const int sl2 = tail ? 6 : a.split_log2;
     const int split = 1 << sl2;
@@ -1066,6 +1069,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan_write_prefix(const float4
 __global__ __launch_bounds__(MCLF_WG) void k_mcl_finish(mcl_finish_args f)
 {
     __shared__ mclf_smem sm;
+    if (f.sh && __hip_atomic_load(&f.state->shard_broken, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;     // (an exchange of this set gave up: k_shard_wait)
     extern __shared__ __align__(16) char s_fin_scratch[];                  // MCLF_LDS_BYTES (the groups do not touch it)
     if (blockIdx.x == 0) mclf_pose(f, sm, s_fin_scratch, (size_t)MCLF_LDS_BYTES);
     else if (blockIdx.x == 1) mclf_pre_chain(f, sm);
@@ -1077,6 +1081,7 @@ __global__ __launch_bounds__(MCLF_WG) void k_mcl_finish(mcl_finish_args f)
 __global__ __launch_bounds__(MCLF_WG) void k_shard_groups(mcl_finish_args f, int group0)
 {
     __shared__ mclf_smem sm;
+    if (__hip_atomic_load(&f.state->shard_broken, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;
     mclf_prefix_group(f, group0 + (int)blockIdx.x, sm);
 }
 
@@ -1426,6 +1431,7 @@ extern "C" int bl_pf_init_at_pose(bl_pf* pf, const bl_pose_xyt_t* pose, uint64_t
     BL_HIP(hipSetDevice(pf->ctx->device));
     if (!pf->prefix) { int rc = pf_alloc(pf); if (rc) return rc; }
     pf->cur = 0;
+    if (pf->sh_broken) { pf->sh_broken = false; BL_HIP(hipMemsetAsync(&pf->state->shard_broken, 0, sizeof(unsigned int), pf->ctx->stream)); }
     hipLaunchKernelGGL(k_pf_init, dim3((pf->N + 255) / 256), dim3(256), 0, pf->ctx->stream, pf->rec[0], pf->parent, pf->N,
                        pf->lo, pf->n_local, *pose, (uint32_t)seed, (uint32_t)(seed >> 32));
     hipLaunchKernelGGL(k_pf_set_pose, dim3(1), dim3(1), 0, pf->ctx->stream, pf->state, *pose, 0);
@@ -1477,7 +1483,11 @@ extern "C" int bl_pf_get_particles(bl_pf* pf, bl_particle_t* out_local)
     BL_HIP(hipGetLastError());
     BL_HIP(hipMemcpyAsync(out_local, pf->d_export, (size_t)pf->n_local * sizeof(bl_particle_t), hipMemcpyDeviceToHost,
                           pf->ctx->stream));
+    unsigned int broken = 0;
+    if (pf->sh_world > 1) BL_HIP(hipMemcpyAsync(&broken, &pf->state->shard_broken, sizeof(broken), hipMemcpyDeviceToHost, pf->ctx->stream));
     BL_HIP(hipStreamSynchronize(pf->ctx->stream));
+    if (broken) pf->sh_broken = true;
+    if (pf->sh_broken) { bl_set_error("the shard exchange of this particle set gave up: its particles are not a valid posterior; set the shards up again or re-initialise the filter"); return BL_ERR_STATE; }
     return BL_OK;
 }
 
@@ -1487,6 +1497,7 @@ extern "C" int64_t bl_pf_encode_particles_lcm(bl_pf* pf, int64_t utime, uint8_t*
 {
     if (!pf || !buf) { bl_set_error("bad argument"); return -(int64_t)BL_ERR_ARG; }
     if (!pf->initialized || pf->pending_end) { bl_set_error("filter not initialised or update pending"); return -(int64_t)BL_ERR_STATE; }
+    if (pf->sh_broken) { bl_set_error("the shard exchange of this particle set gave up: its particles are not a valid posterior"); return -(int64_t)BL_ERR_STATE; }
     const int64_t body = (int64_t)pf->n_local * 48, total = 20 + body;
     if (total > cap) { bl_set_error("LCM encode: %lld bytes do not fit the %lld-byte buffer", (long long)total, (long long)cap); return -(int64_t)BL_ERR_CAPACITY; }
     if (hipSetDevice(pf->ctx->device) != hipSuccess) return -(int64_t)BL_ERR_HIP;
@@ -1741,6 +1752,7 @@ extern "C" int bl_pf_update_begin(bl_pf* pf, const bl_pose_xyt_t* odometry, cons
     BL_CHECK_ARG(pf != nullptr && odometry != nullptr && scan != nullptr && map != nullptr);
     if (!pf->initialized) { bl_set_error("bl_pf_update before bl_pf_init_at_pose / bl_pf_set_particles"); return BL_ERR_STATE; }
     if (pf->pending_end) { bl_set_error("bl_pf_update_begin called twice without bl_pf_update_end"); return BL_ERR_STATE; }
+    if (pf->sh_broken) { bl_set_error("the shard exchange of this particle set gave up earlier: set the shards up again or re-initialise the filter"); return BL_ERR_STATE; }
     BL_HIP(hipSetDevice(pf->ctx->device));
     bool mv = action_update(pf, *odometry);
     if (moved) *moved = mv ? 1 : 0;
@@ -1890,6 +1902,9 @@ extern "C" int bl_pf_shard_setup(bl_pf* pf, int rank, int world, int block)
     pf->scan_blocks = tiles;
     pf->sh_tiles_all = tiles;
     pf->sh_peer = false; pf->sh_gen = 0;
+    pf->sh_broken = false;                                         // a set whose exchange gave up starts over here
+    BL_HIP(hipMemsetAsync(&pf->state->shard_broken, 0, sizeof(unsigned int), pf->ctx->stream));
+    BL_HIP(hipMemsetAsync(&pf->state->wait_timeouts, 0, sizeof(unsigned int), pf->ctx->stream));
     if (!pf->sh_flags) {
         // The counters are POLLED while other devices store into them: fine-grained device memory, which this device's L2 does not
         // keep (a coarse-grained line, once fetched by a poll, would be served from the L2 for ever: a remote store does not pass
@@ -2090,15 +2105,26 @@ __global__ __launch_bounds__(1024) void k_shard_push(const shard_peers* __restri
         __hip_atomic_store(peers->flags[r] + kind * BL_MAX_SHARDS + rank, gen, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
-// One wave: until every other rank's slot of this rank's counter table has reached `gen` (lane r watches rank r)
+// One wave: until every other rank's slot of this rank's counter table has reached `gen` (lane r watches rank r).  Ranks run
+// skewed by whatever their hosts do (a first launch that loads code, a host that plans for seconds inside a fetch, another process
+// on the device), so this wait has its own limit on the 100 MHz clock -- `limit_ticks`, tens of seconds unless
+// BOTLAB_SHARD_WAIT_MS says otherwise -- not the spin count of the waits inside one launch.  When it does give up the particle
+// set can no longer be trusted: it sets the STICKY pf_state::shard_broken, which turns this update's groups, finish, map store
+// and every later k_mcl_main of the set into no-ops and makes every later wait return at once; the host reports BL_ERR_STATE from
+// every call that fetches the pose until the shards are set up again (bl_pf_shard_setup) or the filter re-initialised.
 __global__ __launch_bounds__(64) void k_shard_wait(const unsigned long long* __restrict__ flags, int kind, int rank, int world, unsigned long long gen,
-                                                   pf_state* __restrict__ state)
+                                                   pf_state* __restrict__ state, unsigned long long limit_ticks)
 {
     const int r = threadIdx.x;
     if (r >= world || r == rank) return;
-    unsigned int spins = 0;
+    if (__hip_atomic_load(&state->shard_broken, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
     while (__hip_atomic_load(flags + kind * BL_MAX_SHARDS + r, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < gen) {
-        if (++spins > MCLF_SPIN_LIMIT) { atomicAdd(&state->wait_timeouts, 1u); break; }
+        if (__builtin_amdgcn_s_memrealtime() - t0 > limit_ticks) {
+            atomicAdd(&state->wait_timeouts, 1u);
+            __hip_atomic_store(&state->shard_broken, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            break;
+        }
         __builtin_amdgcn_s_sleep(8);
     }
 }
@@ -2174,7 +2200,7 @@ extern "C" int bl_pf_shard_peer_selftest(bl_pf* pf, int* ok)
     BL_HIP(hipMemcpyAsync(&before, &pf->state->wait_timeouts, 4, hipMemcpyDeviceToHost, pf->ctx->stream));
     hipLaunchKernelGGL(k_shard_probe_fill, dim3(1), dim3(64), 0, pf->ctx->stream, mine, words, pf->sh_rank, gen);
     hipLaunchKernelGGL(k_shard_push, dim3(pf->sh_world), dim3(1024), 0, pf->ctx->stream, pf->sh_peers_dev, 0, off, (size_t)words * 8, pf->sh_rank, pf->sh_world, gen);
-    hipLaunchKernelGGL(k_shard_wait, dim3(1), dim3(64), 0, pf->ctx->stream, pf->sh_flags, 0, pf->sh_rank, pf->sh_world, gen, pf->state);
+    hipLaunchKernelGGL(k_shard_wait, dim3(1), dim3(64), 0, pf->ctx->stream, pf->sh_flags, 0, pf->sh_rank, pf->sh_world, gen, pf->state, (unsigned long long)100000 * 1000);      // (the probe: 1 s)
     hipLaunchKernelGGL(k_shard_probe_check, dim3(1), dim3(64), 0, pf->ctx->stream, pf_shard_partials(pf), words, pf->sh_rank, pf->sh_world, gen, d_bad);
     BL_HIP(hipGetLastError());
     int bad[2] = {0, 0};
@@ -2182,7 +2208,10 @@ extern "C" int bl_pf_shard_peer_selftest(bl_pf* pf, int* ok)
     BL_HIP(hipMemcpyAsync(&after, &pf->state->wait_timeouts, 4, hipMemcpyDeviceToHost, pf->ctx->stream));
     BL_HIP(hipStreamSynchronize(pf->ctx->stream));
     (void)hipFree(d_bad);
-    if (after != before) BL_HIP(hipMemsetAsync(&pf->state->wait_timeouts, 0, 4, pf->ctx->stream));     // (the probe's own time-out is its answer)
+    if (after != before) {                                   // (the probe's own time-out is its answer, not a broken set)
+        BL_HIP(hipMemsetAsync(&pf->state->wait_timeouts, 0, 4, pf->ctx->stream));
+        BL_HIP(hipMemsetAsync(&pf->state->shard_broken, 0, 4, pf->ctx->stream));
+    }
     *ok = (bad[0] == 0 && after == before) ? 1 : 0;
     return BL_OK;
 }
@@ -2194,6 +2223,17 @@ extern "C" int bl_pf_shard_peer_reset(bl_pf* pf, int keep)
     if (pf->pending_end) { bl_set_error("update pending"); return BL_ERR_STATE; }
     if (!keep) pf->sh_peer = false;
     return BL_OK;
+}
+
+// limit of a cross-rank wait in 100 MHz ticks: 30 s, or BOTLAB_SHARD_WAIT_MS (tests)
+static unsigned long long shard_wait_ticks()
+{
+    static const unsigned long long ticks = [] {
+        const char* e = getenv("BOTLAB_SHARD_WAIT_MS");
+        const double ms = e && atof(e) > 0 ? atof(e) : 30000.0;
+        return (unsigned long long)(ms * 100000.0);
+    }();
+    return ticks;
 }
 
 // The running update's exchange in the peer-store form, on the filter's stream, in three phases: 0 = tile sums of the own block,
@@ -2220,7 +2260,7 @@ extern "C" int bl_pf_shard_exchange_peer_phase(bl_pf* pf, int phase)
                            (size_t)tiles * 5 * sizeof(double), pf->sh_rank, pf->sh_world, pf->sh_gen);
     } else if (phase == 1) {
         if (!pf->sh_stage_sums || pf->sh_stage_groups) { bl_set_error("exchange phase 1 out of order"); return BL_ERR_STATE; }
-        hipLaunchKernelGGL(k_shard_wait, dim3(1), dim3(64), 0, pf->ctx->stream, pf->sh_flags, 0, pf->sh_rank, pf->sh_world, pf->sh_gen, pf->state);
+        hipLaunchKernelGGL(k_shard_wait, dim3(1), dim3(64), 0, pf->ctx->stream, pf->sh_flags, 0, pf->sh_rank, pf->sh_world, pf->sh_gen, pf->state, shard_wait_ticks());
         rc = bl_pf_shard_stage(pf, 2);
         if (rc) return rc;
         rc = bl_timer_begin(pf->ctx, BL_K_MCL_SCAN, &e0, &e1);
@@ -2231,7 +2271,7 @@ extern "C" int bl_pf_shard_exchange_peer_phase(bl_pf* pf, int phase)
         if (!pf->sh_stage_groups) { bl_set_error("exchange phase 2 out of order"); return BL_ERR_STATE; }
         rc = bl_timer_begin(pf->ctx, BL_K_MCL_SCAN, &e0, &e1);
         if (rc) return rc;
-        hipLaunchKernelGGL(k_shard_wait, dim3(1), dim3(64), 0, pf->ctx->stream, pf->sh_flags, 1, pf->sh_rank, pf->sh_world, pf->sh_gen, pf->state);
+        hipLaunchKernelGGL(k_shard_wait, dim3(1), dim3(64), 0, pf->ctx->stream, pf->sh_flags, 1, pf->sh_rank, pf->sh_world, pf->sh_gen, pf->state, shard_wait_ticks());
     }
     BL_HIP(hipGetLastError());
     return bl_timer_end(pf->ctx, BL_K_MCL_SCAN, e0, e1);
@@ -2304,11 +2344,22 @@ extern "C" int bl_pf_update_action_only(bl_pf* pf, const bl_pose_xyt_t* odometry
 extern "C" int bl_pf_pose_estimate(bl_pf* pf, bl_pose_xyt_t* out_pose)
 {
     BL_CHECK_ARG(pf != nullptr && out_pose != nullptr && pf->state != nullptr);
-    struct { bl_pose_xyt_t pose; unsigned int wait_timeouts; } h;
+    struct { bl_pose_xyt_t pose; unsigned int wait_timeouts; unsigned int shard_broken; } h;
     static_assert(offsetof(pf_state, wait_timeouts) == offsetof(pf_state, pose) + sizeof(bl_pose_xyt_t), "the counter is read with the pose");
+    static_assert(offsetof(pf_state, shard_broken) == offsetof(pf_state, wait_timeouts) + sizeof(unsigned int), "the flag is read with the pose");
+    if (pf->sh_broken) { bl_set_error("the shard exchange of this particle set gave up earlier: set the shards up again or re-initialise the filter"); return BL_ERR_STATE; }
     BL_HIP(hipMemcpyAsync(&h, &pf->state->pose, sizeof(h), hipMemcpyDeviceToHost, pf->ctx->stream));
     BL_HIP(hipStreamSynchronize(pf->ctx->stream));
     *out_pose = h.pose;
+    if (h.shard_broken != 0) {
+        // sticky, on the device and here: the launches that would have consumed the missing data did nothing (particles, weights,
+        // pose and map are those of the last complete update), and nothing re-creates the set behind the caller's back
+        pf->sh_broken = true;
+        bl_set_error("a wait for another rank's part of the shard exchange gave up (%u): this update's groups, finish, map store and every "
+                     "later resampling did nothing, the particle set is no valid posterior any more; set the shards up again "
+                     "(bl_pf_shard_setup) or re-initialise the filter", h.wait_timeouts);
+        return BL_ERR_STATE;
+    }
     if (h.wait_timeouts != 0) {
         // reported once: the count belongs to the launches since the last estimate was fetched, not to every later one
         BL_HIP(hipMemsetAsync(&pf->state->wait_timeouts, 0, sizeof(unsigned int), pf->ctx->stream));

@@ -33,6 +33,8 @@ struct pf_state {
     double S;                 // total weight units of rec[cur]
     bl_pose_xyt_t pose;       // posteriorPose_
     unsigned int wait_timeouts;    // waits inside a finish launch that ran into MCLF_SPIN_LIMIT (never, unless a launch lost workgroups); read with the pose
+    unsigned int shard_broken;     // STICKY: a cross-rank wait of the peer-store exchange gave up (k_shard_wait): every later launch that would consume
+                                   // another rank's data does nothing; only bl_pf_shard_setup / a new particle set clears it.  Read with the pose
     double sums_used[5];      // units, -, -, units*sin, units*cos the estimate was formed from (diagnostic)
     unsigned int chain_stats[8];   // x then y: generic replays, their phases, table replays, gaps walked the slow way (diagnostic)
     unsigned int lookahead[2];     // map updates that ran ahead of the exact pose; of those, the ones that had to run again (diagnostic)

@@ -324,7 +324,12 @@ int bl_pf_shard_traffic(bl_pf* pf, int64_t* out3);
  * collective latencies per update become two pushes over xGMI.  Layouts and results are the collective form's.  First contact:
  * bl_pf_shard_peer_selftest pushes a pattern to every rank and checks every rank's pattern (device-side spin limit: it cannot
  * hang); the ranks agree on the outcome over their rendezvous and either keep the form (bl_pf_shard_peer_reset(pf, 1)) or all
- * leave it (..., 0) for the collective forms.  Per update: bl_pf_update_begin, bl_pf_shard_exchange_peer, then as above. */
+ * leave it (..., 0) for the collective forms.  Per update: bl_pf_update_begin, bl_pf_shard_exchange_peer, then as above.
+ * A rank that waits for another rank's part longer than the cross-rank limit (30 s on the device's real-time clock;
+ * BOTLAB_SHARD_WAIT_MS for tests) gives up FOR GOOD: a sticky flag on the device turns the update's groups, finish and map store
+ * and every later update of the set into no-ops, and every call that fetches the pose or the particles (bl_pf_update_end,
+ * bl_map_update_finishing_pf + bl_pf_pose_estimate, bl_pf_get_particles) and every later bl_pf_update_begin returns
+ * BL_ERR_STATE until bl_pf_shard_setup or bl_pf_init_at_pose: nothing is computed from another rank's stale data. */
 int bl_pf_shard_local_ptrs_peer(bl_pf* pf, void** sums, void** xchg, void** flags);
 int bl_pf_shard_set_peer_buffers(bl_pf* pf, int rank, void* sums, void* xchg, void* flags);
 int bl_pf_shard_peer_commit(bl_pf* pf);

@@ -263,3 +263,111 @@ def test_eight_ranks_peer_store_exchange_match_single_rank(tmp_path, n, steps):
         if n >= 1_000_000:
             assert sent < n * 16 // 16
     assert np.concatenate(got).tobytes() == one.tobytes()
+
+
+def _run_timeout(_unused_rank, out_dir):
+    """two ranks in one process, peer-store exchange; in the third update rank 1 never shows up"""
+    sys.path.insert(0, HERE)
+    sys.path.insert(0, os.path.dirname(HERE))
+    os.environ["BOTLAB_SHARD_WAIT_MS"] = "300"
+    import ctypes as C
+    import helpers
+    import botlab_amd as bl
+    from botlab_amd import sharded, synth
+    from botlab_amd._capi import check, BotlabHipError as BotlabError
+    n, world, steps = 100_000, 2, 6
+    m = helpers.load_reference_maps()["obstacle_slam_10mx10m_5cm"]
+    truth = np.where(m["cells"] > 0, 127, -127).astype(np.int8)
+    start = (-0.75, 0.2, 0.0)
+    poses = synth.square_trajectory(start, steps, step_len=0.03, turn=0.05, side=0.8)
+    scans = [synth.raycast_scan(truth, m["origin"], 0.05, poses[k - 1], poses[k], 1_000_000 + k * 100_000) for k in range(1, steps + 1)]
+    engs = [sharded.HipShardEngine(n, r, world, 0, composed=True) for r in range(world)]
+    lib = engs[0].ctx.lib
+    grids = [bl.OccupancyGrid.from_cells(m["cells"], m["origin"], m["mpc"], cellsPerMeter=helpers.CPM_DEFAULT, ctx=e.ctx) for e in engs]
+    mappers = [bl.Mapping(5.0, 4, 1, ctx=e.ctx) for e in engs]
+    for e in engs:
+        e.init_at_pose(bl.make_pose(*start, utime=int(scans[0].times[0])), 21)
+        e.shard_setup()
+
+    def ptrs_of(e, fn):
+        p3 = [C.c_void_p() for _ in range(3)]
+        check(fn(e.pf.h, *[C.byref(q) for q in p3]))
+        return [q.value for q in p3]
+
+    recs = [ptrs_of(e, lib.bl_pf_shard_local_ptrs) for e in engs]
+    for e in engs:
+        for r in range(world):
+            check(lib.bl_pf_shard_set_peer(e.pf.h, r, *recs[r]))
+        check(lib.bl_pf_shard_commit(e.pf.h))
+    bufs = [ptrs_of(e, lib.bl_pf_shard_local_ptrs_peer) for e in engs]
+    for e in engs:
+        for r in range(world):
+            check(lib.bl_pf_shard_set_peer_buffers(e.pf.h, r, *bufs[r]))
+        check(lib.bl_pf_shard_peer_commit(e.pf.h))
+    report = {}
+    n_moved, late_k = 0, None
+    for k, sc in enumerate(scans):
+        odo = bl.make_pose(*poses[k + 1], utime=sc.utime)
+        late = n_moved == 2                                    # the third moved update: rank 1's host is stuck somewhere
+        active = engs[:1] if late else engs
+        if late:
+            before_cells = grids[0].cells().copy()
+        moved = [e.begin(odo, sc, g, 900 + k) for e, g in zip(active, grids)]
+        if late:
+            assert moved[0]
+        if moved[0]:
+            n_moved += 1
+            for ph in range(3):
+                for e in active:
+                    check(lib.bl_pf_shard_exchange_peer_phase(e.pf.h, ph))
+        for e, g, mp_ in zip(active, grids, mappers):
+            mp_.updateMapFinishingFilter(sc, e.pf, sc.utime, g)
+        for e in active:
+            try:
+                e.pf.poseEstimate()
+                ok = True
+            except BotlabError as ex:
+                ok = False
+                report["message"] = str(ex)
+            assert ok == (not late), "update %d: estimate %s" % (k, "succeeded" if ok else "failed")
+        if late:
+            late_k = k
+            break
+    assert late_k is not None
+    e0 = engs[0]
+    report["map_unchanged"] = bool(np.array_equal(before_cells, grids[0].cells()))
+    try:                                                       # the particle set is no posterior any more: asking for it is an error too
+        e0.particles()
+        report["particles_refused"] = False
+    except BotlabError:
+        report["particles_refused"] = True
+    # sticky: the estimate stays an error, and no further update starts
+    again, begun = False, False
+    try:
+        e0.pf.poseEstimate()
+        again = True
+    except BotlabError:
+        pass
+    try:
+        e0.begin(bl.make_pose(*poses[late_k + 2], utime=scans[late_k + 1].utime), scans[late_k + 1], grids[0], 999)
+        begun = True
+    except BotlabError:
+        pass
+    report["estimate_after"] = again
+    report["update_after"] = begun
+    import json
+    with open(os.path.join(out_dir, "timeout.json"), "w") as f:
+        json.dump(report, f)
+
+
+def test_peer_store_wait_that_gives_up_is_sticky_and_skips_the_update(tmp_path):
+    """A rank that waits for another rank's part of the exchange longer than the cross-rank limit (BOTLAB_SHARD_WAIT_MS here, 30 s by
+    default) must not go on with stale data: its groups, finish, map store and later resampling do nothing, the very call that
+    fetches the pose says so, and it keeps saying so (no later update starts) until the shards are set up again."""
+    import json
+    import torch.multiprocessing as mp
+    mp.spawn(_run_timeout, args=(str(tmp_path),), nprocs=1, join=True)
+    rep = json.load(open(os.path.join(str(tmp_path), "timeout.json")))
+    assert "gave up" in rep["message"]
+    assert rep["map_unchanged"] and rep["particles_refused"]
+    assert rep["estimate_after"] is False and rep["update_after"] is False
