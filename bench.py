@@ -542,7 +542,7 @@ def main():
                          "arrangement -- the exploration process is a separate LCM subscriber that works on the newest map it has when it "
                          "is free (exploration.cpp:93-109, 296-298) and the SLAM process never waits for it: a second host thread takes the "
                          "steps back, and a map published while every lane is busy is not explored (counted)")
-    ap.add_argument("--preheat-ms", type=float, default=300.0, help="milliseconds of unrelated GPU load (matrix products) before the warmup steps, "
+    ap.add_argument("--preheat-ms", type=float, default=300.0, help="milliseconds of the path's own k_mcl_main on a scratch filter before the warmup steps, "
                     "so that a short run is not a measurement of the clock ramp after the idle seconds of input synthesis (0 = off)")
     ap.add_argument("--astar-fixtures", action="store_true", help="only the reference's own A* table (astar_test's six maps): one JSON line")
     ap.add_argument("--sub", action="store_true", help="a child run of the default invocation (other_configs): no children of its own")
@@ -822,18 +822,21 @@ def main():
     # Setup, not measurement: the device sits idle for seconds while the host synthesises scans, and its clock ramps back over
     # ~0.3 s of load -- longer than a whole 25-step run (measured: k_mcl_main 71-74 us in a 20-step run after idling, 63 us
     # after 300 ms of load, the figure every long run shows).  A SLAM loop is a continuously running service, so the clock is
-    # brought up first, by work that is no part of the path (bf16 matrix products on this stream); the W warmup steps and the K
-    # timed steps follow unchanged.  --preheat-ms 0 switches it off; the line says which was used.
+    # brought up first -- by the path's own dominant kernel: a scratch particle filter of the same size runs updateFilter on the
+    # first scan against the same map (k_mcl_main + its finish; nothing of the measured filter, map or planner is touched); the W
+    # warmup steps and the K timed steps follow unchanged.  --preheat-ms 0 switches it off; the line says which was used.
     preheat_ms = args.preheat_ms
     if preheat_ms > 0:
-        with torch.cuda.stream(engine.stream):
-            xa = torch.randn(4096, 4096, device="cuda", dtype=torch.bfloat16)
-            t_ph = time.perf_counter()
-            while (time.perf_counter() - t_ph) * 1e3 < preheat_ms:
-                for _ in range(8):
-                    xa = (xa @ xa).clamp_(-1, 1)
-                engine.stream.synchronize()
-            del xa
+        heat = bl.ParticleFilter(min(args.particles, 250_000), ctx=ctx)
+        heat.initializeFilterAtPose(bl.make_pose(*odo[0], utime=int(scans[0].times[0])), seed=7)
+        t_ph = time.perf_counter()
+        j = 0
+        while (time.perf_counter() - t_ph) * 1e3 < preheat_ms:
+            for _ in range(16):
+                o = odo[1 + (j & 1)]
+                heat.updateFilter(bl.make_pose(o[0], o[1], o[2], utime=int(scans[0].utime) + j), scans[0], grid)
+                j += 1
+        del heat
     k = 0
     for _ in range(args.warmup):
         step(k)
@@ -860,6 +863,7 @@ def main():
     for _ in range(args.steps):
         step(k)
         k += 1
+    t_steady = time.perf_counter() - t0  # the K steps enqueued, all but the last `depth` results fetched: the loop without its drain tail
     pose = drain(wait_explorer=False)    # all K results delivered inside the timed region
     if explorer is not None and args.explore_mode == "newest-map":
         # the one deviation from "synchronise the device on both sides": the exploration process of this mode is an independent
@@ -986,12 +990,15 @@ def main():
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps,
+            # the same K steps without the drain tail (the last `depth` results -- their distance grids and the longest search of the
+            # last replanner batch -- are fetched behind it): what a long run converges to; `value` stays the whole region
+            "steady_ms_per_step": 1e3 * t_steady / args.steps,
             "higher_is_better": True,
             "scaling": "strong",
             "vs_baseline": None,
             "dtype": "int8 grid / f32 poses with f64 intermediates / int64 weights",
             "data": "synthetic",
-            "preheat_ms": preheat_ms,         # unrelated GPU load before the W warmup steps (the clock ramps over ~0.3 s after the idle input synthesis)
+            "preheat_ms": preheat_ms,         # the path's own k_mcl_main on a scratch filter before the W warmup steps (the clock ramps over ~0.3 s after the idle input synthesis)
             "config": {"workload": f"full SLAM step on {W}x{H} @5cm grid ({world_name}), {N} particles, "
                                    f"{R} rays, " + ("exploration step (setMap + find_map_frontiers + plan_path_to_frontier under the 0.5 m rule) on every "
                                                     f"{EXPLORE_EVERY}th map" if args.explore else f"A* replan {'off' if goal is None else 'on'}"),

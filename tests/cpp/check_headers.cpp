@@ -1,7 +1,7 @@
 // Compile check of the drop-in classes (g++ -fsyntax-only): instantiates every template with plain message structs
 // that carry the fields of the lcm-gen types (lcmtypes/*.lcm).  Not part of the product; see tests/cpp/dropin_test.cpp
 // for the run-time check on a GPU.
-#include <botlab/dropin_test_types.hpp>
+#include "dropin_test_types.hpp"
 
 typedef botlab_hip::MappingT<pose_xyt_t, lidar_t> Mapping;
 typedef botlab_hip::ParticleFilterT<pose_xyt_t, lidar_t, particle_t, particles_t> ParticleFilter;

@@ -4,7 +4,7 @@
 // writes the results for the Python side to compare with the oracle.
 #include <cstdio>
 #include <cstdlib>
-#include <botlab/dropin_test_types.hpp>
+#include "dropin_test_types.hpp"
 
 typedef botlab_hip::MappingT<pose_xyt_t, lidar_t> Mapping;
 typedef botlab_hip::ParticleFilterT<pose_xyt_t, lidar_t, particle_t, particles_t> ParticleFilter;

@@ -3,7 +3,7 @@
 // frontiers and the path for tests/test_gpu_frontiers.py to compare with the oracle.
 #include <cstdio>
 #include <cstdlib>
-#include <botlab/dropin_test_types.hpp>
+#include "dropin_test_types.hpp"
 #include <botlab/planning_dropin.hpp>
 
 typedef botlab_hip::MotionPlannerT<pose_xyt_t, robot_path_t> MotionPlanner;

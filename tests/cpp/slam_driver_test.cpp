@@ -4,7 +4,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <memory>
-#include <botlab/dropin_test_types.hpp>
+#include "dropin_test_types.hpp"
 #include <botlab/slam_driver.hpp>
 
 struct odometry_t { int64_t utime = 0; float x = 0, y = 0, theta = 0; };

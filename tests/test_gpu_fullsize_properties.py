@@ -107,6 +107,38 @@ def test_astar_on_2000x2000_maze_path_is_valid(maps, gpu_ctx):
     assert found >= 1
 
 
+def test_astar_on_2000x2000_maze_equals_oracle(oracle, maps, gpu_ctx):
+    """BASELINE.json configs[3]'s grid: distance grid and search_for_path of the HIP path against the oracle on the same 2000 x 2000
+    tiled maze -- distances bit for bit, then poses, pops and pushes of searches a few hundred cells long (thousands of pops: the
+    straight-line loop's LDS regime and, with the replanner's footprint, its form with tiers in global memory)."""
+    world, origin = _world(maps, 2000)
+    cpm = helpers.CPM_DEFAULT
+    g = bl.OccupancyGrid.from_cells(world, origin, np.float32(0.05), cellsPerMeter=cpm, ctx=gpu_ctx)
+    planner = bl.MotionPlanner(bl.MotionPlannerParams(0.1), ctx=gpu_ctx)
+    planner.setMap(g)
+    dist = planner.distances_.cells()
+    odist = oracle.set_distances(world, np.float32(0.05), cpm, origin)
+    assert np.array_equal(dist.view(np.uint32), odist.view(np.uint32))
+    ys, xs = np.nonzero(dist > 0.25)
+    c0 = np.argmin(np.abs(xs - 1000) + np.abs(ys - 1000))
+    l1 = np.abs(xs - xs[c0]) + np.abs(ys - ys[c0])
+    compared = 0
+    for lo, hi in ((60, 80), (150, 200), (300, 380)):
+        cand = np.nonzero((l1 >= lo) & (l1 < hi))[0]
+        assert cand.size > 0
+        c1 = cand[cand.size // 2]
+        sp = (float(origin[0]) + (xs[c0] + 0.5) * 0.05, float(origin[1]) + (ys[c0] + 0.5) * 0.05)
+        gp = (float(origin[0]) + (xs[c1] + 0.5) * 0.05, float(origin[1]) + (ys[c1] + 0.5) * 0.05)
+        path, stats = bl.search_for_path(bl.make_pose(*sp, 0.0), bl.make_pose(*gp, 0.0), planner.distances_,
+                                         planner.searchParams_, return_stats=True)
+        exp, est = oracle.search(oracle.pose(*sp, 0.0), oracle.pose(*gp, 0.0), odist, np.float32(0.05), cpm, origin, 0.1, 1.0)
+        assert stats == est, (lo, stats, est)
+        got = np.array([(p.utime, p.x, p.y, p.theta) for p in path], dtype=exp.dtype)
+        assert got.tobytes() == exp.tobytes(), lo
+        compared += 1 if len(path) > 1 else 0
+    assert compared >= 2
+
+
 @pytest.mark.parametrize("size,radius", [(2000, 400), (4096, 1500)])
 def test_frontiers_full_size_match_oracle(oracle, gpu_ctx, size, radius):
     """find_map_frontiers on a partially explored open hall (config 5's grid size): the oracle's bitmap flood finishes in

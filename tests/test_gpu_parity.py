@@ -476,6 +476,33 @@ def test_astar_paths_bit_exact_on_reference_fixtures(oracle, maps, gpu_ctx, name
         assert got.tobytes() == exp.tobytes(), (name, i)
 
 
+def test_astar_narrow_case_2_ends_with_capacity_error(maps):
+    """data/astar/narrow_poses.txt:4 (0 -5 -> 0 5, shouldExist 0): the gap is narrower than the robot, so the reference's search has to
+    exhaust the whole near side before it answers "no path" -- 2.6e8 pops of its algorithm, an open list of as many entries
+    (tests/tools/astar_narrow2_probe.py: the HIP path's default 16 M-entry list is full after 16 828 121 pops, 25.6 s).  The defined
+    outcome of the drop-in: BL_ERR_CAPACITY with the 1-pose path of a failed plan, at the same pop count every time -- never a
+    wrong path, never an endless search.  Run here with a 1 M-entry list."""
+    import ctypes as C
+    from botlab_amd import _capi
+    ctx = bl.Context(0)
+    m = maps["astar_narrow"]
+    g = _grid_from_map(m, ctx)
+    planner = bl.MotionPlanner(bl.MotionPlannerParams(0.1), ctx=ctx)
+    planner.setMap(g)
+    row = helpers.load_astar_cases()["narrow"][2]
+    assert row["should_exist"] is False
+    s, gl = bl.make_pose(*row["start"], 0.0), bl.make_pose(*row["goal"], 0.0)
+    assert ctx.lib.bl_astar_set_open_capacity(ctx.h, 1 << 20) == 0
+    seen = []
+    for _ in range(2):
+        buf = (_capi.Pose * 64)(); n = C.c_int(0); stats = (C.c_int64 * 2)()
+        rc = ctx.lib.bl_astar_search(ctx.h, planner.distances_.h, C.byref(s), C.byref(gl), C.byref(planner.searchParams_), buf, 64, C.byref(n), stats)
+        assert rc == _capi.BL_ERR_CAPACITY and n.value == 1
+        assert (buf[0].x, buf[0].y) == (s.x, s.y)
+        seen.append((stats[0], stats[1]))
+    assert seen[0] == seen[1] and seen[0][0] > 1_000_000 and seen[0][1] - seen[0][0] >= (1 << 20) - 4
+
+
 @pytest.mark.parametrize("name,case,counts", [("wide", 2, (526431, 763405)), ("convex", 2, None)])
 def test_astar_long_cases(oracle, maps, gpu_ctx, name, case, counts):
     """The two long searches of the reference's fixtures (data/astar/wide_poses.txt, convex_poses.txt read with the token-stream
