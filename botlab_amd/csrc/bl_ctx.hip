@@ -337,7 +337,7 @@ static int scan_pack(bl_ctx* ctx, const bl_lidar_t* scan, int* kept_out, float* 
     bool thetas_simple = true;
     for (int n = 0; n < R; ++n) {
         if (!(scan->ranges[n] > 0.15f)) continue;
-        if (!(scan->thetas[n] >= 0.0f && scan->thetas[n] <= 6.2831f)) thetas_simple = false;
+        if (!(scan->thetas[n] >= 0.0f && scan->thetas[n] <= BL_THETA_SIMPLE_MAX)) thetas_simple = false;
         if (scan->ranges[n] > max_range) max_range = scan->ranges[n];
         hrange[kept] = scan->ranges[n];
         htheta[kept] = scan->thetas[n];

@@ -1177,7 +1177,12 @@ struct bl_explorer {
     // submit (the SLAM thread) and fetch (possibly another thread: the reference's exploration PROCESS) share `order` and the lanes'
     // busy flags; a lane's other members belong to submit while it is idle and to fetch while it is busy
     std::mutex* mu;
+    // the exploration state (planner, target, path, last): written by fetch, read and written by bl_explorer_set_state /
+    // bl_explorer_frontiers from any thread.  Never held across a plan (seconds): fetch copies the planner out and its results in
+    std::mutex* smu;
 };
+
+extern "C" void bl_explorer_destroy(bl_explorer* e);
 
 extern "C" int bl_explorer_create(bl_ctx* ctx, int lanes, double robot_radius, bl_explorer** out)
 {
@@ -1188,6 +1193,7 @@ extern "C" int bl_explorer_create(bl_ctx* ctx, int lanes, double robot_radius, b
     e->main = ctx; e->lanes = lanes;
     e->order = new std::deque<int>();
     e->mu = new std::mutex();
+    e->smu = new std::mutex();
     e->path = new std::vector<bl_pose_xyt_t>();
     e->min_frontier_length = 0.35;                      // kMinFrontierLength's default (frontiers.hpp:36)
     // MotionPlanner(params) + setParams (motion_planner.cpp:9-16, 105-110): minDist = robotRadius, maxDist = 10 minDist, exponent 1
@@ -1197,8 +1203,8 @@ extern "C" int bl_explorer_create(bl_ctx* ctx, int lanes, double robot_radius, b
     e->planner.search.distanceCostExponent = 1.0;
     e->planner.num_frontiers = 1;
     e->planner.prev_goal.x = 1e9f; e->planner.prev_goal.y = 1e9f;   // never set by the reference's exploration loop (D5)
-    for (int l = 0; l < lanes; ++l) {
-        explorer_lane& L = e->lane[l];
+    // (a failure below hands the partly built explorer to bl_explorer_destroy, which tolerates missing members: nothing leaks)
+    auto build_lane = [&](explorer_lane& L) -> int {
         // a lane's stream has the lowest priority (BOTLAB_EXPLORER_NORMAL_PRIORITY=1: the default one): a plan to a frontier is one
         // kernel of up to seconds, and streams of one priority share the runtime's four hardware queues -- with its stream behind
         // a lane's on one queue the SLAM loop ran at 182 instead of 3 700 steps/s (4096 x 4096, the explorer on every newest map)
@@ -1212,6 +1218,11 @@ extern "C" int bl_explorer_create(bl_ctx* ctx, int lanes, double robot_radius, b
         BL_HIP(hipEventCreateWithFlags(&L.snap_ready, hipEventDisableTiming));
         BL_HIP(hipEventCreate(&L.t0));
         BL_HIP(hipEventCreate(&L.t1));
+        return BL_OK;
+    };
+    for (int l = 0; l < lanes; ++l) {
+        const int rc = build_lane(e->lane[l]);
+        if (rc) { bl_explorer_destroy(e); return rc; }
     }
     *out = e;
     return BL_OK;
@@ -1235,13 +1246,14 @@ extern "C" void bl_explorer_destroy(bl_explorer* e)
         bl_ctx_destroy(L.ctx);
     }
     if (e->last) bl_frontiers_destroy(e->last);
-    delete e->order; delete e->path; delete e->mu;
+    delete e->order; delete e->path; delete e->mu; delete e->smu;
     delete e;
 }
 
 extern "C" int bl_explorer_set_state(bl_explorer* e, const bl_pose_xyt_t* target, const bl_pose_xyt_t* prev_goal)
 {
     BL_CHECK_ARG(e != nullptr);
+    std::lock_guard<std::mutex> g(*e->smu);             // (fetch, on another thread, reads and writes the same state under it)
     if (target) e->target = *target;
     if (prev_goal) e->planner.prev_goal = *prev_goal;
     return BL_OK;
@@ -1313,17 +1325,24 @@ extern "C" int bl_explorer_fetch(bl_explorer* e, bl_explore_result_t* out, bl_po
     bl_frontiers* fr = nullptr;
     int rc = frontiers_collect(L.ctx, L.snap->frame, e->min_frontier_length, &fr);      // (waits for the lane's stream)
     if (rc) return rc;
-    if (e->last) bl_frontiers_destroy(e->last);
-    e->last = fr;
     float fms = 0.0f;
     (void)hipEventElapsedTime(&fms, L.t0, L.t1);
     const bl_pose_xyt_t pose = *L.h_pose;
     const int nf = (int)fr->offsets.size() - 1;
-    e->planner.num_frontiers = nf;                                                       // planner_.setNumFrontiers (:302)
+    bl_motion_planner_t planner;
+    bl_pose_xyt_t target;
+    {
+        std::lock_guard<std::mutex> g(*e->smu);
+        if (e->last) bl_frontiers_destroy(e->last);
+        e->last = new bl_frontiers(*fr);                                                 // (the plan below reads fr itself, outside the lock)
+        e->planner.num_frontiers = nf;                                                   // planner_.setNumFrontiers (:302)
+        planner = e->planner; target = e->target;
+    }
+    struct drop { bl_frontiers* f; ~drop() { bl_frontiers_destroy(f); } } drop_fr{fr};
     // :307-311 -- sqrt(pow(dx, 2) + pow(dy, 2)) in double from float differences, stored to a float
     float currDist = 0.0f;
-    if (e->target.x != 0 || e->target.y != 0) {
-        const double dx = (double)(pose.x - e->target.x), dy = (double)(pose.y - e->target.y);
+    if (target.x != 0 || target.y != 0) {
+        const double dx = (double)(pose.x - target.x), dy = (double)(pose.y - target.y);
         currDist = (float)std::sqrt(dx * dx + dy * dy);
     }
     int64_t st[3] = {0, 0, 0};
@@ -1333,14 +1352,16 @@ extern "C" int bl_explorer_fetch(bl_explorer* e, bl_explore_result_t* out, bl_po
         std::vector<bl_pose_xyt_t> buf((size_t)1 << 16);
         int len = 0;
         bl_pose_xyt_t goal;
-        rc = bl_plan_path_to_frontier(L.ctx, fr, &pose, L.dist, &e->planner, buf.data(), (int)buf.size(), &len, &goal, st);
+        rc = bl_plan_path_to_frontier(L.ctx, fr, &pose, L.dist, &planner, buf.data(), (int)buf.size(), &len, &goal, st);
         if (rc) return rc;
         if (len > (int)buf.size()) { bl_set_error("path of %d poses does not fit", len); return BL_ERR_CAPACITY; }
+        std::lock_guard<std::mutex> g(*e->smu);
         e->path->assign(buf.begin(), buf.begin() + len);
         if (len > 1) e->target = (*e->path)[(size_t)len - 1];
         out->planned = 1;
         plan_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - w0).count();
     }
+    std::lock_guard<std::mutex> gs(*e->smu);
     // :335-368 (D10: the status the reference leaves unset when frontiers remain but no path was found is FAILED)
     const int path_len = (int)e->path->size();
     out->status = nf == 0 ? 1 : (path_len > 1 ? 0 : 2);                                   // COMPLETE / IN_PROGRESS / FAILED
@@ -1360,6 +1381,7 @@ extern "C" int bl_explorer_fetch(bl_explorer* e, bl_explore_result_t* out, bl_po
 extern "C" int bl_explorer_frontiers(const bl_explorer* e, bl_frontiers** out)
 {
     BL_CHECK_ARG(e != nullptr && out != nullptr);
+    std::lock_guard<std::mutex> g(*e->smu);
     if (!e->last) { bl_set_error("no exploration step fetched yet"); return BL_ERR_STATE; }
     *out = new bl_frontiers(*e->last);
     return BL_OK;

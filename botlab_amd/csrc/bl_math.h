@@ -199,4 +199,9 @@ BL_HD void bl_philox4x32(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uin
     out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
 }
 
+// a scan is "theta_simple" when every kept ray angle lies in [0, BL_THETA_SIMPLE_MAX]: below 2 pi, so that a wrapped pose angle less
+// a ray angle needs at most ONE upward 2 pi step (the bound behind the fast ray loop: bl_mcl.hip, ray_cells_fast) -- one constant for
+// the check (bl_ctx.hip), the loop and its probe
+#define BL_THETA_SIMPLE_MAX 6.2831f
+
 #endif  // BL_MATH_H

@@ -309,9 +309,10 @@ __device__ __forceinline__ void ray_cells_pk(float2_t start, float cpm, float ra
 // ---- the same two cells WITHOUT the exact sinf / cosf for almost every ray.
 // The reference takes sinf / cosf of theta' = wrap_to_pi(d), d = fl(pose.theta - ray theta).  Here the direction comes from the
 // addition theorems: cos(p - r) = cp cr + sp sr, sin(p - r) = sp cr - cp sr, with (cp, sp) the particle's and (cr, sr) the ray's
-// pair, each formed in double and rounded to float once -- two packed instructions per ray where v_sin_f32 and v_cos_f32 (quarter
+// pair (the ray's formed in double and rounded once, ray_table_entry; the particle's by bl_sincosf, which is libm's sinf / cosf bit
+// for bit) -- two packed instructions per ray where v_sin_f32 and v_cos_f32 (quarter
 // rate each, and a multiply in front) cost nine issue slots.  How far that is from the reference's float values, for every float
-// p in [-pi, pi] and r in [0, 6.2832] (theta_simple), with u = 2^-24:
+// p in [-pi, pi] and r in [0, BL_THETA_SIMPLE_MAX = 6.2831] (theta_simple: a single wrap), with u = 2^-24:
 //     the reference's angle: |fl(p - r) - (p - r)| <= 4.8e-7 (half an ulp below 16: p - r reaches -3 pi), the wrap's own rounding
 //         <= 1.2e-7 (half an ulp below 4: it adds 2 pi in double and rounds once); sinf / cosf of it, rounded: + 6e-8    <= 6.6e-7
 //     the four table values: each within 0.56 ulp = 3.3e-8 of the true value (libm's sinf / cosf); into the two products: <= 3.3e-8
@@ -2524,8 +2525,21 @@ __global__ __launch_bounds__(256) void k_trig_addition_probe(unsigned long long 
         const unsigned long long rnd = s1 + y;
         const float up = (float)(unsigned int)(rnd >> 40) * (1.0f / 16777216.0f);           // 24 bits each
         const float ur = (float)(unsigned int)((rnd >> 16) & 0xFFFFFFull) * (1.0f / 16777216.0f);
-        const float p = bl_wrap_to_pi((up - 0.5f) * 6.2831855f);
-        const float r = ur * 6.2831f;
+        float p = bl_wrap_to_pi((up - 0.5f) * 6.2831855f);
+        float r = ur * BL_THETA_SIMPLE_MAX;
+        // every fourth pair from the corners uniform sampling rarely meets: p within a few ulps of +-pi, r within a few ulps of 0 or
+        // of the cap (where p - r needs its one wrap and comes closest to a second), p - r within a few ulps of a multiple of pi / 2
+        if ((rnd & 3ull) == 0ull) {
+            const unsigned int j = (unsigned int)(rnd >> 2) & 7u, kind = (unsigned int)(rnd >> 5) & 7u;
+            const float pi_f = 3.14159274f;
+            if (kind & 1u) p = __uint_as_float(__float_as_uint(pi_f) - j) * ((kind & 2u) ? -1.0f : 1.0f);
+            if (kind & 4u) r = (kind & 2u) ? __uint_as_float(__float_as_uint(BL_THETA_SIMPLE_MAX) - j) : __uint_as_float(j * 3u);
+            else if (!(kind & 1u)) {
+                const float q = 1.57079637f * (float)((int)((rnd >> 8) & 7ull) - 5);             // p - r near q
+                r = __builtin_fminf(__builtin_fmaxf(p - q, 0.0f), BL_THETA_SIMPLE_MAX);
+                r = __uint_as_float(__float_as_uint(r) + (r > 0.0f && r < BL_THETA_SIMPLE_MAX ? j : 0u) - (r >= BL_THETA_SIMPLE_MAX ? j : 0u));
+            }
+        }
         float ps, pc;
         bl_sincosf(p, &ps, &pc);
         const float2_t pcs = {pc, ps};

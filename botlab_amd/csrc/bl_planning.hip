@@ -1858,13 +1858,26 @@ extern "C" int bl_dist_debug_fused_stamps(bl_dist* d, unsigned long long* out, i
 }
 #endif
 
+// A whole-grid launch of k_dist_fused that gave up says so in the pinned status word (DST_MODE_BROKEN).  Every entry that has just
+// synchronised the grid's stream and is about to hand out something computed FROM the distances looks at it: the grid is marked
+// invalid and the call returns BL_ERR_STATE instead of results from distances that were never finished.
+static int dist_check_broken(bl_dist* d)
+{
+    if (d && d->h_status && *d->h_status == DST_MODE_BROKEN) {
+        *d->h_status = 0; d->valid = false; d->src_id = 0;
+        bl_set_error("setDistances: the one-launch transform gave up (a tile summary never arrived); the distances it left are not valid");
+        return BL_ERR_STATE;
+    }
+    return BL_OK;
+}
+
 extern "C" int bl_dist_download(bl_dist* d, float* cells)
 {
     BL_CHECK_ARG(d != nullptr && cells != nullptr && d->valid);
     { int rc = dist_floats(d); if (rc) return rc; }
     BL_HIP(hipMemcpyAsync(cells, d->cells, (size_t)d->frame.width * d->frame.height * 4, hipMemcpyDeviceToHost, d->ctx->stream));
     BL_HIP(hipStreamSynchronize(d->ctx->stream));
-    return BL_OK;
+    return dist_check_broken(d);
 }
 
 extern "C" int bl_dist_shape(const bl_dist* d, int* width, int* height)
@@ -1946,6 +1959,7 @@ struct bl_astar_state {
     char* h_out_dev[ASTAR_SLOTS];          // the same slots as the device sees them: k_astar writes its result there itself
     hipEvent_t done[ASTAR_SLOTS];
     bl_frame slot_frame[ASTAR_SLOTS];
+    bl_dist* slot_dist[ASTAR_SLOTS];       // the distance grid each pending search runs on (its status word is looked at when the result is fetched)
     int64_t launched, fetched;
     int32_t* h_cost;                   // pinned staging for the cost table
     bool pending;
@@ -2616,6 +2630,7 @@ static int astar_after(bl_ctx* ctx, const bl_dist* d)
     // the kernel has written [result][path head] into the pinned slot itself
     BL_HIP(hipEventRecord(s->done[slot], ctx->stream));
     s->slot_frame[slot] = d->frame;
+    s->slot_dist[slot] = const_cast<bl_dist*>(d);
     s->slot_search[slot] = s->launched;
     s->launched += 1;
     s->pending = true;
@@ -2725,6 +2740,7 @@ extern "C" int bl_astar_search_result(bl_ctx* ctx, bl_pose_xyt_t* out_path, int 
     s->pending = s->launched != s->fetched;
     s->frame = s->slot_frame[slot];
     astar_result r = *(const astar_result*)s->h_out[slot];
+    { const int rcb = dist_check_broken(s->slot_dist[slot]); if (rcb) { out_path[0] = r.start; *out_len = 1; return rcb; } }
     if (stats) { stats[0] = r.pops; stats[1] = r.pushes; }
 #ifdef BL_ASTAR_STAMPS
     {
@@ -2889,6 +2905,8 @@ static int astar_batch_cells(bl_ctx* ctx, const bl_dist* d, const bl_pose_xyt_t*
         if (rc) return rc;
         BL_HIP(hipMemcpyAsync(s->hb_results, s->b_results, (size_t)m * ASTAR_HDR, hipMemcpyDeviceToHost, ctx->stream));
         BL_HIP(hipStreamSynchronize(ctx->stream));
+        rc = dist_check_broken(const_cast<bl_dist*>(d));           // searches on distances that were never finished are no results
+        if (rc) return rc;
         size_t total = 0;
         for (int i = 0; i < m; ++i) {
             const astar_result* r = (const astar_result*)(s->hb_results + (size_t)i * ASTAR_HDR);
@@ -2970,6 +2988,8 @@ extern "C" int bl_dist_gather(bl_dist* d, const int32_t* xy_cells, int n, float*
     BL_HIP(hipGetLastError());
     BL_HIP(hipMemcpyAsync(s->hg_vals, s->g_vals, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
     BL_HIP(hipStreamSynchronize(ctx->stream));
+    rc = dist_check_broken(d);
+    if (rc) return rc;
     memcpy(out, s->hg_vals, (size_t)n * 4);
     return BL_OK;
 }
