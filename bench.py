@@ -940,7 +940,7 @@ def main():
         # passes, gfx950 correction applied); only valid for the configuration they were collected on
         traffic = None
         traffic_src = None
-        for prof in ("r04_mcl_main_traffic.json", "r03_mcl_main_traffic.json", "r02_mcl_main_traffic.json", "r01_mcl_main_traffic.json"):
+        for prof in ("r05_mcl_main_traffic.json", "r03_mcl_main_traffic.json", "r02_mcl_main_traffic.json", "r01_mcl_main_traffic.json"):
             try:
                 tj = json.load(open(os.path.join(ROOT, "profiles", prof)))
                 if world == 1 and tj["config"] == {"particles": N, "grid": [W, H], "rays": R}:
@@ -969,7 +969,7 @@ def main():
         # committed SQ counter pass, against the 1024 SIMDs issuing one per 4 cycles at 2.4 GHz
         valu = None
         import csv
-        for prof in ("r04_mcl_main_pmc_sq.csv", "r03_mcl_main_pmc_sq.csv", "r02_mcl_main_pmc_sq.csv", "r01_mcl_main_pmc_sq.csv"):
+        for prof in ("r05_mcl_main_pmc_sq.csv", "r03_mcl_main_pmc_sq.csv", "r02_mcl_main_pmc_sq.csv", "r01_mcl_main_pmc_sq.csv"):
             try:
                 if world == 1 and traffic is not None and valu is None:
                     for row in csv.reader(open(os.path.join(ROOT, "profiles", prof))):

@@ -7,7 +7,7 @@ if os.environ.get("STAMPS"):
 import botlab_amd as bl, helpers
 maps = helpers.load_reference_maps()
 ctx = bl.default_context()
-for name, case in (("astar_maze", 0), ("astar_maze", 2), ("astar_maze", 1), ("astar_wide", 2)):
+for name, case in (("astar_maze", 0), ("astar_maze", 2), ("astar_maze", 1), ("astar_wide", 2), ("astar_convex", 2)):
     m = maps[name]
     g = bl.OccupancyGrid.from_cells(m["cells"], m["origin"], m["mpc"], cellsPerMeter=helpers.CPM_DEFAULT, ctx=ctx)
     pl = bl.MotionPlanner(bl.MotionPlannerParams(0.1), ctx=ctx); pl.setMap(g)
