@@ -27,7 +27,7 @@
 
 // a round in global memory, first half: node N, 2 node + 1 -> C_, the children's keys asked for (PAIR; lanes without a left
 // child keep 0xFFFFFFFF); valid lanes -> SQ
-#define A2D_GROUND_ASK(N, C_, PAIR, SQ)                                                                       \
+#define A2D_GROUND_ASK(N, C_, PAIR, SQ, PP)                                                                   \
     "v_lshl_add_u32 " N ", s78, v180, v181\n\t"                                                               \
     "v_cmp_gt_u32_e64 " SQ ", s40, " N "\n\t"                                                                 \
     "s_and_b64 " SQ ", " SQ ", s[64:65]\n\t"                                                                  \
@@ -36,12 +36,14 @@
     "s_and_b64 s[68:69], vcc, " SQ "\n\t"                                                                     \
     "v_lshl_add_u32 v220, " N ", 2, 4\n\t"                                                                    \
     "v_mov_b32 " PAIR ", -1\n\t"                                                                              \
+    "v_lshl_add_u32 v221, " N ", 3, 4\n\t"                                                                    \
     "s_mov_b64 exec, s[68:69]\n\t"                                                                            \
     "global_load_dword " PAIR ", v220, s[30:31]\n\t"                                                          \
+    "global_load_dwordx2 " PP ", v221, s[32:33]\n\t"   /* BOTH children's payloads (adjacent entries): no load behind the decision */ \
     "s_mov_b64 exec, -1\n\t"
-// second half (the keys have arrived): a missing right child reads 0xFFFF; then as A2T_ROUND: mask SQ, child C_, knext K; the
-// child's payload asked for (P); the walk's deepest lane -> s70
-#define A2D_GROUND_DECIDE(N, C_, K, P, PAIR, SQ)                                                              \
+// second half (the keys and payloads have arrived): a missing right child reads 0xFFFF; then as A2T_ROUND: mask SQ, child C_, knext K,
+// the child's payload P (of the pair PLO, PHI); the walk's deepest lane -> s70
+#define A2D_GROUND_DECIDE(N, C_, K, P, PAIR, SQ, PLO, PHI)                                                              \
     "v_add_u32 v221, 1, " C_ "\n\t"                                                                           \
     "v_cmp_gt_u32 vcc, s40, v221\n\t"                                                                         \
     "v_or_b32 v221, 0xffff0000, " PAIR "\n\t"                                                                 \
@@ -51,16 +53,13 @@
     "v_min_u32_sdwa " K ", " PAIR ", " PAIR " dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:WORD_1\n\t" \
     "s_nop 1\n\t"                                                                                             \
     "v_and_b32 v222, vcc_lo, v182\n\t"                                                                        \
+    "v_cndmask_b32 " P ", " PLO ", " PHI ", vcc\n\t"                                                          \
     "v_addc_co_u32 " C_ ", vcc, 0, " C_ ", vcc\n\t"                                                           \
     "v_cmp_eq_u32 vcc, v222, v183\n\t"                                                                        \
     "s_and_b64 " SQ ", vcc, " SQ "\n\t"                                                                       \
     "s_flbit_i32_b64 s70, " SQ "\n\t"                                                                         \
     "s_sub_i32 s70, 63, s70\n\t"                                                                              \
-    "s_bitset0_b64 " SQ ", s70\n\t"                                                                           \
-    "v_lshlrev_b32 v220, 2, " C_ "\n\t"                                                                       \
-    "s_mov_b64 exec, " SQ "\n\t"                                                                              \
-    "global_load_dword " P ", v220, s[32:33]\n\t"                                                             \
-    "s_mov_b64 exec, -1\n\t"
+    "s_bitset0_b64 " SQ ", s70\n\t"
 
 // the value (key v193, payload v197) lands on node s71, whichever tier it is in
 #define A2D_LAND                                                                                              \
@@ -226,8 +225,10 @@
     "v_mov_b32 v176, 0xffff\n\t"                                                                              \
     "s_mov_b32 s88, 0\n\t"                                                                                    \
     "s_mov_b32 s80, 0\n\t"                                                                                    \
+    A2T_STAMPS_IN                                                                                             \
     /* ================================================================== one iteration */                    \
     "1:\n\t"                                                                                                  \
+    A2T_STAMP("0")                                                                                            \
     "s_cmp_ge_u32 s41, s50\n\t"                                                                               \
     "s_cbranch_scc1 93f\n\t"                                                                                  \
     "s_sub_u32 s70, s40, %[dlo]\n\t"                                                                          \
@@ -260,6 +261,7 @@
     "s_mov_b64 exec, -1\n\t"                                                                                  \
     "s_add_i32 s40, s40, -1\n\t"                                                                              \
     /* ---- openList.pop(): three rounds in LDS */                                                            \
+    A2T_STAMP("1")                                                                                            \
     "s_mov_b32 s78, 1\n\t"                                                                                    \
     A2T_ROUND("v200", "v201", "v202", "v203", "s[72:73]", "s[62:63]", A2T_FILL0)                              \
     A2T_ROUND("v205", "v206", "v207", "v208", "s[74:75]", "s[64:65]", "")                                     \
@@ -268,8 +270,11 @@
     "s_cmp_ge_u32 s40, %[kslots]\n\t"                                                                         \
     "s_cbranch_scc1 30f\n\t"                                                                                  \
     /* -- the walk ends inside LDS: expansion, then the climb from the third round */                         \
+    A2T_STAMP("2")                                                                                            \
     "s_waitcnt vmcnt(3)\n\t"                                                                                  \
+    A2T_STAMP("3")                                                                                            \
     A2T_EXPAND("41")                                                                                          \
+    A2T_STAMP("4")                                                                                            \
     "s_waitcnt vmcnt(1)\n\t"                         /* (only the closed entry's store may be under way) */   \
     "v_cndmask_b32_e64 v193, v193, v169, s[38:39]\n\t"                                                        \
     "v_cndmask_b32_e64 v243, v243, v154, s[84:85]\n\t"                                                        \
@@ -283,22 +288,27 @@
     A2D_LAND                                                                                                  \
     /* ---- pushes */                                                                                         \
     "45:\n\t"                                                                                                 \
+    A2T_STAMP("0")                                                                                            \
     A2T_PUSH_CHECK("50f") A2D_PUSH_READ A2D_PUSH_REST                                                         \
     A2T_PUSH_CHECK("50f") A2D_PUSH_READ A2D_PUSH_REST                                                         \
     A2T_PUSH_CHECK("50f") A2D_PUSH_READ A2D_PUSH_REST                                                         \
     "50:\n\t"                                                                                                 \
+    A2T_STAMP("5")                                                                                            \
     "s_cmp_lg_u32 s88, 0\n\t"                                                                                 \
     "s_cbranch_scc1 92f\n\t"                                                                                  \
     "s_branch 1b\n\t"                                                                                         \
     /* ================================================================== the walk goes on in global memory */ \
     "30:\n\t"                                                                                                 \
-    A2D_GROUND_ASK("v155", "v156", "v159", "s[82:83]")                                                        \
-    "s_waitcnt vmcnt(4)\n\t"                         /* the neighbours' loads (the round's keys still travel) */ \
+    A2D_GROUND_ASK("v155", "v156", "v159", "s[82:83]", "v[164:165]")                                                        \
+    A2T_STAMP("2")                                                                                            \
+    "s_waitcnt vmcnt(5)\n\t"                         /* the neighbours' loads (the round's keys and payloads still travel) */ \
+    A2T_STAMP("3")                                                                                            \
     A2T_EXPAND("42")                                                                                          \
+    A2T_STAMP("4")                                                                                            \
     "s_waitcnt vmcnt(1)\n\t"                                                                                  \
     "v_cndmask_b32_e64 v193, v193, v169, s[38:39]\n\t"                                                        \
     "v_cndmask_b32_e64 v243, v243, v154, s[84:85]\n\t"                                                        \
-    A2D_GROUND_DECIDE("v155", "v156", "v157", "v158", "v159", "s[82:83]")                                     \
+    A2D_GROUND_DECIDE("v155", "v156", "v157", "v158", "v159", "s[82:83]", "v164", "v165")                                     \
     /* (open lists beyond 2^(LEV + 6) entries: the walk's node on the round's last level has a child -> a second global round) */ \
     "v_readlane_b32 s78, v155, s70\n\t"                                                                       \
     "s_lshl_b32 s71, s78, 1\n\t"                                                                              \
@@ -310,7 +320,7 @@
     A2T_CLIMB("v156", "v157", "s[82:83]", "31f")                                                              \
     "32:\n\t"                                                                                                 \
     A2T_ADDR("v200", "v204") A2T_ADDR("v205", "v209") A2T_ADDR("v240", "v244")                                \
-    "s_waitcnt vmcnt(0) lgkmcnt(0)\n\t"                                                                       \
+    "s_waitcnt lgkmcnt(0)\n\t"                       /* (everything from global memory came with the wait in front of the decision) */ \
     A2T_STORE("v200", "v204", "v202", "v203", "s[72:73]") A2T_STORE("v205", "v209", "v207", "v208", "s[74:75]") \
     A2T_STORE("v240", "v244", "v242", "v243", "s[76:77]")                                                     \
     A2D_STORE3("s[82:83]")                                                                                    \
@@ -319,9 +329,9 @@
     /* -- five rounds */                                                                                      \
     "60:\n\t"                                                                                                 \
     "s_add_i32 s78, s78, 1\n\t"                                                                               \
-    A2D_GROUND_ASK("v171", "v172", "v175", "s[34:35]")                                                        \
+    A2D_GROUND_ASK("v171", "v172", "v175", "s[34:35]", "v[166:167]")                                                        \
     "s_waitcnt vmcnt(0)\n\t"                                                                                  \
-    A2D_GROUND_DECIDE("v171", "v172", "v173", "v174", "v175", "s[34:35]")                                     \
+    A2D_GROUND_DECIDE("v171", "v172", "v173", "v174", "v175", "s[34:35]", "v166", "v167")                                     \
     A2T_CLIMB("v172", "v173", "s[34:35]", "61f")                                                              \
     "62:\n\t"                                                                                                 \
     A2T_ADDR("v200", "v204") A2T_ADDR("v205", "v209") A2T_ADDR("v240", "v244")                                \
@@ -359,6 +369,7 @@
     "93:\n\t"                                                                                                 \
     "s_mov_b32 %[code], 3\n\t"                                                                                \
     "99:\n\t"                                                                                                 \
+    A2T_STAMPS_OUT                                                                                            \
     "s_waitcnt vmcnt(0) lgkmcnt(0)\n\t"                                                                       \
     "s_mov_b32 %[len], s40\n\t"                                                                               \
     "s_mov_b32 %[pops], s41\n\t"                                                                              \
