@@ -2,6 +2,8 @@
 int8 grids, distance floats, resample indices, likelihoods and A* paths; particle poses / weights / pose estimate
 within the tolerances north_star states (1e-5 relative), written next to each assertion."""
 import ctypes as C
+import os
+import sys
 
 import numpy as np
 import pytest
@@ -836,3 +838,81 @@ def test_large_grid_mirror_kept_current_by_map_updates(maps, gpu_ctx, side, form
             for u_, v_ in zip(a_[1:], b_[1:]):
                 assert np.array_equal(u_, v_)
     assert (out[0][1] != first).sum() > 1000                           # the map really changed
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3, 4])
+def test_astar_random_maps_equal_oracle(oracle, gpu_ctx, seed):
+    """search_for_path on seeded random worlds (blocks and walls on a 320 x 240 grid, robot radius 0.1 and 0.2): poses, pops and pushes
+    equal the oracle's -- open lists from a handful to hundreds of thousands of entries.  The start / goal pairs are those of
+    tests/golden/astar_random_cases.json (tests/tools/make_astar_random_cases.py: pairs whose search the oracle finishes within
+    2e6 pops -- with the reference's cost function and no open-list de-duplication many nearby goals cost 1e7 .. 1e9)."""
+    import json
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools"))
+    import make_astar_random_cases as gen
+    cases = [c for c in json.load(open(os.path.join(helpers.GOLDEN, "astar_random_cases.json"))) if c["seed"] == seed]
+    assert len(cases) >= 6
+    cells, _ = gen.world(seed)
+    mpc = np.float32(0.05)
+    origin = (np.float32(-8.0), np.float32(-6.0))
+    cpm = helpers.CPM_DEFAULT
+    g = bl.OccupancyGrid.from_cells(cells, origin, mpc, cellsPerMeter=cpm, ctx=gpu_ctx)
+    dist = oracle.set_distances(cells, mpc, cpm, origin)
+    found = 0
+    for c in cases:
+        radius = c["radius"]
+        planner = bl.MotionPlanner(bl.MotionPlannerParams(radius), ctx=gpu_ctx)
+        planner.setMap(g)
+        assert np.array_equal(planner.distances_.cells().view(np.uint32), dist.view(np.uint32))
+        sp, gp = c["start"], c["goal"]
+        exp, est = oracle.search(oracle.pose(*sp, 0.3), oracle.pose(*gp, 0.0), dist, mpc, cpm, origin, radius, 10.0 * radius, cap=1 << 16)
+        assert tuple(est) == (c["pops"], c["pushes"]) and len(exp) == c["poses"]          # the fixture is what the oracle says today
+        path, stats = bl.search_for_path(bl.make_pose(*sp, 0.3), bl.make_pose(*gp, 0.0), planner.distances_, planner.searchParams_,
+                                         return_stats=True)
+        assert tuple(stats) == tuple(est), (seed, c, stats, est)
+        got = np.array([(p.utime, p.x, p.y, p.theta) for p in path], dtype=exp.dtype)
+        assert got.tobytes() == exp.tobytes(), (seed, c)
+        found += 1 if len(path) > 1 else 0
+    assert found >= 4
+
+
+def _fixtures_in_child(queue_path):
+    """the fixture searches with the C++ forms of k_astar2 only (the switch is read once per process)"""
+    import json
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import helpers as h
+    import oracle_lib
+    import botlab_amd as b
+    orc = oracle_lib.load_oracle()
+    maps = h.load_reference_maps()
+    ctx = b.default_context()
+    out = {}
+    for name in ("narrow", "wide", "convex", "maze"):
+        m = maps["astar_" + name]
+        g = b.OccupancyGrid.from_cells(m["cells"], m["origin"], m["mpc"], cellsPerMeter=h.CPM_DEFAULT, ctx=ctx)
+        planner = b.MotionPlanner(b.MotionPlannerParams(0.1), ctx=ctx)
+        planner.setMap(g)
+        dist = orc.set_distances(m["cells"], m["mpc"], h.CPM_DEFAULT, m["origin"])
+        for i, row in enumerate(h.load_astar_cases()[name]):
+            if (name, i) == ("narrow", 2):
+                continue
+            path, stats = b.search_for_path(b.make_pose(*row["start"], 0.0), b.make_pose(*row["goal"], 0.0), planner.distances_,
+                                            planner.searchParams_, return_stats=True)
+            exp, est = orc.search(orc.pose(*row["start"], 0.0), orc.pose(*row["goal"], 0.0), dist, m["mpc"], h.CPM_DEFAULT, m["origin"], 0.1, 1.0)
+            got = np.array([(p.utime, p.x, p.y, p.theta) for p in path], dtype=exp.dtype)
+            out[f"{name}{i}"] = bool(tuple(stats) == tuple(est) and got.tobytes() == exp.tobytes())
+    json.dump(out, open(queue_path, "w"))
+
+
+@pytest.mark.parametrize("env", ["BOTLAB_ASTAR_NO_TURBO", "BOTLAB_ASTAR_V1"])
+def test_astar_fixtures_with_the_other_forms_of_the_search(tmp_path, env):
+    """the same fixtures through k_astar2's C++ forms (no straight-line loop) and through round 4's k_astar (8-byte entries): the
+    forms a search falls back to for lists of 0-1 entries, cost tables beyond LDS or below the 16-bit key range"""
+    import json
+    import subprocess
+    out = str(tmp_path / "res.json")
+    code = ("import sys, os; sys.path.insert(0, %r); sys.path.insert(0, %r); import test_gpu_parity as t; t._fixtures_in_child(%r)"
+            % (os.path.dirname(os.path.abspath(__file__)), os.path.dirname(os.path.dirname(os.path.abspath(__file__))), out))
+    e = dict(os.environ); e[env] = "1"
+    subprocess.check_call([sys.executable, "-c", code], env=e)
+    res = json.load(open(out))
+    assert len(res) >= 16 and all(res.values()), {k: v for k, v in res.items() if not v}
