@@ -665,6 +665,14 @@ __device__ __forceinline__ void stage_rows(int* s_map32, int rows, int wq, int q
 __device__ unsigned long long g_mcl_stamps[4096 * 8];
 #define MCL_STAMP(k) do { if (threadIdx.x == 0 && blockIdx.x < 4096) g_mcl_stamps[blockIdx.x * 8 + (k)] = wall_clock64(); } while (0)
 #define MCL_STAMP_T(k, T) do { if ((int)threadIdx.x == (T) && blockIdx.x < 4096) g_mcl_stamps[blockIdx.x * 8 + (k)] = wall_clock64(); } while (0)
+#ifdef MCL_STAMPS_HW
+// ... and, in place of the "bisection done" stamp, where the workgroup ran: HW_ID (se, sh, cu, simd of wave 0) | XCC_ID << 32
+// (tests/tools/mcl_placement_probe.py)
+#define MCL_STAMP_HW() do { if (threadIdx.x == 0 && blockIdx.x < 4096) g_mcl_stamps[blockIdx.x * 8 + 6] = \
+    (unsigned long long)__builtin_amdgcn_s_getreg(63492) | ((unsigned long long)__builtin_amdgcn_s_getreg(63508) << 32); } while (0)
+#else
+#define MCL_STAMP_HW() do { } while (0)
+#endif
 extern "C" int bl_debug_mcl_stamps(unsigned long long* out, int n)
 {
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_mcl_stamps), (size_t)n * 8 * 8) == hipSuccess ? 0 : 1;
@@ -672,6 +680,7 @@ extern "C" int bl_debug_mcl_stamps(unsigned long long* out, int n)
 #else
 #define MCL_STAMP(k) do { } while (0)
 #define MCL_STAMP_T(k, T) do { } while (0)
+#define MCL_STAMP_HW() do { } while (0)
 #endif
 
 template <int INTERP, int BLOCK, int MAP_MODE>
@@ -968,6 +977,7 @@ __global__ __launch_bounds__(BLOCK) void k_mcl_main(mcl_args a)
         a.partials[(size_t)blockIdx.x * 5 + tid] = v;
     }
     MCL_STAMP(3);
+    MCL_STAMP_HW();
 }
 
 // ---------------------------------------------------------------- weight-unit prefix scan over all N from the record (2 launches)

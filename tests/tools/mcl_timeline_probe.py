@@ -8,7 +8,7 @@ import numpy as np
 import botlab_amd as bl
 from botlab_amd import _capi
 import bench, types
-args = types.SimpleNamespace(grid=200, max_range=8.0)
+args = types.SimpleNamespace(grid=200, max_range=8.0, map="obstacle_slam_10mx10m_5cm", start=None, rays=290, explore=False, particles=int(os.environ.get("N", "100000")))
 ctx = bl.default_context()
 m, truth, poses, odo, scans, rands = bench.build_inputs(args, 80, ctx)
 cpm = np.float32(1.0 / np.float64(np.float32(0.05)))
