@@ -212,7 +212,9 @@ def cpu_baseline(args, m, odo, scans, rands, goal, n_steps):
         om.update(scans[k], res["pose"], cells, m["mpc"], cpm, m["origin"])
         if goal is not None:
             d = orc.set_distances(cells, m["mpc"], cpm, m["origin"])
+            tp = time.perf_counter()
             _, st = orc.search(res["pose"], orc.pose(goal[0], goal[1], 0.0), d, m["mpc"], cpm, m["origin"], 0.2, 2.0)
+            t_plan += time.perf_counter() - tp
             pops += st[0]
         elif getattr(args, "explore", False) and k % 5 == 0:
             # the exploration step on every 5th map (slam.cpp:285-289 publishes it, exploration.cpp:277-369 plans on it)
@@ -225,10 +227,15 @@ def cpu_baseline(args, m, odo, scans, rands, goal, n_steps):
                 plans += 1
             t_plan += time.perf_counter() - tp
     dt = time.perf_counter() - t0
-    what = f"A* {pops // max(n_steps, 1)} pops/step"
+    # (the searches of the sampled steps are those of the trajectory's first poses: the HIP row's astar_pops_per_step is its timed
+    # region's average, which lies elsewhere on the trajectory -- the per-pop figure is what carries over)
+    what = f"A* {pops // max(n_steps, 1)} pops/step" + (f" at {1e6 * t_plan / pops:.3f} us/pop on this core" if pops else "")
     if getattr(args, "explore", False):
         what = f"an exploration step on every 5th map: {plans} plans to a frontier, {pops} pops, {t_plan:.2f} s of the {dt:.2f} s"
-    return dict(value=n_steps / dt, unit="steps/s", cores=1, kind="port",
+    extra = {}
+    if goal is not None and pops:
+        extra = dict(astar_pops_per_step=pops / n_steps, astar_us_per_pop=round(1e6 * t_plan / pops, 4), non_planner_s_per_step=round((dt - t_plan) / n_steps, 4))
+    return dict(value=n_steps / dt, unit="steps/s", cores=1, kind="port", **extra,
                 sample=f"{n_steps} full steps of the same workload ({N} particles, {scans[0].num_ranges} rays, "
                        f"{cells.shape[1]}x{cells.shape[0]} grid, {what}), oracle on 1 thread, "
                        f"{os.cpu_count()} host cores visible")
@@ -437,6 +444,11 @@ def run_other_configs(steps, warmup):
                 out.append({"config": cfg, "goal_l1_cells": l1, "flags": extra, "error": err[-1][-300:] if err else f"exit {r.returncode}"})
                 continue
             d = json.loads(line[-1])
+            cb = d.get("cpu_baseline")
+            if cb and cb.get("astar_us_per_pop") and d.get("astar_pops_per_step"):
+                # the oracle's sample searches from the trajectory's first poses; this row's searches average astar_pops_per_step:
+                # one CPU core's rate at THAT search size, from its own per-pop cost and the rest of its step
+                cb["steps_per_s_at_this_rows_pops"] = round(1.0 / (cb["non_planner_s_per_step"] + d["astar_pops_per_step"] * cb["astar_us_per_pop"] * 1e-6), 4)
             out.append({"config": cfg, "goal_l1_cells": l1, "flags": extra, "workload": d["config"]["workload"], "value": d["value"], "unit": d["unit"],
                         "steps": d["steps"], "warmup": d["warmup"], "ms_per_step": d["ms_per_step"], "astar_pops_per_step": d["astar_pops_per_step"],
                         "stage_ms": d["stage_ms"], "planner": [d["config"]["planner_lanes"], d["config"]["planner_batch"], d["config"]["pipeline_depth"]],
