@@ -229,16 +229,45 @@ def cpu_baseline(args, m, odo, scans, rands, goal, n_steps):
     dt = time.perf_counter() - t0
     # (the searches of the sampled steps are those of the trajectory's first poses: the HIP row's astar_pops_per_step is its timed
     # region's average, which lies elsewhere on the trajectory -- the per-pop figure is what carries over)
-    what = f"A* {pops // max(n_steps, 1)} pops/step" + (f" at {1e6 * t_plan / pops:.3f} us/pop on this core" if pops else "")
+    what = f"A* {pops // max(n_steps, 1)} pops/step" + (f", {1e3 * t_plan / n_steps:.2f} ms per search on this core (its grid-sized set-up included)" if pops else "")
     if getattr(args, "explore", False):
         what = f"an exploration step on every 5th map: {plans} plans to a frontier, {pops} pops, {t_plan:.2f} s of the {dt:.2f} s"
     extra = {}
     if goal is not None and pops:
-        extra = dict(astar_pops_per_step=pops / n_steps, astar_us_per_pop=round(1e6 * t_plan / pops, 4), non_planner_s_per_step=round((dt - t_plan) / n_steps, 4))
+        extra = dict(astar_pops_per_step=pops / n_steps, astar_ms_per_search=round(1e3 * t_plan / n_steps, 3), non_planner_s_per_step=round((dt - t_plan) / n_steps, 4))
     return dict(value=n_steps / dt, unit="steps/s", cores=1, kind="port", **extra,
                 sample=f"{n_steps} full steps of the same workload ({N} particles, {scans[0].num_ranges} rays, "
                        f"{cells.shape[1]}x{cells.shape[0]} grid, {what}), oracle on 1 thread, "
                        f"{os.cpu_count()} host cores visible")
+
+
+def same_search(ctx, grid, planner, pose, goal_pose, m):
+    """The planner leg on IDENTICAL inputs for both sides: the map and the pose estimate as the timed region left them, the run's goal.
+    The oracle's sampled steps lie at the start of the trajectory, the HIP rows average over all of it -- the searches differ in size;
+    this one is the same search: pops must be equal, the two times are one search's latency (HIP: setDistances was done, the call is
+    bl_astar_search through the C ABI, best of three; CPU: search_for_path of the oracle on one core, its distance grid made before)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import helpers
+    import oracle_lib
+    import botlab_amd as bl
+    orc = oracle_lib.load_oracle()
+    cells = grid.cells().copy()
+    planner.distances_.forget()
+    planner.setMap(grid)
+    start = bl.make_pose(pose.x, pose.y, pose.theta)
+    best, st_gpu = None, None
+    for _ in range(3):
+        t0 = time.perf_counter()
+        _, st_gpu = bl.search_for_path(start, goal_pose, planner.distances_, planner.searchParams_, return_stats=True)
+        dt = time.perf_counter() - t0
+        best = dt if best is None or dt < best else best
+    d = orc.set_distances(cells, m["mpc"], helpers.CPM_DEFAULT, m["origin"])
+    t0 = time.perf_counter()
+    _, st_cpu = orc.search(orc.pose(pose.x, pose.y, pose.theta), orc.pose(goal_pose.x, goal_pose.y, 0.0), d, m["mpc"], helpers.CPM_DEFAULT, m["origin"], 0.2, 2.0)
+    t_cpu = time.perf_counter() - t0
+    return {"pops": int(st_gpu[0]), "pops_equal": bool(int(st_gpu[0]) == int(st_cpu[0]) and int(st_gpu[1]) == int(st_cpu[1])),
+            "hip_ms": round(1e3 * best, 3), "cpu_oracle_ms": round(1e3 * t_cpu, 3), "cores": 1,
+            "inputs": "map and pose estimate at the end of the timed region, the run's goal"}
 
 
 ASTAR_FIXTURE_MAPS = ["empty", "filled", "narrow", "wide", "convex", "maze"]
@@ -444,16 +473,11 @@ def run_other_configs(steps, warmup):
                 out.append({"config": cfg, "goal_l1_cells": l1, "flags": extra, "error": err[-1][-300:] if err else f"exit {r.returncode}"})
                 continue
             d = json.loads(line[-1])
-            cb = d.get("cpu_baseline")
-            if cb and cb.get("astar_us_per_pop") and d.get("astar_pops_per_step"):
-                # the oracle's sample searches from the trajectory's first poses; this row's searches average astar_pops_per_step:
-                # one CPU core's rate at THAT search size, from its own per-pop cost and the rest of its step
-                cb["steps_per_s_at_this_rows_pops"] = round(1.0 / (cb["non_planner_s_per_step"] + d["astar_pops_per_step"] * cb["astar_us_per_pop"] * 1e-6), 4)
             out.append({"config": cfg, "goal_l1_cells": l1, "flags": extra, "workload": d["config"]["workload"], "value": d["value"], "unit": d["unit"],
                         "steps": d["steps"], "warmup": d["warmup"], "ms_per_step": d["ms_per_step"], "astar_pops_per_step": d["astar_pops_per_step"],
                         "stage_ms": d["stage_ms"], "planner": [d["config"]["planner_lanes"], d["config"]["planner_batch"], d["config"]["pipeline_depth"]],
                         "streaming_kernels": d.get("streaming_kernels"), "explore": d.get("explore"), "particles": d["config"]["particles"],
-                        "cpu_baseline": d.get("cpu_baseline"),
+                        "cpu_baseline": d.get("cpu_baseline"), "same_search": d.get("same_search"),
                         "wall_s": round(time.perf_counter() - t0, 1)})
         except subprocess.TimeoutExpired:
             out.append({"config": cfg, "goal_l1_cells": l1, "flags": extra, "error": "timed out"})
@@ -1097,6 +1121,8 @@ def main():
             out["particle_sweep_steps_per_s"][str(args.particles)] = round(args.steps / elapsed, 1)
         if args.cpu_steps > 0 and world == 1:
             out["cpu_baseline"] = cpu_baseline(args, m, odo, scans, rands, goal, args.cpu_steps)
+            if goal is not None:
+                out["same_search"] = same_search(ctx, grid, planner, pose, goal_pose, m)
         if other is not None and world == 1:
             # the reference's own published table (astar_test's six maps), HIP path beside the CPU oracle
             out["astar_fixtures"] = astar_fixtures(ctx, reps=3)
