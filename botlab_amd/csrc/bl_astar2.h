@@ -26,6 +26,7 @@
 
 #include "bl_astar2_turbo.h"
 #include "bl_astar2_deep.h"
+#include "bl_astar2_duo.h"
 
 #define A2_COSTN 256
 #define A2_INF 0xFFFFu
@@ -575,8 +576,10 @@ __global__ __launch_bounds__(64) void k_heap2_probe(const int* __restrict__ keys
 
 // One wavefront runs the reference's search loop; lanes 0..3 evaluate the four neighbours of the popped node, lane 4 re-derives
 // its gCost (as k_astar does).  Closed cells: closed[] holds (generation << 3) | move, written once per cell.
+// Launched with 64 threads, or with 128: the second wavefront then runs the expansions of the LDS-regime loop beside the first
+// (bl_astar2_duo.h) and waits at a barrier whenever the first is anywhere else.
 template <class C>
-__global__ __launch_bounds__(64) void k_astar2(astar_args a)
+__global__ __launch_bounds__(128) void k_astar2(astar_args a)
 {
     if (a.units) {
         const astar_unit u = a.units[blockIdx.x];
@@ -595,7 +598,8 @@ __global__ __launch_bounds__(64) void k_astar2(astar_args a)
     // the scratch k_astar uses for 8-byte entries holds both arrays: payloads [heap_cap], then key slots [heap_cap + 2]
     a2_g_u32* const gp = (a2_g_u32*)a.heap;
     a2_g_u16* const gk = (a2_g_u16*)((char*)a.heap + 4ll * a.heap_cap);
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     __builtin_amdgcn_s_setprio(3);
     astar_result res; res.status = ASTAR_ST_NOPATH; res.path_len = 0; res.pops = 0; res.pushes = 0;
     for (int q = 0; q < 6; ++q) res.stamps[q] = 0;
@@ -622,7 +626,7 @@ __global__ __launch_bounds__(64) void k_astar2(astar_args a)
     const bool ok = cell_cost(a.gx, a.gy) != ASTAR_INVALID_COST       // astar.cpp:40-44
                     && cell_cost(a.sx, a.sy) != ASTAR_INVALID_COST    // :46-50
                     && !(a.sx == a.gx && a.sy == a.gy);               // :52-56
-    if (!ok) { if (lane == 0) { *a.result = res; if (a.host_out) *(astar_result*)a.host_out = res; } return; }
+    if (!ok) { if (lane == 0 && wave == 0) { *a.result = res; if (a.host_out) *(astar_result*)a.host_out = res; } return; }
 
     const a2_lanes ln = a2_make_lanes(lane);
     const bool fast = kbase == 0u && a.max_pops >= 0;      // (hand-scheduled heap operations: the dynamic LDS segment starts at 0)
@@ -655,9 +659,27 @@ __global__ __launch_bounds__(64) void k_astar2(astar_args a)
             sc[A2T_SC_GK] = (unsigned)(size_t)gk; sc[A2T_SC_GK + 1] = (unsigned)((size_t)gk >> 32);
             sc[A2T_SC_GP] = (unsigned)(size_t)gp; sc[A2T_SC_GP + 1] = (unsigned)((size_t)gp >> 32);
             sc[A2T_SC_DLIM] = deep_max - ((unsigned)C::PLN + 2u);                         // the deep loop runs while PLN + 2 <= length <= deep_max
-            for (int q = 24; q < 32; ++q) sc[q] = 0;
+            for (int q = 21; q < 48; ++q) sc[q] = 0;
+            sc[A2W_RUN_WORD] = A2W_GO;
         }
         __syncthreads();
+    }
+    // ---- two wavefronts: the second runs the expansions of the LDS-regime loop until the first says QUIT (bl_astar2_duo.h)
+    const bool duo = turbo && blockDim.x == 128u;
+    if (wave == 1) {
+        if (duo) {
+            if (ahead) asm volatile(A2W_BODY_EXPAND(A2T_PREFETCH, "4")
+                         :: [tbl] "s"(__builtin_amdgcn_readfirstlane((int)tbl)), [kmax] "n"(C::KEY_BYTES - 4), [pln] "n"(C::PLN),
+                            [ok0lo] "n"((unsigned)(((2ull << ((1 << (C::FD + 1)) - 2)) - 1ull) & 0xffffffffull)),
+                            [ok0hi] "n"((unsigned)(((2ull << ((1 << (C::FD + 1)) - 2)) - 1ull) >> 32))
+                         : A2W_EXPAND_CLOBBERS);
+            else asm volatile(A2W_BODY_EXPAND("", "2")
+                         :: [tbl] "s"(__builtin_amdgcn_readfirstlane((int)tbl)), [kmax] "n"(C::KEY_BYTES - 4), [pln] "n"(C::PLN),
+                            [ok0lo] "n"((unsigned)(((2ull << ((1 << (C::FD + 1)) - 2)) - 1ull) & 0xffffffffull)),
+                            [ok0hi] "n"((unsigned)(((2ull << ((1 << (C::FD + 1)) - 2)) - 1ull) >> 32))
+                         : A2W_EXPAND_CLOBBERS);
+        }
+        return;
     }
     // neighbour offsets: xDeltas {1,-1,0,0}, yDeltas {0,0,1,-1} (astar.cpp:215-216); lane 4: the cell itself
     const int ddx = lane == 0 ? 1 : (lane == 1 ? -1 : 0);
@@ -683,7 +705,13 @@ __global__ __launch_bounds__(64) void k_astar2(astar_args a)
             unsigned s_len = (unsigned)__builtin_amdgcn_readfirstlane((int)len), s_pops = (unsigned)__builtin_amdgcn_readfirstlane((int)pops);
             unsigned s_pushes = (unsigned)__builtin_amdgcn_readfirstlane((int)pushes);
             // (grids whose distance + closed arrays fit the L2 gain nothing from asking for lines ahead)
-            if (ahead) asm volatile(A2T_BODY(A2T_PREFETCH, "2")
+            if (duo) asm volatile(A2W_BODY_HEAP
+                         : [len] "+s"(s_len), [pops] "+s"(s_pops), [pushes] "+s"(s_pushes), [code] "=&s"(code), [gm] "=&s"(gm), [pt] "=&s"(ptop)
+                         : [tbl] "s"(__builtin_amdgcn_readfirstlane((int)tbl)), [kmax] "n"(C::KEY_BYTES - 4), [pln] "n"(C::PLN),
+                           [ok0lo] "n"((unsigned)(((2ull << ((1 << (C::FD + 1)) - 2)) - 1ull) & 0xffffffffull)),
+                           [ok0hi] "n"((unsigned)(((2ull << ((1 << (C::FD + 1)) - 2)) - 1ull) >> 32))
+                         : A2T_CLOBBERS);
+            else if (ahead) asm volatile(A2T_BODY(A2T_PREFETCH, "2")
                          : [len] "+s"(s_len), [pops] "+s"(s_pops), [pushes] "+s"(s_pushes), [code] "=&s"(code), [gm] "=&s"(gm), [pt] "=&s"(ptop)
                          : [tbl] "s"(__builtin_amdgcn_readfirstlane((int)tbl)), [kmax] "n"(C::KEY_BYTES - 4), [pln] "n"(C::PLN),
                            [ok0lo] "n"((unsigned)(((2ull << ((1 << (C::FD + 1)) - 2)) - 1ull) & 0xffffffffull)),
@@ -786,6 +814,13 @@ __global__ __launch_bounds__(64) void k_astar2(astar_args a)
         if (full) { res.status = ASTAR_ST_CAPACITY; break; }
         if (goal_m) { res.status = ASTAR_ST_FOUND; break; }
     }
+    if (duo) {                                                                  // the second wave waits at X: let it go home
+        if (lane == 0) *(a2_lds_u32*)(size_t)(tbl + 4096u + 4u * A2W_RUN_WORD) = A2W_QUIT;
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#ifdef BL_ASTAR_STAMPS
+        for (int q = 0; q < 8; ++q) __builtin_amdgcn_s_sleep(100);           // (the second wave adds its sums on its way out)
+#endif
+    }
     res.pops = pops; res.pushes = pushes;
     if (res.status == ASTAR_ST_FOUND) {                                         // :107-114 -> makePath (:235-274)
         const int kk = __ffs((int)goal_m) - 1;
@@ -812,7 +847,13 @@ __global__ __launch_bounds__(64) void k_astar2(astar_args a)
     tr1 = __builtin_amdgcn_s_memrealtime();
     res.stamps[0] = (long long)acc_all; res.stamps[1] = (long long)acc_adj; res.stamps[2] = (long long)acc_nb;
     res.stamps[3] = (long long)(tr1 - tr0); res.stamps[4] = (long long)acc_wait; res.stamps[5] = (long long)acc_push;
-    if (turbo) {
+    if (duo) {
+        // two-wave loop: wave 0's cycles inside Y, X, Z; wave 1's inside X, Y (bl_astar2_duo.h).  Wave 1 adds its sums on its way out:
+        // it has left by the time the barrier below is through... the sums it has added so far, then
+        const a2_lds_u32* sc = (const a2_lds_u32*)(size_t)(tbl + 4096u);
+        res.stamps[0] = sc[21]; res.stamps[1] = sc[22]; res.stamps[2] = sc[23]; res.stamps[4] = sc[25]; res.stamps[5] = sc[24];
+        res.path_off = (long long)sc[30] | ((long long)sc[31] << 32);      // (diagnostic only) expansions out of registers | asked for
+    } else if (turbo) {
         // the straight-line loop's own sums (table words 16 .. 21) on top: checks + top -> [0] (with the rest), pop -> [1], expansion -> [2], load wait -> [4], pushes -> [5]
         const a2_lds_u32* sc = (const a2_lds_u32*)(size_t)(tbl + 4096u);
         const long long m0 = sc[24], m1 = sc[25], m2 = sc[26], m3 = sc[27], m4 = sc[28], m5 = sc[29];

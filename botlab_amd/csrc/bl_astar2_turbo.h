@@ -36,7 +36,7 @@
 #define A2T_SC_GK 16
 #define A2T_SC_GP 18
 #define A2T_SC_DLIM 20
-#define A2T_TBL_BYTES (4096 + 128)
+#define A2T_TBL_BYTES (4096 + 256)            // lane rows; 32 scalar words; the two-wave loop's record and run word (bl_astar2_duo.h)
 
 // one sift-down round: node N, child C_, knext K, payload P (of the child), mask SQ, lane mask OK (see a2_round_lds); FILL =
 // instructions of the expansion that need nothing from the round: they run while the round's LDS read is under way

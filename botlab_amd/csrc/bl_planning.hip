@@ -2645,6 +2645,16 @@ static bool astar_split_ok(const bl_astar_state* s)
     return !force_v1 && s->lut_valid && s->lut_min > -32768;
 }
 
+// Threads of a k_astar2 workgroup.  128: a second wavefront runs the expansions of the LDS-regime loop beside the first
+// (bl_astar2_duo.h: -4 .. -9 % per pop there).  Only for searches that have their compute unit to themselves (the 147 KB heap):
+// the replanner's units share CUs four at a time, where a second wave per search would take issue slots from the others.
+// BOTLAB_ASTAR_DUO=0: one wave everywhere (A/B runs, tests).
+static int astar2_threads(bool shares_cu = false)
+{
+    static const bool duo = !(getenv("BOTLAB_ASTAR_DUO") && atoi(getenv("BOTLAB_ASTAR_DUO")) == 0);
+    return duo && !shares_cu ? 128 : 64;
+}
+
 static void astar_launch_kernel(bl_ctx* ctx, const astar_args& a, int workgroups, bool split)
 {
     // The 40 KB footprint is for searches that share CUs with the particle filter (the replanner's units): beside its
@@ -2654,8 +2664,8 @@ static void astar_launch_kernel(bl_ctx* ctx, const astar_args& a, int workgroups
     // list spilling past the LDS levels pays an HBM round trip per heap level.
     static const bool force_small = getenv("BOTLAB_ASTAR_SMALL_LDS") != nullptr;     // probes: the replanner's footprint on a lone search
     const bool small = ctx->astar_small_lds || force_small;
-    if (split && small) hipLaunchKernelGGL((k_astar2<a2_small>), dim3(workgroups), dim3(64), a2_small::BYTES, ctx->stream, a);
-    else if (split) hipLaunchKernelGGL((k_astar2<a2_big>), dim3(workgroups), dim3(64), a2_big::BYTES, ctx->stream, a);
+    if (split && small) hipLaunchKernelGGL((k_astar2<a2_small>), dim3(workgroups), dim3(astar2_threads(true)), a2_small::BYTES, ctx->stream, a);
+    else if (split) hipLaunchKernelGGL((k_astar2<a2_big>), dim3(workgroups), dim3(astar2_threads()), a2_big::BYTES, ctx->stream, a);
     else if (small) hipLaunchKernelGGL((k_astar<AH_LDS_SMALL, AH_COST_LDS_SMALL>), dim3(workgroups), dim3(64), AH_LDS_SMALL_BYTES, ctx->stream, a);
     else hipLaunchKernelGGL((k_astar<AH_LDS, AH_COST_LDS>), dim3(workgroups), dim3(64), AH_LDS_BYTES, ctx->stream, a);
 }
@@ -2745,6 +2755,11 @@ extern "C" int bl_astar_search_result(bl_ctx* ctx, bl_pose_xyt_t* out_path, int 
 #ifdef BL_ASTAR_STAMPS
     {
         const double pp = (double)(r.pops ? r.pops : 1);
+        if (astar2_threads() == 128 && !(ctx->astar_small_lds || getenv("BOTLAB_ASTAR_SMALL_LDS")))
+            fprintf(stderr, "[astar duo stamps] pops %lld: cycles/pop -- wave 1: Z to the wait %.0f, the wait %.0f, expansion %.0f, record %.0f; wave 0 inside Y %.0f | search %.0f cycles/pop | tops foreseen %lld, not %lld\n", r.pops,
+                    (double)r.stamps[0] / pp, (double)r.stamps[1] / pp, (double)r.stamps[2] / pp, (double)r.stamps[4] / pp, (double)r.stamps[5] / pp,
+                    (double)r.stamps[3] * 1e-8 * 2.4e9 / pp, (long long)(r.path_off & 0xffffffffll), (long long)(r.path_off >> 32));
+        else
         fprintf(stderr, "[astar stamps] pops %lld pushes %lld cycles/pop: all %.0f = issue %.0f + adjust %.0f + loadwait %.0f + expand %.0f + pushes %.0f | clock %.2f GHz\n",
                 r.pops, r.pushes, (double)r.stamps[0] / pp,
                 ((double)r.stamps[0] - (double)r.stamps[1] - (double)r.stamps[2] - (double)r.stamps[4] - (double)r.stamps[5]) / pp,
@@ -2898,7 +2913,7 @@ static int astar_batch_cells(bl_ctx* ctx, const bl_dist* d, const bl_pose_xyt_t*
         hipEvent_t e0, e1;
         rc = bl_timer_begin(ctx, BL_K_ASTAR, &e0, &e1);
         if (rc) return rc;
-        if (astar_split_ok(s)) hipLaunchKernelGGL((k_astar2<a2_big>), dim3(m), dim3(64), a2_big::BYTES, ctx->stream, a);
+        if (astar_split_ok(s)) hipLaunchKernelGGL((k_astar2<a2_big>), dim3(m), dim3(astar2_threads()), a2_big::BYTES, ctx->stream, a);
         else hipLaunchKernelGGL((k_astar<AH_LDS, AH_COST_LDS>), dim3(m), dim3(64), AH_LDS_BYTES, ctx->stream, a);
         BL_HIP(hipGetLastError());
         rc = bl_timer_end(ctx, BL_K_ASTAR, e0, e1);
