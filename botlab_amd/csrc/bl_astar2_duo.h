@@ -9,15 +9,18 @@
 //                      (astar.cpp:95-135, 213-233) -- it needs the popped top only, which is known before the pop begins
 // Same macros, same order of heap operations, same stores as the one-wave loop: the open list goes through the same states.
 //
-// Hand-over, three barriers per iteration (both waves execute exactly X, Z, Y in turn):
-//     X   the heap is final (wave 0 has finished the previous iteration's pushes)   -> wave 1 reads the top (payload, key)
-//     Z   wave 1 HAS read the top                                                   -> wave 0 may store into the heap (it reaches Z
-//         behind its walk, ~800 cycles after X: it never waits here, but the order is the barrier's, not the clock's)
-//     Y   wave 1's record is in LDS: push mask, goal mask, the popped payload, (key, payload) of up to four candidates
-//                                                                                   -> wave 0 pushes
+// Hand-over, per iteration two barriers and a flag word:
+//     X   (barrier) the heap is final: wave 0 has finished the previous iteration's pushes   -> wave 1 reads the top (payload, key)
+//     Z   (flag)    wave 1 raises it when it HAS read the top; wave 0 looks at it in front of its stores into the heap -- ~800 cycles
+//                   behind X, so it never waits, but the order is the flag's, not the clock's -- and lowers it again.  (A barrier here
+//                   holds BOTH waves: wave 1 stood in it for the whole walk.)
+//     Y   (barrier) wave 1's record is in LDS: push mask, goal mask, the popped payload, (key, payload) of up to four candidates
+//                                                                                           -> wave 0 pushes
 // Wave 1 never leaves its loop while the kernel runs: whenever wave 0 is outside this loop (the general iteration, the deep loop)
-// wave 1 waits at X.  At the end wave 0 stores QUIT in the run word and passes X once more.
-// Record: table words 32..35 = push mask, goal mask, popped payload, -; words 36..43 = (key, payload) x 4; word 44 = run word.
+// wave 1 waits at X; on its way back in wave 0 sets the run word to 3 ("go, and forget what you foresaw"), behind its first gate
+// to 1 ("go").  At the end wave 0 stores QUIT and passes X once more.
+// Record: table words 32..35 = push mask, goal mask, popped payload, -; words 36..43 = (key, payload) x 4; word 44 = run word;
+// word 45 = the flag.
 #ifndef BL_ASTAR2_DUO_H
 #define BL_ASTAR2_DUO_H
 
@@ -27,9 +30,9 @@
 #define A2W_GO 1u
 #define A2W_QUIT 2u
 
-// Diagnostic build (-DBL_ASTAR_STAMPS): cycles a wave spends inside a barrier (ACC an SGPR both loops leave alone), summed into table
-// word W at the loop's exit.  Wave 0: word 24 = at Y (waiting for the record), 25 = at X, 26 = at Z; wave 1: 27 = at X (idle under the
-// pushes and the walk), 28 = at Y.
+// Diagnostic build (-DBL_ASTAR_STAMPS): cycles inside barriers and between marks (ACC an SGPR the loops leave alone), added into table
+// words at the loop's exit.  Wave 0: word 24 = inside Y (waiting for the record); wave 1: words 21 / 22 / 23 / 25 = from the flag to the
+// wait for its loads / the wait / the expansion / the record, 27 / 28 = inside X / Y, 30 / 31 = tops that were the foreseen one / not.
 #ifdef BL_ASTAR_STAMPS
 #define A2W_TIMED_BARRIER(ACC) "s_memtime s[100:101]\n\ts_waitcnt lgkmcnt(0)\n\ts_mov_b32 s43, s100\n\ts_barrier\n\ts_memtime s[100:101]\n\ts_waitcnt lgkmcnt(0)\n\ts_sub_u32 s43, s100, s43\n\ts_add_u32 " ACC ", " ACC ", s43\n\t"
 #define A2W_ACC_OUT(ACC, OFF) "v_mov_b32 v245, %[tbl]\n\tv_mov_b32 v250, " ACC "\n\ts_mov_b64 exec, 1\n\tds_add_u32 v245, v250 offset:" OFF "\n\ts_mov_b64 exec, -1\n\ts_waitcnt lgkmcnt(0)\n\t"
