@@ -67,6 +67,7 @@ struct bl_pf {
     int block_override;       // 0: automatic
     bool debug;               // record resample index / likelihood per particle (parity tests)
     bool strict;              // strict resampling: prefix[] is overwritten with the reference's rounded double cumulative after every finish
+    void* strict_recs; double* strict_starts;     // ... by chunks side by side: a record and the true start per chunk of 128 particles
     unsigned long long* block_sums;   // scan scratch
     int scan_blocks;
     int32_t* dbg_idx;
@@ -1114,8 +1115,8 @@ __global__ __launch_bounds__(256) void k_pf_resample_only(const unsigned long lo
 // resamplePosteriorDistribution (particle_filter.cpp:84-103) compares U with c, c = w_0, then c += w_i: a SEQUENTIALLY ROUNDED
 // double sum of the normalised weights w_i = fl64(units_i / S).  One wave reproduces every c_i: inside a binade the sum is an
 // integer prefix of quantized terms (bl_serial_sum.h, double form), a step that leaves the binade or ties is taken in real
-// arithmetic.  128 particles per round, the next round's weights loaded ahead.  Strict mode only (bl_pf_set_strict_resampling):
-// it costs a launch of its own per update, ~0.6 ms at 100k particles.
+// arithmetic (strict_chunk).  Strict mode only (bl_pf_set_strict_resampling).  One wave walking the whole sum took 0.7 ms at 100k
+// particles and 7.3 ms at 1M; the chunks side by side (k_strict_records / _chain / _fill below) take ~50 / ~140 us.
 __device__ __forceinline__ long long mclf_scan_add_i64(long long v)
 {
 #define MCLF_STEP(C, R) { const int lo_ = mclf_dpp<C, R>(0, (int)(unsigned int)(unsigned long long)v);                       \
@@ -1132,73 +1133,181 @@ __device__ __forceinline__ long long mclf_readlane_i64(long long v, int lane)
     return (long long)(((unsigned long long)(unsigned int)hi << 32) | (unsigned long long)(unsigned int)lo);
 }
 
+// One chunk of up to 128 terms (lane l holds terms 2l, 2l + 1 as w[0], w[1]) stepped from the true accumulator `acc` (wave-uniform):
+// in-binade integer prefix sums up to the first step that leaves the binade, ties or is too large, that step in real arithmetic,
+// and on.  out: where c_i of the chunk's term i goes (out[i]), or null.  Returns the accumulator behind the chunk.
+__device__ __forceinline__ double strict_chunk(double acc, const double (&w)[2], int n, int lane, double* __restrict__ out)
+{
+    int pos = 0;
+    while (pos < n) {
+        const int key = __builtin_amdgcn_readfirstlane(ssd_key(acc));
+        if (!key) {                                            // the very first term (c = w_0), or nothing usable
+            acc = ssd_exact_step(acc, mclf_readlane_f64((pos & 1) ? w[1] : w[0], pos >> 1));
+            if (out && lane == (pos >> 1)) out[pos] = acc;
+            pos++;
+            continue;
+        }
+        const long long M = ssd_mag(acc);
+        const ssd_bin b = ssd_bin_of(key);
+        long long p[2], run = 0;
+        int bad[2];
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int i = 2 * lane + k;
+            int bk = 0;
+            const long long d = ssd_quantize(b, w[k], &bk);
+            const bool on = i >= pos && i < n;
+            run += on ? d : 0; bad[k] = on ? bk : 0;
+            p[k] = run;
+        }
+        const long long excl = mclf_scan_add_i64(run) - run;
+        long long Mi[2];
+        bool ex[2];
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int i = 2 * lane + k;
+            Mi[k] = M + excl + p[k];
+            ex[k] = i >= pos && i < n && (bad[k] || Mi[k] <= SSD_MLO || Mi[k] >= SSD_MHI);
+        }
+        const unsigned long long mask = __builtin_amdgcn_ballot_w64(ex[0] || ex[1]);
+        int j = n;
+        if (mask) {
+            const int fl = __ffsll((long long)mask) - 1;
+            j = 2 * fl + (__builtin_amdgcn_readlane(ex[0] ? 1 : 0, fl) ? 0 : 1);
+        }
+        if (out) {
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const int i = 2 * lane + k;
+                if (i >= pos && i < j) out[i] = ssd_from(key, Mi[k]);
+            }
+        }
+        if (j == n) { acc = ssd_from(key, mclf_readlane_i64((n - 1) & 1 ? Mi[1] : Mi[0], (n - 1) >> 1)); break; }
+        double before = acc;
+        if (j > pos) before = ssd_from(key, mclf_readlane_i64((j - 1) & 1 ? Mi[1] : Mi[0], (j - 1) >> 1));
+        acc = ssd_exact_step(before, mclf_readlane_f64((j & 1) ? w[1] : w[0], j >> 1));
+        if (out && lane == (j >> 1)) out[j] = acc;
+        pos = j + 1;
+    }
+    return acc;
+}
+
+// the chunk's two terms of a lane: w_i = fl64(units_i / S) (particle_filter.cpp:134-141 normalises, :94-99 accumulates)
+__device__ __forceinline__ void strict_terms(const float4* __restrict__ rec, int N, int base, int lane, double S, double (&w)[2])
+{
+    const int i = base + 2 * lane;
+    w[0] = i < N ? (double)__float_as_uint(rec[i].w) / S : 0.0;
+    w[1] = i + 1 < N ? (double)__float_as_uint(rec[i + 1].w) / S : 0.0;
+}
+
+// The whole sum by ONE wave, chunk after chunk: small particle sets (below STRICT_PAR_MIN), and the form the three kernels below are
+// checked against.
 __global__ __launch_bounds__(64) void k_pf_cumulative_strict(const float4* __restrict__ rec, int N, const pf_state* __restrict__ state,
                                                              double* __restrict__ out)
 {
     const int lane = threadIdx.x;
     const double S = state->S;
     double acc = 0.0;                                              // wave-uniform
-    unsigned int un[2] = {0u, 0u};
-    if (2 * lane < N) un[0] = __float_as_uint(rec[2 * lane].w);
-    if (2 * lane + 1 < N) un[1] = __float_as_uint(rec[2 * lane + 1].w);
     for (int base = 0; base < N; base += 128) {
-        const int n = min(128, N - base);
-        const double w[2] = {(double)un[0] / S, (double)un[1] / S};
-        {   // the next round's units, in flight during this round
-            const int nb = base + 128 + 2 * lane;
-            un[0] = nb < N ? __float_as_uint(rec[nb].w) : 0u;
-            un[1] = nb + 1 < N ? __float_as_uint(rec[nb + 1].w) : 0u;
-        }
-        int pos = 0;
-        while (pos < n) {
-            const int key = __builtin_amdgcn_readfirstlane(ssd_key(acc));
-            if (!key) {                                            // the very first term (c = w_0), or nothing usable
-                acc = ssd_exact_step(acc, mclf_readlane_f64((pos & 1) ? w[1] : w[0], pos >> 1));
-                if (lane == (pos >> 1)) out[base + pos] = acc;
-                pos++;
-                continue;
-            }
-            const long long M = ssd_mag(acc);
+        double w[2];
+        strict_terms(rec, N, base, lane, S, w);
+        acc = strict_chunk(acc, w, min(128, N - base), lane, out + base);
+    }
+}
+
+// ---- the same sum with the chunks side by side.  The weights are positive, so the sum only
+// grows: it stays in one binade for long stretches (half of all particles lie in the last one) and changes binade ~17 times in all.
+//   A  k_strict_records   a wave per chunk: with the binade the chunk's start is PREDICTED to lie in -- from the exact integer prefix of
+//                         the weight units, prefix[base - 1] / S -- the chunk's terms as integers of that binade's ulp, their sum D,
+//                         and "bad" if any term ties or is too large there
+//   B  k_strict_chain     one wave walks the chunks' records with the TRUE accumulator, 64 at a time: a run of chunks whose predicted
+//                         binade is the accumulator's, without bad terms and ending below the binade's end, is an integer prefix sum
+//                         (every step in it rounds to the ulp without a tie, so c advances by exactly its integer); the first chunk
+//                         that is not (a crossing, a tie, a misprediction, chunk 0 with the sum's first steps) is stepped from its
+//                         terms (strict_chunk) and the walk goes on behind it.  Leaves every chunk's true start.
+//   C  k_strict_fill      a wave per chunk: strict_chunk from the true start, c_i written out
+// prefix[] is read by A (integers) and overwritten by C (doubles).
+#define STRICT_PAR_MIN 4096
+struct strict_rec { long long D; int key; int bad; };
+
+__global__ __launch_bounds__(256) void k_strict_records(const float4* __restrict__ rec, int N, const pf_state* __restrict__ state,
+                                                        const unsigned long long* __restrict__ prefix, strict_rec* __restrict__ recs)
+{
+    const int lane = threadIdx.x & 63;
+    const int t = (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6);
+    const int base = t * 128;
+    if (base >= N) return;
+    const int n = min(128, N - base);
+    const double S = state->S;
+    strict_rec r; r.D = 0; r.key = 0; r.bad = 1;
+    if (t > 0) {
+        double w[2];
+        strict_terms(rec, N, base, lane, S, w);
+        const int key = ssd_key((double)prefix[base - 1] / S);
+        if (key) {
             const ssd_bin b = ssd_bin_of(key);
-            long long p[2], run = 0;
-            int bad[2];
+            int bad = 0;
+            long long d = 0;
 #pragma unroll
             for (int k = 0; k < 2; ++k) {
-                const int i = 2 * lane + k;
                 int bk = 0;
-                const long long d = ssd_quantize(b, w[k], &bk);
-                const bool on = i >= pos && i < n;
-                run += on ? d : 0; bad[k] = on ? bk : 0;
-                p[k] = run;
+                const long long q = ssd_quantize(b, w[k], &bk);
+                if (2 * lane + k < n) { d += q; bad |= bk; }
             }
-            const long long excl = mclf_scan_add_i64(run) - run;
-            long long Mi[2];
-            bool ex[2];
-#pragma unroll
-            for (int k = 0; k < 2; ++k) {
-                const int i = 2 * lane + k;
-                Mi[k] = M + excl + p[k];
-                ex[k] = i >= pos && i < n && (bad[k] || Mi[k] <= SSD_MLO || Mi[k] >= SSD_MHI);
-            }
-            const unsigned long long mask = __builtin_amdgcn_ballot_w64(ex[0] || ex[1]);
-            int j = n;
-            if (mask) {
-                const int fl = __ffsll((long long)mask) - 1;
-                j = 2 * fl + (__builtin_amdgcn_readlane(ex[0] ? 1 : 0, fl) ? 0 : 1);
-            }
-#pragma unroll
-            for (int k = 0; k < 2; ++k) {
-                const int i = 2 * lane + k;
-                if (i >= pos && i < j) out[base + i] = ssd_from(key, Mi[k]);
-            }
-            if (j == n) { acc = ssd_from(key, mclf_readlane_i64((n - 1) & 1 ? Mi[1] : Mi[0], (n - 1) >> 1)); break; }
-            double before = acc;
-            if (j > pos) before = ssd_from(key, mclf_readlane_i64((j - 1) & 1 ? Mi[1] : Mi[0], (j - 1) >> 1));
-            acc = ssd_exact_step(before, mclf_readlane_f64((j & 1) ? w[1] : w[0], j >> 1));
-            if (lane == (j >> 1)) out[base + j] = acc;
-            pos = j + 1;
+            const long long tot = mclf_readlane_i64(mclf_scan_add_i64(d), 63);
+            r.D = tot; r.key = key; r.bad = __builtin_amdgcn_ballot_w64(bad != 0) != 0ull ? 1 : 0;
         }
     }
+    if (lane == 0) recs[t] = r;
+}
+
+__global__ __launch_bounds__(64) void k_strict_chain(const float4* __restrict__ rec, int N, const pf_state* __restrict__ state,
+                                                     const strict_rec* __restrict__ recs, double* __restrict__ starts)
+{
+    const int lane = threadIdx.x;
+    const double S = state->S;
+    const int nchunks = (N + 127) / 128;
+    double acc = 0.0;                                              // wave-uniform: the true accumulator in front of chunk g0 + pos
+    for (int g0 = 0; g0 < nchunks; g0 += 64) {
+        const int c = g0 + lane;
+        strict_rec r; r.D = 0; r.key = 0; r.bad = 1;
+        if (c < nchunks) r = recs[c];
+        const int cnt = min(64, nchunks - g0);
+        int pos = 0;
+        while (pos < cnt) {
+            const int key = __builtin_amdgcn_readfirstlane(ssd_key(acc));
+            const long long M = key ? ssd_mag(acc) : 0;
+            const bool ok = key != 0 && lane >= pos && lane < cnt && !r.bad && r.key == key;
+            const long long Dm = ok ? r.D : 0;
+            const long long incl = mclf_scan_add_i64(Dm);
+            const long long Mi = M + incl;
+            const bool fail = lane >= pos && (!ok || Mi >= SSD_MHI);
+            const unsigned long long mask = __builtin_amdgcn_ballot_w64(fail);
+            const int j = __builtin_amdgcn_readfirstlane(mask ? __ffsll((long long)mask) - 1 : 64);      // (lanes from cnt on fail: j <= cnt)
+            if (lane >= pos && lane < j) starts[c] = ssd_from(key, Mi - Dm);
+            if (j > pos) acc = ssd_from(key, mclf_readlane_i64(Mi, j - 1));
+            if (j < cnt) {                                          // chunk g0 + j does not go by its record: from its terms
+                if (lane == 0) starts[g0 + j] = acc;
+                const int base = (g0 + j) * 128;
+                double w[2];
+                strict_terms(rec, N, base, lane, S, w);
+                acc = strict_chunk(acc, w, min(128, N - base), lane, nullptr);
+                pos = j + 1;
+            } else pos = cnt;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_strict_fill(const float4* __restrict__ rec, int N, const pf_state* __restrict__ state,
+                                                     const double* __restrict__ starts, double* __restrict__ out)
+{
+    const int lane = threadIdx.x & 63;
+    const int t = (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6);
+    const int base = t * 128;
+    if (base >= N) return;
+    double w[2];
+    strict_terms(rec, N, base, lane, state->S, w);
+    (void)strict_chunk(starts[t], w, min(128, N - base), lane, out + base);
 }
 
 // ---------------------------------------------------------------- init / export / small state kernels
@@ -1341,7 +1450,7 @@ extern "C" void bl_pf_destroy(bl_pf* pf)
     (void)hipStreamSynchronize(pf->ctx->stream);
     if (!pf->rec_external) { if (pf->rec[0]) (void)hipFree(pf->rec[0]); if (pf->rec[1]) (void)hipFree(pf->rec[1]); }
     void* ptrs[] = {pf->fin_wild, pf->tile_partials, pf->fin_recs, pf->fin_tabs, pf->fin_sync, pf->prefix, pf->parent, pf->state, pf->partials, pf->block_sums, pf->dbg_idx, pf->dbg_like,
-                    pf->d_noise, pf->d_export, pf->sh_xchg, pf->sh_tab, pf->sh_fin, pf->sh_flags, pf->sh_peers_dev};
+                    pf->d_noise, pf->d_export, pf->sh_xchg, pf->sh_tab, pf->sh_fin, pf->sh_flags, pf->sh_peers_dev, pf->strict_recs, pf->strict_starts};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     delete pf;
 }
@@ -1361,6 +1470,21 @@ extern "C" const void* bl_pf_pose_device_ptr(bl_pf* pf) { return pf && pf->state
 static void pf_strict_cumulative(bl_pf* pf, int which)
 {
     if (!pf->strict) return;
+    static const bool one_wave = getenv("BOTLAB_STRICT_ONE_WAVE") != nullptr;        // tests, A/B runs
+    const int nchunks = (pf->N + 127) / 128;
+    if (pf->N >= STRICT_PAR_MIN && !one_wave) {
+        if (!pf->strict_recs) {
+            if (hipMalloc((void**)&pf->strict_recs, (size_t)nchunks * sizeof(strict_rec)) != hipSuccess) pf->strict_recs = nullptr;
+            if (pf->strict_recs && hipMalloc((void**)&pf->strict_starts, (size_t)nchunks * sizeof(double)) != hipSuccess) { (void)hipFree(pf->strict_recs); pf->strict_recs = nullptr; }
+        }
+        if (pf->strict_recs) {
+            hipStream_t st = pf->ctx->stream;
+            hipLaunchKernelGGL(k_strict_records, dim3((nchunks + 3) / 4), dim3(256), 0, st, pf->rec[which], pf->N, pf->state, pf->prefix, (strict_rec*)pf->strict_recs);
+            hipLaunchKernelGGL(k_strict_chain, dim3(1), dim3(64), 0, st, pf->rec[which], pf->N, pf->state, (const strict_rec*)pf->strict_recs, pf->strict_starts);
+            hipLaunchKernelGGL(k_strict_fill, dim3((nchunks + 3) / 4), dim3(256), 0, st, pf->rec[which], pf->N, pf->state, pf->strict_starts, (double*)pf->prefix);
+            return;
+        }
+    }
     hipLaunchKernelGGL(k_pf_cumulative_strict, dim3(1), dim3(64), 0, pf->ctx->stream, pf->rec[which], pf->N, pf->state, (double*)pf->prefix);
 }
 
