@@ -1240,7 +1240,14 @@ __global__ __launch_bounds__(256) void k_strict_records(const float4* __restrict
     const int n = min(128, N - base);
     const double S = state->S;
     strict_rec r; r.D = 0; r.key = 0; r.bad = 1;
-    if (t > 0) {
+    if (t == 0) {
+        // the sum's first chunk starts from zero and crosses a binade every few terms: stepped here, beside the other chunks' records;
+        // its record is the accumulator behind it (bad = 2)
+        double w[2];
+        strict_terms(rec, N, 0, lane, S, w);
+        const double end0 = strict_chunk(0.0, w, n, lane, nullptr);
+        r.D = __double_as_longlong(end0); r.bad = 2;
+    } else {
         double w[2];
         strict_terms(rec, N, base, lane, S, w);
         const int key = ssd_key((double)prefix[base - 1] / S);
@@ -1268,12 +1275,20 @@ __global__ __launch_bounds__(64) void k_strict_chain(const float4* __restrict__ 
     const double S = state->S;
     const int nchunks = (N + 127) / 128;
     double acc = 0.0;                                              // wave-uniform: the true accumulator in front of chunk g0 + pos
+    strict_rec nxt; nxt.D = 0; nxt.key = 0; nxt.bad = 1;
+    if (lane < nchunks) nxt = recs[lane];
     for (int g0 = 0; g0 < nchunks; g0 += 64) {
         const int c = g0 + lane;
-        strict_rec r; r.D = 0; r.key = 0; r.bad = 1;
-        if (c < nchunks) r = recs[c];
+        strict_rec r = nxt;
+        nxt.D = 0; nxt.key = 0; nxt.bad = 1;
+        if (c + 64 < nchunks) nxt = recs[c + 64];                   // (the next 64 records travel while these are walked)
         const int cnt = min(64, nchunks - g0);
         int pos = 0;
+        if (g0 == 0) {                                              // chunk 0 was stepped by k_strict_records: its record is the sum behind it
+            if (lane == 0) starts[0] = 0.0;
+            acc = __longlong_as_double(mclf_readlane_i64(r.D, 0));
+            pos = 1;
+        }
         while (pos < cnt) {
             const int key = __builtin_amdgcn_readfirstlane(ssd_key(acc));
             const long long M = key ? ssd_mag(acc) : 0;
