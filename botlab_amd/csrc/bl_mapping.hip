@@ -734,6 +734,7 @@ extern "C" int bl_mapping_update_finishing_pf(bl_mapping* m, const bl_lidar_t* s
     int rc = finishing_pf_prepare(pf, m, scan, map, &fin, &ride);
     if (rc) return rc;
     rc = mapping_update_impl(m, scan, nullptr, bl_pf_pose_device_ptr(pf), pose_utime, map, nullptr, ride ? &fin : nullptr);
+    if (!rc && ride) bl_pf_ride_launched(pf);
     return finish_after_failure(pf, &fin, ride, rc);
 }
 
@@ -749,17 +750,19 @@ extern "C" int bl_planner_submit_with_map_update_finishing_pf(bl_planner* p, bl_
     if ((size_t)map->frame.width * map->frame.height > (size_t)MAP_SNAPSHOT_IN_KERNEL_CELLS) {
         rc = mapping_update_impl(m, scan, nullptr, d_pose, pose_utime, map, nullptr, ride ? &fin : nullptr);
         if (rc) return finish_after_failure(pf, &fin, ride, rc);
+        if (ride) bl_pf_ride_launched(pf);
         return bl_planner_submit(p, map, d_pose, goal, params);
     }
     bl_planner_snap sn;
     rc = bl_planner_reserve(p, map, &sn);
     if (rc) {
         // the filter's bookkeeping is already done: its finish must still be launched (with the map update, which is this step's)
-        if (ride) { const int rc2 = mapping_update_impl(m, scan, nullptr, d_pose, pose_utime, map, nullptr, &fin); (void)finish_after_failure(pf, &fin, true, rc2); }
+        if (ride) { const int rc2 = mapping_update_impl(m, scan, nullptr, d_pose, pose_utime, map, nullptr, &fin); if (!rc2) bl_pf_ride_launched(pf); (void)finish_after_failure(pf, &fin, true, rc2); }
         return rc;
     }
     rc = mapping_update_impl(m, scan, nullptr, d_pose, pose_utime, map, &sn, ride ? &fin : nullptr);
     if (rc) { bl_planner_cancel(p); return finish_after_failure(pf, &fin, ride, rc); }
+    if (ride) bl_pf_ride_launched(pf);
     bl_grid_adopt_lineage(sn.grid, map);
     return bl_planner_commit(p, goal, params);
 }

@@ -1425,6 +1425,8 @@ static int pf_alloc(bl_pf* pf)
     BL_HIP(hipMemsetAsync(pf->fin_sync, 0, MCLF_SYNC_WORDS * sizeof(unsigned long long), pf->ctx->stream));
     BL_HIP(hipMalloc((void**)&pf->dbg_idx, n * sizeof(int32_t)));
     BL_HIP(hipMalloc((void**)&pf->dbg_like, n * sizeof(int32_t)));
+    BL_HIP(hipMemsetAsync(pf->dbg_idx, 0, n * sizeof(int32_t), pf->ctx->stream));
+    BL_HIP(hipMemsetAsync(pf->dbg_like, 0, n * sizeof(int32_t), pf->ctx->stream));
     BL_HIP(hipMemsetAsync(pf->state, 0, sizeof(pf_state), pf->ctx->stream));
     return BL_OK;
 }
@@ -1960,7 +1962,9 @@ extern "C" int bl_pf_update_end(bl_pf* pf, bl_pose_xyt_t* out_pose)
 int bl_pf_take_finish(bl_pf* pf, mcl_finish_args* out)
 {
     if (!pf || !pf->pending_end) return 0;
-    if (pf->strict) return -1;                               // (strict resampling appends a launch of its own to the finish)
+    // (strict resampling: the cumulative's launches follow the launch that carries the finish -- bl_pf_ride_launched; a sharded
+    // set in strict mode ends its update the ordinary way)
+    if (pf->strict && pf->sh_world > 1) return -1;
     if (pf->sh_world > 1) {
         // composed finish: groups and both all-gathers lie behind (else the caller ends the update the ordinary way, which says so)
         if (!pf->sh_stage_groups) return -1;
@@ -2449,11 +2453,18 @@ extern "C" int bl_pf_shard_traffic(bl_pf* pf, int64_t* out3)
 
 bl_ctx* bl_pf_ctx(bl_pf* pf) { return pf ? pf->ctx : nullptr; }
 
+// the launch that carries a taken finish has been enqueued: what follows the finish in strict mode follows it
+void bl_pf_ride_launched(bl_pf* pf)
+{
+    if (pf) pf_strict_cumulative(pf, pf->cur);               // (bl_pf_take_finish has flipped cur: the record the finish works on)
+}
+
 int bl_pf_launch_taken_finish(bl_pf* pf, const mcl_finish_args* fin)
 {
     if (!pf || !fin) return BL_ERR_ARG;
     hipLaunchKernelGGL(k_mcl_finish, dim3(MCLF_EXTRA_WGS + fin->groups_wait), dim3(MCLF_WG), MCLF_LDS_BYTES, pf->ctx->stream, *fin);
     BL_HIP(hipGetLastError());
+    bl_pf_ride_launched(pf);
     return BL_OK;
 }
 
@@ -2728,6 +2739,12 @@ extern "C" int bl_debug_trig_addition_probe(bl_ctx* ctx, uint64_t pairs, uint32_
 extern "C" int bl_pf_debug_enable(bl_pf* pf, int on)
 {
     BL_CHECK_ARG(pf != nullptr);
+    // (what bl_pf_debug_last returns before the first resampling update is zeros, not whatever the allocation held)
+    if (on && !pf->debug && pf->dbg_idx) {
+        BL_HIP(hipSetDevice(pf->ctx->device));
+        BL_HIP(hipMemsetAsync(pf->dbg_idx, 0, (size_t)pf->n_local * sizeof(int32_t), pf->ctx->stream));
+        BL_HIP(hipMemsetAsync(pf->dbg_like, 0, (size_t)pf->n_local * sizeof(int32_t), pf->ctx->stream));
+    }
     pf->debug = on != 0;
     return BL_OK;
 }

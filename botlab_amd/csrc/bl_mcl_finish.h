@@ -1735,5 +1735,7 @@ int bl_pf_take_finish(bl_pf* pf, mcl_finish_args* out);
 bl_ctx* bl_pf_ctx(bl_pf* pf);
 // a finish that was taken and could not ride after all (its carrier failed before the launch): k_mcl_finish on its own
 int bl_pf_launch_taken_finish(bl_pf* pf, const mcl_finish_args* fin);
+// the launch that carries a taken finish has been enqueued (strict resampling: the cumulative's launches go behind it)
+void bl_pf_ride_launched(bl_pf* pf);
 
 #endif

@@ -132,3 +132,47 @@ def test_strict_mode_updates_match_the_oracle(oracle, maps, gpu_ctx):
         assert (np.float32(pose.x), np.float32(pose.y), np.float32(pose.theta)) == (np.float32(res["pose"].x), np.float32(res["pose"].y), np.float32(res["pose"].theta))
     assert moved == 3
     pf.close()
+
+
+def test_strict_mode_with_the_filter_end_riding_in_the_map_kernel(maps, gpu_ctx):
+    """Strict mode keeps the riding form of the update's end (bl_mapping_update_finishing_pf): the cumulative's launches go behind the
+    map kernel that carries the finish.  Same indices, particles, estimates and maps as updateFilter + updateMap in strict mode
+    (which test_strict_mode_updates_match_the_oracle holds against the oracle), with rand() values that make the two resampling
+    rules differ on equal weights."""
+    import helpers
+    from botlab_amd import synth
+    N = 20_000
+    m = maps["obstacle_slam_10mx10m_5cm"]
+    truth = np.where(m["cells"] > 0, 127, -127).astype(np.int8)
+    poses = synth.square_trajectory((-0.75, 0.2, 0.0), 6, step_len=0.02, turn=0.05, side=0.8)
+    scans = [synth.raycast_scan(truth, m["origin"], 0.05, poses[k - 1], poses[k], 1_000_000 + k * 100_000) for k in range(1, 7)]
+    res = []
+    for riding in (False, True):
+        g = bl.OccupancyGrid.from_cells(m["cells"], m["origin"], m["mpc"], cellsPerMeter=helpers.CPM_DEFAULT, ctx=gpu_ctx)
+        pf = bl.ParticleFilter(N, ctx=gpu_ctx)
+        pf.initializeFilterAtPose(bl.make_pose(-0.75, 0.2, 0.0, utime=int(scans[0].times[0])), seed=11)
+        pf.setNoiseSeed(4)
+        pf.setStrictResampling(True)
+        pf.debugEnable(True)
+        mapper = bl.Mapping(5.0, 4, 1, ctx=gpu_ctx)
+        rec = []
+        for k, sc in enumerate(scans):
+            odo = bl.make_pose(*poses[k + 1], utime=sc.utime)
+            rv = (0, 0, RAND_MAX, 1, 12345, 0)[k]
+            if riding:
+                pf.updateBegin(odo, sc, g, rv)
+                mapper.updateMapFinishingFilter(sc, pf, sc.utime, g)
+            else:
+                pf.updateFilter(odo, sc, g, rand_value=rv, want_pose=False)
+                mapper.updateMapDevicePose(sc, pf.poseDevicePtr(), sc.utime, g)
+            p = pf.poseEstimate()
+            idx, like = pf.debugLast()
+            rec.append(((p.utime, p.x, p.y, p.theta), idx.copy(), like.copy(), pf.particles().copy(), g.cells().copy()))
+        res.append(rec)
+        pf.close(); g.close()
+    for k, (a, b) in enumerate(zip(*res)):
+        assert a[0] == b[0]
+        if k > 0:                                   # (the very first update never moves -- action_model.cpp:26-31: nothing was resampled)
+            assert np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
+        assert a[3].tobytes() == b[3].tobytes()
+        assert np.array_equal(a[4], b[4])
