@@ -68,6 +68,10 @@ struct bl_pf {
     bool debug;               // record resample index / likelihood per particle (parity tests)
     bool strict;              // strict resampling: prefix[] is overwritten with the reference's rounded double cumulative after every finish
     void* strict_recs; double* strict_starts;     // ... by chunks side by side: a record and the true start per chunk of 128 particles
+    bool uniform_now;         // every particle of rec[cur] carries the same weight (a fresh filter, equal uploaded weights): the one kind of
+                              // weights on which the integer rule and the reference's rounded cumulative part ways (rand() near 0 or
+                              // RAND_MAX puts every U on a partial sum) -- the next resampling then takes the reference's cumulative
+    bool prefix_is_strict;    // prefix[] holds that cumulative (doubles), not the integer prefix
     unsigned long long* block_sums;   // scan scratch
     int scan_blocks;
     int32_t* dbg_idx;
@@ -1486,7 +1490,9 @@ extern "C" const void* bl_pf_pose_device_ptr(bl_pf* pf) { return pf && pf->state
 // strict resampling: the integer prefix just written gives way to the reference's own cumulative (same buffer, as doubles)
 static void pf_strict_cumulative(bl_pf* pf, int which)
 {
-    if (!pf->strict) return;
+    static const bool no_auto = getenv("BOTLAB_NO_AUTO_STRICT") != nullptr;         // tests: the integer rule on equal weights
+    pf->prefix_is_strict = pf->strict || (pf->uniform_now && pf->sh_world <= 1 && !no_auto);
+    if (!pf->prefix_is_strict) return;
     static const bool one_wave = getenv("BOTLAB_STRICT_ONE_WAVE") != nullptr;        // tests, A/B runs
     const int nchunks = (pf->N + 127) / 128;
     if (pf->N >= STRICT_PAR_MIN && !one_wave) {
@@ -1590,6 +1596,7 @@ extern "C" int bl_pf_init_at_pose(bl_pf* pf, const bl_pose_xyt_t* pose, uint64_t
     BL_HIP(hipGetLastError());
     pf->pose_utime = pose->utime; pf->parent_utime = pose->utime;
     pf->initialized = true;
+    pf->uniform_now = true;                      // weights 1 / N (particle_filter.cpp:25)
     // the reference does not reset its ActionModel here; a filter is initialised once (slam.cpp:232-250)
     return pf_scan(pf, 0, 0, 0);
 }
@@ -1600,8 +1607,10 @@ extern "C" int bl_pf_set_particles(bl_pf* pf, const bl_particle_t* particles, co
     BL_HIP(hipSetDevice(pf->ctx->device));
     if (!pf->prefix) { int rc = pf_alloc(pf); if (rc) return rc; }
     std::vector<float4> rec(pf->N), par(pf->n_local);
+    pf->uniform_now = true;
     for (int m = 0; m < pf->N; ++m) {
         uint32_t u = units ? units[m] : 1u;
+        if (units && units[m] != units[0]) pf->uniform_now = false;
         float w; memcpy(&w, &u, 4);
         rec[m] = make_float4(particles[m].pose.x, particles[m].pose.y, particles[m].pose.theta, w);
     }
@@ -1730,7 +1739,7 @@ static int pf_launch_main(bl_pf* pf, const bl_grid* map, int R, int rand_value, 
     a.seed_lo = (uint32_t)pf->noise_seed; a.seed_hi = (uint32_t)(pf->noise_seed >> 32);
     a.step = pf->step;
     a.resample = resample;
-    a.strict = pf->strict ? 1 : 0;
+    a.strict = pf->prefix_is_strict ? 1 : 0;
     if (getenv("BOTLAB_MCL_DIAG_NOSEARCH")) a.resample = 0;
     // MovingLaserScan(scan, parent_pose, pose): parent_pose.utime is the particle's previous pose utime, pose.utime is
     // ActionModel::utime_ == 0 (D3); they differ only on the first moved update after initialisation.
@@ -1922,6 +1931,7 @@ extern "C" int bl_pf_update_begin(bl_pf* pf, const bl_pose_xyt_t* odometry, cons
     if (noise) { rc = pf_upload_noise(pf, noise); if (rc) return rc; }
     rc = pf_launch_main(pf, map, R, rand_value, noise, 1);
     if (rc) return rc;
+    pf->uniform_now = false;                     // the record this update writes carries the sensor model's weights
     pf->pending_end = true;
     return BL_OK;
 }
@@ -1943,6 +1953,7 @@ extern "C" int bl_pf_update_end(bl_pf* pf, bl_pose_xyt_t* out_pose)
             if (rc) return rc;
             hipLaunchKernelGGL(k_mcl_finish, dim3(MCLF_EXTRA_WGS), dim3(MCLF_WG), MCLF_LDS_BYTES, pf->ctx->stream, f);
             BL_HIP(hipGetLastError());
+            pf->prefix_is_strict = false;        // (a composed shard keeps the integer rule)
             rc = bl_timer_end(pf->ctx, BL_K_MCL_SCAN, e0, e1);
         } else
         rc = pf->fused_finish ? pf_finish_fused(pf, pf->cur ^ 1, pf->pending_utime)
@@ -2617,7 +2628,7 @@ extern "C" int bl_pf_debug_resample(bl_pf* pf, int rand_value, int32_t* out_idx)
     const double M_inv = 1.0 / pf->N;                                              // particle_filter.cpp:89
     const double r = (((double)rand_value) / (double)RAND_MAX) * M_inv;            // particle_filter.cpp:92
     hipLaunchKernelGGL(k_pf_resample_only, dim3((pf->N + 255) / 256), dim3(256), 0, pf->ctx->stream, pf->prefix, pf->state, pf->N, r, M_inv,
-                       pf->strict ? 1 : 0, pf->dbg_idx);
+                       pf->prefix_is_strict ? 1 : 0, pf->dbg_idx);
     BL_HIP(hipGetLastError());
     BL_HIP(hipMemcpyAsync(out_idx, pf->dbg_idx, (size_t)pf->N * 4, hipMemcpyDeviceToHost, pf->ctx->stream));
     BL_HIP(hipStreamSynchronize(pf->ctx->stream));

@@ -164,12 +164,15 @@ int bl_pf_debug_set_finish_generation(bl_pf* pf, uint32_t generation);   /* test
 /* Strict resampling (off by default).  The update's resampler normally compares U_m * S with an exact integer prefix of the
  * weight units; the reference (particle_filter.cpp:84-103) compares U_m with a sequentially rounded double sum of the
  * normalised weights.  The two agree unless U_m falls within that sum's rounding error of a partial sum -- measured: never for
- * weights an update leaves behind, about half of the particles (off by one index) for the equal weights of a fresh filter when
- * rand() <= ~1000 or == RAND_MAX (tests/test_gpu_resample_sweep.py).  With strict mode on, every finish is followed by a launch
- * that forms the reference's cumulative bit for bit and the resampler searches that one: identical indices for every rand()
- * value, at ~50 us per update at 100k particles, ~140 us at 1M (three launches: the chunks' sums with the binade predicted from the
- * integer prefix, one wave walking the chunks' records with the true sum, the chunks filled in side by side) behind the finish -- also
- * behind the map kernel that carries it (bl_mapping_update_finishing_pf): a 100k-particle SLAM step is 154 us instead of 91. */
+ * weights an update leaves behind (tests/test_gpu_resample_sweep.py, tests/test_gpu_config3_1m.py).  The one kind of weights on
+ * which they did part ways -- ALL EQUAL, a fresh filter's or an upload's: rand() <= ~1000 or == RAND_MAX puts every U_m on a partial
+ * sum, and about half of the particles took the neighbouring source -- is detected, and the resampling that follows it runs against
+ * the reference's own cumulative whatever this switch says (BOTLAB_NO_AUTO_STRICT=1: the integer rule there too; composed shards
+ * keep the integer rule).  With strict mode on, EVERY finish is followed by the launches that form the reference's cumulative bit
+ * for bit and the resampler searches that one: identical indices for every rand() value, at ~50 us per update at 100k particles,
+ * ~140 us at 1M (three launches: the chunks' sums with the binade predicted from the integer prefix, one wave walking the chunks'
+ * records with the true sum, the chunks filled in side by side) behind the finish -- also behind the map kernel that carries it
+ * (bl_mapping_update_finishing_pf): a 100k-particle SLAM step is 154 us instead of 91. */
 int bl_pf_set_strict_resampling(bl_pf* pf, int on);
 /* resamplePosteriorDistribution alone (particle_filter.cpp:84-103): the source index each output particle would take for this
  * rand() value, by the very search the update kernel runs; num_particles entries (whole set on this device; synchronises) */

@@ -63,19 +63,14 @@ def test_resample_index_disagreements_are_counted_and_bounded(oracle, gpu_ctx, N
     units = (1000 * rng.integers(30000, 30400, N)).astype(np.uint32)
     report["converged"] = _sweep(oracle, gpu_ctx, N, units)
     assert sum(report["converged"].values()) == 0, report
-    # (c) a fresh filter: all weights 1 / N
+    # (c) a fresh filter: all weights 1 / N.  r = 0, r ~ 0 and r = 1 / N (rand() == RAND_MAX) put EVERY U_m on a partial sum m / N of
+    # the equal weights: which side the reference's rounded cumulative falls on is rounding noise, and the integer rule took the
+    # neighbouring source for about half of the particles there (rounds 2-4; BOTLAB_NO_AUTO_STRICT=1 brings that rule back).  Equal
+    # weights are detected (a fresh filter, an upload of equal weights) and resampled against the reference's own cumulative.
     report["uniform"] = _sweep(oracle, gpu_ctx, N, np.ones(N, np.uint32))
-    # r = 0, r ~ 0 and r = 1 / N (rand() == RAND_MAX) put EVERY U_m on a partial sum m / N of the equal weights: which side the
-    # reference's rounded cumulative falls on is rounding noise, and about half of the particles take the neighbouring source
-    # (index + 1 or - 1, never farther -- checked in _sweep).  Everything else is clear of the partial sums.
-    # (at 300k particles the rounded cumulative is off by up to i * 2^-54 ~ 1.6e-11 at the end, more than the r = 1.5e-12 of
-    # rand() == 1000: that value is "nearly 0" there as well)
-    degenerate = [0, 1, 1000, RAND_MAX]
-    ordinary = [rv for rv in EDGE + GLIBC if rv not in degenerate]
-    assert all(report["uniform"][rv] == 0 for rv in ordinary), report["uniform"]
-    assert all(report["uniform"][rv] <= N for rv in degenerate), report["uniform"]
-    if N <= 100_000:
-        assert report["uniform"][1000] == 0
+    assert sum(report["uniform"].values()) == 0, report["uniform"]
+    report["uniform_other_value"] = _sweep(oracle, gpu_ctx, N, np.full(N, 30_000_000, np.uint32))
+    assert sum(report["uniform_other_value"].values()) == 0, report["uniform_other_value"]
     os.makedirs("gpurun_out", exist_ok=True)
     with open(os.path.join("gpurun_out", f"resample_sweep_{N}.json"), "w") as fh:
         json.dump({k: {str(r): c for r, c in v.items()} for k, v in report.items()}, fh)
