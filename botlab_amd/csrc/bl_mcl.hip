@@ -1235,7 +1235,8 @@ __global__ __launch_bounds__(64) void k_pf_cumulative_strict(const float4* __res
 struct strict_rec { long long D; int key; int bad; };
 
 __global__ __launch_bounds__(256) void k_strict_records(const float4* __restrict__ rec, int N, const pf_state* __restrict__ state,
-                                                        const unsigned long long* __restrict__ prefix, strict_rec* __restrict__ recs)
+                                                        const unsigned long long* __restrict__ prefix, strict_rec* __restrict__ recs,
+                                                        double* __restrict__ first)
 {
     const int lane = threadIdx.x & 63;
     const int t = (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6);
@@ -1245,12 +1246,17 @@ __global__ __launch_bounds__(256) void k_strict_records(const float4* __restrict
     const double S = state->S;
     strict_rec r; r.D = 0; r.key = 0; r.bad = 1;
     if (t == 0) {
-        // the sum's first chunk starts from zero and crosses a binade every few terms: stepped here, beside the other chunks' records;
-        // its record is the accumulator behind it (bad = 2)
+        // the sum's first chunk starts from zero and crosses a binade every few terms (a phase of strict_chunk each: 7 us in all): its
+        // 128 terms are simply added one after the other here, beside the other chunks' records (1.3 us), and kept for k_strict_fill;
+        // the record is the accumulator behind the chunk (bad = 2)
         double w[2];
         strict_terms(rec, N, 0, lane, S, w);
-        const double end0 = strict_chunk(0.0, w, n, lane, nullptr);
-        r.D = __double_as_longlong(end0); r.bad = 2;
+        double acc = 0.0;
+        for (int i = 0; i < n; ++i) {
+            acc = ssd_exact_step(acc, mclf_readlane_f64((i & 1) ? w[1] : w[0], i >> 1));
+            if (lane == (i >> 1)) first[i] = acc;
+        }
+        r.D = __double_as_longlong(acc); r.bad = 2;
     } else {
         double w[2];
         strict_terms(rec, N, base, lane, S, w);
@@ -1318,12 +1324,17 @@ __global__ __launch_bounds__(64) void k_strict_chain(const float4* __restrict__ 
 }
 
 __global__ __launch_bounds__(256) void k_strict_fill(const float4* __restrict__ rec, int N, const pf_state* __restrict__ state,
-                                                     const double* __restrict__ starts, double* __restrict__ out)
+                                                     const double* __restrict__ starts, const double* __restrict__ first,
+                                                     double* __restrict__ out)
 {
     const int lane = threadIdx.x & 63;
     const int t = (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6);
     const int base = t * 128;
     if (base >= N) return;
+    if (t == 0) {                                                   // (stepped by k_strict_records: first[])
+        for (int i = lane; i < min(128, N); i += 64) out[i] = first[i];
+        return;
+    }
     double w[2];
     strict_terms(rec, N, base, lane, state->S, w);
     (void)strict_chunk(starts[t], w, min(128, N - base), lane, out + base);
@@ -1498,13 +1509,13 @@ static void pf_strict_cumulative(bl_pf* pf, int which)
     if (pf->N >= STRICT_PAR_MIN && !one_wave) {
         if (!pf->strict_recs) {
             if (hipMalloc((void**)&pf->strict_recs, (size_t)nchunks * sizeof(strict_rec)) != hipSuccess) pf->strict_recs = nullptr;
-            if (pf->strict_recs && hipMalloc((void**)&pf->strict_starts, (size_t)nchunks * sizeof(double)) != hipSuccess) { (void)hipFree(pf->strict_recs); pf->strict_recs = nullptr; }
+            if (pf->strict_recs && hipMalloc((void**)&pf->strict_starts, ((size_t)nchunks + 128) * sizeof(double)) != hipSuccess) { (void)hipFree(pf->strict_recs); pf->strict_recs = nullptr; }
         }
         if (pf->strict_recs) {
             hipStream_t st = pf->ctx->stream;
-            hipLaunchKernelGGL(k_strict_records, dim3((nchunks + 3) / 4), dim3(256), 0, st, pf->rec[which], pf->N, pf->state, pf->prefix, (strict_rec*)pf->strict_recs);
+            hipLaunchKernelGGL(k_strict_records, dim3((nchunks + 3) / 4), dim3(256), 0, st, pf->rec[which], pf->N, pf->state, pf->prefix, (strict_rec*)pf->strict_recs, pf->strict_starts + nchunks);
             hipLaunchKernelGGL(k_strict_chain, dim3(1), dim3(64), 0, st, pf->rec[which], pf->N, pf->state, (const strict_rec*)pf->strict_recs, pf->strict_starts);
-            hipLaunchKernelGGL(k_strict_fill, dim3((nchunks + 3) / 4), dim3(256), 0, st, pf->rec[which], pf->N, pf->state, pf->strict_starts, (double*)pf->prefix);
+            hipLaunchKernelGGL(k_strict_fill, dim3((nchunks + 3) / 4), dim3(256), 0, st, pf->rec[which], pf->N, pf->state, pf->strict_starts, pf->strict_starts + nchunks, (double*)pf->prefix);
             return;
         }
     }
