@@ -1251,11 +1251,16 @@ __global__ __launch_bounds__(256) void k_strict_records(const float4* __restrict
         // the record is the accumulator behind the chunk (bad = 2)
         double w[2];
         strict_terms(rec, N, 0, lane, S, w);
-        double acc = 0.0;
-        for (int i = 0; i < n; ++i) {
-            acc = ssd_exact_step(acc, mclf_readlane_f64((i & 1) ? w[1] : w[0], i >> 1));
-            if (lane == (i >> 1)) first[i] = acc;
+        double acc = 0.0, k0 = 0.0, k1 = 0.0;                    // (terms beyond n are zeros: the sum simply stays)
+#pragma unroll 4
+        for (int l = 0; l < 64; ++l) {
+            acc = ssd_exact_step(acc, mclf_readlane_f64(w[0], l));
+            k0 = lane == l ? acc : k0;
+            acc = ssd_exact_step(acc, mclf_readlane_f64(w[1], l));
+            k1 = lane == l ? acc : k1;
         }
+        if (2 * lane < n) first[2 * lane] = k0;
+        if (2 * lane + 1 < n) first[2 * lane + 1] = k1;
         r.D = __double_as_longlong(acc); r.bad = 2;
     } else {
         double w[2];

@@ -172,7 +172,7 @@ int bl_pf_debug_set_finish_generation(bl_pf* pf, uint32_t generation);   /* test
  * for bit and the resampler searches that one: identical indices for every rand() value, at ~50 us per update at 100k particles,
  * ~140 us at 1M (three launches: the chunks' sums with the binade predicted from the integer prefix, one wave walking the chunks'
  * records with the true sum, the chunks filled in side by side) behind the finish -- also behind the map kernel that carries it
- * (bl_mapping_update_finishing_pf): a 100k-particle SLAM step is 147 us instead of 90. */
+ * (bl_mapping_update_finishing_pf): a 100k-particle SLAM step is 140 us instead of 90. */
 int bl_pf_set_strict_resampling(bl_pf* pf, int on);
 /* resamplePosteriorDistribution alone (particle_filter.cpp:84-103): the source index each output particle would take for this
  * rand() value, by the very search the update kernel runs; num_particles entries (whole set on this device; synchronises) */
