@@ -726,6 +726,7 @@ __global__ __launch_bounds__(128) void k_astar2(astar_args a)
             len = s_len; pops = s_pops; pushes = s_pushes;
             if (code == 2u) { goal_m = gm; cx = (int)((ptop >> 2) & 0x7fffu); cy = (int)(ptop >> 17); res.status = ASTAR_ST_FOUND; break; }
             if (code == 3u) { res.status = ASTAR_ST_LIMIT; break; }
+            if (code == 4u) { res.status = ASTAR_ST_BROKEN; break; }          // (two-wave loop: the other wave's flag never came)
             if (len == 0) break;
         }
         if (deep && len >= (unsigned)C::PLN + 2u && len <= deep_max) {

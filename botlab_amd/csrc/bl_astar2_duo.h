@@ -85,10 +85,14 @@
 // hundreds of cycles by then) and lowers it again; the run word turns to "go" at the same place.
 #define A2W_GATE_ASK "ds_read_b32 v218, v214 offset:52\n\t"
 #define A2W_STORES_GATE(TAG)                                                                                  \
+    "s_mov_b32 s39, 0\n\t"                                                                                    \
     TAG ":\n\t"                                                                                               \
     "v_readfirstlane_b32 s70, v218\n\t"                                                                       \
     "s_cmp_lg_u32 s70, 0\n\t"                                                                                 \
     "s_cbranch_scc1 " TAG "1f\n\t"                                                                            \
+    "s_add_u32 s39, s39, 1\n\t"                      /* (never seen: the flag goes up a few instructions behind X.  A wave that */ \
+    "s_cmp_gt_u32 s39, 0x400000\n\t"                 /* does not come back from a loop would hang the device: give up instead, */ \
+    "s_cbranch_scc1 94f\n\t"                         /* ~1 s, the search ends as BROKEN) */                   \
     "ds_read_b32 v218, v214 offset:52\n\t"                                                                    \
     "s_waitcnt lgkmcnt(0)\n\t"                                                                                \
     "s_branch " TAG "b\n\t"                                                                                   \
@@ -218,6 +222,9 @@
     "s_branch 99f\n\t"                                                                                        \
     "93:\n\t"                                                                                                 \
     "s_mov_b32 %[code], 3\n\t"                                                                                \
+    "s_branch 99f\n\t"                                                                                        \
+    "94:\n\t"                                                                                                 \
+    "s_mov_b32 %[code], 4\n\t"                                                                                \
     "99:\n\t"                                                                                                 \
     "s_waitcnt lgkmcnt(0)\n\t"                                                                                \
     A2W_ACC_OUT("s36", "4192") A2W_ACC_OUT("s38", "4200")                          \

@@ -1913,6 +1913,7 @@ extern "C" void* bl_dist_device_ptr(bl_dist* d)
 #define ASTAR_ST_NOPATH 1        // early exit or open list exhausted: 1-pose path
 #define ASTAR_ST_CAPACITY 2
 #define ASTAR_ST_LIMIT 3
+#define ASTAR_ST_BROKEN 4          // the two wavefronts of a search lost each other (bl_astar2_duo.h: never observed; ends the search instead of hanging)
 
 struct astar_result { int status; int path_len; long long pops; long long pushes; bl_pose_xyt_t start; long long stamps[6];
                       long long path_off; };           // batch form: where the path went in the shared pool
@@ -2772,6 +2773,7 @@ extern "C" int bl_astar_search_result(bl_ctx* ctx, bl_pose_xyt_t* out_path, int 
     *out_len = 1;
     if (r.status == ASTAR_ST_CAPACITY) { bl_set_error("A* open list exceeded its capacity (%lld pops)", r.pops); return BL_ERR_CAPACITY; }
     if (r.status == ASTAR_ST_LIMIT) { bl_set_error("A* pop limit reached"); return BL_ERR_CAPACITY; }
+    if (r.status == ASTAR_ST_BROKEN) { bl_set_error("A* search gave up: its two wavefronts lost each other (BOTLAB_ASTAR_DUO=0 takes the one-wave loop)"); return BL_ERR_STATE; }
     if (r.status != ASTAR_ST_FOUND) return BL_OK;
     // makePath (astar.cpp:235-274): cells come goal-first; poses are emitted start-side first
     std::vector<int32_t> cells((size_t)r.path_len);
@@ -2927,6 +2929,7 @@ static int astar_batch_cells(bl_ctx* ctx, const bl_dist* d, const bl_pose_xyt_t*
             const astar_result* r = (const astar_result*)(s->hb_results + (size_t)i * ASTAR_HDR);
             if (r->status == ASTAR_ST_CAPACITY) { bl_set_error("A* open list exceeded its capacity (%lld pops)", r->pops); return BL_ERR_CAPACITY; }
             if (r->status == ASTAR_ST_LIMIT) { bl_set_error("A* pop limit reached"); return BL_ERR_CAPACITY; }
+            if (r->status == ASTAR_ST_BROKEN) { bl_set_error("A* search gave up: its two wavefronts lost each other (BOTLAB_ASTAR_DUO=0 takes the one-wave loop)"); return BL_ERR_STATE; }
             if (r->status == ASTAR_ST_FOUND) {
                 if ((size_t)r->path_len > s->b_path_each) { bl_set_error("A* path of %d cells exceeds the batch path capacity", r->path_len); return BL_ERR_CAPACITY; }
                 total += (size_t)r->path_len;
