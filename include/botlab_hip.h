@@ -168,7 +168,7 @@ int bl_pf_debug_set_finish_generation(bl_pf* pf, uint32_t generation);   /* test
  * which they did part ways -- ALL EQUAL, a fresh filter's or an upload's: rand() <= ~1000 or == RAND_MAX puts every U_m on a partial
  * sum, and about half of the particles took the neighbouring source -- is detected, and the resampling that follows it runs against
  * the reference's own cumulative whatever this switch says (BOTLAB_NO_AUTO_STRICT=1: the integer rule there too; composed shards
- * keep the integer rule).  With strict mode on, EVERY finish is followed by the launches that form the reference's cumulative bit
+ * keep the integer rule; equal weights that an update leaves -- every particle at the likelihood floor -- are not detected).  With strict mode on, EVERY finish is followed by the launches that form the reference's cumulative bit
  * for bit and the resampler searches that one: identical indices for every rand() value, at ~50 us per update at 100k particles,
  * ~140 us at 1M (three launches: the chunks' sums with the binade predicted from the integer prefix, one wave walking the chunks'
  * records with the true sum, the chunks filled in side by side) behind the finish -- also behind the map kernel that carries it
