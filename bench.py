@@ -270,6 +270,41 @@ def same_search(ctx, grid, planner, pose, goal_pose, m):
             "inputs": "map and pose estimate at the end of the timed region, the run's goal"}
 
 
+def same_search_fixture(ctx, name="maze", case=0, radius=0.1):
+    """The same comparison on a search that IS a search: the reference's own fixture (data/astar/maze_poses.txt pair 0 on maze.map,
+    robotRadius 0.1 as astar_test.cpp:227-228 sets it: 1 156 pops).  The headline's replan to a point on the driven loop is a handful of
+    pops -- its two times are launch latency, not a search."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import helpers
+    import oracle_lib
+    import botlab_amd as bl
+    orc = oracle_lib.load_oracle()
+    cpm = helpers.CPM_DEFAULT
+    m = load_map("astar_" + name)
+    row = helpers.load_astar_cases()[name][case]
+    g = bl.OccupancyGrid.from_cells(m["cells"], m["origin"], m["mpc"], cellsPerMeter=cpm, ctx=ctx)
+    planner = bl.MotionPlanner(bl.MotionPlannerParams(radius), ctx=ctx)
+    planner.setMap(g)
+    s, gl = bl.make_pose(row["start"][0], row["start"][1], 0.0), bl.make_pose(row["goal"][0], row["goal"][1], 0.0)
+    best, st_gpu = None, None
+    for _ in range(5):
+        ctx.sync()
+        t0 = time.perf_counter()
+        _, st_gpu = bl.search_for_path(s, gl, planner.distances_, planner.searchParams_, return_stats=True)
+        dt = time.perf_counter() - t0
+        best = dt if best is None or dt < best else best
+    d = orc.set_distances(m["cells"], m["mpc"], cpm, m["origin"])
+    t_cpu = None
+    for _ in range(3):
+        t0 = time.perf_counter()
+        _, st_cpu = orc.search(orc.pose(*row["start"], 0.0), orc.pose(*row["goal"], 0.0), d, m["mpc"], cpm, m["origin"], radius, 10.0 * radius, cap=4096)
+        dt = time.perf_counter() - t0
+        t_cpu = dt if t_cpu is None or dt < t_cpu else t_cpu
+    return {"pops": int(st_gpu[0]), "pops_equal": bool(int(st_gpu[0]) == int(st_cpu[0]) and int(st_gpu[1]) == int(st_cpu[1])),
+            "hip_ms": round(1e3 * best, 3), "cpu_oracle_ms": round(1e3 * t_cpu, 3), "cores": 1,
+            "inputs": f"astar fixture {name} pair {case} (tests/golden), robotRadius {radius}; best of 5 / 3 calls"}
+
+
 ASTAR_FIXTURE_MAPS = ["empty", "filled", "narrow", "wide", "convex", "maze"]
 ASTAR_FIXTURE_EXCLUDED = {("narrow", 2): "the search must exhaust the whole free side (2.6e8 pops in the reference's own algorithm): excluded on both sides"}
 
@@ -539,6 +574,127 @@ def streaming_kernels(ctx, grid, planner, aplanner, pose_dev, goal_pose, W, H):
     return out
 
 
+COMPACT_LIMIT = 4096             # bytes: the last stdout line must stay well below what the driver's reader takes (a 21.7 KB line was not read in round 5)
+
+
+def _short(v, n=160):
+    return v if not isinstance(v, str) or len(v) <= n else v[:n - 3] + "..."
+
+
+def compact_line(out):
+    """The ONE line stdout carries: the contract's keys, `roofline` (with traffic and the VALU figure), `cpu_baseline` and a summary of
+    the other rows.  Everything else (other_configs, astar_fixtures, same_search, explore, streaming kernels, slowest steps) is the
+    detail record: gpurun_out/bench_detail.json and stderr.  Serialised length < COMPACT_LIMIT, whatever the run produced: optional
+    keys are dropped from the end of `optional` until it fits."""
+    def rnd(x, n=6):
+        return round(x, n) if isinstance(x, float) else x
+    c = {k: out[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "steady_ms_per_step", "higher_is_better",
+                             "scaling", "vs_baseline", "dtype", "data") if k in out}
+    for k in ("value", "ms_per_step", "steady_ms_per_step"):
+        if k in c:
+            c[k] = rnd(c[k], 6)
+    cfg = out["config"]
+    c["config"] = {"workload": _short(cfg["workload"], 200), "particles": cfg["particles"], "grid": cfg["grid"], "rays": cfg["rays"],
+                   "pipeline_depth": cfg["pipeline_depth"], "planner_lanes": cfg["planner_lanes"], "planner_batch": cfg["planner_batch"],
+                   "parallelism": cfg["parallelism"], "collective": _short(cfg["collective"], 100)}
+    r = out["roofline"]
+    c["roofline"] = {"bound": r["bound"], "achieved": rnd(r["achieved"], 3), "peak": r["peak"], "unit": r["unit"], "frac": rnd(r["frac"], 6),
+                     "traffic": r["traffic"], "kernel": r["kernel"], "algorithmic_bytes_per_launch": r["algorithmic_bytes_per_launch"],
+                     "avg_launch_ms": rnd(r["avg_launch_ms"], 6), "launches_timed": r["launches_timed"], "event_stride": r["event_stride"],
+                     "binding_resource": "VALU issue",
+                     "valu_issue_frac": rnd(r["valu"]["valu_issue_frac_at_4_cycles"], 4) if r.get("valu") else None,
+                     "valu_per_particle_ray": rnd(r["valu"]["per_particle_ray"], 2) if r.get("valu") else None,
+                     "traffic_source": _short((r.get("traffic_source") or "").split(" (")[0], 60) or None,
+                     "step_frac": rnd(r["step"]["frac"], 6)}
+    if "cpu_baseline" in out:
+        b = out["cpu_baseline"]
+        c["cpu_baseline"] = {"value": rnd(b["value"], 4), "unit": b["unit"], "cores": b["cores"], "kind": b["kind"], "sample": _short(b["sample"], 220)}
+    c["preheat_ms"] = out.get("preheat_ms")
+    c["stage_ms"] = out.get("stage_ms")
+    c["astar_pops_per_step"] = rnd(out.get("astar_pops_per_step"), 2)
+    c["final_pose"] = out.get("final_pose")
+    optional = []
+    if out.get("timed_region_note"):
+        optional.append(("timed_region_note", _short(out["timed_region_note"], 200)))
+    summ = out.get("summary")
+    if summ:
+        optional.append(("summary", summ))
+    if "particle_sweep_steps_per_s" in out:
+        optional.append(("particle_sweep_steps_per_s", out["particle_sweep_steps_per_s"]))
+    if "shard_exchange" in out:
+        se = out["shard_exchange"]
+        optional.append(("shard_exchange", {"form": _short(se["form"], 80), "measured_on_more_than_one_device": se["measured_on_more_than_one_device"],
+                                            "bytes_sent_per_rank_per_step": se["bytes_sent_per_rank_per_step"]}))
+    if out.get("detail"):
+        optional.append(("detail", out["detail"]))
+    for k, v in optional:
+        c[k] = v
+    while len(json.dumps(c)) >= COMPACT_LIMIT and optional:
+        k, _ = optional.pop()
+        del c[k]
+    if len(json.dumps(c)) >= COMPACT_LIMIT:                  # cannot happen with the bounded strings above; never print an unreadable line
+        c["config"]["workload"] = _short(c["config"]["workload"], 80)
+        c.get("cpu_baseline", {}).pop("sample", None)
+    return c
+
+
+def summary_of(out):
+    """Five numbers lifted out of the detail rows (the review's list): closed-loop latency, config 4 / goal 400 closed loop, config 5 as
+    written, and the maze row of the reference's A* table, HIP beside the CPU oracle."""
+    s = {}
+    lat = out.get("latency") or {}
+    if "headline" in lat:
+        s["closed_loop_ms"] = round(lat["headline"]["sync_ms_per_step"], 4)
+    if "config4_goal400" in lat:
+        s["config4_goal400_closed_loop_steps_s"] = round(lat["config4_goal400"]["sync_steps_per_s"], 1)
+    for r in out.get("other_configs") or []:
+        if "error" in r:
+            continue
+        if r["config"] == 5 and not r["flags"]:
+            s["config5_as_written_steps_s"] = round(r["value"], 1)
+        if r["config"] == 4 and r["goal_l1_cells"] == 400 and r.get("planner") and r["planner"][2] != 0:
+            s["config4_goal400_pipelined_steps_s"] = round(r["value"], 1)
+        if r["config"] == 3:
+            s["config3_1m_steps_s"] = round(r["value"], 1)
+    fx = (out.get("astar_fixtures") or {}).get("rows") or {}
+    for name in ("maze", "convex"):
+        row = fx.get(name)
+        if row and row["hip"]["success"]:
+            s[f"astar_{name}_success_mean_us"] = {"hip": row["hip"]["success"]["mean_us"],
+                                                  "cpu_1_core": (row.get("cpu_oracle_1_core") or {}).get("success", {}).get("mean_us") if row.get("cpu_oracle_1_core") and row["cpu_oracle_1_core"]["success"] else None}
+    ss = out.get("same_search")
+    if ss:
+        s["same_search"] = {"pops": ss["pops"], "pops_equal": ss["pops_equal"], "hip_ms": ss["hip_ms"], "cpu_oracle_ms": ss["cpu_oracle_ms"]}
+    errs = sum(1 for r in out.get("other_configs") or [] if "error" in r)
+    if errs:
+        s["other_configs_with_error"] = errs
+    return s or None
+
+
+def emit(out, json_fd, full):
+    """Detail record first (stderr + gpurun_out/bench_detail.json), then ONE compact line on stdout (the full record instead for
+    --full-line: the child runs of other_configs and the profile collector read it)."""
+    out["summary"] = summary_of(out)
+    detail_path = None
+    if not full:
+        try:
+            d = os.path.join(ROOT, "gpurun_out")
+            os.makedirs(d, exist_ok=True)
+            detail_path = os.path.join(d, "bench_detail.json")
+            with open(detail_path, "w") as f:
+                json.dump(out, f)
+                f.write("\n")
+        except OSError:
+            detail_path = None
+        sys.stderr.write("[bench-detail] " + json.dumps(out) + "\n")
+        sys.stderr.flush()
+        out["detail"] = ("gpurun_out/bench_detail.json and the [bench-detail] line on stderr: other_configs, astar_fixtures, same_search, latency, "
+                         "explore, streaming_kernels, host times") if detail_path else "the [bench-detail] line on stderr"
+    line = json.dumps(out if full else compact_line(out))
+    sys.stdout.flush()
+    os.write(json_fd, (line + "\n").encode())
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -581,7 +737,8 @@ def main():
     ap.add_argument("--preheat-ms", type=float, default=300.0, help="milliseconds of the path's own k_mcl_main on a scratch filter before the warmup steps, "
                     "so that a short run is not a measurement of the clock ramp after the idle seconds of input synthesis (0 = off)")
     ap.add_argument("--astar-fixtures", action="store_true", help="only the reference's own A* table (astar_test's six maps): one JSON line")
-    ap.add_argument("--sub", action="store_true", help="a child run of the default invocation (other_configs): no children of its own")
+    ap.add_argument("--sub", action="store_true", help="a child run of the default invocation (other_configs): no children of its own; prints the full record")
+    ap.add_argument("--full-line", action="store_true", help="print the full record on stdout instead of the compact line (tools; --sub implies it)")
     ap.add_argument("--no-other-configs", action="store_true", help="default run: skip the short runs of configs 4 and 5")
     ap.add_argument("--other-steps", type=int, default=1000, help="timed steps of each other_configs run")
     args = ap.parse_args()
@@ -976,7 +1133,7 @@ def main():
         # passes, gfx950 correction applied); only valid for the configuration they were collected on
         traffic = None
         traffic_src = None
-        for prof in ("r05_mcl_main_traffic.json", "r03_mcl_main_traffic.json", "r02_mcl_main_traffic.json", "r01_mcl_main_traffic.json"):
+        for prof in ("r06_mcl_main_traffic.json", "r05_mcl_main_traffic.json", "r03_mcl_main_traffic.json", "r02_mcl_main_traffic.json", "r01_mcl_main_traffic.json"):
             try:
                 tj = json.load(open(os.path.join(ROOT, "profiles", prof)))
                 if world == 1 and tj["config"] == {"particles": N, "grid": [W, H], "rays": R}:
@@ -1005,7 +1162,7 @@ def main():
         # committed SQ counter pass, against the 1024 SIMDs issuing one per 4 cycles at 2.4 GHz
         valu = None
         import csv
-        for prof in ("r05_mcl_main_pmc_sq.csv", "r03_mcl_main_pmc_sq.csv", "r02_mcl_main_pmc_sq.csv", "r01_mcl_main_pmc_sq.csv"):
+        for prof in ("r06_mcl_main_pmc_sq.csv", "r05_mcl_main_pmc_sq.csv", "r03_mcl_main_pmc_sq.csv", "r02_mcl_main_pmc_sq.csv", "r01_mcl_main_pmc_sq.csv"):
             try:
                 if world == 1 and traffic is not None and valu is None:
                     for row in csv.reader(open(os.path.join(ROOT, "profiles", prof))):
@@ -1070,6 +1227,20 @@ def main():
             "final_pose": [pose.x, pose.y, pose.theta],
             "truth_pose": [float(v) for v in poses[k]],
         }
+        if args.steps <= 50:
+            # a region of a few milliseconds: K steps of the steady rate + the drain tail (the last batch's distance grids and its longest
+            # search, ~0.2 ms).  The long form of the same command (--steps 2000 --warmup 100, the default) is the figure DESIGN.md quotes.
+            note = (f"{args.steps} timed steps = {1e3 * elapsed:.2f} ms, of which the drain tail {1e3 * (elapsed - t_steady):.2f} ms; "
+                    f"steady_ms_per_step is the region without it")
+            for prof in ("r06_bench_default.json", "r05_bench_default.json"):
+                try:
+                    lj = json.load(open(os.path.join(ROOT, "profiles", prof)))
+                    if lj["config"]["particles"] == N and lj["config"]["grid"] == [W, H] and lj["n_gpus"] == world:
+                        note += f"; the {lj['steps']}-step run of this command: {lj['value']:.0f} steps/s (profiles/{prof}, not measured in this run)"
+                        break
+                except (OSError, KeyError, ValueError):
+                    continue
+            out["timed_region_note"] = note
         if world > 1 or spf.force_collectives:
             sent, received, own = spf.exchange_bytes_per_update()
             out["shard_exchange"] = {"form": ("composed finish, peer stores (no collective)" if getattr(spf, "peer", False) else
@@ -1122,12 +1293,17 @@ def main():
         if args.cpu_steps > 0 and world == 1:
             out["cpu_baseline"] = cpu_baseline(args, m, odo, scans, rands, goal, args.cpu_steps)
             if goal is not None:
-                out["same_search"] = same_search(ctx, grid, planner, pose, goal_pose, m)
+                ss = same_search(ctx, grid, planner, pose, goal_pose, m)
+                if ss["pops"] < 1000:
+                    # (the run's own replan is a handful of pops: kept as "run_goal", the comparison is made on a fixture search)
+                    fx = same_search_fixture(ctx)
+                    fx["run_goal"] = ss
+                    ss = fx
+                out["same_search"] = ss
         if other is not None and world == 1:
             # the reference's own published table (astar_test's six maps), HIP path beside the CPU oracle
             out["astar_fixtures"] = astar_fixtures(ctx, reps=3)
-        sys.stdout.flush()
-        os.write(json_fd, (json.dumps(out) + "\n").encode())
+        emit(out, json_fd, full=bool(args.sub or args.full_line))
     phase(json_fd, "teardown")
     if dist.is_initialized():
         dist.barrier()

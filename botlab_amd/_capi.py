@@ -116,6 +116,7 @@ SIGNATURES = {
     "bl_astar_search": (C.c_int, [_vp, _vp, _P(Pose), _P(Pose), _P(SearchParams), _vp, C.c_int, _P(C.c_int),
                                   _P(C.c_int64)]),
     "bl_astar_set_open_capacity": (C.c_int, [_vp, C.c_int64]),
+    "bl_astar_debug_last_kernel": (C.c_int, [_vp]),
     "bl_debug_heap2_replay": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, C.c_int64, _vp, _vp, _P(C.c_int), _vp]),
     "bl_astar_search_async": (C.c_int, [_vp, _vp, _P(Pose), _P(Pose), _P(SearchParams)]),
     "bl_astar_search_async_dev_start": (C.c_int, [_vp, _vp, _vp, _P(Pose), _P(SearchParams)]),

@@ -10,7 +10,7 @@
 //     -> expansion -> [round 4 decided] -> climb, one pass of stores -> pushes (ancestors' keys + payloads in one round trip).
 //
 // Needs PLV == LEV - 1 (a2_big, a2_small): every node of the LDS rounds has its payload in LDS, every node of the global round in
-// global memory; only the third round's CHILDREN straddle the payload tiers.  Registers: bl_astar2_turbo.h's, plus s30-s35 /
+// global memory; only the third round's CHILDREN straddle the payload tiers.  Registers: bl_astar2_turbo.h's, plus s28-s31, s34-s35 /
 // s82-s85 and v150-v175.
 #ifndef BL_ASTAR2_DEEP_H
 #define BL_ASTAR2_DEEP_H
@@ -22,7 +22,7 @@
     "s_and_b64 s[84:85], vcc, " SQ "\n\t"                                                                     \
     "v_lshlrev_b32 v153, 2, " C_ "\n\t"                                                                       \
     "s_mov_b64 exec, s[84:85]\n\t"                                                                            \
-    "global_load_dword v154, v153, s[32:33]\n\t"                                                              \
+    "global_load_dword v154, v153, s[28:29]\n\t"                                                              \
     "s_mov_b64 exec, -1\n\t"
 
 // a round in global memory, first half: node N, 2 node + 1 -> C_, the children's keys asked for (PAIR; lanes without a left
@@ -39,7 +39,7 @@
     "v_lshl_add_u32 v221, " N ", 3, 4\n\t"                                                                    \
     "s_mov_b64 exec, s[68:69]\n\t"                                                                            \
     "global_load_dword " PAIR ", v220, s[30:31]\n\t"                                                          \
-    "global_load_dwordx2 " PP ", v221, s[32:33]\n\t"   /* BOTH children's payloads (adjacent entries): no load behind the decision */ \
+    "global_load_dwordx2 " PP ", v221, s[28:29]\n\t"   /* BOTH children's payloads (adjacent entries): no load behind the decision */ \
     "s_mov_b64 exec, -1\n\t"
 // second half (the keys and payloads have arrived): a missing right child reads 0xFFFF; then as A2T_ROUND: mask SQ, child C_, knext K,
 // the child's payload P (of the pair PLO, PHI); the walk's deepest lane -> s70
@@ -81,7 +81,7 @@
     "s_mov_b64 exec, s[68:69]\n\t"                                                                            \
     "ds_write_b32 v221, v197\n\t"                                                                             \
     "s_xor_b64 exec, s[68:69], 1\n\t"                                                                         \
-    "global_store_dword v222, v197, s[32:33]\n\t"                                                             \
+    "global_store_dword v222, v197, s[28:29]\n\t"                                                             \
     "s_mov_b64 exec, -1\n\t"
 
 // stores of the first round in global memory under mask M: lane 0's node sits on level LEV (an LDS key slot), the others' keys
@@ -95,7 +95,7 @@
     "s_andn2_b64 exec, " M ", 1\n\t"                                                                          \
     "global_store_short v220, v157, s[30:31]\n\t"                                                             \
     "s_mov_b64 exec, " M "\n\t"                                                                               \
-    "global_store_dword v221, v158, s[32:33]\n\t"                                                             \
+    "global_store_dword v221, v158, s[28:29]\n\t"                                                             \
     "s_mov_b64 exec, -1\n\t"
 // ... of the second: everything global
 #define A2D_STORE4(M)                                                                                         \
@@ -104,7 +104,7 @@
     "v_lshlrev_b32 v221, 2, v171\n\t"                                                                         \
     "s_mov_b64 exec, " M "\n\t"                                                                               \
     "global_store_short v220, v173, s[30:31]\n\t"                                                             \
-    "global_store_dword v221, v174, s[32:33]\n\t"                                                             \
+    "global_store_dword v221, v174, s[28:29]\n\t"                                                             \
     "s_mov_b64 exec, -1\n\t"
 
 // push_back + std::push_heap for a hole beyond the LDS payloads: READ asks for the ancestors' keys and payloads in whichever tier
@@ -131,7 +131,7 @@
     "s_and_b64 s[38:39], vcc, s[68:69]\n\t"          /* ancestors whose payload is global */                  \
     "v_lshlrev_b32 v163, 2, v233\n\t"                                                                         \
     "s_mov_b64 exec, s[38:39]\n\t"                                                                            \
-    "global_load_dword v164, v163, s[32:33]\n\t"                                                              \
+    "global_load_dword v164, v163, s[28:29]\n\t"                                                              \
     "s_mov_b64 exec, -1\n\t"                                                                                  \
     "v_lshlrev_b32 v236, 1, v231\n\t"                /* where it would drop to: key offset (both tiers), */   \
     "v_add_u32 v165, -1, v231\n\t"                                                                            \
@@ -161,7 +161,7 @@
     "s_and_b64 exec, s[92:93], vcc\n\t"                                                                       \
     "ds_write_b32 v237, v235\n\t"                                                                             \
     "s_andn2_b64 exec, s[92:93], vcc\n\t"                                                                     \
-    "global_store_dword v166, v235, s[32:33]\n\t"                                                             \
+    "global_store_dword v166, v235, s[28:29]\n\t"                                                             \
     "s_mov_b64 exec, -1\n\t"                                                                                  \
     "s_lshl_b32 s70, s71, 1\n\t"                                                                              \
     "v_mov_b32 v232, s70\n\t"                                                                                 \
@@ -183,7 +183,7 @@
     "s_mov_b64 exec, s[68:69]\n\t"                                                                            \
     "ds_write_b32 v167, v239\n\t"                                                                             \
     "s_xor_b64 exec, s[68:69], 1\n\t"                                                                         \
-    "global_store_dword v238, v239, s[32:33]\n\t"                                                             \
+    "global_store_dword v238, v239, s[28:29]\n\t"                                                             \
     "s_mov_b64 exec, -1\n\t"                                                                                  \
     "s_add_i32 s40, s40, 1\n\t"                                                                               \
     "s_add_i32 s42, s42, 1\n\t"
@@ -212,7 +212,7 @@
     A2T_RSF("s48", "v196") A2T_RSF("s49", "v197") A2T_RSF("s50", "v198")                                      \
     A2T_RSF("s52", "v200") A2T_RSF("s53", "v201") A2T_RSF("s54", "v202") A2T_RSF("s55", "v203")               \
     A2T_RSF("s56", "v204") A2T_RSF("s57", "v205") A2T_RSF("s59", "v206") A2T_RSF("s60", "v207")               \
-    A2T_RSF("s30", "v150") A2T_RSF("s31", "v151") A2T_RSF("s32", "v152") A2T_RSF("s33", "v153") A2T_RSF("s58", "v154") \
+    A2T_RSF("s30", "v150") A2T_RSF("s31", "v151") A2T_RSF("s28", "v152") A2T_RSF("s29", "v153") A2T_RSF("s58", "v154") \
     "s_mov_b32 s62, %[ok0lo]\n\t"                                                                             \
     "s_mov_b32 s63, %[ok0hi]\n\t"                                                                             \
     "s_mov_b32 s64, -1\n\t"                                                                                   \
@@ -251,7 +251,7 @@
     "s_lshl_b32 s71, s40, 2\n\t"                                                                              \
     "s_add_i32 s71, s71, -4\n\t"                                                                              \
     "v_mov_b32 v170, s71\n\t"                                                                                 \
-    "global_load_dword v197, v170, s[32:33]\n\t"                                                              \
+    "global_load_dword v197, v170, s[28:29]\n\t"                                                              \
     "s_waitcnt lgkmcnt(2)\n\t"                                                                                \
     A2T_NBR                                                                                                   \
     A2T_PREFETCH                                                                                              \
@@ -377,7 +377,7 @@
     "s_mov_b32 %[gm], s88\n\t"                                                                                \
     "s_mov_b32 %[pt], s80\n\t"
 
-#define A2D_CLOBBERS A2T_CLOBBERS, "s30", "s31", "s32", "s33", "s34", "s35",                                  \
+#define A2D_CLOBBERS A2T_CLOBBERS, "s30", "s31", "s28", "s29", "s34", "s35",                                  \
     "v150", "v151", "v152", "v153", "v154", "v155", "v156", "v157", "v158", "v159", "v160", "v161", "v162", "v163", "v164", "v165", "v166", "v167", \
     "v168", "v169", "v170", "v171", "v172", "v173", "v174", "v175"
 

@@ -1969,6 +1969,7 @@ struct bl_astar_state {
     // cost table cache key
     bool lut_valid; bl_search_params_t lut_params; int lut_n; const void* lut_owner;
     int lut_eff;                       // entries [lut_eff - 1, lut_n) of the cost table are all equal: the kernel clamps the index to lut_eff - 1
+    int last_kernel = 0;               // 2: k_astar2, 1: k_astar took the last launch (bl_astar_debug_last_kernel)
     int lut_min;                       // smallest obstacle cost of a valid cell: fCost >= lut_min (k_astar2 keeps fCost in 16 bits)
     // batch form
     int b_cap; size_t b_cells; int64_t b_heap_each; size_t b_path_each;
@@ -2646,6 +2647,8 @@ static bool astar_split_ok(const bl_astar_state* s)
     return !force_v1 && s->lut_valid && s->lut_min > -32768;
 }
 
+extern "C" int bl_astar_debug_last_kernel(bl_ctx* ctx) { return ctx && ctx->astar ? ctx->astar->last_kernel : 0; }
+
 // Threads of a k_astar2 workgroup.  128: a second wavefront runs the expansions of the LDS-regime loop beside the first
 // (bl_astar2_duo.h: -4 .. -9 % per pop there).  Only for searches that have their compute unit to themselves (the 147 KB heap):
 // the replanner's units share CUs four at a time, where a second wave per search would take issue slots from the others.
@@ -2665,6 +2668,7 @@ static void astar_launch_kernel(bl_ctx* ctx, const astar_args& a, int workgroups
     // list spilling past the LDS levels pays an HBM round trip per heap level.
     static const bool force_small = getenv("BOTLAB_ASTAR_SMALL_LDS") != nullptr;     // probes: the replanner's footprint on a lone search
     const bool small = ctx->astar_small_lds || force_small;
+    if (ctx->astar) ctx->astar->last_kernel = split ? 2 : 1;
     if (split && small) hipLaunchKernelGGL((k_astar2<a2_small>), dim3(workgroups), dim3(astar2_threads(true)), a2_small::BYTES, ctx->stream, a);
     else if (split) hipLaunchKernelGGL((k_astar2<a2_big>), dim3(workgroups), dim3(astar2_threads()), a2_big::BYTES, ctx->stream, a);
     else if (small) hipLaunchKernelGGL((k_astar<AH_LDS_SMALL, AH_COST_LDS_SMALL>), dim3(workgroups), dim3(64), AH_LDS_SMALL_BYTES, ctx->stream, a);

@@ -230,6 +230,10 @@ void* bl_dist_device_ptr(bl_dist* d);
 int bl_astar_search(bl_ctx* ctx, const bl_dist* distances, const bl_pose_xyt_t* start, const bl_pose_xyt_t* goal,
                     const bl_search_params_t* params, bl_pose_xyt_t* out_path, int cap, int* out_len, int64_t* stats);
 int bl_astar_set_open_capacity(bl_ctx* ctx, int64_t nodes);
+/* Which kernel the last search launched on this ctx took: 2 = k_astar2 (16-bit keys apart from payloads), 1 = k_astar (8-byte entries:
+ * a cost table that can take an fCost to -32768 or below, e.g. maxDistanceWithCost > 16.4 m at the reference's d * 2000, or an odd
+ * distanceCostExponent > 1), 0 = no search yet.  Diagnostics for the parity tests. */
+int bl_astar_debug_last_kernel(bl_ctx* ctx);
 /* Test entry for the search's open list (std::priority_queue<Node, vector, greater>, astar.cpp:75-76,117-135, as the wave-parallel
  * std::push_heap / std::pop_heap of k_astar2): replays n operations -- keys[i] in [1, 65534]: push (keys[i], pays[i]); keys[i] < 0:
  * pop -- and returns the popped (key, payload) pairs in order.  cfg 0 / 1 / 2: the storage tiers of a lone search, of a
