@@ -2555,7 +2555,7 @@ static int astar_prepare_lut(bl_ctx* ctx, const bl_dist* d, const bl_search_para
             c = 0;
             if (dist > params->minDistanceToObstacle && dist < params->maxDistanceWithCost) {
                 double v = pow(params->maxDistanceWithCost - dist * 2000, params->distanceCostExponent);   // float product
-                c = (v == v && fabs(v) < 2.0e9) ? static_cast<int>(v) : 0;
+                c = (v == v && fabs(v) < 2.0e9) ? static_cast<int>(v) : 0;                                 // (D11: the cast is undefined beyond int)
                 if (c == ASTAR_INVALID_COST) c = ASTAR_INVALID_COST + 1;
             }
         }

@@ -36,6 +36,9 @@
 //       path was found (:344-347 is commented out); the switch of :352-368 then ends in its default branch, so that case
 //       is FAILED (status STATUS_FAILED, next state FAILED_EXPLORATION).  Restated over this file's pieces in
 //       tests/oracle_lib.py (OracleExploringMap).
+//   D11 get_oCost (astar.cpp:181-186) casts pow(maxDist - d * 2000, exponent) to int; a result that does not fit an int (or
+//       is NaN: a negative base with a fractional exponent) makes that cast undefined.  Such a cell's obstacle cost is 0.
+//       (Never reached with the reference's own parameters -- exponent 1, |cost| <= 3998 -- only with exponents >= 3.)
 
 #include <algorithm>
 #include <cmath>
@@ -479,7 +482,10 @@ inline int o_cost(int x, int y, const orc_search_params_t& p, const orc_dist_t& 
     int c = 0;
     float dist = d.cells[y * d.width + x];
     if (dist > p.minDistanceToObstacle && dist < p.maxDistanceWithCost)
-        c = static_cast<int>(pow(p.maxDistanceWithCost - dist * 2000, p.distanceCostExponent));   // float product
+    {
+        const double v = pow(p.maxDistanceWithCost - dist * 2000, p.distanceCostExponent);        // float product
+        c = (v == v && std::fabs(v) < 2.0e9) ? static_cast<int>(v) : 0;                             // D11
+    }
     return c;
 }
 inline void cell_to_global(int cx, int cy, const orc_dist_t& d, float* gx, float* gy)   // grid_utils.hpp:14-19

@@ -938,7 +938,7 @@ def test_astar_cost_table_below_16_bit_keys_takes_k_astar(gpu_ctx, oracle, maps)
     planner.setMap(g)
     dist = oracle.set_distances(m["cells"], m["mpc"], h.CPM_DEFAULT, m["origin"])
     rows = h.load_astar_cases()["maze"]
-    for (mind, maxd, expo), want_kernel in (((0.1, 1.0, 1.0), 2), ((0.1, 20.0, 1.0), 1), ((0.1, 1.0, 3.0), 1)):
+    for (mind, maxd, expo), want_kernel in (((0.1, 1.0, 1.0), 2), ((0.1, 20.0, 1.0), 1), ((0.1, 0.6, 3.0), 1), ((0.1, 1.0, 3.0), 1)):   # (the last one: D11 from 0.65 m on)
         sp = b._capi.SearchParams(mind, maxd, expo)
         for i in (0, 2):
             row = rows[i]
