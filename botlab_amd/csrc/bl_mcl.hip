@@ -667,20 +667,21 @@ __device__ __forceinline__ void stage_rows(int* s_map32, int rows, int wq, int q
 // loop; the kernel is VALU-bound.)
 #ifdef MCL_STAMPS
 // diagnostic build: per workgroup, the 100 MHz clock at entry, behind the first barrier, behind the ray loop and at the end
-__device__ unsigned long long g_mcl_stamps[4096 * 8];
-#define MCL_STAMP(k) do { if (threadIdx.x == 0 && blockIdx.x < 4096) g_mcl_stamps[blockIdx.x * 8 + (k)] = wall_clock64(); } while (0)
-#define MCL_STAMP_T(k, T) do { if ((int)threadIdx.x == (T) && blockIdx.x < 4096) g_mcl_stamps[blockIdx.x * 8 + (k)] = wall_clock64(); } while (0)
+#define MCL_STAMP_SLOTS 12
+__device__ unsigned long long g_mcl_stamps[4096 * MCL_STAMP_SLOTS];
+#define MCL_STAMP(k) do { if (threadIdx.x == 0 && blockIdx.x < 4096) g_mcl_stamps[blockIdx.x * MCL_STAMP_SLOTS + (k)] = wall_clock64(); } while (0)
+#define MCL_STAMP_T(k, T) do { if ((int)threadIdx.x == (T) && blockIdx.x < 4096) g_mcl_stamps[blockIdx.x * MCL_STAMP_SLOTS + (k)] = wall_clock64(); } while (0)
 #ifdef MCL_STAMPS_HW
 // ... and, in place of the "bisection done" stamp, where the workgroup ran: HW_ID (se, sh, cu, simd of wave 0) | XCC_ID << 32
 // (tests/tools/mcl_placement_probe.py)
-#define MCL_STAMP_HW() do { if (threadIdx.x == 0 && blockIdx.x < 4096) g_mcl_stamps[blockIdx.x * 8 + 6] = \
+#define MCL_STAMP_HW() do { if (threadIdx.x == 0 && blockIdx.x < 4096) g_mcl_stamps[blockIdx.x * MCL_STAMP_SLOTS + 6] = \
     (unsigned long long)__builtin_amdgcn_s_getreg(63492) | ((unsigned long long)__builtin_amdgcn_s_getreg(63508) << 32); } while (0)
 #else
 #define MCL_STAMP_HW() do { } while (0)
 #endif
 extern "C" int bl_debug_mcl_stamps(unsigned long long* out, int n)
 {
-    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_mcl_stamps), (size_t)n * 8 * 8) == hipSuccess ? 0 : 1;
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_mcl_stamps), (size_t)n * MCL_STAMP_SLOTS * 8) == hipSuccess ? 0 : 1;
 }
 #else
 #define MCL_STAMP(k) do { } while (0)
@@ -762,11 +763,21 @@ __global__ __launch_bounds__(BLOCK) void k_mcl_main(mcl_args a)
         const int st = tid - pw * 64, n_st = n_sw * 64;
         const int cnt0 = a.R < MCL_LDS_RAYS ? a.R : MCL_LDS_RAYS;
         for (int n = st; n < cnt0; n += n_st) s_ray[n] = ray_table_entry(a.ranges[n], a.thetas[n]);
+        MCL_STAMP_T(8, pw * 64);                                 // this staging wave's ray-table entries are formed
         if (MAP_MODE == 1) {
             // the whole grid as a framed image: rows -MCL_FRAME..H+MCL_FRAME-1, columns -4..stride-5 (zeros outside)
             const int wq = win.stride >> 2;
             const int rows = a.frame.height + 2 * MCL_FRAME;
-            if ((a.frame.width & 3) == 0 && (a.frame.width >> 2) <= 64 && a.stage_dma) {
+            if (a.framed && a.stage_dma) {
+                // the framed copy in device memory, as it stands: whole 16-byte pieces, 64 per instruction (pf_launch_main has
+                // checked the size); a piece is 16 contiguous bytes of both images
+                const int pieces = (wq * rows) >> 2;
+                const char* src = (const char*)(a.framed - MCL_FRAME * a.framed_stride - 4);
+                for (int p0 = sw * 64; p0 < pieces; p0 += n_sw * 64)
+                    if (p0 + lane < pieces)
+                        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (size_t)(p0 + lane) * 16),
+                                                         (__attribute__((address_space(3))) void*)((char*)s_map32 + (size_t)p0 * 16), 16, 0, 0);
+            } else if ((a.frame.width & 3) == 0 && (a.frame.width >> 2) <= 64 && a.stage_dma) {
                 // Rows of up to 64 dwords by LDS-DMA: one global_load_lds_dword per row (lane = dword column; the wave-uniform
                 // destination is the row's first data dword), no register between the load and LDS, so EVERY row of a wave
                 // is in flight at once -- the register-staged form below keeps six rows per wave in flight and took 8 us of a
@@ -823,7 +834,11 @@ __global__ __launch_bounds__(BLOCK) void k_mcl_main(mcl_args a)
         }
     }
 
-    MCL_STAMP_T(4, pw * 64);                                     // a staging wave is through
+    MCL_STAMP_T(4, pw * 64);                                     // a staging wave is through (its loads ISSUED)
+#ifdef MCL_STAMPS
+    if (wave >= pw) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+    MCL_STAMP_T(9, pw * 64);                                     // ... and landed (stamped build only: the shipped one waits at the barrier)
+#endif
     // ---- phase 1b: per-particle prologue
     double t_units = 0, t_x = 0, t_y = 0, t_s = 0, t_c = 0;
     float2 pcs_own = make_float2(2.0f, 0.0f);               // (2, -): "take the hardware sine / cosine" (a.fast_trig == 2)
@@ -1781,11 +1796,8 @@ static int pf_launch_main(bl_pf* pf, const bl_grid* map, int R, int rand_value, 
         const int W = map->frame.width, H = map->frame.height;
         const int stride = ((W + 3) & ~3) + 8;
         const size_t whole = (size_t)stride * (H + 2 * MCL_FRAME);      // framed image
-        if (pf->use_lds && whole <= MCL_WIN_SMALL_BYTES) {
-            a.win_w = W; a.win_h = H;
-            lds_bytes = (int)whole;
-            mode = 1;
-        } else if (a.pk_ok && !a.interp && !pf->no_framed) {
+        // the zero-framed copy in device memory, current as of the work enqueued on this stream (k_map_update keeps it so)
+        auto ensure_mirror = [&]() -> int {
             if (whole > map->mirror_cap) {
                 if (map->mirror) { BL_HIP(hipStreamSynchronize(ctx->stream)); BL_HIP(hipFree(map->mirror)); map->mirror = nullptr; map->mirror_cap = 0; }
                 BL_HIP(hipMalloc((void**)&map->mirror, whole));
@@ -1800,6 +1812,24 @@ static int pf_launch_main(bl_pf* pf, const bl_grid* map, int R, int rand_value, 
             }
             a.framed = map->mirror + MCL_FRAME * stride + 4;
             a.framed_stride = stride;
+            return BL_OK;
+        };
+        if (pf->use_lds && whole <= MCL_WIN_SMALL_BYTES) {
+            a.win_w = W; a.win_h = H;
+            lds_bytes = (int)whole;
+            mode = 1;
+            // Round 6: the LDS image of mode 1 IS the framed copy, byte for byte -- so it is staged from that copy in 16-byte pieces
+            // (global_load_lds_dwordx4: 1 KB per wave instruction, 42 instructions per workgroup) instead of row by row from the
+            // grid in dwords (206 instructions of 200 bytes): the staging waves' loads were issue-bound, 35 per wave in 6 us
+            // (profiles/r06_mcl_timeline.txt).  Needs the image to be whole 16-byte pieces and the map to live on this ctx's
+            // stream (the copy is kept current by k_map_update there); BOTLAB_MCL_NO_STAGE_X4=1: the row form.
+            static const bool no_x4 = getenv("BOTLAB_MCL_NO_STAGE_X4") != nullptr;
+            if (!no_x4 && a.stage_dma && (whole & 15) == 0 && map->ctx == ctx && !map->mirror_external && !pf->no_framed && !pf->no_mirror_reuse) {
+                int rc_m = ensure_mirror();
+                if (rc_m) return rc_m;
+            }
+        } else if (a.pk_ok && !a.interp && !pf->no_framed) {
+            { int rc_m = ensure_mirror(); if (rc_m) return rc_m; }
             // Measured at 100k-1M particles on 2000^2 / 4096^2 grids: with the rays inside it a 208-cell window is 8-22 %
             // faster than gathering everything through L2, with nearly every ray leaving it (8 m rays) it is within
             // -3 .. +6 %; larger windows lose more to occupancy (264: two workgroups per CU) than they gain in hits.

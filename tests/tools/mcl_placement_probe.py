@@ -22,10 +22,10 @@ for k in range(60):
 ctx.sync()
 lib = ctx.lib
 nb = 1400
-buf = (C.c_ulonglong * (nb * 8))()
+buf = (C.c_ulonglong * (nb * 12))()
 lib.bl_debug_mcl_stamps.restype = C.c_int
 assert lib.bl_debug_mcl_stamps(buf, nb) == 0
-t = np.array(buf[:], dtype=np.uint64).reshape(nb, 8)
+t = np.array(buf[:], dtype=np.uint64).reshape(nb, 12)
 t = t[t[:, 0] > 0]
 t0 = t[:, 0].min()
 hw = t[:, 6]

@@ -23,10 +23,10 @@ for k in range(60):
 ctx.sync()
 lib = ctx.lib
 nb = 1400
-buf = (C.c_ulonglong * (nb * 8))()
+buf = (C.c_ulonglong * (nb * 12))()
 lib.bl_debug_mcl_stamps.restype = C.c_int
 assert lib.bl_debug_mcl_stamps(buf, nb) == 0
-t = np.array(buf[:], dtype=np.float64).reshape(nb, 8)
+t = np.array(buf[:], dtype=np.float64).reshape(nb, 12)
 t = t[t[:, 0] > 0]
 t0 = t[:, 0].min()
 t[t == 0] = t0
@@ -38,7 +38,9 @@ for name, r in (("region 1", main), ("region 2", tail)):
     if len(r) == 0: continue
     print(name, "entry           ", q(r[:, 0]))
     print(name, "entry -> barrier", q(r[:, 1] - r[:, 0]))
-    print(name, "  staging wave done   ", q(r[:, 4] - r[:, 0]))
+    print(name, "  ray table formed    ", q(r[:, 8] - r[:, 0]))
+    print(name, "  staging loads issued", q(r[:, 4] - r[:, 0]))
+    print(name, "  staging loads landed", q(r[:, 9] - r[:, 0]))
     print(name, "  bracket known       ", q(r[:, 5] - r[:, 0]))
     print(name, "  bisection done      ", q(r[:, 6] - r[:, 0]))
     print(name, "  prologue arithmetic ", q(r[:, 7] - r[:, 0]))
