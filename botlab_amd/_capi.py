@@ -100,6 +100,7 @@ SIGNATURES = {
     "bl_pf_debug_resample": (C.c_int, [_vp, C.c_int, _vp]),
     "bl_pf_debug_enable": (C.c_int, [_vp, C.c_int]),
     "bl_pf_debug_last": (C.c_int, [_vp, _vp, _vp]),
+    "bl_pf_debug_uniform_runs": (C.c_int, [_vp, _P(C.c_int)]),
     "bl_debug_trig_probe": (C.c_int, [_vp, _P(C.c_float), _P(C.c_float), _P(C.c_float), _P(C.c_uint64)]),
     "bl_debug_trig_addition_probe": (C.c_int, [_vp, C.c_uint64, C.c_uint32, _P(C.c_float), _P(C.c_float), _P(C.c_float), _P(C.c_uint64)]),
     "bl_dist_create": (C.c_int, [_vp, _P(_vp)]),

@@ -72,6 +72,7 @@ struct bl_pf {
                               // weights on which the integer rule and the reference's rounded cumulative part ways (rand() near 0 or
                               // RAND_MAX puts every U on a partial sum) -- the next resampling then takes the reference's cumulative
     bool prefix_is_strict;    // prefix[] holds that cumulative (doubles), not the integer prefix
+    double w_floor;           // 0.001 / wSum of N floor weights as the reference's loop rounds it (particle_filter.cpp:116-141): the all-floor set's weight
     unsigned long long* block_sums;   // scan scratch
     int scan_blocks;
     int32_t* dbg_idx;
@@ -850,14 +851,19 @@ __global__ __launch_bounds__(BLOCK) void k_mcl_main(mcl_args a)
     double rs_T = 0.0;
     int rs_lo = 0, rs_hi = a.N - 1;
     const mcl_prefix_view pview = {a.sh, a.prefix};
+    // equal weights (a fresh filter, every particle at the likelihood floor): U against the runs of the reference's own rounded
+    // cumulative, no prefix (uni_seg, bl_mcl_finish.h).  The same value in every lane of the launch.
+    const int uni_n = a.resample ? a.state->uni_n : 0;
     if (a.resample && (!shared_pro || wave < pw)) {                  // whole waves: the narrowing is cooperative
-        if (pro_active) { rs_T = a.r + mp * a.M_inv; if (!a.strict) rs_T *= a.state->S; }      // U (particle_filter.cpp:95), or U * S
-        if (a.sh) resample_bracket(pview, a.N, rs_T, pro_active, lane, &rs_lo, &rs_hi, a.strict != 0);
+        if (pro_active) { rs_T = a.r + mp * a.M_inv; if (!a.strict && uni_n <= 0) rs_T *= a.state->S; }      // U (particle_filter.cpp:95), or U * S
+        if (uni_n > 0) { }
+        else if (a.sh) resample_bracket(pview, a.N, rs_T, pro_active, lane, &rs_lo, &rs_hi, a.strict != 0);
         else resample_bracket(a.prefix, a.N, rs_T, pro_active, lane, &rs_lo, &rs_hi, a.strict != 0);
     }
     MCL_STAMP(5);                                                // the bracket is known
     if (pro_active) {
-        if (a.resample) i = a.sh ? resample_bisect(pview, rs_T, rs_lo, rs_hi, a.strict != 0) : resample_bisect(a.prefix, rs_T, rs_lo, rs_hi, a.strict != 0);
+        if (a.resample && uni_n > 0) i = uni_search(a.state, uni_n, rs_T, a.N);
+        else if (a.resample) i = a.sh ? resample_bisect(pview, rs_T, rs_lo, rs_hi, a.strict != 0) : resample_bisect(a.prefix, rs_T, rs_lo, rs_hi, a.strict != 0);
         MCL_STAMP(6);
         s = mcl_src_at(a, i);
         // ---- ActionModel::applyAction (action_model.cpp:78-103)
@@ -1059,7 +1065,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan_tile_sums(const float4* _
 // totals of the tiles before it (exact integers), scans its tile and writes the prefix; workgroup 0 records the unit total.
 __global__ __launch_bounds__(SCAN_THREADS) void k_scan_write_prefix(const float4* __restrict__ rec, int N,
                                                                     const unsigned long long* __restrict__ tile_sums, int ntiles,
-                                                                    unsigned long long* __restrict__ prefix, pf_state* state)
+                                                                    unsigned long long* __restrict__ prefix, pf_state* state, int uni_mode, double w_floor)
 {
     __shared__ unsigned long long s_wave[SCAN_THREADS / 64];
     __shared__ unsigned long long s_off[SCAN_THREADS / 64];
@@ -1091,7 +1097,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan_write_prefix(const float4
     for (int w = 0; w < SCAN_THREADS / 64; ++w) { off0 += s_off[w]; total += s_tot[w]; if (w < wave) off0 += s_wave[w]; }
     for (int k = 0; k < SCAN_ITEMS; ++k)
         if (base + k < N) prefix[base + k] = off0 + loc[k];
-    if (blockIdx.x == 0 && threadIdx.x == 0) state->S = (double)total;
+    if (blockIdx.x == 0 && threadIdx.x == 0) { state->S = (double)total; uni_update(state, N, (double)total, uni_mode, w_floor); }     // (equal weights: bl_mcl_finish.h, uni_seg)
 }
 
 // Stand-alone launch of the end of an update (bl_mcl_finish.h): workgroup 0 is the finisher (estimatePosteriorPose,
@@ -1124,6 +1130,8 @@ __global__ __launch_bounds__(256) void k_pf_resample_only(const unsigned long lo
     const int m = blockIdx.x * blockDim.x + threadIdx.x, lane = threadIdx.x & 63;
     const bool on = m < N;
     double T = on ? r + m * M_inv : 0.0;
+    const int uni_n = state->uni_n;                                 // equal weights: the runs of the reference's cumulative (uni_seg)
+    if (uni_n > 0) { if (on) out[m] = uni_search(state, uni_n, T, N); return; }
     if (!strict) T *= state->S;
     int lo, hi;
     resample_bracket(prefix, N, T, on, lane, &lo, &hi, strict != 0);
@@ -1476,6 +1484,11 @@ extern "C" int bl_pf_create(bl_ctx* ctx, int num_particles, int shard_lo, int sh
     memset((void*)pf, 0, sizeof(*pf));
     pf->ctx = ctx;
     pf->N = num_particles; pf->lo = shard_lo; pf->hi = shard_hi; pf->n_local = shard_hi - shard_lo;
+    {   // computeNormalizedPosterior on N floor weights: wSum += 0.001 N times, then 0.001 / wSum (volatile: no vectorised reassociation)
+        volatile double wsum = 0.0;
+        for (int i = 0; i < num_particles; ++i) wsum = wsum + 0.001;
+        pf->w_floor = 0.001 / wsum;
+    }
     pf->noise_seed = 0x243F6A8885A308D3ull;
     pf->use_lds = getenv("BOTLAB_MCL_NO_LDS") == nullptr;
     pf->no_fused_finish = getenv("BOTLAB_MCL_NO_FUSED_FINISH") != nullptr;
@@ -1518,11 +1531,22 @@ extern "C" int bl_pf_set_exchange_buffers(bl_pf* pf, void* d_rec0, void* d_rec1)
 extern "C" void* bl_pf_exchange_rec_ptr(bl_pf* pf) { return pf && pf->prefix ? (void*)pf->rec[pf->pending_end ? pf->cur ^ 1 : pf->cur] : nullptr; }
 extern "C" const void* bl_pf_pose_device_ptr(bl_pf* pf) { return pf && pf->state ? (const void*)&pf->state->pose : nullptr; }
 
+// what the launch that writes the weight total is told about equal weights (uni_update): 1 = the host knows the record's weights are
+// all equal (only a launch over rec[cur] as uploaded / initialised may be told so), 0 = recognise the all-floor set, -1 = off
+// (BOTLAB_NO_AUTO_STRICT=1: the integer rule everywhere -- tests, A/B runs)
+static int pf_uni_mode(const bl_pf* pf, bool plain_scan)
+{
+    static const bool no_auto = getenv("BOTLAB_NO_AUTO_STRICT") != nullptr;
+    if (no_auto) return -1;
+    return plain_scan && pf->uniform_now ? 1 : 0;
+}
+
 // strict resampling: the integer prefix just written gives way to the reference's own cumulative (same buffer, as doubles)
 static void pf_strict_cumulative(bl_pf* pf, int which)
 {
-    static const bool no_auto = getenv("BOTLAB_NO_AUTO_STRICT") != nullptr;         // tests: the integer rule on equal weights
-    pf->prefix_is_strict = pf->strict || (pf->uniform_now && pf->sh_world <= 1 && !no_auto);
+    // (equal weights -- a fresh filter, an upload, an all-floor update -- no longer come here: the launch that writes the total leaves
+    // the runs of the reference's cumulative and k_mcl_main searches those, uni_seg in bl_mcl_finish.h)
+    pf->prefix_is_strict = pf->strict;
     if (!pf->prefix_is_strict) return;
     static const bool one_wave = getenv("BOTLAB_STRICT_ONE_WAVE") != nullptr;        // tests, A/B runs
     const int nchunks = (pf->N + 127) / 128;
@@ -1568,6 +1592,8 @@ static int pf_finish_fill(bl_pf* pf, mcl_finish_args* f)
         pf->fin_last_nrec = nrec;
     }
     f->sh = nullptr;
+    f->uni_mode = pf_uni_mode(pf, false);
+    f->w_floor = pf->w_floor;
     f->wild = pf->sh_world > 1 ? nullptr : pf->fin_wild;      // (a composed finish keeps to records, tables and replays)
     f->no_trees = getenv("BOTLAB_MCL_NO_TREES") != nullptr ? 1 : 0;
     f->recs = pf->fin_recs;
@@ -1599,7 +1625,7 @@ static int pf_scan(bl_pf* pf, int which, int write_pose, int64_t utime)
         hipLaunchKernelGGL(k_mcl_finish, dim3(MCLF_EXTRA_WGS + f.groups_wait), dim3(MCLF_WG), MCLF_LDS_BYTES, ctx->stream, f);
     } else {
         hipLaunchKernelGGL(k_scan_write_prefix, dim3(pf->scan_blocks), dim3(SCAN_THREADS), 0, ctx->stream, pf->rec[which], pf->N,
-                           pf->block_sums, pf->scan_blocks, pf->prefix, pf->state);
+                           pf->block_sums, pf->scan_blocks, pf->prefix, pf->state, pf_uni_mode(pf, true), pf->w_floor);
     }
     BL_HIP(hipGetLastError());
     pf_strict_cumulative(pf, which);
@@ -2677,6 +2703,16 @@ extern "C" int bl_pf_debug_resample(bl_pf* pf, int rand_value, int32_t* out_idx)
                        pf->prefix_is_strict ? 1 : 0, pf->dbg_idx);
     BL_HIP(hipGetLastError());
     BL_HIP(hipMemcpyAsync(out_idx, pf->dbg_idx, (size_t)pf->N * 4, hipMemcpyDeviceToHost, pf->ctx->stream));
+    BL_HIP(hipStreamSynchronize(pf->ctx->stream));
+    return BL_OK;
+}
+
+extern "C" int bl_pf_debug_uniform_runs(bl_pf* pf, int* out_runs)
+{
+    BL_CHECK_ARG(pf != nullptr && out_runs != nullptr);
+    if (!pf->initialized) { bl_set_error("filter not initialised"); return BL_ERR_STATE; }
+    BL_HIP(hipSetDevice(pf->ctx->device));
+    BL_HIP(hipMemcpyAsync(out_runs, &pf->state->uni_n, sizeof(int), hipMemcpyDeviceToHost, pf->ctx->stream));
     BL_HIP(hipStreamSynchronize(pf->ctx->stream));
     return BL_OK;
 }

@@ -29,6 +29,20 @@
 #include "bl_internal.h"
 #include "bl_serial_sum.h"
 
+// ---- equal weights.  On a set of N EQUAL weights w the reference's resampler (particle_filter.cpp:84-103) compares U_m = r + m / N with
+// c_0 = w, c_i = fl(c_{i-1} + w): every U_m lies within the sum's rounding error of a partial sum when r is 0, nearly 0 or 1 / N, so an
+// exact integer prefix picks the neighbouring source for about half of the particles there.  Equal weights are what a fresh filter holds
+// (1 / N, D2), what an upload of equal weights holds, and what an update leaves when EVERY particle ends at the likelihood floor
+// (computeNormalizedPosterior, :116-141: w = 0.001 / wSum, wSum the sequentially rounded sum of N times 0.001 -- a kidnapped or lost
+// filter; the total of the weight units is then exactly 2 N, which no other set of weights gives: a unit is 0.0005, the floor 2 units,
+// the smallest likelihood above it 1000).  For such a set the c_i have a closed form: inside a binade a step adds the same multiple of
+// the binade's ulp every time (after one step inside it: a tie rounds to even, and from an even sum on the step is constant too), so the
+// whole sequence is ~3 runs (c0, inc, n) per binade.  The launch that writes the total (the finisher, k_scan_write_prefix) forms the runs
+// -- one thread, some tens of runs -- and the next k_mcl_main searches them instead of the prefix: U_m against the reference's own
+// rounded cumulative, bit for bit, on any number of ranks (the runs need no particle data).
+#define UNI_MAX 192
+struct uni_seg { double c0, inc, last; int i0, n; };      // c_{i0 + k} = c0 + k * inc (exact), 0 <= k < n; last = c0 + (n - 1) * inc
+
 struct pf_state {
     double S;                 // total weight units of rec[cur]
     bl_pose_xyt_t pose;       // posteriorPose_
@@ -42,6 +56,9 @@ struct pf_state {
     unsigned long long cstamps[16]; // the x chain, entry by entry (diagnostic, -DMCLF_STAMPS)
     unsigned long long gstamps[8]; // one group's timeline (diagnostic, -DMCLF_STAMPS)
     unsigned long long stamps[6];  // finisher timeline in 10 ns ticks (diagnostic, -DMCLF_STAMPS)
+    int uni_n;                // > 0: rec[cur]'s weights are all equal and uni[0 .. uni_n) holds the reference's cumulative of them (see uni_seg)
+    int uni_pad;
+    uni_seg uni[UNI_MAX];
     unsigned long long xstamps[16]; // [0] the stamped group's loads are back; [1] the finisher's stage-a loads are back, [2] its wave 0 is through stage a; [3] the pre-chain has published, [4] the x chain has its start value
 };
 
@@ -73,6 +90,8 @@ struct mcl_finish_args {
     unsigned long long* prefix;
     pf_state* state;
     int64_t utime;
+    int uni_mode;                          // equal weights (uni_seg): 0 = detect the all-floor set from the total, -1 = off (BOTLAB_NO_AUTO_STRICT)
+    double w_floor;                        // the weight computeNormalizedPosterior leaves on N floor weights: 0.001 / (0.001 + ... + 0.001, N terms, rounded at every step); the host forms it once per filter
     ss_rec* recs;                          // [2][groups * subs]: x records, then y records
     mclf_tab_elem* tabs;                   // [2][MCLF_TSLOTS][MCLF_SUB]
     unsigned long long* sync;              // MCLF_SYNC_WORDS words, zero between launches:
@@ -127,6 +146,86 @@ static inline int mclf_groups(const mcl_finish_args& f)
 }
 
 #if defined(__HIPCC__)
+// ---- the runs of the equal-weight cumulative (uni_seg).  One thread; every addition below is the reference's own IEEE addition
+// (the build has -ffp-contract=off; nothing here may be reassociated).
+__device__ __forceinline__ int uni_exp(double v) { return (int)((__double_as_longlong(v) >> 52) & 0x7ffLL); }      // biased exponent
+
+// c_0 = w, c_i = fl(c_{i-1} + w), i < N, as runs; returns their number (0: they do not fit `cap`, or w is not a positive normal
+// number), *last = c_{N-1}.  seg == nullptr: only the last value is wanted (the reference's wSum of N floor weights).
+// A run of constant increment starts at a sum that was reached BY A STEP INSIDE ITS BINADE (then a tie has rounded to even and every
+// later step of the binade adds the same amount: with w = (q + 1/2) ulp and an even sum M, q even gives M + q -- even again --, q odd
+// gives M + q + 1 -- even again; without a tie the step is RN(w / ulp) from any sum) and ends two units below the binade's top, so
+// that every step of it rounds on the binade's own grid; the steps across a binade's top are taken one by one.
+__device__ inline int uni_build(double w, int N, uni_seg* seg, int cap, double* last_out)
+{
+    if (!(w > 0.0) || uni_exp(w) == 0 || uni_exp(w) == 0x7ff || N <= 0) { *last_out = 0.0; return 0; }
+    int ns = 0, i = 0;
+    double c = w;                                              // c = c_i
+    bool fits = true;
+    auto emit = [&](int i0, double c0, double inc, int n) {
+        if (seg) { if (ns < cap) { uni_seg s_; s_.c0 = c0; s_.inc = inc; s_.last = c0 + (double)(n - 1) * inc; s_.i0 = i0; s_.n = n; seg[ns] = s_; } else fits = false; }
+        ns += 1;
+    };
+    while (true) {
+        if (i >= N - 1) { emit(i, c, 0.0, 1); break; }
+        const double c1 = c + w;                               // c_{i+1}
+        const int e = uni_exp(c);
+        bool run = uni_exp(c1) == e && i + 2 < N;
+        double c2 = 0.0;
+        if (run) { c2 = c1 + w; run = uni_exp(c2) == e; }
+        if (!run) { emit(i, c, 0.0, 1); i += 1; c = c1; continue; }
+        // c, c1, c2 in one binade: c1 was reached by a step inside it; from c1 on the step is inc while the sums stay inside
+        const double inc = c2 - c1;                            // exact (both on the binade's grid)
+        const double u = __longlong_as_double((long long)(e - 52) << 52);          // the binade's ulp, 2^(e - 1023 - 52) (e > 52 here: c >= w normal and ... see below)
+        long long nrun = 1;
+        if (e > 52) {
+            const long long M1 = (long long)(c1 / u), Q = (long long)(inc / u);    // exact: integers below 2^53
+            if (Q > 0) nrun = ((1LL << 53) - 2 - M1) / Q + 1;                      // c1 + k inc <= (2^53 - 2) u for k < nrun
+            if (nrun < 1) nrun = 1;
+        }
+        if ((long long)i + 1 + nrun > (long long)N) nrun = (long long)N - (i + 1);
+        emit(i, c, 0.0, 1);
+        emit(i + 1, c1, inc, (int)nrun);
+        const double tail = c1 + (double)(nrun - 1) * inc;     // exact
+        i = i + 1 + (int)nrun;
+        if (i >= N) { c = tail; break; }
+        c = tail + w;                                          // c_i: a real step from the run's last sum
+    }
+    *last_out = c;
+    return (fits || !seg) ? ns : 0;
+}
+
+// first i with T <= c_i, clamped to N - 1 (resamplePosteriorDistribution's `while (U > c)`, D4), from the runs
+__device__ inline int uni_search(const pf_state* st, int uni_n, double T, int N)
+{
+    int lo = 0, hi = uni_n - 1;
+    while (lo < hi) { const int mid = (lo + hi) >> 1; if (st->uni[mid].last >= T) hi = mid; else lo = mid + 1; }
+    const uni_seg s_ = st->uni[lo];
+    if (!(s_.last >= T)) return N - 1;
+    if (T <= s_.c0 || s_.n <= 1) return s_.i0;
+    long long k = (long long)((T - s_.c0) / s_.inc);
+    if (k < 0) k = 0;
+    if (k > s_.n - 1) k = s_.n - 1;
+    while (k < s_.n - 1 && s_.c0 + (double)k * s_.inc < T) ++k;                    // (c0 + k inc is exact: a sum of the run)
+    while (k > 0 && s_.c0 + (double)(k - 1) * s_.inc >= T) --k;
+    return s_.i0 + (int)k;
+}
+
+// the launch that has just written the total S of the weight units decides whether the set is one of equal weights.  mode 1: the host
+// knows it is (a fresh filter, an upload of equal weights: w = fl(units / S) = fl(1 / N)); 0: only the all-floor set is recognised
+// (S == 2 N: w = w_floor = 0.001 / wSum as computeNormalizedPosterior leaves it, formed by the host); -1: never.
+__device__ inline void uni_update(pf_state* st, int N, double S, int mode, double w_floor)
+{
+    int n = 0;
+    if (mode >= 0) {
+        double w = 0.0, last;
+        if (mode == 1) w = 1.0 / (double)N;
+        else if (S == 2.0 * (double)N) w = w_floor;
+        if (w > 0.0) n = uni_build(w, N, st->uni, UNI_MAX, &last);
+    }
+    st->uni_n = n;
+}
+
 #define MCLF_MAXW (MCLF_WG / 64)
 struct mclf_smem {
     unsigned long long off[MCLF_MAXW], wave[MCLF_MAXW], tot[MCLF_MAXW];
@@ -344,10 +443,17 @@ __device__ __forceinline__ void mclf_sub_range(const mcl_finish_args& f, int s, 
 // The term of particle r on an axis: t = fl64(w * x), w = fl64(units / S) (particle_filter.cpp:136-138, 151-152).  With the
 // units exact integers, units / S is the same real quotient as the reference's weight / wSum whenever no weight was floored to
 // 0.001 (then wSum itself is a rounded sum; DESIGN.md "Pose estimate").
+// The all-floor set (uni_seg) is the one case in which that matters to every term: the reference's weight is w_floor = 0.001 / wSum
+// for all N particles (a few 1e-12 away from 2 / S = 1 / N: a last-bit difference in one term of a few thousand, and the float sum
+// rounds differently there).  A NEGATIVE S says "the weight is -S" (mclf_term_S).
 __device__ __forceinline__ double mclf_term(const float4& r, double S, int axis)
 {
-    const double w = (double)__float_as_uint(r.w) / S;
+    const double w = S < 0.0 ? -S : (double)__float_as_uint(r.w) / S;
     return w * (double)(axis ? r.y : r.x);
+}
+__device__ __forceinline__ double mclf_term_S(const mcl_finish_args& f, double S)
+{
+    return (f.uni_mode >= 0 && S == 2.0 * (double)f.N) ? -f.w_floor : S;
 }
 __device__ __forceinline__ void mclf_load_terms(const mcl_finish_args& f, int axis, double S, int lo, int hi, int lane, double (&t)[MCLF_ITEMS])
 {
@@ -606,11 +712,12 @@ __device__ __forceinline__ void mclf_prefix_group(const mcl_finish_args& f, int 
     MCLF_GSTAMP(3);
     // ---- the sub-tile records of the two float accumulators
     const double S = (double)S_u;
+    const double St = mclf_term_S(f, S);
     double tx[MCLF_ITEMS], ty[MCLF_ITEMS];
     double sx = 0.0, sy = 0.0;
 #pragma unroll
     for (int k = 0; k < MCLF_ITEMS; ++k) {
-        tx[k] = mclf_term(r[k], S, 0); ty[k] = mclf_term(r[k], S, 1);
+        tx[k] = mclf_term(r[k], St, 0); ty[k] = mclf_term(r[k], St, 1);
         sx += tx[k]; sy += ty[k];
     }
     sx = mclf_wave_sum_all(sx); sy = mclf_wave_sum_all(sy);
@@ -1389,6 +1496,7 @@ __device__ __forceinline__ void mclf_pre_chain(const mcl_finish_args& f, mclf_sm
 #endif
     double S = 0.0;
     for (int w = 0; w < MCLF_POSE_THREADS / 64; ++w) S += sm.red[w][0];          // exact integer below 2^53, any order gives it
+    S = mclf_term_S(f, S);                                                       // (S feeds the terms only from here on)
     // ---- the terms; their double sums per sub-tile (the builders' predictions)
     double bt[MCLF_ITEMS] = {0.0, 0.0};
     double* pre = sm.pre[axis];
@@ -1518,6 +1626,7 @@ __device__ __forceinline__ void mclf_pose(const mcl_finish_args& f, mclf_smem& s
     __syncthreads();
     double S = 0.0;
     for (int w = 0; w < MCLF_POSE_THREADS / 64; ++w) S += sm.red[w][0];          // exact integer below 2^53, any order gives it
+    S = mclf_term_S(f, S);                                                       // (S feeds the terms only from here on)
     MCLF_STAMP(1);
     const int sh_world = mclf_world(f);
     {
@@ -1719,6 +1828,7 @@ __device__ __forceinline__ void mclf_pose(const mcl_finish_args& f, mclf_smem& s
         }
         for (int k = 0; k < 5; ++k) f.state->sums_used[k] = tot[k];
         for (int k = 0; k < 8; ++k) f.state->chain_stats[k] = sm.stats[k];
+        uni_update(f.state, f.N, tot[0], f.uni_mode, f.w_floor);        // (behind the published pose: one compare and one store unless every particle is at the floor)
 #ifdef MCLF_STAMPS
         stamp[5] = MCLF_NOW();
         for (int k = 0; k < 6; ++k) f.state->stamps[k] = stamp[k];

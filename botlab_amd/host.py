@@ -318,6 +318,12 @@ class ParticleFilter:
         check(self.ctx.lib.bl_pf_debug_resample(self.h, int(rand_value), idx.ctypes.data))
         return idx
 
+    def debugUniformRuns(self):
+        """Runs of the equal-weight cumulative in force for the next resampling (0: the weights are not known to be equal)."""
+        n = C.c_int()
+        check(self.ctx.lib.bl_pf_debug_uniform_runs(self.h, C.byref(n)))
+        return n.value
+
     def debugEstimateStats(self):
         """Per axis (x, then y): generic replays, their phases, table replays, gaps walked the slow way."""
         out = np.zeros(8, np.uint32)

@@ -161,18 +161,23 @@ int bl_pf_estimate_posterior_pose(bl_pf* pf, bl_pose_xyt_t* out_pose);
  * of those replays, sub-tiles stepped through by their table, gaps walked the slow way (bl_serial_sum.h, bl_mcl_finish.h) */
 int bl_pf_debug_estimate_stats(bl_pf* pf, uint32_t* out8);
 int bl_pf_debug_set_finish_generation(bl_pf* pf, uint32_t generation);   /* tests: the record tags of the finish launches wrap every 256 launches */
-/* Strict resampling (off by default).  The update's resampler normally compares U_m * S with an exact integer prefix of the
- * weight units; the reference (particle_filter.cpp:84-103) compares U_m with a sequentially rounded double sum of the
- * normalised weights.  The two agree unless U_m falls within that sum's rounding error of a partial sum -- measured: never for
- * weights an update leaves behind (tests/test_gpu_resample_sweep.py, tests/test_gpu_config3_1m.py).  The one kind of weights on
- * which they did part ways -- ALL EQUAL, a fresh filter's or an upload's: rand() <= ~1000 or == RAND_MAX puts every U_m on a partial
- * sum, and about half of the particles took the neighbouring source -- is detected, and the resampling that follows it runs against
- * the reference's own cumulative whatever this switch says (BOTLAB_NO_AUTO_STRICT=1: the integer rule there too; composed shards
- * keep the integer rule; equal weights that an update leaves -- every particle at the likelihood floor -- are not detected).  With strict mode on, EVERY finish is followed by the launches that form the reference's cumulative bit
+/* Resampling rule.  The update's resampler compares U_m * S with an exact integer prefix of the weight units; the reference
+ * (particle_filter.cpp:84-103) compares U_m with a sequentially rounded double sum of the normalised weights.  The two agree unless
+ * U_m falls within that sum's rounding error of a partial sum -- measured: never for weights an update leaves behind
+ * (tests/test_gpu_resample_sweep.py, tests/test_gpu_config3_1m.py).  The one kind of weights on which they did part ways is ALL EQUAL
+ * weights -- a fresh filter's, an upload's, and the set an update leaves when EVERY particle ends at the likelihood floor (a lost filter:
+ * the total is then exactly 2 N units): rand() <= ~1000 or == RAND_MAX puts every U_m on a partial sum, and about half of the particles
+ * took the neighbouring source.  All three are recognised (the first two by the host, the all-floor set on the device by the launch that
+ * writes the total) and resampled against the reference's own cumulative, which has a closed form for equal weights (a few runs of
+ * constant increment per binade: bl_mcl_finish.h, uni_seg) -- on one device and on composed shards alike, at no cost to other updates.
+ * BOTLAB_NO_AUTO_STRICT=1: the integer rule there too (tests).  bl_pf_debug_uniform_runs: the number of runs in force (0: the weights
+ * of the record are not known to be equal; synchronises).
+ * Strict mode (off by default): EVERY finish is followed by the launches that form the reference's cumulative bit
  * for bit and the resampler searches that one: identical indices for every rand() value, at ~50 us per update at 100k particles,
  * ~140 us at 1M (three launches: the chunks' sums with the binade predicted from the integer prefix, one wave walking the chunks'
  * records with the true sum, the chunks filled in side by side) behind the finish -- also behind the map kernel that carries it
  * (bl_mapping_update_finishing_pf): a 100k-particle SLAM step is 140 us instead of 90. */
+int bl_pf_debug_uniform_runs(bl_pf* pf, int* out_runs);
 int bl_pf_set_strict_resampling(bl_pf* pf, int on);
 /* resamplePosteriorDistribution alone (particle_filter.cpp:84-103): the source index each output particle would take for this
  * rand() value, by the very search the update kernel runs; num_particles entries (whole set on this device; synchronises) */

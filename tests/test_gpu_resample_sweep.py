@@ -171,3 +171,74 @@ def test_strict_mode_with_the_filter_end_riding_in_the_map_kernel(maps, gpu_ctx)
             assert np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
         assert a[3].tobytes() == b[3].tobytes()
         assert np.array_equal(a[4], b[4])
+
+
+@pytest.mark.parametrize("N", [4096, 100_000])
+def test_all_floor_weights_are_resampled_as_the_reference_does(oracle, maps, gpu_ctx, N):
+    """A lost filter: on a map that knows nothing (every cell 0) every particle's likelihood is 0, computeNormalizedPosterior
+    (particle_filter.cpp:116-141) leaves N EQUAL weights 0.001 / wSum, and the next resampling compares U_m with partial sums that lie
+    within rounding of every U_m when rand() is 0, nearly 0 or RAND_MAX -- where the integer rule took the neighbouring source for about
+    half of the particles.  The launch that writes the total recognises the set (2 N units) and leaves the runs of the reference's own
+    cumulative; whole updates then equal the oracle's: indices, particles, estimate -- for those rand() values, riding finish included."""
+    import helpers
+    import oracle_lib
+    from botlab_amd import synth
+    m = maps["obstacle_slam_10mx10m_5cm"]
+    cells = np.zeros_like(m["cells"])
+    truth = np.where(m["cells"] > 0, 127, -127).astype(np.int8)
+    rvs = [12345, 0, 1, 1000, RAND_MAX, 1804289383, 0]
+    poses = synth.square_trajectory((-0.75, 0.2, 0.0), len(rvs) + 1, step_len=0.02, turn=0.05, side=0.8)
+    scans = [synth.raycast_scan(truth, m["origin"], 0.05, poses[k - 1], poses[k], 1_000_000 + k * 100_000) for k in range(1, len(rvs) + 2)]
+    for riding in (False, True):
+        g = bl.OccupancyGrid.from_cells(cells, m["origin"], m["mpc"], cellsPerMeter=helpers.CPM_DEFAULT, ctx=gpu_ctx)
+        opf = oracle_lib.OraclePF(oracle, N)
+        opf.init_at_pose(oracle.pose(-0.75, 0.2, 0.0, utime=int(scans[0].times[0])), 5)
+        pf = bl.ParticleFilter(N, ctx=gpu_ctx)
+        pf.setParticles(opf.particles())
+        pf.debugEnable(True)
+        assert pf.debugUniformRuns() > 0                       # a fresh filter: equal weights, known to the host
+        mapper = bl.Mapping(5.0, 4, 1, ctx=gpu_ctx)
+        moved = 0
+        # update 0 latches the odometry (never moves), update 1 resamples the fresh filter and leaves the all-floor set, the others follow one
+        for k, rv in enumerate([777] + rvs):
+            sc, o = scans[k], poses[k + 1]
+            res = opf.update(oracle.pose(*o, utime=sc.utime), sc, cells, m["mpc"], helpers.CPM_DEFAULT, m["origin"], rv)
+            odo = bl.make_pose(*o, utime=sc.utime)
+            if riding:
+                pf.updateBegin(odo, sc, g, rv, noise=res["noise"])
+                mapper.updateMapFinishingFilter(sc, pf, sc.utime, g)
+                g.upload(cells)                                   # (the map stays unknown: only the filter is under test)
+                pose = pf.poseEstimate()
+            else:
+                pose = pf.updateFilter(odo, sc, g, rand_value=rv, noise=res["noise"])
+            if not res["moved"]:
+                continue
+            moved += 1
+            idx, like = pf.debugLast()
+            assert not like.any()                                 # every likelihood 0: every weight at the floor
+            assert np.array_equal(idx, res["idx"]), (riding, k, rv, int(np.count_nonzero(idx != res["idx"])))
+            got, exp = pf.particles(), opf.particles()
+            for f in ("x", "y", "theta", "p_x", "p_y", "p_theta"):
+                assert np.array_equal(got[f], exp[f]), (riding, k, f)
+            assert (np.float32(pose.x), np.float32(pose.y), np.float32(pose.theta)) == (np.float32(res["pose"].x), np.float32(res["pose"].y), np.float32(res["pose"].theta))
+            assert pf.debugUniformRuns() > 0, (riding, k)      # ... and the set it leaves is recognised again
+        assert moved == len(rvs)
+        pf.close(); g.close()
+
+
+def test_ordinary_weights_leave_no_uniform_runs(oracle, maps, gpu_ctx):
+    """... and an update on a real map does not: the prefix search stays in force (one compare and one store is all the recognition costs)."""
+    import helpers
+    from botlab_amd import synth
+    m = maps["obstacle_slam_10mx10m_5cm"]
+    truth = np.where(m["cells"] > 0, 127, -127).astype(np.int8)
+    g = bl.OccupancyGrid.from_cells(m["cells"], m["origin"], m["mpc"], cellsPerMeter=helpers.CPM_DEFAULT, ctx=gpu_ctx)
+    poses = synth.square_trajectory((-0.75, 0.2, 0.0), 4, step_len=0.02, turn=0.05, side=0.8)
+    pf = bl.ParticleFilter(20_000, ctx=gpu_ctx)
+    pf.initializeFilterAtPose(bl.make_pose(-0.75, 0.2, 0.0, utime=1_000_000), seed=3)
+    assert pf.debugUniformRuns() > 0
+    for k in range(1, 4):
+        sc = synth.raycast_scan(truth, m["origin"], 0.05, poses[k - 1], poses[k], 1_000_000 + k * 100_000)
+        pf.updateFilter(bl.make_pose(*poses[k], utime=sc.utime), sc, g, rand_value=99 + k)
+    assert pf.debugUniformRuns() == 0
+    pf.close(); g.close()

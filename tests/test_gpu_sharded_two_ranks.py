@@ -137,6 +137,9 @@ def test_two_ranks_one_device_match_single_rank(tmp_path, riding):
         assert np.array_equal(g1, np.load(os.path.join(out, f"grid_w2_r{r}.npy")))      # the replicated map stays identical
 
 
+UNKNOWN_RANDS = [5, 0, 2147483647, 1, 1000, 0]      # rand() values that put every U_m on a partial sum of equal weights
+
+
 def _run_inproc(_unused_rank, world, out_dir, n, steps):
     """`world` ranks of the composed finish with the peer-store exchange inside ONE process (the GPU box admits six processes on its
     card; eight ranks need another arrangement): every rank is its own ctx + stream + filter + map, ranks hand each other their raw
@@ -158,8 +161,10 @@ def _run_inproc(_unused_rank, world, out_dir, n, steps):
     assert sharded.composed_possible(n, world)
     engs = [sharded.HipShardEngine(n, r, world, 0, composed=True) for r in range(world)]
     lib = engs[0].ctx.lib
-    grids = [bl.OccupancyGrid.from_cells(m["cells"], m["origin"], m["mpc"], cellsPerMeter=helpers.CPM_DEFAULT, ctx=e.ctx) for e in engs]
-    mappers = [bl.Mapping(5.0, 4, 1, ctx=e.ctx) for e in engs]
+    unknown = bool(os.environ.get("SHARD_TEST_UNKNOWN_MAP"))           # a map that knows nothing, never updated: every weight at the floor
+    cells0 = np.zeros_like(m["cells"]) if unknown else m["cells"]
+    grids = [bl.OccupancyGrid.from_cells(cells0, m["origin"], m["mpc"], cellsPerMeter=helpers.CPM_DEFAULT, ctx=e.ctx) for e in engs]
+    mappers = [bl.Mapping(5.0, 0 if unknown else 4, 0 if unknown else 1, ctx=e.ctx) for e in engs]
     for e in engs:
         e.init_at_pose(bl.make_pose(*start, utime=int(scans[0].times[0])), 21)
         e.shard_setup()
@@ -183,7 +188,8 @@ def _run_inproc(_unused_rank, world, out_dir, n, steps):
     est = [[] for _ in engs]
     for k, sc in enumerate(scans):
         odo = bl.make_pose(*poses[k + 1], utime=sc.utime)
-        moved = [e.begin(odo, sc, g, 900 + k) for e, g in zip(engs, grids)]
+        rv = UNKNOWN_RANDS[k % len(UNKNOWN_RANDS)] if unknown else 900 + k
+        moved = [e.begin(odo, sc, g, rv) for e, g in zip(engs, grids)]
         assert len(set(moved)) == 1
         if moved[0]:
             for phase in range(3):
@@ -221,12 +227,14 @@ def _run_single(_unused_rank, out_dir, n, steps):
     scans = [synth.raycast_scan(truth, m["origin"], 0.05, poses[k - 1], poses[k], 1_000_000 + k * 100_000) for k in range(1, steps + 1)]
     eng = sharded.HipShardEngine(n, 0, 1, 0)
     spf = sharded.ShardedParticleFilter(eng)
-    grid = bl.OccupancyGrid.from_cells(m["cells"], m["origin"], m["mpc"], cellsPerMeter=helpers.CPM_DEFAULT, ctx=eng.ctx)
-    mapper = bl.Mapping(5.0, 4, 1, ctx=eng.ctx)
+    unknown = bool(os.environ.get("SHARD_TEST_UNKNOWN_MAP"))
+    cells0 = np.zeros_like(m["cells"]) if unknown else m["cells"]
+    grid = bl.OccupancyGrid.from_cells(cells0, m["origin"], m["mpc"], cellsPerMeter=helpers.CPM_DEFAULT, ctx=eng.ctx)
+    mapper = bl.Mapping(5.0, 0 if unknown else 4, 0 if unknown else 1, ctx=eng.ctx)
     spf.initializeFilterAtPose(bl.make_pose(*start, utime=int(scans[0].times[0])), seed=21)
     est = []
     for k, sc in enumerate(scans):
-        p = spf.updateFilter(bl.make_pose(*poses[k + 1], utime=sc.utime), sc, grid, 900 + k)
+        p = spf.updateFilter(bl.make_pose(*poses[k + 1], utime=sc.utime), sc, grid, UNKNOWN_RANDS[k % len(UNKNOWN_RANDS)] if unknown else 900 + k)
         mapper.updateMapDevicePose(sc, eng.pf.poseDevicePtr(), sc.utime, grid)
         est.append((p.utime, p.x, p.y, p.theta))
     np.save(os.path.join(out_dir, "grid_w1_r0.npy"), grid.cells())
@@ -262,6 +270,26 @@ def test_eight_ranks_peer_store_exchange_match_single_rank(tmp_path, n, steps):
         assert sent < n * 16 * (world - 1) // world             # less than the replicated form receives ((world - 1) / world x N x 16 B); 1M: 1/16 of it
         if n >= 1_000_000:
             assert sent < n * 16 // 16
+    assert np.concatenate(got).tobytes() == one.tobytes()
+
+
+def test_eight_ranks_all_floor_weights_match_single_rank(tmp_path, monkeypatch):
+    """Equal weights on composed shards: a fresh filter's 1 / N and the all-floor set an update on an unknown map leaves are resampled
+    against the runs of the reference's rounded cumulative on every rank (the launch that writes the total forms them; they need no
+    particle data) -- eight ranks equal the single rank bit for bit for rand() = 0, RAND_MAX, 1, 1000 (the single rank is held against
+    the oracle in tests/test_gpu_resample_sweep.py)."""
+    import torch.multiprocessing as mp
+    monkeypatch.setenv("SHARD_TEST_UNKNOWN_MAP", "1")
+    out = str(tmp_path)
+    world, n, steps = 8, 100_000, 6
+    mp.spawn(_run_single, args=(out, n, steps), nprocs=1, join=True)
+    mp.spawn(_run_inproc, args=(world, out, n, steps), nprocs=1, join=True)
+    one = np.load(os.path.join(out, "parts_w1_r0.npy"))
+    e1 = np.load(os.path.join(out, "est_w1_r0.npy"))
+    got = []
+    for r in range(world):
+        got.append(np.load(os.path.join(out, f"parts_w{world}_r{r}.npy")))
+        assert e1.tobytes() == np.load(os.path.join(out, f"est_w{world}_r{r}.npy")).tobytes(), f"rank {r}: estimates differ"
     assert np.concatenate(got).tobytes() == one.tobytes()
 
 
