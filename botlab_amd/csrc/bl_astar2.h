@@ -27,6 +27,7 @@
 #include "bl_astar2_turbo.h"
 #include "bl_astar2_deep.h"
 #include "bl_astar2_duo.h"
+#include "bl_astar2_ahead.h"
 
 #define A2_COSTN 256
 #define A2_INF 0xFFFFu
@@ -111,6 +112,8 @@ __device__ __forceinline__ void a2_wait_vm4(unsigned& x, unsigned& y, unsigned& 
 
 // BOTLAB_ASTAR_NO_TURBO=1 (read by the host, astar_launch_kernel): the C++ loop everywhere (tests, A/B runs)
 __device__ bool a2_turbo_enabled = true;
+__device__ bool a2_walk_ahead_enabled = false;    // two-wave loop: the next pop's walk beside the pushes (bl_astar2_ahead.h) instead of bl_astar2_duo.h's split; BOTLAB_ASTAR_AHEAD=1
+                                                  // (measured at 0.720 us per pop against 0.712: both waves are busy, neither shorter -- DESIGN.md section 7)
 
 // per-lane constants of the wave-parallel heap operations
 struct a2_lanes {
@@ -666,8 +669,20 @@ __global__ __launch_bounds__(128) void k_astar2(astar_args a)
     }
     // ---- two wavefronts: the second runs the expansions of the LDS-regime loop until the first says QUIT (bl_astar2_duo.h)
     const bool duo = turbo && blockDim.x == 128u;
+    const bool walk_ahead = duo && a2_walk_ahead_enabled;
     if (wave == 1) {
-        if (duo) {
+        if (walk_ahead) {
+            if (ahead) asm volatile(A2A_BODY_EXPUSH(A2T_PREFETCH, "4", "3")
+                         :: [tbl] "s"(__builtin_amdgcn_readfirstlane((int)tbl)), [kmax] "n"(C::KEY_BYTES - 4), [pln] "n"(C::PLN),
+                            [ok0lo] "n"((unsigned)(((2ull << ((1 << (C::FD + 1)) - 2)) - 1ull) & 0xffffffffull)),
+                            [ok0hi] "n"((unsigned)(((2ull << ((1 << (C::FD + 1)) - 2)) - 1ull) >> 32))
+                         : A2A_EXPUSH_CLOBBERS);
+            else asm volatile(A2A_BODY_EXPUSH("", "2", "1")
+                         :: [tbl] "s"(__builtin_amdgcn_readfirstlane((int)tbl)), [kmax] "n"(C::KEY_BYTES - 4), [pln] "n"(C::PLN),
+                            [ok0lo] "n"((unsigned)(((2ull << ((1 << (C::FD + 1)) - 2)) - 1ull) & 0xffffffffull)),
+                            [ok0hi] "n"((unsigned)(((2ull << ((1 << (C::FD + 1)) - 2)) - 1ull) >> 32))
+                         : A2A_EXPUSH_CLOBBERS);
+        } else if (duo) {
             if (ahead) asm volatile(A2W_BODY_EXPAND(A2T_PREFETCH, "4")
                          :: [tbl] "s"(__builtin_amdgcn_readfirstlane((int)tbl)), [kmax] "n"(C::KEY_BYTES - 4), [pln] "n"(C::PLN),
                             [ok0lo] "n"((unsigned)(((2ull << ((1 << (C::FD + 1)) - 2)) - 1ull) & 0xffffffffull)),
@@ -705,7 +720,13 @@ __global__ __launch_bounds__(128) void k_astar2(astar_args a)
             unsigned s_len = (unsigned)__builtin_amdgcn_readfirstlane((int)len), s_pops = (unsigned)__builtin_amdgcn_readfirstlane((int)pops);
             unsigned s_pushes = (unsigned)__builtin_amdgcn_readfirstlane((int)pushes);
             // (grids whose distance + closed arrays fit the L2 gain nothing from asking for lines ahead)
-            if (duo) asm volatile(A2W_BODY_HEAP
+            if (walk_ahead) asm volatile(A2A_BODY_POP
+                         : [len] "+s"(s_len), [pops] "+s"(s_pops), [pushes] "+s"(s_pushes), [code] "=&s"(code), [gm] "=&s"(gm), [pt] "=&s"(ptop)
+                         : [tbl] "s"(__builtin_amdgcn_readfirstlane((int)tbl)), [kmax] "n"(C::KEY_BYTES - 4), [pln] "n"(C::PLN),
+                           [ok0lo] "n"((unsigned)(((2ull << ((1 << (C::FD + 1)) - 2)) - 1ull) & 0xffffffffull)),
+                           [ok0hi] "n"((unsigned)(((2ull << ((1 << (C::FD + 1)) - 2)) - 1ull) >> 32))
+                         : A2A_POP_CLOBBERS);
+            else if (duo) asm volatile(A2W_BODY_HEAP
                          : [len] "+s"(s_len), [pops] "+s"(s_pops), [pushes] "+s"(s_pushes), [code] "=&s"(code), [gm] "=&s"(gm), [pt] "=&s"(ptop)
                          : [tbl] "s"(__builtin_amdgcn_readfirstlane((int)tbl)), [kmax] "n"(C::KEY_BYTES - 4), [pln] "n"(C::PLN),
                            [ok0lo] "n"((unsigned)(((2ull << ((1 << (C::FD + 1)) - 2)) - 1ull) & 0xffffffffull)),
@@ -848,7 +869,13 @@ __global__ __launch_bounds__(128) void k_astar2(astar_args a)
     tr1 = __builtin_amdgcn_s_memrealtime();
     res.stamps[0] = (long long)acc_all; res.stamps[1] = (long long)acc_adj; res.stamps[2] = (long long)acc_nb;
     res.stamps[3] = (long long)(tr1 - tr0); res.stamps[4] = (long long)acc_wait; res.stamps[5] = (long long)acc_push;
-    if (duo) {
+    if (walk_ahead) {
+        // walk-ahead loop (bl_astar2_ahead.h): cycles inside the barriers -- wave 0 in B1 / B2 -> [0] / [1], wave 1 in B1 / B2 -> [2] / [4];
+        // walks taken again -> [5]; tops whose expansion had been made ahead | not -> path_off
+        const a2_lds_u32* sc = (const a2_lds_u32*)(size_t)(tbl + 4096u);
+        res.stamps[0] = sc[24]; res.stamps[1] = sc[26]; res.stamps[2] = sc[27]; res.stamps[4] = sc[28]; res.stamps[5] = sc[29];
+        res.path_off = (long long)sc[30] | ((long long)sc[31] << 32);
+    } else if (duo) {
         // two-wave loop: wave 0's cycles inside Y, X, Z; wave 1's inside X, Y (bl_astar2_duo.h).  Wave 1 adds its sums on its way out:
         // it has left by the time the barrier below is through... the sums it has added so far, then
         const a2_lds_u32* sc = (const a2_lds_u32*)(size_t)(tbl + 4096u);

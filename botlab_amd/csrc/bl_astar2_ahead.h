@@ -1,0 +1,442 @@
+// bl_astar2_ahead.h -- the LDS-regime search loop of k_astar2 on two wavefronts, with the NEXT pop's walk taken beside the pushes.
+//
+// std::pop_heap moves the hole from the root to a leaf along the smaller children (stl_heap.h __adjust_heap) BEFORE it looks at the
+// value it re-inserts: the walk depends on the heap alone, not on the entry from the back of the array.  So pop k + 1's walk can be
+// taken on the heap as pop k left it, while the other wavefront is still pushing expansion k's candidates -- as long as no decision
+// of the walk read a position those pushes wrote.  A push writes an ancestor line: its slot and the ancestors that drop a level, up
+// to the position t where the entry lands; the walk reads the two children of every node on its path; so a written position was read
+// exactly when parent(t) lies on the walk's path (if a deeper written position's parent were on the path, so would parent(t) be: the
+// path is closed under ancestors).  tests/tools/walk_ahead_model.py replays the reference's search on the astar fixtures with
+// libstdc++'s index operations: the early walk reads a written position in 0.1 % (5e5 pops) .. 2.8 % (1e4 - 4e4 pops) of the
+// iterations (a quarter of them in searches of ~1 000 pops: launch-bound anyway).  Such an iteration takes its walk again.
+//
+//     wave 0 (POP)     B1 | test, the entry at the back, climb, stores       | B2 | walk of the NEXT pop (reads only) ....................... | B1
+//     wave 1 (EXPUSH)  B1 | top, Z, "is it the top I expanded?", record      | B2 | pushes, where they landed, expansion of the top FORESEEN next | B1
+//
+// B1 / B2 are workgroup barriers; Z is bl_astar2_duo.h's flag (wave 1 has read the top: wave 0 may store).  The expansion a pop needs
+// is made an iteration AHEAD as well, for the top wave 1 foresees (the smaller child of the root, as bl_astar2_duo.h asks its loads
+// ahead: 99.5 % of the tops here), with the popped cell's closedList entry held back until the top is seen to be that entry.  Same
+// macros, same index operations in the same order as the one-wave loop (bl_astar2_turbo.h) and the two-wave loop without the early
+// walk (bl_astar2_duo.h): the open list goes through the same states (the fixtures run through all of them).
+//
+// MEASURED (profiles/r06_astar_walk_ahead_stamps.txt, maze 2: 13 693 pops, 1.86 pushes per pop): 0.720 us per pop against 0.712 for
+// bl_astar2_duo.h -- no gain, so it is OFF by default (BOTLAB_ASTAR_AHEAD=1).  The stamped build says why: the waves wait for each
+// other for only 185 + 165 cycles of an iteration of ~1 750: BOTH are busy for ~1 580 -- wave 0: ~700 from B1 to B2 (two LDS round
+// trips for the entry at the back and the record, the four tests, climb, gate, stores and their wait) + ~680 for the walk; wave 1:
+// ~440 + ~1 100 (a push is ~345 cycles, the expansion ahead ~450).  The split moves work beside work but adds two hand-overs, the
+// tests and the copies of the expansion made ahead: 3 160 cycles of work per pop where bl_astar2_duo.h has 2 750.  What would pay:
+// a THIRD wavefront for the expansions (then B1 -> B2 ~700, B2 -> B1 ~700: ~0.58 us per pop); DESIGN.md section 9.
+//
+// Hand-over (table words, record at tbl + 4096 + 128):
+//     32..35  wave 1 -> wave 0 before B2: push mask, goal mask, popped payload, -;  word 35 on (re-)entry wave 0 -> wave 1: the length
+//     36..38  wave 1 -> wave 0 before B1: per push max(landing node >> 1, 1) (1-based node index of the landing's parent; the root
+//             when the entry rose to the top: every walk has it), 0x7fffffff for "no push"
+//     44      run word: 1 go, 2 quit, 3 go and forget what you foresaw (wave 0 has been elsewhere; the length is in word 35), 4 park
+//     45      Z
+// Wave 0 leaves the loop at an iteration boundary only, behind a B1 it enters with the run word on "park": wave 1's pushes are in,
+// and wave 1 goes back to B1 and waits there (as it does at the kernel's start) until wave 0 comes back or says quit.
+#ifndef BL_ASTAR2_AHEAD_H
+#define BL_ASTAR2_AHEAD_H
+
+#define A2A_PARK 4u
+
+// the rounds of a pop's walk on a heap of s40 entries (the entry at the back already taken off): round data in v200-v203 / v205-v208 /
+// v240-v243, masks s[72:73] / s[74:75] / s[76:77]; s78 = 1 + the leaf the hole ends in.  Which rounds ran is a function of s40.
+#define A2A_WALK(L)                                                                                           \
+    "s_mov_b32 s78, 1\n\t"                                                                                    \
+    A2T_ROUND("v200", "v201", "v202", "v203", "s[72:73]", "s[62:63]", "")                                     \
+    "s_cmp_lt_u32 s40, s59\n\t"                                                                               \
+    "s_cbranch_scc1 " L "9f\n\t"                                                                              \
+    A2T_ROUND("v205", "v206", "v207", "v208", "s[74:75]", "s[64:65]", "")                                     \
+    "s_cmp_ge_u32 s40, s60\n\t"                                                                               \
+    "s_cbranch_scc0 " L "9f\n\t"                                                                              \
+    A2T_ROUND("v240", "v241", "v242", "v243", "s[76:77]", "s[64:65]", "")                                     \
+    L "9:\n\t"
+
+// is the 1-based node A (an SGPR; 0x7fffffff: none) an ancestor-or-self of the walk's leaf s81 (1-based; s71 = its leading zeros)?
+// yes -> TAKEN.  (A deeper than the leaf: A > s81 >= s81 >> anything, never equal.)
+#define A2A_ON_PATH(A, TAKEN)                                                                                 \
+    "s_flbit_i32_b32 s70, " A "\n\t"                                                                          \
+    "s_sub_i32 s70, s70, s71\n\t"                                                                             \
+    "s_lshr_b32 s70, s81, s70\n\t"                                                                            \
+    "s_cmp_eq_u32 s70, " A "\n\t"                                                                             \
+    "s_cbranch_scc1 " TAKEN "\n\t"
+
+// ---------------------------------------------------------------------------------------------------------- wave 0: the pops
+#define A2A_BODY_POP                                                                                          \
+    "s_mov_b32 s40, %[len]\n\t"                                                                               \
+    "s_mov_b32 s41, %[pops]\n\t"                                                                              \
+    "s_mov_b32 s42, %[pushes]\n\t"                                                                            \
+    A2W_ENTRY                                                                                                 \
+    "s_mov_b32 s88, 0\n\t"                                                                                    \
+    "s_mov_b32 s80, 0\n\t"                                                                                    \
+    "s_mov_b32 s79, 0\n\t"                           /* no walk taken ahead */                                \
+    A2W_ACC_ZERO("s36") A2W_ACC_ZERO("s38") A2W_ACC_ZERO("s86")                                               \
+    "v_add_u32 v214, 4224, v191\n\t"                 /* the record */                                         \
+    "v_mov_b32 v216, 3\n\t"                          /* run word: "go, and forget what you foresaw" (this wave has been elsewhere) */ \
+    "v_mov_b32 v217, 1\n\t"                          /* ... "go" */                                           \
+    "v_mov_b32 v219, 0\n\t"                                                                                   \
+    "v_mov_b32 v225, 4\n\t"                          /* ... "park" */                                         \
+    "v_mov_b32 v224, s40\n\t"                                                                                 \
+    "s_mov_b64 exec, 1\n\t"                                                                                   \
+    "ds_write_b32 v214, v216 offset:48\n\t"                                                                   \
+    "ds_write_b32 v214, v224 offset:12\n\t"          /* the length, for the other wave */                     \
+    "s_mov_b64 exec, -1\n\t"                                                                                  \
+    /* ================================================================== one iteration */                    \
+    "1:\n\t"                                                                                                  \
+    "s_cmp_lg_u32 s88, 0\n\t"                        /* the last expansion reached the goal */                \
+    "s_cbranch_scc1 92f\n\t"                                                                                  \
+    "s_cmp_ge_u32 s41, s50\n\t"                                                                               \
+    "s_cbranch_scc1 93f\n\t"                                                                                  \
+    "s_add_i32 s70, s40, -2\n\t"                                                                              \
+    "s_cmp_gt_u32 s70, s58\n\t"                      /* len < 2 (wraps) or len - 2 > lim - 2 */               \
+    "s_cbranch_scc1 91f\n\t"                                                                                  \
+    "s_waitcnt lgkmcnt(0)\n\t"                                                                                \
+    A2W_TIMED_BARRIER("s36")                     /* B1: the pushes are in; the other wave takes the top from here */ \
+    "ds_read_b128 v[210:213], v214 offset:16\n\t"    /* where they landed */                                  \
+    /* ---- the entry at the back of the array (key v193, payload v197): the value the pop's sift-down places */ \
+    "s_lshl_b32 s70, s40, 1\n\t"                                                                              \
+    "v_mov_b32 v191, s70\n\t"                                                                                 \
+    "ds_read_u16 v193, v191\n\t"                                                                              \
+    "s_lshl_b32 s71, s40, 2\n\t"                                                                              \
+    "s_add_i32 s71, s71, s56\n\t"                                                                             \
+    "s_add_i32 s71, s71, -4\n\t"                                                                              \
+    "v_mov_b32 v195, s71\n\t"                                                                                 \
+    "ds_read_b32 v197, v195\n\t"                                                                              \
+    "s_add_i32 s40, s40, -1\n\t"                                                                              \
+    /* the slot the last entry leaves is "behind the heap" from here on */                                    \
+    "s_mov_b64 exec, 1\n\t"                                                                                   \
+    "ds_write_b16 v191, v176\n\t"                                                                             \
+    "s_mov_b64 exec, -1\n\t"                                                                                  \
+    "s_cmp_eq_u32 s79, 0\n\t"                                                                                 \
+    "s_cbranch_scc1 60f\n\t"                                                                                  \
+    /* ---- the walk taken ahead: did it read what the pushes wrote, or the entry that has just left? */      \
+    "s_waitcnt lgkmcnt(0)\n\t"                                                                                \
+    "v_readfirstlane_b32 s82, v210\n\t"                                                                       \
+    "v_readfirstlane_b32 s83, v211\n\t"                                                                       \
+    "v_readfirstlane_b32 s84, v212\n\t"                                                                       \
+    "s_add_i32 s85, s40, 1\n\t"                                                                               \
+    "s_lshr_b32 s85, s85, 1\n\t"                     /* parent of the node that entry held (1-based) */        \
+    "s_flbit_i32_b32 s71, s81\n\t"                                                                            \
+    A2A_ON_PATH("s82", "60f") A2A_ON_PATH("s83", "60f") A2A_ON_PATH("s84", "60f") A2A_ON_PATH("s85", "60f")   \
+    "61:\n\t"                                                                                                 \
+    /* ---- the climb and one pass of stores, by the number of rounds the walk had */                         \
+    "s_cmp_lt_u32 s40, s59\n\t"                                                                               \
+    "s_cbranch_scc1 20f\n\t"                                                                                  \
+    "s_cmp_ge_u32 s40, s60\n\t"                                                                               \
+    "s_cbranch_scc1 30f\n\t"                                                                                  \
+    /* two rounds */                                                                                          \
+    A2T_CLIMB("v206", "v207", "s[74:75]", "25f")                                                              \
+    "26:\n\t"                                                                                                 \
+    A2W_GATE_ASK                                                                                              \
+    A2T_ADDR("v200", "v204") A2T_ADDR("v205", "v209") A2T_LAND_ADDR                                           \
+    "s_waitcnt lgkmcnt(0)\n\t"                                                                                \
+    A2W_STORES_GATE("70")                                                                                     \
+    A2T_STORE("v200", "v204", "v202", "v203", "s[72:73]") A2T_STORE("v205", "v209", "v207", "v208", "s[74:75]") \
+    A2T_LAND_STORE                                                                                            \
+    /* ---- the pop is in: the other wave pushes, this one takes the next pop's walk */                       \
+    "40:\n\t"                                                                                                 \
+    "s_waitcnt lgkmcnt(0)\n\t"                                                                                \
+    A2W_TIMED_BARRIER("s38")                     /* B2 */                                                     \
+    "ds_read_b128 v[210:213], v214\n\t"              /* the expansion's outcome: push mask, goal mask, popped payload */ \
+    "s_add_i32 s41, s41, 1\n\t"                                                                               \
+    "s_mov_b32 s79, 0\n\t"                                                                                    \
+    "s_waitcnt lgkmcnt(0)\n\t"                                                                                \
+    "v_readfirstlane_b32 s87, v210\n\t"                                                                       \
+    "v_readfirstlane_b32 s88, v211\n\t"                                                                       \
+    "v_readfirstlane_b32 s80, v212\n\t"                                                                       \
+    "s_bcnt1_i32_b32 s70, s87\n\t"                                                                            \
+    "s_add_i32 s40, s40, s70\n\t"                    /* the length once the pushes are in */                  \
+    "s_add_i32 s42, s42, s70\n\t"                                                                             \
+    "s_cmp_lg_u32 s88, 0\n\t"                        /* the loop ends at the top of the next iteration: no walk */ \
+    "s_cbranch_scc1 1b\n\t"                                                                                   \
+    "s_cmp_ge_u32 s41, s50\n\t"                                                                               \
+    "s_cbranch_scc1 1b\n\t"                                                                                   \
+    "s_add_i32 s70, s40, -2\n\t"                                                                              \
+    "s_cmp_gt_u32 s70, s58\n\t"                                                                               \
+    "s_cbranch_scc1 1b\n\t"                                                                                   \
+    "s_add_i32 s40, s40, -1\n\t"                     /* (the walk's heap: without the entry at the back) */   \
+    A2A_WALK("5")                                                                                             \
+    "s_mov_b32 s81, s78\n\t"                                                                                  \
+    "s_add_i32 s40, s40, 1\n\t"                                                                               \
+    "s_mov_b32 s79, 1\n\t"                                                                                    \
+    "s_branch 1b\n\t"                                                                                         \
+    /* ================================================================== out of line */                      \
+    /* the walk, now: none was taken ahead, or the one taken read a position that has changed since */        \
+    "60:\n\t"                                                                                                 \
+    A2W_ACC_COUNT("s86")                                                                                      \
+    A2A_WALK("6")                                                                                             \
+    "s_branch 61b\n\t"                                                                                        \
+    /* one round */                                                                                           \
+    "20:\n\t"                                                                                                 \
+    A2T_CLIMB("v201", "v202", "s[72:73]", "21f")                                                              \
+    "22:\n\t"                                                                                                 \
+    A2W_GATE_ASK                                                                                              \
+    A2T_ADDR("v200", "v204") A2T_LAND_ADDR                                                                    \
+    "s_waitcnt lgkmcnt(0)\n\t"                                                                                \
+    A2W_STORES_GATE("75")                                                                                     \
+    A2T_STORE("v200", "v204", "v202", "v203", "s[72:73]")                                                     \
+    A2T_LAND_STORE                                                                                            \
+    "s_branch 40b\n\t"                                                                                        \
+    "21:\n\t"                                                                                                 \
+    A2T_RARE_ROOT("s[72:73]", "22b")                                                                          \
+    /* three rounds */                                                                                        \
+    "30:\n\t"                                                                                                 \
+    A2T_CLIMB("v241", "v242", "s[76:77]", "35f")                                                              \
+    "36:\n\t"                                                                                                 \
+    A2W_GATE_ASK                                                                                              \
+    A2T_ADDR("v200", "v204") A2T_ADDR("v205", "v209") A2T_ADDR("v240", "v244") A2T_LAND_ADDR                  \
+    "s_waitcnt lgkmcnt(0)\n\t"                                                                                \
+    A2W_STORES_GATE("78")                                                                                     \
+    A2T_STORE("v200", "v204", "v202", "v203", "s[72:73]") A2T_STORE("v205", "v209", "v207", "v208", "s[74:75]") \
+    A2T_STORE("v240", "v244", "v242", "v243", "s[76:77]")                                                     \
+    A2T_LAND_STORE                                                                                            \
+    "s_branch 40b\n\t"                                                                                        \
+    "35:\n\t"                                                                                                 \
+    A2T_RARE_UP("s[76:77]", "v206", "v207", "s[74:75]", "36b", "37")                                          \
+    A2T_RARE_UP("s[74:75]", "v201", "v202", "s[72:73]", "36b", "38")                                          \
+    A2T_RARE_ROOT("s[72:73]", "36b")                                                                          \
+    /* two rounds, the climb leaves the second */                                                             \
+    "25:\n\t"                                                                                                 \
+    A2T_RARE_UP("s[74:75]", "v201", "v202", "s[72:73]", "26b", "27")                                          \
+    A2T_RARE_ROOT("s[72:73]", "26b")                                                                          \
+    /* ---- exits: the other wave is parked behind the barrier (its pushes are in by then) */                 \
+    "91:\n\t"                                                                                                 \
+    "s_mov_b32 %[code], 1\n\t"                                                                                \
+    "s_branch 98f\n\t"                                                                                        \
+    "92:\n\t"                                                                                                 \
+    "s_mov_b32 %[code], 2\n\t"                                                                                \
+    "s_branch 98f\n\t"                                                                                        \
+    "93:\n\t"                                                                                                 \
+    "s_mov_b32 %[code], 3\n\t"                                                                                \
+    "98:\n\t"                                                                                                 \
+    "s_mov_b64 exec, 1\n\t"                                                                                   \
+    "ds_write_b32 v214, v225 offset:48\n\t"                                                                   \
+    "s_mov_b64 exec, -1\n\t"                                                                                  \
+    "s_waitcnt lgkmcnt(0)\n\t"                                                                                \
+    "s_barrier\n\t"                                                                                           \
+    "s_branch 99f\n\t"                                                                                        \
+    "94:\n\t"                                        /* the other wave's flag never came: no barrier would either */ \
+    "s_mov_b32 %[code], 4\n\t"                                                                                \
+    "99:\n\t"                                                                                                 \
+    "s_waitcnt lgkmcnt(0)\n\t"                                                                                \
+    A2W_ACC_OUT("s36", "4192") A2W_ACC_OUT("s38", "4200") A2W_ACC_OUT("s86", "4212")                          \
+    "s_mov_b32 %[len], s40\n\t"                                                                               \
+    "s_mov_b32 %[pops], s41\n\t"                                                                              \
+    "s_mov_b32 %[pushes], s42\n\t"                                                                            \
+    "s_mov_b32 %[gm], s88\n\t"                                                                                \
+    "s_mov_b32 %[pt], s80\n\t"
+
+#define A2A_POP_CLOBBERS A2T_CLOBBERS
+
+// ---------------------------------------------------------------------------------------------------------- wave 1: expansions and pushes
+// A2T_PUSH_REST, and where the entry landed: max(landing node >> 1, 1) into lane J of v167
+#define A2A_PUSH_REST(J)                                                                                      \
+    "s_ff1_i32_b32 s91, s87\n\t"                                                                              \
+    "s_add_i32 s70, s87, -1\n\t"                                                                              \
+    "s_and_b32 s87, s87, s70\n\t"                                                                             \
+    "v_readlane_b32 s89, v226, s91\n\t"                                                                       \
+    "s_waitcnt lgkmcnt(1)\n\t"                                                                                \
+    "s_nop 1\n\t"                                                                                             \
+    "v_cmp_lt_u32 vcc, s89, v234\n\t"                                                                         \
+    "s_not_b64 s[92:93], vcc\n\t"                                                                             \
+    "s_ff1_i32_b64 s70, s[92:93]\n\t"                                                                         \
+    "s_bfm_b64 s[92:93], s70, 0\n\t"                                                                          \
+    "s_lshr_b32 s70, s78, s70\n\t"                                                                            \
+    "s_lshr_b32 s39, s70, 1\n\t"                                                                              \
+    "s_max_u32 s39, s39, 1\n\t"                                                                               \
+    "v_writelane_b32 v167, s39, " J "\n\t"                                                                    \
+    "s_lshl_b32 s71, s70, 1\n\t"                                                                              \
+    "s_lshl_b32 s70, s70, 2\n\t"                                                                              \
+    "s_add_i32 s70, s70, s56\n\t"                                                                             \
+    "s_add_i32 s70, s70, -4\n\t"                                                                              \
+    "s_waitcnt lgkmcnt(0)\n\t"                                                                                \
+    "v_mov_b32 v232, s71\n\t"                                                                                 \
+    "v_mov_b32 v238, s70\n\t"                                                                                 \
+    "s_mov_b64 exec, s[92:93]\n\t"                                                                            \
+    "ds_write_b16 v236, v234\n\t"                                                                             \
+    "ds_write_b32 v237, v235\n\t"                                                                             \
+    "s_lshl_b64 exec, 1, s91\n\t"                    /* the entry itself: straight from the lane that holds it */ \
+    "ds_write_b16 v232, v226\n\t"                                                                             \
+    "ds_write_b32 v238, v227\n\t"                                                                             \
+    "s_mov_b64 exec, -1\n\t"                                                                                  \
+    "s_add_i32 s40, s40, 1\n\t"
+
+// A2T_EXPAND without its store: the closedList entry of the popped cell (address v214, value v218, lane mask -> s[72:73]) is left to
+// A2A_COMMIT -- the expansion below is made for a top that is only FORESEEN.
+#define A2A_EXPAND_NOSTORE(TAG)                                                                               \
+    "v_lshrrev_b32 v222, 3, v216\n\t"                                                                         \
+    "v_cmp_ne_u32 vcc, s48, v222\n\t"           /* not closed by this search (lane 4: the popped cell itself) */ \
+    "s_and_b64 s[72:73], vcc, s[96:97]\n\t"                                                                   \
+    "s_andn2_b64 s[92:93], s[94:95], s[96:97]\n\t"   /* neighbour lanes inside the grid */                    \
+    "s_and_b64 s[92:93], s[92:93], vcc\n\t"          /* ... and not closed */                                 \
+    "v_min_u32 v223, s49, v215\n\t"                                                                           \
+    "v_lshl_add_u32 v223, v223, 2, s57\n\t"                                                                   \
+    "ds_read_b32 v224, v223\n\t"                     /* isValid + get_oCost by the cell's L1 distance */      \
+    "v_cmp_ne_u32 vcc, 0xffff, v215\n\t"                                                                      \
+    "s_and_b64 s[92:93], s[92:93], vcc\n\t"                                                                   \
+    "s_and_b64 s[36:37], s[36:37], vcc\n\t"                                                                   \
+    "s_and_b64 s[36:37], s[36:37], s[94:95]\n\t"                                                              \
+    "s_andn2_b64 s[36:37], s[36:37], s[96:97]\n\t"   /* goal neighbours: in grid, lanes 0..3 */               \
+    "v_add_u32 v217, 0xffff8000, v192\n\t"           /* fCost of the popped entry */                          \
+    "s_waitcnt lgkmcnt(0)\n\t"                                                                                \
+    "v_cmp_ne_u32 vcc, 0x80000000, v224\n\t"         /* the cell is valid */                                  \
+    "s_and_b64 s[92:93], s[92:93], vcc\n\t"                                                                   \
+    "s_and_b64 s[36:37], s[36:37], vcc\n\t"                                                                   \
+    "v_add_u32 v225, v219, v224\n\t"                 /* hCost + oCost */                                      \
+    "v_sub_u32 v226, v217, v225\n\t"                 /* lane 4: gCost of the popped node */                   \
+    "s_nop 0\n\t"                                                                                             \
+    "v_readlane_b32 s86, v226, 4\n\t"                                                                         \
+    "s_add_i32 s86, s86, 0x800a\n\t"                 /* + 10 (get_gCost), + 32768 (key bias) */               \
+    "v_add_u32 v226, s86, v225\n\t"                  /* key of the neighbour's entry */                       \
+    "v_cmp_gt_u32 vcc, 0xffff, v226\n\t"             /* fNew < INT16_MAX (astar.cpp:103,124) */               \
+    "s_and_b64 s[92:93], s[92:93], vcc\n\t"                                                                   \
+    "s_mov_b32 s87, s92\n\t"                                                                                  \
+    "s_mov_b32 s88, s36\n\t"                                                                                  \
+    "s_cmp_eq_u32 s88, 0\n\t"                                                                                 \
+    "s_cbranch_scc1 " TAG "f\n\t"                                                                             \
+    "s_sub_i32 s70, 0, s88\n\t"                      /* neighbours before the goal neighbour only */          \
+    "s_and_b32 s70, s70, s88\n\t"                                                                             \
+    "s_add_i32 s70, s70, -1\n\t"                                                                              \
+    "s_and_b32 s87, s87, s70\n\t"                                                                             \
+    TAG ":\n\t"                                                                                               \
+    "v_readlane_b32 s75, v212, 4\n\t"                /* the cell this expansion closes */
+
+// the foreseen top of the NEXT iteration (the smaller child of the root as read at B1, of equal keys the right one: payload v150,
+// key v164) and the loads of its expansion, into (v160, v161)
+#define A2A_FORESEE                                                                                           \
+    "v_cmp_le_u32_sdwa vcc, v244, v244 src0_sel:WORD_1 src1_sel:WORD_0\n\t"                                   \
+    "v_min_u32_sdwa v164, v244, v244 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:WORD_1\n\t" \
+    "s_nop 3\n\t"                                                                                             \
+    "v_cndmask_b32 v150, v162, v163, vcc\n\t"                                                                 \
+    A2W_NBR2_TO("v160", "v161")
+
+// One iteration.  The expansion a pop needs is made one iteration AHEAD, for the top the wave foresees (bl_astar2_duo.h: right for
+// 95 - 99.5 % of the tops), behind the pushes and beside the other wave's walk: key v192 / payload v196 of the entry it is for, the
+// candidates' keys v226 / payloads v227, push mask s87, goal mask s88, and its closedList entry not stored yet (s[72:73], v214, v218,
+// cell s75); s74 = "there is one".  At B1 the top really there is compared with it: the same entry (payload and key) -> the entry is
+// stored and the record goes out at once; another (or none foreseen: wave 0 has been elsewhere) -> the expansion is made now, from
+// loads asked for now (v158, v159).  v169 = the record's address, v168 = the lane's word of "where the pushes landed" (lanes 0..3).
+#define A2A_XBODY(PREFETCH, VMWAIT, SPECWAIT)                                                                           \
+    "10:\n\t"                                                                                                 \
+    A2W_TIMED_BARRIER("s41")                     /* B1: the heap is final */                                  \
+    "ds_read_b32 v240, v169 offset:48\n\t"           /* the run word */                                       \
+    "ds_read_b32 v241, v177\n\t"                     /* the top: payload, key */                              \
+    "ds_read_u16 v246, v190\n\t"                                                                              \
+    "ds_read_b32 v244, v165\n\t"                     /* the root's children: keys (slots 2, 3), payloads (entries 1, 2) */ \
+    "ds_read_b64 v[162:163], v177 offset:4\n\t"                                                               \
+    "ds_read_b32 v242, v169 offset:12\n\t"           /* the length (of use behind run word 3 only) */         \
+    "s_waitcnt lgkmcnt(0)\n\t"                                                                                \
+    "v_readfirstlane_b32 s70, v240\n\t"                                                                       \
+    "s_cmp_eq_u32 s70, 2\n\t"                                                                                 \
+    "s_cbranch_scc1 99f\n\t"                                                                                  \
+    "s_cmp_eq_u32 s70, 4\n\t"                        /* parked: the other wave is elsewhere */                \
+    "s_cbranch_scc1 10b\n\t"                                                                                  \
+    "s_mov_b64 exec, 1\n\t"                      /* Z: the top and the children have been read -- wave 0 may store */ \
+    "ds_write_b32 v169, v170 offset:52\n\t"                                                                   \
+    "s_mov_b64 exec, -1\n\t"                                                                                  \
+    "s_cmp_eq_u32 s70, 3\n\t"                        /* wave 0 has been elsewhere: what was foreseen is void, the length is its */ \
+    "s_cbranch_scc0 14f\n\t"                                                                                  \
+    "v_readfirstlane_b32 s40, v242\n\t"                                                                       \
+    "s_branch 13f\n\t"                                                                                        \
+    "14:\n\t"                                                                                                 \
+    "s_cmp_eq_u32 s74, 0\n\t"                                                                                 \
+    "s_cbranch_scc1 13f\n\t"                                                                                  \
+    "v_readfirstlane_b32 s70, v241\n\t"                                                                       \
+    "v_readfirstlane_b32 s71, v196\n\t"                                                                       \
+    "s_cmp_eq_u32 s70, s71\n\t"                                                                               \
+    "s_cbranch_scc0 13f\n\t"                                                                                  \
+    "v_readfirstlane_b32 s70, v246\n\t"                                                                       \
+    "v_readfirstlane_b32 s71, v192\n\t"                                                                       \
+    "s_cmp_eq_u32 s70, s71\n\t"                                                                               \
+    "s_cbranch_scc1 11f\n\t"                                                                                  \
+    "13:\n\t"                                      /* not the foreseen top: its expansion now */              \
+    A2W_ACC_COUNT("s81")                                                                                      \
+    "v_mov_b32 v196, v241\n\t"                                                                                \
+    "v_mov_b32 v192, v246\n\t"                                                                                \
+    A2W_NBR_ADDR                                                                                              \
+    "global_load_ushort v158, v213, s[52:53]\n\t"                                                             \
+    "global_load_dword v159, v214, s[54:55] sc1\n\t"                                                          \
+    A2A_FORESEE                                                                                               \
+    PREFETCH                                                                                                  \
+    A2T_FILL0                                                                                                 \
+    "s_waitcnt vmcnt(" VMWAIT ")\n\t"              /* (what has just been asked for for the next top stays under way) */ \
+    "v_mov_b32 v215, v158\n\t"                                                                                \
+    "v_mov_b32 v216, v159\n\t"                                                                                \
+    "v_cmp_eq_u32 vcc, s84, v212\n\t"                /* the cell the last expansion closed: closed */         \
+    "s_nop 3\n\t"                                                                                             \
+    "v_cndmask_b32 v216, v216, v166, vcc\n\t"                                                                 \
+    A2A_EXPAND_NOSTORE("15")                                                                                  \
+    "s_branch 12f\n\t"                                                                                        \
+    "11:\n\t"                                      /* the foreseen top: its expansion has been made */        \
+    A2W_ACC_COUNT("s79")                                                                                      \
+    A2A_FORESEE                                                                                               \
+    PREFETCH                                                                                                  \
+    "12:\n\t"                                                                                                 \
+    "s_mov_b64 exec, s[72:73]\n\t"                                                                            \
+    "global_store_dword v214, v218, s[54:55]\n\t"    /* closedList.push_back: the first entry per cell is the one observed */ \
+    "s_mov_b64 exec, -1\n\t"                                                                                  \
+    "s_mov_b32 s84, s75\n\t"                                                                                  \
+    "v_mov_b32 v230, s87\n\t"                                                                                 \
+    "v_mov_b32 v231, s88\n\t"                                                                                 \
+    "v_mov_b32 v232, v196\n\t"                                                                                \
+    "v_mov_b32 v233, 0\n\t"                                                                                   \
+    "s_mov_b64 exec, 1\n\t"                                                                                   \
+    "ds_write_b128 v169, v[230:233]\n\t"                                                                      \
+    "s_mov_b64 exec, -1\n\t"                                                                                  \
+    "s_waitcnt lgkmcnt(0)\n\t"                                                                                \
+    A2W_TIMED_BARRIER("s42")                     /* B2: the pop is in */                                      \
+    "s_add_i32 s40, s40, -1\n\t"                                                                              \
+    "v_mov_b32 v167, 0x7fffffff\n\t"                                                                          \
+    A2T_PUSH_CHECK("17f") A2T_PUSH_READ A2A_PUSH_REST("0")                                                    \
+    A2T_PUSH_CHECK("17f") A2T_PUSH_READ A2A_PUSH_REST("1")                                                    \
+    A2T_PUSH_CHECK("17f") A2T_PUSH_READ A2A_PUSH_REST("2")                                                    \
+    "17:\n\t"                                                                                                 \
+    "s_mov_b64 exec, 15\n\t"                                                                                  \
+    "ds_write_b32 v168, v167\n\t"                                                                             \
+    "s_mov_b64 exec, -1\n\t"                                                                                  \
+    /* ---- the expansion of the top foreseen for the next iteration, from the loads asked for at B1 */       \
+    "v_mov_b32 v196, v150\n\t"                                                                                \
+    "v_mov_b32 v192, v164\n\t"                                                                                \
+    "v_mov_b32 v228, v151\n\t"                                                                                \
+    "v_mov_b32 v229, v152\n\t"                                                                                \
+    "v_mov_b32 v210, v153\n\t"                                                                                \
+    "v_mov_b32 v211, v154\n\t"                                                                                \
+    "v_mov_b32 v212, v155\n\t"                                                                                \
+    "v_mov_b32 v213, v156\n\t"                                                                                \
+    "v_mov_b32 v214, v157\n\t"                                                                                \
+    "s_mov_b64 s[94:95], s[82:83]\n\t"                                                                        \
+    A2T_FILL0                                                                                                 \
+    "s_waitcnt vmcnt(" SPECWAIT ")\n\t"          /* (the lines asked for ahead and the closedList entry's store may be under way) */ \
+    "v_mov_b32 v215, v160\n\t"                                                                                \
+    "v_mov_b32 v216, v161\n\t"                                                                                \
+    "v_cmp_eq_u32 vcc, s84, v212\n\t"                /* the cell the last expansion closed: closed */         \
+    "s_nop 3\n\t"                                                                                             \
+    "v_cndmask_b32 v216, v216, v166, vcc\n\t"                                                                 \
+    A2A_EXPAND_NOSTORE("16")                                                                                  \
+    "s_mov_b32 s74, 1\n\t"                                                                                    \
+    "s_waitcnt lgkmcnt(0)\n\t"                                                                                \
+    "s_branch 10b\n\t"
+
+#define A2A_BODY_EXPUSH(PREFETCH, VMWAIT, SPECWAIT)                                                                    \
+    A2W_ENTRY                                                                                                 \
+    "s_mov_b32 s40, 0\n\t"                                                                                    \
+    "s_mov_b32 s74, 0\n\t"                           /* no expansion made ahead */                            \
+    A2W_ACC_ZERO("s41") A2W_ACC_ZERO("s42") A2W_ACC_ZERO("s79") A2W_ACC_ZERO("s81")                           \
+    "v_mov_b32 v190, 2\n\t"                                                                                   \
+    "v_mov_b32 v165, 4\n\t"                                                                                   \
+    "v_add_u32 v169, 4224, v191\n\t"                 /* the record */                                         \
+    "v_min_u32 v168, 3, v188\n\t"                                                                             \
+    "v_lshl_add_u32 v168, v168, 2, v169\n\t"                                                                  \
+    "v_add_u32 v168, 16, v168\n\t"                   /* the lane's word of where the pushes landed (lanes 0..3) */ \
+    "v_mov_b32 v166, s51\n\t"                        /* a closed entry of this search */                      \
+    "v_mov_b32 v170, 1\n\t"                                                                                   \
+    "s_mov_b32 s84, -1\n\t"                          /* no cell closed */                                     \
+    A2A_XBODY(PREFETCH, VMWAIT, SPECWAIT)                                                                             \
+    "99:\n\t"                                                                                                 \
+    A2W_ACC_OUT("s41", "4204") A2W_ACC_OUT("s42", "4208") A2W_ACC_OUT("s79", "4216") A2W_ACC_OUT("s81", "4220") \
+    "s_waitcnt vmcnt(0)\n\t"
+
+#define A2A_EXPUSH_CLOBBERS A2W_EXPAND_CLOBBERS, "v164", "v167", "v168", "v169", "v170", "v246"
+
+#endif

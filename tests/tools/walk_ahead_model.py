@@ -49,8 +49,10 @@ def run(name, case, radius=0.1, cells=None, origin=None, mpc=None, start=None, g
     exp, est = orc.search(orc.pose(*start, 0.0), orc.pose(*goal, 0.0), dist, mpc, cpm, origin, radius, maxd)
     H, W = dist.shape
     f = np.float32
-    ex = int((float(goal[0]) - float(origin[0])) * float(cpm)); ey = int((float(goal[1]) - float(origin[1])) * float(cpm))
-    sx = int((float(start[0]) - float(origin[0])) * float(cpm)); sy = int((float(start[1]) - float(origin[1])) * float(cpm))
+    def cell_of(v, o):                               # global_position_to_grid_cell on the pose's FLOAT coordinate (grid_utils.hpp:33-38)
+        return int((float(f(v)) - float(f(o))) * float(f(cpm)))
+    ex, ey = cell_of(goal[0], origin[0]), cell_of(goal[1], origin[1])
+    sx, sy = cell_of(start[0], origin[0]), cell_of(start[1], origin[1])
     valid = dist > np.float64(radius) * 1.000001
     ocost = np.zeros((H, W), np.int64)
     band = (dist > radius) & (dist < maxd)
@@ -98,6 +100,7 @@ def run(name, case, radius=0.1, cells=None, origin=None, mpc=None, start=None, g
                 continue
             if kx == ex and ky == ey:
                 done = True
+                pushes += len(new)                           # (the neighbours in front of the goal neighbour were pushed: astar.cpp:117-129)
                 break
             if closed[ky, kx]:
                 continue
@@ -139,5 +142,5 @@ def run(name, case, radius=0.1, cells=None, origin=None, mpc=None, start=None, g
 
 
 if __name__ == "__main__":
-    for name, case in (("maze", 0), ("maze", 2), ("maze", 1), ("narrow", 0), ("wide", 1), ("wide", 2)):
+    for name, case in (("maze", 0), ("maze", 2), ("maze", 1), ("narrow", 0), ("narrow", 1), ("wide", 1), ("wide", 2), ("convex", 0)):
         run(name, case)
