@@ -588,7 +588,13 @@ __device__ __forceinline__ bool resample_reaches(double T, unsigned long long v,
     return strict ? T <= __longlong_as_double((long long)v) : T <= (double)v;
 }
 
-template <class Prefix>
+// Q probes per lane and search in a round: 64 Q probes narrow a range by that factor per dependent round trip.  Measured at 100 000
+// particles (round 6, profiles/r06_mcl_timeline.txt): Q = 8 -- two rounds instead of three -- has the bracket at 7.0 us after the
+// workgroup's entry where Q = 1 has it at 3.1: every one of the launch's 1 488 prologue waves probes the same positions in its first
+// round and different lines per lane in every round, so a round is bound by the L2's request rate (64 Q lines per wave and search),
+// not by its latency.  Q = 1 stands.
+#define MCL_BRACKET_Q 1
+template <int Q, class Prefix>
 __device__ __forceinline__ void resample_bracket(const Prefix& prefix, int N, double T, bool active,
                                                  int lane, int* out_lo, int* out_hi, bool strict = false)
 {
@@ -598,17 +604,33 @@ __device__ __forceinline__ void resample_bracket(const Prefix& prefix, int N, do
     const double T0 = readlane_f64(T, __ffsll((long long)act) - 1), T1 = readlane_f64(T, 63 - __clzll((long long)act));
     int lo0 = 0, hi0 = N - 1, lo1 = 0, hi1 = N - 1;
     for (int round = 0; round < 8 && (lo0 < hi0 || lo1 < hi1); ++round) {     // 64^8 entries: the cap only bounds the loop
-        const int step0 = (hi0 - lo0 + 64) >> 6, step1 = (hi1 - lo1 + 64) >> 6;
-        const unsigned long long v0 = prefix[kary_pos(lo0, hi0, step0, lane)];
-        const unsigned long long v1 = prefix[kary_pos(lo1, hi1, step1, lane)];
-        const unsigned long long b0 = __builtin_amdgcn_ballot_w64(resample_reaches(T0, v0, strict));
-        const unsigned long long b1 = __builtin_amdgcn_ballot_w64(resample_reaches(T1, v1, strict));
-        if (b0 == 0) lo0 = hi0;                                                // nothing reaches T: the clamp
-        else { const int f = __ffsll((long long)b0) - 1; const int nl = f ? kary_pos(lo0, hi0, step0, f - 1) + 1 : lo0; hi0 = kary_pos(lo0, hi0, step0, f); lo0 = nl; }
-        if (b1 == 0) lo1 = hi1;
-        else { const int f = __ffsll((long long)b1) - 1; const int nl = f ? kary_pos(lo1, hi1, step1, f - 1) + 1 : lo1; hi1 = kary_pos(lo1, hi1, step1, f); lo1 = nl; }
+        const int step0 = (hi0 - lo0 + 64 * Q) / (64 * Q), step1 = (hi1 - lo1 + 64 * Q) / (64 * Q);
+        unsigned long long v0[Q], v1[Q];
+#pragma unroll
+        for (int u = 0; u < Q; ++u) {                                          // probe k = 64 u + lane: ascending in (u, lane)
+            v0[u] = prefix[kary_pos(lo0, hi0, step0, 64 * u + lane)];
+            v1[u] = prefix[kary_pos(lo1, hi1, step1, 64 * u + lane)];
+        }
+        int f0 = -1, f1 = -1;                                                  // first probe that reaches T (-1: none)
+#pragma unroll
+        for (int u = Q - 1; u >= 0; --u) {
+            const unsigned long long b0 = __builtin_amdgcn_ballot_w64(resample_reaches(T0, v0[u], strict));
+            const unsigned long long b1 = __builtin_amdgcn_ballot_w64(resample_reaches(T1, v1[u], strict));
+            if (b0) f0 = 64 * u + __ffsll((long long)b0) - 1;
+            if (b1) f1 = 64 * u + __ffsll((long long)b1) - 1;
+        }
+        if (f0 < 0) lo0 = hi0;                                                 // nothing reaches T: the clamp
+        else { const int nl = f0 ? kary_pos(lo0, hi0, step0, f0 - 1) + 1 : lo0; hi0 = kary_pos(lo0, hi0, step0, f0); lo0 = nl; }
+        if (f1 < 0) lo1 = hi1;
+        else { const int nl = f1 ? kary_pos(lo1, hi1, step1, f1 - 1) + 1 : lo1; hi1 = kary_pos(lo1, hi1, step1, f1); lo1 = nl; }
     }
     if (lo0 == hi0 && lo1 == hi1) { *out_lo = lo0; *out_hi = lo1; }             // (else the full range stands)
+}
+template <class Prefix>
+__device__ __forceinline__ void resample_bracket(const Prefix& prefix, int N, double T, bool active,
+                                                 int lane, int* out_lo, int* out_hi, bool strict = false)
+{
+    resample_bracket<1>(prefix, N, T, active, lane, out_lo, out_hi, strict);
 }
 
 // second part: the lane's own bisection inside the bracket.  index(T) = first i with T <= prefix[i] (clamped by the bracket).
@@ -858,9 +880,12 @@ __global__ __launch_bounds__(BLOCK) void k_mcl_main(mcl_args a)
         if (pro_active) { rs_T = a.r + mp * a.M_inv; if (!a.strict && uni_n <= 0) rs_T *= a.state->S; }      // U (particle_filter.cpp:95), or U * S
         if (uni_n > 0) { }
         else if (a.sh) resample_bracket(pview, a.N, rs_T, pro_active, lane, &rs_lo, &rs_hi, a.strict != 0);
-        else resample_bracket(a.prefix, a.N, rs_T, pro_active, lane, &rs_lo, &rs_hi, a.strict != 0);
+        else resample_bracket<MCL_BRACKET_Q>(a.prefix, a.N, rs_T, pro_active, lane, &rs_lo, &rs_hi, a.strict != 0);
     }
     MCL_STAMP(5);                                                // the bracket is known
+    // (Round 6, measured and dropped: the bracket's entries -- usually ~100 -- brought into the wave's quarter of the particle table in
+    // ONE round trip and the lanes' searches run on LDS instead of seven or eight dependent loads each: prologue done at 6.4 us after
+    // the workgroup's entry against 6.3 -- those loads hit lines the last bracket round brought in; profiles/r06_mcl_timeline.txt.)
     if (pro_active) {
         if (a.resample && uni_n > 0) i = uni_search(a.state, uni_n, rs_T, a.N);
         else if (a.resample) i = a.sh ? resample_bisect(pview, rs_T, rs_lo, rs_hi, a.strict != 0) : resample_bisect(a.prefix, rs_T, rs_lo, rs_hi, a.strict != 0);
