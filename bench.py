@@ -998,6 +998,8 @@ def main():
                     ex_cv.wait()
         while explorer is not None and args.explore_mode != "newest-map" and explorer.pending():
             explore_fetch()
+        if goal_pose is not None and in_flight and not os.environ.get("BENCH_NO_FLUSH"):
+            aplanner.flush()                 # end of the scan stream: the batches still collecting go out beside the SLAM stream's last steps
         while in_flight:
             fetch()
         if goal_pose is None or last_pose[0] is None:

@@ -127,6 +127,7 @@ SIGNATURES = {
     "bl_planner_destroy": (None, [_vp]),
     "bl_planner_submit": (C.c_int, [_vp, _vp, _vp, _P(Pose), _P(SearchParams)]),
     "bl_planner_fetch": (C.c_int, [_vp, _vp, C.c_int, _P(C.c_int), _P(C.c_int64)]),
+    "bl_planner_flush": (C.c_int, [_vp]),
     "bl_planner_timing": (C.c_int, [_vp, C.c_int, _P(C.c_double), _P(C.c_double), _P(C.c_int64)]),
     "bl_planner_submit_with_map_update": (C.c_int, [_vp, _vp, _P(Lidar), _vp, C.c_int64, _vp, _P(Pose), _P(SearchParams)]),
     "bl_mapping_update_finishing_pf": (C.c_int, [_vp, _P(Lidar), _vp, C.c_int64, _vp]),

@@ -3412,6 +3412,21 @@ extern "C" int bl_planner_fetch(bl_planner* p, bl_pose_xyt_t* out_path, int cap,
     return rc;
 }
 
+// End of input: no further submission will come soon, so the batch every lane is collecting goes out as it is -- its distance grids
+// and searches then run beside the SLAM stream's remaining steps instead of behind the fetch that would have sent it off.
+extern "C" int bl_planner_flush(bl_planner* p)
+{
+    BL_CHECK_ARG(p != nullptr);
+    for (int l = 0; l < p->lanes; ++l) {
+        if (p->lane[l].filled == 0) continue;
+        bl_astar_state* st = p->lane[l].unit[0].ctx->astar;
+        if (st && st->launched != st->fetched) continue;       // (an earlier batch of the lane still holds its units' result slots: the fetch will send this one)
+        const int rc = planner_launch_lane(p, l);
+        if (rc) return rc;
+    }
+    return BL_OK;
+}
+
 extern "C" int bl_planner_timing(bl_planner* p, int on, double* dist_ms, double* astar_ms, int64_t* launches)
 {
     BL_CHECK_ARG(p != nullptr);

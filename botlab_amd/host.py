@@ -679,6 +679,10 @@ class AsyncPlanner:
         path = [Pose(p.utime, p.x, p.y, p.theta) for p in self._buf[:min(n.value, 4097)]]
         return (path, (stats[0], stats[1])) if return_stats else path
 
+    def flush(self):
+        """End of input: the batch every lane is still collecting goes out as it is (bl_planner_flush)."""
+        check(self.ctx.lib.bl_planner_flush(self.h))
+
     def timing(self, on=-1):
         d, a, n = C.c_double(), C.c_double(), C.c_int64()
         check(self.ctx.lib.bl_planner_timing(self.h, on, C.byref(d), C.byref(a), C.byref(n)))

@@ -275,6 +275,9 @@ void bl_planner_destroy(bl_planner* p);
 int bl_planner_submit(bl_planner* p, const bl_grid* map, const void* d_start_pose /* bl_pose_xyt_t* on the device */,
                       const bl_pose_xyt_t* goal, const bl_search_params_t* params);
 int bl_planner_fetch(bl_planner* p, bl_pose_xyt_t* out_path, int cap, int* out_len, int64_t* stats);
+/* End of input (the scan stream pauses, a run ends): sends off the batch every lane is still collecting, so that its work runs beside
+ * whatever the SLAM stream still holds instead of behind the fetch that would have sent it.  Results are fetched as ever. */
+int bl_planner_flush(bl_planner* p);
 /* on: -1 = just read; 0/1 = disable/enable(+reset) HIP-event timing of the planner stream's kernels (totals in ms) */
 int bl_planner_timing(bl_planner* p, int on, double* dist_ms, double* astar_ms, int64_t* launches);
 /* bl_mapping_update_dev_pose followed by bl_planner_submit(p, map, d_pose, goal, params) as one call: on grids up to

@@ -1,6 +1,6 @@
 """us per pop of single searches (time of bl_astar_search on the host, launch and fetch included) for the split-storage kernel
 (k_astar2: LDS loop, deep loop, C++ forms) and for round 4's k_astar (BOTLAB_ASTAR_V1=1), with the stamped build's cycle shares of
-the straight-line loop -> gpurun_out/profiles_new/r05_astar_pop.csv.  Searches: the four fixture searches of astar_probe.py (open
+the straight-line loop -> gpurun_out/profiles_new/r06_astar_pop.csv.  Searches: the four fixture searches of astar_probe.py (open
 lists of ~1e3, ~1.2e4, ~2.1e4 and ~2.4e5 entries) and convex case 2 (1.8e6 pops)."""
 import os, re, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -28,7 +28,7 @@ one, _ = run({"BOTLAB_ASTAR_DUO": "0"})
 v1, _ = run({"BOTLAB_ASTAR_V1": "1"})
 cpp, _ = run({"BOTLAB_ASTAR_NO_TURBO": "1", "BOTLAB_ASTAR_DUO": "0"})
 _, st2 = run({"STAMPS": "1", "BOTLAB_ASTAR_DUO": "0"})
-with open(os.path.join(OUT, "r05_astar_pop.csv"), "w") as f:
+with open(os.path.join(OUT, "r06_astar_pop.csv"), "w") as f:
     f.write("# python3 tests/tools/astar_pop_table.py (tests/tools/astar_probe.py per column; best of 3 host-timed calls of bl_astar_search)\n"
             "# k_astar2 = split-storage open list with the straight-line loops: two wavefronts in the LDS regime (bl_astar2_duo.h), one in the deep\n"
             "# loop (bl_astar2_deep.h); one_wave = BOTLAB_ASTAR_DUO=0 (bl_astar2_turbo.h: what the replanner's units run); cpp = the same kernel\n"
@@ -42,4 +42,4 @@ with open(os.path.join(OUT, "r05_astar_pop.csv"), "w") as f:
         s = st2[3 * i + 2] if 3 * i + 2 < len(st2) and r[1] <= 20000 else ("",) * 7      # (the deep loop carries no marks)
         f.write("%s,%d,%d,%.2f,%.3f,%s,%s,%s,%s,%s\n" % (r[0], r[1], r[2], r[3], r[4], "%.3f" % o[4] if o else "", "%.3f" % c[4] if c else "", "%.3f" % a[4] if a else "",
                                                     "%.2f" % (a[4] / r[4]) if a else "", ",".join(s)))
-print(open(os.path.join(OUT, "r05_astar_pop.csv")).read())
+print(open(os.path.join(OUT, "r06_astar_pop.csv")).read())

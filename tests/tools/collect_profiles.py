@@ -14,7 +14,7 @@ import sqlite3
 import subprocess
 import sys
 
-ROUND = "r05"
+ROUND = "r06"
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 OUT = os.path.join(ROOT, "gpurun_out", "profiles_new")
 os.makedirs(OUT, exist_ok=True)
