@@ -469,6 +469,7 @@ OTHER_CONFIGS = [                                      # (preset, goal_l1 in cel
     # closed-loop latency: every step's pose and path fetched before the next step is enqueued (slam.cpp:191-207 is synchronous per scan)
     (0, 0, ["--depth", "0", "--lanes", "1", "--batch", "1", "--sync-steps", "200"]),
     (4, 400, ["--depth", "0", "--lanes", "1", "--batch", "1", "--sync-steps", "200"]),
+    (4, 40, ["--depth", "0", "--lanes", "1", "--batch", "1", "--sync-steps", "200"]),      # ... with a replan to a goal 2 m away (~850 pops): the north star's 2000 x 2000 step, closed loop
 ]
 OTHER_BUDGET_S = 420.0                                 # wall clock all of them together may take: a slow or hung child costs the others, never the headline
 
@@ -647,6 +648,8 @@ def summary_of(out):
         s["closed_loop_ms"] = round(lat["headline"]["sync_ms_per_step"], 4)
     if "config4_goal400" in lat:
         s["config4_goal400_closed_loop_steps_s"] = round(lat["config4_goal400"]["sync_steps_per_s"], 1)
+    if "config4_goal40" in lat:
+        s["config4_goal40_closed_loop_steps_s"] = round(lat["config4_goal40"]["sync_steps_per_s"], 1)
     for r in out.get("other_configs") or []:
         if "error" in r:
             continue
