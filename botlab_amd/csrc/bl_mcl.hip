@@ -60,7 +60,7 @@ struct bl_pf {
     bool use_lds;
     int last_blocks, last_tile;   // launch shape of the last k_mcl_main
     int last_main_blocks, last_main_particles, last_tail_tile;
-    bool fused_finish, no_fused_finish, no_packed, no_balance, no_framed, no_window, no_fast_trig, no_mirror_reuse, no_stage_dma;
+    bool fused_finish, no_fused_finish, no_packed, no_balance, no_framed, no_window, no_fast_trig, no_mirror_reuse, no_stage_dma, no_stage_x4;
     int window_override;          // window side in cells (0: from the scan's reach)
     int cus;                      // compute units of the device
     int split_log2_override;  // -1: automatic
@@ -1522,6 +1522,7 @@ extern "C" int bl_pf_create(bl_ctx* ctx, int num_particles, int shard_lo, int sh
     pf->no_framed = getenv("BOTLAB_MCL_NO_FRAMED") != nullptr;
     pf->no_mirror_reuse = getenv("BOTLAB_MCL_NO_MIRROR_REUSE") != nullptr;
     pf->no_stage_dma = getenv("BOTLAB_MCL_NO_STAGE_DMA") != nullptr;
+    pf->no_stage_x4 = getenv("BOTLAB_MCL_NO_STAGE_X4") != nullptr;
     pf->no_window = getenv("BOTLAB_MCL_NO_WINDOW") != nullptr;
     pf->no_fast_trig = getenv("BOTLAB_MCL_NO_FAST_TRIG") != nullptr;
     pf->window_override = getenv("BOTLAB_MCL_WINDOW") ? atoi(getenv("BOTLAB_MCL_WINDOW")) : 0;
@@ -1874,8 +1875,7 @@ static int pf_launch_main(bl_pf* pf, const bl_grid* map, int R, int rand_value, 
             // grid in dwords (206 instructions of 200 bytes): the staging waves' loads were issue-bound, 35 per wave in 6 us
             // (profiles/r06_mcl_timeline.txt).  Needs the image to be whole 16-byte pieces and the map to live on this ctx's
             // stream (the copy is kept current by k_map_update there); BOTLAB_MCL_NO_STAGE_X4=1: the row form.
-            static const bool no_x4 = getenv("BOTLAB_MCL_NO_STAGE_X4") != nullptr;
-            if (!no_x4 && a.stage_dma && (whole & 15) == 0 && map->ctx == ctx && !map->mirror_external && !pf->no_framed && !pf->no_mirror_reuse) {
+            if (!pf->no_stage_x4 && a.stage_dma && (whole & 15) == 0 && map->ctx == ctx && !map->mirror_external && !pf->no_framed && !pf->no_mirror_reuse) {
                 int rc_m = ensure_mirror();
                 if (rc_m) return rc_m;
             }

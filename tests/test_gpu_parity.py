@@ -840,6 +840,54 @@ def test_large_grid_mirror_kept_current_by_map_updates(maps, gpu_ctx, side, form
     assert (out[0][1] != first).sum() > 1000                           # the map really changed
 
 
+@pytest.mark.parametrize("form", ["riding", "host_pose"])
+def test_whole_grid_staging_forms_agree(maps, gpu_ctx, form, monkeypatch):
+    """A 200 x 200 grid is staged whole in LDS by every workgroup of k_mcl_main: from the grid's zero-framed copy in 16-byte pieces
+    (round 6, the default: the copy is built once and kept current by the map updates), row by row from the grid itself by LDS-DMA
+    (BOTLAB_MCL_NO_STAGE_X4) or through registers (BOTLAB_MCL_NO_STAGE_DMA).  A SLAM loop gives the same particles, poses and map in
+    all three -- across map updates that change the cells the next scan scores and an upload that replaces them behind the copy's back."""
+    N = 6000
+    m = maps["obstacle_slam_10mx10m_5cm"]
+    truth = np.where(m["cells"] > 0, 127, -127).astype(np.int8)
+    first = m["cells"].copy()
+    first[:, 100:] = 0                                                  # half the map still unknown: the updates matter
+    poses = synth.square_trajectory((-0.75, 0.2, 0.0), 10, step_len=0.04, turn=0.1, side=0.6)
+    scans = [synth.raycast_scan(truth, m["origin"], 0.05, poses[k - 1], poses[k], 1_000_000 + k * 100_000) for k in range(1, len(poses))]
+    out = []
+    for env in ({}, {"BOTLAB_MCL_NO_STAGE_X4": "1"}, {"BOTLAB_MCL_NO_STAGE_DMA": "1"}):
+        with monkeypatch.context() as mp:
+            for k_, v_ in env.items():
+                mp.setenv(k_, v_)                                       # read when the filter is created
+            g = bl.OccupancyGrid.from_cells(first, m["origin"], m["mpc"], cellsPerMeter=helpers.CPM_DEFAULT, ctx=gpu_ctx)
+            pf = bl.ParticleFilter(N, ctx=gpu_ctx)
+            pf.initializeFilterAtPose(bl.make_pose(-0.75, 0.2, 0.0, utime=int(scans[0].times[0])), seed=5)
+            pf.setNoiseSeed(9)
+            mapper = bl.Mapping(5.0, 4, 1, ctx=gpu_ctx)
+            rec = []
+            for k, sc in enumerate(scans):
+                odo = bl.make_pose(*poses[k + 1], utime=sc.utime)
+                if k == 5:                                              # the cells are replaced behind the copy's back
+                    g.upload(np.where(m["cells"] > 0, 10, -5).astype(np.int8))
+                if form == "riding":
+                    pf.updateBegin(odo, sc, g, 1000 + k)
+                    mapper.updateMapFinishingFilter(sc, pf, sc.utime, g)
+                    pose = pf.poseEstimate()
+                else:
+                    pose = pf.updateFilter(odo, sc, g, rand_value=1000 + k)
+                    mapper.updateMap(sc, pose, g)
+                parts = pf.particles()
+                rec.append(((pose.x, pose.y, pose.theta), parts["x"].copy(), parts["y"].copy(), parts["theta"].copy(), parts["weight"].copy()))
+            out.append((rec, g.cells().copy()))
+            pf.close(); g.close()
+    for o in out[1:]:
+        assert np.array_equal(o[1], out[0][1])
+        for a_, b_ in zip(o[0], out[0][0]):
+            assert a_[0] == b_[0]
+            for u_, v_ in zip(a_[1:], b_[1:]):
+                assert np.array_equal(u_, v_)
+    assert (out[0][1] != first).sum() > 500                            # the map really changed
+
+
 @pytest.mark.parametrize("seed", [1, 2, 3, 4])
 def test_astar_random_maps_equal_oracle(oracle, gpu_ctx, seed):
     """search_for_path on seeded random worlds (blocks and walls on a 320 x 240 grid, robot radius 0.1 and 0.2): poses, pops and pushes
