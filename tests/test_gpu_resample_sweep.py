@@ -50,7 +50,7 @@ def _sweep(oracle, ctx, N, units, strict=False):
     return out
 
 
-@pytest.mark.parametrize("N", [4096, 100_000, 300_000])
+@pytest.mark.parametrize("N", [200, 4096, 100_000, 300_000])
 def test_resample_index_disagreements_are_counted_and_bounded(oracle, gpu_ctx, N):
     rng = np.random.default_rng(7 * N)
     report = {}
@@ -173,7 +173,7 @@ def test_strict_mode_with_the_filter_end_riding_in_the_map_kernel(maps, gpu_ctx)
         assert np.array_equal(a[4], b[4])
 
 
-@pytest.mark.parametrize("N", [4096, 100_000])
+@pytest.mark.parametrize("N", [200, 1000, 4096, 12_345, 100_000])            # (200: the reference's default particle count, slam_main.cpp:21)
 def test_all_floor_weights_are_resampled_as_the_reference_does(oracle, maps, gpu_ctx, N):
     """A lost filter: on a map that knows nothing (every cell 0) every particle's likelihood is 0, computeNormalizedPosterior
     (particle_filter.cpp:116-141) leaves N EQUAL weights 0.001 / wSum, and the next resampling compares U_m with partial sums that lie

@@ -85,7 +85,7 @@ def uni_search(segs, T, N):
     return i0 + k
 
 
-CASES = [(1.0 / 4096, 4096), (1.0 / 100000, 100000), (1.0 / 300000, 300000), (1.0 / 1000, 1000), (1.0 / 7, 7), (1.0 / 3, 3), (0.5, 2), (1.0, 1),
+CASES = [(1.0 / 200, 200), (0.001 / 0.20000000000000015, 200), (1.0 / 2, 2), (1.0 / 12345, 12345), (1.0 / 4096, 4096), (1.0 / 100000, 100000), (1.0 / 300000, 300000), (1.0 / 1000, 1000), (1.0 / 7, 7), (1.0 / 3, 3), (0.5, 2), (1.0, 1),
          (0.001, 100000), (0.001, 4096), (0.001 / 100.00000000000001, 100000), (2.0 ** -17, 1 << 17), (3.0 * 2.0 ** -19, 150000),
          # ties: w = (q + 1/2) ulp of the binade the sum runs through -- 1 + 2^-52 is (2^51 + 1/2) ulps of [2, 4)
          (1.0 + 2.0 ** -52, 5000), (1.0 + 3 * 2.0 ** -52, 5000), (2.0 ** -10 * (1.0 + 2.0 ** -52), 200000), (2.0 ** -10 * (1.0 + 7 * 2.0 ** -52), 200000)]
