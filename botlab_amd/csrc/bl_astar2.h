@@ -582,7 +582,7 @@ __global__ __launch_bounds__(64) void k_heap2_probe(const int* __restrict__ keys
 // Launched with 64 threads, or with 128: the second wavefront then runs the expansions of the LDS-regime loop beside the first
 // (bl_astar2_duo.h) and waits at a barrier whenever the first is anywhere else.
 template <class C>
-__global__ __launch_bounds__(128) void k_astar2(astar_args a)
+__global__ __launch_bounds__(192) void k_astar2(astar_args a)
 {
     if (a.units) {
         const astar_unit u = a.units[blockIdx.x];
@@ -662,16 +662,38 @@ __global__ __launch_bounds__(128) void k_astar2(astar_args a)
             sc[A2T_SC_GK] = (unsigned)(size_t)gk; sc[A2T_SC_GK + 1] = (unsigned)((size_t)gk >> 32);
             sc[A2T_SC_GP] = (unsigned)(size_t)gp; sc[A2T_SC_GP + 1] = (unsigned)((size_t)gp >> 32);
             sc[A2T_SC_DLIM] = deep_max - ((unsigned)C::PLN + 2u);                         // the deep loop runs while PLN + 2 <= length <= deep_max
-            for (int q = 21; q < 48; ++q) sc[q] = 0;
+            for (int q = 21; q < 64; ++q) sc[q] = 0;
             sc[A2W_RUN_WORD] = A2W_GO;
         }
         __syncthreads();
     }
     // ---- two wavefronts: the second runs the expansions of the LDS-regime loop until the first says QUIT (bl_astar2_duo.h)
-    const bool duo = turbo && blockDim.x == 128u;
+    const bool duo = turbo && blockDim.x >= 128u;
     const bool walk_ahead = duo && a2_walk_ahead_enabled;
+    const bool ahead3 = walk_ahead && blockDim.x == 192u;      // ... with the expansions on a third wave (BOTLAB_ASTAR_AHEAD=2)
+    if (wave == 2) {
+        if (ahead3) {
+            if (ahead) asm volatile(A2A_BODY_EXPAND3(A2T_PREFETCH, "4", "3")
+                         :: [tbl] "s"(__builtin_amdgcn_readfirstlane((int)tbl)), [kmax] "n"(C::KEY_BYTES - 4), [pln] "n"(C::PLN),
+                            [ok0lo] "n"((unsigned)(((2ull << ((1 << (C::FD + 1)) - 2)) - 1ull) & 0xffffffffull)),
+                            [ok0hi] "n"((unsigned)(((2ull << ((1 << (C::FD + 1)) - 2)) - 1ull) >> 32))
+                         : A2A_EXPUSH_CLOBBERS);
+            else asm volatile(A2A_BODY_EXPAND3("", "2", "1")
+                         :: [tbl] "s"(__builtin_amdgcn_readfirstlane((int)tbl)), [kmax] "n"(C::KEY_BYTES - 4), [pln] "n"(C::PLN),
+                            [ok0lo] "n"((unsigned)(((2ull << ((1 << (C::FD + 1)) - 2)) - 1ull) & 0xffffffffull)),
+                            [ok0hi] "n"((unsigned)(((2ull << ((1 << (C::FD + 1)) - 2)) - 1ull) >> 32))
+                         : A2A_EXPUSH_CLOBBERS);
+        }
+        return;
+    }
     if (wave == 1) {
-        if (walk_ahead) {
+        if (ahead3) {
+            asm volatile(A2A_BODY_PUSH3
+                         :: [tbl] "s"(__builtin_amdgcn_readfirstlane((int)tbl)), [kmax] "n"(C::KEY_BYTES - 4), [pln] "n"(C::PLN),
+                            [ok0lo] "n"((unsigned)(((2ull << ((1 << (C::FD + 1)) - 2)) - 1ull) & 0xffffffffull)),
+                            [ok0hi] "n"((unsigned)(((2ull << ((1 << (C::FD + 1)) - 2)) - 1ull) >> 32))
+                         : A2A_PUSH3_CLOBBERS);
+        } else if (walk_ahead) {
             if (ahead) asm volatile(A2A_BODY_EXPUSH(A2T_PREFETCH, "4", "3")
                          :: [tbl] "s"(__builtin_amdgcn_readfirstlane((int)tbl)), [kmax] "n"(C::KEY_BYTES - 4), [pln] "n"(C::PLN),
                             [ok0lo] "n"((unsigned)(((2ull << ((1 << (C::FD + 1)) - 2)) - 1ull) & 0xffffffffull)),

@@ -1,4 +1,4 @@
-// bl_astar2_ahead.h -- the LDS-regime search loop of k_astar2 on two wavefronts, with the NEXT pop's walk taken beside the pushes.
+// bl_astar2_ahead.h -- the LDS-regime search loop of k_astar2 on two (or three) wavefronts, with the NEXT pop's walk taken beside the pushes.
 //
 // std::pop_heap moves the hole from the root to a leaf along the smaller children (stl_heap.h __adjust_heap) BEFORE it looks at the
 // value it re-inserts: the walk depends on the heap alone, not on the entry from the back of the array.  So pop k + 1's walk can be
@@ -24,8 +24,11 @@
 // other for only 185 + 165 cycles of an iteration of ~1 750: BOTH are busy for ~1 580 -- wave 0: ~700 from B1 to B2 (two LDS round
 // trips for the entry at the back and the record, the four tests, climb, gate, stores and their wait) + ~680 for the walk; wave 1:
 // ~440 + ~1 100 (a push is ~345 cycles, the expansion ahead ~450).  The split moves work beside work but adds two hand-overs, the
-// tests and the copies of the expansion made ahead: 3 160 cycles of work per pop where bl_astar2_duo.h has 2 750.  What would pay:
-// a THIRD wavefront for the expansions (then B1 -> B2 ~700, B2 -> B1 ~700: ~0.58 us per pop); DESIGN.md section 9.
+// tests and the copies of the expansion made ahead: 3 160 cycles of work per pop where bl_astar2_duo.h has 2 750.
+// With a THIRD wavefront (BOTLAB_ASTAR_AHEAD=2: wave 0 pops, wave 1 pushes, wave 2 expansions; A2A_BODY_PUSH3 / _EXPAND3 below):
+// 0.685 - 0.704 us per pop against 0.713 - 0.725 on the same box (-4 %); the stamps show wave 0 waiting 55 + 53 cycles and the
+// expansion wave 460 + 159: the pops alone are the chain now, ~1 600 cycles -- the duo loop's pop is ~1 000 of its 1 750; the two
+// barriers, the two record reads with their LDS round trips, the tests and the checks cost the rest.  Off as well.
 //
 // Hand-over (table words, record at tbl + 4096 + 128):
 //     32..35  wave 1 -> wave 0 before B2: push mask, goal mask, popped payload, -;  word 35 on (re-)entry wave 0 -> wave 1: the length
@@ -302,6 +305,23 @@
     TAG ":\n\t"                                                                                               \
     "v_readlane_b32 s75, v212, 4\n\t"                /* the cell this expansion closes */
 
+// the pushes of an expansion (mask s87, keys v226, payloads v227 in lanes 0..3) into a heap of s40 entries behind the pop, and where
+// each landed (A2A_PUSH_REST) into the record's words 36..38 (v168 = the lane's word)
+#define A2A_PUSHES                                                                                            \
+    "s_add_i32 s40, s40, -1\n\t"                                                                              \
+    "v_mov_b32 v167, 0x7fffffff\n\t"                                                                          \
+    A2T_PUSH_CHECK("17f") A2T_PUSH_READ A2A_PUSH_REST("0")                                                    \
+    A2T_PUSH_CHECK("17f") A2T_PUSH_READ A2A_PUSH_REST("1")                                                    \
+    A2T_PUSH_CHECK("17f") A2T_PUSH_READ A2A_PUSH_REST("2")                                                    \
+    "17:\n\t"                                                                                                 \
+    "s_mov_b64 exec, 15\n\t"                                                                                  \
+    "ds_write_b32 v168, v167\n\t"                                                                             \
+    "s_mov_b64 exec, -1\n\t"
+// (three waves) the candidates for the wave that pushes: (key, payload) of lanes 0..3 into the record's words 48..55
+#define A2A_REC_CANDIDATES                                                                                    \
+    "s_mov_b64 exec, 15\n\t"                                                                                  \
+    "ds_write_b64 v171, v[226:227]\n\t"
+
 // the foreseen top of the NEXT iteration (the smaller child of the root as read at B1, of equal keys the right one: payload v150,
 // key v164) and the loads of its expansion, into (v160, v161)
 #define A2A_FORESEE                                                                                           \
@@ -317,7 +337,7 @@
 // cell s75); s74 = "there is one".  At B1 the top really there is compared with it: the same entry (payload and key) -> the entry is
 // stored and the record goes out at once; another (or none foreseen: wave 0 has been elsewhere) -> the expansion is made now, from
 // loads asked for now (v158, v159).  v169 = the record's address, v168 = the lane's word of "where the pushes landed" (lanes 0..3).
-#define A2A_XBODY(PREFETCH, VMWAIT, SPECWAIT)                                                                           \
+#define A2A_XBODY(PREFETCH, VMWAIT, SPECWAIT, RECX, MID)                                                                           \
     "10:\n\t"                                                                                                 \
     A2W_TIMED_BARRIER("s41")                     /* B1: the heap is final */                                  \
     "ds_read_b32 v240, v169 offset:48\n\t"           /* the run word */                                       \
@@ -380,21 +400,13 @@
     "v_mov_b32 v230, s87\n\t"                                                                                 \
     "v_mov_b32 v231, s88\n\t"                                                                                 \
     "v_mov_b32 v232, v196\n\t"                                                                                \
-    "v_mov_b32 v233, 0\n\t"                                                                                   \
     "s_mov_b64 exec, 1\n\t"                                                                                   \
-    "ds_write_b128 v169, v[230:233]\n\t"                                                                      \
+    "ds_write_b96 v169, v[230:232]\n\t"              /* (word 35 -- the length for a re-entry -- is wave 0's) */ \
+    RECX                                                                                                      \
     "s_mov_b64 exec, -1\n\t"                                                                                  \
     "s_waitcnt lgkmcnt(0)\n\t"                                                                                \
     A2W_TIMED_BARRIER("s42")                     /* B2: the pop is in */                                      \
-    "s_add_i32 s40, s40, -1\n\t"                                                                              \
-    "v_mov_b32 v167, 0x7fffffff\n\t"                                                                          \
-    A2T_PUSH_CHECK("17f") A2T_PUSH_READ A2A_PUSH_REST("0")                                                    \
-    A2T_PUSH_CHECK("17f") A2T_PUSH_READ A2A_PUSH_REST("1")                                                    \
-    A2T_PUSH_CHECK("17f") A2T_PUSH_READ A2A_PUSH_REST("2")                                                    \
-    "17:\n\t"                                                                                                 \
-    "s_mov_b64 exec, 15\n\t"                                                                                  \
-    "ds_write_b32 v168, v167\n\t"                                                                             \
-    "s_mov_b64 exec, -1\n\t"                                                                                  \
+    MID                                                                                                       \
     /* ---- the expansion of the top foreseen for the next iteration, from the loads asked for at B1 */       \
     "v_mov_b32 v196, v150\n\t"                                                                                \
     "v_mov_b32 v192, v164\n\t"                                                                                \
@@ -432,11 +444,70 @@
     "v_mov_b32 v166, s51\n\t"                        /* a closed entry of this search */                      \
     "v_mov_b32 v170, 1\n\t"                                                                                   \
     "s_mov_b32 s84, -1\n\t"                          /* no cell closed */                                     \
-    A2A_XBODY(PREFETCH, VMWAIT, SPECWAIT)                                                                             \
+    A2A_XBODY(PREFETCH, VMWAIT, SPECWAIT, "", A2A_PUSHES)                                                     \
     "99:\n\t"                                                                                                 \
     A2W_ACC_OUT("s41", "4204") A2W_ACC_OUT("s42", "4208") A2W_ACC_OUT("s79", "4216") A2W_ACC_OUT("s81", "4220") \
     "s_waitcnt vmcnt(0)\n\t"
 
-#define A2A_EXPUSH_CLOBBERS A2W_EXPAND_CLOBBERS, "v164", "v167", "v168", "v169", "v170", "v246"
+// ---------------------------------------------------------------------------------------------------------- three waves
+// The same loop with the expansions on a wave of their own: wave 0 the pops (A2A_BODY_POP, unchanged), wave 1 the pushes, wave 2 the
+// expansions (what wave 1 does above, without the pushes; the candidates go to wave 1 through the record's words 48..55).  All three
+// meet at B1 and B2; wave 1 and wave 2 park at B1 together.
+#define A2A_BODY_EXPAND3(PREFETCH, VMWAIT, SPECWAIT)                                                          \
+    A2W_ENTRY                                                                                                 \
+    "s_mov_b32 s40, 0\n\t"                                                                                    \
+    "s_mov_b32 s74, 0\n\t"                           /* no expansion made ahead */                            \
+    A2W_ACC_ZERO("s41") A2W_ACC_ZERO("s42") A2W_ACC_ZERO("s79") A2W_ACC_ZERO("s81")                           \
+    "v_mov_b32 v190, 2\n\t"                                                                                   \
+    "v_mov_b32 v165, 4\n\t"                                                                                   \
+    "v_add_u32 v169, 4224, v191\n\t"                 /* the record */                                         \
+    "v_min_u32 v171, 3, v188\n\t"                                                                             \
+    "v_lshl_add_u32 v171, v171, 3, v169\n\t"                                                                  \
+    "v_add_u32 v171, 64, v171\n\t"                   /* the lane's candidate (lanes 0..3): words 48..55 */    \
+    "v_mov_b32 v166, s51\n\t"                        /* a closed entry of this search */                      \
+    "v_mov_b32 v150, -1\n\t"                         /* no top foreseen */                                    \
+    "v_mov_b32 v170, 1\n\t"                                                                                   \
+    "s_mov_b32 s84, -1\n\t"                          /* no cell closed */                                     \
+    A2A_XBODY(PREFETCH, VMWAIT, SPECWAIT, A2A_REC_CANDIDATES, "")                                             \
+    "99:\n\t"                                                                                                 \
+    A2W_ACC_OUT("s41", "4204") A2W_ACC_OUT("s42", "4208") A2W_ACC_OUT("s79", "4216") A2W_ACC_OUT("s81", "4220") \
+    "s_waitcnt vmcnt(0)\n\t"
+
+#define A2A_BODY_PUSH3                                                                                        \
+    A2W_ENTRY                                                                                                 \
+    "s_mov_b32 s40, 0\n\t"                                                                                    \
+    "v_add_u32 v169, 4224, v191\n\t"                 /* the record */                                         \
+    "v_min_u32 v168, 3, v188\n\t"                                                                             \
+    "v_lshl_add_u32 v171, v168, 3, v169\n\t"                                                                  \
+    "v_add_u32 v171, 64, v171\n\t"                   /* the lane's candidate (lanes 0..3): words 48..55 */    \
+    "v_lshl_add_u32 v168, v168, 2, v169\n\t"                                                                  \
+    "v_add_u32 v168, 16, v168\n\t"                   /* the lane's word of where the pushes landed */         \
+    "10:\n\t"                                                                                                 \
+    "s_barrier\n\t"                                  /* B1 */                                                 \
+    "ds_read_b32 v240, v169 offset:48\n\t"           /* the run word */                                       \
+    "ds_read_b32 v242, v169 offset:12\n\t"           /* the length (of use behind run word 3 only) */         \
+    "s_waitcnt lgkmcnt(0)\n\t"                                                                                \
+    "v_readfirstlane_b32 s70, v240\n\t"                                                                       \
+    "s_cmp_eq_u32 s70, 2\n\t"                                                                                 \
+    "s_cbranch_scc1 99f\n\t"                                                                                  \
+    "s_cmp_eq_u32 s70, 4\n\t"                        /* parked: wave 0 is elsewhere */                        \
+    "s_cbranch_scc1 10b\n\t"                                                                                  \
+    "s_cmp_eq_u32 s70, 3\n\t"                                                                                 \
+    "s_cbranch_scc0 11f\n\t"                                                                                  \
+    "v_readfirstlane_b32 s40, v242\n\t"                                                                       \
+    "11:\n\t"                                                                                                 \
+    "s_barrier\n\t"                                  /* B2: the pop is in, the expansion's record is there */ \
+    "ds_read_b32 v210, v169\n\t"                     /* the push mask */                                      \
+    "ds_read_b64 v[226:227], v171\n\t"               /* the lane's candidate */                               \
+    "s_waitcnt lgkmcnt(0)\n\t"                                                                                \
+    "v_readfirstlane_b32 s87, v210\n\t"                                                                       \
+    A2A_PUSHES                                                                                                \
+    "s_waitcnt lgkmcnt(0)\n\t"                                                                                \
+    "s_branch 10b\n\t"                                                                                        \
+    "99:\n\t"
+
+#define A2A_PUSH3_CLOBBERS A2T_CLOBBERS, "v167", "v168", "v169", "v171"
+
+#define A2A_EXPUSH_CLOBBERS A2W_EXPAND_CLOBBERS, "v164", "v167", "v168", "v169", "v170", "v171", "v246"
 
 #endif

@@ -2657,7 +2657,8 @@ extern "C" int bl_astar_debug_last_kernel(bl_ctx* ctx) { return ctx && ctx->asta
 static int astar2_threads(bool shares_cu = false)
 {
     static const bool duo = !(getenv("BOTLAB_ASTAR_DUO") && atoi(getenv("BOTLAB_ASTAR_DUO")) == 0);
-    return duo && !shares_cu ? 128 : 64;
+    static const bool three = getenv("BOTLAB_ASTAR_AHEAD") && atoi(getenv("BOTLAB_ASTAR_AHEAD")) == 2;     // (bl_astar2_ahead.h: pops / pushes / expansions)
+    return duo && !shares_cu ? (three ? 192 : 128) : 64;
 }
 
 static void astar_launch_kernel(bl_ctx* ctx, const astar_args& a, int workgroups, bool split)
@@ -2761,7 +2762,7 @@ extern "C" int bl_astar_search_result(bl_ctx* ctx, bl_pose_xyt_t* out_path, int 
 #ifdef BL_ASTAR_STAMPS
     {
         const double pp = (double)(r.pops ? r.pops : 1);
-        if (astar2_threads() == 128 && !(ctx->astar_small_lds || getenv("BOTLAB_ASTAR_SMALL_LDS")) && getenv("BOTLAB_ASTAR_AHEAD") && atoi(getenv("BOTLAB_ASTAR_AHEAD")) != 0)
+        if (astar2_threads() >= 128 && !(ctx->astar_small_lds || getenv("BOTLAB_ASTAR_SMALL_LDS")) && getenv("BOTLAB_ASTAR_AHEAD") && atoi(getenv("BOTLAB_ASTAR_AHEAD")) != 0)
             fprintf(stderr, "[astar ahead stamps] pops %lld: cycles/pop inside barriers -- wave 0: B1 %.0f, B2 %.0f; wave 1: B1 %.0f, B2 %.0f | walks taken again %.4f per pop | search %.0f cycles/pop | expansions made ahead %lld, not %lld\n", r.pops,
                     (double)r.stamps[0] / pp, (double)r.stamps[1] / pp, (double)r.stamps[2] / pp, (double)r.stamps[4] / pp, (double)r.stamps[5] / pp,
                     (double)r.stamps[3] * 1e-8 * 2.4e9 / pp, (long long)(r.path_off & 0xffffffffll), (long long)(r.path_off >> 32));

@@ -951,7 +951,7 @@ def _fixtures_in_child(queue_path):
     json.dump(out, open(queue_path, "w"))
 
 
-@pytest.mark.parametrize("env", ["BOTLAB_ASTAR_NO_TURBO", "BOTLAB_ASTAR_V1", "BOTLAB_ASTAR_DUO=0", "BOTLAB_ASTAR_AHEAD=1"])
+@pytest.mark.parametrize("env", ["BOTLAB_ASTAR_NO_TURBO", "BOTLAB_ASTAR_V1", "BOTLAB_ASTAR_DUO=0", "BOTLAB_ASTAR_AHEAD=1", "BOTLAB_ASTAR_AHEAD=2"])
 def test_astar_fixtures_with_the_other_forms_of_the_search(tmp_path, env):
     """the same fixtures through k_astar2's C++ forms (no straight-line loop), through round 4's k_astar (8-byte entries) -- the
     forms a search falls back to for lists of 0-1 entries, cost tables beyond LDS or below the 16-bit key range -- and through the
