@@ -135,10 +135,13 @@ def run(name, case, radius=0.1, cells=None, origin=None, mpc=None, start=None, g
     ok = (pops, pushes) == tuple(est)
     tot = max(pops, 1)
     r = rises / max(rises.sum(), 1)
+    stats = dict(pops=pops, pushes=pushes, oracle=tuple(est), early_walk_reads_a_written_position=conservative / tot, early_walk_differs=differs / tot,
+                 pushes_landing_at_the_root=root_land / max(pushes, 1), pushes_that_do_not_rise=float(r[0]))
     print(f"{name} {case}: pops {pops} pushes {pushes} (oracle {tuple(est)}: {'equal' if ok else 'DIFFERENT'}) | early walk reads a written "
           f"position {100.0 * conservative / tot:.2f} %, really differs {100.0 * differs / tot:.2f} % | pushes landing at the root "
           f"{100.0 * root_land / max(pushes, 1):.2f} % | rise 0: {100 * r[0]:.0f} %, 1-2: {100 * r[1:3].sum():.0f} %, 3-5: {100 * r[3:6].sum():.0f} %, "
           f"6-9: {100 * r[6:10].sum():.0f} %, 10+: {100 * r[10:].sum():.0f} %", flush=True)
+    return stats
 
 
 if __name__ == "__main__":
