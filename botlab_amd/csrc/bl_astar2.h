@@ -112,8 +112,8 @@ __device__ __forceinline__ void a2_wait_vm4(unsigned& x, unsigned& y, unsigned& 
 
 // BOTLAB_ASTAR_NO_TURBO=1 (read by the host, astar_launch_kernel): the C++ loop everywhere (tests, A/B runs)
 __device__ bool a2_turbo_enabled = true;
-__device__ bool a2_walk_ahead_enabled = false;    // two-wave loop: the next pop's walk beside the pushes (bl_astar2_ahead.h) instead of bl_astar2_duo.h's split; BOTLAB_ASTAR_AHEAD=1
-                                                  // (measured at 0.720 us per pop against 0.712: both waves are busy, neither shorter -- DESIGN.md section 7)
+__device__ bool a2_walk_ahead_enabled = true;     // LDS-regime loop of single searches: the next pop's walk beside the pushes (bl_astar2_ahead.h: pops / pushes / expansions
+                                                  // on three waves, 0.634 us per pop where bl_astar2_duo.h's two take 0.71 - 0.72); BOTLAB_ASTAR_AHEAD=0: the duo loop, =1: two waves
 
 // per-lane constants of the wave-parallel heap operations
 struct a2_lanes {

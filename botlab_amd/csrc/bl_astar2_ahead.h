@@ -56,6 +56,44 @@
     A2T_ROUND("v240", "v241", "v242", "v243", "s[76:77]", "s[64:65]", "")                                     \
     L "9:\n\t"
 
+// A2T_ROUND in two halves: the read of the nodes' child pairs needs the subtree's root only (s78), the rest also the length (s40) --
+// the first round of a walk taken ahead asks for its pairs before the length is known (the record with the push count is on its way)
+#define A2A_ROUND_ASK(N)                                                                                      \
+    "v_lshl_add_u32 " N ", s78, v180, v181\n\t"                                                               \
+    "v_lshl_add_u32 v220, " N ", 2, 4\n\t"                                                                    \
+    "v_min_u32 v220, %[kmax], v220\n\t"                                                                       \
+    "ds_read_b32 v221, v220\n\t"
+#define A2A_ROUND_REST(N, C_, K, P, SQ, OK)                                                                   \
+    "v_cmp_gt_u32_e64 s[68:69], s40, " N "\n\t"                                                               \
+    "s_and_b64 s[68:69], s[68:69], " OK "\n\t"                                                                \
+    "v_lshl_add_u32 " C_ ", " N ", 1, 1\n\t"                                                                  \
+    "s_waitcnt lgkmcnt(0)\n\t"                                                                                \
+    "v_cmp_le_u32_sdwa vcc, v221, v221 src0_sel:WORD_1 src1_sel:WORD_0\n\t"                                   \
+    "v_min_u32_sdwa " K ", v221, v221 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:WORD_1\n\t" \
+    "s_nop 1\n\t"                                                                                             \
+    "v_and_b32 v222, vcc_lo, v182\n\t"                                                                        \
+    "v_addc_co_u32 " C_ ", vcc, 0, " C_ ", vcc\n\t"                                                           \
+    "v_cmp_eq_u32 vcc, v222, v183\n\t"                                                                        \
+    "s_and_b64 " SQ ", vcc, s[68:69]\n\t"                                                                     \
+    "s_flbit_i32_b64 s70, " SQ "\n\t"                                                                         \
+    "s_sub_i32 s70, 63, s70\n\t"                                                                              \
+    "s_bitset0_b64 " SQ ", s70\n\t"                                                                           \
+    "v_readlane_b32 s78, " N ", s70\n\t"                                                                      \
+    "s_add_i32 s78, s78, 1\n\t"                                                                               \
+    "v_min_u32 v220, %[pln], " C_ "\n\t"                                                                      \
+    "v_lshl_add_u32 v220, v220, 2, s56\n\t"                                                                   \
+    "ds_read_b32 " P ", v220\n\t"
+// the walk behind a first round whose pairs have been asked for (A2A_ROUND_ASK("v200") with s78 = 1)
+#define A2A_WALK_REST(L)                                                                                      \
+    A2A_ROUND_REST("v200", "v201", "v202", "v203", "s[72:73]", "s[62:63]")                                    \
+    "s_cmp_lt_u32 s40, s59\n\t"                                                                               \
+    "s_cbranch_scc1 " L "9f\n\t"                                                                              \
+    A2T_ROUND("v205", "v206", "v207", "v208", "s[74:75]", "s[64:65]", "")                                     \
+    "s_cmp_ge_u32 s40, s60\n\t"                                                                               \
+    "s_cbranch_scc0 " L "9f\n\t"                                                                              \
+    A2T_ROUND("v240", "v241", "v242", "v243", "s[76:77]", "s[64:65]", "")                                     \
+    L "9:\n\t"
+
 // is the 1-based node A (an SGPR; 0x7fffffff: none) an ancestor-or-self of the walk's leaf s81 (1-based; s71 = its leading zeros)?
 // yes -> TAKEN.  (A deeper than the leaf: A > s81 >= s81 >> anything, never equal.)
 #define A2A_ON_PATH(A, TAKEN)                                                                                 \
@@ -85,6 +123,10 @@
     "ds_write_b32 v214, v216 offset:48\n\t"                                                                   \
     "ds_write_b32 v214, v224 offset:12\n\t"          /* the length, for the other wave */                     \
     "s_mov_b64 exec, -1\n\t"                                                                                  \
+    "v_min_u32 v215, 3, v188\n\t"                                                                             \
+    "v_lshl_add_u32 v215, v215, 2, v214\n\t"                                                                  \
+    "v_add_u32 v215, 16, v215\n\t"                   /* the lane's word of where the pushes landed (lanes 0..2; lane 3's says "none") */ \
+    "s_waitcnt lgkmcnt(0)\n\t"                                                                                \
     /* ================================================================== one iteration */                    \
     "1:\n\t"                                                                                                  \
     "s_cmp_lg_u32 s88, 0\n\t"                        /* the last expansion reached the goal */                \
@@ -94,9 +136,10 @@
     "s_add_i32 s70, s40, -2\n\t"                                                                              \
     "s_cmp_gt_u32 s70, s58\n\t"                      /* len < 2 (wraps) or len - 2 > lim - 2 */               \
     "s_cbranch_scc1 91f\n\t"                                                                                  \
-    "s_waitcnt lgkmcnt(0)\n\t"                                                                                \
+    /* (nothing this wave has WRITTEN is under way here: the walk taken ahead only reads) */                  \
+    "2:\n\t"                                                                                                  \
     A2W_TIMED_BARRIER("s36")                     /* B1: the pushes are in; the other wave takes the top from here */ \
-    "ds_read_b128 v[210:213], v214 offset:16\n\t"    /* where they landed */                                  \
+    "ds_read_b32 v210, v215\n\t"                     /* where they landed: lane j the j-th push */            \
     /* ---- the entry at the back of the array (key v193, payload v197): the value the pop's sift-down places */ \
     "s_lshl_b32 s70, s40, 1\n\t"                                                                              \
     "v_mov_b32 v191, s70\n\t"                                                                                 \
@@ -114,14 +157,21 @@
     "s_cmp_eq_u32 s79, 0\n\t"                                                                                 \
     "s_cbranch_scc1 60f\n\t"                                                                                  \
     /* ---- the walk taken ahead: did it read what the pushes wrote, or the entry that has just left? */      \
-    "s_waitcnt lgkmcnt(0)\n\t"                                                                                \
-    "v_readfirstlane_b32 s82, v210\n\t"                                                                       \
-    "v_readfirstlane_b32 s83, v211\n\t"                                                                       \
-    "v_readfirstlane_b32 s84, v212\n\t"                                                                       \
+    /* lanes 0..2: the parents of the pushes' landings; lane 3: the parent of the node the entry at the back held (1-based) --  */ \
+    /* is any of them an ancestor-or-self of the walk's leaf s81?  a on the path <=> s81 >> (lvl(s81) - lvl(a)) == a            */ \
     "s_add_i32 s85, s40, 1\n\t"                                                                               \
-    "s_lshr_b32 s85, s85, 1\n\t"                     /* parent of the node that entry held (1-based) */        \
+    "s_lshr_b32 s85, s85, 1\n\t"                                                                              \
+    "v_mov_b32 v211, s85\n\t"                                                                                 \
     "s_flbit_i32_b32 s71, s81\n\t"                                                                            \
-    A2A_ON_PATH("s82", "60f") A2A_ON_PATH("s83", "60f") A2A_ON_PATH("s84", "60f") A2A_ON_PATH("s85", "60f")   \
+    "s_mov_b64 s[82:83], 8\n\t"                                                                               \
+    "s_waitcnt lgkmcnt(0)\n\t"                                                                                \
+    "v_cndmask_b32_e64 v210, v210, v211, s[82:83]\n\t"                                                        \
+    "v_ffbh_u32 v211, v210\n\t"                                                                               \
+    "v_subrev_u32 v211, s71, v211\n\t"                                                                        \
+    "v_lshrrev_b32_e64 v212, v211, s81\n\t"                                                                   \
+    "v_cmp_eq_u32 vcc, v212, v210\n\t"                                                                        \
+    "s_and_b64 s[82:83], vcc, 15\n\t"                                                                         \
+    "s_cbranch_scc1 60f\n\t"                                                                                  \
     "61:\n\t"                                                                                                 \
     /* ---- the climb and one pass of stores, by the number of rounds the walk had */                         \
     "s_cmp_lt_u32 s40, s59\n\t"                                                                               \
@@ -144,7 +194,9 @@
     "ds_read_b128 v[210:213], v214\n\t"              /* the expansion's outcome: push mask, goal mask, popped payload */ \
     "s_add_i32 s41, s41, 1\n\t"                                                                               \
     "s_mov_b32 s79, 0\n\t"                                                                                    \
-    "s_waitcnt lgkmcnt(0)\n\t"                                                                                \
+    "s_mov_b32 s78, 1\n\t"                                                                                    \
+    A2A_ROUND_ASK("v200")                          /* (the next walk's first pairs: on their way while the record is waited for) */ \
+    "s_waitcnt lgkmcnt(1)\n\t"                                                                                \
     "v_readfirstlane_b32 s87, v210\n\t"                                                                       \
     "v_readfirstlane_b32 s88, v211\n\t"                                                                       \
     "v_readfirstlane_b32 s80, v212\n\t"                                                                       \
@@ -159,11 +211,11 @@
     "s_cmp_gt_u32 s70, s58\n\t"                                                                               \
     "s_cbranch_scc1 1b\n\t"                                                                                   \
     "s_add_i32 s40, s40, -1\n\t"                     /* (the walk's heap: without the entry at the back) */   \
-    A2A_WALK("5")                                                                                             \
+    A2A_WALK_REST("5")                                                                                        \
     "s_mov_b32 s81, s78\n\t"                                                                                  \
     "s_add_i32 s40, s40, 1\n\t"                                                                               \
     "s_mov_b32 s79, 1\n\t"                                                                                    \
-    "s_branch 1b\n\t"                                                                                         \
+    "s_branch 2b\n\t"                              /* (the checks of the loop's top have just been made) */ \
     /* ================================================================== out of line */                      \
     /* the walk, now: none was taken ahead, or the one taken read a position that has changed since */        \
     "60:\n\t"                                                                                                 \
@@ -499,9 +551,18 @@
     "s_barrier\n\t"                                  /* B2: the pop is in, the expansion's record is there */ \
     "ds_read_b32 v210, v169\n\t"                     /* the push mask */                                      \
     "ds_read_b64 v[226:227], v171\n\t"               /* the lane's candidate */                               \
-    "s_waitcnt lgkmcnt(0)\n\t"                                                                                \
+    "s_add_i32 s40, s40, -1\n\t"                                                                              \
+    "v_mov_b32 v167, 0x7fffffff\n\t"                                                                          \
+    A2T_PUSH_READ                                  /* the first push's ancestors: they need the length only */ \
+    "s_waitcnt lgkmcnt(2)\n\t"                                                                                \
     "v_readfirstlane_b32 s87, v210\n\t"                                                                       \
-    A2A_PUSHES                                                                                                \
+    A2T_PUSH_CHECK("17f") A2A_PUSH_REST("0")                                                                  \
+    A2T_PUSH_CHECK("17f") A2T_PUSH_READ A2A_PUSH_REST("1")                                                    \
+    A2T_PUSH_CHECK("17f") A2T_PUSH_READ A2A_PUSH_REST("2")                                                    \
+    "17:\n\t"                                                                                                 \
+    "s_mov_b64 exec, 15\n\t"                                                                                  \
+    "ds_write_b32 v168, v167\n\t"                                                                             \
+    "s_mov_b64 exec, -1\n\t"                                                                                  \
     "s_waitcnt lgkmcnt(0)\n\t"                                                                                \
     "s_branch 10b\n\t"                                                                                        \
     "99:\n\t"

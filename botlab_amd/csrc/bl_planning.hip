@@ -2481,7 +2481,7 @@ static int astar_prepare(bl_ctx* ctx, const bl_dist* d)
         memset((void*)ctx->astar, 0, sizeof(bl_astar_state));
         ctx->astar->path_head = ASTAR_PATH_HEAD;
         if (getenv("BOTLAB_ASTAR_NO_TURBO")) { const bool off = false; BL_HIP(hipMemcpyToSymbol(HIP_SYMBOL(a2_turbo_enabled), &off, sizeof(off))); }
-        if (getenv("BOTLAB_ASTAR_AHEAD") && atoi(getenv("BOTLAB_ASTAR_AHEAD")) != 0) { const bool on = true; BL_HIP(hipMemcpyToSymbol(HIP_SYMBOL(a2_walk_ahead_enabled), &on, sizeof(on))); }
+        if (getenv("BOTLAB_ASTAR_AHEAD") && atoi(getenv("BOTLAB_ASTAR_AHEAD")) == 0) { const bool off = false; BL_HIP(hipMemcpyToSymbol(HIP_SYMBOL(a2_walk_ahead_enabled), &off, sizeof(off))); }
         if (const char* e = getenv("BOTLAB_ASTAR_PATH_HEAD")) { const int v = atoi(e); if (v >= 1 && v <= ASTAR_PATH_HEAD) ctx->astar->path_head = v; }
         for (int i = 0; i < ASTAR_SLOTS; ++i) {
             BL_HIP(hipHostMalloc((void**)&ctx->astar->h_out[i], ASTAR_HDR + ASTAR_PATH_HEAD * 4, hipHostMallocDefault));
@@ -2657,7 +2657,8 @@ extern "C" int bl_astar_debug_last_kernel(bl_ctx* ctx) { return ctx && ctx->asta
 static int astar2_threads(bool shares_cu = false)
 {
     static const bool duo = !(getenv("BOTLAB_ASTAR_DUO") && atoi(getenv("BOTLAB_ASTAR_DUO")) == 0);
-    static const bool three = getenv("BOTLAB_ASTAR_AHEAD") && atoi(getenv("BOTLAB_ASTAR_AHEAD")) == 2;     // (bl_astar2_ahead.h: pops / pushes / expansions)
+    // (bl_astar2_ahead.h: pops / pushes / expansions on three waves unless BOTLAB_ASTAR_AHEAD says 0 -- the duo loop -- or 1 -- its two-wave form)
+    static const bool three = !(getenv("BOTLAB_ASTAR_AHEAD") && atoi(getenv("BOTLAB_ASTAR_AHEAD")) != 2);
     return duo && !shares_cu ? (three ? 192 : 128) : 64;
 }
 
@@ -2762,11 +2763,11 @@ extern "C" int bl_astar_search_result(bl_ctx* ctx, bl_pose_xyt_t* out_path, int 
 #ifdef BL_ASTAR_STAMPS
     {
         const double pp = (double)(r.pops ? r.pops : 1);
-        if (astar2_threads() >= 128 && !(ctx->astar_small_lds || getenv("BOTLAB_ASTAR_SMALL_LDS")) && getenv("BOTLAB_ASTAR_AHEAD") && atoi(getenv("BOTLAB_ASTAR_AHEAD")) != 0)
+        if (astar2_threads() >= 128 && !(ctx->astar_small_lds || getenv("BOTLAB_ASTAR_SMALL_LDS")) && !(getenv("BOTLAB_ASTAR_AHEAD") && atoi(getenv("BOTLAB_ASTAR_AHEAD")) == 0))
             fprintf(stderr, "[astar ahead stamps] pops %lld: cycles/pop inside barriers -- wave 0: B1 %.0f, B2 %.0f; wave 1: B1 %.0f, B2 %.0f | walks taken again %.4f per pop | search %.0f cycles/pop | expansions made ahead %lld, not %lld\n", r.pops,
                     (double)r.stamps[0] / pp, (double)r.stamps[1] / pp, (double)r.stamps[2] / pp, (double)r.stamps[4] / pp, (double)r.stamps[5] / pp,
                     (double)r.stamps[3] * 1e-8 * 2.4e9 / pp, (long long)(r.path_off & 0xffffffffll), (long long)(r.path_off >> 32));
-        else if (astar2_threads() == 128 && !(ctx->astar_small_lds || getenv("BOTLAB_ASTAR_SMALL_LDS")))
+        else if (astar2_threads() >= 128 && !(ctx->astar_small_lds || getenv("BOTLAB_ASTAR_SMALL_LDS")))
             fprintf(stderr, "[astar duo stamps] pops %lld: cycles/pop -- wave 1: Z to the wait %.0f, the wait %.0f, expansion %.0f, record %.0f; wave 0 inside Y %.0f | search %.0f cycles/pop | tops foreseen %lld, not %lld\n", r.pops,
                     (double)r.stamps[0] / pp, (double)r.stamps[1] / pp, (double)r.stamps[2] / pp, (double)r.stamps[4] / pp, (double)r.stamps[5] / pp,
                     (double)r.stamps[3] * 1e-8 * 2.4e9 / pp, (long long)(r.path_off & 0xffffffffll), (long long)(r.path_off >> 32));

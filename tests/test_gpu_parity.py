@@ -951,13 +951,13 @@ def _fixtures_in_child(queue_path):
     json.dump(out, open(queue_path, "w"))
 
 
-@pytest.mark.parametrize("env", ["BOTLAB_ASTAR_NO_TURBO", "BOTLAB_ASTAR_V1", "BOTLAB_ASTAR_DUO=0", "BOTLAB_ASTAR_AHEAD=1", "BOTLAB_ASTAR_AHEAD=2"])
+@pytest.mark.parametrize("env", ["BOTLAB_ASTAR_NO_TURBO", "BOTLAB_ASTAR_V1", "BOTLAB_ASTAR_DUO=0", "BOTLAB_ASTAR_AHEAD=1", "BOTLAB_ASTAR_AHEAD=0"])
 def test_astar_fixtures_with_the_other_forms_of_the_search(tmp_path, env):
     """the same fixtures through k_astar2's C++ forms (no straight-line loop), through round 4's k_astar (8-byte entries) -- the
     forms a search falls back to for lists of 0-1 entries, cost tables beyond LDS or below the 16-bit key range -- and through the
-    one-wave straight-line loop (what the replanner's units run; single searches take the two-wave loop, bl_astar2_duo.h), and through
-    the two-wave loop that takes the next pop's walk beside the pushes and makes expansions ahead (bl_astar2_ahead.h: an experiment,
-    off by default)"""
+    one-wave straight-line loop (what the replanner's units run), through round 5's two-wave loop (bl_astar2_duo.h, BOTLAB_ASTAR_AHEAD=0)
+    and through the two-wave form of the loop single searches take by default (bl_astar2_ahead.h: the next pop's walk beside the
+    pushes, expansions made ahead; three waves by default)"""
     import json
     import subprocess
     out = str(tmp_path / "res.json")
