@@ -1,4 +1,5 @@
-// bl_astar2_ahead.h -- the LDS-regime search loop of k_astar2 on two (or three) wavefronts, with the NEXT pop's walk taken beside the pushes.
+// bl_astar2_ahead.h -- the LDS-regime search loop of k_astar2 on three (or two) wavefronts, with the NEXT pop's walk taken beside the pushes.
+// The default for searches that have their compute unit to themselves (round 6).
 //
 // std::pop_heap moves the hole from the root to a leaf along the smaller children (stl_heap.h __adjust_heap) BEFORE it looks at the
 // value it re-inserts: the walk depends on the heap alone, not on the entry from the back of the array.  So pop k + 1's walk can be
@@ -10,8 +11,11 @@
 // libstdc++'s index operations: the early walk reads a written position in 0.1 % (5e5 pops) .. 2.8 % (1e4 - 4e4 pops) of the
 // iterations (a quarter of them in searches of ~1 000 pops: launch-bound anyway).  Such an iteration takes its walk again.
 //
+//   two waves:
 //     wave 0 (POP)     B1 | test, the entry at the back, climb, stores       | B2 | walk of the NEXT pop (reads only) ....................... | B1
 //     wave 1 (EXPUSH)  B1 | top, Z, "is it the top I expanded?", record      | B2 | pushes, where they landed, expansion of the top FORESEEN next | B1
+//   three waves (the default): wave 1 keeps the pushes, wave 2 takes everything else of it; the candidates go from wave 2 to wave 1
+//   through the record (words 48..55) before B2.
 //
 // B1 / B2 are workgroup barriers; Z is bl_astar2_duo.h's flag (wave 1 has read the top: wave 0 may store).  The expansion a pop needs
 // is made an iteration AHEAD as well, for the top wave 1 foresees (the smaller child of the root, as bl_astar2_duo.h asks its loads
@@ -19,21 +23,22 @@
 // macros, same index operations in the same order as the one-wave loop (bl_astar2_turbo.h) and the two-wave loop without the early
 // walk (bl_astar2_duo.h): the open list goes through the same states (the fixtures run through all of them).
 //
-// MEASURED (profiles/r06_astar_walk_ahead_stamps.txt, maze 2: 13 693 pops, 1.86 pushes per pop): 0.720 us per pop against 0.712 for
-// bl_astar2_duo.h -- no gain, so it is OFF by default (BOTLAB_ASTAR_AHEAD=1).  The stamped build says why: the waves wait for each
-// other for only 185 + 165 cycles of an iteration of ~1 750: BOTH are busy for ~1 580 -- wave 0: ~700 from B1 to B2 (two LDS round
-// trips for the entry at the back and the record, the four tests, climb, gate, stores and their wait) + ~680 for the walk; wave 1:
-// ~440 + ~1 100 (a push is ~345 cycles, the expansion ahead ~450).  The split moves work beside work but adds two hand-overs, the
-// tests and the copies of the expansion made ahead: 3 160 cycles of work per pop where bl_astar2_duo.h has 2 750.
-// With a THIRD wavefront (BOTLAB_ASTAR_AHEAD=2: wave 0 pops, wave 1 pushes, wave 2 expansions; A2A_BODY_PUSH3 / _EXPAND3 below):
-// 0.685 - 0.704 us per pop against 0.713 - 0.725 on the same box (-4 %); the stamps show wave 0 waiting 55 + 53 cycles and the
-// expansion wave 460 + 159: the pops alone are the chain now, ~1 600 cycles -- the duo loop's pop is ~1 000 of its 1 750; the two
-// barriers, the two record reads with their LDS round trips, the tests and the checks cost the rest.  Off as well.
+// MEASURED (profiles/r06_astar_walk_ahead_stamps.txt, r06_astar_pop.csv; maze 2: 13 693 pops, 1.86 pushes per pop, bl_astar2_duo.h
+// 0.71 - 0.72 us per pop):
+//   two waves (BOTLAB_ASTAR_AHEAD=1, the forms above)                          0.705 - 0.720: both waves busy (~1 580 of ~1 750 cycles)
+//   THREE waves (the default): wave 0 pops, wave 1 pushes, wave 2 expansions     0.69 as first built, 0.63 - 0.64 with wave 0 trimmed
+// With three waves the pops alone are the chain (wave 0 waits ~55 cycles in either barrier -- the barrier's own cost --, the expansion
+// wave ~400 + ~90), so every cycle off wave 0 counts: the four path tests as ONE vector test (lane j = push j, lane 3 = the entry
+// at the back), no wait in front of B1 (the walk taken ahead only reads), the loop's checks made once per iteration, the next
+// walk's first pairs asked for while the record is on its way; on wave 1 the first push's ancestor reads go out with the record
+// reads (they need the length only).  What is left on wave 0, ~1 400 cycles: two LDS round trips in front of the climb (the entry
+// at the back, the flag), the stores and the wait for them, the record's round trip, a walk of 2 - 3 rounds (~470).
 //
 // Hand-over (table words, record at tbl + 4096 + 128):
 //     32..35  wave 1 -> wave 0 before B2: push mask, goal mask, popped payload, -;  word 35 on (re-)entry wave 0 -> wave 1: the length
 //     36..38  wave 1 -> wave 0 before B1: per push max(landing node >> 1, 1) (1-based node index of the landing's parent; the root
 //             when the entry rose to the top: every walk has it), 0x7fffffff for "no push"
+//     48..55  (three waves) wave 2 -> wave 1 before B2: (key, payload) of the expansion's four candidates
 //     44      run word: 1 go, 2 quit, 3 go and forget what you foresaw (wave 0 has been elsewhere; the length is in word 35), 4 park
 //     45      Z
 // Wave 0 leaves the loop at an iteration boundary only, behind a B1 it enters with the run word on "park": wave 1's pushes are in,
