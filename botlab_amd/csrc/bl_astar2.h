@@ -112,6 +112,8 @@ __device__ __forceinline__ void a2_wait_vm4(unsigned& x, unsigned& y, unsigned& 
 
 // BOTLAB_ASTAR_NO_TURBO=1 (read by the host, astar_launch_kernel): the C++ loop everywhere (tests, A/B runs)
 __device__ bool a2_turbo_enabled = true;
+__device__ bool a2_deep_ahead_enabled = true;     // the same three waves beyond LDS (bl_astar2_ahead.h, "the deep regime": 0.88 - 0.90 us per pop where
+                                                  // bl_astar2_deep.h's one wave takes 1.12 - 1.14); BOTLAB_ASTAR_DEEP_AHEAD=0: that one-wave loop
 __device__ bool a2_walk_ahead_enabled = true;     // LDS-regime loop of single searches: the next pop's walk beside the pushes (bl_astar2_ahead.h: pops / pushes / expansions
                                                   // on three waves, 0.634 us per pop where bl_astar2_duo.h's two take 0.71 - 0.72); BOTLAB_ASTAR_AHEAD=0: the duo loop, =1: two waves
 
@@ -671,6 +673,8 @@ __global__ __launch_bounds__(192) void k_astar2(astar_args a)
     const bool duo = turbo && blockDim.x >= 128u;
     const bool walk_ahead = duo && a2_walk_ahead_enabled;
     const bool ahead3 = walk_ahead && blockDim.x == 192u;      // ... with the expansions on a third wave (BOTLAB_ASTAR_AHEAD=2)
+    // (deep_max etc. are wave-uniform; the three waves agree on the forms they run)
+    const bool deep3 = ahead3 && a2_deep_ahead_enabled && turbo && C::PLEV == C::LEV - 1;
     if (wave == 2) {
         if (ahead3) {
             if (ahead) asm volatile(A2A_BODY_EXPAND3(A2T_PREFETCH, "4", "3")
@@ -687,7 +691,14 @@ __global__ __launch_bounds__(192) void k_astar2(astar_args a)
         return;
     }
     if (wave == 1) {
-        if (ahead3) {
+        if (deep3) {
+            asm volatile(A2A_BODY_PUSH3D
+                         :: [tbl] "s"(__builtin_amdgcn_readfirstlane((int)tbl)), [kmax] "n"(C::KEY_BYTES - 4), [kmax2] "n"(C::KEY_BYTES - 2), [pln] "n"(C::PLN),
+                            [kslots] "n"(C::KSLOTS), [kslotsm1] "n"(C::KSLOTS - 1),
+                            [ok0lo] "n"((unsigned)(((2ull << ((1 << (C::FD + 1)) - 2)) - 1ull) & 0xffffffffull)),
+                            [ok0hi] "n"((unsigned)(((2ull << ((1 << (C::FD + 1)) - 2)) - 1ull) >> 32))
+                         : A2A_PUSH3D_CLOBBERS);
+        } else if (ahead3) {
             asm volatile(A2A_BODY_PUSH3
                          :: [tbl] "s"(__builtin_amdgcn_readfirstlane((int)tbl)), [kmax] "n"(C::KEY_BYTES - 4), [pln] "n"(C::PLN),
                             [ok0lo] "n"((unsigned)(((2ull << ((1 << (C::FD + 1)) - 2)) - 1ull) & 0xffffffffull)),
@@ -777,7 +788,14 @@ __global__ __launch_bounds__(192) void k_astar2(astar_args a)
             unsigned code, gm, ptop;
             unsigned s_len = (unsigned)__builtin_amdgcn_readfirstlane((int)len), s_pops = (unsigned)__builtin_amdgcn_readfirstlane((int)pops);
             unsigned s_pushes = (unsigned)__builtin_amdgcn_readfirstlane((int)pushes);
-            asm volatile(A2D_BODY
+            if (deep3) asm volatile(A2A_BODY_POPD
+                         : [len] "+s"(s_len), [pops] "+s"(s_pops), [pushes] "+s"(s_pushes), [code] "=&s"(code), [gm] "=&s"(gm), [pt] "=&s"(ptop)
+                         : [tbl] "s"(__builtin_amdgcn_readfirstlane((int)tbl)), [kmax] "n"(C::KEY_BYTES - 4), [kmax2] "n"(C::KEY_BYTES - 2), [pln] "n"(C::PLN),
+                           [kslots] "n"(C::KSLOTS), [kslotsm1] "n"(C::KSLOTS - 1), [dlo] "n"(C::PLN + 2),
+                           [ok0lo] "n"((unsigned)(((2ull << ((1 << (C::FD + 1)) - 2)) - 1ull) & 0xffffffffull)),
+                           [ok0hi] "n"((unsigned)(((2ull << ((1 << (C::FD + 1)) - 2)) - 1ull) >> 32))
+                         : A2D_CLOBBERS);
+            else asm volatile(A2D_BODY
                          : [len] "+s"(s_len), [pops] "+s"(s_pops), [pushes] "+s"(s_pushes), [code] "=&s"(code), [gm] "=&s"(gm), [pt] "=&s"(ptop)
                          : [tbl] "s"(__builtin_amdgcn_readfirstlane((int)tbl)), [kmax] "n"(C::KEY_BYTES - 4), [kmax2] "n"(C::KEY_BYTES - 2), [pln] "n"(C::PLN),
                            [kslots] "n"(C::KSLOTS), [kslotsm1] "n"(C::KSLOTS - 1), [dlo] "n"(C::PLN + 2),
@@ -787,6 +805,7 @@ __global__ __launch_bounds__(192) void k_astar2(astar_args a)
             len = s_len; pops = s_pops; pushes = s_pushes;
             if (code == 2u) { goal_m = gm; cx = (int)((ptop >> 2) & 0x7fffu); cy = (int)(ptop >> 17); res.status = ASTAR_ST_FOUND; break; }
             if (code == 3u) { res.status = ASTAR_ST_LIMIT; break; }
+            if (code == 4u) { res.status = ASTAR_ST_BROKEN; break; }
             if (len == 0) break;
             if (len >= 2u && len <= (unsigned)C::PLN - 3u) continue;        // back in the LDS regime
         }
@@ -897,6 +916,9 @@ __global__ __launch_bounds__(192) void k_astar2(astar_args a)
         const a2_lds_u32* sc = (const a2_lds_u32*)(size_t)(tbl + 4096u);
         res.stamps[0] = sc[24]; res.stamps[1] = sc[26]; res.stamps[2] = sc[27]; res.stamps[4] = sc[28]; res.stamps[5] = sc[29];
         res.path_off = (long long)sc[30] | ((long long)sc[31] << 32);
+        // (deep regime on three waves: the wave that pushes inside B1 in place of wave 2's B2; first pushes whose ancestors were read
+        // again in place of the expansions not made ahead)
+        if (deep3) { res.stamps[4] = sc[21]; res.path_off = (long long)sc[30] | ((long long)sc[22] << 32); }
     } else if (duo) {
         // two-wave loop: wave 0's cycles inside Y, X, Z; wave 1's inside X, Y (bl_astar2_duo.h).  Wave 1 adds its sums on its way out:
         // it has left by the time the barrier below is through... the sums it has added so far, then

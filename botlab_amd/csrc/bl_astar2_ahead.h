@@ -572,6 +572,443 @@
     "s_branch 10b\n\t"                                                                                        \
     "99:\n\t"
 
+// ---------------------------------------------------------------------------------------------------------- the deep regime
+// The same three waves for open lists that reach into global memory (bl_astar2_deep.h: PLN + 2 <= length <= deep_max): wave 0's
+// walk of the NEXT pop -- three rounds in LDS, one or two in global memory -- beside wave 1's pushes, wave 2 as above (the top and the
+// root's children are LDS words in either regime).  Differences from the LDS forms:
+//   * the entry at the back of the array comes from wave 1 (record words 40, 41: key, payload), read back behind its own pushes
+//     (its loads and stores of one address stay in program order); that wait also acknowledges wave 1's global stores before B1;
+//   * wave 0's global stores of a pop are ISSUED before B2, not acknowledged (~500 cycles): wave 1's loads of the same lines follow
+//     them through the same vector L1 (tests/tools/cross_wave_store_probe.hip: 0 stale reads in 2e8 per form, profiles/r06_cross_wave_store_probe.txt);
+//   * s79 remembers where the walk taken ahead ended: 1 in LDS, 2 one global round, 3 two; record word 46 tells wave 1 the regime.
+// Registers as A2D_BODY's (s28-s31, s34-s35, s82-s85, v150-v175); the path test's temporaries are s90-s92 and v224 here.
+#define A2A_WALKD(FIRST, L)                                                                                   \
+    FIRST                                                                                                     \
+    A2T_ROUND("v205", "v206", "v207", "v208", "s[74:75]", "s[64:65]", "")                                     \
+    A2T_ROUND("v240", "v241", "v242", "v243", "s[76:77]", "s[64:65]", "")                                     \
+    A2D_ROUND2_PAYLOAD("v241", "s[76:77]")                                                                    \
+    "s_mov_b32 s79, 1\n\t"                                                                                    \
+    "s_mov_b32 s81, s78\n\t"                                                                                  \
+    "s_cmp_ge_u32 s40, %[kslots]\n\t"                                                                         \
+    "s_cbranch_scc0 " L "9f\n\t"                                                                              \
+    A2D_GROUND_ASK("v155", "v156", "v159", "s[82:83]", "v[164:165]")                                          \
+    "s_waitcnt vmcnt(0)\n\t"                                                                                  \
+    A2D_GROUND_DECIDE("v155", "v156", "v157", "v158", "v159", "s[82:83]", "v164", "v165")                     \
+    "v_readlane_b32 s78, v155, s70\n\t"                                                                       \
+    "s_mov_b32 s79, 2\n\t"                                                                                    \
+    "s_add_i32 s81, s78, 1\n\t"                                                                               \
+    "s_lshl_b32 s71, s78, 1\n\t"                                                                              \
+    "s_add_i32 s71, s71, 1\n\t"                                                                               \
+    "s_cmp_lt_u32 s71, s40\n\t"                                                                               \
+    "s_cselect_b32 s71, s70, 0\n\t"                                                                           \
+    "s_cmp_ge_u32 s71, 31\n\t"                       /* the walk's node on the round's last level has a child: a second global round */ \
+    "s_cbranch_scc0 " L "9f\n\t"                                                                              \
+    "s_add_i32 s78, s78, 1\n\t"                                                                               \
+    A2D_GROUND_ASK("v171", "v172", "v175", "s[34:35]", "v[166:167]")                                          \
+    "s_waitcnt vmcnt(0)\n\t"                                                                                  \
+    A2D_GROUND_DECIDE("v171", "v172", "v173", "v174", "v175", "s[34:35]", "v166", "v167")                     \
+    "v_readlane_b32 s81, v171, s70\n\t"                                                                       \
+    "s_add_i32 s81, s81, 1\n\t"                                                                               \
+    "s_mov_b32 s79, 3\n\t"                                                                                    \
+    L "9:\n\t"
+
+// A2D_LAND, and where the value landed (1-based node) into the record's word 42 for wave 1: the pop wrote the nodes from the root to
+// there.  The usual landing -- key slot and payload both global -- in 13 instructions instead of A2D_LAND's 21.
+#define A2A_LANDD(TAG)                                                                                        \
+    "s_mov_b64 exec, -1\n\t"                                                                                  \
+    "s_add_i32 s70, s71, 1\n\t"                                                                               \
+    "v_mov_b32 v224, s70\n\t"                                                                                 \
+    "s_cmp_lt_u32 s70, %[kslots]\n\t"                                                                         \
+    "s_cbranch_scc1 " TAG "1f\n\t"                                                                            \
+    "s_lshl_b32 s70, s70, 1\n\t"                                                                              \
+    "v_mov_b32 v220, s70\n\t"                                                                                 \
+    "s_lshl_b32 s70, s71, 2\n\t"                                                                              \
+    "v_mov_b32 v222, s70\n\t"                                                                                 \
+    "s_mov_b64 exec, 1\n\t"                                                                                   \
+    "global_store_short v220, v193, s[30:31]\n\t"                                                             \
+    "global_store_dword v222, v197, s[28:29]\n\t"                                                             \
+    "s_branch " TAG "2f\n\t"                                                                                  \
+    TAG "1:\n\t"                                                                                              \
+    A2D_LAND                                                                                                  \
+    "s_mov_b64 exec, 1\n\t"                                                                                   \
+    TAG "2:\n\t"                                                                                              \
+    "ds_write_b32 v214, v224 offset:40\n\t"                                                                   \
+    "s_mov_b64 exec, -1\n\t"
+
+#define A2A_BODY_POPD                                                                                         \
+    "s_mov_b32 s40, %[len]\n\t"                                                                               \
+    "s_mov_b32 s41, %[pops]\n\t"                                                                              \
+    "s_mov_b32 s42, %[pushes]\n\t"                                                                            \
+    A2W_ENTRY                                                                                                 \
+    "ds_read_b128 v[150:153], v191 offset:4160\n\t"                                                           \
+    "ds_read_b32 v154, v191 offset:4176\n\t"                                                                  \
+    "s_waitcnt lgkmcnt(0)\n\t"                                                                                \
+    A2T_RSF("s30", "v150") A2T_RSF("s31", "v151") A2T_RSF("s28", "v152") A2T_RSF("s29", "v153") A2T_RSF("s58", "v154") \
+    "s_mov_b32 s88, 0\n\t"                                                                                    \
+    "s_mov_b32 s80, 0\n\t"                                                                                    \
+    "s_mov_b32 s79, 0\n\t"                           /* no walk taken ahead */                                \
+    A2W_ACC_ZERO("s94") A2W_ACC_ZERO("s95") A2W_ACC_ZERO("s86")                                               \
+    "v_add_u32 v214, 4224, v191\n\t"                 /* the record */                                         \
+    "v_mov_b32 v216, 3\n\t"                          /* run word: "go, and forget what you foresaw" */        \
+    "v_mov_b32 v217, 1\n\t"                          /* ... "go" (and the regime word: deep) */               \
+    "v_mov_b32 v219, 0\n\t"                                                                                   \
+    "v_mov_b32 v225, 4\n\t"                          /* ... "park" */                                         \
+    "v_mov_b32 v224, s40\n\t"                                                                                 \
+    "s_mov_b64 exec, 1\n\t"                                                                                   \
+    "ds_write_b32 v214, v216 offset:48\n\t"                                                                   \
+    "ds_write_b32 v214, v224 offset:12\n\t"          /* the length, for the other waves */                    \
+    "ds_write_b32 v214, v217 offset:56\n\t"          /* the regime, for wave 1 */                             \
+    /* the entry at the back, this once by this wave (wave 1 hands over the later ones): key slot s40, payload entry s40 - 1 */ \
+    "s_mov_b64 exec, -1\n\t"                                                                                  \
+    "s_lshl_b32 s70, s40, 1\n\t"                                                                              \
+    "v_mov_b32 v168, s70\n\t"                                                                                 \
+    "s_min_u32 s71, s70, %[kmax2]\n\t"                                                                        \
+    "v_mov_b32 v160, s71\n\t"                                                                                 \
+    "ds_read_u16 v162, v160\n\t"                                                                              \
+    "s_cmp_ge_u32 s40, %[kslots]\n\t"                                                                         \
+    "s_cselect_b64 s[38:39], -1, 0\n\t"                                                                       \
+    "s_mov_b64 exec, s[38:39]\n\t"                                                                            \
+    "global_load_ushort v169, v168, s[30:31]\n\t"                                                             \
+    "s_mov_b64 exec, -1\n\t"                                                                                  \
+    "s_lshl_b32 s71, s40, 2\n\t"                                                                              \
+    "s_add_i32 s71, s71, -4\n\t"                                                                              \
+    "v_mov_b32 v170, s71\n\t"                                                                                 \
+    "global_load_dword v163, v170, s[28:29]\n\t"                                                              \
+    "s_waitcnt vmcnt(0) lgkmcnt(0)\n\t"                                                                       \
+    "v_cndmask_b32_e64 v162, v162, v169, s[38:39]\n\t"                                                        \
+    "s_mov_b64 exec, 1\n\t"                                                                                   \
+    "ds_write_b64 v214, v[162:163] offset:32\n\t"                                                             \
+    "s_mov_b64 exec, -1\n\t"                                                                                  \
+    "v_min_u32 v215, 3, v188\n\t"                                                                             \
+    "v_lshl_add_u32 v215, v215, 2, v214\n\t"                                                                  \
+    "v_add_u32 v215, 16, v215\n\t"                   /* the lane's word of where the pushes landed */         \
+    "s_waitcnt lgkmcnt(0)\n\t"                                                                                \
+    /* ================================================================== one iteration */                    \
+    "1:\n\t"                                                                                                  \
+    "s_cmp_lg_u32 s88, 0\n\t"                        /* the last expansion reached the goal */                \
+    "s_cbranch_scc1 92f\n\t"                                                                                  \
+    "s_cmp_ge_u32 s41, s50\n\t"                                                                               \
+    "s_cbranch_scc1 93f\n\t"                                                                                  \
+    "s_sub_u32 s70, s40, %[dlo]\n\t"                                                                          \
+    "s_cmp_gt_u32 s70, s58\n\t"                      /* len < PLN + 2 (wraps) or beyond the deep loop's depth */ \
+    "s_cbranch_scc1 91f\n\t"                                                                                  \
+    "2:\n\t"                                                                                                  \
+    A2W_TIMED_BARRIER("s94")                     /* B1: the pushes are in; wave 2 takes the top from here */ \
+    "ds_read_b32 v210, v215\n\t"                     /* where they landed: lane j the j-th push */            \
+    "ds_read_b64 v[212:213], v214 offset:32\n\t"     /* the entry at the back: key, payload */                \
+    "s_lshl_b32 s70, s40, 1\n\t"                                                                              \
+    "s_min_u32 s71, s70, %[kmax2]\n\t"                                                                        \
+    "v_mov_b32 v191, s71\n\t"                                                                                 \
+    "s_cmp_ge_u32 s40, %[kslots]\n\t"                                                                         \
+    "s_cselect_b64 s[38:39], -1, 0\n\t"              /* its key slot is global */                             \
+    "s_add_i32 s40, s40, -1\n\t"                                                                              \
+    /* the slot the last entry leaves is "behind the heap" from here on (an LDS slot: 0xFFFF) */              \
+    "s_andn2_b64 exec, 1, s[38:39]\n\t"                                                                       \
+    "ds_write_b16 v191, v176\n\t"                                                                             \
+    "s_mov_b64 exec, -1\n\t"                                                                                  \
+    "s_cmp_eq_u32 s79, 0\n\t"                                                                                 \
+    "s_cbranch_scc1 60f\n\t"                                                                                  \
+    /* ---- the walk taken ahead: did it read what the pushes wrote, or the entry that has just left?  (A2A_BODY_POP's test) */ \
+    "s_add_i32 s92, s40, 1\n\t"                                                                               \
+    "s_lshr_b32 s92, s92, 1\n\t"                                                                              \
+    "v_mov_b32 v211, s92\n\t"                                                                                 \
+    "s_flbit_i32_b32 s71, s81\n\t"                                                                            \
+    "s_mov_b64 s[90:91], 8\n\t"                                                                               \
+    "s_waitcnt lgkmcnt(0)\n\t"                                                                                \
+    "v_cndmask_b32_e64 v210, v210, v211, s[90:91]\n\t"                                                        \
+    "v_ffbh_u32 v211, v210\n\t"                                                                               \
+    "v_subrev_u32 v211, s71, v211\n\t"                                                                        \
+    "v_lshrrev_b32_e64 v224, v211, s81\n\t"                                                                   \
+    "v_cmp_eq_u32 vcc, v224, v210\n\t"                                                                        \
+    "s_and_b64 s[90:91], vcc, 15\n\t"                                                                         \
+    "s_cbranch_scc1 60f\n\t"                                                                                  \
+    "61:\n\t"                                                                                                 \
+    "s_waitcnt vmcnt(0) lgkmcnt(0)\n\t"                                                                       \
+    "v_mov_b32 v193, v212\n\t"                                                                                \
+    "v_mov_b32 v197, v213\n\t"                                                                                \
+    "v_cndmask_b32_e64 v243, v243, v154, s[84:85]\n\t"                                                        \
+    /* ---- the climb and one pass of stores, by where the walk ended */                                      \
+    "s_cmp_eq_u32 s79, 1\n\t"                                                                                 \
+    "s_cbranch_scc1 30f\n\t"                                                                                  \
+    "s_cmp_eq_u32 s79, 3\n\t"                                                                                 \
+    "s_cbranch_scc1 50f\n\t"                                                                                  \
+    /* one round in global memory */                                                                          \
+    A2T_CLIMB("v156", "v157", "s[82:83]", "31f")                                                              \
+    "32:\n\t"                                                                                                 \
+    A2W_GATE_ASK                                                                                              \
+    A2T_ADDR("v200", "v204") A2T_ADDR("v205", "v209") A2T_ADDR("v240", "v244")                                \
+    "s_waitcnt lgkmcnt(0)\n\t"                                                                                \
+    A2W_STORES_GATE("70")                                                                                     \
+    A2T_STORE("v200", "v204", "v202", "v203", "s[72:73]") A2T_STORE("v205", "v209", "v207", "v208", "s[74:75]") \
+    A2T_STORE("v240", "v244", "v242", "v243", "s[76:77]")                                                     \
+    A2D_STORE3("s[82:83]")                                                                                    \
+    A2A_LANDD("41")                                                                                           \
+    /* ---- the pop is in (its global stores are on their way): wave 1 pushes, this one takes the next pop's walk */ \
+    "40:\n\t"                                                                                                 \
+    "s_waitcnt lgkmcnt(0)\n\t"                                                                                \
+    A2W_TIMED_BARRIER("s95")                     /* B2 */                                                 \
+    "ds_read_b128 v[210:213], v214\n\t"              /* the expansion's outcome: push mask, goal mask, popped payload */ \
+    "s_add_i32 s41, s41, 1\n\t"                                                                               \
+    "s_mov_b32 s79, 0\n\t"                                                                                    \
+    "s_mov_b32 s78, 1\n\t"                                                                                    \
+    A2A_ROUND_ASK("v200")                                                                                     \
+    "s_waitcnt lgkmcnt(1)\n\t"                                                                                \
+    "v_readfirstlane_b32 s87, v210\n\t"                                                                       \
+    "v_readfirstlane_b32 s88, v211\n\t"                                                                       \
+    "v_readfirstlane_b32 s80, v212\n\t"                                                                       \
+    "s_bcnt1_i32_b32 s70, s87\n\t"                                                                            \
+    "s_add_i32 s40, s40, s70\n\t"                    /* the length once the pushes are in */                  \
+    "s_add_i32 s42, s42, s70\n\t"                                                                             \
+    "s_cmp_lg_u32 s88, 0\n\t"                        /* the loop ends at the top of the next iteration: no walk */ \
+    "s_cbranch_scc1 1b\n\t"                                                                                   \
+    "s_cmp_ge_u32 s41, s50\n\t"                                                                               \
+    "s_cbranch_scc1 1b\n\t"                                                                                   \
+    "s_sub_u32 s70, s40, %[dlo]\n\t"                                                                          \
+    "s_cmp_gt_u32 s70, s58\n\t"                                                                               \
+    "s_cbranch_scc1 1b\n\t"                                                                                   \
+    "s_add_i32 s40, s40, -1\n\t"                     /* (the walk's heap: without the entry at the back) */   \
+    A2A_WALKD(A2A_ROUND_REST("v200", "v201", "v202", "v203", "s[72:73]", "s[62:63]"), "5")                    \
+    "s_add_i32 s40, s40, 1\n\t"                                                                               \
+    "s_branch 2b\n\t"                                                                                         \
+    /* ================================================================== out of line */                      \
+    "60:\n\t"                                                                                                 \
+    A2W_ACC_COUNT("s86")                                                                                      \
+    "s_mov_b32 s78, 1\n\t"                                                                                    \
+    A2A_WALKD(A2T_ROUND("v200", "v201", "v202", "v203", "s[72:73]", "s[62:63]", ""), "6")                     \
+    "s_branch 61b\n\t"                                                                                        \
+    /* the walk ended inside LDS */                                                                           \
+    "30:\n\t"                                                                                                 \
+    A2T_CLIMB("v241", "v242", "s[76:77]", "35f")                                                              \
+    "36:\n\t"                                                                                                 \
+    A2W_GATE_ASK                                                                                              \
+    A2T_ADDR("v200", "v204") A2T_ADDR("v205", "v209") A2T_ADDR("v240", "v244")                                \
+    "s_waitcnt lgkmcnt(0)\n\t"                                                                                \
+    A2W_STORES_GATE("75")                                                                                     \
+    A2T_STORE("v200", "v204", "v202", "v203", "s[72:73]") A2T_STORE("v205", "v209", "v207", "v208", "s[74:75]") \
+    A2T_STORE("v240", "v244", "v242", "v243", "s[76:77]")                                                     \
+    A2A_LANDD("42")                                                                                           \
+    "s_branch 40b\n\t"                                                                                        \
+    /* two rounds in global memory */                                                                         \
+    "50:\n\t"                                                                                                 \
+    A2T_CLIMB("v172", "v173", "s[34:35]", "51f")                                                              \
+    "52:\n\t"                                                                                                 \
+    A2W_GATE_ASK                                                                                              \
+    A2T_ADDR("v200", "v204") A2T_ADDR("v205", "v209") A2T_ADDR("v240", "v244")                                \
+    "s_waitcnt lgkmcnt(0)\n\t"                                                                                \
+    A2W_STORES_GATE("78")                                                                                     \
+    A2T_STORE("v200", "v204", "v202", "v203", "s[72:73]") A2T_STORE("v205", "v209", "v207", "v208", "s[74:75]") \
+    A2T_STORE("v240", "v244", "v242", "v243", "s[76:77]")                                                     \
+    A2D_STORE3("s[82:83]")                                                                                    \
+    A2D_STORE4("s[34:35]")                                                                                    \
+    A2A_LANDD("43")                                                                                           \
+    "s_branch 40b\n\t"                                                                                        \
+    /* rare climbs */                                                                                         \
+    "51:\n\t"                                                                                                 \
+    A2T_RARE_UP("s[34:35]", "v156", "v157", "s[82:83]", "52b", "53")                                          \
+    A2T_RARE_UP("s[82:83]", "v241", "v242", "s[76:77]", "52b", "54")                                          \
+    A2T_RARE_UP("s[76:77]", "v206", "v207", "s[74:75]", "52b", "55")                                          \
+    A2T_RARE_UP("s[74:75]", "v201", "v202", "s[72:73]", "52b", "56")                                          \
+    A2T_RARE_ROOT("s[72:73]", "52b")                                                                          \
+    "31:\n\t"                                                                                                 \
+    A2T_RARE_UP("s[82:83]", "v241", "v242", "s[76:77]", "32b", "33")                                          \
+    A2T_RARE_UP("s[76:77]", "v206", "v207", "s[74:75]", "32b", "34")                                          \
+    A2T_RARE_UP("s[74:75]", "v201", "v202", "s[72:73]", "32b", "39")                                          \
+    A2T_RARE_ROOT("s[72:73]", "32b")                                                                          \
+    "35:\n\t"                                                                                                 \
+    A2T_RARE_UP("s[76:77]", "v206", "v207", "s[74:75]", "36b", "37")                                          \
+    A2T_RARE_UP("s[74:75]", "v201", "v202", "s[72:73]", "36b", "38")                                          \
+    A2T_RARE_ROOT("s[72:73]", "36b")                                                                          \
+    /* ---- exits: the other waves are parked behind the barrier (the pushes are in by then) */               \
+    "91:\n\t"                                                                                                 \
+    "s_mov_b32 %[code], 1\n\t"                                                                                \
+    "s_branch 98f\n\t"                                                                                        \
+    "92:\n\t"                                                                                                 \
+    "s_mov_b32 %[code], 2\n\t"                                                                                \
+    "s_branch 98f\n\t"                                                                                        \
+    "93:\n\t"                                                                                                 \
+    "s_mov_b32 %[code], 3\n\t"                                                                                \
+    "98:\n\t"                                                                                                 \
+    "s_mov_b64 exec, 1\n\t"                                                                                   \
+    "ds_write_b32 v214, v225 offset:48\n\t"                                                                   \
+    "ds_write_b32 v214, v219 offset:56\n\t"          /* the regime word back to "LDS" */                      \
+    "s_mov_b64 exec, -1\n\t"                                                                                  \
+    "s_waitcnt lgkmcnt(0)\n\t"                                                                                \
+    "s_barrier\n\t"                                                                                           \
+    "s_branch 99f\n\t"                                                                                        \
+    "94:\n\t"                                        /* wave 2's flag never came: no barrier would either */  \
+    "s_mov_b32 %[code], 4\n\t"                                                                                \
+    "99:\n\t"                                                                                                 \
+    "s_waitcnt vmcnt(0) lgkmcnt(0)\n\t"                                                                       \
+    A2W_ACC_OUT("s94", "4192") A2W_ACC_OUT("s95", "4200") A2W_ACC_OUT("s86", "4212")                                                                       \
+    "s_mov_b32 %[len], s40\n\t"                                                                               \
+    "s_mov_b32 %[pops], s41\n\t"                                                                              \
+    "s_mov_b32 %[pushes], s42\n\t"                                                                            \
+    "s_mov_b32 %[gm], s88\n\t"                                                                                \
+    "s_mov_b32 %[pt], s80\n\t"
+
+// wave 1 for both regimes: the LDS pushes of A2A_BODY_PUSH3, or (regime word 1) bl_astar2_deep.h's with where they landed, and then
+// the entry at the back of the array for wave 0's next pop.  s61 = the regime; v172 landings, v173 record, v174 / v175 the lane's
+// landing word / candidate.
+#define A2A_PUSH_WHERE(J)                                                                                     \
+    "s_lshr_b32 s39, s71, 1\n\t"                                                                              \
+    "s_max_u32 s39, s39, 1\n\t"                                                                               \
+    "v_writelane_b32 v172, s39, " J "\n\t"                                                                    \
+    /* what the array's last slot holds now: the entry itself if no ancestor dropped, else its parent (lane 0 of the ancestors) */ \
+    "v_readlane_b32 s36, v234, 0\n\t"                                                                         \
+    "v_readlane_b32 s37, v235, 0\n\t"                                                                         \
+    "s_cmp_eq_u32 s71, s78\n\t"                                                                               \
+    "s_cselect_b32 s36, s89, s36\n\t"                                                                         \
+    "s_cselect_b32 s37, s90, s37\n\t"
+#define A2A_PUSH_REST_L(J)                                                                                    \
+    "s_ff1_i32_b32 s91, s87\n\t"                                                                              \
+    "s_add_i32 s70, s87, -1\n\t"                                                                              \
+    "s_and_b32 s87, s87, s70\n\t"                                                                             \
+    "v_readlane_b32 s89, v226, s91\n\t"                                                                       \
+    "s_waitcnt lgkmcnt(1)\n\t"                                                                                \
+    "s_nop 1\n\t"                                                                                             \
+    "v_cmp_lt_u32 vcc, s89, v234\n\t"                                                                         \
+    "s_not_b64 s[92:93], vcc\n\t"                                                                             \
+    "s_ff1_i32_b64 s70, s[92:93]\n\t"                                                                         \
+    "s_bfm_b64 s[92:93], s70, 0\n\t"                                                                          \
+    "s_lshr_b32 s70, s78, s70\n\t"                                                                            \
+    "s_lshr_b32 s39, s70, 1\n\t"                                                                              \
+    "s_max_u32 s39, s39, 1\n\t"                                                                               \
+    "v_writelane_b32 v172, s39, " J "\n\t"                                                                    \
+    "s_lshl_b32 s71, s70, 1\n\t"                                                                              \
+    "s_lshl_b32 s70, s70, 2\n\t"                                                                              \
+    "s_add_i32 s70, s70, s56\n\t"                                                                             \
+    "s_add_i32 s70, s70, -4\n\t"                                                                              \
+    "s_waitcnt lgkmcnt(0)\n\t"                                                                                \
+    "v_mov_b32 v232, s71\n\t"                                                                                 \
+    "v_mov_b32 v238, s70\n\t"                                                                                 \
+    "s_mov_b64 exec, s[92:93]\n\t"                                                                            \
+    "ds_write_b16 v236, v234\n\t"                                                                             \
+    "ds_write_b32 v237, v235\n\t"                                                                             \
+    "s_lshl_b64 exec, 1, s91\n\t"                                                                             \
+    "ds_write_b16 v232, v226\n\t"                                                                             \
+    "ds_write_b32 v238, v227\n\t"                                                                             \
+    "s_mov_b64 exec, -1\n\t"                                                                                  \
+    "s_add_i32 s40, s40, 1\n\t"
+#define A2A_BODY_PUSH3D                                                                                       \
+    A2W_ENTRY                                                                                                 \
+    "ds_read_b128 v[150:153], v191 offset:4160\n\t"                                                           \
+    "s_waitcnt lgkmcnt(0)\n\t"                                                                                \
+    A2T_RSF("s30", "v150") A2T_RSF("s31", "v151") A2T_RSF("s28", "v152") A2T_RSF("s29", "v153")               \
+    "s_mov_b32 s40, 0\n\t"                                                                                    \
+    "s_mov_b32 s61, 0\n\t"                                                                                    \
+    A2W_ACC_ZERO("s94") A2W_ACC_ZERO("s95")                                                                                       \
+    "v_add_u32 v173, 4224, v191\n\t"                 /* the record */                                         \
+    "v_min_u32 v174, 3, v188\n\t"                                                                             \
+    "v_lshl_add_u32 v175, v174, 3, v173\n\t"                                                                  \
+    "v_add_u32 v175, 64, v175\n\t"                   /* the lane's candidate (lanes 0..3): words 48..55 */    \
+    "v_lshl_add_u32 v174, v174, 2, v173\n\t"                                                                  \
+    "v_add_u32 v174, 16, v174\n\t"                   /* the lane's word of where the pushes landed */         \
+    "10:\n\t"                                                                                                 \
+    A2W_TIMED_BARRIER("s94")                     /* B1 */                                                 \
+    "ds_read_b32 v240, v173 offset:48\n\t"           /* the run word */                                       \
+    "ds_read_b32 v242, v173 offset:12\n\t"           /* the length, the regime (of use behind run word 3 only) */ \
+    "ds_read_b32 v241, v173 offset:56\n\t"                                                                    \
+    "s_waitcnt lgkmcnt(0)\n\t"                                                                                \
+    "v_readfirstlane_b32 s70, v240\n\t"                                                                       \
+    "s_cmp_eq_u32 s70, 2\n\t"                                                                                 \
+    "s_cbranch_scc1 99f\n\t"                                                                                  \
+    "s_cmp_eq_u32 s70, 4\n\t"                        /* parked: wave 0 is elsewhere */                        \
+    "s_cbranch_scc1 10b\n\t"                                                                                  \
+    "s_cmp_eq_u32 s70, 3\n\t"                                                                                 \
+    "s_cbranch_scc0 11f\n\t"                                                                                  \
+    "v_readfirstlane_b32 s40, v242\n\t"                                                                       \
+    "v_readfirstlane_b32 s61, v241\n\t"                                                                       \
+    "11:\n\t"                                                                                                 \
+    "s_add_i32 s40, s40, -1\n\t"                                                                              \
+    "s_cmp_lg_u32 s61, 0\n\t"                                                                                 \
+    "s_cbranch_scc0 12f\n\t"                                                                                  \
+    /* deep regime: the first push's ancestors (a global round trip) are asked for NOW, beside the pop -- whether the pop wrote one */ \
+    /* of those the push looked at is seen behind B2 (the pop writes the nodes from the root to where its value landed) */ \
+    A2D_PUSH_READ                                                                                             \
+    "12:\n\t"                                                                                                 \
+    "s_barrier\n\t"                                  /* B2: the pop is in, the expansion's record is there */ \
+    "ds_read_b32 v210, v173\n\t"                     /* the push mask */                                      \
+    "ds_read_b64 v[226:227], v175\n\t"               /* the lane's candidate */                               \
+    "v_mov_b32 v172, 0x7fffffff\n\t"                                                                          \
+    "s_cmp_lg_u32 s61, 0\n\t"                                                                                 \
+    "s_cbranch_scc1 20f\n\t"                                                                                  \
+    A2T_PUSH_READ                                  /* the first push's ancestors: they need the length only */ \
+    "s_waitcnt lgkmcnt(2)\n\t"                                                                                \
+    "v_readfirstlane_b32 s87, v210\n\t"                                                                       \
+    A2T_PUSH_CHECK("17f") A2A_PUSH_REST_L("0")                                                                \
+    A2T_PUSH_CHECK("17f") A2T_PUSH_READ A2A_PUSH_REST_L("1")                                                  \
+    A2T_PUSH_CHECK("17f") A2T_PUSH_READ A2A_PUSH_REST_L("2")                                                  \
+    "17:\n\t"                                                                                                 \
+    "s_mov_b64 exec, 15\n\t"                                                                                  \
+    "ds_write_b32 v174, v172\n\t"                                                                             \
+    "s_mov_b64 exec, -1\n\t"                                                                                  \
+    "s_waitcnt lgkmcnt(0)\n\t"                                                                                \
+    "s_branch 10b\n\t"                                                                                        \
+    /* ---- the deep regime */                                                                                \
+    "20:\n\t"                                                                                                 \
+    "ds_read_b32 v241, v173 offset:40\n\t"           /* where the pop's value landed (1-based node) */        \
+    "s_mov_b32 s36, -1\n\t"                          /* no push made */                                       \
+    "s_waitcnt lgkmcnt(0)\n\t"                                                                                \
+    "v_readfirstlane_b32 s87, v210\n\t"                                                                       \
+    "v_readfirstlane_b32 s85, v241\n\t"                                                                       \
+    A2T_PUSH_CHECK("27f") A2D_PUSH_PICK A2D_PUSH_DECIDE                                                       \
+    /* the ancestor that stopped the entry (node s71 >> 1; none: it rose to the root) -- did the pop write it?  If not, it wrote */ \
+    /* none of the deeper ones the push looked at either: what was read in front of the pop is what is there now */ \
+    "s_lshr_b32 s84, s71, 1\n\t"                                                                              \
+    "s_cmp_eq_u32 s84, 0\n\t"                                                                                 \
+    "s_cbranch_scc1 24f\n\t"                                                                                  \
+    "s_flbit_i32_b32 s82, s84\n\t"                                                                            \
+    "s_flbit_i32_b32 s83, s85\n\t"                                                                            \
+    "s_sub_i32 s82, s82, s83\n\t"                                                                             \
+    "s_lshr_b32 s82, s85, s82\n\t"                   /* (a stopper deeper than the landing is larger than it: never equal) */ \
+    "s_cmp_eq_u32 s82, s84\n\t"                                                                               \
+    "s_cbranch_scc0 25f\n\t"                                                                                  \
+    "24:\n\t"                                        /* it did: read again */                                 \
+    A2W_ACC_COUNT("s95")                                                                                      \
+    A2D_PUSH_READ A2D_PUSH_DECIDE                                                                             \
+    "25:\n\t"                                                                                                 \
+    A2D_PUSH_STORES A2A_PUSH_WHERE("0")                                                                       \
+    A2T_PUSH_CHECK("27f") A2D_PUSH_READ A2D_PUSH_REST A2A_PUSH_WHERE("1")                                     \
+    A2T_PUSH_CHECK("27f") A2D_PUSH_READ A2D_PUSH_REST A2A_PUSH_WHERE("2")                                     \
+    "27:\n\t"                                                                                                 \
+    "s_cmp_eq_u32 s36, -1\n\t"                                                                                \
+    "s_cbranch_scc1 26f\n\t"                                                                                  \
+    /* the entry at the back of the array as the pushes leave it: out of the last push's registers */         \
+    "v_mov_b32 v162, s36\n\t"                                                                                 \
+    "v_mov_b32 v163, s37\n\t"                                                                                 \
+    "s_waitcnt vmcnt(0)\n\t"                         /* (this wave's global stores are acknowledged in front of B1) */ \
+    "s_branch 28f\n\t"                                                                                        \
+    "26:\n\t"                                                                                                 \
+    /* no push: read it -- key slot s40 (LDS or global), payload entry s40 - 1 (global) */                    \
+    "s_lshl_b32 s70, s40, 1\n\t"                                                                              \
+    "v_mov_b32 v168, s70\n\t"                                                                                 \
+    "s_min_u32 s71, s70, %[kmax2]\n\t"                                                                        \
+    "v_mov_b32 v160, s71\n\t"                                                                                 \
+    "ds_read_u16 v162, v160\n\t"                                                                              \
+    "s_cmp_ge_u32 s40, %[kslots]\n\t"                                                                         \
+    "s_cselect_b64 s[38:39], -1, 0\n\t"                                                                       \
+    "s_mov_b64 exec, s[38:39]\n\t"                                                                            \
+    "global_load_ushort v169, v168, s[30:31]\n\t"                                                             \
+    "s_mov_b64 exec, -1\n\t"                                                                                  \
+    "s_lshl_b32 s71, s40, 2\n\t"                                                                              \
+    "s_add_i32 s71, s71, -4\n\t"                                                                              \
+    "v_mov_b32 v170, s71\n\t"                                                                                 \
+    "global_load_dword v163, v170, s[28:29]\n\t"                                                              \
+    "s_waitcnt vmcnt(0) lgkmcnt(0)\n\t"              /* (this wave's global stores are acknowledged with it) */ \
+    "v_cndmask_b32_e64 v162, v162, v169, s[38:39]\n\t"                                                        \
+    "28:\n\t"                                                                                                 \
+    "s_mov_b64 exec, 1\n\t"                                                                                   \
+    "ds_write_b64 v173, v[162:163] offset:32\n\t"                                                             \
+    "s_mov_b64 exec, 15\n\t"                                                                                  \
+    "ds_write_b32 v174, v172\n\t"                                                                             \
+    "s_mov_b64 exec, -1\n\t"                                                                                  \
+    "s_waitcnt lgkmcnt(0)\n\t"                                                                                \
+    "s_branch 10b\n\t"                                                                                        \
+    "99:\n\t"                                                                                                 \
+    A2W_ACC_OUT("s94", "4180") A2W_ACC_OUT("s95", "4184")
+
+#define A2A_PUSH3D_CLOBBERS A2D_CLOBBERS
+
 #define A2A_PUSH3_CLOBBERS A2T_CLOBBERS, "v167", "v168", "v169", "v171"
 
 #define A2A_EXPUSH_CLOBBERS A2W_EXPAND_CLOBBERS, "v164", "v167", "v168", "v169", "v170", "v171", "v246"

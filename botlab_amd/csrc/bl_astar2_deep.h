@@ -137,12 +137,16 @@
     "v_add_u32 v165, -1, v231\n\t"                                                                            \
     "v_lshlrev_b32 v166, 2, v165\n\t"                /* payload global offset, */                             \
     "v_add_u32 v237, s56, v166\n\t"                  /* payload LDS address */
-#define A2D_PUSH_REST                                                                                         \
+// (REST in three pieces -- which candidate, how far it rises, the stores -- for bl_astar2_ahead.h, which asks for the first push's
+// ancestors before the pop is in and looks at where the pop landed between the second and the third)
+#define A2D_PUSH_REST A2D_PUSH_PICK A2D_PUSH_DECIDE A2D_PUSH_STORES
+#define A2D_PUSH_PICK                                                                                         \
     "s_ff1_i32_b32 s91, s87\n\t"                                                                              \
     "s_add_i32 s70, s87, -1\n\t"                                                                              \
     "s_and_b32 s87, s87, s70\n\t"                                                                             \
     "v_readlane_b32 s89, v226, s91\n\t"                                                                       \
-    "v_readlane_b32 s90, v227, s91\n\t"                                                                       \
+    "v_readlane_b32 s90, v227, s91\n\t"
+#define A2D_PUSH_DECIDE                                                                                       \
     "s_waitcnt vmcnt(0) lgkmcnt(0)\n\t"                                                                       \
     "v_cndmask_b32_e64 v234, v234, v162, s[34:35]\n\t"                                                        \
     "v_cndmask_b32_e64 v235, v235, v164, s[38:39]\n\t"                                                        \
@@ -150,7 +154,8 @@
     "s_not_b64 s[92:93], vcc\n\t"                                                                             \
     "s_ff1_i32_b64 s70, s[92:93]\n\t"                                                                         \
     "s_bfm_b64 s[92:93], s70, 0\n\t"                 /* the ancestors that drop */                            \
-    "s_lshr_b32 s71, s78, s70\n\t"                   /* the slot the new entry takes */                       \
+    "s_lshr_b32 s71, s78, s70\n\t"                   /* the slot the new entry takes */
+#define A2D_PUSH_STORES                                                                                       \
     "v_cmp_gt_u32 vcc, %[kslots], v231\n\t"                                                                   \
     "s_and_b64 exec, s[92:93], vcc\n\t"                                                                       \
     "ds_write_b16 v236, v234\n\t"                                                                             \

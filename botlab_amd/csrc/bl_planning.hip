@@ -2481,6 +2481,7 @@ static int astar_prepare(bl_ctx* ctx, const bl_dist* d)
         memset((void*)ctx->astar, 0, sizeof(bl_astar_state));
         ctx->astar->path_head = ASTAR_PATH_HEAD;
         if (getenv("BOTLAB_ASTAR_NO_TURBO")) { const bool off = false; BL_HIP(hipMemcpyToSymbol(HIP_SYMBOL(a2_turbo_enabled), &off, sizeof(off))); }
+        if (getenv("BOTLAB_ASTAR_DEEP_AHEAD") && atoi(getenv("BOTLAB_ASTAR_DEEP_AHEAD")) == 0) { const bool off = false; BL_HIP(hipMemcpyToSymbol(HIP_SYMBOL(a2_deep_ahead_enabled), &off, sizeof(off))); }
         if (getenv("BOTLAB_ASTAR_AHEAD") && atoi(getenv("BOTLAB_ASTAR_AHEAD")) == 0) { const bool off = false; BL_HIP(hipMemcpyToSymbol(HIP_SYMBOL(a2_walk_ahead_enabled), &off, sizeof(off))); }
         if (const char* e = getenv("BOTLAB_ASTAR_PATH_HEAD")) { const int v = atoi(e); if (v >= 1 && v <= ASTAR_PATH_HEAD) ctx->astar->path_head = v; }
         for (int i = 0; i < ASTAR_SLOTS; ++i) {
@@ -2672,7 +2673,9 @@ static void astar_launch_kernel(bl_ctx* ctx, const astar_args& a, int workgroups
     static const bool force_small = getenv("BOTLAB_ASTAR_SMALL_LDS") != nullptr;     // probes: the replanner's footprint on a lone search
     const bool small = ctx->astar_small_lds || force_small;
     if (ctx->astar) ctx->astar->last_kernel = split ? 2 : 1;
-    if (split && small) hipLaunchKernelGGL((k_astar2<a2_small>), dim3(workgroups), dim3(astar2_threads(true)), a2_small::BYTES, ctx->stream, a);
+    // (BOTLAB_ASTAR_SMALL_LDS=3: the small footprint on three waves -- tests reach the deep regime's three-wave loop with short searches)
+    static const bool small3 = force_small && atoi(getenv("BOTLAB_ASTAR_SMALL_LDS")) == 3;
+    if (split && small) hipLaunchKernelGGL((k_astar2<a2_small>), dim3(workgroups), dim3(astar2_threads(!(small3 && !ctx->astar_small_lds))), a2_small::BYTES, ctx->stream, a);
     else if (split) hipLaunchKernelGGL((k_astar2<a2_big>), dim3(workgroups), dim3(astar2_threads()), a2_big::BYTES, ctx->stream, a);
     else if (small) hipLaunchKernelGGL((k_astar<AH_LDS_SMALL, AH_COST_LDS_SMALL>), dim3(workgroups), dim3(64), AH_LDS_SMALL_BYTES, ctx->stream, a);
     else hipLaunchKernelGGL((k_astar<AH_LDS, AH_COST_LDS>), dim3(workgroups), dim3(64), AH_LDS_BYTES, ctx->stream, a);

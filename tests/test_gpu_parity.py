@@ -951,24 +951,25 @@ def _fixtures_in_child(queue_path):
     json.dump(out, open(queue_path, "w"))
 
 
-@pytest.mark.parametrize("env", ["BOTLAB_ASTAR_NO_TURBO", "BOTLAB_ASTAR_V1", "BOTLAB_ASTAR_DUO=0", "BOTLAB_ASTAR_AHEAD=1", "BOTLAB_ASTAR_AHEAD=0"])
+@pytest.mark.parametrize("env", ["BOTLAB_ASTAR_NO_TURBO", "BOTLAB_ASTAR_V1", "BOTLAB_ASTAR_DUO=0", "BOTLAB_ASTAR_AHEAD=1", "BOTLAB_ASTAR_AHEAD=0",
+                                 "BOTLAB_ASTAR_DEEP_AHEAD=0", "BOTLAB_ASTAR_SMALL_LDS=3", "BOTLAB_ASTAR_SMALL_LDS=3,BOTLAB_ASTAR_DEEP_AHEAD=0"])
 def test_astar_fixtures_with_the_other_forms_of_the_search(tmp_path, env):
     """the same fixtures through k_astar2's C++ forms (no straight-line loop), through round 4's k_astar (8-byte entries) -- the
     forms a search falls back to for lists of 0-1 entries, cost tables beyond LDS or below the 16-bit key range -- and through the
     one-wave straight-line loop (what the replanner's units run), through round 5's two-wave loop (bl_astar2_duo.h, BOTLAB_ASTAR_AHEAD=0)
     and through the two-wave form of the loop single searches take by default (bl_astar2_ahead.h: the next pop's walk beside the
-    pushes, expansions made ahead; three waves by default)"""
+    pushes, expansions made ahead; three waves by default); with the one-wave loop beyond LDS in place of the three-wave one
+    (BOTLAB_ASTAR_DEEP_AHEAD=0), and with the 40 KB footprint on three waves (BOTLAB_ASTAR_SMALL_LDS=3: every maze search of more than
+    ~5 000 pops then crosses into the deep regime and back, and the three-wave loops run with the small footprint's tree shape)"""
     import json
     import subprocess
     out = str(tmp_path / "res.json")
     code = ("import sys, os; sys.path.insert(0, %r); sys.path.insert(0, %r); import test_gpu_parity as t; t._fixtures_in_child(%r)"
             % (os.path.dirname(os.path.abspath(__file__)), os.path.dirname(os.path.dirname(os.path.abspath(__file__))), out))
     e = dict(os.environ)
-    if "=" in env:
-        k, v = env.split("=")
-        e[k] = v
-    else:
-        e[env] = "1"
+    for item in env.split(","):
+        k, _, v = item.partition("=")
+        e[k] = v or "1"
     subprocess.check_call([sys.executable, "-c", code], env=e)
     res = json.load(open(out))
     assert len(res) >= 16 and all(res.values()), {k: v for k, v in res.items() if not v}
