@@ -1,4 +1,5 @@
-// bl_astar2_ahead.h -- the LDS-regime search loop of k_astar2 on three (or two) wavefronts, with the NEXT pop's walk taken beside the pushes.
+// bl_astar2_ahead.h -- the search loop of k_astar2 on three (or two) wavefronts, with the NEXT pop's walk taken beside the pushes: the
+// LDS regime first, its form for open lists that reach into global memory at the end of the file ("the deep regime").
 // The default for searches that have their compute unit to themselves (round 6).
 //
 // std::pop_heap moves the hole from the root to a leaf along the smaller children (stl_heap.h __adjust_heap) BEFORE it looks at the
@@ -580,7 +581,11 @@
 //     (its loads and stores of one address stay in program order); that wait also acknowledges wave 1's global stores before B1;
 //   * wave 0's global stores of a pop are ISSUED before B2, not acknowledged (~500 cycles): wave 1's loads of the same lines follow
 //     them through the same vector L1 (tests/tools/cross_wave_store_probe.hip: 0 stale reads in 2e8 per form, profiles/r06_cross_wave_store_probe.txt);
+//   * wave 1's first push's ancestors -- a global round trip -- are asked for at B1, beside the pop, and checked behind B2 against
+//     where the pop's value landed (record word 42: the pop wrote the nodes from the root to there);
 //   * s79 remembers where the walk taken ahead ended: 1 in LDS, 2 one global round, 3 two; record word 46 tells wave 1 the regime.
+// MEASURED (profiles/r06_astar_deep_three_waves.txt, r06_astar_pop.csv): wide 2 (5.3e5 pops) 1.125 -> 0.881 us per pop, convex 2
+// (1.8e6) 1.154 -> 0.898; wave 0 waits ~110 cycles per pop for wave 1 (three pushes), wave 2 ~900.
 // Registers as A2D_BODY's (s28-s31, s34-s35, s82-s85, v150-v175); the path test's temporaries are s90-s92 and v224 here.
 #define A2A_WALKD(FIRST, L)                                                                                   \
     FIRST                                                                                                     \

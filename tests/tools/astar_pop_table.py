@@ -24,6 +24,7 @@ def run(env):
 
 
 v2, _ = run({})
+d1, _ = run({"BOTLAB_ASTAR_DEEP_AHEAD": "0"})
 duo, _ = run({"BOTLAB_ASTAR_AHEAD": "0"})
 one, _ = run({"BOTLAB_ASTAR_DUO": "0"})
 v1, _ = run({"BOTLAB_ASTAR_V1": "1"})
@@ -31,18 +32,20 @@ cpp, _ = run({"BOTLAB_ASTAR_NO_TURBO": "1", "BOTLAB_ASTAR_DUO": "0"})
 _, st2 = run({"STAMPS": "1", "BOTLAB_ASTAR_DUO": "0"})
 with open(os.path.join(OUT, "r06_astar_pop.csv"), "w") as f:
     f.write("# python3 tests/tools/astar_pop_table.py (tests/tools/astar_probe.py per column; best of 3 host-timed calls of bl_astar_search)\n"
-            "# k_astar2 = split-storage open list with the straight-line loops: in the LDS regime three wavefronts -- pops with the next walk taken\n"
-            "# beside the pushes / pushes / expansions made ahead (bl_astar2_ahead.h, round 6) --, one in the deep loop (bl_astar2_deep.h);\n"
+            "# k_astar2 = split-storage open list with the straight-line loops on three wavefronts -- pops with the next walk taken beside the\n"
+            "# pushes / pushes / expansions made ahead (bl_astar2_ahead.h, round 6) -- in the LDS regime and beyond it; deep_one_wave =\n"
+            "# BOTLAB_ASTAR_DEEP_AHEAD=0: one wave beyond LDS (bl_astar2_deep.h, the default until this round's last change);\n"
             "# duo = BOTLAB_ASTAR_AHEAD=0 (round 5's two-wave loop, bl_astar2_duo.h); one_wave = BOTLAB_ASTAR_DUO=0 (bl_astar2_turbo.h: what the replanner's units run); cpp = the same kernel\n"
             "# with BOTLAB_ASTAR_NO_TURBO=1 (C++ forms only); k_astar = round 4's kernel (BOTLAB_ASTAR_V1=1).  stamped = cycles per pop of the\n"
             "# ONE-wave loop in the -DBL_ASTAR_STAMPS build (every mark drains the LDS queue: shares, not the undisturbed loop's time)\n")
-    f.write("search,pops,pushes,k_astar2_ms,k_astar2_us_per_pop,duo_r05_us_per_pop,one_wave_us_per_pop,cpp_us_per_pop,k_astar_r04_us_per_pop,speedup_vs_r04,stamped_all,stamped_top_and_loads,stamped_pop,stamped_loadwait,stamped_expand,stamped_pushes,clock_GHz\n")
+    f.write("search,pops,pushes,k_astar2_ms,k_astar2_us_per_pop,deep_one_wave_us_per_pop,duo_r05_us_per_pop,one_wave_us_per_pop,cpp_us_per_pop,k_astar_r04_us_per_pop,speedup_vs_r04,stamped_all,stamped_top_and_loads,stamped_pop,stamped_loadwait,stamped_expand,stamped_pushes,clock_GHz\n")
     for i, r in enumerate(v2):
         a = v1[i] if i < len(v1) else None
         c = cpp[i] if i < len(cpp) else None
         o = one[i] if i < len(one) else None
         du = duo[i] if i < len(duo) else None
+        dd = d1[i] if i < len(d1) else None
         s = st2[3 * i + 2] if 3 * i + 2 < len(st2) and r[1] <= 20000 else ("",) * 7      # (the deep loop carries no marks)
-        f.write("%s,%d,%d,%.2f,%.3f,%s,%s,%s,%s,%s,%s\n" % (r[0], r[1], r[2], r[3], r[4], "%.3f" % du[4] if du else "", "%.3f" % o[4] if o else "", "%.3f" % c[4] if c else "", "%.3f" % a[4] if a else "",
+        f.write("%s,%d,%d,%.2f,%.3f,%s,%s,%s,%s,%s,%s,%s\n" % (r[0], r[1], r[2], r[3], r[4], "%.3f" % dd[4] if dd else "", "%.3f" % du[4] if du else "", "%.3f" % o[4] if o else "", "%.3f" % c[4] if c else "", "%.3f" % a[4] if a else "",
                                                     "%.2f" % (a[4] / r[4]) if a else "", ",".join(s)))
 print(open(os.path.join(OUT, "r06_astar_pop.csv")).read())
