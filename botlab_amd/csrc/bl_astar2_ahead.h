@@ -854,6 +854,157 @@
 // wave 1 for both regimes: the LDS pushes of A2A_BODY_PUSH3, or (regime word 1) bl_astar2_deep.h's with where they landed, and then
 // the entry at the back of the array for wave 0's next pop.  s61 = the regime; v172 landings, v173 record, v174 / v175 the lane's
 // landing word / candidate.
+// ---- the pushes of the deep regime out of ancestor lines read BESIDE THE POP (wave 1 idles while wave 0 finishes it; a line is a
+// global round trip).  The slots the pushes go to follow from the length alone, so all three lines are asked for at B1, into a
+// register set each (A = A2D_PUSH_*'s own registers).  Behind B2 a line is what memory holds now unless
+//   * the pop wrote a node of it the push looks at.  The pop writes the nodes from the root to where its value landed (record word 42):
+//     an ancestor-closed set, so it is enough to ask whether the ancestor that STOPS the entry lies on that path (for a patched
+//     line: its parent, because a patch moves values one lane down).  Then the line is read again (A2D_PUSH_READ, as before);
+//   * an earlier push of the same expansion wrote nodes of it: push i (slot s_i, d_i ancestors dropped) moved the values of the
+//     heights 1 .. d_i of ITS line one level down and put its entry at height d_i; the lines of s_i and s_j are the same nodes from
+//     height c = bit length of (s_i xor s_j) up.  So if d_i >= c, lanes c - 1 .. d_i - 2 of line j take their upper neighbour's
+//     value (one wave shift) and lane d_i - 1 the entry of push i: A2P_PATCH, ~20 instructions where a second read is a round trip.
+//   SL the slot, V231 where an ancestor would drop to, K / P its key / payload (LDS reads, then the merged values), GK / GP (global
+//   loads), O236 / E165 / O166 / L237 the addresses of the drop, MK / MP the lanes whose key / payload is global
+#define A2P_SET_A "s78", "v231", "v234", "v235", "v162", "v164", "v236", "v165", "v166", "v237", "s[34:35]", "s[38:39]"
+#define A2P_SET_B "s79", "v192", "v193", "v194", "v195", "v196", "v197", "v198", "v199", "v200", "s[72:73]", "s[74:75]"
+#define A2P_SET_C "s86", "v201", "v202", "v203", "v204", "v205", "v206", "v207", "v208", "v209", "s[76:77]", "s[80:81]"
+#define A2P_READ(OFF, ...) A2P_READ_(OFF, __VA_ARGS__)
+#define A2P_READ_(OFF, SL, V231, K, P, GK, GP, O236, E165, O166, L237, MK, MP)                                \
+    "s_add_i32 " SL ", s40, " OFF "\n\t"                                                                      \
+    "v_lshrrev_b32_e64 v230, v184, " SL "\n\t"       /* ancestor's slot (0: none) */                          \
+    "v_lshrrev_b32_e64 " V231 ", v185, " SL "\n\t"   /* the slot it would drop to */                          \
+    "v_min_u32 v232, %[kslotsm1], v230\n\t"                                                                   \
+    "v_lshlrev_b32 v232, 1, v232\n\t"                                                                         \
+    "ds_read_u16 " K ", v232\n\t"                                                                             \
+    "v_add_u32 v233, -1, v230\n\t"                                                                            \
+    "v_min_u32 v160, %[pln], v233\n\t"                                                                        \
+    "v_lshl_add_u32 v160, v160, 2, s56\n\t"                                                                   \
+    "ds_read_b32 " P ", v160\n\t"                                                                             \
+    "v_cmp_le_u32 vcc, %[kslots], v230\n\t"                                                                   \
+    "s_mov_b64 " MK ", vcc\n\t"                                                                               \
+    "v_lshlrev_b32 v161, 1, v230\n\t"                                                                         \
+    "s_mov_b64 exec, vcc\n\t"                                                                                 \
+    "global_load_ushort " GK ", v161, s[30:31]\n\t"                                                           \
+    "s_mov_b64 exec, -1\n\t"                                                                                  \
+    "v_cmp_le_u32 vcc, %[pln], v233\n\t"                                                                      \
+    "v_cmp_ne_u32_e64 s[68:69], 0, v230\n\t"                                                                  \
+    "s_and_b64 " MP ", vcc, s[68:69]\n\t"                                                                     \
+    "v_lshlrev_b32 v163, 2, v233\n\t"                                                                         \
+    "s_mov_b64 exec, " MP "\n\t"                                                                              \
+    "global_load_dword " GP ", v163, s[28:29]\n\t"                                                            \
+    "s_mov_b64 exec, -1\n\t"                                                                                  \
+    "v_lshlrev_b32 " O236 ", 1, " V231 "\n\t"                                                                 \
+    "v_add_u32 " E165 ", -1, " V231 "\n\t"                                                                    \
+    "v_lshlrev_b32 " O166 ", 2, " E165 "\n\t"                                                                 \
+    "v_add_u32 " L237 ", s56, " O166 "\n\t"
+// the two tiers of a line into K / P (everything asked for has arrived)
+#define A2P_MERGE(...) A2P_MERGE_(__VA_ARGS__)
+#define A2P_MERGE_(SL, V231, K, P, GK, GP, O236, E165, O166, L237, MK, MP)                                    \
+    "v_cndmask_b32_e64 " K ", " K ", " GK ", " MK "\n\t"                                                      \
+    "v_cndmask_b32_e64 " P ", " P ", " GP ", " MP "\n\t"
+// how far the entry (key s89) rises on a merged line: s70 = the ancestors that drop, s[92:93] their lanes, s71 = the slot it takes
+#define A2P_DECIDE(...) A2P_DECIDE_(__VA_ARGS__)
+#define A2P_DECIDE_(SL, V231, K, P, GK, GP, O236, E165, O166, L237, MK, MP)                                   \
+    "v_cmp_lt_u32 vcc, s89, " K "\n\t"                                                                        \
+    "s_not_b64 s[92:93], vcc\n\t"                                                                             \
+    "s_ff1_i32_b64 s70, s[92:93]\n\t"                                                                         \
+    "s_bfm_b64 s[92:93], s70, 0\n\t"                                                                          \
+    "s_lshr_b32 s71, " SL ", s70\n\t"
+// A2D_PUSH_STORES over a set; the push's (drops, slot, key, payload) -> the four SGPRs of INFO for the patches of later lines
+#define A2P_STORES(ID, IS, IK, IP, ...) A2P_STORES_(ID, IS, IK, IP, __VA_ARGS__)
+#define A2P_STORES_(ID, IS, IK, IP, SL, V231, K, P, GK, GP, O236, E165, O166, L237, MK, MP)                   \
+    "s_mov_b32 " ID ", s70\n\t"                                                                               \
+    "s_mov_b32 " IS ", " SL "\n\t"                                                                            \
+    "s_mov_b32 " IK ", s89\n\t"                                                                               \
+    "s_mov_b32 " IP ", s90\n\t"                                                                               \
+    "v_cmp_gt_u32 vcc, %[kslots], " V231 "\n\t"                                                               \
+    "s_and_b64 exec, s[92:93], vcc\n\t"                                                                       \
+    "ds_write_b16 " O236 ", " K "\n\t"                                                                        \
+    "s_andn2_b64 exec, s[92:93], vcc\n\t"                                                                     \
+    "global_store_short " O236 ", " K ", s[30:31]\n\t"                                                        \
+    "s_mov_b64 exec, -1\n\t"                                                                                  \
+    "v_cmp_gt_u32 vcc, %[pln], " E165 "\n\t"                                                                  \
+    "s_and_b64 exec, s[92:93], vcc\n\t"                                                                       \
+    "ds_write_b32 " L237 ", " P "\n\t"                                                                        \
+    "s_andn2_b64 exec, s[92:93], vcc\n\t"                                                                     \
+    "global_store_dword " O166 ", " P ", s[28:29]\n\t"                                                        \
+    "s_mov_b64 exec, -1\n\t"                                                                                  \
+    "s_lshl_b32 s70, s71, 1\n\t"                                                                              \
+    "v_mov_b32 v232, s70\n\t"                                                                                 \
+    "v_mov_b32 v233, s89\n\t"                                                                                 \
+    "s_add_i32 s70, s71, -1\n\t"                                                                              \
+    "s_lshl_b32 s70, s70, 2\n\t"                                                                              \
+    "v_mov_b32 v238, s70\n\t"                                                                                 \
+    "v_add_u32 v167, s56, v238\n\t"                                                                           \
+    "v_mov_b32 v239, s90\n\t"                                                                                 \
+    "s_cmp_lt_u32 s71, %[kslots]\n\t"                                                                         \
+    "s_cselect_b64 s[68:69], 1, 0\n\t"                                                                        \
+    "s_mov_b64 exec, s[68:69]\n\t"                                                                            \
+    "ds_write_b16 v232, v233\n\t"                                                                             \
+    "s_xor_b64 exec, s[68:69], 1\n\t"                                                                         \
+    "global_store_short v232, v233, s[30:31]\n\t"                                                             \
+    "s_add_i32 s70, s71, -1\n\t"                                                                              \
+    "s_cmp_lt_u32 s70, %[pln]\n\t"                                                                            \
+    "s_cselect_b64 s[68:69], 1, 0\n\t"                                                                        \
+    "s_mov_b64 exec, s[68:69]\n\t"                                                                            \
+    "ds_write_b32 v167, v239\n\t"                                                                             \
+    "s_xor_b64 exec, s[68:69], 1\n\t"                                                                         \
+    "global_store_dword v238, v239, s[28:29]\n\t"                                                             \
+    "s_mov_b64 exec, -1\n\t"                                                                                  \
+    "s_add_i32 s40, s40, 1\n\t"
+// where the entry landed (max(landing >> 1, 1) into lane J of v172) and what the array's last slot holds now (s36 key, s37 payload: the
+// entry itself if no ancestor dropped, else its parent = lane 0 of the line)
+#define A2P_WHERE(J, ...) A2P_WHERE_(J, __VA_ARGS__)
+#define A2P_WHERE_(J, SL, V231, K, P, GK, GP, O236, E165, O166, L237, MK, MP)                                 \
+    "s_lshr_b32 s39, s71, 1\n\t"                                                                              \
+    "s_max_u32 s39, s39, 1\n\t"                                                                               \
+    "v_writelane_b32 v172, s39, " J "\n\t"                                                                    \
+    "v_readlane_b32 s36, " K ", 0\n\t"                                                                        \
+    "v_readlane_b32 s37, " P ", 0\n\t"                                                                        \
+    "s_cmp_eq_u32 s71, " SL "\n\t"                                                                            \
+    "s_cselect_b32 s36, s89, s36\n\t"                                                                         \
+    "s_cselect_b32 s37, s90, s37\n\t"
+// line SET as an earlier push (ID drops, slot IS, key IK, payload IP) left it
+#define A2P_PATCH(TAG, ID, IS, IK, IP, ...) A2P_PATCH_(TAG, ID, IS, IK, IP, __VA_ARGS__)
+#define A2P_PATCH_(TAG, ID, IS, IK, IP, SL, V231, K, P, GK, GP, O236, E165, O166, L237, MK, MP)               \
+    "s_xor_b32 s82, " IS ", " SL "\n\t"                                                                       \
+    "s_flbit_i32_b32 s82, s82\n\t"                                                                            \
+    "s_sub_i32 s82, 32, s82\n\t"                     /* c: the two lines are the same nodes from this height up */ \
+    "s_cmp_ge_u32 " ID ", s82\n\t"                                                                            \
+    "s_cbranch_scc0 " TAG "f\n\t"                                                                             \
+    "s_add_i32 s83, s83, 1\n\t"                      /* (patched: the pop's test looks one node higher per patch) */ \
+    "s_add_i32 s84, " ID ", -1\n\t"                                                                           \
+    "s_bfm_b64 s[92:93], s84, 0\n\t"                 /* lanes 0 .. d - 2 */                                   \
+    "s_add_i32 s82, s82, -1\n\t"                                                                              \
+    "s_bfm_b64 s[68:69], s82, 0\n\t"                 /* lanes 0 .. c - 2 */                                   \
+    "s_andn2_b64 s[92:93], s[92:93], s[68:69]\n\t"   /* lanes c - 1 .. d - 2: the upper neighbour's value */  \
+    "s_lshl_b64 s[68:69], 1, s84\n\t"                /* lane d - 1: the earlier push's entry */               \
+    "v_mov_b32 v150, " IK "\n\t"                                                                              \
+    "v_mov_b32 v151, " IP "\n\t"                                                                              \
+    "v_mov_b32_dpp v152, " K " wave_shl:1 row_mask:0xf bank_mask:0xf\n\t"                                     \
+    "v_mov_b32_dpp v153, " P " wave_shl:1 row_mask:0xf bank_mask:0xf\n\t"                                     \
+    "s_nop 1\n\t"                                                                                             \
+    "v_cndmask_b32_e64 " K ", " K ", v152, s[92:93]\n\t"                                                      \
+    "v_cndmask_b32_e64 " P ", " P ", v153, s[92:93]\n\t"                                                      \
+    "v_cndmask_b32_e64 " K ", " K ", v150, s[68:69]\n\t"                                                      \
+    "v_cndmask_b32_e64 " P ", " P ", v151, s[68:69]\n\t"                                                      \
+    "s_nop 1\n\t"                                                                                             \
+    TAG ":\n\t"
+// did the pop (its value landed on the 1-based node s85) write the ancestor that stopped the entry (node s71 >> 1; for a line
+// patched s83 times the node s83 levels above it: a patch moves values one lane down; none: the entry rose to the root)?  yes -> STALE
+#define A2P_TEST(STALE)                                                                                       \
+    "s_add_i32 s84, s83, 1\n\t"                                                                               \
+    "s_lshr_b32 s84, s71, s84\n\t"                                                                            \
+    "s_cmp_eq_u32 s84, 0\n\t"                                                                                 \
+    "s_cbranch_scc1 " STALE "\n\t"                                                                            \
+    "s_flbit_i32_b32 s82, s84\n\t"                                                                            \
+    "s_flbit_i32_b32 s39, s85\n\t"                                                                            \
+    "s_sub_i32 s82, s82, s39\n\t"                                                                             \
+    "s_lshr_b32 s82, s85, s82\n\t"                   /* (a node deeper than the landing is larger than it: never equal) */ \
+    "s_cmp_eq_u32 s82, s84\n\t"                                                                               \
+    "s_cbranch_scc1 " STALE "\n\t"
+
 #define A2A_PUSH_WHERE(J)                                                                                     \
     "s_lshr_b32 s39, s71, 1\n\t"                                                                              \
     "s_max_u32 s39, s39, 1\n\t"                                                                               \
@@ -927,9 +1078,8 @@
     "s_add_i32 s40, s40, -1\n\t"                                                                              \
     "s_cmp_lg_u32 s61, 0\n\t"                                                                                 \
     "s_cbranch_scc0 12f\n\t"                                                                                  \
-    /* deep regime: the first push's ancestors (a global round trip) are asked for NOW, beside the pop -- whether the pop wrote one */ \
-    /* of those the push looked at is seen behind B2 (the pop writes the nodes from the root to where its value landed) */ \
-    A2D_PUSH_READ                                                                                             \
+    /* deep regime: the pushes' ancestor lines (a global round trip each) are asked for NOW, beside the pop (A2P_*) */ \
+    A2P_READ("1", A2P_SET_A) A2P_READ("2", A2P_SET_B) A2P_READ("3", A2P_SET_C)                                 \
     "12:\n\t"                                                                                                 \
     "s_barrier\n\t"                                  /* B2: the pop is in, the expansion's record is there */ \
     "ds_read_b32 v210, v173\n\t"                     /* the push mask */                                      \
@@ -953,35 +1103,54 @@
     "20:\n\t"                                                                                                 \
     "ds_read_b32 v241, v173 offset:40\n\t"           /* where the pop's value landed (1-based node) */        \
     "s_mov_b32 s36, -1\n\t"                          /* no push made */                                       \
-    "s_waitcnt lgkmcnt(0)\n\t"                                                                                \
+    "s_waitcnt vmcnt(0) lgkmcnt(0)\n\t"              /* (what was asked for in front of B2 arrived long ago) */ \
     "v_readfirstlane_b32 s87, v210\n\t"                                                                       \
     "v_readfirstlane_b32 s85, v241\n\t"                                                                       \
-    A2T_PUSH_CHECK("27f") A2D_PUSH_PICK A2D_PUSH_DECIDE                                                       \
-    /* the ancestor that stopped the entry (node s71 >> 1; none: it rose to the root) -- did the pop write it?  If not, it wrote */ \
-    /* none of the deeper ones the push looked at either: what was read in front of the pop is what is there now */ \
-    "s_lshr_b32 s84, s71, 1\n\t"                                                                              \
-    "s_cmp_eq_u32 s84, 0\n\t"                                                                                 \
-    "s_cbranch_scc1 24f\n\t"                                                                                  \
-    "s_flbit_i32_b32 s82, s84\n\t"                                                                            \
-    "s_flbit_i32_b32 s83, s85\n\t"                                                                            \
-    "s_sub_i32 s82, s82, s83\n\t"                                                                             \
-    "s_lshr_b32 s82, s85, s82\n\t"                   /* (a stopper deeper than the landing is larger than it: never equal) */ \
-    "s_cmp_eq_u32 s82, s84\n\t"                                                                               \
-    "s_cbranch_scc0 25f\n\t"                                                                                  \
-    "24:\n\t"                                        /* it did: read again */                                 \
+    A2P_MERGE(A2P_SET_A) A2P_MERGE(A2P_SET_B) A2P_MERGE(A2P_SET_C)                                            \
+    /* ---- the first push: line A */                                                                         \
+    A2T_PUSH_CHECK("27f") A2D_PUSH_PICK                                                                       \
+    "s_mov_b32 s83, 0\n\t"                                                                                    \
+    A2P_DECIDE(A2P_SET_A)                                                                                     \
+    A2P_TEST("21f")                                                                                           \
+    "s_branch 22f\n\t"                                                                                        \
+    "21:\n\t"                                        /* the pop wrote what it looked at: read again */        \
     A2W_ACC_COUNT("s95")                                                                                      \
     A2D_PUSH_READ A2D_PUSH_DECIDE                                                                             \
+    "22:\n\t"                                                                                                 \
+    A2P_STORES("s72", "s73", "s74", "s75", A2P_SET_A) A2P_WHERE("0", A2P_SET_A)                               \
+    /* ---- the second: line B as the first push left it */                                                   \
+    A2T_PUSH_CHECK("27f") A2D_PUSH_PICK                                                                       \
+    "s_mov_b32 s83, 0\n\t"                                                                                    \
+    A2P_PATCH("231", "s72", "s73", "s74", "s75", A2P_SET_B)                                                   \
+    A2P_DECIDE(A2P_SET_B)                                                                                     \
+    A2P_TEST("23f")                                                                                           \
+    A2P_STORES("s76", "s77", "s80", "s81", A2P_SET_B) A2P_WHERE("1", A2P_SET_B)                               \
+    "s_branch 24f\n\t"                                                                                        \
+    "23:\n\t"                                                                                                 \
+    A2W_ACC_COUNT("s95")                                                                                      \
+    A2D_PUSH_READ A2D_PUSH_DECIDE                                                                             \
+    A2P_STORES("s76", "s77", "s80", "s81", A2P_SET_A) A2P_WHERE("1", A2P_SET_A)                               \
+    "24:\n\t"                                                                                                 \
+    /* ---- the third: line C as the first two left it */                                                     \
+    A2T_PUSH_CHECK("27f") A2D_PUSH_PICK                                                                       \
+    "s_mov_b32 s83, 0\n\t"                                                                                    \
+    A2P_PATCH("251", "s72", "s73", "s74", "s75", A2P_SET_C)                                                   \
+    A2P_PATCH("252", "s76", "s77", "s80", "s81", A2P_SET_C)                                                   \
+    A2P_DECIDE(A2P_SET_C)                                                                                     \
+    A2P_TEST("25f")                                                                                           \
+    A2P_STORES("s72", "s73", "s74", "s75", A2P_SET_C) A2P_WHERE("2", A2P_SET_C)                               \
+    "s_branch 27f\n\t"                                                                                        \
     "25:\n\t"                                                                                                 \
-    A2D_PUSH_STORES A2A_PUSH_WHERE("0")                                                                       \
-    A2T_PUSH_CHECK("27f") A2D_PUSH_READ A2D_PUSH_REST A2A_PUSH_WHERE("1")                                     \
-    A2T_PUSH_CHECK("27f") A2D_PUSH_READ A2D_PUSH_REST A2A_PUSH_WHERE("2")                                     \
+    A2W_ACC_COUNT("s95")                                                                                      \
+    A2D_PUSH_READ A2D_PUSH_DECIDE                                                                             \
+    A2P_STORES("s72", "s73", "s74", "s75", A2P_SET_A) A2P_WHERE("2", A2P_SET_A)                               \
     "27:\n\t"                                                                                                 \
     "s_cmp_eq_u32 s36, -1\n\t"                                                                                \
     "s_cbranch_scc1 26f\n\t"                                                                                  \
     /* the entry at the back of the array as the pushes leave it: out of the last push's registers */         \
     "v_mov_b32 v162, s36\n\t"                                                                                 \
     "v_mov_b32 v163, s37\n\t"                                                                                 \
-    "s_waitcnt vmcnt(0)\n\t"                         /* (this wave's global stores are acknowledged in front of B1) */ \
+    /* (this wave's global stores are ISSUED in front of B1, as wave 0's are in front of B2: wave 0's loads follow them through the same L1) */ \
     "s_branch 28f\n\t"                                                                                        \
     "26:\n\t"                                                                                                 \
     /* no push: read it -- key slot s40 (LDS or global), payload entry s40 - 1 (global) */                    \

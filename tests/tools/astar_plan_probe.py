@@ -4,6 +4,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 import botlab_amd._capi as capi
+if os.environ.get("PROBE_LIB"):          # A/B runs: another build of the library beside the tree's (libbotlab_hip_<name>.so)
+    capi.LIB_PATH = capi.LIB_PATH.replace("libbotlab_hip.so", "libbotlab_hip_%s.so" % os.environ["PROBE_LIB"])
 if os.environ.get("STAMPS"):
     capi.LIB_PATH = capi.LIB_PATH.replace("libbotlab_hip.so", "libbotlab_hip_stamps.so")
 import botlab_amd as bl, helpers

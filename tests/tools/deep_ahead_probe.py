@@ -4,6 +4,9 @@
 import os, sys, time
 sys.path.insert(0, '/root/repo'); sys.path.insert(0, '/root/repo/tests')
 import numpy as np
+import botlab_amd._capi as capi
+if os.environ.get("PROBE_LIB"):          # A/B runs: another build of the library beside the tree's (libbotlab_hip_<name>.so)
+    capi.LIB_PATH = capi.LIB_PATH.replace("libbotlab_hip.so", "libbotlab_hip_%s.so" % os.environ["PROBE_LIB"])
 import botlab_amd as bl, helpers, oracle_lib
 orc = oracle_lib.load_oracle()
 maps = helpers.load_reference_maps()
