@@ -577,15 +577,17 @@
 // The same three waves for open lists that reach into global memory (bl_astar2_deep.h: PLN + 2 <= length <= deep_max): wave 0's
 // walk of the NEXT pop -- three rounds in LDS, one or two in global memory -- beside wave 1's pushes, wave 2 as above (the top and the
 // root's children are LDS words in either regime).  Differences from the LDS forms:
-//   * the entry at the back of the array comes from wave 1 (record words 40, 41: key, payload), read back behind its own pushes
-//     (its loads and stores of one address stay in program order); that wait also acknowledges wave 1's global stores before B1;
-//   * wave 0's global stores of a pop are ISSUED before B2, not acknowledged (~500 cycles): wave 1's loads of the same lines follow
-//     them through the same vector L1 (tests/tools/cross_wave_store_probe.hip: 0 stale reads in 2e8 per form, profiles/r06_cross_wave_store_probe.txt);
-//   * wave 1's first push's ancestors -- a global round trip -- are asked for at B1, beside the pop, and checked behind B2 against
-//     where the pop's value landed (record word 42: the pop wrote the nodes from the root to there);
+//   * the entry at the back of the array comes from wave 1 (record words 40, 41: key, payload): out of its last push's registers,
+//     read from memory only behind an expansion without pushes;
+//   * neither wave waits for the ACKNOWLEDGEMENT of its global stores in front of the barrier that hands the heap over (~500 cycles
+//     each): they are issued, and the other wave's loads of the same lines follow them through the same vector L1
+//     (tests/tools/cross_wave_store_probe.hip: 0 stale reads in 2e8 per form, profiles/r06_cross_wave_store_probe.txt);
+//   * wave 1 is idle while wave 0 finishes a pop and a push's ancestor line is a global round trip: all three lines are asked for at
+//     B1, beside the pop, checked behind B2 against where the pop's value landed (record word 42: the pop wrote the nodes from the
+//     root to there) and patched in registers for what the earlier pushes of the expansion wrote (A2P_*);
 //   * s79 remembers where the walk taken ahead ended: 1 in LDS, 2 one global round, 3 two; record word 46 tells wave 1 the regime.
-// MEASURED (profiles/r06_astar_deep_three_waves.txt, r06_astar_pop.csv): wide 2 (5.3e5 pops) 1.125 -> 0.881 us per pop, convex 2
-// (1.8e6) 1.154 -> 0.898; wave 0 waits ~110 cycles per pop for wave 1 (three pushes), wave 2 ~900.
+// MEASURED (profiles/r06_astar_deep_push_wave_variants.txt, r06_astar_pop.csv): wide 2 (5.3e5 pops) 1.13 -> 0.85 us per pop, convex 2
+// (1.8e6) 1.15 -> 0.87; as first built (first line only, wave 1 waiting for its stores' acknowledgement) 0.89.
 // Registers as A2D_BODY's (s28-s31, s34-s35, s82-s85, v150-v175); the path test's temporaries are s90-s92 and v224 here.
 #define A2A_WALKD(FIRST, L)                                                                                   \
     FIRST                                                                                                     \
@@ -1005,16 +1007,6 @@
     "s_cmp_eq_u32 s82, s84\n\t"                                                                               \
     "s_cbranch_scc1 " STALE "\n\t"
 
-#define A2A_PUSH_WHERE(J)                                                                                     \
-    "s_lshr_b32 s39, s71, 1\n\t"                                                                              \
-    "s_max_u32 s39, s39, 1\n\t"                                                                               \
-    "v_writelane_b32 v172, s39, " J "\n\t"                                                                    \
-    /* what the array's last slot holds now: the entry itself if no ancestor dropped, else its parent (lane 0 of the ancestors) */ \
-    "v_readlane_b32 s36, v234, 0\n\t"                                                                         \
-    "v_readlane_b32 s37, v235, 0\n\t"                                                                         \
-    "s_cmp_eq_u32 s71, s78\n\t"                                                                               \
-    "s_cselect_b32 s36, s89, s36\n\t"                                                                         \
-    "s_cselect_b32 s37, s90, s37\n\t"
 #define A2A_PUSH_REST_L(J)                                                                                    \
     "s_ff1_i32_b32 s91, s87\n\t"                                                                              \
     "s_add_i32 s70, s87, -1\n\t"                                                                              \
