@@ -853,9 +853,6 @@
     "s_mov_b32 %[gm], s88\n\t"                                                                                \
     "s_mov_b32 %[pt], s80\n\t"
 
-// wave 1 for both regimes: the LDS pushes of A2A_BODY_PUSH3, or (regime word 1) bl_astar2_deep.h's with where they landed, and then
-// the entry at the back of the array for wave 0's next pop.  s61 = the regime; v172 landings, v173 record, v174 / v175 the lane's
-// landing word / candidate.
 // ---- the pushes of the deep regime out of ancestor lines read BESIDE THE POP (wave 1 idles while wave 0 finishes it; a line is a
 // global round trip).  The slots the pushes go to follow from the length alone, so all three lines are asked for at B1, into a
 // register set each (A = A2D_PUSH_*'s own registers).  Behind B2 a line is what memory holds now unless
@@ -1007,6 +1004,9 @@
     "s_cmp_eq_u32 s82, s84\n\t"                                                                               \
     "s_cbranch_scc1 " STALE "\n\t"
 
+// wave 1 for both regimes: the LDS pushes of A2A_BODY_PUSH3, or (regime word 1) the deep regime's (A2P_* above) with where they landed, and then
+// the entry at the back of the array for wave 0's next pop.  s61 = the regime; v172 landings, v173 record, v174 / v175 the lane's
+// landing word / candidate.
 #define A2A_PUSH_REST_L(J)                                                                                    \
     "s_ff1_i32_b32 s91, s87\n\t"                                                                              \
     "s_add_i32 s70, s87, -1\n\t"                                                                              \
