@@ -361,11 +361,17 @@ __device__ __forceinline__ float2_t trig_by_addition(float2_t pcs, float cr, flo
     const float2_t t = a * float2_t{sr, sr};
     return __builtin_elementwise_fma(pcs, float2_t{cr, cr}, t);           // (cp cr + sp sr, sp cr - cp sr)
 }
-__device__ __forceinline__ void ray_cells_fast(float2_t start, float cpm, float range, float d, float2_t pcs, float cr, float sr, float k1, float k2,
-                                               short2_t& E, short2_t& X)
+// (p, r: the particle's and the ray's angle -- their difference is formed only where it is used, the hardware form and the exact path;
+// hw: wave-uniform, a kernel argument)
+template <bool HW>
+__device__ __forceinline__ void ray_cells_fast(float2_t start, float cpm, float range, float p, float r, float2_t pcs, float cr, float sr,
+                                               float k1, float k2, short2_t& E, short2_t& X)
 {
     float sn, cs;
-    if (pcs.x > 1.5f) hw_sincos_unwrapped(d, &sn, &cs);      // (wave-uniform: BOTLAB_MCL_HW_TRIG marks the pair)
+    if (HW) {                                                // (BOTLAB_MCL_HW_TRIG: a loop of its own, chosen outside it; the marker
+        asm volatile("; hardware sine / cosine");            // keeps the optimiser from folding the two loops back into one with this
+        hw_sincos_unwrapped(p - r, &sn, &cs);                // branch inside)
+    }
     else { const float2_t dir = trig_by_addition(pcs, cr, sr); cs = dir.x; sn = dir.y; }
     float2_t e, x;
     ray_points_pk(start, cpm, range, cs, sn, e, x);
@@ -376,7 +382,9 @@ __device__ __forceinline__ void ray_cells_fast(float2_t start, float cpm, float 
     ray_points_to_cells(e, x, E, X);
     if (__builtin_amdgcn_ballot_w64(near)) {
         float sn2, cs2;
-        bl_sincosf_cells(wrap_to_pi_cells(d, true), &sn2, &cs2);
+        float p2 = p;
+        asm volatile("" : "+v"(p2));                          // (keeps the subtraction inside the branch: 1-4 rays in a thousand come here)
+        bl_sincosf_cells(wrap_to_pi_cells(p2 - r, true), &sn2, &cs2);
         short2_t E2, X2;
         ray_cells_pk(start, cpm, range, cs2, sn2, E2, X2);
         E = near ? E2 : E;
@@ -548,24 +556,24 @@ __device__ __forceinline__ void philox_normals3(uint32_t m, uint32_t step, uint3
 
 // The same loops with the two cells from ray_cells_fast (theta_simple scans only): the direction by the addition theorems from
 // the particle's (cos, sin) pair pcs_ and the table's.  Rays [LO, HI) of the chunk (LO a multiple of the split).
-#define MCL_RAY_LOOP_FAST_RANGE(PM, LO, HI)                                             \
+#define MCL_RAY_LOOP_FAST_RANGE(PM, LO, HI, HW)                                         \
     do {                                                                                \
         const int rounds_ = ((HI) - (LO)) >> sl2;                                       \
         int off_ = ((LO) + sub) * 16;                                                   \
         for (int k_ = 0; k_ < rounds_; ++k_, off_ += split * 16) {                      \
             const float4 rt = *(const float4*)((const char*)s_ray + off_);              \
             short2_t E_, X_;                                                            \
-            ray_cells_fast(start, a.frame.cpm, rt.x, pth_r - rt.y, pcs_, rt.z, rt.w, trig_k1, trig_k2, E_, X_);   \
+            ray_cells_fast<HW>(start, a.frame.cpm, rt.x, pth_r, rt.y, pcs_, rt.z, rt.w, trig_k1, trig_k2, E_, X_);   \
             acc += score_cells_pk(PM, S, E_, X_);                                       \
         }                                                                               \
         if ((off_ >> 4) < (HI)) {                                                       \
             const float4 rt = *(const float4*)((const char*)s_ray + off_);              \
             short2_t E_, X_;                                                            \
-            ray_cells_fast(start, a.frame.cpm, rt.x, pth_r - rt.y, pcs_, rt.z, rt.w, trig_k1, trig_k2, E_, X_);   \
+            ray_cells_fast<HW>(start, a.frame.cpm, rt.x, pth_r, rt.y, pcs_, rt.z, rt.w, trig_k1, trig_k2, E_, X_);   \
             acc += score_cells_pk(PM, S, E_, X_);                                       \
         }                                                                               \
     } while (0)
-#define MCL_RAY_LOOP_FAST(PM) MCL_RAY_LOOP_FAST_RANGE(PM, 0, cnt)
+#define MCL_RAY_LOOP_FAST(PM) do { if (hw_trig_) MCL_RAY_LOOP_FAST_RANGE(PM, 0, cnt, true); else MCL_RAY_LOOP_FAST_RANGE(PM, 0, cnt, false); } while (0)
 
 // ---- resampling search, first part: a wave narrows the range its lanes have to bisect -----------------------------------
 // The lanes of a wave resample consecutive particles, so their targets T ascend and every lane's source index lies
@@ -927,6 +935,7 @@ __global__ __launch_bounds__(BLOCK) void k_mcl_main(mcl_args a)
     const float2_t pcs_ = {r_pcs.x, r_pcs.y};
     const float trig_k1 = 1.02f * a.frame.cpm * (MCL_TRIG_EPS + 2.3842e-7f);      // 4u = 2^-22
     const bool fast_trig = a.fast_trig != 0;                                       // wave-uniform
+    const bool hw_trig_ = a.fast_trig == 2;
     const int isx0 = (int)r_sx0, isy0 = (int)r_sy0;
 
     // ---- SensorModel::likelihood (sensor_model.cpp:14-25) over MovingLaserScan(scan, parent_pose, pose)
