@@ -205,12 +205,13 @@ __device__ __forceinline__ short2_t pk_sign_fill(short2_t v)              // per
 __device__ __forceinline__ short2_t first_step_pk(short2_t e, short2_t target)
 {
     const short2_t d = target - e;
-    const short2_t ad = __builtin_elementwise_max(d, -d);
+    const short2_t nd = -d;
+    const short2_t ad = __builtin_elementwise_max(d, nd);
     const short2_t t = (ad << 1) - ad.yx;
     const short2_t nostep = pk_sign_fill(t);
-    const short2_t dneg = pk_sign_fill(d - (short)1);                     // d > 0 ? 0 : -1
-    // (dneg | 1) & ~nostep, i.e. (d > 0 ? 1 : -1) where the axis steps, in one v_bitop3 (truth table a=dneg, b=nostep, c=1)
-    const int sg = __builtin_amdgcn_bitop3_b32(__builtin_bit_cast(int, dneg), __builtin_bit_cast(int, nostep), 0x00010001, 0x32);
+    const short2_t dpos = pk_sign_fill(nd);                               // d > 0 ? -1 : 0 (the sign of -d, which |d| needed anyway)
+    // (~dpos | 1) & ~nostep, i.e. (d > 0 ? 1 : -1) where the axis steps, in one v_bitop3 (truth table a=dpos, b=nostep, c=1: bits 0, 1, 5)
+    const int sg = __builtin_amdgcn_bitop3_b32(__builtin_bit_cast(int, dpos), __builtin_bit_cast(int, nostep), 0x00010001, 0x23);
     return e + __builtin_bit_cast(short2_t, sg);
 }
 
@@ -335,7 +336,9 @@ __device__ __forceinline__ void ray_cells_pk(float2_t start, float cpm, float ra
 // so the truncated cells agree whenever e' (x') is farther than B1 (B2) from every integer, B1 = range * k1 + k2, B2 = range * 2 k1
 // + k2 with k1 = 1.02 * cpm * (eps + 4u) and k2 = 2.04u * (a bound on the particle's cell coordinates: |start| + 2 * longest
 // ray + 8).  A ray inside a band (1-4 in a thousand) makes its whole wave take the exact path for that round and keeps the exact
-// cells; everything downstream is integer.
+// cells; everything downstream is integer.  The test itself (round 6): the distance of c to the nearest integer is 0.5 - |fract(c) - 0.5|,
+// exactly, so "both coordinates farther than B" is max(|fract - 0.5|) < 0.5 - B -- two v_fract, one packed add, one max per point;
+// the threshold 0.5 - B is formed with 1.2e-7 taken off (its two roundings are half an ulp of 0.5 each), which only widens the band.
 // MCL_TRIG_EPS: 5.5 % above the larger maximum measured for the hardware form (bl_debug_trig_probe, kept: BOTLAB_MCL_HW_TRIG=1 takes
 // that form), 13 % above the addition form's analytic bound and 45 % above its measured maximum; tests/test_gpu_trig_guard.py
 // asserts the measured maxima of both forms stay below it.
@@ -365,7 +368,7 @@ __device__ __forceinline__ float2_t trig_by_addition(float2_t pcs, float cr, flo
 // hw: wave-uniform, a kernel argument)
 template <bool HW>
 __device__ __forceinline__ void ray_cells_fast(float2_t start, float cpm, float range, float p, float r, float2_t pcs, float cr, float sr,
-                                               float k1, float k2, short2_t& E, short2_t& X)
+                                               float k1, float kh, short2_t& E, short2_t& X)
 {
     float sn, cs;
     if (HW) {                                                // (BOTLAB_MCL_HW_TRIG: a loop of its own, chosen outside it; the marker
@@ -375,10 +378,15 @@ __device__ __forceinline__ void ray_cells_fast(float2_t start, float cpm, float 
     else { const float2_t dir = trig_by_addition(pcs, cr, sr); cs = dir.x; sn = dir.y; }
     float2_t e, x;
     ray_points_pk(start, cpm, range, cs, sn, e, x);
-    const float B1 = __builtin_fmaf(range, k1, k2), B2 = __builtin_fmaf(range, k1 + k1, k2);
-    const float ge = __builtin_fminf(__builtin_fabsf(e.x - __builtin_rintf(e.x)), __builtin_fabsf(e.y - __builtin_rintf(e.y)));
-    const float gx = __builtin_fminf(__builtin_fabsf(x.x - __builtin_rintf(x.x)), __builtin_fabsf(x.y - __builtin_rintf(x.y)));
-    const bool near = !(ge > B1) || !(gx > B2);                          // (a nan lands here too)
+    // the distance of a coordinate c to the nearest integer is 0.5 - |fract(c) - 0.5|, every step of it exact in float (fract(c) is
+    // c - floor(c), a multiple of c's ulp below 1): "farther than B from every integer" is max(|fract - 0.5|) < 0.5 - B.  kh = 0.5 - k2
+    // - 1.2e-7: the threshold's own rounding (half an ulp of 0.5, twice) only ever widens the band.
+    const float C1 = __builtin_fmaf(range, -k1, kh), C2 = __builtin_fmaf(range, -(k1 + k1), kh);
+    const float2_t fe = float2_t{__builtin_amdgcn_fractf(e.x), __builtin_amdgcn_fractf(e.y)} - 0.5f;
+    const float2_t fx = float2_t{__builtin_amdgcn_fractf(x.x), __builtin_amdgcn_fractf(x.y)} - 0.5f;
+    const float me = __builtin_fmaxf(__builtin_fabsf(fe.x), __builtin_fabsf(fe.y));
+    const float mx = __builtin_fmaxf(__builtin_fabsf(fx.x), __builtin_fabsf(fx.y));
+    const bool near = !(me < C1) || !(mx < C2);                          // (a nan lands here too)
     ray_points_to_cells(e, x, E, X);
     if (__builtin_amdgcn_ballot_w64(near)) {
         float sn2, cs2;
@@ -563,13 +571,13 @@ __device__ __forceinline__ void philox_normals3(uint32_t m, uint32_t step, uint3
         for (int k_ = 0; k_ < rounds_; ++k_, off_ += split * 16) {                      \
             const float4 rt = *(const float4*)((const char*)s_ray + off_);              \
             short2_t E_, X_;                                                            \
-            ray_cells_fast<HW>(start, a.frame.cpm, rt.x, pth_r, rt.y, pcs_, rt.z, rt.w, trig_k1, trig_k2, E_, X_);   \
+            ray_cells_fast<HW>(start, a.frame.cpm, rt.x, pth_r, rt.y, pcs_, rt.z, rt.w, trig_k1, trig_kh, E_, X_);   \
             acc += score_cells_pk(PM, S, E_, X_);                                       \
         }                                                                               \
         if ((off_ >> 4) < (HI)) {                                                       \
             const float4 rt = *(const float4*)((const char*)s_ray + off_);              \
             short2_t E_, X_;                                                            \
-            ray_cells_fast<HW>(start, a.frame.cpm, rt.x, pth_r, rt.y, pcs_, rt.z, rt.w, trig_k1, trig_k2, E_, X_);   \
+            ray_cells_fast<HW>(start, a.frame.cpm, rt.x, pth_r, rt.y, pcs_, rt.z, rt.w, trig_k1, trig_kh, E_, X_);   \
             acc += score_cells_pk(PM, S, E_, X_);                                       \
         }                                                                               \
     } while (0)
@@ -934,6 +942,7 @@ __global__ __launch_bounds__(BLOCK) void k_mcl_main(mcl_args a)
     if (shared_pro) { const float4 e = s_pp[jl]; r_pth = e.x; r_sx0 = e.y; r_sy0 = e.z; trig_k2 = e.w; r_pcs = s_pcs[jl]; }
     const float2_t pcs_ = {r_pcs.x, r_pcs.y};
     const float trig_k1 = 1.02f * a.frame.cpm * (MCL_TRIG_EPS + 2.3842e-7f);      // 4u = 2^-22
+    const float trig_kh = 0.5f - trig_k2 - 1.2e-7f;                                // (ray_cells_fast: the band as a threshold on |fract - 0.5|)
     const bool fast_trig = a.fast_trig != 0;                                       // wave-uniform
     const bool hw_trig_ = a.fast_trig == 2;
     const int isx0 = (int)r_sx0, isy0 = (int)r_sy0;
