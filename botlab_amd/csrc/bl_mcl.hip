@@ -206,8 +206,9 @@ __device__ __forceinline__ short2_t first_step_pk(short2_t e, short2_t target)
 {
     const short2_t d = target - e;
     const short2_t nd = -d;
-    const short2_t ad = __builtin_elementwise_max(d, nd);
-    const short2_t t = (ad << 1) - ad.yx;
+    const short2_t nad = __builtin_elementwise_min(d, nd);              // -|d|
+    short2_t t;                                                           // 2|dx| - |dy|, 2|dy| - |dx| = -2 nad + nad.yx in one v_pk_mad_i16
+    asm("v_pk_mad_i16 %0, %1, -2, %1 op_sel:[0,0,1] op_sel_hi:[1,0,0]" : "=v"(t) : "v"(nad));
     const short2_t nostep = pk_sign_fill(t);
     const short2_t dpos = pk_sign_fill(nd);                               // d > 0 ? -1 : 0 (the sign of -d, which |d| needed anyway)
     // (~dpos | 1) & ~nostep, i.e. (d > 0 ? 1 : -1) where the axis steps, in one v_bitop3 (truth table a=dpos, b=nostep, c=1: bits 0, 1, 5)
