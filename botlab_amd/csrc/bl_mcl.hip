@@ -334,8 +334,10 @@ __device__ __forceinline__ void ray_cells_pk(float2_t start, float cpm, float ra
 //     |t' - t|, t = fl(fl(range * dir) * cpm)   <= range * cpm * (eps + 4u) (1 + 2u)
 //     |e' - e|, e = fl(t + start)                <= range * cpm * (eps + 4u) (1 + 2u) + 2u * max(|e|, |e'|)
 //     |x' - x|, x = fl(fl(t + t) + start)        <= 2 * range * cpm * (eps + 4u) (1 + 2u) + 2u * max(|x|, |x'|)
-// so the truncated cells agree whenever e' (x') is farther than B1 (B2) from every integer, B1 = range * k1 + k2, B2 = range * 2 k1
-// + k2 with k1 = 1.02 * cpm * (eps + 4u) and k2 = 2.04u * (a bound on the particle's cell coordinates: |start| + 2 * longest
+//     x'' = fl(e' + t') (round 6: one addition; t + t is exact, so x = (2t + start)(1 + d), and x'' = (2t' + start) + d2 e' + d3 x''):
+//     |x'' - x|                                   <= 2 * range * cpm * (eps + 4u) (1 + 2u) + 3u * max(|x|, |x''|, |e'|)
+// so the truncated cells agree whenever e' (x'') is farther than B1 (B2) from every integer, B1 = range * k1 + k2, B2 = range * 2 k1
+// + 1.5 k2 with k1 = 1.02 * cpm * (eps + 4u) and k2 = 2.04u * (a bound on the particle's cell coordinates: |start| + 2 * longest
 // ray + 8).  A ray inside a band (1-4 in a thousand) makes its whole wave take the exact path for that round and keeps the exact
 // cells; everything downstream is integer.  The test itself (round 6): the distance of c to the nearest integer is 0.5 - |fract(c) - 0.5|,
 // exactly, so "both coordinates farther than B" is max(|fract - 0.5|) < 0.5 - B -- two v_fract, one packed add, one max per point;
@@ -369,7 +371,7 @@ __device__ __forceinline__ float2_t trig_by_addition(float2_t pcs, float cr, flo
 // hw: wave-uniform, a kernel argument)
 template <bool HW>
 __device__ __forceinline__ void ray_cells_fast(float2_t start, float cpm, float range, float p, float r, float2_t pcs, float cr, float sr,
-                                               float k1, float kh, short2_t& E, short2_t& X)
+                                               float k1, float kh, float kh2, short2_t& E, short2_t& X)
 {
     float sn, cs;
     if (HW) {                                                // (BOTLAB_MCL_HW_TRIG: a loop of its own, chosen outside it; the marker
@@ -377,12 +379,14 @@ __device__ __forceinline__ void ray_cells_fast(float2_t start, float cpm, float 
         hw_sincos_unwrapped(p - r, &sn, &cs);                // branch inside)
     }
     else { const float2_t dir = trig_by_addition(pcs, cr, sr); cs = dir.x; sn = dir.y; }
-    float2_t e, x;
-    ray_points_pk(start, cpm, range, cs, sn, e, x);
+    // (the point at twice the range as e + t, one addition instead of the reference's (t + t) + start: see "x'' = " above)
+    const float2_t dir = {cs, sn};
+    const float2_t t = (range * dir) * cpm;
+    const float2_t e = t + start, x = e + t;
     // the distance of a coordinate c to the nearest integer is 0.5 - |fract(c) - 0.5|, every step of it exact in float (fract(c) is
     // c - floor(c), a multiple of c's ulp below 1): "farther than B from every integer" is max(|fract - 0.5|) < 0.5 - B.  kh = 0.5 - k2
     // - 1.2e-7: the threshold's own rounding (half an ulp of 0.5, twice) only ever widens the band.
-    const float C1 = __builtin_fmaf(range, -k1, kh), C2 = __builtin_fmaf(range, -(k1 + k1), kh);
+    const float C1 = __builtin_fmaf(range, -k1, kh), C2 = __builtin_fmaf(range, -(k1 + k1), kh2);
     const float2_t fe = float2_t{__builtin_amdgcn_fractf(e.x), __builtin_amdgcn_fractf(e.y)} - 0.5f;
     const float2_t fx = float2_t{__builtin_amdgcn_fractf(x.x), __builtin_amdgcn_fractf(x.y)} - 0.5f;
     const float me = __builtin_fmaxf(__builtin_fabsf(fe.x), __builtin_fabsf(fe.y));
@@ -572,13 +576,13 @@ __device__ __forceinline__ void philox_normals3(uint32_t m, uint32_t step, uint3
         for (int k_ = 0; k_ < rounds_; ++k_, off_ += split * 16) {                      \
             const float4 rt = *(const float4*)((const char*)s_ray + off_);              \
             short2_t E_, X_;                                                            \
-            ray_cells_fast<HW>(start, a.frame.cpm, rt.x, pth_r, rt.y, pcs_, rt.z, rt.w, trig_k1, trig_kh, E_, X_);   \
+            ray_cells_fast<HW>(start, a.frame.cpm, rt.x, pth_r, rt.y, pcs_, rt.z, rt.w, trig_k1, trig_kh, trig_kh2, E_, X_);   \
             acc += score_cells_pk(PM, S, E_, X_);                                       \
         }                                                                               \
         if ((off_ >> 4) < (HI)) {                                                       \
             const float4 rt = *(const float4*)((const char*)s_ray + off_);              \
             short2_t E_, X_;                                                            \
-            ray_cells_fast<HW>(start, a.frame.cpm, rt.x, pth_r, rt.y, pcs_, rt.z, rt.w, trig_k1, trig_kh, E_, X_);   \
+            ray_cells_fast<HW>(start, a.frame.cpm, rt.x, pth_r, rt.y, pcs_, rt.z, rt.w, trig_k1, trig_kh, trig_kh2, E_, X_);   \
             acc += score_cells_pk(PM, S, E_, X_);                                       \
         }                                                                               \
     } while (0)
@@ -944,6 +948,7 @@ __global__ __launch_bounds__(BLOCK) void k_mcl_main(mcl_args a)
     const float2_t pcs_ = {r_pcs.x, r_pcs.y};
     const float trig_k1 = 1.02f * a.frame.cpm * (MCL_TRIG_EPS + 2.3842e-7f);      // 4u = 2^-22
     const float trig_kh = 0.5f - trig_k2 - 1.2e-7f;                                // (ray_cells_fast: the band as a threshold on |fract - 0.5|)
+    const float trig_kh2 = 0.5f - 1.5f * trig_k2 - 1.2e-7f;                        // ... for the point at twice the range, formed as e + t
     const bool fast_trig = a.fast_trig != 0;                                       // wave-uniform
     const bool hw_trig_ = a.fast_trig == 2;
     const int isx0 = (int)r_sx0, isy0 = (int)r_sy0;
