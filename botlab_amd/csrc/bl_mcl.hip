@@ -327,6 +327,10 @@ __device__ __forceinline__ void ray_cells_pk(float2_t start, float cpm, float ra
 //         (|cr| + |cp| + |sr| + |sp|) <= 9.4e-8; the product's and the fma's own roundings: 2 x 3e-8                    <= 1.6e-7
 // together <= 8.2e-7 < MCL_TRIG_EPS = 9.3e-7 (measured maximum over 1e10 random pairs: bl_debug_trig_addition_probe,
 // profiles/r04_trig_addition_probe.json).
+// pcs scaled (round 6): the particle's pair is carried as fl(cpm cp), fl(cpm sp), so that the two packed instructions give cpm * dir and
+// range * that is t in one multiplication where the reference has two.  The scaling's rounding is half an ulp of each of cp, sp:
+// <= 6e-8 (|cp cr| + |sp sr|) <= 6e-8 into the direction, together <= 8.8e-7 < MCL_TRIG_EPS; t' = fl(range * (cpm dir')) has ONE
+// rounding where t = fl(fl(range * dir) * cpm) has two, inside the 4u the second line below allows.  The probe measures this form.
 // The guard band below is the one the hardware-sine form was proven with (tests/tools/sincos_hw_probe.hip measured 8.81e-7 for it);
 // it is kept, so the exact path behind it is taken as often as before.
 // With dir' = dir + eta, |eta| <= eps, and u = 2^-24 the relative error of one float operation:
@@ -373,15 +377,15 @@ template <bool HW>
 __device__ __forceinline__ void ray_cells_fast(float2_t start, float cpm, float range, float p, float r, float2_t pcs, float cr, float sr,
                                                float k1, float kh, float kh2, short2_t& E, short2_t& X)
 {
-    float sn, cs;
+    float2_t t;
     if (HW) {                                                // (BOTLAB_MCL_HW_TRIG: a loop of its own, chosen outside it; the marker
-        asm volatile("; hardware sine / cosine");            // keeps the optimiser from folding the two loops back into one with this
-        hw_sincos_unwrapped(p - r, &sn, &cs);                // branch inside)
-    }
-    else { const float2_t dir = trig_by_addition(pcs, cr, sr); cs = dir.x; sn = dir.y; }
+        float sn, cs;                                        // keeps the optimiser from folding the two loops back into one with this
+        asm volatile("; hardware sine / cosine");            // branch inside)
+        hw_sincos_unwrapped(p - r, &sn, &cs);
+        t = (range * float2_t{cs, sn}) * cpm;
+    } else
+        t = range * trig_by_addition(pcs, cr, sr);           // pcs = cpm (cos p, sin p): the direction comes out in cells per metre ("pcs scaled" above)
     // (the point at twice the range as e + t, one addition instead of the reference's (t + t) + start: see "x'' = " above)
-    const float2_t dir = {cs, sn};
-    const float2_t t = (range * dir) * cpm;
     const float2_t e = t + start, x = e + t;
     // the distance of a coordinate c to the nearest integer is 0.5 - |fract(c) - 0.5|, every step of it exact in float (fract(c) is
     // c - floor(c), a multiple of c's ulp below 1): "farther than B from every integer" is max(|fract - 0.5|) < 0.5 - B.  kh = 0.5 - k2
@@ -931,7 +935,7 @@ __global__ __launch_bounds__(BLOCK) void k_mcl_main(mcl_args a)
         pth = bl_wrap_to_pi(s.z + n1 + n3);
         if (a.cells) bl_global_to_grid(px, py, a.frame, &sx0, &sy0);
         bl_sincosf(pth, &pth_sin, &pth_cos);                 // (the estimate's partial sums need them anyway: particle_filter.cpp:151-152)
-        if (a.cells && a.fast_trig == 1) pcs_own = make_float2(pth_cos, pth_sin);
+        if (a.cells && a.fast_trig == 1) pcs_own = make_float2(a.frame.cpm * pth_cos, a.frame.cpm * pth_sin);    // ("pcs scaled", ray_cells_fast)
     }
     // guard-band offset of the fast trig path for this particle: 2.04 u times a bound on its cell coordinates (ray_cells_fast)
     const float trig_reach = 2.0f * a.max_range_cells + 8.0f;
@@ -2844,12 +2848,15 @@ __global__ __launch_bounds__(256) void k_trig_addition_probe(unsigned long long 
         }
         float ps, pc;
         bl_sincosf(p, &ps, &pc);
-        const float2_t pcs = {pc, ps};
+        // the form the ray loop runs: the pair scaled by the cells per metre (20 for the shipped maps; every fourth pair with a scale
+        // that is no power of two times a short mantissa), the result taken back to a direction in double
+        const float cpm = (rnd & 12ull) == 4ull ? 13.7f + (float)((rnd >> 44) & 1023ull) * 0.01f : 20.0f;
+        const float2_t pcs = {cpm * pc, cpm * ps};
         const float4 rt = ray_table_entry(1.0f, r);
-        const float2_t dir = trig_by_addition(pcs, rt.z, rt.w);
+        const float2_t dc = trig_by_addition(pcs, rt.z, rt.w);
         float sn, cs;
         bl_sincosf_cells(wrap_to_pi_cells(p - r, true), &sn, &cs);
-        const float es = __builtin_fabsf(dir.y - sn), ec = __builtin_fabsf(dir.x - cs);
+        const float es = (float)__builtin_fabs((double)dc.y / (double)cpm - (double)sn), ec = (float)__builtin_fabs((double)dc.x / (double)cpm - (double)cs);
         ms = max(ms, __float_as_uint(es)); mc = max(mc, __float_as_uint(ec));
     }
     for (int off = 32; off > 0; off >>= 1) { ms = max(ms, (unsigned int)__shfl_xor((int)ms, off, 64)); mc = max(mc, (unsigned int)__shfl_xor((int)mc, off, 64)); }

@@ -38,19 +38,20 @@ def test_hardware_trig_stays_inside_the_guard_band(gpu_ctx):
 
 def test_trig_by_addition_stays_inside_the_guard_band(gpu_ctx):
     """The default form of the fast path: the ray's direction from the particle's and the ray's (cos, sin) pairs by the addition
-    theorems (bl_mcl.hip, ray_cells_fast).  Its distance from the reference's sinf / cosf is bounded analytically by 8.2e-7; this
+    theorems (bl_mcl.hip, ray_cells_fast), with the particle's pair carried scaled by the cells per metre as the ray loop carries it
+    (round 6).  Its distance from the reference's sinf / cosf is bounded analytically by 8.8e-7 (8.2e-7 unscaled); this
     measures it over 4e9 random pairs with the functions the ray loop calls (the committed figure, profiles/r04_trig_addition_probe.json,
     is from 1e10) and asserts the same constant the band is built from, with at least 25 % to spare."""
     ms, mc, eps, n = C.c_float(), C.c_float(), C.c_float(), C.c_uint64()
     check(gpu_ctx.lib.bl_debug_trig_addition_probe(gpu_ctx.h, 4_000_000_000, 20261004, C.byref(ms), C.byref(mc), C.byref(eps), C.byref(n)))
     report = dict(pairs_checked=int(n.value), max_sin_err=float(ms.value), max_cos_err=float(mc.value), eps_used=float(eps.value),
-                  analytic_bound=8.2e-7, margin=float(eps.value) / max(float(ms.value), float(mc.value)) - 1.0)
+                  analytic_bound=8.8e-7, margin=float(eps.value) / max(float(ms.value), float(mc.value)) - 1.0)
     os.makedirs("gpurun_out", exist_ok=True)
     with open(os.path.join("gpurun_out", "trig_addition_probe.json"), "w") as fh:
         json.dump(report, fh)
     assert n.value >= 4_000_000_000
     assert 0.0 < ms.value and 0.0 < mc.value
-    assert ms.value <= 8.2e-7 and mc.value <= 8.2e-7, report          # the derived bound holds for every pair seen
+    assert ms.value <= 8.8e-7 and mc.value <= 8.8e-7, report          # the derived bound holds for every pair seen
     assert ms.value * 1.25 <= eps.value and mc.value * 1.25 <= eps.value, report
 
 
