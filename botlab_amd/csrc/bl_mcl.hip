@@ -375,7 +375,7 @@ __device__ __forceinline__ float2_t trig_by_addition(float2_t pcs, float cr, flo
 // hw: wave-uniform, a kernel argument)
 template <bool HW>
 __device__ __forceinline__ void ray_cells_fast(float2_t start, float cpm, float range, float p, float r, float2_t pcs, float cr, float sr,
-                                               float k1, float kh, float kh2, short2_t& E, short2_t& X)
+                                               float k1, float kh2, short2_t& E, short2_t& X)
 {
     float2_t t;
     if (HW) {                                                // (BOTLAB_MCL_HW_TRIG: a loop of its own, chosen outside it; the marker
@@ -388,14 +388,16 @@ __device__ __forceinline__ void ray_cells_fast(float2_t start, float cpm, float 
     // (the point at twice the range as e + t, one addition instead of the reference's (t + t) + start: see "x'' = " above)
     const float2_t e = t + start, x = e + t;
     // the distance of a coordinate c to the nearest integer is 0.5 - |fract(c) - 0.5|, every step of it exact in float (fract(c) is
-    // c - floor(c), a multiple of c's ulp below 1): "farther than B from every integer" is max(|fract - 0.5|) < 0.5 - B.  kh = 0.5 - k2
-    // - 1.2e-7: the threshold's own rounding (half an ulp of 0.5, twice) only ever widens the band.
-    const float C1 = __builtin_fmaf(range, -k1, kh), C2 = __builtin_fmaf(range, -(k1 + k1), kh2);
+    // c - floor(c), a multiple of c's ulp below 1): "farther than B from every integer" is max(|fract - 0.5|) < 0.5 - B.  kh2 = 0.5 -
+    // 1.5 k2 - 1.2e-7: the threshold's own rounding (half an ulp of 0.5, twice) only ever widens the band.
+    // (one threshold for the four coordinates, the far point's -- B2 >= B1, so the endpoint is only tested more strictly than it
+    // needs: a third more rays in the band, two instructions less on every ray)
+    const float C2 = __builtin_fmaf(range, -(k1 + k1), kh2);
     const float2_t fe = float2_t{__builtin_amdgcn_fractf(e.x), __builtin_amdgcn_fractf(e.y)} - 0.5f;
     const float2_t fx = float2_t{__builtin_amdgcn_fractf(x.x), __builtin_amdgcn_fractf(x.y)} - 0.5f;
-    const float me = __builtin_fmaxf(__builtin_fabsf(fe.x), __builtin_fabsf(fe.y));
     const float mx = __builtin_fmaxf(__builtin_fabsf(fx.x), __builtin_fabsf(fx.y));
-    const bool near = !(me < C1) || !(mx < C2);                          // (a nan lands here too)
+    const float m4 = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(fe.x), __builtin_fabsf(fe.y)), mx);
+    const bool near = !(m4 < C2);                                        // (a nan lands here too)
     ray_points_to_cells(e, x, E, X);
     if (__builtin_amdgcn_ballot_w64(near)) {
         float sn2, cs2;
@@ -580,13 +582,13 @@ __device__ __forceinline__ void philox_normals3(uint32_t m, uint32_t step, uint3
         for (int k_ = 0; k_ < rounds_; ++k_, off_ += split * 16) {                      \
             const float4 rt = *(const float4*)((const char*)s_ray + off_);              \
             short2_t E_, X_;                                                            \
-            ray_cells_fast<HW>(start, a.frame.cpm, rt.x, pth_r, rt.y, pcs_, rt.z, rt.w, trig_k1, trig_kh, trig_kh2, E_, X_);   \
+            ray_cells_fast<HW>(start, a.frame.cpm, rt.x, pth_r, rt.y, pcs_, rt.z, rt.w, trig_k1, trig_kh2, E_, X_);   \
             acc += score_cells_pk(PM, S, E_, X_);                                       \
         }                                                                               \
         if ((off_ >> 4) < (HI)) {                                                       \
             const float4 rt = *(const float4*)((const char*)s_ray + off_);              \
             short2_t E_, X_;                                                            \
-            ray_cells_fast<HW>(start, a.frame.cpm, rt.x, pth_r, rt.y, pcs_, rt.z, rt.w, trig_k1, trig_kh, trig_kh2, E_, X_);   \
+            ray_cells_fast<HW>(start, a.frame.cpm, rt.x, pth_r, rt.y, pcs_, rt.z, rt.w, trig_k1, trig_kh2, E_, X_);   \
             acc += score_cells_pk(PM, S, E_, X_);                                       \
         }                                                                               \
     } while (0)
@@ -951,8 +953,7 @@ __global__ __launch_bounds__(BLOCK) void k_mcl_main(mcl_args a)
     if (shared_pro) { const float4 e = s_pp[jl]; r_pth = e.x; r_sx0 = e.y; r_sy0 = e.z; trig_k2 = e.w; r_pcs = s_pcs[jl]; }
     const float2_t pcs_ = {r_pcs.x, r_pcs.y};
     const float trig_k1 = 1.02f * a.frame.cpm * (MCL_TRIG_EPS + 2.3842e-7f);      // 4u = 2^-22
-    const float trig_kh = 0.5f - trig_k2 - 1.2e-7f;                                // (ray_cells_fast: the band as a threshold on |fract - 0.5|)
-    const float trig_kh2 = 0.5f - 1.5f * trig_k2 - 1.2e-7f;                        // ... for the point at twice the range, formed as e + t
+    const float trig_kh2 = 0.5f - 1.5f * trig_k2 - 1.2e-7f;                        // (ray_cells_fast: the band as a threshold on |fract - 0.5|; the far point's, formed as e + t)
     const bool fast_trig = a.fast_trig != 0;                                       // wave-uniform
     const bool hw_trig_ = a.fast_trig == 2;
     const int isx0 = (int)r_sx0, isy0 = (int)r_sy0;
