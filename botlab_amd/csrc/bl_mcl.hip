@@ -202,7 +202,7 @@ __device__ __forceinline__ short2_t pk_sign_fill(short2_t v)              // per
 }
 
 // bl_bresenham_first_step on packed cells: step x iff 2dx - dy >= 0, step y iff 2dy - dx >= 0, toward the target
-__device__ __forceinline__ short2_t first_step_pk(short2_t e, short2_t target)
+__device__ __forceinline__ short2_t first_step_sg(short2_t e, short2_t target)     // the step itself: (+-1 or 0, +-1 or 0)
 {
     const short2_t d = target - e;
     const short2_t nd = -d;
@@ -213,8 +213,9 @@ __device__ __forceinline__ short2_t first_step_pk(short2_t e, short2_t target)
     const short2_t dpos = pk_sign_fill(nd);                               // d > 0 ? -1 : 0 (the sign of -d, which |d| needed anyway)
     // (~dpos | 1) & ~nostep, i.e. (d > 0 ? 1 : -1) where the axis steps, in one v_bitop3 (truth table a=dpos, b=nostep, c=1: bits 0, 1, 5)
     const int sg = __builtin_amdgcn_bitop3_b32(__builtin_bit_cast(int, dpos), __builtin_bit_cast(int, nostep), 0x00010001, 0x23);
-    return e + __builtin_bit_cast(short2_t, sg);
+    return __builtin_bit_cast(short2_t, sg);
 }
+__device__ __forceinline__ short2_t first_step_pk(short2_t e, short2_t target) { return e + first_step_sg(e, target); }
 
 // A wave-uniform value held in a vector register for the whole ray loop (an asm operand of pk_dot2 that the compiler only
 // knows as a scalar is re-materialised with a v_mov in front of every use)
@@ -257,6 +258,13 @@ __device__ __forceinline__ int pk_read(const pk_map_global& pm, short2_t c)
 {
     return pm.base[pk_dot2(c, pm.K, 0)];                                   // |offset| < 2^27
 }
+// the same reads by position: where cell c lies (the LDS address, or the offset in the framed copy), and a cell one step sg from
+// a position -- the dot product is linear, so the neighbour's position is dot2(sg, K) + the cell's: one instruction where forming
+// the neighbour cell and its position takes two
+__device__ __forceinline__ int pk_pos(const pk_map& pm, short2_t c) { return pk_dot2(c, pm.K, pm.base); }
+__device__ __forceinline__ int pk_pos(const pk_map_global& pm, short2_t c) { return pk_dot2(c, pm.K, 0); }
+__device__ __forceinline__ int pk_at(const pk_map&, int pos) { return *(const lds_i8_t*)(size_t)(unsigned int)pos; }
+__device__ __forceinline__ int pk_at(const pk_map_global& pm, int pos) { return pm.base[pos]; }
 
 // SensorModel::scoreRay in half-units (see score_ray_half_units), packed form.  The float endpoint arithmetic is written on
 // (x, y) pairs as well (v_pk_mul_f32 / v_pk_add_f32): each lane-wise operation is the reference's own IEEE operation
@@ -420,7 +428,8 @@ template <class PM>
 __device__ __forceinline__ int score_cells_pk(const PM& pm, short2_t S, short2_t E, short2_t X)
 {
     const short2_t Ec = pk_clamp_endpoint(E, pm.hi);
-    return score_pick(pk_read(pm, Ec), pk_read(pm, first_step_pk(Ec, S)), pk_read(pm, first_step_pk(Ec, X)));
+    const int p0 = pk_pos(pm, Ec);
+    return score_pick(pk_at(pm, p0), pk_at(pm, pk_dot2(first_step_sg(Ec, S), pm.K, p0)), pk_at(pm, pk_dot2(first_step_sg(Ec, X), pm.K, p0)));
 }
 template <class PM>
 __device__ __forceinline__ int score_ray_pk(const PM& pm, float2_t start, short2_t S, float cpm, float range, float cs, float sn)
@@ -444,9 +453,10 @@ __device__ __forceinline__ int score_cells_pk(const pk_map_window& pm, short2_t 
     const bool miss = __builtin_bit_cast(int, Ec) != __builtin_bit_cast(int, Ew);
     // window coordinates throughout: the directions toward S and X are differences, so both move with the origin
     const short2_t Sw = S - pm.org, Xw = X - pm.org;
-    int odds = *(const lds_i8_t*)(size_t)(unsigned int)pk_dot2(Ec, pm.K, pm.base);
-    int o1 = *(const lds_i8_t*)(size_t)(unsigned int)pk_dot2(first_step_pk(Ec, Sw), pm.K, pm.base);
-    int o2 = *(const lds_i8_t*)(size_t)(unsigned int)pk_dot2(first_step_pk(Ec, Xw), pm.K, pm.base);
+    const int p0 = pk_dot2(Ec, pm.K, pm.base);
+    int odds = *(const lds_i8_t*)(size_t)(unsigned int)p0;
+    int o1 = *(const lds_i8_t*)(size_t)(unsigned int)pk_dot2(first_step_sg(Ec, Sw), pm.K, p0);
+    int o2 = *(const lds_i8_t*)(size_t)(unsigned int)pk_dot2(first_step_sg(Ec, Xw), pm.K, p0);
     if (__builtin_amdgcn_ballot_w64(miss)) {
         if (miss) {
             const short2_t Eg = pk_clamp_endpoint(E, pm.g.hi);
