@@ -346,8 +346,11 @@ __device__ __forceinline__ void ray_cells_pk(float2_t start, float cpm, float ra
 //     |t' - t|, t = fl(fl(range * dir) * cpm)   <= range * cpm * (eps + 4u) (1 + 2u)
 //     |e' - e|, e = fl(t + start)                <= range * cpm * (eps + 4u) (1 + 2u) + 2u * max(|e|, |e'|)
 //     |x' - x|, x = fl(fl(t + t) + start)        <= 2 * range * cpm * (eps + 4u) (1 + 2u) + 2u * max(|x|, |x'|)
-//     x'' = fl(e' + t') (round 6: one addition; t + t is exact, so x = (2t + start)(1 + d), and x'' = (2t' + start) + d2 e' + d3 x''):
-//     |x'' - x|                                   <= 2 * range * cpm * (eps + 4u) (1 + 2u) + 3u * max(|x|, |x''|, |e'|)
+//     round 6: e' = fl(range * dc + start), x'' = fl(range * dc + e') with dc = cpm * dir' -- one fused multiply-add each.  With
+//     T = range * dc (no rounding): |T - t| <= range * cpm * (eps + 2u) (t has two roundings), e' = (T + start)(1 + d1), x'' = (T + e')(1 + d2),
+//     and t + t exact in x = (2t + start)(1 + d):
+//     |e' - e|                                    <= range * cpm * (eps + 2u) + 2u * max(|e|, |e'|)
+//     |x'' - x|                                   <= 2 * range * cpm * (eps + 2u) + 3u * max(|x|, |x''|, |e'|)
 // so the truncated cells agree whenever e' (x'') is farther than B1 (B2) from every integer, B1 = range * k1 + k2, B2 = range * 2 k1
 // + 1.5 k2 with k1 = 1.02 * cpm * (eps + 4u) and k2 = 2.04u * (a bound on the particle's cell coordinates: |start| + 2 * longest
 // ray + 8).  A ray inside a band (1-4 in a thousand) makes its whole wave take the exact path for that round and keeps the exact
@@ -385,16 +388,18 @@ template <bool HW>
 __device__ __forceinline__ void ray_cells_fast(float2_t start, float cpm, float range, float p, float r, float2_t pcs, float cr, float sr,
                                                float k1, float kh2, short2_t& E, short2_t& X)
 {
-    float2_t t;
+    float2_t dc;                                             // cpm * (cos, sin)(p - r)
     if (HW) {                                                // (BOTLAB_MCL_HW_TRIG: a loop of its own, chosen outside it; the marker
         float sn, cs;                                        // keeps the optimiser from folding the two loops back into one with this
         asm volatile("; hardware sine / cosine");            // branch inside)
         hw_sincos_unwrapped(p - r, &sn, &cs);
-        t = (range * float2_t{cs, sn}) * cpm;
+        dc = float2_t{cs, sn} * cpm;
     } else
-        t = range * trig_by_addition(pcs, cr, sr);           // pcs = cpm (cos p, sin p): the direction comes out in cells per metre ("pcs scaled" above)
-    // (the point at twice the range as e + t, one addition instead of the reference's (t + t) + start: see "x'' = " above)
-    const float2_t e = t + start, x = e + t;
+        dc = trig_by_addition(pcs, cr, sr);                  // pcs = cpm (cos p, sin p): the direction comes out in cells per metre ("pcs scaled" above)
+    // the two points by two packed multiply-adds (e = range dc + start, x = range dc + e) where the reference has a product, its
+    // double and two additions: see "x'' = " above -- one rounding per point instead of two or three, inside the same bounds
+    const float2_t rr = {range, range};
+    const float2_t e = __builtin_elementwise_fma(rr, dc, start), x = __builtin_elementwise_fma(rr, dc, e);
     // the distance of a coordinate c to the nearest integer is 0.5 - |fract(c) - 0.5|, every step of it exact in float (fract(c) is
     // c - floor(c), a multiple of c's ulp below 1): "farther than B from every integer" is max(|fract - 0.5|) < 0.5 - B.  kh2 = 0.5 -
     // 1.5 k2 - 1.2e-7: the threshold's own rounding (half an ulp of 0.5, twice) only ever widens the band.
