@@ -456,12 +456,12 @@ __device__ __forceinline__ int score_cells_pk(const pk_map_window& pm, short2_t 
     const short2_t Ew = E - pm.org;
     const short2_t Ec = __builtin_elementwise_min(__builtin_elementwise_max(Ew, one), pm.hi);
     const bool miss = __builtin_bit_cast(int, Ec) != __builtin_bit_cast(int, Ew);
-    // window coordinates throughout: the directions toward S and X are differences, so both move with the origin
-    const short2_t Sw = S - pm.org, Xw = X - pm.org;
+    // the directions toward S and X are differences: taken from the endpoint itself in grid coordinates -- where the clamp moved it
+    // (miss) all three values are read again below
     const int p0 = pk_dot2(Ec, pm.K, pm.base);
     int odds = *(const lds_i8_t*)(size_t)(unsigned int)p0;
-    int o1 = *(const lds_i8_t*)(size_t)(unsigned int)pk_dot2(first_step_sg(Ec, Sw), pm.K, p0);
-    int o2 = *(const lds_i8_t*)(size_t)(unsigned int)pk_dot2(first_step_sg(Ec, Xw), pm.K, p0);
+    int o1 = *(const lds_i8_t*)(size_t)(unsigned int)pk_dot2(first_step_sg(E, S), pm.K, p0);
+    int o2 = *(const lds_i8_t*)(size_t)(unsigned int)pk_dot2(first_step_sg(E, X), pm.K, p0);
     if (__builtin_amdgcn_ballot_w64(miss)) {
         if (miss) {
             const short2_t Eg = pk_clamp_endpoint(E, pm.g.hi);
