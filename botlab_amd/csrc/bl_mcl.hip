@@ -351,9 +351,11 @@ __device__ __forceinline__ void ray_cells_pk(float2_t start, float cpm, float ra
 //     and t + t exact in x = (2t + start)(1 + d):
 //     |e' - e|                                    <= range * cpm * (eps + 2u) + 2u * max(|e|, |e'|)
 //     |x'' - x|                                   <= 2 * range * cpm * (eps + 2u) + 3u * max(|x|, |x''|, |e'|)
-// so the truncated cells agree whenever e' (x'') is farther than B1 (B2) from every integer, B1 = range * k1 + k2, B2 = range * 2 k1
-// + 1.5 k2 with k1 = 1.02 * cpm * (eps + 4u) and k2 = 2.04u * (a bound on the particle's cell coordinates: |start| + 2 * longest
-// ray + 8).  A ray inside a band (1-4 in a thousand) makes its whole wave take the exact path for that round and keeps the exact
+// so the truncated cells agree whenever e' (x'') is farther than B1 (B2) from every integer.  With max(|x|, |x''|, |e'|) <= |start| +
+// 2 range cpm + 8 the far point's band -- the one the test uses for all four coordinates -- is
+//     B2 = range * cpm * (2.04 (eps + 4u) + 6.12 u) + 3.06 u (|start| + 8)
+// (until round 6 the coordinate bound used the LONGEST ray for every ray: the constant part was 2.5 times what it is now and, at the
+// scan's typical 2 - 3 m, a quarter of the band).  A ray inside a band (1-4 in a thousand) makes its whole wave take the exact path for that round and keeps the exact
 // cells; everything downstream is integer.  The test itself (round 6): the distance of c to the nearest integer is 0.5 - |fract(c) - 0.5|,
 // exactly, so "both coordinates farther than B" is max(|fract - 0.5|) < 0.5 - B -- two v_fract, one packed add, one max per point;
 // the threshold 0.5 - B is formed with 1.2e-7 taken off (its two roundings are half an ulp of 0.5 each), which only widens the band.
@@ -405,7 +407,7 @@ __device__ __forceinline__ void ray_cells_fast(float2_t start, float cpm, float 
     // 1.5 k2 - 1.2e-7: the threshold's own rounding (half an ulp of 0.5, twice) only ever widens the band.
     // (one threshold for the four coordinates, the far point's -- B2 >= B1, so the endpoint is only tested more strictly than it
     // needs: a third more rays in the band, two instructions less on every ray)
-    const float C2 = __builtin_fmaf(range, -(k1 + k1), kh2);
+    const float C2 = __builtin_fmaf(range, -k1, kh2);
     const float2_t fe = float2_t{__builtin_amdgcn_fractf(e.x), __builtin_amdgcn_fractf(e.y)} - 0.5f;
     const float2_t fx = float2_t{__builtin_amdgcn_fractf(x.x), __builtin_amdgcn_fractf(x.y)} - 0.5f;
     const float mx = __builtin_fmaxf(__builtin_fabsf(fx.x), __builtin_fabsf(fx.y));
@@ -955,8 +957,9 @@ __global__ __launch_bounds__(BLOCK) void k_mcl_main(mcl_args a)
         if (a.cells && a.fast_trig == 1) pcs_own = make_float2(a.frame.cpm * pth_cos, a.frame.cpm * pth_sin);    // ("pcs scaled", ray_cells_fast)
     }
     // guard-band offset of the fast trig path for this particle: 2.04 u times a bound on its cell coordinates (ray_cells_fast)
-    const float trig_reach = 2.0f * a.max_range_cells + 8.0f;
-    const float k2_own = 1.2159e-7f * (__builtin_fmaxf(__builtin_fabsf(sx0), __builtin_fabsf(sy0)) + trig_reach);
+    // (the part of the band that does not grow with the range: 2.04 u times the particle's own cell coordinates; what a ray adds to
+    // the coordinates -- up to twice its length -- is in the per-metre coefficient, trig_k1 below)
+    const float k2_own = 1.2159e-7f * (__builtin_fmaxf(__builtin_fabsf(sx0), __builtin_fabsf(sy0)) + 8.0f);
     MCL_STAMP(7);                                                // prologue arithmetic done
     if (shared_pro && tid < P) { s_pp[tid] = make_float4(pth, sx0, sy0, k2_own); s_pcs[tid] = pcs_own; }
     __syncthreads();                                            // map, ray table and particle table are in place
@@ -967,7 +970,10 @@ __global__ __launch_bounds__(BLOCK) void k_mcl_main(mcl_args a)
     float2 r_pcs = pcs_own;
     if (shared_pro) { const float4 e = s_pp[jl]; r_pth = e.x; r_sx0 = e.y; r_sy0 = e.z; trig_k2 = e.w; r_pcs = s_pcs[jl]; }
     const float2_t pcs_ = {r_pcs.x, r_pcs.y};
-    const float trig_k1 = 1.02f * a.frame.cpm * (MCL_TRIG_EPS + 2.3842e-7f);      // 4u = 2^-22
+    // the far point's band per metre of range, in cells: 2 x 1.02 cpm (eps + 4u) for the direction and the products (4u = 2^-22; the
+    // fused form needs 2u, the hardware-trig form 3u), + 3.06 u x 2 cpm for the roundings at coordinates that a ray moves by up to 2 cpm
+    // cells per metre (6.12 u = 3.648e-7)
+    const float trig_k1 = a.frame.cpm * (2.04f * (MCL_TRIG_EPS + 2.3842e-7f) + 3.648e-7f);
     const float trig_kh2 = 0.5f - 1.5f * trig_k2 - 1.2e-7f;                        // (ray_cells_fast: the band as a threshold on |fract - 0.5|; the far point's, formed as e + t)
     const bool fast_trig = a.fast_trig != 0;                                       // wave-uniform
     const bool hw_trig_ = a.fast_trig == 2;
