@@ -638,14 +638,37 @@ __device__ __forceinline__ bool resample_reaches(double T, unsigned long long v,
 // round and different lines per lane in every round, so a round is bound by the L2's request rate (64 Q lines per wave and search),
 // not by its latency.  Q = 1 stands.
 #define MCL_BRACKET_Q 1
+// m (round 6): the lane's own output index, or -1.  U_m = r + m / N, so with weights that do not differ wildly the source index lies
+// near m: ONE round of 64 probes, 64 entries apart, around the first lane's m -- probe 0 the guard below the window, probe 63 its top
+// -- brackets both ends of the wave when the guard does not reach the first target and the top reaches the last; the lanes then
+// bisect a bracket of up to ~200 entries (8 steps instead of 6 - 7) and two of the three dependent rounds are gone.  Anything else
+// (a cumulative far from linear, the array's ends) takes the rounds below from the full range, as before.
+#define MCL_BRACKET_WINDOW 64
 template <int Q, class Prefix>
 __device__ __forceinline__ void resample_bracket(const Prefix& prefix, int N, double T, bool active,
-                                                 int lane, int* out_lo, int* out_hi, bool strict = false)
+                                                 int lane, int* out_lo, int* out_hi, bool strict = false, int m = -1)
 {
     *out_lo = 0; *out_hi = N - 1;
     const unsigned long long act = __builtin_amdgcn_ballot_w64(active);
     if (!act) return;
     const double T0 = readlane_f64(T, __ffsll((long long)act) - 1), T1 = readlane_f64(T, 63 - __clzll((long long)act));
+    const int m0 = __builtin_amdgcn_readlane(m, __ffsll((long long)act) - 1);
+    if (m0 >= 0) {
+        // probes at g, g + W, ..., g + 63 W with g = m0 - 31 W (the wave's targets span about 64 entries around m0 + 32)
+        const int g = m0 - 31 * MCL_BRACKET_WINDOW;
+        if (g >= 0 && g + 63 * MCL_BRACKET_WINDOW < N) {
+            const unsigned long long v = prefix[g + lane * MCL_BRACKET_WINDOW];
+            const unsigned long long b0 = __builtin_amdgcn_ballot_w64(resample_reaches(T0, v, strict));
+            const unsigned long long b1 = __builtin_amdgcn_ballot_w64(resample_reaches(T1, v, strict));
+            // the probes ascend, so each ballot is a run of ones at the top: its lowest set bit f is the first probe that reaches T
+            if (b0 && !(b0 & 1ull) && b1) {
+                const int f0 = __ffsll((long long)b0) - 1, f1 = __ffsll((long long)b1) - 1;
+                *out_lo = g + (f0 - 1) * MCL_BRACKET_WINDOW + 1;        // the probe below f0 does not reach T0: index(T0) lies above it
+                *out_hi = g + f1 * MCL_BRACKET_WINDOW;                  // probe f1 reaches T1: index(T1) is at most there
+                return;
+            }
+        }
+    }
     int lo0 = 0, hi0 = N - 1, lo1 = 0, hi1 = N - 1;
     for (int round = 0; round < 8 && (lo0 < hi0 || lo1 < hi1); ++round) {     // 64^8 entries: the cap only bounds the loop
         const int step0 = (hi0 - lo0 + 64 * Q) / (64 * Q), step1 = (hi1 - lo1 + 64 * Q) / (64 * Q);
@@ -672,9 +695,9 @@ __device__ __forceinline__ void resample_bracket(const Prefix& prefix, int N, do
 }
 template <class Prefix>
 __device__ __forceinline__ void resample_bracket(const Prefix& prefix, int N, double T, bool active,
-                                                 int lane, int* out_lo, int* out_hi, bool strict = false)
+                                                 int lane, int* out_lo, int* out_hi, bool strict = false, int m = -1)
 {
-    resample_bracket<1>(prefix, N, T, active, lane, out_lo, out_hi, strict);
+    resample_bracket<1>(prefix, N, T, active, lane, out_lo, out_hi, strict, m);
 }
 
 // second part: the lane's own bisection inside the bracket.  index(T) = first i with T <= prefix[i] (clamped by the bracket).
@@ -924,7 +947,7 @@ __global__ __launch_bounds__(BLOCK) void k_mcl_main(mcl_args a)
         if (pro_active) { rs_T = a.r + mp * a.M_inv; if (!a.strict && uni_n <= 0) rs_T *= a.state->S; }      // U (particle_filter.cpp:95), or U * S
         if (uni_n > 0) { }
         else if (a.sh) resample_bracket(pview, a.N, rs_T, pro_active, lane, &rs_lo, &rs_hi, a.strict != 0);
-        else resample_bracket<MCL_BRACKET_Q>(a.prefix, a.N, rs_T, pro_active, lane, &rs_lo, &rs_hi, a.strict != 0);
+        else resample_bracket<MCL_BRACKET_Q>(a.prefix, a.N, rs_T, pro_active, lane, &rs_lo, &rs_hi, a.strict != 0, pro_active ? mp : -1);
     }
     MCL_STAMP(5);                                                // the bracket is known
     // (Round 6, measured and dropped: the bracket's entries -- usually ~100 -- brought into the wave's quarter of the particle table in
