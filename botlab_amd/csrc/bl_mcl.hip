@@ -1991,7 +1991,7 @@ static int pf_launch_main(bl_pf* pf, const bl_grid* map, int R, int rand_value, 
     // particles 0.128 ms; the straggling round lasts T/4, the time one wave needs for its particles' rays on an idle CU).
     // When the count exceeds whole rounds by less than ~60 % of a round, the excess particles therefore go to a second
     // region of the same launch, dispatched last, in which every particle has a whole wave (5 rays per lane instead of
-    // 73): those workgroups last ~T/10.  One round is counted 1/32 short of what the device holds, because the
+    // 73): those workgroups last ~T/10.  One round is counted a little short of what the device holds (below), because the
     // replanner's kernels on the other streams occupy a few workgroup slots.
     const int gpb = block >> a.split_log2;                  // particles per region-1 workgroup
     int64_t main_blocks = ((int64_t)pf->n_local + gpb - 1) / gpb, tail_blocks = 0;
@@ -2003,7 +2003,10 @@ static int pf_launch_main(bl_pf* pf, const bl_grid* map, int R, int rand_value, 
         const int lds_per_wg = lds_bytes + 9 * 1024;        // + static LDS (ray table, partial sums)
         if ((160 * 1024) / lds_per_wg < per_cu) per_cu = (160 * 1024) / lds_per_wg;
         if (per_cu < 1) per_cu = 1;
-        const int64_t round = (int64_t)cus * per_cu - (int64_t)cus * per_cu / 32;
+        // (round 6: 1/128 short -- six slots -- where it was 1/32 until the ray loop lost a quarter of its instructions: 11 930 -> 12 250
+        // steps/s on the headline, profiles/r06_mcl_round_split.txt; BOTLAB_MCL_ROUND_SHORT = the divisor, 0 = a full round)
+        static const int short_div = getenv("BOTLAB_MCL_ROUND_SHORT") ? atoi(getenv("BOTLAB_MCL_ROUND_SHORT")) : 128;
+        const int64_t round = (int64_t)cus * per_cu - (short_div > 0 ? (int64_t)cus * per_cu / short_div : 0);
         const int64_t full = main_blocks / round, excess = main_blocks - full * round;
         // (a particle of the second region costs a wave about a tenth of a region-1 workgroup's time, and the device runs ~6000
         // such waves at once: past ~25 000 excess particles the second region outlasts the straggling round it replaces --
