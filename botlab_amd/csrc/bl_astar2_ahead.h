@@ -965,9 +965,14 @@
     "s_cselect_b32 s36, s89, s36\n\t"                                                                         \
     "s_cselect_b32 s37, s90, s37\n\t"
 // line SET as an earlier push (ID drops, slot IS, key IK, payload IP) left it
-#define A2P_PATCH(TAG, ID, IS, IK, IP, ...) A2P_PATCH_(TAG, ID, IS, IK, IP, __VA_ARGS__)
-#define A2P_PATCH_(TAG, ID, IS, IK, IP, SL, V231, K, P, GK, GP, O236, E165, O166, L237, MK, MP)               \
+// (STALE: where to go when the two slots lie on different LEVELS of the heap -- the later one is, or follows, a power of two: the
+// lines then share the root at different heights, which no lane shift expresses; such a line is read again.  The xor exceeds the
+// earlier slot exactly then.  tests/test_push_lines_model_cpu.py found this case; no fixture ever met it with a push at the root.)
+#define A2P_PATCH(TAG, STALE, ID, IS, IK, IP, ...) A2P_PATCH_(TAG, STALE, ID, IS, IK, IP, __VA_ARGS__)
+#define A2P_PATCH_(TAG, STALE, ID, IS, IK, IP, SL, V231, K, P, GK, GP, O236, E165, O166, L237, MK, MP)        \
     "s_xor_b32 s82, " IS ", " SL "\n\t"                                                                       \
+    "s_cmp_gt_u32 s82, " IS "\n\t"                                                                            \
+    "s_cbranch_scc1 " STALE "\n\t"                                                                            \
     "s_flbit_i32_b32 s82, s82\n\t"                                                                            \
     "s_sub_i32 s82, 32, s82\n\t"                     /* c: the two lines are the same nodes from this height up */ \
     "s_cmp_ge_u32 " ID ", s82\n\t"                                                                            \
@@ -1113,7 +1118,7 @@
     /* ---- the second: line B as the first push left it */                                                   \
     A2T_PUSH_CHECK("27f") A2D_PUSH_PICK                                                                       \
     "s_mov_b32 s83, 0\n\t"                                                                                    \
-    A2P_PATCH("231", "s72", "s73", "s74", "s75", A2P_SET_B)                                                   \
+    A2P_PATCH("231", "23f", "s72", "s73", "s74", "s75", A2P_SET_B)                                                   \
     A2P_DECIDE(A2P_SET_B)                                                                                     \
     A2P_TEST("23f")                                                                                           \
     A2P_STORES("s76", "s77", "s80", "s81", A2P_SET_B) A2P_WHERE("1", A2P_SET_B)                               \
@@ -1126,8 +1131,8 @@
     /* ---- the third: line C as the first two left it */                                                     \
     A2T_PUSH_CHECK("27f") A2D_PUSH_PICK                                                                       \
     "s_mov_b32 s83, 0\n\t"                                                                                    \
-    A2P_PATCH("251", "s72", "s73", "s74", "s75", A2P_SET_C)                                                   \
-    A2P_PATCH("252", "s76", "s77", "s80", "s81", A2P_SET_C)                                                   \
+    A2P_PATCH("251", "25f", "s72", "s73", "s74", "s75", A2P_SET_C)                                                   \
+    A2P_PATCH("252", "25f", "s76", "s77", "s80", "s81", A2P_SET_C)                                                   \
     A2P_DECIDE(A2P_SET_C)                                                                                     \
     A2P_TEST("25f")                                                                                           \
     A2P_STORES("s72", "s73", "s74", "s75", A2P_SET_C) A2P_WHERE("2", A2P_SET_C)                               \
