@@ -150,3 +150,57 @@ def test_a_line_read_before_the_pop_is_good_where_the_rule_says_so():
                 stale += 1                                  # the kernel reads the line again
             push_heap(h, key)
     assert fresh > 1000 and stale > 10
+
+
+def test_the_push_wave_as_the_kernel_runs_it():
+    """The whole sequence of an iteration beyond LDS: the three lines are read BEFORE the pop (the slots follow from the length), the
+    pop goes in, then each push decides from its line -- patched for the earlier pushes, read again where a rule says so -- and must
+    drop exactly the ancestors, with exactly the values, that std::push_heap drops on the heap as it stands."""
+    rng = random.Random(77)
+    decided = reread = 0
+    for trial in range(500):
+        n0 = rng.choice([4, 9, 33, 130, 1030, 4100])
+        spread = rng.choice([2, 5, 40, 100000])
+        h = []
+        for k in range(n0):
+            push_heap(h, (rng.randrange(spread), ("old", k)))
+        for step in range(25):
+            if len(h) < 3:
+                break
+            npush = rng.randrange(0, 4)
+            base = len(h) - 1                               # the length behind the pop
+            lines = [line(h, base + 1 + j) for j in range(3)]               # asked for at B1, beside the pop
+            top, landing = pop_heap(h)
+            info = []
+            for j in range(npush):
+                s_j = base + 1 + j
+                lo = min(x[0] for x in h)
+                key = (rng.choice([lo - 1, lo, lo, rng.randrange(spread), rng.randrange(spread)]), ("new", trial, step, j))
+                ln, patches, again = lines[j], 0, False
+                for (d_i, s_i, key_i) in info:
+                    ln2, did = patch(ln, d_i, s_i, key_i, s_j)
+                    if ln2 is None:
+                        again = True
+                        break
+                    ln, patches = ln2, patches + did
+                if not again:
+                    d = 0
+                    while d < len(ln) and ln[d] is not None and ln[d][0] > key[0]:
+                        d += 1
+                    node = s_j >> (d + 1 + patches)         # the stopper, or the node `patches` levels above it
+                    again = node < 1 or on_path(node, landing)
+                if again:
+                    reread += 1
+                    ln = line(h, s_j)
+                    d = 0
+                    while d < len(ln) and ln[d] is not None and ln[d][0] > key[0]:
+                        d += 1
+                else:
+                    decided += 1
+                dropped = ln[:d]
+                true_line = line(h, s_j)
+                slot, drops = push_heap(h, key)
+                assert slot == s_j and drops == d, (trial, step, j, again)
+                assert dropped == true_line[:d], (trial, step, j, again)
+                info.append((drops, slot, key))
+    assert decided > 3000 and reread > 100
