@@ -37,9 +37,12 @@ struct frontier_args {
     int32_t* out_cells;         // frontier cells, frontier after frontier, each in growth-queue order
     int32_t* out_offsets; int cap_frontiers;
     int32_t* counts;            // [0] frontiers, [1] frontier cells, [2] free cells reached (+1), [3] levels, [4] overflow flag,
-                                // [5], [6] time stamps, [7] touches found (k_frontier_touches), [8] "take the one-workgroup sweep" flag
+                                // [5], [6] time stamps, [8] "take the one-workgroup sweep" flag, [10] "k_frontier_grow2 declined: k_frontier_grow"
+                                // flag, [12] frontier-class cells found, [13] touches found (k_frontier_touches: one 64-bit counter)
     int phase;                  // k_frontiers: 0 flood + sweep (small grids), 1 flood only, 2 sweep only (and only if counts[8] is set)
     uint2* touch;               // (key, cell) of every frontier cell the flood touched, in no order; FR_TOUCH_MAX entries
+    int32_t* fcell;             // every frontier-class cell of the grid, in no order; FG_CELL_MAX entries (k_frontier_touches; counts[12])
+    int grow_v1;                // take k_frontier_grow (visited set only, classes from global memory) whatever the map holds
     uint8_t* nb;                // large grids: per cell, the static classes of its four neighbours, 2 bits each (k_frontier_nb)
     const bl_pose_xyt_t* d_pose; // the robot pose in device memory (then rx, ry are formed by every kernel that needs them), or null
     bl_frame frame;
@@ -363,7 +366,7 @@ __global__ __launch_bounds__(FR_T) void k_frontiers(frontier_args a)
     const int qn = hi;
     const long long t_flood = wall_clock64();
     if (a.phase == 1) {
-        if (tid == 0) { a.counts[2] = qn; a.counts[3] = levels; a.counts[5] = (int)(t_flood - t_begin); a.counts[7] = 0; a.counts[8] = 0; }
+        if (tid == 0) { a.counts[2] = qn; a.counts[3] = levels; a.counts[5] = (int)(t_flood - t_begin); a.counts[8] = 0; a.counts[10] = 0; a.counts[12] = 0; a.counts[13] = 0; }
         return;
     }
     // ---- frontiers in discovery order (:66-75): touches in key order; a touched frontier cell that is not part of a grown
@@ -821,7 +824,7 @@ __global__ __launch_bounds__(FL_T) void k_frontier_flood(frontier_args a)
         }
         lo = hi; hi += total; levels += 1;
     }
-    if (tid == 0) { a.counts[2] = hi; a.counts[3] = levels; a.counts[5] = (int)(wall_clock64() - t_begin); a.counts[7] = 0; a.counts[8] = 0; }
+    if (tid == 0) { a.counts[2] = hi; a.counts[3] = levels; a.counts[5] = (int)(wall_clock64() - t_begin); a.counts[8] = 0; a.counts[10] = 0; a.counts[12] = 0; a.counts[13] = 0; }
 #ifdef FL_STAMPS
     if (tid == 0) {
         printf("[flood stamps, 100 MHz ticks] insert %lld  barrier1 %lld  claims %lld  scan %lld  write %lld  barrier4 %lld\n",
@@ -846,16 +849,55 @@ __global__ __launch_bounds__(FL_T) void k_frontier_flood(frontier_args a)
 #define FR_TOUCH_PER_THREAD (FR_TOUCH_MAX / FR_T)
 #define FR_HASH 16384                       // slots of the visited set (a power of two); a frontier may fill half of them
 #define FR_RING 1024                        // growth queue entries mirrored in LDS
+#define FG_SLOTS 32768                      // k_frontier_grow2: slots of the set of ALL frontier-class cells (a power of two) ...
+#define FG_CELL_MAX 16384                   // ... which it fills to one half at most
+#define FG_DMAX 64                          // an insert that finds no room within so many slots of its home gives the sweep to k_frontier_grow
+#define FG_PAD 128                          // no wrap-around: spare slots behind the last home
+#define FG_LDS_BYTES ((FG_SLOTS + FG_PAD) * 4 + FR_RING * 4)
 
 __global__ __launch_bounds__(256) void k_frontier_touches(frontier_args a)
 {
+    // four class bytes per thread and round; a wave that sees no frontier-class cell (nearly all do not) goes on after one ballot
     const long long ncell = (long long)a.W * a.H;
-    for (long long c = (long long)blockIdx.x * 256 + threadIdx.x; c < ncell; c += (long long)gridDim.x * 256) {
-        if (a.cls[c] != 2) continue;
-        const unsigned int key = a.claim[c];
-        if (key == FR_INF) continue;
-        const int at = atomicAdd(&a.counts[7], 1);
-        if (at < FR_TOUCH_MAX) a.touch[at] = make_uint2(key, (unsigned int)c);
+    const int lane = threadIdx.x & 63;
+    for (long long c0 = ((long long)blockIdx.x * 256) * 4; c0 < ncell; c0 += (long long)gridDim.x * 256 * 4) {
+        const long long c = c0 + 4 * (long long)threadIdx.x;
+        unsigned int w = 0;
+        if (c + 3 < ncell) w = *(const unsigned int*)(a.cls + c);
+        else for (int b = 0; b < 4; ++b) if (c + b < ncell) w |= (unsigned int)a.cls[c + b] << (8 * b);
+        const unsigned int x = w ^ 0x02020202u;
+        const bool any = ((x - 0x01010101u) & ~x & 0x80808080u) != 0u;          // some byte of w is 2
+        if (__ballot(any) == 0ull) continue;
+        // every frontier-class cell goes on k_frontier_grow2's list, every touched one on the touch list.  The two counters are this
+        // kernel's bottleneck (every add returns, and adds to one cache line take ~10 ns each at the L2): ONE 64-bit add per wave
+        // and round carries both counts
+        unsigned int key[4];
+        unsigned long long m2[4], mt[4];
+        int n2 = 0, nt = 0;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const bool is2 = ((w >> (8 * b)) & 0xFFu) == 2u;
+            key[b] = FR_INF;
+            if (is2) key[b] = a.claim[c + b];
+            m2[b] = __ballot(is2); mt[b] = __ballot(key[b] != FR_INF);
+            n2 += __popcll(m2[b]); nt += __popcll(mt[b]);
+        }
+        unsigned long long base = 0ull;
+        if (lane == 0) base = atomicAdd((unsigned long long*)&a.counts[12], (unsigned long long)(unsigned int)n2 | ((unsigned long long)(unsigned int)nt << 32));
+        base = __shfl(base, 0, 64);
+        int at2 = (int)(unsigned int)base, at = (int)(base >> 32);
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            if ((m2[b] >> lane) & 1ull) {
+                const int i2 = at2 + (int)__builtin_amdgcn_mbcnt_hi((unsigned int)(m2[b] >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)m2[b], 0u));
+                if (i2 < FG_CELL_MAX) a.fcell[i2] = (int)(c + b);
+            }
+            if ((mt[b] >> lane) & 1ull) {
+                const int it = at + (int)__builtin_amdgcn_mbcnt_hi((unsigned int)(mt[b] >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)mt[b], 0u));
+                if (it < FR_TOUCH_MAX) a.touch[it] = make_uint2(key[b], (unsigned int)(c + b));
+            }
+            at2 += __popcll(m2[b]); at += __popcll(mt[b]);
+        }
     }
 }
 
@@ -882,7 +924,8 @@ __global__ __launch_bounds__(FR_T) void k_frontier_grow(frontier_args a)
     __shared__ int s_seed, s_cnt, s_fail;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const long long t_begin = wall_clock64();
-    const int T = a.counts[7];
+    const int T = a.counts[13];
+    if (a.counts[10] == 0) return;                         // k_frontier_grow2 has grown the frontiers
     if (T > FR_TOUCH_MAX || a.W > 65535 || a.H > 32767) { if (tid == 0) a.counts[8] = 1; return; }      // (the ring packs x | y << 16)
     unsigned int tk[FR_TOUCH_PER_THREAD]; int tc[FR_TOUCH_PER_THREAD];
 #pragma unroll
@@ -970,6 +1013,149 @@ __global__ __launch_bounds__(FR_T) void k_frontier_grow(frontier_args a)
     }
 }
 
+
+// ---- the same sweep with nothing of a frontier's growth in global memory -----------------------------------------------------
+// k_frontier_grow pays a global round trip per step of the growth queue for the classes of the neighbours (a frontier is a thin
+// curve: two cells per step; 1.35 us per step, 5.7 ms for the 8 400 cells of an explored disc at 4096^2), resets its visited set per
+// frontier and reads cls[] once per live touch and frontier.  Here ALL frontier-class cells of the grid (k_frontier_touches lists
+// them: counts[12], fcell[]) sit in ONE LDS set, a word per cell: cell | visited << 31.  "Is the neighbour a frontier cell?" and "has
+// it been grown?" are the same lookup -- one lane per (queued cell, neighbour), linear probing from a multiplicative home, one or
+// two LDS round trips -- the visited bits outlive the frontier (they are the reference's class mark), and a touch is dead when the
+// bit of its cell's slot (found once, in front of the first frontier) is set.  Growth order as before: ascending lane = queue order,
+// then neighbour order; lanes that name one cell in the same step are told apart in registers.
+// More than FG_CELL_MAX frontier-class cells, or a home region without room: k_frontier_grow takes the sweep (counts[10]).
+__device__ __forceinline__ unsigned int fg_home(int c) { return ((unsigned int)c * 2654435761u) >> (32 - 15); }       // FG_SLOTS = 2^15
+
+__global__ __launch_bounds__(FR_T) void k_frontier_grow2(frontier_args a)
+{
+    extern __shared__ __align__(16) int s_fg[];
+    int* s_set = s_fg;
+    int* s_ring = s_fg + FG_SLOTS + FG_PAD;
+    __shared__ unsigned int s_umin[FR_T / 64];
+    __shared__ int s_seed, s_cnt, s_fail;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const long long t_begin = wall_clock64();
+    const int F = a.counts[12], T = a.counts[13];
+    if (T > FR_TOUCH_MAX || a.W > 65535 || a.H > 32767) { if (tid == 0) a.counts[8] = 1; return; }      // (the ring packs x | y << 16)
+    if (F > FG_CELL_MAX || a.grow_v1) { if (tid == 0) a.counts[10] = 1; return; }
+    for (int i = tid; i < FG_SLOTS + FG_PAD; i += FR_T) s_set[i] = -1;
+    if (tid == 0) s_fail = 0;
+    __syncthreads();
+    for (int i = tid; i < F; i += FR_T) {
+        const int c = a.fcell[i];
+        const unsigned int h = fg_home(c);
+        int d = 0;
+#pragma unroll 1
+        for (; d < FG_DMAX; ++d)
+            if (atomicCAS(&s_set[h + (unsigned int)d], -1, c) == -1) break;
+        if (d == FG_DMAX) s_fail = 1;
+    }
+    __syncthreads();
+    if (s_fail) { if (tid == 0) a.counts[10] = 1; return; }
+    // ---- the touches of this thread: key and the slot of the cell (every touched cell is a frontier-class cell: it is there)
+    unsigned int tk[FR_TOUCH_PER_THREAD]; int ts[FR_TOUCH_PER_THREAD];
+#pragma unroll
+    for (int j = 0; j < FR_TOUCH_PER_THREAD; ++j) {
+        const int i = j * FR_T + tid;
+        tk[j] = FR_INF; ts[j] = 0;
+        if (i < T) {
+            const uint2 t = a.touch[i];
+            const unsigned int h = fg_home((int)t.y);
+#pragma unroll 1
+            for (int d = 0; d < FG_DMAX; ++d) {
+                const int sl = (int)(h + (unsigned int)d);
+                if (s_set[sl] == (int)t.y) { tk[j] = t.x; ts[j] = sl; break; }
+            }
+        }
+    }
+    int nf = 0, total = 0, overflow = 0;
+    while (true) {
+        // ---- the next seed: the live touch with the smallest key (frontiers.cpp:66-75 meets them in that order)
+        unsigned int mine = FR_INF; int mine_s = 0;
+#pragma unroll
+        for (int j = 0; j < FR_TOUCH_PER_THREAD; ++j) {
+            if (tk[j] == FR_INF) continue;
+            if (s_set[ts[j]] < 0) { tk[j] = FR_INF; continue; }                  // its frontier has been grown
+            if (tk[j] < mine) { mine = tk[j]; mine_s = ts[j]; }
+        }
+        const unsigned int best = block_min(mine, s_umin);
+        if (best == FR_INF) break;
+        if (mine == best) s_seed = mine_s;                                      // keys are unique
+        __syncthreads();
+        int32_t* fq = a.out_cells + total;
+        if (wave == 0) {
+            // ---- grow_frontier (:249-288) by one wave, serially in queue order; xDeltas {-1,-1,-1,1,1,1,0,0}, yDeltas {0,1,-1,0,1,-1,1,-1}
+            const int seed_slot = s_seed;
+            const int seed = __builtin_amdgcn_readfirstlane(s_set[seed_slot]);
+            int head = 0, tail = 1;
+            int last_xy = (seed % a.W) | ((seed / a.W) << 16);                   // the entry at the back of the queue, in a scalar register
+            if (lane == 0) { fq[0] = seed; s_ring[0] = last_xy; s_set[seed_slot] = seed | (int)0x80000000; }
+            const int n = lane & 7, qi = lane >> 3;
+            const int dx = n < 3 ? -1 : (n < 6 ? 1 : 0);
+            const int dy = (n == 1 || n == 4 || n == 6) ? 1 : ((n == 2 || n == 5 || n == 7) ? -1 : 0);
+            while (head < tail) {
+                const int live = tail - head;
+                const int nb = min(live, 8);
+                int cx = 0, cy = 0;
+                if (live == 1) { cx = last_xy & 0xFFFF; cy = last_xy >> 16; }   // a thin curve: the one queued cell is the one just written
+                else if (live <= FR_RING) { if (qi < nb) { const int e = s_ring[(head + qi) & (FR_RING - 1)]; cx = e & 0xFFFF; cy = e >> 16; } }
+                else if (qi < nb) { const int c = __hip_atomic_load(&fq[head + qi], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); cx = c % a.W; cy = c / a.W; }
+                const int x = cx + dx, y = cy + dy;
+                const bool in = qi < nb && x >= 0 && y >= 0 && x < a.W && y < a.H;
+                const int nc = in ? y * a.W + x : -1, nxy = x | (y << 16);
+                // the neighbour in the set: a frontier-class cell, grown or not; not there: any other class.  Home slot and the next
+                // in one read, without a branch; longer chains (rare at half load) lane by lane
+                const unsigned int h = fg_home(nc);
+                const int v0 = s_set[h], v1 = s_set[h + 1u];
+                const bool m0 = in && (v0 & 0x7FFFFFFF) == nc;                   // (an empty slot reads 0x7FFFFFFF: no cell)
+                const bool on = in && !m0 && v0 != -1;
+                const bool m1 = on && (v1 & 0x7FFFFFFF) == nc;
+                int slot = (int)h + (m0 ? 0 : 1);
+                bool fresh = (m0 && v0 >= 0) || (m1 && v1 >= 0);
+                if (__ballot(on && !m1 && v1 != -1)) {
+                    if (on && !m1 && v1 != -1) {
+#pragma unroll 1
+                        for (int d = 2; d < FG_DMAX; ++d) {
+                            const int v = s_set[h + (unsigned int)d];
+                            if (v == -1) break;
+                            if ((v & 0x7FFFFFFF) == nc) { slot = (int)h + d; fresh = v >= 0; break; }
+                        }
+                    }
+                }
+                unsigned long long m = __ballot(fresh);
+                // ascending lane = queue order, then neighbour order; later lanes of this step that name the same cell drop out with it
+#define FG_TAKE() do { \
+                    const int l = __ffsll((long long)m) - 1; \
+                    const int xc = __builtin_amdgcn_readlane(nc, l), xy = __builtin_amdgcn_readlane(nxy, l), sl = __builtin_amdgcn_readlane(slot, l); \
+                    m &= ~__ballot(nc == xc); \
+                    if (lane == 0) { \
+                        s_set[sl] = xc | (int)0x80000000; \
+                        __hip_atomic_store(&fq[tail], xc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); \
+                        s_ring[tail & (FR_RING - 1)] = xy; \
+                    } \
+                    last_xy = xy; \
+                    tail += 1; \
+                } while (0)
+                if (m) { FG_TAKE(); if (m) { FG_TAKE(); while (m) FG_TAKE(); } }    // (a taken branch costs this lone wave ten instructions: the first two in line)
+#undef FG_TAKE
+                __builtin_amdgcn_wave_barrier();
+                head += nb;
+            }
+            if (lane == 0) s_cnt = tail;
+        }
+        __syncthreads();
+        const int cnt = s_cnt;
+        if (nf < a.cap_frontiers) { if (tid == 0) a.out_offsets[nf] = total; } else overflow = 1;
+        nf += 1;
+        total += cnt;
+    }
+    if (tid == 0) {
+        if (nf <= a.cap_frontiers) a.out_offsets[nf] = total;
+        a.counts[0] = nf; a.counts[1] = total; a.counts[4] = overflow;
+        a.counts[6] = (int)(wall_clock64() - t_begin);
+    }
+}
+
 struct bl_frontier_scratch {
     size_t cells = 0;
     uint8_t* cls = nullptr; unsigned int* claim = nullptr; unsigned int* fclaim = nullptr;
@@ -978,13 +1164,14 @@ struct bl_frontier_scratch {
     int32_t* h_counts = nullptr;
     uint2* touch = nullptr;
     uint8_t* nb = nullptr;
+    int32_t* fcell = nullptr;
 };
 
 void bl_frontier_scratch_free(bl_ctx* ctx)
 {
     bl_frontier_scratch* s = ctx->frontier;
     if (!s) return;
-    void* dev[] = {s->cls, s->claim, s->fclaim, s->queue, s->out_cells, s->out_offsets, s->counts, s->touch, s->nb};
+    void* dev[] = {s->cls, s->claim, s->fclaim, s->queue, s->out_cells, s->out_offsets, s->counts, s->touch, s->nb, s->fcell};
     for (void* q : dev) if (q) (void)hipFree(q);
     if (s->h_counts) (void)hipHostFree(s->h_counts);
     delete s;
@@ -1017,6 +1204,7 @@ static int frontiers_launch(bl_ctx* ctx, const bl_grid* map, const bl_pose_xyt_t
         if (!s->counts) BL_HIP(hipMalloc((void**)&s->counts, 16 * 4));
         if (!s->h_counts) BL_HIP(hipHostMalloc((void**)&s->h_counts, 16 * 4, hipHostMallocDefault));
         if (!s->touch) BL_HIP(hipMalloc((void**)&s->touch, (size_t)FR_TOUCH_MAX * sizeof(uint2)));
+        if (!s->fcell) BL_HIP(hipMalloc((void**)&s->fcell, (size_t)FG_CELL_MAX * 4));
         s->cells = n;
     }
     frontier_args a;
@@ -1025,7 +1213,9 @@ static int frontiers_launch(bl_ctx* ctx, const bl_grid* map, const bl_pose_xyt_t
     if (!d_pose) bl_global_to_cell((double)robot_pose->x, (double)robot_pose->y, map->frame, &a.rx, &a.ry);      // :39
     a.cls = s->cls; a.claim = s->claim; a.fclaim = s->fclaim; a.queue = s->queue;
     a.out_cells = s->out_cells; a.out_offsets = s->out_offsets; a.cap_frontiers = s->cap_frontiers; a.counts = s->counts;
-    a.phase = 0; a.touch = s->touch; a.nb = s->nb;
+    a.phase = 0; a.touch = s->touch; a.nb = s->nb; a.fcell = s->fcell;
+    static const bool grow_v1 = getenv("BOTLAB_FRONTIER_GROW_V1") != nullptr;                             // A/B runs and tests of that form
+    a.grow_v1 = grow_v1 ? 1 : 0;
     hipEvent_t e0, e1;
     int rc = bl_timer_begin(ctx, BL_K_FRONTIERS, &e0, &e1);
     if (rc) return rc;
@@ -1060,8 +1250,17 @@ static int frontiers_launch(bl_ctx* ctx, const bl_grid* map, const bl_pose_xyt_t
             } else {
                 hipLaunchKernelGGL(k_frontiers<false>, dim3(1), dim3(FR_T), 0, ctx->stream, a);
             }
-            hipLaunchKernelGGL(k_frontier_touches, dim3((unsigned int)cblocks), dim3(256), 0, ctx->stream, a);
-            hipLaunchKernelGGL(k_frontier_grow, dim3(1), dim3(FR_T), 0, ctx->stream, a);
+            hipLaunchKernelGGL(k_frontier_touches, dim3((unsigned int)((cblocks + 3) / 4)), dim3(256), 0, ctx->stream, a);       // (four cells per thread)
+            {
+                static unsigned long long attr_set_devices = 0ull;
+                const unsigned long long bit = 1ull << (ctx->device & 63);
+                if (!(attr_set_devices & bit)) {
+                    BL_HIP(hipFuncSetAttribute((const void*)k_frontier_grow2, hipFuncAttributeMaxDynamicSharedMemorySize, FG_LDS_BYTES));
+                    attr_set_devices |= bit;
+                }
+            }
+            hipLaunchKernelGGL(k_frontier_grow2, dim3(1), dim3(FR_T), FG_LDS_BYTES, ctx->stream, a);
+            hipLaunchKernelGGL(k_frontier_grow, dim3(1), dim3(FR_T), 0, ctx->stream, a);         // (returns at once unless counts[10] is set)
             a.phase = 2;
             hipLaunchKernelGGL(k_frontiers<false>, dim3(1), dim3(FR_T), 0, ctx->stream, a);
         }
@@ -1082,8 +1281,8 @@ static int frontiers_collect(bl_ctx* ctx, const bl_frame& frame, double min_fron
     const int nf = s->h_counts[0], total = s->h_counts[1];
     if (getenv("BOTLAB_FRONTIER_STAMPS"))
         fprintf(stderr, "[frontiers] flood %.3f ms (%d cells, %d levels), frontier sweep %.3f ms (%d frontiers, %d cells; %d touches%s)\n",
-                s->h_counts[5] * 1e-5, s->h_counts[2], s->h_counts[3], s->h_counts[6] * 1e-5, nf, total, s->h_counts[7],
-                s->h_counts[8] ? ", one-workgroup sweep" : "");
+                s->h_counts[5] * 1e-5, s->h_counts[2], s->h_counts[3], s->h_counts[6] * 1e-5, nf, total, s->h_counts[13],
+                s->h_counts[8] ? ", one-workgroup sweep" : (s->h_counts[10] ? ", k_frontier_grow" : ""));
     if (s->h_counts[4] || nf > s->cap_frontiers) { bl_set_error("internal: frontier table overflow (%d frontiers)", nf); return BL_ERR_CAPACITY; }
     std::vector<int32_t> offs((size_t)nf + 1), cells((size_t)total);
     BL_HIP(hipMemcpy(offs.data(), s->out_offsets, ((size_t)nf + 1) * 4, hipMemcpyDeviceToHost));

@@ -133,6 +133,37 @@ def test_find_map_frontiers_one_frontier_larger_than_the_visited_set(oracle, gpu
     _same_frontiers(got, exp)
 
 
+def test_find_map_frontiers_more_frontier_cells_than_the_lds_set_holds(oracle, gpu_ctx):
+    """k_frontier_grow2 keeps ALL frontier-class cells of the grid in one LDS set (16 384 at most).  Here 25 600: a reachable free
+    square (one frontier of 8 000 cells) and 22 free squares the flood never reaches -- the sweep goes to k_frontier_grow (visited
+    set only, classes from global memory).  Same list as the oracle's."""
+    S = 3000
+    cells = np.zeros((S, S), np.int8)
+    cells[100:2100, 100:2100] = -50
+    for j in range(11):
+        for i in range(2):
+            cells[100 + 250 * j:300 + 250 * j, 2300 + 300 * i:2500 + 300 * i] = -50
+    origin, mpc = _frame((S, S))
+    grid = bl.OccupancyGrid.from_cells(cells, origin, mpc, cellsPerMeter=helpers.CPM_DEFAULT, ctx=gpu_ctx)
+    rx, ry = float(origin[0]) + 300.5 * 0.05, float(origin[1]) + 1200.5 * 0.05
+    exp = oracle.find_frontiers(cells, mpc, helpers.CPM_DEFAULT, origin, oracle.pose(rx, ry, 0.0), 0.1)
+    got = bl.find_map_frontiers(grid, bl.make_pose(rx, ry, 0.0), 0.1).cells()
+    assert len(exp) == 1 and len(exp[0]) == 8000
+    _same_frontiers(got, exp)
+
+
+def test_find_map_frontiers_through_the_grow_kernel_without_the_cell_set():
+    """BOTLAB_FRONTIER_GROW_V1: every sweep of the multi-launch form through k_frontier_grow (the form k_frontier_grow2 hands over to
+    when the grid holds more frontier-class cells than its LDS set) -- the tests of that form again, in a child process."""
+    import os
+    import subprocess
+    import sys
+    e = dict(os.environ)
+    e["BOTLAB_FRONTIER_GROW_V1"] = "1"
+    subprocess.check_call([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider",
+                           "-k", "beyond_lds or larger_than_the_visited_set"], env=e)
+
+
 def test_find_map_frontiers_cut_reference_map(oracle, maps, gpu_ctx):
     m = maps["obstacle_slam_10mx10m_5cm"]
     cells = m["cells"].copy()
