@@ -42,7 +42,7 @@ struct frontier_args {
     int phase;                  // k_frontiers: 0 flood + sweep (small grids), 1 flood only, 2 sweep only (and only if counts[8] is set)
     uint2* touch;               // (key, cell) of every frontier cell the flood touched, in no order; FR_TOUCH_MAX entries
     int32_t* fcell;             // every frontier-class cell of the grid, in no order; FG_CELL_MAX entries (k_frontier_touches; counts[12])
-    int grow_v1;                // take k_frontier_grow (visited set only, classes from global memory) whatever the map holds
+    int grow_v1;                // 1, 2: take k_frontier_grow (visited set only, classes from global memory) whatever the map holds
     uint8_t* nb;                // large grids: per cell, the static classes of its four neighbours, 2 bits each (k_frontier_nb)
     const bl_pose_xyt_t* d_pose; // the robot pose in device memory (then rx, ry are formed by every kernel that needs them), or null
     bl_frame frame;
@@ -1024,7 +1024,15 @@ __global__ __launch_bounds__(FR_T) void k_frontier_grow(frontier_args a)
 // bit of its cell's slot (found once, in front of the first frontier) is set.  Growth order as before: ascending lane = queue order,
 // then neighbour order; lanes that name one cell in the same step are told apart in registers.
 // More than FG_CELL_MAX frontier-class cells, or a home region without room: k_frontier_grow takes the sweep (counts[10]).
-__device__ __forceinline__ unsigned int fg_home(int c) { return ((unsigned int)c * 2654435761u) >> (32 - 15); }       // FG_SLOTS = 2^15
+// (The home: a multiplicative hash alone maps the cells of a column -- an arithmetic progression of stride W -- to an arithmetic
+// progression of homes, with a stride of 0.63 slots at W = 10 946, a Fibonacci number: a vertical frontier of 200 cells overflowed
+// its home region.  One xor-shift and a second multiplication end that; tests/test_gpu_frontiers.py has the width.)
+__device__ __forceinline__ unsigned int fg_home(int c)
+{
+    unsigned int h = (unsigned int)c * 2654435761u;
+    h ^= h >> 15;
+    return (h * 0x85EBCA6Bu) >> (32 - 15);                                     // FG_SLOTS = 2^15
+}
 
 __global__ __launch_bounds__(FR_T) void k_frontier_grow2(frontier_args a)
 {
@@ -1037,7 +1045,7 @@ __global__ __launch_bounds__(FR_T) void k_frontier_grow2(frontier_args a)
     const long long t_begin = wall_clock64();
     const int F = a.counts[12], T = a.counts[13];
     if (T > FR_TOUCH_MAX || a.W > 65535 || a.H > 32767) { if (tid == 0) a.counts[8] = 1; return; }      // (the ring packs x | y << 16)
-    if (F > FG_CELL_MAX || a.grow_v1) { if (tid == 0) a.counts[10] = 1; return; }
+    if (F > FG_CELL_MAX || a.grow_v1 == 1) { if (tid == 0) a.counts[10] = 1; return; }
     for (int i = tid; i < FG_SLOTS + FG_PAD; i += FR_T) s_set[i] = -1;
     if (tid == 0) s_fail = 0;
     __syncthreads();
@@ -1051,7 +1059,7 @@ __global__ __launch_bounds__(FR_T) void k_frontier_grow2(frontier_args a)
         if (d == FG_DMAX) s_fail = 1;
     }
     __syncthreads();
-    if (s_fail) { if (tid == 0) a.counts[10] = 1; return; }
+    if (s_fail || a.grow_v1 == 2) { if (tid == 0) a.counts[10] = 1; return; }           // (2: the tests' way into this exit)
     // ---- the touches of this thread: key and the slot of the cell (every touched cell is a frontier-class cell: it is there)
     unsigned int tk[FR_TOUCH_PER_THREAD]; int ts[FR_TOUCH_PER_THREAD];
 #pragma unroll
@@ -1214,8 +1222,8 @@ static int frontiers_launch(bl_ctx* ctx, const bl_grid* map, const bl_pose_xyt_t
     a.cls = s->cls; a.claim = s->claim; a.fclaim = s->fclaim; a.queue = s->queue;
     a.out_cells = s->out_cells; a.out_offsets = s->out_offsets; a.cap_frontiers = s->cap_frontiers; a.counts = s->counts;
     a.phase = 0; a.touch = s->touch; a.nb = s->nb; a.fcell = s->fcell;
-    static const bool grow_v1 = getenv("BOTLAB_FRONTIER_GROW_V1") != nullptr;                             // A/B runs and tests of that form
-    a.grow_v1 = grow_v1 ? 1 : 0;
+    static const int grow_v1 = getenv("BOTLAB_FRONTIER_GROW_V1") ? atoi(getenv("BOTLAB_FRONTIER_GROW_V1")) : 0;     // A/B runs and tests of that form
+    a.grow_v1 = grow_v1;                                   // 1: k_frontier_grow from the start; 2: k_frontier_grow2 gives up once its set is built
     hipEvent_t e0, e1;
     int rc = bl_timer_begin(ctx, BL_K_FRONTIERS, &e0, &e1);
     if (rc) return rc;

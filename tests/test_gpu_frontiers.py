@@ -152,16 +152,35 @@ def test_find_map_frontiers_more_frontier_cells_than_the_lds_set_holds(oracle, g
     _same_frontiers(got, exp)
 
 
+def test_find_map_frontiers_a_grid_width_that_crowded_the_lds_set(oracle, gpu_ctx):
+    """The cells of a COLUMN are an arithmetic progression of cell indices with stride W.  Under a multiplicative home alone
+    (index * 2654435761 >> 17) their homes step by W * 2654435761 mod 2^32 -- 0.63 slots at W = 10 946, a Fibonacci number (the
+    multiplier is the golden ratio's): a vertical frontier of 600 cells needs 600 slots where 380 homes lie, and k_frontier_grow2
+    (and k_frontier_grow's visited set behind it) overflowed their home regions and handed the sweep down to the one-workgroup form.
+    k_frontier_grow2's home now mixes once more; the map stays as a test.  Same list as the oracle's."""
+    W, H = 10946, 800
+    cells = np.zeros((H, W), np.int8)
+    cells[100:700, 200:500] = -50
+    origin, mpc = _frame((H, W))
+    grid = bl.OccupancyGrid.from_cells(cells, origin, mpc, cellsPerMeter=helpers.CPM_DEFAULT, ctx=gpu_ctx)
+    rx, ry = float(origin[0]) + 300.5 * 0.05, float(origin[1]) + 400.5 * 0.05
+    exp = oracle.find_frontiers(cells, mpc, helpers.CPM_DEFAULT, origin, oracle.pose(rx, ry, 0.0), 0.1)
+    got = bl.find_map_frontiers(grid, bl.make_pose(rx, ry, 0.0), 0.1).cells()
+    assert len(exp) == 1 and len(exp[0]) == 1800
+    _same_frontiers(got, exp)
+
+
 def test_find_map_frontiers_through_the_grow_kernel_without_the_cell_set():
     """BOTLAB_FRONTIER_GROW_V1: every sweep of the multi-launch form through k_frontier_grow (the form k_frontier_grow2 hands over to
     when the grid holds more frontier-class cells than its LDS set) -- the tests of that form again, in a child process."""
     import os
     import subprocess
     import sys
-    e = dict(os.environ)
-    e["BOTLAB_FRONTIER_GROW_V1"] = "1"
-    subprocess.check_call([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider",
-                           "-k", "beyond_lds or larger_than_the_visited_set"], env=e)
+    for form in ("1", "2"):                                # 1: from the start; 2: k_frontier_grow2 builds its set, then gives up
+        e = dict(os.environ)
+        e["BOTLAB_FRONTIER_GROW_V1"] = form
+        subprocess.check_call([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider",
+                               "-k", "beyond_lds or larger_than_the_visited_set"], env=e)
 
 
 def test_find_map_frontiers_cut_reference_map(oracle, maps, gpu_ctx):
