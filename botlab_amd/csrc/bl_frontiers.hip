@@ -1110,18 +1110,17 @@ __global__ __launch_bounds__(FR_T) void k_frontier_grow2(frontier_args a)
                 else if (qi < nb) { const int c = __hip_atomic_load(&fq[head + qi], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); cx = c % a.W; cy = c / a.W; }
                 const int x = cx + dx, y = cy + dy;
                 const bool in = qi < nb && x >= 0 && y >= 0 && x < a.W && y < a.H;
-                const int nc = in ? y * a.W + x : -1, nxy = x | (y << 16);
+                const int nc = in ? y * a.W + x : -2, nxy = x | (y << 16);      // (-2: no slot ever holds it, empty ones hold -1)
                 // the neighbour in the set: a frontier-class cell, grown or not; not there: any other class.  Home slot and the next
-                // in one read, without a branch; longer chains (rare at half load) lane by lane
+                // in one read.  A word EQUAL to the cell is the cell not yet grown (the visited bit is clear) -- and a cell one slot
+                // behind its home implies an occupied home (nothing is ever removed): two compares decide the common case.  Both
+                // slots taken by others: the chain goes on, lane by lane (rare at a quarter load)
                 const unsigned int h = fg_home(nc);
                 const int v0 = s_set[h], v1 = s_set[h + 1u];
-                const bool m0 = in && (v0 & 0x7FFFFFFF) == nc;                   // (an empty slot reads 0x7FFFFFFF: no cell)
-                const bool on = in && !m0 && v0 != -1;
-                const bool m1 = on && (v1 & 0x7FFFFFFF) == nc;
-                int slot = (int)h + (m0 ? 0 : 1);
-                bool fresh = (m0 && v0 >= 0) || (m1 && v1 >= 0);
-                if (__ballot(on && !m1 && v1 != -1)) {
-                    if (on && !m1 && v1 != -1) {
+                int slot = (int)h + (v0 == nc ? 0 : 1);
+                bool fresh = v0 == nc || v1 == nc;
+                if (__ballot(((unsigned int)v0 > (unsigned int)v1 ? (unsigned int)v0 : (unsigned int)v1) != 0xFFFFFFFFu)) {      // some lane: both slots taken
+                    if (in && !fresh && v0 != -1 && v1 != -1 && (v0 & 0x7FFFFFFF) != nc && (v1 & 0x7FFFFFFF) != nc) {
 #pragma unroll 1
                         for (int d = 2; d < FG_DMAX; ++d) {
                             const int v = s_set[h + (unsigned int)d];
@@ -1133,18 +1132,21 @@ __global__ __launch_bounds__(FR_T) void k_frontier_grow2(frontier_args a)
                 unsigned long long m = __ballot(fresh);
                 // ascending lane = queue order, then neighbour order; later lanes of this step that name the same cell drop out with it
 #define FG_TAKE() do { \
-                    const int l = __ffsll((long long)m) - 1; \
-                    const int xc = __builtin_amdgcn_readlane(nc, l), xy = __builtin_amdgcn_readlane(nxy, l), sl = __builtin_amdgcn_readlane(slot, l); \
+                    l_last = __ffsll((long long)m) - 1; \
+                    const int xc = __builtin_amdgcn_readlane(nc, l_last); \
                     m &= ~__ballot(nc == xc); \
-                    if (lane == 0) { \
-                        s_set[sl] = xc | (int)0x80000000; \
-                        __hip_atomic_store(&fq[tail], xc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); \
-                        s_ring[tail & (FR_RING - 1)] = xy; \
+                    if (lane == l_last) {                                        /* the lane that found it has slot, cell and x | y << 16 */ \
+                        s_set[slot] = nc | (int)0x80000000; \
+                        __hip_atomic_store(&fq[tail], nc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); \
+                        s_ring[tail & (FR_RING - 1)] = nxy; \
                     } \
-                    last_xy = xy; \
                     tail += 1; \
                 } while (0)
-                if (m) { FG_TAKE(); if (m) { FG_TAKE(); while (m) FG_TAKE(); } }    // (a taken branch costs this lone wave ten instructions: the first two in line)
+                if (m) {                                                         // (a taken branch costs this lone wave ten instructions: the first two in line)
+                    int l_last;
+                    FG_TAKE(); if (m) { FG_TAKE(); while (m) FG_TAKE(); }
+                    last_xy = __builtin_amdgcn_readlane(nxy, l_last);
+                }
 #undef FG_TAKE
                 __builtin_amdgcn_wave_barrier();
                 head += nb;
