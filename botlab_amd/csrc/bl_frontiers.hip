@@ -117,8 +117,10 @@ __device__ __forceinline__ void fr_classify(const frontier_args& a, uint8_t* cls
     if (k == 0 && v < 0) k = 1;
     if (x == a.rx && y == a.ry) k = 3;                  // visitedCells.insert(robotCell) before anything else (:42)
     cls[c] = (uint8_t)k;
-    a.claim[c] = FR_INF;
-    a.fclaim[c] = FR_INF;
+    // the claim words are only ever read or written at cells of class 1 or 2 (a cell leaves those classes for 4 / 5 and never enters
+    // them), the growth claims only at class 2: nothing else is reset -- 9 bytes written per cell became 1 on an unknown map
+    if (k == 1 || k == 2) a.claim[c] = FR_INF;
+    if (k == 2) a.fclaim[c] = FR_INF;
 }
 
 __global__ __launch_bounds__(256) void k_frontier_classify(frontier_args a)
