@@ -67,7 +67,7 @@ def test_find_map_frontiers_random_maps(oracle, gpu_ctx, seed):
     assert total > 10
 
 
-@pytest.mark.parametrize("seed,shape", [(11, (400, 420)), (12, (700, 333)), (13, (1000, 1000))])
+@pytest.mark.parametrize("seed,shape", [(11, (400, 420)), (12, (700, 333)), (13, (1000, 1000)), (14, (401, 419)), (15, (333, 1021))])      # (the last two: cell counts that are no multiple of 4 -- k_frontier_touches reads four class bytes at a time)
 def test_find_map_frontiers_random_maps_beyond_lds(oracle, gpu_ctx, seed, shape):
     """Grids whose class bytes do not fit LDS take the multi-launch form: classification over the whole device, the flood by one
     workgroup, the touches collected by all workgroups, the frontiers grown by one wave with an LDS visited set.  Random blob maps
