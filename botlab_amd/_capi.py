@@ -169,6 +169,7 @@ SIGNATURES = {
     "bl_frontiers_total_cells": (C.c_int, [_vp]),
     "bl_frontiers_get": (C.c_int, [_vp, _vp, _vp]),
     "bl_frontiers_stats": (C.c_int, [_vp, _P(C.c_int), _P(C.c_int)]),
+    "bl_frontiers_debug_sweep_kernel": (C.c_int, [_vp]),
     "bl_frontiers_destroy": (None, [_vp]),
     "bl_lcm_fingerprint": (C.c_uint64, [C.c_int]),
     "bl_lcm_encode_pose": (C.c_int64, [C.c_int, _P(Pose), _vp, C.c_int64]),

@@ -1177,6 +1177,7 @@ struct bl_frontier_scratch {
     uint2* touch = nullptr;
     uint8_t* nb = nullptr;
     int32_t* fcell = nullptr;
+    int form = 0;                     // the last launch: 0 one workgroup with the classes in LDS, 1 one workgroup (large grid), 2 the multi-launch form
 };
 
 void bl_frontier_scratch_free(bl_ctx* ctx)
@@ -1239,11 +1240,13 @@ static int frontiers_launch(bl_ctx* ctx, const bl_grid* map, const bl_pose_xyt_t
             attr_set_devices |= bit;
         }
         hipLaunchKernelGGL(k_frontiers<true>, dim3(1), dim3(FR_T), (n + 15) & ~(size_t)15, ctx->stream, a);
+        s->form = 0;
     } else {
         long long cblocks = ((long long)n + 255) / 256;
         if (cblocks > 8192) cblocks = 8192;
         hipLaunchKernelGGL(k_frontier_classify, dim3((unsigned int)cblocks), dim3(256), 0, ctx->stream, a);
         static const bool one_wg_sweep = getenv("BOTLAB_FRONTIER_ONE_WG_SWEEP") != nullptr;       // A/B runs and tests of the fallback
+        s->form = one_wg_sweep ? 1 : 2;
         if (one_wg_sweep) {
             hipLaunchKernelGGL(k_frontiers<false>, dim3(1), dim3(FR_T), 0, ctx->stream, a);
         } else {
@@ -1301,6 +1304,7 @@ static int frontiers_collect(bl_ctx* ctx, const bl_frame& frame, double min_fron
     if (total > 0) BL_HIP(hipMemcpy(cells.data(), s->out_cells, (size_t)total * 4, hipMemcpyDeviceToHost));
     bl_frontiers* f = new bl_frontiers();
     f->bfs_cells = s->h_counts[2]; f->bfs_levels = s->h_counts[3];
+    f->sweep_kernel = s->form < 2 ? s->form : (s->h_counts[8] ? 1 : (s->h_counts[10] ? 2 : 3));
     f->offsets.push_back(0);
     for (int k = 0; k < nf; ++k) {
         const int cnt = offs[k + 1] - offs[k];
@@ -1358,6 +1362,7 @@ extern "C" int bl_frontiers_stats(const bl_frontiers* f, int* bfs_cells, int* bf
     if (bfs_levels) *bfs_levels = f->bfs_levels;
     return BL_OK;
 }
+extern "C" int bl_frontiers_debug_sweep_kernel(const bl_frontiers* f) { return f ? f->sweep_kernel : -1; }
 extern "C" void bl_frontiers_destroy(bl_frontiers* f) { delete f; }
 
 // =============================================================================================== the exploration step on side streams

@@ -91,6 +91,7 @@ struct bl_frontiers {
     std::vector<int32_t> offsets;
     std::vector<float> xy;
     int bfs_cells = 0, bfs_levels = 0;
+    int sweep_kernel = 0;             // bl_frontiers_debug_sweep_kernel
 };
 
 // Zero-framed mirror of a grid too large to stage whole in LDS (rows -BL_MIRROR_FRAME..H+BL_MIRROR_FRAME-1, columns

@@ -514,6 +514,11 @@ class Frontiers:
         check(self.ctx.lib.bl_frontiers_stats(self.h, C.byref(a), C.byref(b)))
         return a.value, b.value
 
+    def sweep_kernel(self):
+        """which kernels grew these frontiers (bl_frontiers_debug_sweep_kernel): 0 / 1 one workgroup (small / large grid),
+        2 k_frontier_grow, 3 k_frontier_grow2"""
+        return int(self.ctx.lib.bl_frontiers_debug_sweep_kernel(self.h))
+
     def close(self):
         if self.h:
             self.ctx.lib.bl_frontiers_destroy(self.h)

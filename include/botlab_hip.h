@@ -389,6 +389,10 @@ int bl_frontiers_count(const bl_frontiers* f);
 int bl_frontiers_total_cells(const bl_frontiers* f);
 int bl_frontiers_get(const bl_frontiers* f, int32_t* offsets /* count + 1 */, float* xy /* 2 * total_cells */);
 int bl_frontiers_stats(const bl_frontiers* f, int* bfs_cells, int* bfs_levels);   /* free-space flood size / depth (diagnostic) */
+/* which kernels grew the frontiers of this result (diagnostic, for tests of the fall-backs): 0 the one-workgroup form of grids up to
+ * 96 K cells (or a caller-made list), 1 the one-workgroup sweep of larger grids, 2 k_frontier_grow (visited set in LDS, classes from
+ * global memory), 3 k_frontier_grow2 (all frontier-class cells of the grid in one LDS set: up to 16 384 of them) */
+int bl_frontiers_debug_sweep_kernel(const bl_frontiers* f);
 void bl_frontiers_destroy(bl_frontiers* f);
 
 /* ------------------------------------------------------------------ simulator lidar  

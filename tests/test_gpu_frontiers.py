@@ -34,6 +34,13 @@ def _frame(shape):
     return (np.float32(-w * 0.05 / 2), np.float32(-h * 0.05 / 2)), np.float32(0.05)
 
 
+def _sweep_kernel_is(fr, k):
+    """which kernels grew the frontiers (bl_frontiers_debug_sweep_kernel) -- checked only when no switch forces another form"""
+    import os
+    if not any(v in os.environ for v in ("BOTLAB_FRONTIER_GROW_V1", "BOTLAB_FRONTIER_ONE_WG_SWEEP")):
+        assert fr.sweep_kernel() == k, (fr.sweep_kernel(), k)
+
+
 def _same_frontiers(got, exp):
     assert len(got) == len(exp), (len(got), len(exp))
     for k, (a, b) in enumerate(zip(got, exp)):
@@ -82,10 +89,34 @@ def test_find_map_frontiers_random_maps_beyond_lds(oracle, gpu_ctx, seed, shape)
         k = rng.integers(len(xs))
         rx, ry = float(origin[0]) + (xs[k] + 0.5) * 0.05, float(origin[1]) + (ys[k] + 0.5) * 0.05
         exp = oracle.find_frontiers(cells, mpc, helpers.CPM_DEFAULT, origin, oracle.pose(rx, ry, 0.0), 0.1)
-        got = bl.find_map_frontiers(grid, bl.make_pose(rx, ry, 0.0), 0.1).cells()
-        _same_frontiers(got, exp)
+        fr = bl.find_map_frontiers(grid, bl.make_pose(rx, ry, 0.0), 0.1)
+        _sweep_kernel_is(fr, 2)                            # a ninth of a blob map's cells are frontier-class: more than k_frontier_grow2's set holds
+        _same_frontiers(fr.cells(), exp)
         total += len(exp)
     assert total > 3
+
+
+@pytest.mark.parametrize("seed,shape", [(21, (320, 330)), (22, (330, 320)), (25, (310, 340))])
+def test_find_map_frontiers_random_maps_just_beyond_lds_through_the_cell_set(oracle, gpu_ctx, seed, shape):
+    """Random blob maps small enough for k_frontier_grow2's set (about 12 000 frontier-class cells, reachable or not; 16 384 fit) and
+    too large for the one-workgroup form (96 K cells): dozens of small frontiers, blobs and rims of every shape, grown from the LDS
+    set -- same lists as the oracle's."""
+    cells = _blob_map(seed, shape)
+    origin, mpc = _frame(shape)
+    grid = bl.OccupancyGrid.from_cells(cells, origin, mpc, cellsPerMeter=helpers.CPM_DEFAULT, ctx=gpu_ctx)
+    rng = np.random.default_rng(500 + seed)
+    ys, xs = np.nonzero(cells < -5)
+    total = 0
+    for _ in range(6):
+        k = rng.integers(len(xs))
+        rx, ry = float(origin[0]) + (xs[k] + 0.5) * 0.05, float(origin[1]) + (ys[k] + 0.5) * 0.05
+        for min_len in (0.1, 0.35):
+            exp = oracle.find_frontiers(cells, mpc, helpers.CPM_DEFAULT, origin, oracle.pose(rx, ry, 0.0), min_len)
+            fr = bl.find_map_frontiers(grid, bl.make_pose(rx, ry, 0.0), min_len)
+            _sweep_kernel_is(fr, 3)
+            _same_frontiers(fr.cells(), exp)
+            total += len(exp)
+    assert total > 10
 
 
 @pytest.mark.parametrize("case", ["all_free", "all_unknown", "robot_outside", "robot_on_unknown", "robot_on_frontier_value", "walls_only"])
@@ -128,9 +159,10 @@ def test_find_map_frontiers_one_frontier_larger_than_the_visited_set(oracle, gpu
     grid = bl.OccupancyGrid.from_cells(cells, origin, mpc, cellsPerMeter=helpers.CPM_DEFAULT, ctx=gpu_ctx)
     rx, ry = float(origin[0]) + 300.5 * 0.05, float(origin[1]) + 1200.5 * 0.05
     exp = oracle.find_frontiers(cells, mpc, helpers.CPM_DEFAULT, origin, oracle.pose(rx, ry, 0.0), 0.1)
-    got = bl.find_map_frontiers(grid, bl.make_pose(rx, ry, 0.0), 0.1).cells()
+    fr = bl.find_map_frontiers(grid, bl.make_pose(rx, ry, 0.0), 0.1)
     assert len(exp) == 1 and len(exp[0]) > 8192
-    _same_frontiers(got, exp)
+    _sweep_kernel_is(fr, 3 if free == 2400 else 1)          # 9 600 cells fit k_frontier_grow2's set (k_frontier_grow's visited set they do not: the child runs below); 16 800 touches fit neither
+    _same_frontiers(fr.cells(), exp)
 
 
 def test_find_map_frontiers_more_frontier_cells_than_the_lds_set_holds(oracle, gpu_ctx):
@@ -147,9 +179,10 @@ def test_find_map_frontiers_more_frontier_cells_than_the_lds_set_holds(oracle, g
     grid = bl.OccupancyGrid.from_cells(cells, origin, mpc, cellsPerMeter=helpers.CPM_DEFAULT, ctx=gpu_ctx)
     rx, ry = float(origin[0]) + 300.5 * 0.05, float(origin[1]) + 1200.5 * 0.05
     exp = oracle.find_frontiers(cells, mpc, helpers.CPM_DEFAULT, origin, oracle.pose(rx, ry, 0.0), 0.1)
-    got = bl.find_map_frontiers(grid, bl.make_pose(rx, ry, 0.0), 0.1).cells()
+    fr = bl.find_map_frontiers(grid, bl.make_pose(rx, ry, 0.0), 0.1)
     assert len(exp) == 1 and len(exp[0]) == 8000
-    _same_frontiers(got, exp)
+    _sweep_kernel_is(fr, 2)
+    _same_frontiers(fr.cells(), exp)
 
 
 def test_find_map_frontiers_a_grid_width_that_crowded_the_lds_set(oracle, gpu_ctx):
@@ -165,9 +198,10 @@ def test_find_map_frontiers_a_grid_width_that_crowded_the_lds_set(oracle, gpu_ct
     grid = bl.OccupancyGrid.from_cells(cells, origin, mpc, cellsPerMeter=helpers.CPM_DEFAULT, ctx=gpu_ctx)
     rx, ry = float(origin[0]) + 300.5 * 0.05, float(origin[1]) + 400.5 * 0.05
     exp = oracle.find_frontiers(cells, mpc, helpers.CPM_DEFAULT, origin, oracle.pose(rx, ry, 0.0), 0.1)
-    got = bl.find_map_frontiers(grid, bl.make_pose(rx, ry, 0.0), 0.1).cells()
+    fr = bl.find_map_frontiers(grid, bl.make_pose(rx, ry, 0.0), 0.1)
     assert len(exp) == 1 and len(exp[0]) == 1800
-    _same_frontiers(got, exp)
+    _sweep_kernel_is(fr, 3)
+    _same_frontiers(fr.cells(), exp)
 
 
 def test_find_map_frontiers_through_the_grow_kernel_without_the_cell_set():
